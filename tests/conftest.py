@@ -1,0 +1,88 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import __graft_entry__ as ge  # noqa: E402
+
+ge.load_package()
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # `-m gpu` tests must not silently run on a CPU-only box
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+class Golden:
+    def __init__(self, name):
+        self.z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.meta = json.loads(bytes(self.z["__meta__"]).decode())
+
+    def t(self, key, dtype=torch.float32):
+        return torch.from_numpy(np.asarray(self.z[key])).to(dtype)
+
+    def has(self, key):
+        return key in self.z.files
+
+    def grads(self, tag):
+        pre = f"{tag}/grad:"
+        return {k[len(pre):]: torch.from_numpy(self.z[k]) for k in self.z.files if k.startswith(pre)}
+
+    def gnorms(self, tag):
+        pre = f"{tag}/gnorm:"
+        return {k[len(pre):]: float(self.z[k]) for k in self.z.files if k.startswith(pre)}
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = Golden(name)
+        return cache[name]
+    return get
+
+
+def sample(t, n=4096):
+    """Same deterministic strided sample as oracle/tools/make_golden.py."""
+    f = t.detach().reshape(-1)
+    if f.numel() <= n:
+        return f.float().cpu()
+    idx = torch.linspace(0, f.numel() - 1, n).round().long()
+    return f[idx.to(f.device)].float().cpu()
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def state_from_meta(case, requires_grad=True):
+    """Rebuild a reference-layout state_dict from fixture metadata with the deterministic fill."""
+    from mi_seg_amd.utils.detfill import det_values
+    from oracle.functional import relative_position_index
+    sd = {}
+    for k, shp in zip(case["state_keys"], case["state_shapes"]):
+        if k.endswith("relative_position_index"):
+            sd[k] = relative_position_index()
+        else:
+            sd[k] = torch.from_numpy(det_values(k, shp)).requires_grad_(requires_grad)
+    return sd
