@@ -1,0 +1,283 @@
+/* libmiseg_hip.so -- C ABI of the MI355X (gfx950) hot path for MI-Seg's 3D cross-modality nets.
+ *
+ * Nothing like this exists in the reference (it is pure Python on torch/cuDNN/cuBLAS);
+ * each entry point below names the reference code whose device arithmetic it replaces, as
+ * /root/reference-relative file:line.  The Python host in mi-seg_amd/ binds these with ctypes
+ * (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - plain C symbols, POD structs, raw device pointers; no C++/torch types cross the boundary.
+ *   - every call only ENQUEUES work on `stream` and returns; no implicit device synchronisation, no
+ *     allocation: all buffers (incl. workspaces, sized by the *_workspace_bytes helpers) are the caller's.
+ *   - return 0 on success, a negative MISEG_E_* otherwise; miseg_last_error() gives a thread-local message.
+ *   - activations are channels-last rows: element (row r, channel c) lives at base[r * ld + c]; a 3D volume
+ *     is rows in (b, d, h, w) row-major order.  dtype is MISEG_F32 or MISEG_BF16 (bf16 storage, fp32 math).
+ *   - parameters and their gradients are always fp32.
+ */
+#ifndef MISEG_HIP_H
+#define MISEG_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* miseg_stream_t; /* hipStream_t */
+
+enum { MISEG_F32 = 0, MISEG_BF16 = 1 };
+enum { MISEG_OK = 0, MISEG_E_BADARG = -1, MISEG_E_UNSUPPORTED = -2, MISEG_E_LAUNCH = -3 };
+enum { MISEG_ACT_NONE = 0, MISEG_ACT_LEAKY = 1, MISEG_ACT_GELU = 2, MISEG_ACT_PRELU = 3 };
+#define MISEG_MAX_STYLES 4
+
+int miseg_abi_version(void);
+const char* miseg_last_error(void);
+/* writes e.g. "gfx950" for the code objects embedded in the library */
+int miseg_device_arch(char* buf, size_t n);
+
+/* ------------------------------------------------------------------------------------------------
+ * (Conditional) instance norm over channels-last rows.
+ * Replaces networks/norms/conditional_instance_norm.py:59-68 (per-sample style lookup + stack),
+ * nn.InstanceNorm{1,3}d in networks/blocks/dynunet_block.py:80-81,98 and F.instance_norm in
+ * networks/nets/swin_transformer.py:135-136, plus the LeakyReLU / residual add that follow them in
+ * dynunet_block.py:100-126.
+ *   x: [B][S][C] rows (ldx), statistics per (b, c) over the S rows, biased variance, eps inside sqrt.
+ *   styles: device int32[B] or NULL (=> row 0); gamma/beta[s]: fp32[C] per style or NULL (no affine).
+ *   y = act((x - mean) * rstd * gamma[s] + beta[s] + res)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* x; int64_t ldx;
+  int B, S, C, dtype;
+  float eps;
+  float* mean; float* rstd;       /* out, fp32 [B][C] */
+  void* workspace;                /* miseg_instnorm_workspace_bytes */
+} miseg_instnorm_stats_params;
+size_t miseg_instnorm_workspace_bytes(int B, int S, int C);
+int miseg_instnorm_stats(const miseg_instnorm_stats_params* p, miseg_stream_t stream);
+
+typedef struct {
+  const void* x; int64_t ldx;
+  const void* res; int64_t ldres;  /* optional residual added before the activation */
+  void* y; int64_t ldy;
+  int B, S, C, dtype;
+  const float* mean; const float* rstd;
+  const int32_t* styles; int num_styles;
+  const float* gamma[MISEG_MAX_STYLES]; const float* beta[MISEG_MAX_STYLES];
+  int act; float slope;            /* MISEG_ACT_NONE | MISEG_ACT_LEAKY */
+} miseg_instnorm_apply_params;
+int miseg_instnorm_apply(const miseg_instnorm_apply_params* p, miseg_stream_t stream);
+
+/* backward of the fused op above.  dy is the gradient w.r.t. y; when act != NONE, y (the saved output)
+ * supplies the sign for the activation gradient.  Outputs: dx, optionally dres (= gradient flowing to the
+ * residual input), dgamma/dbeta[s] (ACCUMULATED with atomics: caller zero-fills once per step). */
+typedef struct {
+  const void* dy; int64_t lddy;
+  const void* y; int64_t ldy;
+  const void* x; int64_t ldx;
+  void* dx; int64_t lddx;
+  void* dres; int64_t lddres;
+  int B, S, C, dtype;
+  const float* mean; const float* rstd;
+  const int32_t* styles; int num_styles;
+  const float* gamma[MISEG_MAX_STYLES];
+  float* dgamma[MISEG_MAX_STYLES]; float* dbeta[MISEG_MAX_STYLES];
+  int act; float slope;
+  void* workspace;                 /* miseg_instnorm_workspace_bytes */
+} miseg_instnorm_bwd_params;
+int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stream_t stream);
+
+/* LayerNorm over the channel dim of channels-last rows (vit_norm_name="layer", the reference default:
+ * networks/blocks/swin_transformer_block.py:104-105, transformer_block.py:82-83).  gamma/beta may be NULL. */
+typedef struct {
+  const void* x; int64_t ldx; void* y; int64_t ldy;
+  int64_t rows; int C, dtype; float eps;
+  const float* gamma; const float* beta;
+  float* mean; float* rstd;        /* out fp32 [rows], saved for backward */
+} miseg_layernorm_fwd_params;
+int miseg_layernorm_fwd(const miseg_layernorm_fwd_params* p, miseg_stream_t stream);
+typedef struct {
+  const void* dy; int64_t lddy; const void* x; int64_t ldx; void* dx; int64_t lddx;
+  int64_t rows; int C, dtype;
+  const float* gamma; const float* mean; const float* rstd;
+  float* dgamma; float* dbeta;     /* accumulated (atomics); may be NULL */
+} miseg_layernorm_bwd_params;
+int miseg_layernorm_bwd(const miseg_layernorm_bwd_params* p, miseg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM on the matrix cores:  C[M][N] = A * B (+ bias[N]) (-> act).
+ * Replaces every nn.Linear on the path (window_attention.py:92,94 qkv/proj; MONAI MLPBlock used at
+ * swin_transformer_block.py:97; patch_merging.py:48 reduction; transformer_block.py:58-59), the 1x1x1
+ * convolutions (dynunet_block.py:87-97,278-289) and, with gather/scatter kernels, ConvTranspose3d k2 s2
+ * (unetr_block.py:51-59).
+ *   ta == 0: A is [M][K] (lda)   ta == 1: A is stored [K][M] (lda)   -- likewise tb for B: 0 => [N][K], 1 => [K][N]
+ *   only (ta,tb) = (0,0) "NT" and (1,1) "TN" are implemented (weights are re-packed once per step).
+ *   out_dtype: dtype of C (MISEG_F32 for weight gradients).  accumulate != 0: C += result (fp32 C only).
+ *   split_k > 1 partitions K over workgroups and reduces with fp32 atomics into a zero-filled or
+ *   accumulate-mode C (fp32 C only).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* A; int64_t lda; const void* B; int64_t ldb; void* C; int64_t ldc;
+  int M, N, K;
+  int ta, tb;
+  int dtype, out_dtype;
+  const float* bias; int act;
+  int accumulate, split_k;
+} miseg_gemm_params;
+int miseg_gemm(const miseg_gemm_params* p, miseg_stream_t stream);
+
+/* fp32 re-layout: dst[i0][i1][i2] (+)= src[i0*s0 + i1*s1 + i2*s2]  (weight-gradient unpacking) */
+int miseg_permute3(const float* src, float* dst, int n0, int n1, int n2, int64_t s0, int64_t s1, int64_t s2, int accumulate,
+                   miseg_stream_t stream);
+
+/* column sums: out[c] (+)= sum_r x[r][c]  (bias gradients) */
+typedef struct { const void* x; int64_t ldx; int64_t rows; int C, dtype; float* out; int accumulate; } miseg_colsum_params;
+int miseg_colsum(const miseg_colsum_params* p, miseg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * 3x3x3 convolution, stride 1, zero padding 1, no bias, as an implicit GEMM on the matrix cores.
+ * Replaces nn.Conv3d built by get_conv_layer (networks/blocks/dynunet_block.py:295-326) as used in
+ * UnetResBlock/UnetBasicBlock (dynunet_block.py:55-76,100-126).
+ *   x: [B][D][H][W][Cin] rows (ldx)   y: [B][D][H][W][Cout] rows (ldy)
+ *   wpk: packed weights [Cout][27][Cin] in `dtype` (miseg_pack_conv3_weight); the data gradient is the
+ *   same kernel run on dy with the flipped/transposed pack.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* x; int64_t ldx; void* y; int64_t ldy; const void* wpk;
+  int B, D, H, W, Cin, Cout, dtype;
+} miseg_conv3_params;
+int miseg_conv3_fwd(const miseg_conv3_params* p, miseg_stream_t stream);
+
+/* w: fp32 torch layout [Cout][Cin][3][3][3].  fwd_pack: [Cout][27][Cin]; bwd_pack: [Cin][27][Cout] with taps
+ * mirrored (either may be NULL). */
+typedef struct { const float* w; void* fwd_pack; void* bwd_pack; int Cin, Cout, dtype; } miseg_pack_conv3_params;
+int miseg_pack_conv3_weight(const miseg_pack_conv3_params* p, miseg_stream_t stream);
+
+/* weight gradient: dw[Cout][Cin][27] (fp32, torch layout) (+)= sum_v dy[v][co] * x[v + tap][ci] */
+typedef struct {
+  const void* x; int64_t ldx; const void* dy; int64_t lddy; float* dw;
+  int B, D, H, W, Cin, Cout, dtype, accumulate;
+  void* workspace;                 /* miseg_conv3_wgrad_workspace_bytes */
+} miseg_conv3_wgrad_params;
+size_t miseg_conv3_wgrad_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout);
+int miseg_conv3_wgrad(const miseg_conv3_wgrad_params* p, miseg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused 3D (shifted-)window attention core: zero pad -> cyclic roll -> window partition -> per-head
+ * softmax(q*scale k^T + bias_table[index] + shift mask) v -> window reverse -> roll back -> crop, with the
+ * scores never leaving the CU.  Replaces networks/blocks/window_attention.py:99-119 (everything between
+ * the qkv and proj Linears) and the data movement of swin_transformer_block.py:116-169 +
+ * networks/utils/swin_utils.py:15-143.
+ *   qkv: [B][D][H][W][3*C] rows (ldq) holding qkv = Linear(norm1(x)) of the UNPADDED grid; rows of padded
+ *        tokens are synthesised in-kernel as the qkv bias (a zero token through the Linear).
+ *   out: [B][D][H][W][C] rows (ldo), head-major channels, ready for the proj Linear.
+ *   window wd/wh/ww (already clamped), shift sd/sh/sw (0 for un-shifted blocks),
+ *   rel-pos index always computed for a `tw`^3 table window (reference quirk: 7^3 index sliced [:n,:n]).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* qkv; int64_t ldq; void* out; int64_t ldo;
+  const float* qkv_bias;           /* fp32 [3C] or NULL */
+  const float* bias_table;         /* fp32 [(2tw-1)^3][heads] or NULL (global attention) */
+  float* lse;                      /* out fp32 [B*nW][heads][n]: log-sum-exp per query row, saved for bwd */
+  int B, D, H, W, C, heads, dtype;
+  int wd, wh, ww, sd, sh, sw, tw;
+  float scale;
+} miseg_winattn_params;
+int miseg_winattn_fwd(const miseg_winattn_params* p, miseg_stream_t stream);
+
+typedef struct {
+  miseg_winattn_params f;          /* same geometry; f.out is the saved forward output */
+  const void* dout; int64_t lddo;  /* gradient w.r.t. out */
+  void* dqkv; int64_t lddq;        /* gradient w.r.t. qkv (unpadded grid) */
+  float* dqkv_bias;                /* accumulated: contribution of padded tokens; may be NULL */
+  float* dbias_table;              /* accumulated fp32 [(2tw-1)^3][heads]; may be NULL */
+} miseg_winattn_bwd_params;
+int miseg_winattn_bwd(const miseg_winattn_bwd_params* p, miseg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Data-movement / small kernels (all channels-last rows)
+ * ---------------------------------------------------------------------------------------------- */
+/* y = a + b (elementwise over rows x C), any of the three may alias */
+typedef struct { const void* a; int64_t lda; const void* b; int64_t ldb; void* y; int64_t ldy; int64_t rows; int C, dtype; } miseg_add_params;
+int miseg_add(const miseg_add_params* p, miseg_stream_t stream);
+
+/* strided 2D copy with dtype conversion: dst[r][c] = src[r][c] */
+typedef struct { const void* src; int64_t lds; int sdtype; void* dst; int64_t ldd; int ddtype; int64_t rows; int C; } miseg_copy2d_params;
+int miseg_copy2d(const miseg_copy2d_params* p, miseg_stream_t stream);
+
+/* fp32 [R][C] -> dtype, optionally transposed to [C][R]  (weight re-packing for the NT GEMM) */
+typedef struct { const float* src; void* dst; int R, C, dtype, transpose; } miseg_cast_params;
+int miseg_cast_matrix(const miseg_cast_params* p, miseg_stream_t stream);
+
+/* GELU (exact, erf): y = gelu(x); backward: dx = dy * gelu'(x)  (MONAI MLPBlock act, swin_transformer_block.py:97) */
+typedef struct { const void* x; int64_t ldx; void* y; int64_t ldy; int64_t rows; int C, dtype; } miseg_gelu_fwd_params;
+int miseg_gelu_fwd(const miseg_gelu_fwd_params* p, miseg_stream_t stream);
+typedef struct { const void* dy; int64_t lddy; const void* x; int64_t ldx; void* dx; int64_t lddx; int64_t rows; int C, dtype; } miseg_gelu_bwd_params;
+int miseg_gelu_bwd(const miseg_gelu_bwd_params* p, miseg_stream_t stream);
+
+/* 2x2x2 space<->channel gathers.  `offsets` is 8 (dz,dy,dx) triples (host array): output channel block j of
+ * the coarse voxel (d,h,w) is the fine voxel (2d+dz_j, 2h+dy_j, 2w+dx_j)  (zero beyond the fine grid).
+ *   gather : fine [B][D][H][W][C] -> coarse [B][D2][H2][W2][8C]     (PatchMerging patch_merging.py:120-128 /
+ *            PatchMergingV2 :69-71 slice tables; ConvTranspose k2s2 data gradient)
+ *   scatter: coarse -> fine, fine[v] = sum of the blocks that reference v   (PatchMerging backward;
+ *            ConvTranspose3d k2 s2 forward unetr_block.py:51-59 after the [Cin]x[8*Cout] GEMM)
+ */
+typedef struct {
+  const void* src; int64_t lds; void* dst; int64_t ldd;
+  int B, D, H, W, C, dtype;        /* D,H,W: FINE grid; coarse grid is ceil(./2) */
+  int8_t offsets[24];
+} miseg_s2c_params;
+int miseg_space_to_channel(const miseg_s2c_params* p, miseg_stream_t stream);
+int miseg_channel_to_space(const miseg_s2c_params* p, miseg_stream_t stream);
+
+/* PatchEmbed Conv3d(k2,s2)+bias with Cin input channels given as NCDHW fp32 (the network input)
+ * (networks/blocks/patch_embedding.py:167-169,204).  w: fp32 [Cout][Cin][2][2][2]. */
+typedef struct {
+  const float* x; void* y; int64_t ldy; const float* w; const float* bias;
+  int B, Cin, D, H, W, Cout, dtype;  /* D,H,W: input grid (even) */
+} miseg_patch_embed_params;
+int miseg_patch_embed_fwd(const miseg_patch_embed_params* p, miseg_stream_t stream);
+typedef struct {
+  const float* x; const void* dy; int64_t lddy; float* dw; float* dbias;   /* accumulated */
+  int B, Cin, D, H, W, Cout, dtype;
+} miseg_patch_embed_bwd_params;
+int miseg_patch_embed_bwd(const miseg_patch_embed_bwd_params* p, miseg_stream_t stream);
+
+/* First encoder conv: 3x3x3, Cin in {1..4} NCDHW fp32 input -> channels-last Cout (dynunet_block.py:55-64 with
+ * in_channels = image channels).  Weight gradient accumulated into dw fp32 [Cout][Cin][27]. */
+typedef struct {
+  const float* x; void* y; int64_t ldy; const float* w;
+  int B, Cin, D, H, W, Cout, dtype;
+} miseg_conv3_thin_params;
+int miseg_conv3_thin_fwd(const miseg_conv3_thin_params* p, miseg_stream_t stream);
+typedef struct {
+  const float* x; const void* dy; int64_t lddy; float* dw;
+  int B, Cin, D, H, W, Cout, dtype;
+} miseg_conv3_thin_wgrad_params;
+int miseg_conv3_thin_wgrad(const miseg_conv3_thin_wgrad_params* p, miseg_stream_t stream);
+
+/* Output head: Conv3d 1x1x1 + bias from channels-last rows to NCDHW fp32 logits (dynunet_block.py:273-292),
+ * and its backward (dx channels-last, dw/dbias accumulated). */
+typedef struct {
+  const void* x; int64_t ldx; float* y; const float* w; const float* bias;
+  int B, S, Cin, Cout, dtype;
+} miseg_head_params;
+int miseg_head_fwd(const miseg_head_params* p, miseg_stream_t stream);
+typedef struct {
+  const void* x; int64_t ldx; const float* dy; void* dx; int64_t lddx; const float* w; float* dw; float* dbias;
+  int B, S, Cin, Cout, dtype;
+} miseg_head_bwd_params;
+int miseg_head_bwd(const miseg_head_bwd_params* p, miseg_stream_t stream);
+
+/* im2col for 3x3x3/pad 1 on small grids (<= 6^3): col[v][tap][ci]; and its adjoint col2im (dst zero-filled by
+ * the kernel).  Used with miseg_gemm where the implicit-GEMM tile would be mostly halo. */
+typedef struct { const void* src; int64_t lds; void* dst; int64_t ldd; int B, D, H, W, C, dtype; } miseg_im2col3_params;
+int miseg_im2col3(const miseg_im2col3_params* p, miseg_stream_t stream);
+int miseg_col2im3(const miseg_im2col3_params* p, miseg_stream_t stream);
+
+/* fill a buffer of n 32-bit words with a value (gradient arenas, accumulators) */
+int miseg_fill32(void* dst, uint32_t value, size_t n, miseg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

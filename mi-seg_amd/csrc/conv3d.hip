@@ -1,0 +1,466 @@
+// 3x3x3 / stride 1 / pad 1 convolution over channels-last volumes as an implicit GEMM on the matrix cores.
+//
+// forward (and data gradient, with the mirrored pack):
+//   one workgroup = one 4x8x8 output brick x up to 96 output channels.  The (4+2)x(8+2)x(8+2) input halo of a
+//   channel chunk (<= 128 bytes per voxel) is staged once in LDS; the im2col matrix is never materialised: a
+//   lane's MFMA operand is the 16-byte channel group (tap, cg) of "its" voxel, read straight from the halo at
+//   row (voxel + tap offset).  K = 27 * Cin is walked in groups of 16 bytes, four groups per MFMA k-step, so
+//   channel counts that are not a multiple of the MFMA depth (48!) waste nothing.  Weights come from the
+//   [Cout][27][CinP] pack (L2 resident, 16-byte loads).
+// weight gradient:
+//   one workgroup = (48 out-ch) x (48 in-ch) x 27 taps, accumulated in registers over a strided set of bricks
+//   (k = voxels; operands are "transposed": ds_read_b64_tr_b16 for bf16, 4-byte reads for fp32), written as one
+//   fp32 slab per workgroup and reduced by a second kernel (deterministic, no atomics).
+#include "common.h"
+
+namespace miseg {
+
+template <class T> struct MmaC;
+template <> struct MmaC<bf16> {
+  static constexpr int KPC = 8;
+  __device__ static __forceinline__ void run(f32x4& acc, const bf16x8& a, const bf16x8& b) { acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0); }
+};
+template <> struct MmaC<float> {
+  static constexpr int KPC = 4;
+  __device__ static __forceinline__ void run(f32x4& acc, const f32x4& a, const f32x4& b) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+  }
+};
+
+static constexpr int BD = 4, BH = 8, BW = 8;             // output brick
+static constexpr int HH = BH + 2, HW = BW + 2;            // halo extents (depth = bd + 2)
+
+struct ConvGeom {
+  int B, D, H, W;
+  int nbd, nbh, nbw;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------
+template <class T, int NT>
+__global__ void __launch_bounds__(256) conv3_fwd_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, const T* __restrict__ wpk, ConvGeom g,
+                                                        int Cin, int CinP, int Cout, int chunk_elems, int rowb, bool vec_x) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int KPC = MmaC<T>::KPC;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  __shared__ int tapoff[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  const int bw = bid % g.nbw; bid /= g.nbw;
+  const int bh = bid % g.nbh; bid /= g.nbh;
+  const int bd = bid % g.nbd;
+  const int b = bid / g.nbd;
+  const int d0 = bd * BD, h0 = bh * BH, w0 = bw * BW;
+  const int n0 = blockIdx.y * (16 * NT);
+  if (tid < 27) tapoff[tid] = ((tid / 9) * HH + (tid / 3) % 3) * HW + tid % 3;
+
+  const int fi = lane & 15, fq = lane >> 4;
+  // halo row of this lane's voxel in M-tile mt at tap (0,0,0): d = wave, h = 2mt + (fi>>3), w = fi&7
+  int vbase[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) vbase[mt] = (wave * HH + 2 * mt + (fi >> 3)) * HW + (fi & 7);
+
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const T* wrow[NT];
+  bool wvalid[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int co = n0 + nt * 16 + fi;
+    wvalid[nt] = co < Cout;
+    wrow[nt] = wpk + (int64_t)(wvalid[nt] ? co : 0) * 27 * CinP;
+  }
+
+  const int HROWS = (BD + 2) * HH * HW;
+  for (int c0 = 0; c0 < CinP; c0 += chunk_elems) {
+    const int cl = min(chunk_elems, CinP - c0);  // elements in this chunk
+    const int gpt = cl / KPC;                    // 16-byte groups per tap
+    const int G = 27 * gpt;
+    const unsigned inv = (65536u + gpt - 1) / gpt;
+    __syncthreads();
+    // ---- stage halo chunk: rows x gpt 16-byte groups
+    for (int idx = tid; idx < HROWS * gpt; idx += 256) {
+      const int row = idx / gpt, cg = idx - row * gpt;
+      const int hd = row / (HH * HW), rem = row - hd * (HH * HW);
+      const int hh = rem / HW, hw = rem - hh * HW;
+      const int d = d0 - 1 + hd, h = h0 - 1 + hh, w = w0 - 1 + hw;
+      VT v;
+#pragma unroll
+      for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(0.f);
+      if (d >= 0 && d < g.D && h >= 0 && h < g.H && w >= 0 && w < g.W) {
+        const int c = c0 + cg * KPC;
+        const T* p = x + ((((int64_t)b * g.D + d) * g.H + h) * g.W + w) * ldx + c;
+        if (vec_x && c + KPC <= Cin) v = *reinterpret_cast<const VT*>(p);
+        else {
+#pragma unroll
+          for (int e = 0; e < KPC; ++e)
+            if (c + e < Cin) v[e] = p[e];
+        }
+      }
+      *reinterpret_cast<VT*>(lds + row * rowb + cg * 16) = v;
+    }
+    __syncthreads();
+    // ---- K loop over (tap, group) in steps of 4 groups
+    const int nsteps = (G + 3) / 4;
+    for (int s = 0; s < nsteps; ++s) {
+      int gi = 4 * s + fq;
+      const bool gv = gi < G;
+      gi = gv ? gi : 0;
+      const int tap = (int)(((unsigned)gi * inv) >> 16);
+      const int cg = gi - tap * gpt;
+      const int aoff = tapoff[tap] * rowb + cg * 16;
+      VT bfr[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        VT v;
+#pragma unroll
+        for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(0.f);
+        if (gv && wvalid[nt]) v = *reinterpret_cast<const VT*>(wrow[nt] + tap * CinP + c0 + cg * KPC);
+        bfr[nt] = v;
+      }
+      VT af[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const VT*>(lds + vbase[mt] * rowb + aoff);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) MmaC<T>::run(acc[mt][nt], bfr[nt], af[mt]);
+    }
+  }
+  // ---- epilogue: lane holds channels n0 + 16nt + 4fq .. +3 of voxel (d0+wave, h0+2mt+(fi>>3), w0+(fi&7))
+  const int d = d0 + wave;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int h = h0 + 2 * mt + (fi >> 3), w = w0 + (fi & 7);
+    if (d < g.D && h < g.H && w < g.W) {
+      T* yr = y + ((((int64_t)b * g.D + d) * g.H + h) * g.W + w) * ldy;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co = n0 + nt * 16 + fq * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (co + r < Cout) yr[co + r] = from_f32<T>(acc[mt][nt][r]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight packing:  fwd[co][tap][ciP] = w[co][ci][tap] ; bwd[ci][tap][coP] = w[co][ci][26 - tap]   (zero padded)
+// ---------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(256) pack_conv3_kernel(const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ bwd, int Cin, int Cout, int CinP, int CoutP) {
+  const int64_t nf = (int64_t)Cout * 27 * CinP, nb = (int64_t)Cin * 27 * CoutP;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nb; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < nf) {
+      if (!fwd) continue;
+      const int ci = (int)(i % CinP);
+      const int tap = (int)((i / CinP) % 27);
+      const int co = (int)(i / ((int64_t)CinP * 27));
+      fwd[i] = from_f32<T>(ci < Cin ? w[((int64_t)co * Cin + ci) * 27 + tap] : 0.f);
+    } else {
+      if (!bwd) continue;
+      const int64_t j = i - nf;
+      const int co = (int)(j % CoutP);
+      const int tap = (int)((j / CoutP) % 27);
+      const int ci = (int)(j / ((int64_t)CoutP * 27));
+      bwd[j] = from_f32<T>(co < Cout ? w[((int64_t)co * Cin + ci) * 27 + (26 - tap)] : 0.f);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------------------------------------
+static constexpr int WG_THREADS = 512;
+static constexpr int WG_CB = 48;   // channel block (3 MFMA tiles) on both the out- and in-channel side
+
+template <class T, int WBD /*brick depth*/>
+__global__ void __launch_bounds__(WG_THREADS) conv3_wgrad_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ dy, int64_t lddy, float* __restrict__ slabs,
+                                                                 ConvGeom g, int Cin, int Cout, int ncib, int nsplit, int rowb, bool vec_x, bool vec_dy) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int KPC = MmaC<T>::KPC;
+  constexpr int GPR = WG_CB / KPC;        // 16-byte groups per staged row
+  constexpr int NVOX = WBD * BH * BW;     // voxels (k) per brick
+  constexpr int HROWS = (WBD + 2) * HH * HW;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* lx = lds;                          // halo of x : [HROWS][rowb]
+  char* ld = lds + HROWS * rowb;           // dy brick  : [NVOX][rowb]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pair = blockIdx.y, cob = pair / ncib, cib = pair - cob * ncib;
+  const int co0 = cob * WG_CB, ci0 = cib * WG_CB;
+  const int fi = lane & 15, fq = lane >> 4;
+
+  // taps owned by this wave: wave, wave+8, wave+16, wave+24
+  f32x4 acc[4][3][3];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int toff[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int tap = wave + 8 * t;
+    toff[t] = tap < 27 ? (((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3) : 0;
+  }
+
+  const int nbricks = g.B * g.nbd * g.nbh * g.nbw;
+  for (int brick = blockIdx.x; brick < nbricks; brick += nsplit) {
+    int bid = brick;
+    const int bw = bid % g.nbw; bid /= g.nbw;
+    const int bh = bid % g.nbh; bid /= g.nbh;
+    const int bd = bid % g.nbd;
+    const int b = bid / g.nbd;
+    const int d0 = bd * WBD, h0 = bh * BH, w0 = bw * BW;
+    __syncthreads();
+    for (int idx = tid; idx < HROWS * GPR; idx += WG_THREADS) {
+      const int row = idx / GPR, cg = idx - row * GPR;
+      const int hd = row / (HH * HW), rem = row - hd * (HH * HW);
+      const int hh = rem / HW, hw = rem - hh * HW;
+      const int d = d0 - 1 + hd, h = h0 - 1 + hh, w = w0 - 1 + hw;
+      VT v;
+#pragma unroll
+      for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(0.f);
+      if (d >= 0 && d < g.D && h >= 0 && h < g.H && w >= 0 && w < g.W) {
+        const int c = ci0 + cg * KPC;
+        const T* p = x + ((((int64_t)b * g.D + d) * g.H + h) * g.W + w) * ldx + c;
+        if (vec_x && c + KPC <= Cin) v = *reinterpret_cast<const VT*>(p);
+        else {
+#pragma unroll
+          for (int e = 0; e < KPC; ++e)
+            if (c + e < Cin) v[e] = p[e];
+        }
+      }
+      *reinterpret_cast<VT*>(lx + row * rowb + cg * 16) = v;
+    }
+    for (int idx = tid; idx < NVOX * GPR; idx += WG_THREADS) {
+      const int row = idx / GPR, cg = idx - row * GPR;
+      const int vd = row / (BH * BW), rem = row - vd * (BH * BW);
+      const int vh = rem / BW, vw = rem - vh * BW;
+      const int d = d0 + vd, h = h0 + vh, w = w0 + vw;
+      VT v;
+#pragma unroll
+      for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(0.f);
+      if (d < g.D && h < g.H && w < g.W) {
+        const int c = co0 + cg * KPC;
+        const T* p = dy + ((((int64_t)b * g.D + d) * g.H + h) * g.W + w) * lddy + c;
+        if (vec_dy && c + KPC <= Cout) v = *reinterpret_cast<const VT*>(p);
+        else {
+#pragma unroll
+          for (int e = 0; e < KPC; ++e)
+            if (c + e < Cout) v[e] = p[e];
+        }
+      }
+      *reinterpret_cast<VT*>(ld + row * rowb + cg * 16) = v;
+    }
+    __syncthreads();
+    if constexpr (std::is_same<T, bf16>::value) {
+      // k-step = 32 voxels = 4 h-rows x 8 w at one depth; MFMA k-group fq <-> h-row, element j <-> w
+      const int qq = fi >> 2, p4 = (fi & 3) * 4;
+#pragma unroll 1
+      for (int ks = 0; ks < NVOX / 32; ++ks) {
+        const int vd = ks >> 1, vh = (ks & 1) * 4 + fq;
+        // rows supplied by this lane for the two transposed reads: w = qq and w = 4 + qq
+        const int vrow = (vd * BH + vh) * BW + qq;
+        const int hrow = (vd * HH + vh) * HW + qq;  // halo row at tap (0,0,0)
+        bf16x8 af[3];
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) {
+          const char* a1 = ld + vrow * rowb + (mt * 16 + p4) * 2;
+          bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1));
+          bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1 + 4 * rowb));
+          af[mt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (wave + 8 * t < 27) {
+            bf16x8 bfr[3];
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {
+              const char* a1 = lx + (hrow + toff[t]) * rowb + (nt * 16 + p4) * 2;
+              bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1));
+              bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1 + 4 * rowb));
+              bfr[nt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < 3; ++nt) acc[t][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[mt], acc[t][mt][nt], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+      // fp32: k-step = 4 voxels (w = 4*(ks&1) .. +3 of one (d,h) row); lane k index = fq
+#pragma unroll 1
+      for (int ks = 0; ks < NVOX / 4; ++ks) {
+        const int vrow = ks * 4 + fq;                  // voxel index in brick
+        const int vd = vrow / (BH * BW), rem = vrow - vd * (BH * BW);
+        const int vh = rem / BW, vw = rem - vh * BW;
+        const int hrow = (vd * HH + vh) * HW + vw;
+        float af[3];
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) af[mt] = *reinterpret_cast<const float*>(ld + vrow * rowb + (mt * 16 + fi) * 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (wave + 8 * t < 27) {
+            float bfr[3];
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) bfr[nt] = *reinterpret_cast<const float*>(lx + (hrow + toff[t]) * rowb + (nt * 16 + fi) * 4);
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < 3; ++nt) acc[t][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[nt], af[mt], acc[t][mt][nt], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // slab[pair][split][tap][co 48][ci 48]; swapped operands => lane holds ci = 16nt + 4fq + r, co = 16mt + fi
+  float* slab = slabs + ((int64_t)pair * nsplit + blockIdx.x) * 27 * WG_CB * WG_CB;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int tap = wave + 8 * t;
+    if (tap < 27) {
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+          *reinterpret_cast<f32x4*>(slab + ((int64_t)tap * WG_CB + mt * 16 + fi) * WG_CB + nt * 16 + fq * 4) = acc[t][mt][nt];
+    }
+  }
+}
+
+// dw[co][ci][tap] (+)= sum_split slab[pair(co,ci)][split][tap][co%48][ci%48]
+__global__ void __launch_bounds__(256) conv3_wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int Cin, int Cout, int ncib, int nsplit,
+                                                                 int accumulate) {
+  const int64_t total = (int64_t)Cout * Cin * 27;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    // iterate in slab-friendly order: (co, tap, ci) with ci fastest
+    const int ci = (int)(i % Cin);
+    const int tap = (int)((i / Cin) % 27);
+    const int co = (int)(i / ((int64_t)Cin * 27));
+    const int pair = (co / WG_CB) * ncib + ci / WG_CB;
+    const float* s = slabs + (int64_t)pair * nsplit * 27 * WG_CB * WG_CB + ((int64_t)tap * WG_CB + co % WG_CB) * WG_CB + ci % WG_CB;
+    float acc = 0.f;
+    for (int k = 0; k < nsplit; ++k) acc += s[(int64_t)k * 27 * WG_CB * WG_CB];
+    float* o = dw + ((int64_t)co * Cin + ci) * 27 + tap;
+    *o = accumulate ? *o + acc : acc;
+  }
+}
+
+}  // namespace miseg
+
+using namespace miseg;
+
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+template <class T>
+static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
+  constexpr int KPC = Vec16<T>::N;
+  const int CinP = round_up(p->Cin, KPC);
+  const int rowbytes = CinP * (int)sizeof(T);
+  int chunk_bytes;
+  if (rowbytes <= 128) chunk_bytes = rowbytes;
+  else if (rowbytes % 96 == 0) chunk_bytes = 96;
+  else if (rowbytes % 128 == 0) chunk_bytes = 128;
+  else chunk_bytes = 64;
+  const int chunk_elems = chunk_bytes / (int)sizeof(T);
+  const int rowb = chunk_bytes + 16;
+  ConvGeom g{p->B, p->D, p->H, p->W, cdiv(p->D, BD), cdiv(p->H, BH), cdiv(p->W, BW)};
+  const size_t lds = (size_t)(BD + 2) * HH * HW * rowb;
+  const bool vec_x = ((uintptr_t)p->x % 16 == 0) && (p->ldx % KPC == 0);
+  const int nt = p->Cout <= 16 ? 1 : p->Cout <= 32 ? 2 : p->Cout <= 48 ? 3 : p->Cout <= 64 ? 4 : (p->Cout % 96 == 0 || p->Cout > 128) ? 6 : 4;
+  dim3 grid(g.B * g.nbd * g.nbh * g.nbw, cdiv(p->Cout, 16 * nt));
+#define FWD_CASE(n)                                                                                                                             \
+  case n:                                                                                                                                       \
+    hipFuncSetAttribute((const void*)conv3_fwd_kernel<T, n>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+    conv3_fwd_kernel<T, n><<<grid, 256, lds, s>>>((const T*)p->x, p->ldx, (T*)p->y, p->ldy, (const T*)p->wpk, g, p->Cin, CinP, p->Cout, chunk_elems, \
+                                                  rowb, vec_x);                                                                                 \
+    break;
+  switch (nt) { FWD_CASE(1) FWD_CASE(2) FWD_CASE(3) FWD_CASE(4) FWD_CASE(6) }
+#undef FWD_CASE
+  MISEG_LAUNCH_CHECK("conv3_fwd");
+  return MISEG_OK;
+}
+
+extern "C" int miseg_conv3_fwd(const miseg_conv3_params* p, miseg_stream_t s_) {
+  MISEG_REQUIRE(p && p->x && p->y && p->wpk, MISEG_E_BADARG, "conv3_fwd: null pointer");
+  MISEG_REQUIRE(p->B > 0 && p->D > 0 && p->H > 0 && p->W > 0 && p->Cin > 0 && p->Cout > 0, MISEG_E_BADARG, "conv3_fwd: bad shape");
+  MISEG_REQUIRE(p->ldx >= p->Cin && p->ldy >= p->Cout, MISEG_E_BADARG, "conv3_fwd: row stride smaller than channel count");
+  if (p->dtype == MISEG_F32) return conv3_fwd_launch<float>(p, (hipStream_t)s_);
+  if (p->dtype == MISEG_BF16) return conv3_fwd_launch<bf16>(p, (hipStream_t)s_);
+  return set_error(MISEG_E_BADARG, "conv3_fwd: dtype %d", p->dtype);
+}
+
+extern "C" int miseg_pack_conv3_weight(const miseg_pack_conv3_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->w && (p->fwd_pack || p->bwd_pack) && p->Cin > 0 && p->Cout > 0, MISEG_E_BADARG, "pack_conv3_weight: bad args");
+  return dispatch_dtype(p->dtype, [&](auto* tag) -> int {
+    typedef typename std::remove_pointer<decltype(tag)>::type T;
+    constexpr int KPC = Vec16<T>::N;
+    const int CinP = round_up(p->Cin, KPC), CoutP = round_up(p->Cout, KPC);
+    const int64_t n = (int64_t)p->Cout * 27 * CinP + (int64_t)p->Cin * 27 * CoutP;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    pack_conv3_kernel<T><<<grid, 256, 0, s>>>(p->w, (T*)p->fwd_pack, (T*)p->bwd_pack, p->Cin, p->Cout, CinP, CoutP);
+    MISEG_LAUNCH_CHECK("pack_conv3_weight");
+    return MISEG_OK;
+  });
+}
+
+static void wgrad_plan(int B, int D, int H, int W, int Cin, int Cout, int wbd, int* ncob, int* ncib, int* nsplit) {
+  *ncob = cdiv(Cout, WG_CB);
+  *ncib = cdiv(Cin, WG_CB);
+  const int nbricks = B * cdiv(D, wbd) * cdiv(H, BH) * cdiv(W, BW);
+  int pairs = (*ncob) * (*ncib);
+  int ns = 512 / pairs;
+  if (ns < 1) ns = 1;
+  if (ns > nbricks) ns = nbricks;
+  *nsplit = ns;
+}
+
+extern "C" size_t miseg_conv3_wgrad_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout) {
+  int ncob, ncib, ns2, ns4;
+  wgrad_plan(B, D, H, W, Cin, Cout, 2, &ncob, &ncib, &ns2);
+  wgrad_plan(B, D, H, W, Cin, Cout, 4, &ncob, &ncib, &ns4);
+  const int ns = ns2 > ns4 ? ns2 : ns4;
+  return (size_t)ncob * ncib * ns * 27 * WG_CB * WG_CB * sizeof(float);
+}
+
+template <class T, int WBD>
+static int conv3_wgrad_launch(const miseg_conv3_wgrad_params* p, hipStream_t s) {
+  constexpr int KPC = Vec16<T>::N;
+  int ncob, ncib, nsplit;
+  wgrad_plan(p->B, p->D, p->H, p->W, p->Cin, p->Cout, WBD, &ncob, &ncib, &nsplit);
+  ConvGeom g{p->B, p->D, p->H, p->W, cdiv(p->D, WBD), cdiv(p->H, BH), cdiv(p->W, BW)};
+  const int rowb = WG_CB * (int)sizeof(T) + 16;
+  const size_t lds = (size_t)((WBD + 2) * HH * HW + WBD * BH * BW) * rowb;
+  const bool vec_x = ((uintptr_t)p->x % 16 == 0) && (p->ldx % KPC == 0);
+  const bool vec_dy = ((uintptr_t)p->dy % 16 == 0) && (p->lddy % KPC == 0);
+  hipFuncSetAttribute((const void*)conv3_wgrad_kernel<T, WBD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  dim3 grid(nsplit, ncob * ncib);
+  conv3_wgrad_kernel<T, WBD><<<grid, WG_THREADS, lds, s>>>((const T*)p->x, p->ldx, (const T*)p->dy, p->lddy, (float*)p->workspace, g, p->Cin, p->Cout, ncib, nsplit,
+                                                           rowb, vec_x, vec_dy);
+  const int64_t total = (int64_t)p->Cout * p->Cin * 27;
+  int rg = (int)((total + 255) / 256);
+  if (rg > 2048) rg = 2048;
+  conv3_wgrad_reduce_kernel<<<rg, 256, 0, s>>>((const float*)p->workspace, p->dw, p->Cin, p->Cout, ncib, nsplit, p->accumulate);
+  MISEG_LAUNCH_CHECK("conv3_wgrad");
+  return MISEG_OK;
+}
+
+extern "C" int miseg_conv3_wgrad(const miseg_conv3_wgrad_params* p, miseg_stream_t s_) {
+  MISEG_REQUIRE(p && p->x && p->dy && p->dw && p->workspace, MISEG_E_BADARG, "conv3_wgrad: null pointer");
+  MISEG_REQUIRE(p->B > 0 && p->D > 0 && p->H > 0 && p->W > 0 && p->Cin > 0 && p->Cout > 0, MISEG_E_BADARG, "conv3_wgrad: bad shape");
+  if (p->dtype == MISEG_F32) return conv3_wgrad_launch<float, 2>(p, (hipStream_t)s_);
+  if (p->dtype == MISEG_BF16) return conv3_wgrad_launch<bf16, 4>(p, (hipStream_t)s_);
+  return set_error(MISEG_E_BADARG, "conv3_wgrad: dtype %d", p->dtype);
+}

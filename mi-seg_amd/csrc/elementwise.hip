@@ -1,0 +1,771 @@
+// Data-movement and thin-channel kernels (all HBM-bound): add, copy/cast, GELU', 2x2x2 space<->channel,
+// PatchEmbed (k2 s2), the 1-channel 3x3x3 stem conv, the 1x1x1 output head, im2col for tiny grids.
+#include "common.h"
+
+namespace miseg {
+
+// ----------------------------------------------------------------------------- generic row-wise helpers
+template <class T, int VEC, class F>
+__global__ void __launch_bounds__(256) rowwise_kernel(int64_t rows, int cv, F f) {
+  const int64_t total = rows * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cv;
+    const int c = (int)(i % cv) * VEC;
+    f(r, c);
+  }
+}
+
+static inline int ew_grid(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+template <class T, int VEC> struct V {
+  float v[VEC];
+  __device__ __forceinline__ void load(const T* p) {
+    if constexpr (VEC == 1) v[0] = to_f32(p[0]);
+    else {
+      typename Vec16<T>::type t = *reinterpret_cast<const typename Vec16<T>::type*>(p);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) v[i] = to_f32(t[i]);
+    }
+  }
+  __device__ __forceinline__ void store(T* p) const {
+    if constexpr (VEC == 1) p[0] = from_f32<T>(v[0]);
+    else {
+      typename Vec16<T>::type t;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) t[i] = from_f32<T>(v[i]);
+      *reinterpret_cast<typename Vec16<T>::type*>(p) = t;
+    }
+  }
+};
+
+static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// ----------------------------------------------------------------------------- add
+template <class T, int VEC>
+__global__ void __launch_bounds__(256) add_kernel(const T* a, int64_t lda, const T* b, int64_t ldb, T* y, int64_t ldy, int64_t rows, int cv) {
+  const int64_t total = rows * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cv;
+    const int c = (int)(i % cv) * VEC;
+    V<T, VEC> va, vb;
+    va.load(a + r * lda + c);
+    vb.load(b + r * ldb + c);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) va.v[k] += vb.v[k];
+    va.store(y + r * ldy + c);
+  }
+}
+
+// ----------------------------------------------------------------------------- copy2d with conversion
+template <class TS, class TD>
+__global__ void __launch_bounds__(256) copy2d_kernel(const TS* s, int64_t lds, TD* d, int64_t ldd, int64_t rows, int C) {
+  const int64_t total = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / C;
+    const int c = (int)(i % C);
+    d[r * ldd + c] = from_f32<TD>(to_f32(s[r * lds + c]));
+  }
+}
+
+// ----------------------------------------------------------------------------- cast (+transpose) fp32 matrix
+template <class T>
+__global__ void __launch_bounds__(256) cast_kernel(const float* s, T* d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = from_f32<T>(s[i]);
+}
+template <class T>
+__global__ void __launch_bounds__(256) cast_transpose_kernel(const float* s, T* d, int R, int C) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8)
+    if (by + j < R && bx + tx < C) tile[j][tx] = s[(int64_t)(by + j) * C + bx + tx];
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (bx + j < C && by + tx < R) d[(int64_t)(bx + j) * R + by + tx] = from_f32<T>(tile[tx][j]);
+}
+
+// ----------------------------------------------------------------------------- GELU backward
+template <class T, int VEC>
+__global__ void __launch_bounds__(256) gelu_bwd_kernel(const T* dy, int64_t lddy, const T* x, int64_t ldx, T* dx, int64_t lddx, int64_t rows, int cv) {
+  const int64_t total = rows * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cv;
+    const int c = (int)(i % cv) * VEC;
+    V<T, VEC> g, xv;
+    g.load(dy + r * lddy + c);
+    xv.load(x + r * ldx + c);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const float t = xv.v[k];
+      const float cdf = 0.5f * (1.f + erff(t * 0.70710678118654752f));
+      const float pdf = 0.39894228040143268f * __expf(-0.5f * t * t);
+      g.v[k] *= cdf + t * pdf;
+    }
+    g.store(dx + r * lddx + c);
+  }
+}
+
+template <class T, int VEC>
+__global__ void __launch_bounds__(256) gelu_fwd_kernel(const T* x, int64_t ldx, T* y, int64_t ldy, int64_t rows, int cv) {
+  const int64_t total = rows * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cv;
+    const int c = (int)(i % cv) * VEC;
+    V<T, VEC> xv;
+    xv.load(x + r * ldx + c);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) xv.v[k] = 0.5f * xv.v[k] * (1.f + erff(xv.v[k] * 0.70710678118654752f));
+    xv.store(y + r * ldy + c);
+  }
+}
+
+// ----------------------------------------------------------------------------- 2x2x2 space <-> channel
+struct Off8 { int8_t o[24]; };
+
+template <class T, int VEC>
+__global__ void __launch_bounds__(256) s2c_kernel(const T* src, int64_t lds, T* dst, int64_t ldd, int B, int D, int H, int W, int C, Off8 off) {
+  const int D2 = (D + 1) / 2, H2 = (H + 1) / 2, W2 = (W + 1) / 2, cv = C / VEC;
+  const int64_t total = (int64_t)B * D2 * H2 * W2 * 8 * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * VEC;
+    int64_t t = i / cv;
+    const int j = (int)(t % 8); t /= 8;
+    const int w2 = (int)(t % W2); t /= W2;
+    const int h2 = (int)(t % H2); t /= H2;
+    const int d2 = (int)(t % D2);
+    const int b = (int)(t / D2);
+    const int d = 2 * d2 + off.o[3 * j], h = 2 * h2 + off.o[3 * j + 1], w = 2 * w2 + off.o[3 * j + 2];
+    V<T, VEC> v;
+    if (d < D && h < H && w < W) v.load(src + ((((int64_t)b * D + d) * H + h) * W + w) * lds + c);
+    else {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) v.v[k] = 0.f;
+    }
+    v.store(dst + ((((int64_t)b * D2 + d2) * H2 + h2) * W2 + w2) * ldd + (int64_t)j * C + c);
+  }
+}
+
+template <class T, int VEC>
+__global__ void __launch_bounds__(256) c2s_kernel(const T* src, int64_t lds, T* dst, int64_t ldd, int B, int D, int H, int W, int C, Off8 off) {
+  const int D2 = (D + 1) / 2, H2 = (H + 1) / 2, W2 = (W + 1) / 2, cv = C / VEC;
+  const int64_t total = (int64_t)B * D * H * W * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * VEC;
+    int64_t t = i / cv;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H); t /= H;
+    const int d = (int)(t % D);
+    const int b = (int)(t / D);
+    const int pd = d & 1, ph = h & 1, pw = w & 1;
+    const T* srow = src + ((((int64_t)b * D2 + (d >> 1)) * H2 + (h >> 1)) * W2 + (w >> 1)) * lds + c;
+    V<T, VEC> acc;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc.v[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (off.o[3 * j] == pd && off.o[3 * j + 1] == ph && off.o[3 * j + 2] == pw) {
+        V<T, VEC> v;
+        v.load(srow + (int64_t)j * C);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc.v[k] += v.v[k];
+      }
+    }
+    acc.store(dst + ((((int64_t)b * D + d) * H + h) * W + w) * ldd + c);
+  }
+}
+
+// ----------------------------------------------------------------------------- PatchEmbed k2 s2 (+bias)
+// thread = (coarse voxel, group of 8 output channels)
+template <class T>
+__global__ void __launch_bounds__(256) patch_embed_fwd_kernel(const float* __restrict__ x, T* __restrict__ y, int64_t ldy, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, int B, int Cin, int D, int H, int W, int Cout) {
+  extern __shared__ float ws[];  // [Cin*8][Cout] transposed weights + bias[Cout]
+  const int K = Cin * 8;
+  for (int i = threadIdx.x; i < K * Cout; i += blockDim.x) {
+    const int co = i / K, k = i % K;
+    ws[k * Cout + co] = w[i];
+  }
+  for (int i = threadIdx.x; i < Cout; i += blockDim.x) ws[K * Cout + i] = bias ? bias[i] : 0.f;
+  __syncthreads();
+  const int D2 = D / 2, H2 = H / 2, W2 = W / 2, cg = (Cout + 7) / 8;
+  const int64_t total = (int64_t)B * D2 * H2 * W2 * cg;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % cg);
+    int64_t t = i / cg;
+    const int w2 = (int)(t % W2); t /= W2;
+    const int h2 = (int)(t % H2); t /= H2;
+    const int d2 = (int)(t % D2);
+    const int b = (int)(t / D2);
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = (g * 8 + k < Cout) ? ws[K * Cout + g * 8 + k] : 0.f;
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int a = 0; a < 2; ++a)
+        for (int bb = 0; bb < 2; ++bb)
+          for (int c = 0; c < 2; ++c) {
+            const float xv = x[((((int64_t)b * Cin + ci) * D + 2 * d2 + a) * H + 2 * h2 + bb) * W + 2 * w2 + c];
+            const float* wr = ws + ((ci * 2 + a) * 2 + bb) * 2 * Cout + c * Cout + g * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+              if (g * 8 + k < Cout) acc[k] = fmaf(xv, wr[k], acc[k]);
+          }
+    T* yr = y + ((((int64_t)b * D2 + d2) * H2 + h2) * W2 + w2) * ldy + g * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (g * 8 + k < Cout) yr[k] = from_f32<T>(acc[k]);
+  }
+}
+
+// dw[co][k] += sum_v dy[v][co] * xpatch[v][k],  dbias[co] += sum_v dy[v][co];   k in [0, Cin*8)
+template <class T>
+__global__ void __launch_bounds__(256) patch_embed_bwd_kernel(const float* __restrict__ x, const T* __restrict__ dy, int64_t lddy, float* __restrict__ dw,
+                                                              float* __restrict__ dbias, int B, int Cin, int D, int H, int W, int Cout, int vox_per_block) {
+  extern __shared__ float sm[];  // xs[VT][K+1], ds[VT][Cout]
+  const int K = Cin * 8, VT = 64;
+  float* xs = sm;
+  float* ds = sm + VT * (K + 1);
+  const int D2 = D / 2, H2 = H / 2, W2 = W / 2;
+  const int64_t nv = (int64_t)B * D2 * H2 * W2;
+  const int64_t v0 = (int64_t)blockIdx.x * vox_per_block, v1 = min(nv, v0 + vox_per_block);
+  const int nout = Cout * (K + 1);
+  float acc[8];  // outputs owned: o = threadIdx.x + j*256
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int64_t vb = v0; vb < v1; vb += VT) {
+    const int nvt = (int)min((int64_t)VT, v1 - vb);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nvt * (K + 1); i += blockDim.x) {
+      const int vi = i / (K + 1), k = i % (K + 1);
+      float val = 1.f;  // column K is the bias "input"
+      if (k < K) {
+        int64_t t = vb + vi;
+        const int w2 = (int)(t % W2); t /= W2;
+        const int h2 = (int)(t % H2); t /= H2;
+        const int d2 = (int)(t % D2);
+        const int b = (int)(t / D2);
+        const int ci = k / 8, a = (k >> 2) & 1, bb = (k >> 1) & 1, c = k & 1;
+        val = x[((((int64_t)b * Cin + ci) * D + 2 * d2 + a) * H + 2 * h2 + bb) * W + 2 * w2 + c];
+      }
+      xs[vi * (K + 1) + k] = val;
+    }
+    for (int i = threadIdx.x; i < nvt * Cout; i += blockDim.x) {
+      const int vi = i / Cout, co = i % Cout;
+      ds[vi * Cout + co] = to_f32(dy[(vb + vi) * lddy + co]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int o = threadIdx.x + j * 256;
+      if (o < nout) {
+        const int co = o / (K + 1), k = o % (K + 1);
+        float a = acc[j];
+        for (int vi = 0; vi < nvt; ++vi) a = fmaf(ds[vi * Cout + co], xs[vi * (K + 1) + k], a);
+        acc[j] = a;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int o = threadIdx.x + j * 256;
+    if (o < nout) {
+      const int co = o / (K + 1), k = o % (K + 1);
+      if (k < K) atomicAdd(dw + co * K + k, acc[j]);
+      else if (dbias) atomicAdd(dbias + co, acc[j]);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------- thin 3x3x3 stem conv (Cin <= 4, NCDHW fp32 in)
+// thread = voxel; weights transposed in LDS as [ci*27+tap][Cout]; loops output channels in groups of 8.
+template <class T>
+__global__ void __launch_bounds__(256) conv3_thin_fwd_kernel(const float* __restrict__ x, T* __restrict__ y, int64_t ldy, const float* __restrict__ w, int B,
+                                                             int Cin, int D, int H, int W, int Cout) {
+  extern __shared__ float ws[];  // [Cin*27][Cout]
+  const int K = Cin * 27;
+  for (int i = threadIdx.x; i < K * Cout; i += blockDim.x) {
+    const int co = i / K, k = i % K;
+    ws[k * Cout + co] = w[i];
+  }
+  __syncthreads();
+  const int64_t nv = (int64_t)B * D * H * W;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = v;
+    const int wq = (int)(t % W); t /= W;
+    const int h = (int)(t % H); t /= H;
+    const int d = (int)(t % D);
+    const int b = (int)(t / D);
+    for (int c0 = 0; c0 < Cout; c0 += 8) {
+      float acc[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+      for (int ci = 0; ci < Cin; ++ci) {
+        const float* xc = x + ((int64_t)b * Cin + ci) * D * H * W;
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+          const int dd = d + tap / 9 - 1, hh = h + (tap / 3) % 3 - 1, ww = wq + tap % 3 - 1;
+          float xv = 0.f;
+          if (dd >= 0 && dd < D && hh >= 0 && hh < H && ww >= 0 && ww < W) xv = xc[((int64_t)dd * H + hh) * W + ww];
+          const float* wr = ws + (ci * 27 + tap) * Cout + c0;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc[k] = fmaf(xv, (c0 + k < Cout) ? wr[k] : 0.f, acc[k]);
+        }
+      }
+      T* yr = y + v * ldy + c0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (c0 + k < Cout) yr[k] = from_f32<T>(acc[k]);
+    }
+  }
+}
+
+// dw[co][ci][tap] += sum_v dy[v][co] x[ci][v+tap].  Block = 8x8x8 voxel brick; x halo + dy brick staged in LDS;
+// thread = (tap, group of 8 output channels).
+template <class T>
+__global__ void __launch_bounds__(256) conv3_thin_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dy, int64_t lddy, float* __restrict__ dw,
+                                                               int B, int Cin, int D, int H, int W, int Cout) {
+  extern __shared__ float sm[];
+  constexpr int BT = 8, HT = BT + 2;
+  float* xs = sm;                       // [HT^3]
+  float* ds = sm + HT * HT * HT;        // [512][Cout]
+  const int nbw = cdiv(W, BT), nbh = cdiv(H, BT), nbd = cdiv(D, BT);
+  int bid = blockIdx.x;
+  const int bw = bid % nbw; bid /= nbw;
+  const int bh = bid % nbh; bid /= nbh;
+  const int bd = bid % nbd;
+  const int b = bid / nbd;
+  const int d0 = bd * BT, h0 = bh * BT, w0 = bw * BT;
+  for (int i = threadIdx.x; i < BT * BT * BT * Cout; i += blockDim.x) {
+    const int co = i % Cout, vi = i / Cout;
+    const int d = d0 + vi / 64, h = h0 + (vi / 8) % 8, w = w0 + vi % 8;
+    float val = 0.f;
+    if (d < D && h < H && w < W) val = to_f32(dy[((((int64_t)b * D + d) * H + h) * W + w) * lddy + co]);
+    ds[vi * Cout + co] = val;
+  }
+  const int ncg = (Cout + 7) / 8;
+  const int tap = threadIdx.x % 27, cg = threadIdx.x / 27;
+  for (int ci = 0; ci < Cin; ++ci) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < HT * HT * HT; i += blockDim.x) {
+      const int d = d0 - 1 + i / (HT * HT), h = h0 - 1 + (i / HT) % HT, w = w0 - 1 + i % HT;
+      float val = 0.f;
+      if (d >= 0 && d < D && h >= 0 && h < H && w >= 0 && w < W) val = x[((((int64_t)b * Cin + ci) * D + d) * H + h) * W + w];
+      xs[i] = val;
+    }
+    __syncthreads();
+    for (int g = cg; g < ncg; g += 256 / 27) {
+      if (cg >= 256 / 27) break;
+      float acc[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+      const int td = tap / 9, th = (tap / 3) % 3, tw = tap % 3;
+      for (int vi = 0; vi < 512; ++vi) {
+        const int vd = vi >> 6, vh = (vi >> 3) & 7, vw = vi & 7;
+        const float xv = xs[((vd + td) * HT + vh + th) * HT + vw + tw];
+        const float* dr = ds + vi * Cout + g * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = fmaf(xv, (g * 8 + k < Cout) ? dr[k] : 0.f, acc[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (g * 8 + k < Cout) atomicAdd(dw + ((int64_t)(g * 8 + k) * Cin + ci) * 27 + tap, acc[k]);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------- output head (1x1x1 + bias -> NCDHW fp32)
+template <class T>
+__global__ void __launch_bounds__(256) head_fwd_kernel(const T* __restrict__ x, int64_t ldx, float* __restrict__ y, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, int B, int S, int Cin, int Cout) {
+  extern __shared__ float ws[];  // [Cout][Cin] + bias
+  for (int i = threadIdx.x; i < Cout * Cin; i += blockDim.x) ws[i] = w[i];
+  for (int i = threadIdx.x; i < Cout; i += blockDim.x) ws[Cout * Cin + i] = bias ? bias[i] : 0.f;
+  __syncthreads();
+  const int64_t nv = (int64_t)B * S;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(v / S);
+    const int64_t s = v % S;
+    const T* xr = x + v * ldx;
+    for (int co = 0; co < Cout; ++co) {
+      float acc = ws[Cout * Cin + co];
+      for (int ci = 0; ci < Cin; ++ci) acc = fmaf(to_f32(xr[ci]), ws[co * Cin + ci], acc);
+      y[((int64_t)b * Cout + co) * S + s] = acc;
+    }
+  }
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) head_bwd_dx_kernel(const float* __restrict__ dy, T* __restrict__ dx, int64_t lddx, const float* __restrict__ w, int B, int S,
+                                                          int Cin, int Cout) {
+  extern __shared__ float ws[];  // [Cout][Cin]
+  for (int i = threadIdx.x; i < Cout * Cin; i += blockDim.x) ws[i] = w[i];
+  __syncthreads();
+  const int64_t nv = (int64_t)B * S;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(v / S);
+    const int64_t s = v % S;
+    float g[16];
+    for (int co = 0; co < Cout; ++co) g[co] = dy[((int64_t)b * Cout + co) * S + s];
+    T* dr = dx + v * lddx;
+    for (int ci = 0; ci < Cin; ++ci) {
+      float acc = 0.f;
+      for (int co = 0; co < Cout; ++co) acc = fmaf(g[co], ws[co * Cin + ci], acc);
+      dr[ci] = from_f32<T>(acc);
+    }
+  }
+}
+
+// dw[co][ci] += sum_v dy[co][v] x[v][ci] ; dbias[co] += sum_v dy[co][v].  thread = (co, ci or bias column)
+template <class T>
+__global__ void __launch_bounds__(256) head_bwd_dw_kernel(const T* __restrict__ x, int64_t ldx, const float* __restrict__ dy, float* __restrict__ dw,
+                                                          float* __restrict__ dbias, int B, int S, int Cin, int Cout, int vox_per_block) {
+  extern __shared__ float sm[];
+  constexpr int VT = 64;
+  float* xs = sm;                  // [VT][Cin+1]
+  float* ds = sm + VT * (Cin + 1); // [Cout][VT]
+  const int64_t nv = (int64_t)B * S;
+  const int64_t v0 = (int64_t)blockIdx.x * vox_per_block, v1 = min(nv, v0 + vox_per_block);
+  const int nout = Cout * (Cin + 1);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t vb = v0; vb < v1; vb += VT) {
+    const int nvt = (int)min((int64_t)VT, v1 - vb);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nvt * (Cin + 1); i += blockDim.x) {
+      const int vi = i / (Cin + 1), ci = i % (Cin + 1);
+      xs[i] = ci < Cin ? to_f32(x[(vb + vi) * ldx + ci]) : 1.f;
+    }
+    for (int i = threadIdx.x; i < nvt * Cout; i += blockDim.x) {
+      const int co = i / nvt, vi = i % nvt;
+      const int64_t v = vb + vi;
+      ds[co * VT + vi] = dy[((v / S) * Cout + co) * S + v % S];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int o = threadIdx.x + j * 256;
+      if (o < nout) {
+        const int co = o / (Cin + 1), ci = o % (Cin + 1);
+        float a = acc[j];
+        for (int vi = 0; vi < nvt; ++vi) a = fmaf(ds[co * VT + vi], xs[vi * (Cin + 1) + ci], a);
+        acc[j] = a;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int o = threadIdx.x + j * 256;
+    if (o < nout) {
+      const int co = o / (Cin + 1), ci = o % (Cin + 1);
+      if (ci < Cin) atomicAdd(dw + co * Cin + ci, acc[j]);
+      else if (dbias) atomicAdd(dbias + co, acc[j]);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------- im2col / col2im (3x3x3 pad 1)
+template <class T, int VEC>
+__global__ void __launch_bounds__(256) im2col3_kernel(const T* src, int64_t lds, T* dst, int64_t ldd, int B, int D, int H, int W, int C) {
+  const int cv = C / VEC;
+  const int64_t total = (int64_t)B * D * H * W * 27 * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * VEC;
+    int64_t t = i / cv;
+    const int tap = (int)(t % 27); t /= 27;
+    const int64_t v = t;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H); t /= H;
+    const int d = (int)(t % D);
+    const int b = (int)(t / D);
+    const int dd = d + tap / 9 - 1, hh = h + (tap / 3) % 3 - 1, ww = w + tap % 3 - 1;
+    V<T, VEC> val;
+    if (dd >= 0 && dd < D && hh >= 0 && hh < H && ww >= 0 && ww < W) val.load(src + ((((int64_t)b * D + dd) * H + hh) * W + ww) * lds + c);
+    else {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) val.v[k] = 0.f;
+    }
+    val.store(dst + v * ldd + (int64_t)tap * C + c);
+  }
+}
+
+template <class T, int VEC>
+__global__ void __launch_bounds__(256) col2im3_kernel(const T* col, int64_t ldc, T* dst, int64_t ldd, int B, int D, int H, int W, int C) {
+  const int cv = C / VEC;
+  const int64_t total = (int64_t)B * D * H * W * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * VEC;
+    int64_t t = i / cv;
+    const int64_t v = t;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H); t /= H;
+    const int d = (int)(t % D);
+    const int b = (int)(t / D);
+    V<T, VEC> acc;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc.v[k] = 0.f;
+    for (int tap = 0; tap < 27; ++tap) {
+      // col[u][tap] holds src[u + off(tap)]  =>  dst[v] += col[v - off(tap)][tap]
+      const int dd = d - (tap / 9 - 1), hh = h - ((tap / 3) % 3 - 1), ww = w - (tap % 3 - 1);
+      if (dd >= 0 && dd < D && hh >= 0 && hh < H && ww >= 0 && ww < W) {
+        V<T, VEC> val;
+        val.load(col + ((((int64_t)b * D + dd) * H + hh) * W + ww) * ldc + (int64_t)tap * C + c);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc.v[k] += val.v[k];
+      }
+    }
+    acc.store(dst + v * ldd + c);
+  }
+}
+
+// ----------------------------------------------------------------------------- column sums
+template <class T>
+__global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, int64_t ldx, int64_t rows, int C, float* __restrict__ out, int rows_per_block) {
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += to_f32(x[r * ldx + c]);
+    atomicAdd(out + c, s);
+  }
+}
+// many rows, few channels: thread (ty, c) strides rows, LDS reduce
+template <class T>
+__global__ void __launch_bounds__(256) colsum_tall_kernel(const T* __restrict__ x, int64_t ldx, int64_t rows, int C, float* __restrict__ out, int rows_per_block) {
+  __shared__ float red[256];
+  const int tx_n = C, ty_n = 256 / C;
+  const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float s = 0.f;
+  if (ty < ty_n)
+    for (int64_t r = r0 + ty; r < r1; r += ty_n) s += to_f32(x[r * ldx + tx]);
+  red[threadIdx.x] = (ty < ty_n) ? s : 0.f;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float a = 0.f;
+    for (int y = 0; y < ty_n; ++y) a += red[y * tx_n + threadIdx.x];
+    atomicAdd(out + threadIdx.x, a);
+  }
+}
+
+}  // namespace miseg
+
+using namespace miseg;
+
+#define DT(p, ...)                                                          \
+  return dispatch_dtype((p)->dtype, [&](auto* tag) -> int {                 \
+    typedef typename std::remove_pointer<decltype(tag)>::type T;            \
+    __VA_ARGS__;                                                            \
+    return MISEG_OK;                                                        \
+  })
+
+extern "C" int miseg_add(const miseg_add_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->a && p->b && p->y && p->rows > 0 && p->C > 0, MISEG_E_BADARG, "add: bad args");
+  DT(p, {
+    constexpr int N = Vec16<T>::N;
+    const bool vec = p->C % N == 0 && p->lda % N == 0 && p->ldb % N == 0 && p->ldy % N == 0 && al16(p->a) && al16(p->b) && al16(p->y);
+    if (vec) add_kernel<T, N><<<ew_grid(p->rows * (p->C / N)), 256, 0, s>>>((const T*)p->a, p->lda, (const T*)p->b, p->ldb, (T*)p->y, p->ldy, p->rows, p->C / N);
+    else add_kernel<T, 1><<<ew_grid(p->rows * p->C), 256, 0, s>>>((const T*)p->a, p->lda, (const T*)p->b, p->ldb, (T*)p->y, p->ldy, p->rows, p->C);
+    MISEG_LAUNCH_CHECK("add");
+  });
+}
+
+extern "C" int miseg_copy2d(const miseg_copy2d_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->src && p->dst && p->rows > 0 && p->C > 0, MISEG_E_BADARG, "copy2d: bad args");
+  const int g = ew_grid(p->rows * p->C);
+  if (p->sdtype == MISEG_F32 && p->ddtype == MISEG_F32) copy2d_kernel<float, float><<<g, 256, 0, s>>>((const float*)p->src, p->lds, (float*)p->dst, p->ldd, p->rows, p->C);
+  else if (p->sdtype == MISEG_F32 && p->ddtype == MISEG_BF16) copy2d_kernel<float, bf16><<<g, 256, 0, s>>>((const float*)p->src, p->lds, (bf16*)p->dst, p->ldd, p->rows, p->C);
+  else if (p->sdtype == MISEG_BF16 && p->ddtype == MISEG_F32) copy2d_kernel<bf16, float><<<g, 256, 0, s>>>((const bf16*)p->src, p->lds, (float*)p->dst, p->ldd, p->rows, p->C);
+  else if (p->sdtype == MISEG_BF16 && p->ddtype == MISEG_BF16) copy2d_kernel<bf16, bf16><<<g, 256, 0, s>>>((const bf16*)p->src, p->lds, (bf16*)p->dst, p->ldd, p->rows, p->C);
+  else return set_error(MISEG_E_BADARG, "copy2d: dtypes %d -> %d", p->sdtype, p->ddtype);
+  MISEG_LAUNCH_CHECK("copy2d");
+  return MISEG_OK;
+}
+
+extern "C" int miseg_cast_matrix(const miseg_cast_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->src && p->dst && p->R > 0 && p->C > 0, MISEG_E_BADARG, "cast_matrix: bad args");
+  DT(p, {
+    if (p->transpose) cast_transpose_kernel<T><<<dim3(cdiv(p->C, 32), cdiv(p->R, 32)), 256, 0, s>>>(p->src, (T*)p->dst, p->R, p->C);
+    else cast_kernel<T><<<ew_grid((int64_t)p->R * p->C), 256, 0, s>>>(p->src, (T*)p->dst, (int64_t)p->R * p->C);
+    MISEG_LAUNCH_CHECK("cast_matrix");
+  });
+}
+
+extern "C" int miseg_gelu_bwd(const miseg_gelu_bwd_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->dy && p->x && p->dx && p->rows > 0 && p->C > 0, MISEG_E_BADARG, "gelu_bwd: bad args");
+  DT(p, {
+    constexpr int N = Vec16<T>::N;
+    const bool vec = p->C % N == 0 && p->lddy % N == 0 && p->ldx % N == 0 && p->lddx % N == 0 && al16(p->dy) && al16(p->x) && al16(p->dx);
+    if (vec) gelu_bwd_kernel<T, N><<<ew_grid(p->rows * (p->C / N)), 256, 0, s>>>((const T*)p->dy, p->lddy, (const T*)p->x, p->ldx, (T*)p->dx, p->lddx, p->rows, p->C / N);
+    else gelu_bwd_kernel<T, 1><<<ew_grid(p->rows * p->C), 256, 0, s>>>((const T*)p->dy, p->lddy, (const T*)p->x, p->ldx, (T*)p->dx, p->lddx, p->rows, p->C);
+    MISEG_LAUNCH_CHECK("gelu_bwd");
+  });
+}
+
+extern "C" int miseg_gelu_fwd(const miseg_gelu_fwd_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->x && p->y && p->rows > 0 && p->C > 0, MISEG_E_BADARG, "gelu_fwd: bad args");
+  DT(p, {
+    constexpr int N = Vec16<T>::N;
+    const bool vec = p->C % N == 0 && p->ldx % N == 0 && p->ldy % N == 0 && al16(p->x) && al16(p->y);
+    if (vec) gelu_fwd_kernel<T, N><<<ew_grid(p->rows * (p->C / N)), 256, 0, s>>>((const T*)p->x, p->ldx, (T*)p->y, p->ldy, p->rows, p->C / N);
+    else gelu_fwd_kernel<T, 1><<<ew_grid(p->rows * p->C), 256, 0, s>>>((const T*)p->x, p->ldx, (T*)p->y, p->ldy, p->rows, p->C);
+    MISEG_LAUNCH_CHECK("gelu_fwd");
+  });
+}
+
+static int s2c_common(const miseg_s2c_params* p, hipStream_t s, bool gather) {
+  MISEG_REQUIRE(p && p->src && p->dst && p->B > 0 && p->D > 0 && p->H > 0 && p->W > 0 && p->C > 0, MISEG_E_BADARG, "space/channel: bad args");
+  Off8 off;
+  for (int i = 0; i < 24; ++i) {
+    off.o[i] = p->offsets[i];
+    MISEG_REQUIRE(off.o[i] == 0 || off.o[i] == 1, MISEG_E_BADARG, "space/channel: offsets must be 0/1");
+  }
+  DT(p, {
+    constexpr int N = Vec16<T>::N;
+    const bool vec = p->C % N == 0 && p->lds % N == 0 && p->ldd % N == 0 && al16(p->src) && al16(p->dst);
+    const int D2 = (p->D + 1) / 2, H2 = (p->H + 1) / 2, W2 = (p->W + 1) / 2;
+    if (gather) {
+      const int64_t tot = (int64_t)p->B * D2 * H2 * W2 * 8;
+      if (vec) s2c_kernel<T, N><<<ew_grid(tot * (p->C / N)), 256, 0, s>>>((const T*)p->src, p->lds, (T*)p->dst, p->ldd, p->B, p->D, p->H, p->W, p->C, off);
+      else s2c_kernel<T, 1><<<ew_grid(tot * p->C), 256, 0, s>>>((const T*)p->src, p->lds, (T*)p->dst, p->ldd, p->B, p->D, p->H, p->W, p->C, off);
+    } else {
+      const int64_t tot = (int64_t)p->B * p->D * p->H * p->W;
+      if (vec) c2s_kernel<T, N><<<ew_grid(tot * (p->C / N)), 256, 0, s>>>((const T*)p->src, p->lds, (T*)p->dst, p->ldd, p->B, p->D, p->H, p->W, p->C, off);
+      else c2s_kernel<T, 1><<<ew_grid(tot * p->C), 256, 0, s>>>((const T*)p->src, p->lds, (T*)p->dst, p->ldd, p->B, p->D, p->H, p->W, p->C, off);
+    }
+    MISEG_LAUNCH_CHECK("space/channel");
+  });
+}
+extern "C" int miseg_space_to_channel(const miseg_s2c_params* p, miseg_stream_t s) { return s2c_common(p, (hipStream_t)s, true); }
+extern "C" int miseg_channel_to_space(const miseg_s2c_params* p, miseg_stream_t s) { return s2c_common(p, (hipStream_t)s, false); }
+
+extern "C" int miseg_patch_embed_fwd(const miseg_patch_embed_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->x && p->y && p->w, MISEG_E_BADARG, "patch_embed_fwd: null pointer");
+  MISEG_REQUIRE(p->D % 2 == 0 && p->H % 2 == 0 && p->W % 2 == 0, MISEG_E_BADARG, "patch_embed_fwd: grid %dx%dx%d must be even (pad on host)", p->D, p->H, p->W);
+  MISEG_REQUIRE(p->Cin * 8 * p->Cout <= 12000, MISEG_E_UNSUPPORTED, "patch_embed_fwd: Cin*8*Cout too large");
+  DT(p, {
+    const int64_t tot = (int64_t)p->B * (p->D / 2) * (p->H / 2) * (p->W / 2) * ((p->Cout + 7) / 8);
+    size_t sh = ((size_t)p->Cin * 8 * p->Cout + p->Cout) * sizeof(float);
+    patch_embed_fwd_kernel<T><<<ew_grid(tot), 256, sh, s>>>(p->x, (T*)p->y, p->ldy, p->w, p->bias, p->B, p->Cin, p->D, p->H, p->W, p->Cout);
+    MISEG_LAUNCH_CHECK("patch_embed_fwd");
+  });
+}
+
+extern "C" int miseg_patch_embed_bwd(const miseg_patch_embed_bwd_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->x && p->dy && p->dw, MISEG_E_BADARG, "patch_embed_bwd: null pointer");
+  MISEG_REQUIRE(p->Cout * (p->Cin * 8 + 1) <= 2048, MISEG_E_UNSUPPORTED, "patch_embed_bwd: Cout*(8Cin+1) > 2048");
+  DT(p, {
+    const int64_t nv = (int64_t)p->B * (p->D / 2) * (p->H / 2) * (p->W / 2);
+    const int vpb = 1024;
+    size_t sh = ((size_t)64 * (p->Cin * 8 + 1) + 64 * p->Cout) * sizeof(float);
+    patch_embed_bwd_kernel<T><<<cdiv(nv, vpb), 256, sh, s>>>(p->x, (const T*)p->dy, p->lddy, p->dw, p->dbias, p->B, p->Cin, p->D, p->H, p->W, p->Cout, vpb);
+    MISEG_LAUNCH_CHECK("patch_embed_bwd");
+  });
+}
+
+extern "C" int miseg_conv3_thin_fwd(const miseg_conv3_thin_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->x && p->y && p->w, MISEG_E_BADARG, "conv3_thin_fwd: null pointer");
+  MISEG_REQUIRE(p->Cin >= 1 && p->Cin <= 4 && p->Cin * 27 * p->Cout <= 15000, MISEG_E_UNSUPPORTED, "conv3_thin_fwd: Cin %d Cout %d", p->Cin, p->Cout);
+  DT(p, {
+    const int64_t nv = (int64_t)p->B * p->D * p->H * p->W;
+    size_t sh = (size_t)p->Cin * 27 * p->Cout * sizeof(float);
+    conv3_thin_fwd_kernel<T><<<ew_grid(nv), 256, sh, s>>>(p->x, (T*)p->y, p->ldy, p->w, p->B, p->Cin, p->D, p->H, p->W, p->Cout);
+    MISEG_LAUNCH_CHECK("conv3_thin_fwd");
+  });
+}
+
+extern "C" int miseg_conv3_thin_wgrad(const miseg_conv3_thin_wgrad_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->x && p->dy && p->dw, MISEG_E_BADARG, "conv3_thin_wgrad: null pointer");
+  MISEG_REQUIRE(p->Cin >= 1 && p->Cin <= 4 && p->Cout <= 64, MISEG_E_UNSUPPORTED, "conv3_thin_wgrad: Cin %d Cout %d", p->Cin, p->Cout);
+  DT(p, {
+    const int nb = p->B * cdiv(p->D, 8) * cdiv(p->H, 8) * cdiv(p->W, 8);
+    size_t sh = ((size_t)1000 + 512 * p->Cout) * sizeof(float);
+    hipFuncSetAttribute((const void*)conv3_thin_wgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    conv3_thin_wgrad_kernel<T><<<nb, 256, sh, s>>>(p->x, (const T*)p->dy, p->lddy, p->dw, p->B, p->Cin, p->D, p->H, p->W, p->Cout);
+    MISEG_LAUNCH_CHECK("conv3_thin_wgrad");
+  });
+}
+
+extern "C" int miseg_head_fwd(const miseg_head_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->x && p->y && p->w, MISEG_E_BADARG, "head_fwd: null pointer");
+  MISEG_REQUIRE(p->Cout <= 16 && p->Cin * p->Cout <= 8192, MISEG_E_UNSUPPORTED, "head_fwd: Cout %d (max 16)", p->Cout);
+  DT(p, {
+    size_t sh = ((size_t)p->Cin * p->Cout + p->Cout) * sizeof(float);
+    head_fwd_kernel<T><<<ew_grid((int64_t)p->B * p->S), 256, sh, s>>>((const T*)p->x, p->ldx, p->y, p->w, p->bias, p->B, p->S, p->Cin, p->Cout);
+    MISEG_LAUNCH_CHECK("head_fwd");
+  });
+}
+
+extern "C" int miseg_head_bwd(const miseg_head_bwd_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->x && p->dy && p->w, MISEG_E_BADARG, "head_bwd: null pointer");
+  MISEG_REQUIRE(p->Cout <= 16 && p->Cout * (p->Cin + 1) <= 1024, MISEG_E_UNSUPPORTED, "head_bwd: Cout %d Cin %d", p->Cout, p->Cin);
+  DT(p, {
+    const int64_t nv = (int64_t)p->B * p->S;
+    if (p->dx) {
+      size_t sh = (size_t)p->Cin * p->Cout * sizeof(float);
+      head_bwd_dx_kernel<T><<<ew_grid(nv), 256, sh, s>>>(p->dy, (T*)p->dx, p->lddx, p->w, p->B, p->S, p->Cin, p->Cout);
+    }
+    if (p->dw) {
+      const int vpb = 2048;
+      size_t sh = ((size_t)64 * (p->Cin + 1) + (size_t)p->Cout * 64) * sizeof(float);
+      head_bwd_dw_kernel<T><<<cdiv(nv, vpb), 256, sh, s>>>((const T*)p->x, p->ldx, p->dy, p->dw, p->dbias, p->B, p->S, p->Cin, p->Cout, vpb);
+    }
+    MISEG_LAUNCH_CHECK("head_bwd");
+  });
+}
+
+static int im2col_common(const miseg_im2col3_params* p, hipStream_t s, bool fwd) {
+  MISEG_REQUIRE(p && p->src && p->dst && p->B > 0 && p->C > 0, MISEG_E_BADARG, "im2col3: bad args");
+  DT(p, {
+    constexpr int N = Vec16<T>::N;
+    const bool vec = p->C % N == 0 && p->lds % N == 0 && p->ldd % N == 0 && al16(p->src) && al16(p->dst);
+    const int64_t nv = (int64_t)p->B * p->D * p->H * p->W;
+    if (fwd) {
+      if (vec) im2col3_kernel<T, N><<<ew_grid(nv * 27 * (p->C / N)), 256, 0, s>>>((const T*)p->src, p->lds, (T*)p->dst, p->ldd, p->B, p->D, p->H, p->W, p->C);
+      else im2col3_kernel<T, 1><<<ew_grid(nv * 27 * p->C), 256, 0, s>>>((const T*)p->src, p->lds, (T*)p->dst, p->ldd, p->B, p->D, p->H, p->W, p->C);
+    } else {
+      if (vec) col2im3_kernel<T, N><<<ew_grid(nv * (p->C / N)), 256, 0, s>>>((const T*)p->src, p->lds, (T*)p->dst, p->ldd, p->B, p->D, p->H, p->W, p->C);
+      else col2im3_kernel<T, 1><<<ew_grid(nv * p->C), 256, 0, s>>>((const T*)p->src, p->lds, (T*)p->dst, p->ldd, p->B, p->D, p->H, p->W, p->C);
+    }
+    MISEG_LAUNCH_CHECK("im2col3");
+  });
+}
+extern "C" int miseg_im2col3(const miseg_im2col3_params* p, miseg_stream_t s) { return im2col_common(p, (hipStream_t)s, true); }
+extern "C" int miseg_col2im3(const miseg_im2col3_params* p, miseg_stream_t s) { return im2col_common(p, (hipStream_t)s, false); }
+
+extern "C" int miseg_colsum(const miseg_colsum_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->x && p->out && p->rows > 0 && p->C > 0, MISEG_E_BADARG, "colsum: bad args");
+  if (!p->accumulate) {
+    hipError_t e = hipMemsetAsync(p->out, 0, (size_t)p->C * sizeof(float), s);
+    MISEG_REQUIRE(e == hipSuccess, MISEG_E_LAUNCH, "colsum: memset failed");
+  }
+  DT(p, {
+    if (p->C <= 128) {
+      const int rpb = 4096;
+      colsum_tall_kernel<T><<<cdiv(p->rows, rpb), 256, 0, s>>>((const T*)p->x, p->ldx, p->rows, p->C, p->out, rpb);
+    } else {
+      const int rpb = 64;
+      colsum_kernel<T><<<cdiv(p->rows, rpb), 256, 0, s>>>((const T*)p->x, p->ldx, p->rows, p->C, p->out, rpb);
+    }
+    MISEG_LAUNCH_CHECK("colsum");
+  });
+}
+
+extern "C" int miseg_fill32(void* dst, uint32_t value, size_t n, miseg_stream_t s_) {
+  MISEG_REQUIRE(dst || n == 0, MISEG_E_BADARG, "fill32: null pointer");
+  if (n == 0) return MISEG_OK;
+  hipError_t e = hipMemsetD32Async((hipDeviceptr_t)dst, (int)value, n, (hipStream_t)s_);
+  MISEG_REQUIRE(e == hipSuccess, MISEG_E_LAUNCH, "fill32: %s", hipGetErrorString(e));
+  return MISEG_OK;
+}

@@ -1,0 +1,379 @@
+"""torch.autograd glue over the C-ABI kernels.  Every forward AND backward arithmetic op below is a HIP kernel
+from csrc/ (see hip/ops.py); torch supplies tensors, the caching allocator, streams and the autograd tape only.
+
+Layout contract: activations are channels-last ([B, D, H, W, C] or [B, L, C]) in the compute dtype (float32 for the
+parity mode, bfloat16 for throughput); parameters and their gradients are float32.
+"""
+import torch
+from torch.autograd import Function
+
+from . import lib as L
+from . import ops
+
+STD_OFFSETS = tuple((a, b, c) for a in range(2) for b in range(2) for c in range(2))
+"""(dz,dy,dx) of block j = 4a+2b+c: ConvTranspose3d k2 s2 taps and PatchMergingV2's itertools.product order."""
+MERGE_V1_OFFSETS = ((0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (0, 1, 0), (0, 0, 1), (1, 1, 1))
+"""reference networks/blocks/patch_merging.py:120-127 (v0.9 PatchMerging; slots 5,6 duplicate 2,3)."""
+
+
+def _rv(t):
+    """make a gradient usable as a channels-last row view (autograd may hand us expanded / permuted tensors)."""
+    if t is None:
+        return None
+    try:
+        ops.rows(t)
+        return t
+    except ValueError:
+        return t.contiguous()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class _Fork(Function):
+    """y1 = y2 = x with the gradient sum done by our add kernel instead of the autograd engine's."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None:
+            return g2
+        if g2 is None:
+            return g1
+        return ops.add(_rv(g1), _rv(g2))
+
+
+def fork(x):
+    return _Fork.apply(x)
+
+
+class _Add(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.add(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class _InstNorm(Function):
+    """(conditional) instance norm over all rows of each sample, + optional residual, + optional LeakyReLU.
+    reference: networks/norms/conditional_instance_norm.py:59-68, dynunet_block.py:100-126."""
+
+    @staticmethod
+    def forward(ctx, x, res, styles_dev, styles_host, num_styles, affine, act, slope, eps, *params):
+        B = x.shape[0]
+        S = ops.rows(x)[1] // B
+        mean, rstd = ops.instnorm_stats(x, B, S, eps)
+        gammas = list(params[0::2]) if affine else None
+        betas = list(params[1::2]) if affine else None
+        y = ops.instnorm_apply(x, B, S, mean, rstd, styles_dev, gammas, betas, res=res, act=act, slope=slope)
+        ctx.meta = (B, S, styles_host, num_styles, affine, act, slope, res is not None)
+        ctx.save_for_backward(x, y if act != L.ACT_NONE else None, mean, rstd, styles_dev, *(gammas or []))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, S, styles_host, num_styles, affine, act, slope, has_res = ctx.meta
+        x, y, mean, rstd, styles_dev, *gammas = ctx.saved_tensors
+        dy = _rv(dy)
+        C = x.shape[-1]
+        present = sorted(set(styles_host)) if styles_host is not None else [0]
+        dgam = dbet = None
+        if affine:
+            buf = ops.zeros_f32((num_styles, 2, C), x.device)
+            # parameters of a style absent from the batch get no gradient (reference: grad is None)
+            dgam = [buf[s, 0] if s in present else None for s in range(num_styles)]
+            dbet = [buf[s, 1] if s in present else None for s in range(num_styles)]
+        dx, dres = ops.instnorm_bwd(dy, y, x, B, S, mean, rstd, styles_dev, gammas if affine else None, dgam, dbet, act=act, slope=slope,
+                                    want_dres=has_res and ctx.needs_input_grad[1])
+        pg = []
+        if affine:
+            for s in range(num_styles):
+                pg += [dgam[s], dbet[s]]
+        return (dx, dres, None, None, None, None, None, None, None, *pg)
+
+
+def instance_norm(x, params=None, styles_dev=None, styles_host=None, res=None, act=L.ACT_NONE, slope=0.01, eps=1e-5):
+    """params: None (no affine) | [(gamma, beta)] (plain) | [(g0,b0),(g1,b1),...] (conditional, one pair per style)."""
+    flat = []
+    n = 1
+    if params is not None:
+        n = len(params)
+        for g, b in params:
+            flat += [g, b]
+    return _InstNorm.apply(x, res, styles_dev, styles_host, n, params is not None, act, slope, eps, *flat)
+
+
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, eps)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.has_beta = beta is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dy = _rv(dy)
+        C = x.shape[-1]
+        dg = ops.zeros_f32((C,), x.device) if gamma is not None else None
+        db = ops.zeros_f32((C,), x.device) if ctx.has_beta else None
+        dx = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dg, db)
+        return dx, dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return _LayerNorm.apply(x, gamma, beta, eps)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class _Linear(Function):
+    """y = x W^T + b on the matrix cores (NT GEMM); dX via the transposed pack, dW via the TN GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        w = ops.cast_matrix(weight, x.dtype)
+        y = ops.gemm_nt(x, w, bias)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _rv(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = ops.cast_matrix(weight, dy.dtype, transpose=True)      # [K, N]
+            dx = ops.gemm_nt(dy, wt)
+        if ctx.needs_input_grad[1]:
+            dw = ops.gemm_tn(dy, x).view(weight.shape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(dy)
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    return _Linear.apply(x, weight, bias)
+
+
+class _Gelu(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.gelu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.gelu_bwd(_rv(dy), x)
+
+
+def gelu(x):
+    return _Gelu.apply(x)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class _Conv3(Function):
+    """3x3x3 / s1 / p1 / no bias (dynunet_block.py:295-326) as implicit GEMM; dgrad = same kernel, mirrored pack."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        need_dx = ctx.needs_input_grad[0]
+        fwdp, bwdp = ops.pack_conv3(weight, x.dtype, True, need_dx)
+        y = ops.conv3_fwd(x, fwdp, weight.shape[0])
+        ctx.save_for_backward(x, bwdp)
+        ctx.wshape = weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, bwdp = ctx.saved_tensors
+        dy = _rv(dy)
+        dx = ops.conv3_fwd(dy, bwdp, ctx.wshape[1]) if ctx.needs_input_grad[0] else None
+        dw = ops.conv3_wgrad(x, dy) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+def conv3(x, weight):
+    return _Conv3.apply(x, weight)
+
+
+class _Conv3Thin(Function):
+    """stem conv straight from the NCDHW fp32 network input (Cin <= 4)."""
+
+    @staticmethod
+    def forward(ctx, x_ncdhw, weight, dtype):
+        ctx.save_for_backward(x_ncdhw, weight)
+        return ops.conv3_thin_fwd(x_ncdhw, weight, dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dw = ops.conv3_thin_wgrad(x, _rv(dy), ops.zeros_f32(weight.shape, x.device))
+        return None, dw, None
+
+
+def conv3_thin(x_ncdhw, weight, dtype):
+    return _Conv3Thin.apply(x_ncdhw, weight, dtype)
+
+
+class _Conv1(Function):
+    """1x1x1 conv, no bias (ResBlock shortcut dynunet_block.py:87-97) == Linear over the channel dim."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        w = ops.cast_matrix(weight, x.dtype)
+        ctx.save_for_backward(x, weight)
+        return ops.gemm_nt(x, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _rv(dy)
+        dx = ops.gemm_nt(dy, ops.cast_matrix(weight, dy.dtype, transpose=True)) if ctx.needs_input_grad[0] else None
+        dw = ops.gemm_tn(dy, x).view(weight.shape) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+def conv1(x, weight):
+    return _Conv1.apply(x, weight)
+
+
+class _UpCat(Function):
+    """ConvTranspose3d(k2, s2, no bias) followed by cat([up, skip], C)  (unetr_block.py:80-85): one GEMM
+    [voxels, Cin] x [Cin, 8*Cout], a 2x2x2 scatter straight into the first half of the concat buffer, and a strided
+    copy of the skip into the second half.  skip=None gives the bare transposed conv (UnetrPrUpBlock)."""
+
+    @staticmethod
+    def forward(ctx, x, skip, weight):
+        Cin, Cout = weight.shape[0], weight.shape[1]
+        B, d, h, w = x.shape[0], x.shape[1], x.shape[2], x.shape[3]
+        dev = x.device
+        wf32 = torch.empty(8 * Cout, Cin, dtype=torch.float32, device=dev)
+        ops.permute3(weight, wf32, (8, Cout, Cin), (1, 8, Cout * 8))                 # [(j,co)][ci]
+        wf = ops.cast_matrix(wf32, x.dtype)
+        y8 = ops.gemm_nt(x, wf)
+        width = 2 * Cout if skip is not None else Cout
+        cat = torch.empty(B, 2 * d, 2 * h, 2 * w, width, dtype=x.dtype, device=dev)
+        ops.channel_to_space(y8, STD_OFFSETS, (B, 2 * d, 2 * h, 2 * w, Cout), out=cat[..., :Cout])
+        if skip is not None:
+            ops.copy2d(skip, cat[..., Cout:])
+        ctx.save_for_backward(x, weight)
+        ctx.has_skip = skip is not None
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        x, weight = ctx.saved_tensors
+        Cin, Cout = weight.shape[0], weight.shape[1]
+        dcat = _rv(dcat)
+        dskip = dcat[..., Cout:] if ctx.has_skip and ctx.needs_input_grad[1] else None
+        dy8 = ops.space_to_channel(dcat[..., :Cout], STD_OFFSETS)                     # [B,d,h,w,8*Cout]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wb32 = torch.empty(Cin, 8 * Cout, dtype=torch.float32, device=x.device)
+            ops.permute3(weight, wb32, (Cin, 8, Cout), (Cout * 8, 1, 8))              # [ci][(j,co)]
+            dx = ops.gemm_nt(dy8, ops.cast_matrix(wb32, x.dtype))
+        if ctx.needs_input_grad[2]:
+            dwf = ops.gemm_tn(dy8, x)                                                 # [(j,co)][ci]
+            dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+            ops.permute3(dwf, dw, (Cin, Cout, 8), (1, Cin, Cout * Cin))
+        return dx, dskip, dw
+
+
+def upconv_cat(x, skip, weight):
+    return _UpCat.apply(x, skip, weight)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class _S2C(Function):
+    @staticmethod
+    def forward(ctx, x, offsets):
+        ctx.offsets, ctx.shape = offsets, tuple(x.shape)
+        return ops.space_to_channel(x, offsets)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.channel_to_space(_rv(g), ctx.offsets, ctx.shape), None
+
+
+def space_to_channel(x, offsets):
+    return _S2C.apply(x, offsets)
+
+
+class _WinAttn(Function):
+    """fused pad/roll/partition + softmax(q k^T * scale + bias + mask) v + reverse/roll/crop
+    (window_attention.py:99-119, swin_transformer_block.py:116-169)."""
+
+    @staticmethod
+    def forward(ctx, qkv, qkv_bias, table, heads, window, shift, tw, scale):
+        out, lse = ops.winattn_fwd(qkv, qkv_bias, table, heads, window, shift, tw, scale)
+        ctx.save_for_backward(qkv, out, lse, qkv_bias, table)
+        ctx.meta = (heads, window, shift, tw, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse, qkv_bias, table = ctx.saved_tensors
+        heads, window, shift, tw, scale = ctx.meta
+        dqb = ops.zeros_f32(qkv_bias.shape, qkv.device) if qkv_bias is not None and ctx.needs_input_grad[1] else None
+        dtab = ops.zeros_f32(table.shape, qkv.device) if table is not None and ctx.needs_input_grad[2] else None
+        dqkv = ops.winattn_bwd(qkv, out, lse, _rv(dout), qkv_bias, table, heads, window, shift, tw, scale, dqb, dtab)
+        return dqkv, dqb, dtab, None, None, None, None, None
+
+
+def window_attention(qkv, qkv_bias, table, heads, window, shift, tw, scale):
+    return _WinAttn.apply(qkv, qkv_bias, table, heads, tuple(window), tuple(shift), tw, scale)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class _PatchEmbed(Function):
+    @staticmethod
+    def forward(ctx, x_ncdhw, weight, bias, dtype):
+        ctx.save_for_backward(x_ncdhw, weight, bias)
+        return ops.patch_embed_fwd(x_ncdhw, weight, bias, dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias = ctx.saved_tensors
+        dw = ops.zeros_f32(weight.shape, x.device)
+        db = ops.zeros_f32(bias.shape, x.device) if bias is not None else None
+        ops.patch_embed_bwd(x, _rv(dy), dw, db)
+        return None, dw, db, None
+
+
+def patch_embed(x_ncdhw, weight, bias, dtype):
+    return _PatchEmbed.apply(x_ncdhw, weight, bias, dtype)
+
+
+class _Head(Function):
+    """UnetOutBlock: 1x1x1 conv + bias, channels-last in -> NCDHW fp32 logits out (dynunet_block.py:273-292)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return ops.head_fwd(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        dw = ops.zeros_f32(weight.shape, x.device)
+        db = ops.zeros_f32((weight.shape[0],), x.device) if ctx.has_bias else None
+        dx = ops.head_bwd(x, dy, weight, dw, db, want_dx=ctx.needs_input_grad[0])
+        return dx, dw, db
+
+
+def head(x, weight, bias):
+    return _Head.apply(x, weight, bias)

@@ -1,0 +1,147 @@
+"""ctypes binding of csrc/libmiseg_hip.so (the C ABI declared in include/miseg_hip.h).
+
+The product path has NO fallback: if the shared object is missing or a symbol is absent, importing an op raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(HERE), "csrc", "libmiseg_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_LEAKY, ACT_GELU, ACT_PRELU = 0, 1, 2, 3
+MAX_STYLES = 4
+
+vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+fp4 = vp * MAX_STYLES
+
+
+class _S(C.Structure):
+    pass
+
+
+def _struct(name, fields):
+    return type(name, (C.Structure,), {"_fields_": fields})
+
+
+InstnormStats = _struct("InstnormStats", [("x", vp), ("ldx", i64), ("B", i32), ("S", i32), ("C", i32), ("dtype", i32),
+                                          ("eps", f32), ("mean", vp), ("rstd", vp), ("workspace", vp)])
+InstnormApply = _struct("InstnormApply", [("x", vp), ("ldx", i64), ("res", vp), ("ldres", i64), ("y", vp), ("ldy", i64),
+                                          ("B", i32), ("S", i32), ("C", i32), ("dtype", i32), ("mean", vp), ("rstd", vp),
+                                          ("styles", vp), ("num_styles", i32), ("gamma", fp4), ("beta", fp4),
+                                          ("act", i32), ("slope", f32)])
+InstnormBwd = _struct("InstnormBwd", [("dy", vp), ("lddy", i64), ("y", vp), ("ldy", i64), ("x", vp), ("ldx", i64),
+                                      ("dx", vp), ("lddx", i64), ("dres", vp), ("lddres", i64),
+                                      ("B", i32), ("S", i32), ("C", i32), ("dtype", i32), ("mean", vp), ("rstd", vp),
+                                      ("styles", vp), ("num_styles", i32), ("gamma", fp4), ("dgamma", fp4), ("dbeta", fp4),
+                                      ("act", i32), ("slope", f32), ("workspace", vp)])
+LayernormFwd = _struct("LayernormFwd", [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32),
+                                        ("dtype", i32), ("eps", f32), ("gamma", vp), ("beta", vp), ("mean", vp), ("rstd", vp)])
+LayernormBwd = _struct("LayernormBwd", [("dy", vp), ("lddy", i64), ("x", vp), ("ldx", i64), ("dx", vp), ("lddx", i64),
+                                        ("rows", i64), ("C", i32), ("dtype", i32), ("gamma", vp), ("mean", vp), ("rstd", vp),
+                                        ("dgamma", vp), ("dbeta", vp)])
+Gemm = _struct("Gemm", [("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32),
+                        ("K", i32), ("ta", i32), ("tb", i32), ("dtype", i32), ("out_dtype", i32), ("bias", vp), ("act", i32),
+                        ("accumulate", i32), ("split_k", i32)])
+Colsum = _struct("Colsum", [("x", vp), ("ldx", i64), ("rows", i64), ("C", i32), ("dtype", i32), ("out", vp), ("accumulate", i32)])
+Conv3 = _struct("Conv3", [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("wpk", vp), ("B", i32), ("D", i32), ("H", i32),
+                          ("W", i32), ("Cin", i32), ("Cout", i32), ("dtype", i32)])
+PackConv3 = _struct("PackConv3", [("w", vp), ("fwd_pack", vp), ("bwd_pack", vp), ("Cin", i32), ("Cout", i32), ("dtype", i32)])
+Conv3Wgrad = _struct("Conv3Wgrad", [("x", vp), ("ldx", i64), ("dy", vp), ("lddy", i64), ("dw", vp), ("B", i32), ("D", i32),
+                                    ("H", i32), ("W", i32), ("Cin", i32), ("Cout", i32), ("dtype", i32), ("accumulate", i32),
+                                    ("workspace", vp)])
+Winattn = _struct("Winattn", [("qkv", vp), ("ldq", i64), ("out", vp), ("ldo", i64), ("qkv_bias", vp), ("bias_table", vp),
+                              ("lse", vp), ("B", i32), ("D", i32), ("H", i32), ("W", i32), ("C", i32), ("heads", i32),
+                              ("dtype", i32), ("wd", i32), ("wh", i32), ("ww", i32), ("sd", i32), ("sh", i32), ("sw", i32),
+                              ("tw", i32), ("scale", f32)])
+WinattnBwd = _struct("WinattnBwd", [("f", Winattn), ("dout", vp), ("lddo", i64), ("dqkv", vp), ("lddq", i64),
+                                    ("dqkv_bias", vp), ("dbias_table", vp)])
+Add = _struct("Add", [("a", vp), ("lda", i64), ("b", vp), ("ldb", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
+Copy2d = _struct("Copy2d", [("src", vp), ("lds", i64), ("sdtype", i32), ("dst", vp), ("ldd", i64), ("ddtype", i32), ("rows", i64), ("C", i32)])
+Cast = _struct("Cast", [("src", vp), ("dst", vp), ("R", i32), ("C", i32), ("dtype", i32), ("transpose", i32)])
+GeluFwd = _struct("GeluFwd", [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
+GeluBwd = _struct("GeluBwd", [("dy", vp), ("lddy", i64), ("x", vp), ("ldx", i64), ("dx", vp), ("lddx", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
+S2C = _struct("S2C", [("src", vp), ("lds", i64), ("dst", vp), ("ldd", i64), ("B", i32), ("D", i32), ("H", i32), ("W", i32),
+                      ("C", i32), ("dtype", i32), ("offsets", C.c_int8 * 24)])
+PatchEmbed = _struct("PatchEmbed", [("x", vp), ("y", vp), ("ldy", i64), ("w", vp), ("bias", vp), ("B", i32), ("Cin", i32), ("D", i32),
+                                    ("H", i32), ("W", i32), ("Cout", i32), ("dtype", i32)])
+PatchEmbedBwd = _struct("PatchEmbedBwd", [("x", vp), ("dy", vp), ("lddy", i64), ("dw", vp), ("dbias", vp), ("B", i32), ("Cin", i32),
+                                          ("D", i32), ("H", i32), ("W", i32), ("Cout", i32), ("dtype", i32)])
+Conv3Thin = _struct("Conv3Thin", [("x", vp), ("y", vp), ("ldy", i64), ("w", vp), ("B", i32), ("Cin", i32), ("D", i32), ("H", i32),
+                                  ("W", i32), ("Cout", i32), ("dtype", i32)])
+Conv3ThinWgrad = _struct("Conv3ThinWgrad", [("x", vp), ("dy", vp), ("lddy", i64), ("dw", vp), ("B", i32), ("Cin", i32), ("D", i32),
+                                            ("H", i32), ("W", i32), ("Cout", i32), ("dtype", i32)])
+Head = _struct("Head", [("x", vp), ("ldx", i64), ("y", vp), ("w", vp), ("bias", vp), ("B", i32), ("S", i32), ("Cin", i32),
+                        ("Cout", i32), ("dtype", i32)])
+HeadBwd = _struct("HeadBwd", [("x", vp), ("ldx", i64), ("dy", vp), ("dx", vp), ("lddx", i64), ("w", vp), ("dw", vp), ("dbias", vp),
+                              ("B", i32), ("S", i32), ("Cin", i32), ("Cout", i32), ("dtype", i32)])
+Im2col3 = _struct("Im2col3", [("src", vp), ("lds", i64), ("dst", vp), ("ldd", i64), ("B", i32), ("D", i32), ("H", i32), ("W", i32),
+                              ("C", i32), ("dtype", i32)])
+
+# symbol -> (restype, argtypes); every prototype of include/miseg_hip.h appears here (checked by tests/test_abi.py)
+PROTOS = {
+    "miseg_abi_version": (i32, []),
+    "miseg_last_error": (C.c_char_p, []),
+    "miseg_device_arch": (i32, [C.c_char_p, C.c_size_t]),
+    "miseg_instnorm_workspace_bytes": (C.c_size_t, [i32, i32, i32]),
+    "miseg_instnorm_stats": (i32, [C.POINTER(InstnormStats), vp]),
+    "miseg_instnorm_apply": (i32, [C.POINTER(InstnormApply), vp]),
+    "miseg_instnorm_bwd": (i32, [C.POINTER(InstnormBwd), vp]),
+    "miseg_layernorm_fwd": (i32, [C.POINTER(LayernormFwd), vp]),
+    "miseg_layernorm_bwd": (i32, [C.POINTER(LayernormBwd), vp]),
+    "miseg_gemm": (i32, [C.POINTER(Gemm), vp]),
+    "miseg_permute3": (i32, [vp, vp, i32, i32, i32, i64, i64, i64, i32, vp]),
+    "miseg_colsum": (i32, [C.POINTER(Colsum), vp]),
+    "miseg_conv3_fwd": (i32, [C.POINTER(Conv3), vp]),
+    "miseg_pack_conv3_weight": (i32, [C.POINTER(PackConv3), vp]),
+    "miseg_conv3_wgrad_workspace_bytes": (C.c_size_t, [i32, i32, i32, i32, i32, i32]),
+    "miseg_conv3_wgrad": (i32, [C.POINTER(Conv3Wgrad), vp]),
+    "miseg_winattn_fwd": (i32, [C.POINTER(Winattn), vp]),
+    "miseg_winattn_bwd": (i32, [C.POINTER(WinattnBwd), vp]),
+    "miseg_add": (i32, [C.POINTER(Add), vp]),
+    "miseg_copy2d": (i32, [C.POINTER(Copy2d), vp]),
+    "miseg_cast_matrix": (i32, [C.POINTER(Cast), vp]),
+    "miseg_gelu_fwd": (i32, [C.POINTER(GeluFwd), vp]),
+    "miseg_gelu_bwd": (i32, [C.POINTER(GeluBwd), vp]),
+    "miseg_space_to_channel": (i32, [C.POINTER(S2C), vp]),
+    "miseg_channel_to_space": (i32, [C.POINTER(S2C), vp]),
+    "miseg_patch_embed_fwd": (i32, [C.POINTER(PatchEmbed), vp]),
+    "miseg_patch_embed_bwd": (i32, [C.POINTER(PatchEmbedBwd), vp]),
+    "miseg_conv3_thin_fwd": (i32, [C.POINTER(Conv3Thin), vp]),
+    "miseg_conv3_thin_wgrad": (i32, [C.POINTER(Conv3ThinWgrad), vp]),
+    "miseg_head_fwd": (i32, [C.POINTER(Head), vp]),
+    "miseg_head_bwd": (i32, [C.POINTER(HeadBwd), vp]),
+    "miseg_im2col3": (i32, [C.POINTER(Im2col3), vp]),
+    "miseg_col2im3": (i32, [C.POINTER(Im2col3), vp]),
+    "miseg_fill32": (i32, [vp, C.c_uint32, C.c_size_t, vp]),
+}
+
+_lib = None
+
+
+class MisegHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared object (once).  Raises if it was not built -- there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MisegHipError(f"{LIB_PATH} is missing: run `python __graft_entry__.py` (build()) first; "
+                            "the MI355X path has no fallback implementation")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().miseg_last_error().decode()
+        if rc == -1:
+            raise ValueError(f"miseg {what}: {msg}")
+        raise MisegHipError(f"miseg {what} failed ({rc}): {msg}")

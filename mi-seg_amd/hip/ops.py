@@ -1,0 +1,383 @@
+"""Tensor-level wrappers over the C ABI (no autograd here).  torch is only the allocator / stream provider.
+
+Activations are "channels-last rows": any tensor whose last dim is the channel dim with stride 1 and whose leading
+dims collapse to one uniform row stride (e.g. a contiguous [B, D, H, W, C] tensor or a channel slice of one).
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return L.F32
+    if t.dtype == torch.bfloat16:
+        return L.BF16
+    raise ValueError(f"unsupported dtype {t.dtype} (float32 / bfloat16 only)")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def rows(t):
+    """(ld, nrows, C) of a channels-last row view; raises if the leading dims are not uniformly strided."""
+    if not t.is_cuda:
+        raise L.MisegHipError("miseg ops need CUDA/HIP tensors: the MI355X path has no CPU fallback")
+    if t.dim() < 2:
+        raise ValueError("need at least [rows, C]")
+    if t.stride(-1) != 1 and t.shape[-1] != 1:
+        raise ValueError(f"channel dim must be contiguous, got strides {t.stride()}")
+    ld = t.stride(-2)
+    n = t.shape[-2]
+    for i in range(t.dim() - 3, -1, -1):
+        if t.shape[i] != 1 and t.stride(i) != ld * n:
+            raise ValueError(f"rows are not uniformly strided: shape {tuple(t.shape)} strides {t.stride()}")
+        n *= t.shape[i]
+    return ld, n, t.shape[-1]
+
+
+def _fp32(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError("parameters / gradients must be contiguous float32")
+    return t
+
+
+def _call(fn_name, params):
+    lib = L.load()
+    L.check(getattr(lib, fn_name)(C.byref(params), _stream()), fn_name)
+
+
+# ------------------------------------------------------------------------------------------ instance norm
+def instnorm_stats(x, B, S, eps=1e-5):
+    """x: rows view of [B*S, C].  Returns (mean, rstd) fp32 [B, C]."""
+    ld, n, Cc = rows(x)
+    assert n == B * S, (n, B, S)
+    lib = L.load()
+    ws = torch.empty(max(1, lib.miseg_instnorm_workspace_bytes(B, S, Cc) // 4), dtype=torch.float32, device=x.device)
+    mean = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+    _call("miseg_instnorm_stats", L.InstnormStats(_ptr(x), ld, B, S, Cc, _dt(x), eps, _ptr(mean), _ptr(rstd), _ptr(ws)))
+    return mean, rstd
+
+
+def _style_arrays(tensors, n):
+    arr = (C.c_void_p * L.MAX_STYLES)()
+    for i in range(L.MAX_STYLES):
+        arr[i] = tensors[i].data_ptr() if (tensors is not None and i < n and tensors[i] is not None) else None
+    return arr
+
+
+def instnorm_apply(x, B, S, mean, rstd, styles, gammas, betas, res=None, act=L.ACT_NONE, slope=0.01, out=None):
+    ld, n, Cc = rows(x)
+    y = out if out is not None else torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    ldy, ny, Cy = rows(y)
+    assert ny == n and Cy == Cc
+    ldr = rows(res)[0] if res is not None else 0
+    ns = len(gammas) if gammas is not None else 1
+    p = L.InstnormApply(_ptr(x), ld, _ptr(res), ldr, _ptr(y), ldy, B, S, Cc, _dt(x), _ptr(mean), _ptr(rstd), _ptr(styles), ns,
+                        _style_arrays(gammas, ns), _style_arrays(betas, ns), act, slope)
+    _call("miseg_instnorm_apply", p)
+    return y
+
+
+def instnorm_bwd(dy, y, x, B, S, mean, rstd, styles, gammas, dgammas, dbetas, act=L.ACT_NONE, slope=0.01, want_dres=False):
+    ld, n, Cc = rows(x)
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    dres = torch.empty(x.shape, dtype=x.dtype, device=x.device) if want_dres else None
+    lib = L.load()
+    ws = torch.empty(max(1, lib.miseg_instnorm_workspace_bytes(B, S, Cc) // 4), dtype=torch.float32, device=x.device)
+    ns = len(gammas) if gammas is not None else 1
+    p = L.InstnormBwd(_ptr(dy), rows(dy)[0], _ptr(y), rows(y)[0] if y is not None else 0, _ptr(x), ld, _ptr(dx), rows(dx)[0],
+                      _ptr(dres), rows(dres)[0] if dres is not None else 0, B, S, Cc, _dt(x), _ptr(mean), _ptr(rstd), _ptr(styles), ns,
+                      _style_arrays(gammas, ns), _style_arrays(dgammas, ns), _style_arrays(dbetas, ns), act, slope, _ptr(ws))
+    _call("miseg_instnorm_bwd", p)
+    return dx, dres
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5):
+    ld, n, Cc = rows(x)
+    y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    mean = torch.empty(n, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(n, dtype=torch.float32, device=x.device)
+    _call("miseg_layernorm_fwd", L.LayernormFwd(_ptr(x), ld, _ptr(y), rows(y)[0], n, Cc, _dt(x), eps, _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd)))
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta):
+    ld, n, Cc = rows(x)
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    _call("miseg_layernorm_bwd", L.LayernormBwd(_ptr(dy), rows(dy)[0], _ptr(x), ld, _ptr(dx), rows(dx)[0], n, Cc, _dt(x), _ptr(gamma), _ptr(mean),
+                                               _ptr(rstd), _ptr(dgamma), _ptr(dbeta)))
+    return dx
+
+
+# ------------------------------------------------------------------------------------------ GEMM family
+def gemm_nt(a, w, bias=None, act=L.ACT_NONE, out=None, out_dtype=None, split_k=1):
+    """out[M,N] = a[M,K] @ w[N,K]^T (+bias) ; a rows view, w contiguous [N,K] in a.dtype."""
+    lda, M, K = rows(a)
+    N, Kw = w.shape
+    assert Kw == K and w.is_contiguous() and w.dtype == a.dtype, (w.shape, K, w.dtype, a.dtype)
+    odt = out_dtype or a.dtype
+    if out is None:
+        out = torch.empty(a.shape[:-1] + (N,), dtype=odt, device=a.device)
+    ldc, Mo, No = rows(out)
+    assert Mo == M and No == N
+    p = L.Gemm(_ptr(a), lda, _ptr(w), K, _ptr(out), ldc, M, N, K, 0, 0, _dt(a), _dt(out), _ptr(_fp32(bias)), act, 0, split_k)
+    _call("miseg_gemm", p)
+    return out
+
+
+def gemm_tn(a, b, out=None, accumulate=False, split_k=0):
+    """out[M,N] (fp32) (+)= a[K,M]^T @ b[K,N]; a, b row views sharing the row count K (weight gradients)."""
+    lda, K, M = rows(a)
+    ldb, Kb, N = rows(b)
+    assert K == Kb and a.dtype == b.dtype
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+        accumulate = False
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == M * N
+    if split_k <= 0:
+        tiles = ((M + 63) // 64) * ((N + 63) // 64)
+        split_k = max(1, min((K + 255) // 256, 1024 // max(1, tiles)))
+    p = L.Gemm(_ptr(a), lda, _ptr(b), ldb, _ptr(out), N, M, N, K, 1, 1, _dt(a), L.F32, None, L.ACT_NONE, int(accumulate), split_k)
+    _call("miseg_gemm", p)
+    return out
+
+
+def permute3(src, dst, n, strides, accumulate=False):
+    lib = L.load()
+    L.check(lib.miseg_permute3(_ptr(src), _ptr(dst), n[0], n[1], n[2], strides[0], strides[1], strides[2], int(accumulate), _stream()), "permute3")
+    return dst
+
+
+def colsum(x, out=None, accumulate=False):
+    ld, n, Cc = rows(x)
+    if out is None:
+        out = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        accumulate = False
+    _call("miseg_colsum", L.Colsum(_ptr(x), ld, n, Cc, _dt(x), _ptr(out), int(accumulate)))
+    return out
+
+
+def cast_matrix(w, dtype, transpose=False):
+    """fp32 [R, C] parameter -> compute dtype, optionally transposed to [C, R]."""
+    w2 = _fp32(w).reshape(w.shape[0], -1)
+    R, Cc = w2.shape
+    if dtype == torch.float32 and not transpose:
+        return w2
+    out = torch.empty((Cc, R) if transpose else (R, Cc), dtype=dtype, device=w.device)
+    _call("miseg_cast_matrix", L.Cast(_ptr(w2), _ptr(out), R, Cc, L.F32 if dtype == torch.float32 else L.BF16, int(transpose)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------ conv 3x3x3
+def _round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+def pack_conv3(w, dtype, want_fwd=True, want_bwd=True):
+    Cout, Cin = w.shape[0], w.shape[1]
+    kpc = 4 if dtype == torch.float32 else 8
+    fwd = torch.empty(Cout, 27, _round_up(Cin, kpc), dtype=dtype, device=w.device) if want_fwd else None
+    bwd = torch.empty(Cin, 27, _round_up(Cout, kpc), dtype=dtype, device=w.device) if want_bwd else None
+    _call("miseg_pack_conv3_weight", L.PackConv3(_ptr(_fp32(w)), _ptr(fwd), _ptr(bwd), Cin, Cout, L.F32 if dtype == torch.float32 else L.BF16))
+    return fwd, bwd
+
+
+def _vol(x):
+    assert x.dim() == 5, "expected [B, D, H, W, C]"
+    return x.shape[0], x.shape[1], x.shape[2], x.shape[3]
+
+
+def conv3_fwd(x, wpk, Cout, out=None):
+    """x [B,D,H,W,Cin] rows view; wpk [Cout][27][CinP]."""
+    B, D, H, W = _vol(x)
+    ld, n, Cin = rows(x)
+    if out is None:
+        out = torch.empty(B, D, H, W, Cout, dtype=x.dtype, device=x.device)
+    _call("miseg_conv3_fwd", L.Conv3(_ptr(x), ld, _ptr(out), rows(out)[0], _ptr(wpk), B, D, H, W, Cin, Cout, _dt(x)))
+    return out
+
+
+def conv3_wgrad(x, dy, dw=None, accumulate=False):
+    B, D, H, W = _vol(x)
+    ldx, n, Cin = rows(x)
+    lddy, n2, Cout = rows(dy)
+    assert n == n2
+    if dw is None:
+        dw = torch.empty(Cout, Cin, 3, 3, 3, dtype=torch.float32, device=x.device)
+        accumulate = False
+    lib = L.load()
+    ws = torch.empty(lib.miseg_conv3_wgrad_workspace_bytes(B, D, H, W, Cin, Cout) // 4, dtype=torch.float32, device=x.device)
+    _call("miseg_conv3_wgrad", L.Conv3Wgrad(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), B, D, H, W, Cin, Cout, _dt(x), int(accumulate), _ptr(ws)))
+    return dw
+
+
+def conv3_thin_fwd(x_ncdhw, w, dtype):
+    B, Cin, D, H, W = x_ncdhw.shape
+    assert x_ncdhw.dtype == torch.float32 and x_ncdhw.is_contiguous()
+    Cout = w.shape[0]
+    y = torch.empty(B, D, H, W, Cout, dtype=dtype, device=x_ncdhw.device)
+    _call("miseg_conv3_thin_fwd", L.Conv3Thin(_ptr(x_ncdhw), _ptr(y), Cout, _ptr(_fp32(w)), B, Cin, D, H, W, Cout, _dt(y)))
+    return y
+
+
+def conv3_thin_wgrad(x_ncdhw, dy, dw):
+    B, Cin, D, H, W = x_ncdhw.shape
+    Cout = dy.shape[-1]
+    _call("miseg_conv3_thin_wgrad", L.Conv3ThinWgrad(_ptr(x_ncdhw), _ptr(dy), rows(dy)[0], _ptr(dw), B, Cin, D, H, W, Cout, _dt(dy)))
+    return dw
+
+
+def im2col3(x, adjoint=False, C_out=None):
+    """forward: x [B,D,H,W,C] -> col [B,D,H,W,27*C];  adjoint: col -> [B,D,H,W,C]."""
+    B, D, H, W = _vol(x)
+    ld, n, Cc = rows(x)
+    if not adjoint:
+        out = torch.empty(B, D, H, W, 27 * Cc, dtype=x.dtype, device=x.device)
+        _call("miseg_im2col3", L.Im2col3(_ptr(x), ld, _ptr(out), 27 * Cc, B, D, H, W, Cc, _dt(x)))
+    else:
+        Co = Cc // 27
+        out = torch.empty(B, D, H, W, Co, dtype=x.dtype, device=x.device)
+        _call("miseg_col2im3", L.Im2col3(_ptr(x), ld, _ptr(out), Co, B, D, H, W, Co, _dt(x)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------ attention
+def winattn_params(qkv, out, qkv_bias, table, lse, heads, window, shift, tw, scale):
+    B, D, H, W = _vol(qkv)
+    ldq, n, C3 = rows(qkv)
+    Cc = C3 // 3
+    return L.Winattn(_ptr(qkv), ldq, _ptr(out), rows(out)[0], _ptr(qkv_bias), _ptr(table), _ptr(lse), B, D, H, W, Cc, heads, _dt(qkv),
+                     window[0], window[1], window[2], shift[0], shift[1], shift[2], tw, scale)
+
+
+def winattn_fwd(qkv, qkv_bias, table, heads, window, shift, tw, scale):
+    B, D, H, W = _vol(qkv)
+    Cc = qkv.shape[-1] // 3
+    out = torch.empty(B, D, H, W, Cc, dtype=qkv.dtype, device=qkv.device)
+    nw = B * -(-D // window[0]) * -(-H // window[1]) * -(-W // window[2])
+    lse = torch.empty(nw, heads, window[0] * window[1] * window[2], dtype=torch.float32, device=qkv.device)
+    _call("miseg_winattn_fwd", winattn_params(qkv, out, qkv_bias, table, lse, heads, window, shift, tw, scale))
+    return out, lse
+
+
+def winattn_bwd(qkv, out, lse, dout, qkv_bias, table, heads, window, shift, tw, scale, dqkv_bias, dtable):
+    dqkv = torch.empty(qkv.shape, dtype=qkv.dtype, device=qkv.device)
+    f = winattn_params(qkv, out, qkv_bias, table, lse, heads, window, shift, tw, scale)
+    p = L.WinattnBwd(f, _ptr(dout), rows(dout)[0], _ptr(dqkv), rows(dqkv)[0], _ptr(dqkv_bias), _ptr(dtable))
+    _call("miseg_winattn_bwd", p)
+    return dqkv
+
+
+# ------------------------------------------------------------------------------------------ elementwise / movement
+def add(a, b, out=None):
+    lda, n, Cc = rows(a)
+    y = out if out is not None else torch.empty(a.shape, dtype=a.dtype, device=a.device)
+    _call("miseg_add", L.Add(_ptr(a), lda, _ptr(b), rows(b)[0], _ptr(y), rows(y)[0], n, Cc, _dt(a)))
+    return y
+
+
+def copy2d(src, dst):
+    lds, n, Cc = rows(src)
+    ldd, n2, C2 = rows(dst)
+    assert n == n2 and Cc == C2
+    _call("miseg_copy2d", L.Copy2d(_ptr(src), lds, _dt(src), _ptr(dst), ldd, _dt(dst), n, Cc))
+    return dst
+
+
+def gelu_fwd(x):
+    ld, n, Cc = rows(x)
+    y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    _call("miseg_gelu_fwd", L.GeluFwd(_ptr(x), ld, _ptr(y), rows(y)[0], n, Cc, _dt(x)))
+    return y
+
+
+def gelu_bwd(dy, x):
+    ld, n, Cc = rows(x)
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    _call("miseg_gelu_bwd", L.GeluBwd(_ptr(dy), rows(dy)[0], _ptr(x), ld, _ptr(dx), rows(dx)[0], n, Cc, _dt(x)))
+    return dx
+
+
+def _offs(offsets):
+    arr = (C.c_int8 * 24)()
+    flat = [v for o in offsets for v in o]
+    assert len(flat) == 24
+    for i, v in enumerate(flat):
+        arr[i] = v
+    return arr
+
+
+def space_to_channel(fine, offsets, out=None):
+    """fine [B,D,H,W,C] -> coarse [B,ceil(D/2),ceil(H/2),ceil(W/2),8C] with block j taken at offsets[j]."""
+    B, D, H, W = _vol(fine)
+    ld, n, Cc = rows(fine)
+    if out is None:
+        out = torch.empty(B, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2, 8 * Cc, dtype=fine.dtype, device=fine.device)
+    _call("miseg_space_to_channel", L.S2C(_ptr(fine), ld, _ptr(out), rows(out)[0], B, D, H, W, Cc, _dt(fine), _offs(offsets)))
+    return out
+
+
+def channel_to_space(coarse, offsets, fine_shape, out=None):
+    """adjoint of space_to_channel: coarse [B,D2,H2,W2,8C] -> fine [B,D,H,W,C] (sum over blocks referencing a voxel)."""
+    B, D, H, W, Cc = fine_shape
+    if out is None:
+        out = torch.empty(B, D, H, W, Cc, dtype=coarse.dtype, device=coarse.device)
+    _call("miseg_channel_to_space", L.S2C(_ptr(coarse), rows(coarse)[0], _ptr(out), rows(out)[0], B, D, H, W, Cc, _dt(coarse), _offs(offsets)))
+    return out
+
+
+def patch_embed_fwd(x_ncdhw, w, bias, dtype):
+    B, Cin, D, H, W = x_ncdhw.shape
+    assert x_ncdhw.dtype == torch.float32 and x_ncdhw.is_contiguous()
+    Cout = w.shape[0]
+    y = torch.empty(B, D // 2, H // 2, W // 2, Cout, dtype=dtype, device=x_ncdhw.device)
+    _call("miseg_patch_embed_fwd", L.PatchEmbed(_ptr(x_ncdhw), _ptr(y), Cout, _ptr(_fp32(w)), _ptr(_fp32(bias)), B, Cin, D, H, W, Cout, _dt(y)))
+    return y
+
+
+def patch_embed_bwd(x_ncdhw, dy, dw, dbias):
+    B, Cin, D, H, W = x_ncdhw.shape
+    Cout = dy.shape[-1]
+    _call("miseg_patch_embed_bwd", L.PatchEmbedBwd(_ptr(x_ncdhw), _ptr(dy), rows(dy)[0], _ptr(dw), _ptr(dbias), B, Cin, D, H, W, Cout, _dt(dy)))
+
+
+def head_fwd(x, w, bias):
+    B, D, H, W = _vol(x)
+    ld, n, Cin = rows(x)
+    Cout = w.shape[0]
+    y = torch.empty(B, Cout, D, H, W, dtype=torch.float32, device=x.device)
+    _call("miseg_head_fwd", L.Head(_ptr(x), ld, _ptr(y), _ptr(_fp32(w)), _ptr(_fp32(bias)), B, D * H * W, Cin, Cout, _dt(x)))
+    return y
+
+
+def head_bwd(x, dy_ncdhw, w, dw, dbias, want_dx=True):
+    B, D, H, W = _vol(x)
+    ld, n, Cin = rows(x)
+    Cout = w.shape[0]
+    assert dy_ncdhw.dtype == torch.float32 and dy_ncdhw.is_contiguous()
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device) if want_dx else None
+    _call("miseg_head_bwd", L.HeadBwd(_ptr(x), ld, _ptr(dy_ncdhw), _ptr(dx), rows(dx)[0] if dx is not None else 0, _ptr(_fp32(w)), _ptr(dw), _ptr(dbias),
+                                      B, D * H * W, Cin, Cout, _dt(x)))
+    return dx
+
+
+def fill32(t, word=0):
+    lib = L.load()
+    assert t.is_contiguous() and t.element_size() == 4
+    L.check(lib.miseg_fill32(_ptr(t), word, t.numel(), _stream()), "fill32")
+    return t
+
+
+def zeros_f32(shape, device):
+    return fill32(torch.empty(shape, dtype=torch.float32, device=device))

@@ -1,0 +1,23 @@
+"""MLPBlock with MONAI 1.1.0's parameter names (linear1 / linear2), as used at reference
+swin_transformer_block.py:97 and transformer_block.py:58: Linear -> exact GELU -> Linear (dropouts are p=0)."""
+import torch.nn as nn
+
+from ...hip import functional as HF
+
+
+class MLPBlock(nn.Module):
+    def __init__(self, hidden_size: int, mlp_dim: int, dropout_rate: float = 0.0, act="GELU", dropout_mode="vit"):
+        super().__init__()
+        if not (0 <= dropout_rate <= 1):
+            raise ValueError("dropout_rate should be between 0 and 1.")
+        if dropout_rate != 0.0:
+            raise NotImplementedError("dropout > 0 is not implemented by the MI355X path")
+        if str(act).upper() != "GELU":
+            raise NotImplementedError(f"activation {act}")
+        mlp_dim = mlp_dim or hidden_size
+        self.linear1 = nn.Linear(hidden_size, mlp_dim)
+        self.linear2 = nn.Linear(mlp_dim, hidden_size)
+
+    def forward(self, x):
+        h = HF.gelu(HF.linear(x, self.linear1.weight, self.linear1.bias))
+        return HF.linear(h, self.linear2.weight, self.linear2.bias)

@@ -1,0 +1,55 @@
+"""SwinTransformerBlock (reference networks/blocks/swin_transformer_block.py:24-252) on channels-last activations."""
+from typing import Sequence, Tuple, Union
+
+import torch.nn as nn
+
+from ...hip import functional as HF
+from ..layers.utils import apply_norm, get_norm_layer
+from ..utils.swin_utils import get_window_size
+from .mlp import MLPBlock as Mlp
+from .window_attention import WindowAttention
+
+__all__ = ["SwinTransformerBlock"]
+
+
+def norm_spec_with_shape(norm_type, dim):
+    """layer norm needs normalized_shape injected (reference :70-75); returns a fresh spec."""
+    name = norm_type[0] if isinstance(norm_type, tuple) else norm_type
+    if name == "layer":
+        args = dict(norm_type[1]) if isinstance(norm_type, tuple) else {}
+        args["normalized_shape"] = dim
+        return (name, args)
+    return norm_type
+
+
+class SwinTransformerBlock(nn.Module):
+    def __init__(self, dim: int, num_heads: int, window_size: Sequence[int], shift_size: Sequence[int], mlp_ratio: float = 4.0,
+                 qkv_bias: bool = True, drop: float = 0.0, attn_drop: float = 0.0, drop_path: float = 0.0, act_layer: str = "GELU",
+                 use_checkpoint: bool = False, norm_type: Union[Tuple, str] = "layer") -> None:
+        super().__init__()
+        if drop_path != 0.0 or drop != 0.0:
+            raise NotImplementedError("drop / drop_path > 0 is not implemented by the MI355X path")
+        self.dim = dim
+        self.num_heads = num_heads
+        self.window_size = tuple(window_size)
+        self.shift_size = tuple(shift_size)
+        self.mlp_ratio = mlp_ratio
+        self.use_checkpoint = use_checkpoint  # activations are kept (288 GB HBM); flag accepted for API parity
+        self.norm_type = norm_type[0] if isinstance(norm_type, tuple) else norm_type
+        spec = norm_spec_with_shape(norm_type, dim)
+        self.norm1 = get_norm_layer(name=spec, spatial_dims=len(self.window_size), channels=dim)
+        self.norm2 = get_norm_layer(name=spec, spatial_dims=len(self.window_size), channels=dim)
+        self.attn = WindowAttention(dim, window_size=self.window_size, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop,
+                                    proj_drop=drop)
+        self.drop_path = nn.Identity()
+        self.mlp = Mlp(hidden_size=dim, mlp_dim=int(dim * mlp_ratio), act=act_layer, dropout_rate=drop, dropout_mode="swin")
+
+    def forward(self, x, styles=None):
+        """x [B, D, H, W, C].  part1 (:99-174) + residual, part2 (:176-205) + residual (:241-252)."""
+        _, d, h, w, _ = x.shape
+        window, shift = get_window_size((d, h, w), self.window_size, self.shift_size)
+        xa, xs = HF.fork(x)
+        y = self.attn(apply_norm(self.norm1, xa, styles), window, shift)
+        x = HF.add(xs, y)
+        xa, xs = HF.fork(x)
+        return HF.add(xs, self.mlp(apply_norm(self.norm2, xa, styles)))

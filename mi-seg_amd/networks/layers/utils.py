@@ -1,0 +1,63 @@
+"""Norm-layer lookup with the reference's contract (networks/layers/utils.py:22-50, factories.py:219-257) and the
+channels-last application used by every block of this package."""
+from typing import Optional, Tuple, Union
+
+import torch.nn as nn
+
+from ...hip import functional as HF
+from ...hip import lib as L
+from ..norms.conditional_instance_norm import (ConditionalInstanceNorm1d, ConditionalInstanceNorm2d, ConditionalInstanceNorm3d,
+                                               _ConditionalInstanceNorm)
+
+_INSTANCE = (nn.InstanceNorm1d, nn.InstanceNorm2d, nn.InstanceNorm3d)
+_COND = (ConditionalInstanceNorm1d, ConditionalInstanceNorm2d, ConditionalInstanceNorm3d)
+
+
+def split_args(args):
+    if isinstance(args, str):
+        return args, {}
+    name_obj, name_args = args
+    if not (isinstance(name_obj, str) or callable(name_obj)) or not isinstance(name_args, dict):
+        raise TypeError("Layer specifiers must be single strings or pairs of the form (name/object-types, argument dict)")
+    return name_obj, name_args
+
+
+def get_norm_layer(name: Union[Tuple, str], spatial_dims: Optional[int] = 1, channels: Optional[int] = 1):
+    """``Norm[name, spatial_dims](**args)`` for the norm families the HIP path implements."""
+    if name == "":
+        return nn.Identity()
+    norm_name, norm_args = split_args(name)
+    kw = dict(norm_args)
+    key = norm_name.lower() if isinstance(norm_name, str) else norm_name
+    if key == "instance_cond":
+        kw.setdefault("num_features", channels)
+        return _COND[spatial_dims - 1](**kw)
+    if key == "instance":
+        kw.setdefault("num_features", channels)
+        return _INSTANCE[spatial_dims - 1](**kw)
+    if key == "layer":
+        kw.setdefault("normalized_shape", channels)
+        return nn.LayerNorm(**kw)
+    if key in ("batch", "group", "localresponse", "syncbatch", "instance_nvfuser"):
+        raise NotImplementedError(f"normalisation '{key}' is not implemented by the MI355X path "
+                                  "(supported: instance_cond, instance, layer)")
+    raise ValueError(f"Unsupported option '{norm_name}'")
+
+
+def apply_norm(norm: nn.Module, x, styles=None, res=None, act=L.ACT_NONE, slope=0.01):
+    """Apply a norm *module* (used as a parameter container) to a channels-last tensor through the HIP kernels.
+    ``styles`` is the (device int32 tensor, host tuple) pair from styles_to_device."""
+    if isinstance(norm, _ConditionalInstanceNorm):
+        if styles is None:
+            raise ValueError("Modalities must be passed to the forward step when encoder_norm_type is 'instance_cond'.")
+        return HF.instance_norm(x, norm.style_params(), styles[0], styles[1], res=res, act=act, slope=slope, eps=norm.eps)
+    if isinstance(norm, _INSTANCE):
+        params = [(norm.weight, norm.bias)] if norm.affine else None
+        return HF.instance_norm(x, params, None, None, res=res, act=act, slope=slope, eps=norm.eps)
+    if isinstance(norm, nn.LayerNorm):
+        if res is not None or act != L.ACT_NONE:
+            raise NotImplementedError("LayerNorm with fused residual / activation")
+        return HF.layer_norm(x, norm.weight, norm.bias, norm.eps)
+    if isinstance(norm, nn.Identity):
+        return x
+    raise NotImplementedError(type(norm))

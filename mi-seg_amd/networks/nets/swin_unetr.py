@@ -1,0 +1,148 @@
+"""SwinUNETR -- drop-in for reference networks/nets/swin_unetr.py (same constructor, from_argparse_args,
+forward(x_in, modalities) and state_dict keys); all device arithmetic runs in csrc/libmiseg_hip.so."""
+from typing import Sequence, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..blocks.dynunet_block import UnetOutBlock
+from ..blocks.patch_merging import PatchMerging, PatchMergingV2
+from ..blocks.unetr_block import UnetrBasicBlock, UnetrUpBlock
+from ..norms.conditional_instance_norm import styles_to_device
+from ..norms.utils import parse_normalization
+from .swin_transformer import SwinTransformer, look_up_option
+
+__all__ = ["SwinUNETR", "MERGING_MODE"]
+
+MERGING_MODE = {"merging": PatchMerging, "mergingv2": PatchMergingV2}
+
+
+def ensure_tuple_rep(x, n):
+    if isinstance(x, (list, tuple)):
+        if len(x) != n:
+            raise ValueError(f"Sequence must have length {n}, got {len(x)}.")
+        return tuple(x)
+    return (x,) * n
+
+
+class SwinUNETR(nn.Module):
+    def __init__(self, img_size: Union[Sequence[int], int], in_channels: int, out_channels: int, depths: Sequence[int] = (2, 2, 2, 2),
+                 num_heads: Sequence[int] = (3, 6, 12, 24), feature_size: int = 24, drop_rate: float = 0.0, attn_drop_rate: float = 0.0,
+                 dropout_path_rate: float = 0.0, normalize: bool = True, use_checkpoint: bool = False, spatial_dims: int = 3,
+                 downsample="merging", vit_norm_name: Union[Tuple, str] = "layer", decoder_norm_name: Union[Tuple, str] = "instance",
+                 encoder_norm_name: Union[Tuple, str] = "instance", freeze_encoder: bool = False) -> None:
+        super().__init__()
+        if not (spatial_dims == 2 or spatial_dims == 3):
+            raise ValueError("spatial dimension should be 2 or 3.")
+        if spatial_dims != 3:
+            raise NotImplementedError("only spatial_dims=3 is implemented by the MI355X path")
+        img_size = ensure_tuple_rep(img_size, spatial_dims)
+        patch_size = ensure_tuple_rep(2, spatial_dims)
+        window_size = ensure_tuple_rep(7, spatial_dims)
+        for m, p in zip(img_size, patch_size):
+            for i in range(5):
+                if m % np.power(p, i + 1) != 0:
+                    raise ValueError("input image size (img_size) should be divisible by stage-wise image resolution.")
+        if not (0 <= drop_rate <= 1):
+            raise ValueError("dropout rate should be between 0 and 1.")
+        if not (0 <= attn_drop_rate <= 1):
+            raise ValueError("attention dropout rate should be between 0 and 1.")
+        if not (0 <= dropout_path_rate <= 1):
+            raise ValueError("drop path rate should be between 0 and 1.")
+        if feature_size % 12 != 0:
+            raise ValueError("feature_size should be divisible by 12.")
+        self.vit_norm_name = vit_norm_name[0] if isinstance(vit_norm_name, tuple) else vit_norm_name
+        self.decoder_norm_name = decoder_norm_name[0] if isinstance(decoder_norm_name, tuple) else decoder_norm_name
+        self.encoder_norm_name = encoder_norm_name[0] if isinstance(encoder_norm_name, tuple) else encoder_norm_name
+        if self.decoder_norm_name == "layer" or self.encoder_norm_name == "layer":
+            raise ValueError("Layer normalization not yet implemented for encoder and decoder blocks, please "
+                             "select another normalization.")
+        self.normalize = normalize
+        self.in_channels = in_channels
+        self.compute_dtype = torch.float32
+
+        self.swinViT = SwinTransformer(
+            in_chans=in_channels, embed_dim=feature_size, window_size=window_size, patch_size=patch_size, depths=depths,
+            num_heads=num_heads, mlp_ratio=4.0, qkv_bias=True, drop_rate=drop_rate, attn_drop_rate=attn_drop_rate,
+            drop_path_rate=dropout_path_rate, use_checkpoint=use_checkpoint, spatial_dims=spatial_dims,
+            downsample=look_up_option(downsample, MERGING_MODE) if isinstance(downsample, str) else downsample,
+            norm_type=vit_norm_name)
+        fs = feature_size
+
+        def enc(cin, cout):
+            return UnetrBasicBlock(spatial_dims=spatial_dims, in_channels=cin, out_channels=cout, kernel_size=3, stride=1,
+                                   norm_name=encoder_norm_name, res_block=True)
+
+        def dec(cin, cout):
+            return UnetrUpBlock(spatial_dims=spatial_dims, in_channels=cin, out_channels=cout, kernel_size=3, upsample_kernel_size=2,
+                                norm_name=decoder_norm_name, res_block=True)
+
+        self.encoder1 = enc(in_channels, fs)
+        self.encoder2 = enc(fs, fs)
+        self.encoder3 = enc(2 * fs, 2 * fs)
+        self.encoder4 = enc(4 * fs, 4 * fs)
+        self.encoder10 = enc(16 * fs, 16 * fs)
+        self.decoder5 = dec(16 * fs, 8 * fs)
+        self.decoder4 = dec(8 * fs, 4 * fs)
+        self.decoder3 = dec(4 * fs, 2 * fs)
+        self.decoder2 = dec(2 * fs, fs)
+        self.decoder1 = dec(fs, fs)
+        self.out = UnetOutBlock(spatial_dims=spatial_dims, in_channels=fs, out_channels=out_channels)
+        if freeze_encoder:
+            for m in (self.swinViT, self.encoder1, self.encoder2, self.encoder3, self.encoder4, self.encoder10):
+                m.requires_grad_(False)
+
+    def set_compute_dtype(self, dtype):
+        """torch.float32 (parity mode) or torch.bfloat16 (bf16 activations / MFMA, fp32 statistics and parameters)."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute dtype must be float32 or bfloat16")
+        self.compute_dtype = dtype
+        return self
+
+    @classmethod
+    def from_argparse_args(cls, args):
+        vit_norm_name = parse_normalization(args.vit_norm_name, not args.vit_norm_no_affine, args.num_groups, args.num_styles)
+        decoder_norm_name = parse_normalization(args.decoder_norm_name, not args.decoder_norm_no_affine, args.num_groups, args.num_styles)
+        encoder_norm_name = parse_normalization(args.encoder_norm_name, not args.encoder_norm_no_affine, args.num_groups, args.num_styles)
+        if len(args.depth_swin_block) == 1:
+            depths = (args.depth_swin_block[0],) * 4
+        else:
+            assert len(args.depth_swin_block) == 4, "The length of depth_swin_block should be 4"
+            depths = args.depth_swin_block
+        num_heads = tuple(2 ** i * args.num_heads for i in range(0, 4))
+        fs = args.feature_size[0] if isinstance(args.feature_size, (list, tuple)) else args.feature_size
+        return cls(img_size=(args.roi_x, args.roi_y, args.roi_z), in_channels=args.in_channels, out_channels=args.out_channels,
+                   depths=depths, num_heads=num_heads, feature_size=fs, drop_rate=args.dropout_rate,
+                   attn_drop_rate=args.attn_drop_rate, dropout_path_rate=args.dropout_path_rate, normalize=not args.no_normalize_swin,
+                   use_checkpoint=args.use_checkpoint, spatial_dims=args.spatial_dims, downsample=args.downsample,
+                   vit_norm_name=vit_norm_name, encoder_norm_name=encoder_norm_name, decoder_norm_name=decoder_norm_name,
+                   freeze_encoder=args.freeze_encoder)
+
+    def load_from(self, weights):
+        """MONAI self-supervised Swin-ViT weights (reference swin_unetr.py:303-351); plain-norm checkpoints only."""
+        sd = {k.replace("module.", "").replace("fc1", "linear1").replace("fc2", "linear2"): v for k, v in weights["state_dict"].items()}
+        return self.swinViT.load_state_dict(sd, strict=False)
+
+    def forward(self, x_in, modalities=None):
+        """x_in [B, C, D, H, W] float; modalities None | list[int] | int64 Tensor[B].  Returns fp32 logits [B, out, D, H, W]."""
+        if not x_in.is_cuda:
+            raise RuntimeError("SwinUNETR (MI355X path) needs a HIP device tensor; there is no CPU fallback")
+        needs = "instance_cond" in (self.vit_norm_name, self.encoder_norm_name, self.decoder_norm_name)
+        if needs and modalities is None:
+            raise ValueError("Modalities must be passed to the forward step when encoder_norm_type is 'instance_cond'.")
+        styles = styles_to_device(modalities, x_in.device, x_in.shape[0]) if modalities is not None else None
+        x_in = x_in.float().contiguous()
+        dt = self.compute_dtype
+        hs = self.swinViT(x_in, self.normalize, styles, dt)
+        enc0 = self.encoder1(None, styles, image=x_in, dtype=dt)
+        enc1 = self.encoder2(hs[0], styles)
+        enc2 = self.encoder3(hs[1], styles)
+        enc3 = self.encoder4(hs[2], styles)
+        dec4 = self.encoder10(hs[4], styles)
+        dec3 = self.decoder5(dec4, hs[3], styles)
+        dec2 = self.decoder4(dec3, enc3, styles)
+        dec1 = self.decoder3(dec2, enc2, styles)
+        dec0 = self.decoder2(dec1, enc1, styles)
+        out = self.decoder1(dec0, enc0, styles)
+        return self.out(out)

@@ -1,0 +1,209 @@
+"""GPU parity tests, module level: the drop-in modules (HIP kernels through the C ABI) against the golden vectors
+captured from the reference's own modules, and against the CPU oracle.  fp32 tolerance 1e-3 (north_star)."""
+import copy
+
+import pytest
+import torch
+
+from conftest import rel_err, sample, state_from_meta
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 1e-3          # north_star: within 1e-3 relative fp32
+TOL_BF16 = 4e-2
+
+
+def _fill(m):
+    from mi_seg_amd.utils.detfill import fill_module_
+    fill_module_(m)
+    return m.to(DEV)
+
+
+def _styles(mods, B):
+    from mi_seg_amd.networks.norms.conditional_instance_norm import styles_to_device
+    return styles_to_device(mods, DEV, B)
+
+
+def _norm(name):
+    from mi_seg_amd.networks.norms.utils import parse_normalization
+    return parse_normalization(name, True, 4, 2)
+
+
+def _check_param_grads(module, want, none_list, tol):
+    named = dict(module.named_parameters())
+    for k, g in want.items():
+        got = named[k].grad
+        assert got is not None, k
+        assert rel_err(got, g) < tol, (k, rel_err(got, g))
+    for k in none_list:
+        assert named[k].grad is None, f"{k} must have no gradient"
+
+
+def test_conditional_instance_norm_module(golden):
+    from mi_seg_amd.networks.norms.conditional_instance_norm import ConditionalInstanceNorm1d, ConditionalInstanceNorm3d
+    G = golden("cond_instnorm")
+    for tag, cls in (("3d_mixed", ConditionalInstanceNorm3d), ("3d_same", ConditionalInstanceNorm3d),
+                     ("3d_tensor_styles", ConditionalInstanceNorm3d), ("1d_mixed", ConditionalInstanceNorm1d)):
+        case = G.meta["cases"][tag]
+        m = _fill(cls(2, case["shape"][1]))
+        x = G.t(f"{tag}/x").to(DEV).requires_grad_(True)
+        styles = case["styles"] if tag != "3d_tensor_styles" else torch.tensor(case["styles"], device=DEV)
+        y = m(x, styles)
+        y.backward(G.t(f"{tag}/g").to(DEV))
+        assert rel_err(y, G.t(f"{tag}/y")) < TOL
+        assert rel_err(x.grad, G.t(f"{tag}/dx")) < TOL
+        _check_param_grads(m, G.grads(tag), case["grad_none"], TOL)
+    m = _fill(ConditionalInstanceNorm3d(2, 3))
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 3, 4, 4, 4, device=DEV), [0])
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 3, 4, 4, device=DEV), [0, 1])
+
+
+@pytest.mark.parametrize("tag", ["n343_nomask", "n343_mask", "n216_sliced"])
+def test_window_attention(golden, tag):
+    from mi_seg_amd.networks.blocks.window_attention import WindowAttention
+    from oracle.functional import window_partition, window_reverse
+    G = golden("window_attention")
+    case = G.meta["cases"][tag]
+    m = _fill(WindowAttention(case["dim"], case["heads"], (7, 7, 7), qkv_bias=True))
+    xw, gw, yw, dxw = (G.t(f"{tag}/{k}") for k in ("x", "g", "y", "dx"))
+    C = case["dim"]
+    if tag == "n343_nomask":
+        dims, ws, ss = (2, 7, 7, 7), (7, 7, 7), (0, 0, 0)
+    elif tag == "n216_sliced":
+        dims, ws, ss = (2, 6, 6, 6), (6, 6, 6), (0, 0, 0)
+    else:
+        dims, ws, ss = (2, 14, 7, 7), (7, 7, 7), (3, 3, 3)
+
+    def to_grid(t):     # windows of the rolled grid -> un-rolled grid
+        g = window_reverse(t, ws, dims)
+        return torch.roll(g, shifts=ss, dims=(1, 2, 3)) if any(ss) else g
+
+    def to_win(t):
+        g = torch.roll(t, shifts=tuple(-s for s in ss), dims=(1, 2, 3)) if any(ss) else t
+        return window_partition(g, ws)
+
+    x = to_grid(xw).contiguous().to(DEV).requires_grad_(True)
+    y = m(x, ws, ss)
+    y.backward(to_grid(gw).contiguous().to(DEV))
+    assert rel_err(to_win(y.detach().cpu()), yw) < TOL
+    assert rel_err(to_win(x.grad.cpu()), dxw) < TOL
+    _check_param_grads(m, G.grads(tag), [], TOL)
+
+
+@pytest.mark.parametrize("tag", ["pad_noshift", "pad_shift", "clamped6", "layer_shift", "inst_noshift"])
+def test_swin_block(golden, tag):
+    from mi_seg_amd.networks.blocks.swin_transformer_block import SwinTransformerBlock
+    G = golden("swin_block")
+    case = G.meta["cases"][tag]
+    m = _fill(SwinTransformerBlock(case["dim"], case["heads"], (7, 7, 7), tuple(case["shift"]), norm_type=_norm(case["norm"])))
+    x = G.t(f"{tag}/x").to(DEV).requires_grad_(True)
+    y = m(x, _styles(case["modalities"], x.shape[0]))
+    y.backward(G.t(f"{tag}/g").to(DEV))
+    assert rel_err(y, G.t(f"{tag}/y")) < TOL
+    assert rel_err(x.grad, G.t(f"{tag}/dx")) < TOL
+    _check_param_grads(m, G.grads(tag), case["grad_none"], TOL)
+
+
+@pytest.mark.parametrize("tag", ["merging", "mergingv2", "merging_odd_layer"])
+def test_patch_merging(golden, tag):
+    from mi_seg_amd.networks.blocks.patch_merging import PatchMerging, PatchMergingV2
+    G = golden("patch_merging")
+    case = G.meta["cases"][tag]
+    cls = PatchMergingV2 if tag == "mergingv2" else PatchMerging
+    m = _fill(cls(4, norm_type=_norm(case["norm"]), spatial_dims=3))
+    x = G.t(f"{tag}/x").to(DEV).requires_grad_(True)
+    y = m(x, _styles(case["modalities"], 2))
+    y.backward(G.t(f"{tag}/g").to(DEV))
+    assert rel_err(y, G.t(f"{tag}/y")) < TOL
+    assert rel_err(x.grad, G.t(f"{tag}/dx")) < TOL
+    _check_param_grads(m, G.grads(tag), case["grad_none"], TOL)
+
+
+def _cl(t):
+    return t.permute(0, 2, 3, 4, 1).contiguous()
+
+
+@pytest.mark.parametrize("tag", ["res_8_to_12_cond", "res_8_to_8_cond", "res_1_to_8_inst", "up_16_to_8_inst", "prup_16_to_8_cond"])
+def test_unetr_blocks(golden, tag):
+    from mi_seg_amd.networks.blocks.dynunet_block import UnetResBlock
+    from mi_seg_amd.networks.blocks.unetr_block import UnetrPrUpBlock, UnetrUpBlock
+    G = golden("unetr_blocks")
+    case = G.meta["cases"][tag]
+    cond, inst = _norm("instance_cond"), _norm("instance")
+    st = _styles(case["modalities"], 2)
+    x_nc = G.t(f"{tag}/x").to(DEV)
+    if tag == "res_1_to_8_inst":
+        m = _fill(UnetResBlock(3, 1, 8, 3, 1, inst))
+        y = m(None, st, image=x_nc, dtype=torch.float32)
+        x = None
+    else:
+        x = _cl(x_nc).requires_grad_(True)
+        if tag == "res_8_to_12_cond":
+            m = _fill(UnetResBlock(3, 8, 12, 3, 1, cond))
+            y = m(x, st)
+        elif tag == "res_8_to_8_cond":
+            m = _fill(UnetResBlock(3, 8, 8, 3, 1, cond))
+            y = m(x, st)
+        elif tag == "up_16_to_8_inst":
+            m = _fill(UnetrUpBlock(3, 16, 8, 3, 2, inst, res_block=True))
+            skip = _cl(G.t(f"{tag}/skip").to(DEV)).requires_grad_(True)
+            y = m(x, skip, st)
+        else:
+            m = _fill(UnetrPrUpBlock(3, 16, 8, 1, 3, 1, 2, cond, conv_block=True, res_block=True))
+            y = m(x, st)
+    y.backward(_cl(G.t(f"{tag}/g").to(DEV)))
+    assert rel_err(y.permute(0, 4, 1, 2, 3), G.t(f"{tag}/y")) < TOL
+    if x is not None:
+        assert rel_err(x.grad.permute(0, 4, 1, 2, 3), G.t(f"{tag}/dx")) < TOL
+    if tag == "up_16_to_8_inst":
+        assert rel_err(skip.grad.permute(0, 4, 1, 2, 3), G.t(f"{tag}/dskip")) < TOL
+    _check_param_grads(m, G.grads(tag), case["grad_none"], TOL)
+
+
+def _whole(G, tag, model, tol, dtype=torch.float32):
+    from mi_seg_amd.utils.detfill import det_input
+    case = G.meta["cases"][tag]
+    model = _fill(model)
+    assert list(model.state_dict().keys()) == case["state_keys"]
+    model.set_compute_dtype(dtype)
+    x = det_input(1234, case["x"]).to(DEV)
+    y = model(x, case["modalities"])
+    assert y.dtype == torch.float32 and list(y.shape[:2]) == [case["x"][0], 6]
+    e = rel_err(sample(y), G.t(f"{tag}/logits_samples"))
+    assert e < tol, ("logits", e)
+    y.backward(det_input(4321, tuple(y.shape)).to(DEV))
+    gn = G.gnorms(tag)
+    named = dict(model.named_parameters())
+    worst = ("", 0.0)
+    for k, g in G.grads(tag).items():
+        got = named[k].grad
+        assert got is not None, k
+        e = rel_err(sample(got), g)
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] < 5 * tol, worst
+    none = [k for k, p in named.items() if p.grad is None]
+    assert sorted(none) == sorted(case["grad_none"])
+    return worst
+
+
+@pytest.mark.parametrize("tag", ["fs12_64_m10", "fs12_64_v2_layer"])
+def test_swin_unetr_small(golden, tag):
+    from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
+    G = golden("swin_unetr_small")
+    c = G.meta["cases"][tag]
+    m = SwinUNETR((64, 64, 64), 1, 6, feature_size=12, num_heads=(3, 6, 12, 24), downsample=c["downsample"], vit_norm_name=_norm(c["vit_norm"]),
+                  encoder_norm_name=_norm(c["encoder_norm"]), decoder_norm_name=_norm(c["decoder_norm"]))
+    _whole(G, tag, m, TOL)
+
+
+@pytest.mark.parametrize("tag,dtype,tol", [("c2_m0", torch.float32, TOL), ("c2_m1", torch.float32, TOL), ("c2_m0", torch.bfloat16, TOL_BF16)])
+def test_swin_unetr_c2_headline(golden, tag, dtype, tol):
+    """BASELINE configs[1]: C-Swin-UNETR fs=48, 96^3, 6 classes -- fwd + bwd on the same seeded patch as the reference."""
+    from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
+    G = golden("swin_unetr_c2")
+    m = SwinUNETR((96, 96, 96), 1, 6, feature_size=48, num_heads=(3, 6, 12, 24), vit_norm_name=_norm("instance_cond"),
+                  encoder_norm_name=_norm("instance_cond"), decoder_norm_name=_norm("instance"))
+    _whole(G, tag, m, tol, dtype)
