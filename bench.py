@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""bench.py -- 96^3 patches/s, forward+backward, C-Swin-UNETR fs=48 / 6 classes (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+For N > 1 launch one rank per GPU:  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One step = forward + backward of one 96^3 patch per rank (batch 1/rank, synthetic CT/MR volume already resident in
+HBM, cotangent = d(sum of logits * fixed noise)); at N > 1 the fp32 gradient arena is mean-all-reduced over RCCL
+inside the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import __graft_entry__ as ge  # noqa: E402
+
+
+def build_model(dtype):
+    from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
+    from mi_seg_amd.networks.norms.utils import parse_normalization
+    from mi_seg_amd.utils.detfill import fill_module_
+    cond = parse_normalization("instance_cond", True, 4, 2)
+    inst = parse_normalization("instance", True, 4, 2)
+    m = SwinUNETR((96, 96, 96), 1, 6, feature_size=48, num_heads=(3, 6, 12, 24), vit_norm_name=cond, encoder_norm_name=cond,
+                  decoder_norm_name=inst)
+    fill_module_(m)
+    return m.cuda().set_compute_dtype(dtype)
+
+
+def synthetic_pool(n, seed, device):
+    """n volumes in [0,1] (what ScaleIntensityd yields): smooth noise + ellipsoids; first half CT (0), second half MR (1)."""
+    g = torch.Generator().manual_seed(seed)
+    vols, mods = [], []
+    zz, yy, xx = torch.meshgrid(*[torch.linspace(-1, 1, 96)] * 3, indexing="ij")
+    for i in range(n):
+        v = torch.nn.functional.interpolate(torch.rand(1, 1, 12, 12, 12, generator=g), size=96, mode="trilinear")[0, 0]
+        for _ in range(5):
+            c = torch.rand(3, generator=g) * 1.2 - 0.6
+            r = torch.rand(3, generator=g) * 0.3 + 0.1
+            v = v + 0.5 * ((((zz - c[0]) / r[0]) ** 2 + ((yy - c[1]) / r[1]) ** 2 + ((xx - c[2]) / r[2]) ** 2) < 1).float()
+        v = (v - v.min()) / (v.max() - v.min())
+        mod = 0 if i < n // 2 else 1
+        if mod == 1:
+            v = v ** 0.6          # different intensity transfer curve for "MR"
+        vols.append(v)
+        mods.append(mod)
+    return torch.stack(vols).unsqueeze(1).to(device), mods
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    ge.load_package()
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    model = build_model(dtype)
+    from mi_seg_amd.data.sampler import rank_indices
+    pool, mods = synthetic_pool(16, 1000 + rank, dev)
+    order = rank_indices(len(mods), world_size=1, rank=0, epoch=rank, seed=0)   # per-rank pool, interleaved CT/MR stream
+    cot = torch.randn(1, 6, 96, 96, 96, generator=torch.Generator().manual_seed(4321)).to(dev)
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def step(i):
+        k = order[i % len(order)]
+        for p in params:
+            p.grad = None
+        y = model(pool[k:k + 1], [mods[k]])
+        y.backward(cot)
+        if dist is not None:
+            from mi_seg_amd.parallel.ddp import allreduce_gradients
+            allreduce_gradients(params, world)
+
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    out = {
+        "metric": "96^3 patches/sec fwd+bwd, C-Swin-UNETR fs=48 6-class", "value": world * a.steps / dt, "unit": "patches/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1000 * dt / a.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": "configs[1]: C-Swin-UNETR feature_size=48 heads=(3,6,12,24) instance_cond, 96^3 patch, 6 classes, "
+                               "batch 1 per GPU, fwd+bwd (+ gradient all-reduce at N>1)", "global_batch": world},
+    }
+    if rank == 0:
+        if not a.no_roofline:
+            from mi_seg_amd.testing.roofline import profile_step, summarize
+            out["roofline"] = summarize(profile_step(lambda: step(a.warmup + a.steps)), dtype)
+        if world == 1 and not a.no_cpu_baseline:
+            from mi_seg_amd.testing.cpu_baseline import cpu_baseline
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -51,8 +51,18 @@ def _fp32(t):
     return t
 
 
-def _call(fn_name, params):
+PROFILE_HOOK = None   # bench.py roofline leg: list collecting (kernel, start_event, end_event, flops)
+
+
+def _call(fn_name, params, prof=None):
     lib = L.load()
+    if PROFILE_HOOK is not None and prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(getattr(lib, fn_name)(C.byref(params), _stream()), fn_name)
+        e1.record()
+        PROFILE_HOOK.append((prof[0], e0, e1, prof[1]))
+        return
     L.check(getattr(lib, fn_name)(C.byref(params), _stream()), fn_name)
 
 
@@ -125,7 +135,8 @@ def gemm_nt(a, w, bias=None, act=L.ACT_NONE, out=None, out_dtype=None, split_k=1
     """out[M,N] = a[M,K] @ w[N,K]^T (+bias) ; a rows view, w contiguous [N,K] in a.dtype."""
     lda, M, K = rows(a)
     N, Kw = w.shape
-    assert Kw == K and w.is_contiguous() and w.dtype == a.dtype, (w.shape, K, w.dtype, a.dtype)
+    if not (Kw == K and w.is_contiguous() and w.dtype == a.dtype):
+        raise ValueError(f"gemm_nt: weight {tuple(w.shape)} {w.dtype} does not match activations K={K} {a.dtype}")
     odt = out_dtype or a.dtype
     if out is None:
         out = torch.empty(a.shape[:-1] + (N,), dtype=odt, device=a.device)
@@ -198,13 +209,20 @@ def _vol(x):
     return x.shape[0], x.shape[1], x.shape[2], x.shape[3]
 
 
+def _conv_nt(Cout):
+    """mirror of the tile choice in csrc/conv3d.hip::conv3_fwd_launch"""
+    return 1 if Cout <= 16 else 2 if Cout <= 32 else 3 if Cout <= 48 else 4 if Cout <= 64 else (6 if (Cout % 96 == 0 or Cout > 128) else 4)
+
+
 def conv3_fwd(x, wpk, Cout, out=None):
     """x [B,D,H,W,Cin] rows view; wpk [Cout][27][CinP]."""
     B, D, H, W = _vol(x)
     ld, n, Cin = rows(x)
     if out is None:
         out = torch.empty(B, D, H, W, Cout, dtype=x.dtype, device=x.device)
-    _call("miseg_conv3_fwd", L.Conv3(_ptr(x), ld, _ptr(out), rows(out)[0], _ptr(wpk), B, D, H, W, Cin, Cout, _dt(x)))
+    flops = 2.0 * B * D * H * W * 27 * Cin * Cout
+    _call("miseg_conv3_fwd", L.Conv3(_ptr(x), ld, _ptr(out), rows(out)[0], _ptr(wpk), B, D, H, W, Cin, Cout, _dt(x)),
+          prof=(f"conv3_fwd_kernel<{'bf16' if x.dtype == torch.bfloat16 else 'f32'},NT={_conv_nt(Cout)}>", flops))
     return out
 
 
@@ -218,7 +236,8 @@ def conv3_wgrad(x, dy, dw=None, accumulate=False):
         accumulate = False
     lib = L.load()
     ws = torch.empty(lib.miseg_conv3_wgrad_workspace_bytes(B, D, H, W, Cin, Cout) // 4, dtype=torch.float32, device=x.device)
-    _call("miseg_conv3_wgrad", L.Conv3Wgrad(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), B, D, H, W, Cin, Cout, _dt(x), int(accumulate), _ptr(ws)))
+    _call("miseg_conv3_wgrad", L.Conv3Wgrad(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), B, D, H, W, Cin, Cout, _dt(x), int(accumulate), _ptr(ws)),
+          prof=(f"conv3_wgrad_kernel<{'bf16' if x.dtype == torch.bfloat16 else 'f32'}>", 2.0 * B * D * H * W * 27 * Cin * Cout))
     return dw
 
 

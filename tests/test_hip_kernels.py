@@ -55,19 +55,21 @@ def test_instnorm_fwd_bwd(dtype, B, S, C):
     mean, rstd = ops.instnorm_stats(x, B, S)
     y = ops.instnorm_apply(x, B, S, mean, rstd, styles, gam, bet, res=res, act=L.ACT_LEAKY, slope=0.01)
     # reference (fp32 on device)
-    xf = x.float().requires_grad_(True)
-    rf = res.float().requires_grad_(True)
-    gp = [g.clone().requires_grad_(True) for g in gam]
-    bp = [b.clone().requires_grad_(True) for b in bet]
+    xf = x.double().requires_grad_(True)
+    rf = res.double().requires_grad_(True)
+    gp = [g.double().requires_grad_(True) for g in gam]
+    bp = [b.double().requires_grad_(True) for b in bet]
     outs = []
     for i in range(B):
         s = styles_h[i]
-        outs.append(F.instance_norm(xf[i:i + 1].transpose(1, 2), weight=gp[s], bias=bp[s]).transpose(1, 2))
-    yr = F.leaky_relu(torch.cat(outs) + rf, 0.01)
+        mu = xf[i].mean(0, keepdim=True)
+        var = xf[i].var(0, unbiased=False, keepdim=True)
+        outs.append((xf[i] - mu) / torch.sqrt(var + 1e-5) * gp[s] + bp[s])
+    yr = F.leaky_relu(torch.stack(outs) + rf, 0.01)
     assert rel_err(mean, xf.mean(1)) < 1e-4
     assert rel_err(y, yr) < TOL[dtype]
     dy = rnd(B, S, C, dtype=dtype, seed=7)
-    yr.backward(dy.float())
+    yr.backward(dy.double())
     dg = [torch.zeros(C, device=DEV) for _ in range(2)]
     db = [torch.zeros(C, device=DEV) for _ in range(2)]
     dx, dres = ops.instnorm_bwd(dy, y, x, B, S, mean, rstd, styles, gam, dg, db, act=L.ACT_LEAKY, slope=0.01, want_dres=True)
@@ -85,7 +87,7 @@ def test_layernorm(dtype):
     x = rnd(777, 96, dtype=dtype, seed=11)
     g, b = rnd(96, seed=12) * 0.2 + 1, rnd(96, seed=13) * 0.1
     y, mean, rstd = ops.layernorm_fwd(x, g, b)
-    xf = x.float().requires_grad_(True)
+    xf = x.float().clone().requires_grad_(True)
     gp, bp = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
     yr = F.layer_norm(xf, (96,), gp, bp)
     assert rel_err(y, yr) < TOL[dtype]
@@ -154,7 +156,7 @@ def test_conv3_fwd_dgrad_wgrad(dtype, B, D, H, W, Cin, Cout):
     x, w = _conv_case(dtype, B, D, H, W, Cin, Cout)
     fwdp, bwdp = ops.pack_conv3(w, dtype)
     y = ops.conv3_fwd(x, fwdp, Cout)
-    xr = x.float().permute(0, 4, 1, 2, 3).requires_grad_(True)
+    xr = x.float().clone().permute(0, 4, 1, 2, 3).requires_grad_(True)
     wr = w.clone().requires_grad_(True)
     wq = wr.to(dtype).float() if dtype == torch.bfloat16 else wr
     yr = F.conv3d(xr, wq, padding=1)
@@ -231,7 +233,7 @@ def test_space_channel_im2col_misc(dtype):
         yr = torch.cat([xp[:, i::2, j::2, k::2, :] for (i, j, k) in offs], -1)
         assert torch.equal(y, yr)
         g = rnd(*y.shape, dtype=dtype, seed=72)
-        xr = x.float().requires_grad_(True)
+        xr = x.float().clone().requires_grad_(True)
         xpr = F.pad(xr, (0, 0, 0, 1, 0, 0, 0, 1))
         torch.cat([xpr[:, i::2, j::2, k::2, :] for (i, j, k) in offs], -1).backward(g.float())
         dx = ops.channel_to_space(g, offs, tuple(x.shape))
@@ -242,7 +244,7 @@ def test_space_channel_im2col_misc(dtype):
     ref = torch.cat([xp[:, a:a + 5, b:b + 6, c:c + 7, :] for a in range(3) for b in range(3) for c in range(3)], -1)
     assert torch.equal(col, ref)
     back = ops.im2col3(col, adjoint=True)
-    xr = x.float().requires_grad_(True)
+    xr = x.float().clone().requires_grad_(True)
     xpr = F.pad(xr, (0, 0, 1, 1, 1, 1, 1, 1))
     torch.cat([xpr[:, a:a + 5, b:b + 6, c:c + 7, :] for a in range(3) for b in range(3) for c in range(3)], -1).backward(col.float())
     assert rel_err(back, xr.grad) < TOL[dtype]
@@ -250,7 +252,7 @@ def test_space_channel_im2col_misc(dtype):
     a, b = rnd(100, 48, dtype=dtype, seed=73), rnd(100, 48, dtype=dtype, seed=74)
     assert rel_err(ops.add(a, b), a.float() + b.float()) < TOL[dtype]
     assert rel_err(ops.gelu_fwd(a), F.gelu(a.float())) < TOL[dtype]
-    af = a.float().requires_grad_(True)
+    af = a.float().clone().requires_grad_(True)
     F.gelu(af).backward(b.float())
     assert rel_err(ops.gelu_bwd(b, a), af.grad) < TOL[dtype]
     assert rel_err(ops.colsum(a), a.float().sum(0)) < TOL[dtype]

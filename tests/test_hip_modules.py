@@ -5,7 +5,7 @@ import copy
 import pytest
 import torch
 
-from conftest import rel_err, sample, state_from_meta
+from conftest import compare_grads, rel_err, sample, state_from_meta
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -31,10 +31,7 @@ def _norm(name):
 
 def _check_param_grads(module, want, none_list, tol):
     named = dict(module.named_parameters())
-    for k, g in want.items():
-        got = named[k].grad
-        assert got is not None, k
-        assert rel_err(got, g) < tol, (k, rel_err(got, g))
+    compare_grads({k: p.grad for k, p in named.items()}, want, tol)
     for k in none_list:
         assert named[k].grad is None, f"{k} must have no gradient"
 
@@ -174,16 +171,12 @@ def _whole(G, tag, model, tol, dtype=torch.float32):
     e = rel_err(sample(y), G.t(f"{tag}/logits_samples"))
     assert e < tol, ("logits", e)
     y.backward(det_input(4321, tuple(y.shape)).to(DEV))
-    gn = G.gnorms(tag)
     named = dict(model.named_parameters())
-    worst = ("", 0.0)
-    for k, g in G.grads(tag).items():
-        got = named[k].grad
-        assert got is not None, k
-        e = rel_err(sample(got), g)
-        if e > worst[1]:
-            worst = (k, e)
-    assert worst[1] < 5 * tol, worst
+    worst = compare_grads({k: p.grad for k, p in named.items()}, G.grads(tag), 5 * tol, sampled=True,
+                          vanish_tol=1e-2 if dtype == torch.float32 else 0.5,
+                          # 1-channel 1x1x1 conv in front of an instance norm: d/dw == 0 analytically (the norm removes the
+                          # per-channel scale), so in bf16 the value is rounding noise of either implementation
+                          skip=() if dtype == torch.float32 else ("encoder1.layer.conv3.conv.weight",))
     none = [k for k, p in named.items() if p.grad is None]
     assert sorted(none) == sorted(case["grad_none"])
     return worst
