@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -81,17 +82,27 @@ def main():
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     model = build_model(dtype)
     from mi_seg_amd.data.sampler import rank_indices
+    from mi_seg_amd.hip import ops
     pool, mods = synthetic_pool(16, 1000 + rank, dev)
     order = rank_indices(len(mods), world_size=1, rank=0, epoch=rank, seed=0)   # per-rank pool, interleaved CT/MR stream
     cot = torch.randn(1, 6, 96, 96, 96, generator=torch.Generator().manual_seed(4321)).to(dev)
     params = [p for p in model.parameters() if p.requires_grad]
 
-    def step(i):
+    graphed = None
+    if not a.no_graph:
+        from mi_seg_amd.runtime.graph import GraphedStep
+        graphed = GraphedStep(model, (1, 1, 96, 96, 96), (1, 6, 96, 96, 96))
+
+    def step(i, eager=False):
         k = order[i % len(order)]
-        for p in params:
-            p.grad = None
-        y = model(pool[k:k + 1], [mods[k]])
-        y.backward(cot)
+        if graphed is not None and not eager:
+            graphed(pool[k:k + 1], [mods[k]], cot)
+        else:
+            ops.begin_step()
+            for p in params:
+                p.grad = None
+            y = model(pool[k:k + 1], [mods[k]])
+            y.backward(cot)
         if dist is not None:
             from mi_seg_amd.parallel.ddp import allreduce_gradients
             allreduce_gradients(params, world)
@@ -116,14 +127,14 @@ def main():
     out = {
         "metric": "96^3 patches/sec fwd+bwd, C-Swin-UNETR fs=48 6-class", "value": world * a.steps / dt, "unit": "patches/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1000 * dt / a.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic", "launch": "eager" if graphed is None else "hipGraph",
         "config": {"workload": "configs[1]: C-Swin-UNETR feature_size=48 heads=(3,6,12,24) instance_cond, 96^3 patch, 6 classes, "
                                "batch 1 per GPU, fwd+bwd (+ gradient all-reduce at N>1)", "global_batch": world},
     }
     if rank == 0:
         if not a.no_roofline:
             from mi_seg_amd.testing.roofline import profile_step, summarize
-            out["roofline"] = summarize(profile_step(lambda: step(a.warmup + a.steps)), dtype)
+            out["roofline"] = summarize(profile_step(lambda: step(a.warmup + a.steps, eager=True)), dtype)
         if world == 1 and not a.no_cpu_baseline:
             from mi_seg_amd.testing.cpu_baseline import cpu_baseline
             out["cpu_baseline"] = cpu_baseline()

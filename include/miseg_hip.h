@@ -45,14 +45,15 @@ int miseg_device_arch(char* buf, size_t n);
  *   styles: device int32[B] or NULL (=> row 0); gamma/beta[s]: fp32[C] per style or NULL (no affine).
  *   y = act((x - mean) * rstd * gamma[s] + beta[s] + res)
  * ---------------------------------------------------------------------------------------------- */
+/* statistics are kept as fp64 (sum x, sum x^2) pairs: stat is double[B][C][2] (miseg_instnorm_stat_bytes); the CALLER
+ * zero-fills it (the host pools all statistics buffers of a step behind one fill), miseg_instnorm_stats accumulates into it
+ * with fp64 atomics; apply / backward derive mean and 1/sqrt(var+eps) from it. */
+size_t miseg_instnorm_stat_bytes(int B, int C);
 typedef struct {
   const void* x; int64_t ldx;
   int B, S, C, dtype;
-  float eps;
-  float* mean; float* rstd;       /* out, fp32 [B][C] */
-  void* workspace;                /* miseg_instnorm_workspace_bytes */
+  void* stat;                      /* in/out: double [B][C][2], zero on entry */
 } miseg_instnorm_stats_params;
-size_t miseg_instnorm_workspace_bytes(int B, int S, int C);
 int miseg_instnorm_stats(const miseg_instnorm_stats_params* p, miseg_stream_t stream);
 
 typedef struct {
@@ -60,7 +61,7 @@ typedef struct {
   const void* res; int64_t ldres;  /* optional residual added before the activation */
   void* y; int64_t ldy;
   int B, S, C, dtype;
-  const float* mean; const float* rstd;
+  const void* stat; float eps;
   const int32_t* styles; int num_styles;
   const float* gamma[MISEG_MAX_STYLES]; const float* beta[MISEG_MAX_STYLES];
   int act; float slope;            /* MISEG_ACT_NONE | MISEG_ACT_LEAKY */
@@ -69,7 +70,8 @@ int miseg_instnorm_apply(const miseg_instnorm_apply_params* p, miseg_stream_t st
 
 /* backward of the fused op above.  dy is the gradient w.r.t. y; when act != NONE, y (the saved output)
  * supplies the sign for the activation gradient.  Outputs: dx, optionally dres (= gradient flowing to the
- * residual input), dgamma/dbeta[s] (ACCUMULATED with atomics: caller zero-fills once per step). */
+ * residual input), dgamma/dbeta[s] (ACCUMULATED with atomics: caller zero-fills once per step).
+ * dstat: scratch double [B][C][2], zero on entry. */
 typedef struct {
   const void* dy; int64_t lddy;
   const void* y; int64_t ldy;
@@ -77,12 +79,11 @@ typedef struct {
   void* dx; int64_t lddx;
   void* dres; int64_t lddres;
   int B, S, C, dtype;
-  const float* mean; const float* rstd;
+  const void* stat; float eps; void* dstat;
   const int32_t* styles; int num_styles;
   const float* gamma[MISEG_MAX_STYLES];
   float* dgamma[MISEG_MAX_STYLES]; float* dbeta[MISEG_MAX_STYLES];
   int act; float slope;
-  void* workspace;                 /* miseg_instnorm_workspace_bytes */
 } miseg_instnorm_bwd_params;
 int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stream_t stream);
 
@@ -144,7 +145,10 @@ int miseg_colsum(const miseg_colsum_params* p, miseg_stream_t stream);
 typedef struct {
   const void* x; int64_t ldx; void* y; int64_t ldy; const void* wpk;
   int B, D, H, W, Cin, Cout, dtype;
+  void* workspace;                 /* miseg_conv3_fwd_workspace_bytes (0 bytes for most shapes: may be NULL then) */
 } miseg_conv3_params;
+/* small grids split the reduction over workgroups and need an fp32 staging buffer of the output */
+size_t miseg_conv3_fwd_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int dtype);
 int miseg_conv3_fwd(const miseg_conv3_params* p, miseg_stream_t stream);
 
 /* w: fp32 torch layout [Cout][Cin][3][3][3].  fwd_pack: [Cout][27][Cin]; bwd_pack: [Cin][27][Cout] with taps

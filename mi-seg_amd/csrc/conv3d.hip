@@ -152,6 +152,178 @@ __global__ void __launch_bounds__(256) conv3_fwd_kernel(const T* __restrict__ x,
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// forward, fast path: channel chunks of exactly 96 bytes (6 groups per tap: 48 bf16 / 24 fp32 channels), weights
+// staged through LDS in phases of 2 taps (12 groups = 3 MFMA k-steps) shared by the 4 waves, next phase's weights
+// prefetched into registers while the current phase computes.  LDS: halo 600 x 112 B + weights 16NT x 208 B.
+// ---------------------------------------------------------------------------------------------------------
+template <class T, int NT>
+__global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, const T* __restrict__ wpk,
+                                                             ConvGeom g, int Cin, int CinP, int Cout, bool vec_x, float* __restrict__ scratch,
+                                                             int chunks_per_split) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int KPC = MmaC<T>::KPC;
+  constexpr int GPT = 6, CHUNK = GPT * KPC;          // elements per chunk
+  constexpr int ROWB = 112, WROWB = 208;               // padded LDS row strides (bytes)
+  constexpr int HROWS = (BD + 2) * HH * HW;
+  constexpr int NROWS = 16 * NT;
+  constexpr int WLOADS = (NROWS * 12 + 255) / 256;     // 16-byte weight loads per thread per phase
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* lh = lds;                    // halo
+  char* lw = lds + HROWS * ROWB;     // weights of the current phase
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  const int bw = bid % g.nbw; bid /= g.nbw;
+  const int bh = bid % g.nbh; bid /= g.nbh;
+  const int bd = bid % g.nbd;
+  const int b = bid / g.nbd;
+  const int d0 = bd * BD, h0 = bh * BH, w0 = bw * BW;
+  const int n0 = blockIdx.y * NROWS;
+  const int fi = lane & 15, fq = lane >> 4;
+
+  int vbase[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) vbase[mt] = ((wave * HH + 2 * mt + (fi >> 3)) * HW + (fi & 7)) * ROWB;
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // per-thread weight-load slots of a phase: idx -> (row, grp)
+  int wrow[WLOADS], wgrp[WLOADS];
+  const T* wsrc[WLOADS];
+#pragma unroll
+  for (int i = 0; i < WLOADS; ++i) {
+    const int idx = tid + 256 * i;
+    wrow[i] = idx / 12;
+    wgrp[i] = idx - wrow[i] * 12;
+    const int co = n0 + wrow[i];
+    const bool ok = idx < NROWS * 12 && co < Cout;
+    // element offset of (tap 0 or 1 of the phase, cg) relative to the phase base
+    wsrc[i] = ok ? wpk + (int64_t)co * 27 * CinP + (wgrp[i] / GPT) * CinP + (wgrp[i] % GPT) * KPC : nullptr;
+  }
+  VT wreg[WLOADS];
+  auto wload = [&](int phase, int c0) {
+#pragma unroll
+    for (int i = 0; i < WLOADS; ++i) {
+      VT v;
+#pragma unroll
+      for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(0.f);
+      const bool second_tap = wgrp[i] >= GPT;
+      if (wsrc[i] && !(second_tap && 2 * phase + 1 >= 27)) v = *reinterpret_cast<const VT*>(wsrc[i] + (int64_t)(2 * phase) * CinP + c0);
+      wreg[i] = v;
+    }
+  };
+  auto wstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < WLOADS; ++i)
+      if (tid + 256 * i < NROWS * 12) *reinterpret_cast<VT*>(lw + wrow[i] * WROWB + wgrp[i] * 16) = wreg[i];
+  };
+  // static per-lane k-step geometry inside a phase: group gi = 4*s + fq -> (tap select, byte offset of its channel group)
+  const int sel1 = fq >= 2;                      // step 1: groups 4..7 -> tap0 cg 4,5 | tap1 cg 0,1
+  const int cgo0 = fq * 16;                      // step 0: tap0 cg 0..3
+  const int cgo1 = (sel1 ? fq - 2 : fq + 4) * 16;
+  const int cgo2 = (fq + 2) * 16;                // step 2: tap1 cg 2..5
+
+  const int cbeg = blockIdx.z * chunks_per_split * CHUNK, cend = min(CinP, cbeg + chunks_per_split * CHUNK);
+  for (int c0 = cbeg; c0 < cend; c0 += CHUNK) {
+    wload(0, c0);
+    __syncthreads();   // previous chunk's readers are done with halo + weights
+    for (int idx = tid; idx < HROWS * GPT; idx += 256) {
+      const int row = idx / GPT, cg = idx - row * GPT;
+      const int hd = row / (HH * HW), rem = row - hd * (HH * HW);
+      const int hh = rem / HW, hw = rem - hh * HW;
+      const int d = d0 - 1 + hd, h = h0 - 1 + hh, w = w0 - 1 + hw;
+      VT v;
+#pragma unroll
+      for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(0.f);
+      if (d >= 0 && d < g.D && h >= 0 && h < g.H && w >= 0 && w < g.W) {
+        const int c = c0 + cg * KPC;
+        const T* p = x + ((((int64_t)b * g.D + d) * g.H + h) * g.W + w) * ldx + c;
+        if (vec_x && c + KPC <= Cin) v = *reinterpret_cast<const VT*>(p);
+        else {
+#pragma unroll
+          for (int e = 0; e < KPC; ++e)
+            if (c + e < Cin) v[e] = p[e];
+        }
+      }
+      *reinterpret_cast<VT*>(lh + row * ROWB + cg * 16) = v;
+    }
+    wstore();
+    __syncthreads();
+#pragma unroll 1
+    for (int phase = 0; phase < 14; ++phase) {
+      if (phase + 1 < 14) wload(phase + 1, c0);
+      const int t0 = 2 * phase, t1 = (2 * phase + 1 < 27) ? 2 * phase + 1 : 2 * phase;   // last phase: 2nd tap has zero weights
+      const int toff0 = (((t0 / 9) * HH + (t0 / 3) % 3) * HW + t0 % 3) * ROWB;
+      const int toff1 = (((t1 / 9) * HH + (t1 / 3) % 3) * HW + t1 % 3) * ROWB;
+      const int nsteps = phase == 13 ? 2 : 3;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        if (s < nsteps) {
+          const int aoff = (s == 0 ? toff0 + cgo0 : s == 1 ? (sel1 ? toff1 : toff0) + cgo1 : toff1 + cgo2);
+          VT bfr[NT], af[4];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bfr[nt] = *reinterpret_cast<const VT*>(lw + (nt * 16 + fi) * WROWB + (4 * s + fq) * 16);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const VT*>(lh + vbase[mt] + aoff);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) MmaC<T>::run(acc[mt][nt], bfr[nt], af[mt]);
+        }
+      }
+      if (phase + 1 < 14) {
+        __syncthreads();
+        wstore();
+        __syncthreads();
+      }
+    }
+  }
+  const int d = d0 + wave;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int h = h0 + 2 * mt + (fi >> 3), w = w0 + (fi & 7);
+    if (d < g.D && h < g.H && w < g.W) {
+      const int64_t vox = (((int64_t)b * g.D + d) * g.H + h) * g.W + w;
+      if (scratch) {   // split over channel chunks: fp32 partial sums, converted by a second kernel
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int co = n0 + nt * 16 + fq * 4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (co + r < Cout) atomicAdd(scratch + vox * Cout + co + r, acc[mt][nt][r]);
+        }
+        continue;
+      }
+      T* yr = y + vox * ldy;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co = n0 + nt * 16 + fq * 4;
+        if (co + 3 < Cout) {
+          if constexpr (std::is_same<T, bf16>::value) {
+            bf16x4 o{(bf16)acc[mt][nt][0], (bf16)acc[mt][nt][1], (bf16)acc[mt][nt][2], (bf16)acc[mt][nt][3]};
+            *reinterpret_cast<bf16x4*>(yr + co) = o;
+          } else {
+            *reinterpret_cast<f32x4*>(yr + co) = acc[mt][nt];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (co + r < Cout) yr[co + r] = from_f32<T>(acc[mt][nt][r]);
+        }
+      }
+    }
+  }
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) conv3_scratch_to_out_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t ldd, int64_t rows, int C) {
+  const int64_t total = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) dst[(i / C) * ldd + i % C] = from_f32<T>(src[i]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // weight packing:  fwd[co][tap][ciP] = w[co][ci][tap] ; bwd[ci][tap][coP] = w[co][ci][26 - tap]   (zero padded)
 // ---------------------------------------------------------------------------------------------------------
 template <class T>
@@ -338,22 +510,42 @@ __global__ void __launch_bounds__(WG_THREADS) conv3_wgrad_kernel(const T* __rest
   }
 }
 
-// dw[co][ci][tap] (+)= sum_split slab[pair(co,ci)][split][tap][co%48][ci%48]
+// dw[co][ci0..+48][tap] += sum over this group's splits of slab[pair][split][tap][co%48][0..48).
+// block = (co, ci block, split group): slab reads are 192-byte runs, the 48x27 result is transposed through LDS so the
+// atomics land on one contiguous 5 KB run of the torch-layout gradient.
 __global__ void __launch_bounds__(256) conv3_wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int Cin, int Cout, int ncib, int nsplit,
-                                                                 int accumulate) {
-  const int64_t total = (int64_t)Cout * Cin * 27;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    // iterate in slab-friendly order: (co, tap, ci) with ci fastest
-    const int ci = (int)(i % Cin);
-    const int tap = (int)((i / Cin) % 27);
-    const int co = (int)(i / ((int64_t)Cin * 27));
-    const int pair = (co / WG_CB) * ncib + ci / WG_CB;
-    const float* s = slabs + (int64_t)pair * nsplit * 27 * WG_CB * WG_CB + ((int64_t)tap * WG_CB + co % WG_CB) * WG_CB + ci % WG_CB;
-    float acc = 0.f;
-    for (int k = 0; k < nsplit; ++k) acc += s[(int64_t)k * 27 * WG_CB * WG_CB];
-    float* o = dw + ((int64_t)co * Cin + ci) * 27 + tap;
-    *o = accumulate ? *o + acc : acc;
+                                                                 int splits_per_group) {
+  __shared__ float tile[WG_CB * 28];
+  constexpr int64_t SLAB = 27 * WG_CB * WG_CB;
+  constexpr int NE = 27 * WG_CB;            // elements of one (co, ci-block) tile
+  const int co = blockIdx.x / ncib, cib = blockIdx.x % ncib;
+  const int pair = (co / WG_CB) * ncib + cib;
+  const int k0 = blockIdx.y * splits_per_group, k1 = min(nsplit, k0 + splits_per_group);
+  const float* base = slabs + (int64_t)pair * nsplit * SLAB + (int64_t)(co % WG_CB) * WG_CB;
+  float acc[6];
+  int off[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int e = threadIdx.x + 256 * j;   // (tap, cil) with cil fastest
+    acc[j] = 0.f;
+    off[j] = e < NE ? (e / WG_CB) * WG_CB * WG_CB + e % WG_CB : -1;
   }
+  for (int k = k0; k < k1; ++k) {
+    const float* s = base + (int64_t)k * SLAB;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      if (off[j] >= 0) acc[j] += s[off[j]];
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int e = threadIdx.x + 256 * j;
+    if (e < NE) tile[(e % WG_CB) * 28 + e / WG_CB] = acc[j];
+  }
+  __syncthreads();
+  const int ci0 = cib * WG_CB;
+  const int nci = min(WG_CB, Cin - ci0);
+  float* out = dw + ((int64_t)co * Cin + ci0) * 27;
+  for (int o = threadIdx.x; o < nci * 27; o += 256) atomicAdd(out + o, tile[(o / 27) * 28 + o % 27]);
 }
 
 }  // namespace miseg
@@ -362,23 +554,77 @@ using namespace miseg;
 
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
+// fast-path plan: output-channel tiles per block and the split over 96-byte channel chunks (small grids)
+static void fwd96_plan(int nbricks, int Cout, int nchunks, int* nt, int* ksplit) {
+  *nt = Cout <= 16 ? 1 : Cout <= 32 ? 2 : 3;
+  int blocks = nbricks * cdiv(Cout, 16 * (*nt));
+  if (blocks < 256 && *nt > 1) { *nt = 1; blocks = nbricks * cdiv(Cout, 16); }
+  int ks = 1;
+  if (blocks < 256 && nchunks > 1) {
+    ks = cdiv(512, blocks);
+    if (ks > nchunks) ks = nchunks;
+  }
+  *ksplit = ks;
+}
+
+extern "C" size_t miseg_conv3_fwd_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int dtype) {
+  const int esz = dtype == MISEG_F32 ? 4 : 2, kpc = 16 / esz;
+  const int rowbytes = round_up(Cin, kpc) * esz;
+  if (rowbytes % 96 != 0) return 0;
+  int nt, ks;
+  fwd96_plan(B * cdiv(D, BD) * cdiv(H, BH) * cdiv(W, BW), Cout, rowbytes / 96, &nt, &ks);
+  return ks > 1 ? (size_t)B * D * H * W * Cout * sizeof(float) : 0;
+}
+
 template <class T>
 static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
   constexpr int KPC = Vec16<T>::N;
   const int CinP = round_up(p->Cin, KPC);
   const int rowbytes = CinP * (int)sizeof(T);
+  ConvGeom g{p->B, p->D, p->H, p->W, cdiv(p->D, BD), cdiv(p->H, BH), cdiv(p->W, BW)};
+  const int nbricks = g.B * g.nbd * g.nbh * g.nbw;
+  const bool vec_x = ((uintptr_t)p->x % 16 == 0) && (p->ldx % KPC == 0);
+  // ---- fast path: 96-byte channel chunks, weights through LDS (needs 4-channel-aligned stores: ldy % 4)
+  if (rowbytes % 96 == 0 && ((uintptr_t)p->y % 16 == 0) && (p->ldy % KPC == 0) && p->Cout % 4 == 0) {
+    int nt, ksplit;
+    const int nchunks = rowbytes / 96;
+    fwd96_plan(nbricks, p->Cout, nchunks, &nt, &ksplit);
+    const int cps = cdiv(nchunks, ksplit);
+    ksplit = cdiv(nchunks, cps);
+    float* scratch = nullptr;
+    const int64_t nvox = (int64_t)p->B * p->D * p->H * p->W;
+    if (ksplit > 1) {
+      MISEG_REQUIRE(p->workspace, MISEG_E_BADARG, "conv3_fwd: workspace required (miseg_conv3_fwd_workspace_bytes)");
+      scratch = (float*)p->workspace;
+      MISEG_REQUIRE(hipMemsetAsync(scratch, 0, (size_t)nvox * p->Cout * sizeof(float), s) == hipSuccess, MISEG_E_LAUNCH, "conv3_fwd: memset");
+    }
+    const size_t lds = (size_t)(BD + 2) * HH * HW * 112 + (size_t)16 * nt * 208;
+    dim3 grid(nbricks, cdiv(p->Cout, 16 * nt), ksplit);
+#define F96_CASE(n)                                                                                                                          \
+  case n:                                                                                                                                   \
+    hipFuncSetAttribute((const void*)conv3_fwd96_kernel<T, n>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+    conv3_fwd96_kernel<T, n><<<grid, 256, lds, s>>>((const T*)p->x, p->ldx, (T*)p->y, p->ldy, (const T*)p->wpk, g, p->Cin, CinP, p->Cout, vec_x, \
+                                                    scratch, cps);                                                                          \
+    break;
+    switch (nt) { F96_CASE(1) F96_CASE(2) F96_CASE(3) }
+#undef F96_CASE
+    if (scratch) {
+      int cg = (int)((nvox * p->Cout + 255) / 256);
+      if (cg > 4096) cg = 4096;
+      conv3_scratch_to_out_kernel<T><<<cg, 256, 0, s>>>(scratch, (T*)p->y, p->ldy, nvox, p->Cout);
+    }
+    MISEG_LAUNCH_CHECK("conv3_fwd96");
+    return MISEG_OK;
+  }
   int chunk_bytes;
   if (rowbytes <= 128) chunk_bytes = rowbytes;
-  else if (rowbytes % 96 == 0) chunk_bytes = 96;
   else if (rowbytes % 128 == 0) chunk_bytes = 128;
   else chunk_bytes = 64;
   const int chunk_elems = chunk_bytes / (int)sizeof(T);
   const int rowb = chunk_bytes + 16;
-  ConvGeom g{p->B, p->D, p->H, p->W, cdiv(p->D, BD), cdiv(p->H, BH), cdiv(p->W, BW)};
   const size_t lds = (size_t)(BD + 2) * HH * HW * rowb;
-  const bool vec_x = ((uintptr_t)p->x % 16 == 0) && (p->ldx % KPC == 0);
   const int nt = p->Cout <= 16 ? 1 : p->Cout <= 32 ? 2 : p->Cout <= 48 ? 3 : p->Cout <= 64 ? 4 : (p->Cout % 96 == 0 || p->Cout > 128) ? 6 : 4;
-  dim3 grid(g.B * g.nbd * g.nbh * g.nbw, cdiv(p->Cout, 16 * nt));
+  dim3 grid(nbricks, cdiv(p->Cout, 16 * nt));
 #define FWD_CASE(n)                                                                                                                             \
   case n:                                                                                                                                       \
     hipFuncSetAttribute((const void*)conv3_fwd_kernel<T, n>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
@@ -421,7 +667,7 @@ static void wgrad_plan(int B, int D, int H, int W, int Cin, int Cout, int wbd, i
   *ncib = cdiv(Cin, WG_CB);
   const int nbricks = B * cdiv(D, wbd) * cdiv(H, BH) * cdiv(W, BW);
   int pairs = (*ncob) * (*ncib);
-  int ns = 512 / pairs;
+  int ns = 256 / pairs;
   if (ns < 1) ns = 1;
   if (ns > nbricks) ns = nbricks;
   *nsplit = ns;
@@ -450,9 +696,13 @@ static int conv3_wgrad_launch(const miseg_conv3_wgrad_params* p, hipStream_t s) 
   conv3_wgrad_kernel<T, WBD><<<grid, WG_THREADS, lds, s>>>((const T*)p->x, p->ldx, (const T*)p->dy, p->lddy, (float*)p->workspace, g, p->Cin, p->Cout, ncib, nsplit,
                                                            rowb, vec_x, vec_dy);
   const int64_t total = (int64_t)p->Cout * p->Cin * 27;
-  int rg = (int)((total + 255) / 256);
-  if (rg > 2048) rg = 2048;
-  conv3_wgrad_reduce_kernel<<<rg, 256, 0, s>>>((const float*)p->workspace, p->dw, p->Cin, p->Cout, ncib, nsplit, p->accumulate);
+  if (!p->accumulate) MISEG_REQUIRE(hipMemsetAsync(p->dw, 0, (size_t)total * sizeof(float), s) == hipSuccess, MISEG_E_LAUNCH, "conv3_wgrad: memset");
+  const int tiles = p->Cout * ncib;
+  int groups = cdiv(1024, tiles);
+  if (groups > nsplit) groups = nsplit;
+  const int spg = cdiv(nsplit, groups);
+  groups = cdiv(nsplit, spg);
+  conv3_wgrad_reduce_kernel<<<dim3(tiles, groups), 256, 0, s>>>((const float*)p->workspace, p->dw, p->Cin, p->Cout, ncib, nsplit, spg);
   MISEG_LAUNCH_CHECK("conv3_wgrad");
   return MISEG_OK;
 }

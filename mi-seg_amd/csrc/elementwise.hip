@@ -376,7 +376,8 @@ __global__ void __launch_bounds__(256) conv3_thin_wgrad_kernel(const float* __re
 }
 
 // ----------------------------------------------------------------------------- output head (1x1x1 + bias -> NCDHW fp32)
-template <class T>
+// thread = voxel: the channels-last row is read once in 16-byte pieces; weights [Cout][Cin] are LDS broadcasts.
+template <class T, int VEC>
 __global__ void __launch_bounds__(256) head_fwd_kernel(const T* __restrict__ x, int64_t ldx, float* __restrict__ y, const float* __restrict__ w,
                                                        const float* __restrict__ bias, int B, int S, int Cin, int Cout) {
   extern __shared__ float ws[];  // [Cout][Cin] + bias
@@ -388,15 +389,27 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(const T* __restrict__ x, 
     const int b = (int)(v / S);
     const int64_t s = v % S;
     const T* xr = x + v * ldx;
-    for (int co = 0; co < Cout; ++co) {
-      float acc = ws[Cout * Cin + co];
-      for (int ci = 0; ci < Cin; ++ci) acc = fmaf(to_f32(xr[ci]), ws[co * Cin + ci], acc);
-      y[((int64_t)b * Cout + co) * S + s] = acc;
+    float acc[16];
+#pragma unroll
+    for (int co = 0; co < 16; ++co) acc[co] = co < Cout ? ws[Cout * Cin + co] : 0.f;
+    for (int c0 = 0; c0 < Cin; c0 += VEC) {
+      V<T, VEC> xv;
+      xv.load(xr + c0);
+#pragma unroll
+      for (int co = 0; co < 16; ++co) {
+        if (co < Cout) {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) acc[co] = fmaf(xv.v[k], ws[co * Cin + c0 + k], acc[co]);
+        }
+      }
     }
+#pragma unroll
+    for (int co = 0; co < 16; ++co)
+      if (co < Cout) y[((int64_t)b * Cout + co) * S + s] = acc[co];
   }
 }
 
-template <class T>
+template <class T, int VEC>
 __global__ void __launch_bounds__(256) head_bwd_dx_kernel(const float* __restrict__ dy, T* __restrict__ dx, int64_t lddx, const float* __restrict__ w, int B, int S,
                                                           int Cin, int Cout) {
   extern __shared__ float ws[];  // [Cout][Cin]
@@ -407,12 +420,20 @@ __global__ void __launch_bounds__(256) head_bwd_dx_kernel(const float* __restric
     const int b = (int)(v / S);
     const int64_t s = v % S;
     float g[16];
-    for (int co = 0; co < Cout; ++co) g[co] = dy[((int64_t)b * Cout + co) * S + s];
+#pragma unroll
+    for (int co = 0; co < 16; ++co) g[co] = co < Cout ? dy[((int64_t)b * Cout + co) * S + s] : 0.f;
     T* dr = dx + v * lddx;
-    for (int ci = 0; ci < Cin; ++ci) {
-      float acc = 0.f;
-      for (int co = 0; co < Cout; ++co) acc = fmaf(g[co], ws[co * Cin + ci], acc);
-      dr[ci] = from_f32<T>(acc);
+    for (int c0 = 0; c0 < Cin; c0 += VEC) {
+      V<T, VEC> o;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        float acc = 0.f;
+#pragma unroll
+        for (int co = 0; co < 16; ++co)
+          if (co < Cout) acc = fmaf(g[co], ws[co * Cin + c0 + k], acc);
+        o.v[k] = acc;
+      }
+      o.store(dr + c0);
     }
   }
 }
@@ -519,31 +540,35 @@ __global__ void __launch_bounds__(256) col2im3_kernel(const T* col, int64_t ldc,
 }
 
 // ----------------------------------------------------------------------------- column sums
-template <class T>
-__global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, int64_t ldx, int64_t rows, int C, float* __restrict__ out, int rows_per_block) {
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) s += to_f32(x[r * ldx + c]);
-    atomicAdd(out + c, s);
-  }
-}
-// many rows, few channels: thread (ty, c) strides rows, LDS reduce
-template <class T>
-__global__ void __launch_bounds__(256) colsum_tall_kernel(const T* __restrict__ x, int64_t ldx, int64_t rows, int C, float* __restrict__ out, int rows_per_block) {
-  __shared__ float red[256];
-  const int tx_n = C, ty_n = 256 / C;
+// grid (row chunks, channel tiles); tx = 16-byte channel vector, ty walks rows; LDS reduce; one atomic per channel.
+template <class T, int VEC>
+__global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, int64_t ldx, int64_t rows, int C, int cv, int tx_n, int ty_n,
+                                                     float* __restrict__ out, int rows_per_block) {
+  extern __shared__ float red[];
   const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
+  const int c0 = blockIdx.y * tx_n, c = c0 + tx;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-  float s = 0.f;
-  if (ty < ty_n)
-    for (int64_t r = r0 + ty; r < r1; r += ty_n) s += to_f32(x[r * ldx + tx]);
-  red[threadIdx.x] = (ty < ty_n) ? s : 0.f;
+  float s[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s[i] = 0.f;
+  if (ty < ty_n && c < cv) {
+    for (int64_t r = r0 + ty; r < r1; r += ty_n) {
+      V<T, VEC> v;
+      v.load(x + r * ldx + c * VEC);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) s[i] += v.v[i];
+    }
+  }
+  if (ty < ty_n) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) red[ty * tx_n * VEC + tx * VEC + i] = s[i];
+  }
   __syncthreads();
-  if (threadIdx.x < C) {
-    float a = 0.f;
-    for (int y = 0; y < ty_n; ++y) a += red[y * tx_n + threadIdx.x];
-    atomicAdd(out + threadIdx.x, a);
+  for (int e = threadIdx.x; e < tx_n * VEC; e += 256) {
+    float acc = 0.f;
+    for (int y = 0; y < ty_n; ++y) acc += red[y * tx_n * VEC + e];
+    const int ch = c0 * VEC + e;
+    if (ch < C) atomicAdd(out + ch, acc);
   }
 }
 
@@ -700,7 +725,11 @@ extern "C" int miseg_head_fwd(const miseg_head_params* p, miseg_stream_t s_) {
   MISEG_REQUIRE(p->Cout <= 16 && p->Cin * p->Cout <= 8192, MISEG_E_UNSUPPORTED, "head_fwd: Cout %d (max 16)", p->Cout);
   DT(p, {
     size_t sh = ((size_t)p->Cin * p->Cout + p->Cout) * sizeof(float);
-    head_fwd_kernel<T><<<ew_grid((int64_t)p->B * p->S), 256, sh, s>>>((const T*)p->x, p->ldx, p->y, p->w, p->bias, p->B, p->S, p->Cin, p->Cout);
+    constexpr int N = Vec16<T>::N;
+    if (p->Cin % N == 0 && p->ldx % N == 0 && al16(p->x))
+      head_fwd_kernel<T, N><<<ew_grid((int64_t)p->B * p->S), 256, sh, s>>>((const T*)p->x, p->ldx, p->y, p->w, p->bias, p->B, p->S, p->Cin, p->Cout);
+    else
+      head_fwd_kernel<T, 1><<<ew_grid((int64_t)p->B * p->S), 256, sh, s>>>((const T*)p->x, p->ldx, p->y, p->w, p->bias, p->B, p->S, p->Cin, p->Cout);
     MISEG_LAUNCH_CHECK("head_fwd");
   });
 }
@@ -713,7 +742,11 @@ extern "C" int miseg_head_bwd(const miseg_head_bwd_params* p, miseg_stream_t s_)
     const int64_t nv = (int64_t)p->B * p->S;
     if (p->dx) {
       size_t sh = (size_t)p->Cin * p->Cout * sizeof(float);
-      head_bwd_dx_kernel<T><<<ew_grid(nv), 256, sh, s>>>(p->dy, (T*)p->dx, p->lddx, p->w, p->B, p->S, p->Cin, p->Cout);
+      constexpr int N = Vec16<T>::N;
+      if (p->Cin % N == 0 && p->lddx % N == 0 && al16(p->dx))
+        head_bwd_dx_kernel<T, N><<<ew_grid(nv), 256, sh, s>>>(p->dy, (T*)p->dx, p->lddx, p->w, p->B, p->S, p->Cin, p->Cout);
+      else
+        head_bwd_dx_kernel<T, 1><<<ew_grid(nv), 256, sh, s>>>(p->dy, (T*)p->dx, p->lddx, p->w, p->B, p->S, p->Cin, p->Cout);
     }
     if (p->dw) {
       const int vpb = 2048;
@@ -751,13 +784,15 @@ extern "C" int miseg_colsum(const miseg_colsum_params* p, miseg_stream_t s_) {
     MISEG_REQUIRE(e == hipSuccess, MISEG_E_LAUNCH, "colsum: memset failed");
   }
   DT(p, {
-    if (p->C <= 128) {
-      const int rpb = 4096;
-      colsum_tall_kernel<T><<<cdiv(p->rows, rpb), 256, 0, s>>>((const T*)p->x, p->ldx, p->rows, p->C, p->out, rpb);
-    } else {
-      const int rpb = 64;
-      colsum_kernel<T><<<cdiv(p->rows, rpb), 256, 0, s>>>((const T*)p->x, p->ldx, p->rows, p->C, p->out, rpb);
-    }
+    constexpr int N = Vec16<T>::N;
+    const bool vec = p->C % N == 0 && p->ldx % N == 0 && al16(p->x);
+    const int cv = vec ? p->C / N : p->C;
+    const int tx = cv < 32 ? cv : 32, ty = 256 / tx;
+    const int rpb = p->rows >= 65536 ? 512 : 128;
+    dim3 grid(cdiv(p->rows, rpb), cdiv(cv, tx));
+    const size_t sh = (size_t)ty * tx * (vec ? N : 1) * sizeof(float);
+    if (vec) colsum_kernel<T, N><<<grid, 256, sh, s>>>((const T*)p->x, p->ldx, p->rows, p->C, cv, tx, ty, p->out, rpb);
+    else colsum_kernel<T, 1><<<grid, 256, sh, s>>>((const T*)p->x, p->ldx, p->rows, p->C, cv, tx, ty, p->out, rpb);
     MISEG_LAUNCH_CHECK("colsum");
   });
 }

@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const T* __restrict__ A, i
                                                       int M, int N, int K, int mode, bool vec_a, bool vec_b, int k_per_split) {
   typedef typename Vec16<T>::type VT;
   constexpr int KPC = Mma<T>::KPC;     // elements per 16-byte chunk (here along m / n)
-  constexpr int BM = 64, BN = 64, BK = 32;
+  constexpr int BM = 64, BN = 64, BK = std::is_same<T, bf16>::value ? 128 : 64;   // k rows per stage
   constexpr int ROWB = BM * (int)sizeof(T) + 16;   // bytes per k-row of a tile (padded)
   __shared__ __attribute__((aligned(16))) char lds[2 * BK * ROWB];
   char* lA = lds;
@@ -211,16 +211,19 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const T* __restrict__ A, i
     __syncthreads();
     if (k0 + BK < kend) gload(k0 + BK);
     if constexpr (std::is_same<T, bf16>::value) {
-      bf16x8 af[2], bfr[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        af[t] = TnFrag<bf16>::load(lA, ROWB, wm * 32 + t * 16, lane);
-        bfr[t] = TnFrag<bf16>::load(lB, ROWB, wn * 32 + t * 16, lane);
+      for (int ks = 0; ks < BK / 32; ++ks) {
+        bf16x8 af[2], bfr[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          af[t] = TnFrag<bf16>::load(lA + ks * 32 * ROWB, ROWB, wm * 32 + t * 16, lane);
+          bfr[t] = TnFrag<bf16>::load(lB + ks * 32 * ROWB, ROWB, wn * 32 + t * 16, lane);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[mt], acc[mt][nt], 0, 0, 0);
       }
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[mt], acc[mt][nt], 0, 0, 0);
     } else {
 #pragma unroll
       for (int kk = 0; kk < BK / 4; ++kk) {
@@ -292,7 +295,8 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
 #undef NT_CASE
   } else if (p->ta == 1 && p->tb == 1) {
     if (p->bias || p->act != MISEG_ACT_NONE) return set_error(MISEG_E_UNSUPPORTED, "gemm TN: no bias/act epilogue");
-    int kps = cdiv(cdiv(p->K, split), 32) * 32;
+    constexpr int TN_BK = std::is_same<T, bf16>::value ? 128 : 64;
+    int kps = cdiv(cdiv(p->K, split), TN_BK) * TN_BK;
     split = cdiv(p->K, kps);
     mode = split > 1 ? 2 : (p->accumulate ? 1 : 0);
     if (split > 1 && !p->accumulate) {

@@ -8,23 +8,30 @@
 namespace miseg {
 
 static constexpr int NORM_THREADS = 256;
-static constexpr int NORM_ROWS_PER_BLOCK = 1024;
+static constexpr int NORM_TX_MAX = 32;   // channel vectors per block (wider rows are tiled over blockIdx.z)
 
 struct NormGeom {
   int vec;      // elements per lane access (Vec16<T>::N or 1)
   int cv;       // channel vectors per row
   int tx, ty;   // thread grid inside a block
+  int rpb;      // rows per block
   int chunks;   // row chunks per sample
+  int ctiles;   // channel tiles
 };
 
-static NormGeom norm_geom(int S, int C, int64_t ld_all_or, const void* ptr_or, int vecN) {
+static NormGeom norm_geom(int S, int C, bool vec_ok, int vecN) {
   NormGeom g;
-  bool vec_ok = (C % vecN == 0) && (ld_all_or % vecN == 0) && (((uintptr_t)ptr_or) % 16 == 0);
-  g.vec = vec_ok ? vecN : 1;
+  g.vec = (vec_ok && C % vecN == 0) ? vecN : 1;
   g.cv = C / g.vec;
-  g.tx = g.cv < NORM_THREADS ? g.cv : NORM_THREADS;
+  g.tx = g.cv < NORM_TX_MAX ? g.cv : NORM_TX_MAX;
   g.ty = NORM_THREADS / g.tx;
-  g.chunks = cdiv(S, NORM_ROWS_PER_BLOCK);
+  g.ctiles = cdiv(g.cv, g.tx);
+  // enough workgroups to fill 256 CUs even on the small grids of the deep stages, >= 4 rows per lane
+  int rpb = cdiv(S, 256);
+  if (rpb < 4 * g.ty) rpb = 4 * g.ty;
+  if (rpb > 1024) rpb = 1024;
+  g.rpb = rpb;
+  g.chunks = cdiv(S, rpb);
   return g;
 }
 
@@ -51,183 +58,161 @@ template <class T, int VEC> struct RowVec {
   }
 };
 
+// block-level reduction over ty of two per-thread vectors, then one fp64 atomic per (channel, which) into
+// stat[b][ch][which] -- no finalize kernel, no workspace.
+template <int VEC>
+__device__ __forceinline__ void block_reduce_to_stat(float* red, const float* s, const float* q, int tx, int ty, int tx_n, int ty_n, int c0, int C,
+                                                     double* stat_b) {
+  if (ty < ty_n) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      red[(ty * 2 + 0) * tx_n * VEC + tx * VEC + i] = s[i];
+      red[(ty * 2 + 1) * tx_n * VEC + tx * VEC + i] = q[i];
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * tx_n * VEC; e += NORM_THREADS) {
+    const int which = e / (tx_n * VEC), col = e % (tx_n * VEC);
+    float acc = 0.f;
+    for (int y = 0; y < ty_n; ++y) acc += red[(y * 2 + which) * tx_n * VEC + col];
+    const int ch = c0 * VEC + col;
+    if (ch < C) atomicAdd(stat_b + 2 * ch + which, (double)acc);
+  }
+}
+
+__device__ __forceinline__ void mean_rstd(const double* stat_bc, int S, float eps, float& m, float& rs) {
+  const double mu = stat_bc[0] / S;
+  double var = stat_bc[1] / S - mu * mu;
+  if (var < 0.0) var = 0.0;
+  m = (float)mu;
+  rs = (float)(1.0 / sqrt(var + (double)eps));
+}
+
 // ---------------------------------------------------------------------------------------------------
-// stats: partial (sum, sumsq) per (b, chunk, c) -> workspace; finalize in fp64 -> mean, rstd
-// workspace layout: float ws[B][chunks][2][C]
+// stats: stat[b][c] += (sum x, sum x^2) over this block's rows      grid (chunks, B, ctiles)
 // ---------------------------------------------------------------------------------------------------
 template <class T, int VEC>
-__global__ void __launch_bounds__(NORM_THREADS) instnorm_stats_kernel(const T* __restrict__ x, int64_t ldx, int S, int C,
-                                                                      int cv, int tx_n, int ty_n, float* __restrict__ ws,
-                                                                      int chunks) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [ty][2][tx*VEC] per cv-iteration
-  const int b = blockIdx.y, chunk = blockIdx.x;
+__global__ void __launch_bounds__(NORM_THREADS) instnorm_stats_kernel(const T* __restrict__ x, int64_t ldx, int S, int C, int cv, int tx_n, int ty_n, int rpb,
+                                                                      double* __restrict__ stat) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int b = blockIdx.y, chunk = blockIdx.x, c0 = blockIdx.z * tx_n;
   const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
-  const int r0 = chunk * NORM_ROWS_PER_BLOCK;
-  const int r1 = min(S, r0 + NORM_ROWS_PER_BLOCK);
+  const int r0 = chunk * rpb, r1 = min(S, r0 + rpb);
   const T* xb = x + (int64_t)b * S * ldx;
-  float* out = ws + ((int64_t)(b * chunks + chunk) * 2) * C;
-  for (int c0 = 0; c0 < cv; c0 += tx_n) {
-    const int c = c0 + tx;
-    float s[VEC], q[VEC];
+  const int c = c0 + tx;
+  float s[VEC], q[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) s[i] = q[i] = 0.f;
-    if (ty < ty_n && c < cv) {
-      for (int r = r0 + ty; r < r1; r += ty_n) {
-        RowVec<T, VEC> v;
-        v.load(xb + (int64_t)r * ldx + c * VEC);
+  for (int i = 0; i < VEC; ++i) s[i] = q[i] = 0.f;
+  if (ty < ty_n && c < cv) {
+    int r = r0 + ty;
+    for (; r + 3 * ty_n < r1; r += 4 * ty_n) {   // 4 independent row loads in flight per lane
+      RowVec<T, VEC> v[4];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) { s[i] += v.v[i]; q[i] = fmaf(v.v[i], v.v[i], q[i]); }
-      }
+      for (int u = 0; u < 4; ++u) v[u].load(xb + (int64_t)(r + u * ty_n) * ldx + c * VEC);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { s[i] += v[u].v[i]; q[i] = fmaf(v[u].v[i], v[u].v[i], q[i]); }
     }
-    // reduce over ty through LDS
-    __syncthreads();
-    if (ty < ty_n) {
+    for (; r < r1; r += ty_n) {
+      RowVec<T, VEC> v;
+      v.load(xb + (int64_t)r * ldx + c * VEC);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        red[(ty * 2 + 0) * tx_n * VEC + tx * VEC + i] = s[i];
-        red[(ty * 2 + 1) * tx_n * VEC + tx * VEC + i] = q[i];
-      }
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < 2 * tx_n * VEC; e += NORM_THREADS) {
-      const int which = e / (tx_n * VEC), col = e % (tx_n * VEC);
-      float acc = 0.f;
-      for (int y = 0; y < ty_n; ++y) acc += red[(y * 2 + which) * tx_n * VEC + col];
-      const int ch = c0 * VEC + col;
-      if (ch < C) out[which * C + ch] = acc;
+      for (int i = 0; i < VEC; ++i) { s[i] += v.v[i]; q[i] = fmaf(v.v[i], v.v[i], q[i]); }
     }
   }
+  block_reduce_to_stat<VEC>(red, s, q, tx, ty, tx_n, ty_n, c0, C, stat + (int64_t)b * C * 2);
 }
 
-__global__ void instnorm_finalize_kernel(const float* __restrict__ ws, int chunks, int S, int C, float eps,
-                                         float* __restrict__ mean, float* __restrict__ rstd, int total) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (b, c)
-  if (i >= total) return;
-  const int b = i / C, c = i % C;
-  double s = 0.0, q = 0.0;
-  for (int k = 0; k < chunks; ++k) {
-    s += (double)ws[((int64_t)(b * chunks + k) * 2 + 0) * C + c];
-    q += (double)ws[((int64_t)(b * chunks + k) * 2 + 1) * C + c];
-  }
-  const double m = s / S;
-  double var = q / S - m * m;
-  if (var < 0.0) var = 0.0;
-  mean[i] = (float)m;
-  rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
-}
-
-// ---------------------------------------------------------------------------------------------------
-// apply
-// ---------------------------------------------------------------------------------------------------
 struct StylePtrs {
   const float* gamma[MISEG_MAX_STYLES];
   const float* beta[MISEG_MAX_STYLES];
 };
 
 template <class T, int VEC>
-__global__ void __launch_bounds__(NORM_THREADS) instnorm_apply_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ res,
-                                                                      int64_t ldres, T* __restrict__ y, int64_t ldy, int S, int C, int cv,
-                                                                      int tx_n, int ty_n, const float* __restrict__ mean,
-                                                                      const float* __restrict__ rstd, const int32_t* __restrict__ styles,
+__global__ void __launch_bounds__(NORM_THREADS) instnorm_apply_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ res, int64_t ldres,
+                                                                      T* __restrict__ y, int64_t ldy, int S, int C, int cv, int tx_n, int ty_n, int rpb,
+                                                                      const double* __restrict__ stat, float eps, const int32_t* __restrict__ styles,
                                                                       StylePtrs sp, int act, float slope) {
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
-  if (ty >= ty_n) return;
-  const int r0 = chunk * NORM_ROWS_PER_BLOCK;
-  const int r1 = min(S, r0 + NORM_ROWS_PER_BLOCK);
+  const int c = blockIdx.z * tx_n + tx;
+  if (ty >= ty_n || c >= cv) return;
+  const int r0 = chunk * rpb, r1 = min(S, r0 + rpb);
   const int st = styles ? styles[b] : 0;
   const float* g = sp.gamma[st];
   const float* be = sp.beta[st];
   const int64_t boff = (int64_t)b * S;
-  for (int c = tx; c < cv; c += tx_n) {
-    float sc[VEC], sh[VEC];
+  float sc[VEC], sh[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      const int ch = c * VEC + i;
-      const float m = mean[b * C + ch], rs = rstd[b * C + ch];
-      const float gg = g ? g[ch] : 1.f, bb = be ? be[ch] : 0.f;
-      sc[i] = rs * gg;
-      sh[i] = bb - m * sc[i];
+  for (int i = 0; i < VEC; ++i) {
+    const int ch = c * VEC + i;
+    float m, rs;
+    mean_rstd(stat + ((int64_t)b * C + ch) * 2, S, eps, m, rs);
+    const float gg = g ? g[ch] : 1.f, bb = be ? be[ch] : 0.f;
+    sc[i] = rs * gg;
+    sh[i] = bb - m * sc[i];
+  }
+#pragma unroll 4
+  for (int r = r0 + ty; r < r1; r += ty_n) {
+    RowVec<T, VEC> v, o;
+    v.load(x + (boff + r) * ldx + c * VEC);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o.v[i] = fmaf(v.v[i], sc[i], sh[i]);
+    if (res) {
+      RowVec<T, VEC> rr;
+      rr.load(res + (boff + r) * ldres + c * VEC);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o.v[i] += rr.v[i];
     }
-    for (int r = r0 + ty; r < r1; r += ty_n) {
-      RowVec<T, VEC> v, o;
-      v.load(x + (boff + r) * ldx + c * VEC);
+    if (act == MISEG_ACT_LEAKY) {
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) o.v[i] = fmaf(v.v[i], sc[i], sh[i]);
-      if (res) {
-        RowVec<T, VEC> rr;
-        rr.load(res + (boff + r) * ldres + c * VEC);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) o.v[i] += rr.v[i];
-      }
-      if (act == MISEG_ACT_LEAKY) {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) o.v[i] = o.v[i] > 0.f ? o.v[i] : o.v[i] * slope;
-      }
-      o.store(y + (boff + r) * ldy + c * VEC);
+      for (int i = 0; i < VEC; ++i) o.v[i] = o.v[i] > 0.f ? o.v[i] : o.v[i] * slope;
     }
+    o.store(y + (boff + r) * ldy + c * VEC);
   }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// backward: reduce  (sum dz, sum dz*xhat) -> ws ; finalize -> a,b per (b,c) + dgamma/dbeta atomics ; apply
+// backward: reduce (sum dz, sum dz*xhat) -> dstat (fp64 atomics) ; param kernel ; apply
 // ---------------------------------------------------------------------------------------------------
 template <class T, int VEC>
-__global__ void __launch_bounds__(NORM_THREADS) instnorm_bwd_reduce_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ yact,
-                                                                           int64_t ldy, const T* __restrict__ x, int64_t ldx, int S, int C, int cv,
-                                                                           int tx_n, int ty_n, const float* __restrict__ mean,
-                                                                           const float* __restrict__ rstd, int act, float slope,
-                                                                           float* __restrict__ ws, int chunks) {
+__global__ void __launch_bounds__(NORM_THREADS) instnorm_bwd_reduce_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ yact, int64_t ldy,
+                                                                           const T* __restrict__ x, int64_t ldx, int S, int C, int cv, int tx_n, int ty_n, int rpb,
+                                                                           const double* __restrict__ stat, float eps, int act, float slope,
+                                                                           double* __restrict__ dstat) {
   extern __shared__ __attribute__((aligned(16))) float red[];
-  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int b = blockIdx.y, chunk = blockIdx.x, c0 = blockIdx.z * tx_n;
   const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
-  const int r0 = chunk * NORM_ROWS_PER_BLOCK;
-  const int r1 = min(S, r0 + NORM_ROWS_PER_BLOCK);
+  const int r0 = chunk * rpb, r1 = min(S, r0 + rpb);
   const int64_t boff = (int64_t)b * S;
-  float* out = ws + ((int64_t)(b * chunks + chunk) * 2) * C;
-  for (int c0 = 0; c0 < cv; c0 += tx_n) {
-    const int c = c0 + tx;
-    float s[VEC], q[VEC];
+  const int c = c0 + tx;
+  float s[VEC], q[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) s[i] = q[i] = 0.f;
-    if (ty < ty_n && c < cv) {
-      float m[VEC], rs[VEC];
+  for (int i = 0; i < VEC; ++i) s[i] = q[i] = 0.f;
+  if (ty < ty_n && c < cv) {
+    float m[VEC], rs[VEC];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) { m[i] = mean[b * C + c * VEC + i]; rs[i] = rstd[b * C + c * VEC + i]; }
-      for (int r = r0 + ty; r < r1; r += ty_n) {
-        RowVec<T, VEC> g, xv;
-        g.load(dy + (boff + r) * lddy + c * VEC);
-        xv.load(x + (boff + r) * ldx + c * VEC);
-        if (act == MISEG_ACT_LEAKY) {
-          RowVec<T, VEC> yv;
-          yv.load(yact + (boff + r) * ldy + c * VEC);
+    for (int i = 0; i < VEC; ++i) mean_rstd(stat + ((int64_t)b * C + c * VEC + i) * 2, S, eps, m[i], rs[i]);
+#pragma unroll 4
+    for (int r = r0 + ty; r < r1; r += ty_n) {
+      RowVec<T, VEC> g, xv;
+      g.load(dy + (boff + r) * lddy + c * VEC);
+      xv.load(x + (boff + r) * ldx + c * VEC);
+      if (act == MISEG_ACT_LEAKY) {
+        RowVec<T, VEC> yv;
+        yv.load(yact + (boff + r) * ldy + c * VEC);
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) g.v[i] = yv.v[i] > 0.f ? g.v[i] : g.v[i] * slope;
-        }
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-          s[i] += g.v[i];
-          q[i] = fmaf(g.v[i], (xv.v[i] - m[i]) * rs[i], q[i]);
-        }
+        for (int i = 0; i < VEC; ++i) g.v[i] = yv.v[i] > 0.f ? g.v[i] : g.v[i] * slope;
       }
-    }
-    __syncthreads();
-    if (ty < ty_n) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
-        red[(ty * 2 + 0) * tx_n * VEC + tx * VEC + i] = s[i];
-        red[(ty * 2 + 1) * tx_n * VEC + tx * VEC + i] = q[i];
+        s[i] += g.v[i];
+        q[i] = fmaf(g.v[i], (xv.v[i] - m[i]) * rs[i], q[i]);
       }
     }
-    __syncthreads();
-    for (int e = threadIdx.x; e < 2 * tx_n * VEC; e += NORM_THREADS) {
-      const int which = e / (tx_n * VEC), col = e % (tx_n * VEC);
-      float acc = 0.f;
-      for (int yy = 0; yy < ty_n; ++yy) acc += red[(yy * 2 + which) * tx_n * VEC + col];
-      const int ch = c0 * VEC + col;
-      if (ch < C) out[which * C + ch] = acc;
-    }
   }
+  block_reduce_to_stat<VEC>(red, s, q, tx, ty, tx_n, ty_n, c0, C, dstat + (int64_t)b * C * 2);
 }
 
 struct StyleGradPtrs {
@@ -235,71 +220,56 @@ struct StyleGradPtrs {
   float* dbeta[MISEG_MAX_STYLES];
 };
 
-// writes the per-(b,c) means a = sum(dz)/S, bq = sum(dz*xhat)/S over ws[b][0][0..1][c] (in place) and
-// accumulates dgamma / dbeta of the sample's style.
-__global__ void instnorm_bwd_finalize_kernel(float* __restrict__ ws, int chunks, int S, int C, const int32_t* __restrict__ styles,
-                                             StyleGradPtrs gp, int total) {
+__global__ void instnorm_bwd_param_kernel(const double* __restrict__ dstat, int C, const int32_t* __restrict__ styles, StyleGradPtrs gp, int total) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int b = i / C, c = i % C;
-  double s = 0.0, q = 0.0;
-  for (int k = 0; k < chunks; ++k) {
-    s += (double)ws[((int64_t)(b * chunks + k) * 2 + 0) * C + c];
-    q += (double)ws[((int64_t)(b * chunks + k) * 2 + 1) * C + c];
-  }
   const int st = styles ? styles[b] : 0;
-  if (gp.dgamma[st]) atomicAdd(gp.dgamma[st] + c, (float)q);
-  if (gp.dbeta[st]) atomicAdd(gp.dbeta[st] + c, (float)s);
-  ws[((int64_t)(b * chunks) * 2 + 0) * C + c] = (float)(s / S);
-  ws[((int64_t)(b * chunks) * 2 + 1) * C + c] = (float)(q / S);
+  if (gp.dgamma[st]) atomicAdd(gp.dgamma[st] + c, (float)dstat[2 * i + 1]);
+  if (gp.dbeta[st]) atomicAdd(gp.dbeta[st] + c, (float)dstat[2 * i]);
 }
 
 template <class T, int VEC>
-__global__ void __launch_bounds__(NORM_THREADS) instnorm_bwd_apply_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ yact,
-                                                                          int64_t ldy, const T* __restrict__ x, int64_t ldx, T* __restrict__ dx,
-                                                                          int64_t lddx, T* __restrict__ dres, int64_t lddres, int S, int C, int cv,
-                                                                          int tx_n, int ty_n, const float* __restrict__ mean,
-                                                                          const float* __restrict__ rstd, const int32_t* __restrict__ styles,
-                                                                          StylePtrs sp, int act, float slope, const float* __restrict__ ws,
-                                                                          int chunks) {
+__global__ void __launch_bounds__(NORM_THREADS) instnorm_bwd_apply_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ yact, int64_t ldy,
+                                                                          const T* __restrict__ x, int64_t ldx, T* __restrict__ dx, int64_t lddx,
+                                                                          T* __restrict__ dres, int64_t lddres, int S, int C, int cv, int tx_n, int ty_n, int rpb,
+                                                                          const double* __restrict__ stat, float eps, const int32_t* __restrict__ styles,
+                                                                          StylePtrs sp, int act, float slope, const double* __restrict__ dstat) {
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
-  if (ty >= ty_n) return;
-  const int r0 = chunk * NORM_ROWS_PER_BLOCK;
-  const int r1 = min(S, r0 + NORM_ROWS_PER_BLOCK);
+  const int c = blockIdx.z * tx_n + tx;
+  if (ty >= ty_n || c >= cv) return;
+  const int r0 = chunk * rpb, r1 = min(S, r0 + rpb);
   const int st = styles ? styles[b] : 0;
   const float* g = sp.gamma[st];
   const int64_t boff = (int64_t)b * S;
-  const float* ab = ws + ((int64_t)(b * chunks) * 2) * C;
-  for (int c = tx; c < cv; c += tx_n) {
-    float m[VEC], rs[VEC], sc[VEC], a[VEC], bq[VEC];
+  float m[VEC], rs[VEC], sc[VEC], a[VEC], bq[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int ch = c * VEC + i;
+    mean_rstd(stat + ((int64_t)b * C + ch) * 2, S, eps, m[i], rs[i]);
+    sc[i] = rs[i] * (g ? g[ch] : 1.f);
+    a[i] = (float)(dstat[((int64_t)b * C + ch) * 2] / S);
+    bq[i] = (float)(dstat[((int64_t)b * C + ch) * 2 + 1] / S);
+  }
+#pragma unroll 4
+  for (int r = r0 + ty; r < r1; r += ty_n) {
+    RowVec<T, VEC> gv, xv, o;
+    gv.load(dy + (boff + r) * lddy + c * VEC);
+    xv.load(x + (boff + r) * ldx + c * VEC);
+    if (act == MISEG_ACT_LEAKY) {
+      RowVec<T, VEC> yv;
+      yv.load(yact + (boff + r) * ldy + c * VEC);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) gv.v[i] = yv.v[i] > 0.f ? gv.v[i] : gv.v[i] * slope;
+    }
+    if (dres) gv.store(dres + (boff + r) * lddres + c * VEC);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      const int ch = c * VEC + i;
-      m[i] = mean[b * C + ch];
-      rs[i] = rstd[b * C + ch];
-      sc[i] = rs[i] * (g ? g[ch] : 1.f);
-      a[i] = ab[ch];
-      bq[i] = ab[C + ch];
+      const float xh = (xv.v[i] - m[i]) * rs[i];
+      o.v[i] = sc[i] * (gv.v[i] - a[i] - xh * bq[i]);
     }
-    for (int r = r0 + ty; r < r1; r += ty_n) {
-      RowVec<T, VEC> gv, xv, o;
-      gv.load(dy + (boff + r) * lddy + c * VEC);
-      xv.load(x + (boff + r) * ldx + c * VEC);
-      if (act == MISEG_ACT_LEAKY) {
-        RowVec<T, VEC> yv;
-        yv.load(yact + (boff + r) * ldy + c * VEC);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) gv.v[i] = yv.v[i] > 0.f ? gv.v[i] : gv.v[i] * slope;
-      }
-      if (dres) gv.store(dres + (boff + r) * lddres + c * VEC);
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        const float xh = (xv.v[i] - m[i]) * rs[i];
-        o.v[i] = sc[i] * (gv.v[i] - a[i] - xh * bq[i]);
-      }
-      o.store(dx + (boff + r) * lddx + c * VEC);
-    }
+    o.store(dx + (boff + r) * lddx + c * VEC);
   }
 }
 
@@ -383,52 +353,48 @@ __global__ void __launch_bounds__(256) layernorm_bwd_param_kernel(const T* __res
 
 using namespace miseg;
 
-extern "C" size_t miseg_instnorm_workspace_bytes(int B, int S, int C) {
-  return (size_t)B * cdiv(S, NORM_ROWS_PER_BLOCK) * 2 * C * sizeof(float);
-}
+static bool aligned16(const void* p) { return ((uintptr_t)p % 16) == 0; }
+
+extern "C" size_t miseg_instnorm_stat_bytes(int B, int C) { return (size_t)B * C * 2 * sizeof(double); }
 
 extern "C" int miseg_instnorm_stats(const miseg_instnorm_stats_params* p, miseg_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  MISEG_REQUIRE(p && p->x && p->mean && p->rstd && p->workspace, MISEG_E_BADARG, "instnorm_stats: null pointer");
-  MISEG_REQUIRE(p->B > 0 && p->S > 0 && p->C > 0 && p->ldx >= p->C, MISEG_E_BADARG, "instnorm_stats: bad shape B=%d S=%d C=%d ld=%ld",
-                p->B, p->S, p->C, (long)p->ldx);
+  MISEG_REQUIRE(p && p->x && p->stat, MISEG_E_BADARG, "instnorm_stats: null pointer");
+  MISEG_REQUIRE(p->B > 0 && p->S > 0 && p->C > 0 && p->ldx >= p->C, MISEG_E_BADARG, "instnorm_stats: bad shape B=%d S=%d C=%d ld=%ld", p->B, p->S, p->C,
+                (long)p->ldx);
   return dispatch_dtype(p->dtype, [&](auto* tag) -> int {
     typedef typename std::remove_pointer<decltype(tag)>::type T;
-    NormGeom g = norm_geom(p->S, p->C, p->ldx, p->x, Vec16<T>::N);
-    dim3 grid(g.chunks, p->B);
+    constexpr int V = Vec16<T>::N;
+    NormGeom g = norm_geom(p->S, p->C, aligned16(p->x) && p->ldx % V == 0, V);
+    dim3 grid(g.chunks, p->B, g.ctiles);
     size_t sh = (size_t)g.ty * 2 * g.tx * g.vec * sizeof(float);
-    if (g.vec == 1)
-      instnorm_stats_kernel<T, 1><<<grid, NORM_THREADS, sh, stream>>>((const T*)p->x, p->ldx, p->S, p->C, g.cv, g.tx, g.ty, (float*)p->workspace, g.chunks);
-    else
-      instnorm_stats_kernel<T, Vec16<T>::N><<<grid, NORM_THREADS, sh, stream>>>((const T*)p->x, p->ldx, p->S, p->C, g.cv, g.tx, g.ty, (float*)p->workspace, g.chunks);
-    const int total = p->B * p->C;
-    instnorm_finalize_kernel<<<cdiv(total, 256), 256, 0, stream>>>((const float*)p->workspace, g.chunks, p->S, p->C, p->eps, p->mean, p->rstd, total);
+    if (g.vec == 1) instnorm_stats_kernel<T, 1><<<grid, NORM_THREADS, sh, stream>>>((const T*)p->x, p->ldx, p->S, p->C, g.cv, g.tx, g.ty, g.rpb, (double*)p->stat);
+    else instnorm_stats_kernel<T, V><<<grid, NORM_THREADS, sh, stream>>>((const T*)p->x, p->ldx, p->S, p->C, g.cv, g.tx, g.ty, g.rpb, (double*)p->stat);
     MISEG_LAUNCH_CHECK("instnorm_stats");
     return MISEG_OK;
   });
 }
 
-static bool aligned16(const void* p) { return ((uintptr_t)p % 16) == 0; }
-
 extern "C" int miseg_instnorm_apply(const miseg_instnorm_apply_params* p, miseg_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  MISEG_REQUIRE(p && p->x && p->y && p->mean && p->rstd, MISEG_E_BADARG, "instnorm_apply: null pointer");
+  MISEG_REQUIRE(p && p->x && p->y && p->stat, MISEG_E_BADARG, "instnorm_apply: null pointer");
   MISEG_REQUIRE(p->num_styles >= 1 && p->num_styles <= MISEG_MAX_STYLES, MISEG_E_BADARG, "instnorm_apply: num_styles %d", p->num_styles);
   MISEG_REQUIRE(p->act == MISEG_ACT_NONE || p->act == MISEG_ACT_LEAKY, MISEG_E_UNSUPPORTED, "instnorm_apply: act %d", p->act);
   return dispatch_dtype(p->dtype, [&](auto* tag) -> int {
     typedef typename std::remove_pointer<decltype(tag)>::type T;
-    int64_t ldor = p->ldx | p->ldy | (p->res ? p->ldres : 0);
-    bool al = aligned16(p->x) && aligned16(p->y) && (!p->res || aligned16(p->res));
-    NormGeom g = norm_geom(p->S, p->C, al ? ldor : 1, p->x, Vec16<T>::N);
+    constexpr int V = Vec16<T>::N;
+    const int64_t ldor = p->ldx | p->ldy | (p->res ? p->ldres : 0);
+    const bool al = aligned16(p->x) && aligned16(p->y) && (!p->res || aligned16(p->res)) && ldor % V == 0;
+    NormGeom g = norm_geom(p->S, p->C, al, V);
     StylePtrs sp;
     for (int s = 0; s < MISEG_MAX_STYLES; ++s) { sp.gamma[s] = s < p->num_styles ? p->gamma[s] : nullptr; sp.beta[s] = s < p->num_styles ? p->beta[s] : nullptr; }
-    dim3 grid(g.chunks, p->B);
+    dim3 grid(g.chunks, p->B, g.ctiles);
     if (g.vec == 1)
-      instnorm_apply_kernel<T, 1><<<grid, NORM_THREADS, 0, stream>>>((const T*)p->x, p->ldx, (const T*)p->res, p->ldres, (T*)p->y, p->ldy, p->S, p->C, g.cv,
-                                                                      g.tx, g.ty, p->mean, p->rstd, p->styles, sp, p->act, p->slope);
+      instnorm_apply_kernel<T, 1><<<grid, NORM_THREADS, 0, stream>>>((const T*)p->x, p->ldx, (const T*)p->res, p->ldres, (T*)p->y, p->ldy, p->S, p->C, g.cv, g.tx,
+                                                                      g.ty, g.rpb, (const double*)p->stat, p->eps, p->styles, sp, p->act, p->slope);
     else
-      instnorm_apply_kernel<T, Vec16<T>::N><<<grid, NORM_THREADS, 0, stream>>>((const T*)p->x, p->ldx, (const T*)p->res, p->ldres, (T*)p->y, p->ldy, p->S,
-                                                                                p->C, g.cv, g.tx, g.ty, p->mean, p->rstd, p->styles, sp, p->act, p->slope);
+      instnorm_apply_kernel<T, V><<<grid, NORM_THREADS, 0, stream>>>((const T*)p->x, p->ldx, (const T*)p->res, p->ldres, (T*)p->y, p->ldy, p->S, p->C, g.cv, g.tx,
+                                                                      g.ty, g.rpb, (const double*)p->stat, p->eps, p->styles, sp, p->act, p->slope);
     MISEG_LAUNCH_CHECK("instnorm_apply");
     return MISEG_OK;
   });
@@ -436,42 +402,39 @@ extern "C" int miseg_instnorm_apply(const miseg_instnorm_apply_params* p, miseg_
 
 extern "C" int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  MISEG_REQUIRE(p && p->dy && p->x && p->dx && p->mean && p->rstd && p->workspace, MISEG_E_BADARG, "instnorm_bwd: null pointer");
+  MISEG_REQUIRE(p && p->dy && p->x && p->dx && p->stat && p->dstat, MISEG_E_BADARG, "instnorm_bwd: null pointer");
   MISEG_REQUIRE(p->act == MISEG_ACT_NONE || (p->act == MISEG_ACT_LEAKY && p->y), MISEG_E_BADARG, "instnorm_bwd: act %d needs y", p->act);
   MISEG_REQUIRE(p->num_styles >= 1 && p->num_styles <= MISEG_MAX_STYLES, MISEG_E_BADARG, "instnorm_bwd: num_styles %d", p->num_styles);
   return dispatch_dtype(p->dtype, [&](auto* tag) -> int {
     typedef typename std::remove_pointer<decltype(tag)>::type T;
-    int64_t ldor = p->lddy | p->ldx | p->lddx | (p->act ? p->ldy : 0) | (p->dres ? p->lddres : 0);
-    bool al = aligned16(p->dy) && aligned16(p->x) && aligned16(p->dx) && (!p->act || aligned16(p->y)) && (!p->dres || aligned16(p->dres));
-    NormGeom g = norm_geom(p->S, p->C, al ? ldor : 1, p->x, Vec16<T>::N);
+    constexpr int V = Vec16<T>::N;
+    const int64_t ldor = p->lddy | p->ldx | p->lddx | (p->act ? p->ldy : 0) | (p->dres ? p->lddres : 0);
+    const bool al = aligned16(p->dy) && aligned16(p->x) && aligned16(p->dx) && (!p->act || aligned16(p->y)) && (!p->dres || aligned16(p->dres)) && ldor % V == 0;
+    NormGeom g = norm_geom(p->S, p->C, al, V);
     StylePtrs sp;
     StyleGradPtrs gp;
+    bool any_param = false;
     for (int s = 0; s < MISEG_MAX_STYLES; ++s) {
       sp.gamma[s] = s < p->num_styles ? p->gamma[s] : nullptr;
       sp.beta[s] = nullptr;
       gp.dgamma[s] = s < p->num_styles ? p->dgamma[s] : nullptr;
       gp.dbeta[s] = s < p->num_styles ? p->dbeta[s] : nullptr;
+      any_param = any_param || gp.dgamma[s] || gp.dbeta[s];
     }
-    dim3 grid(g.chunks, p->B);
+    dim3 grid(g.chunks, p->B, g.ctiles);
     size_t sh = (size_t)g.ty * 2 * g.tx * g.vec * sizeof(float);
-    float* ws = (float*)p->workspace;
+    const double* stat = (const double*)p->stat;
+    double* dstat = (double*)p->dstat;
     const int total = p->B * p->C;
-    if (g.vec == 1) {
-      instnorm_bwd_reduce_kernel<T, 1><<<grid, NORM_THREADS, sh, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, p->S, p->C,
-                                                                            g.cv, g.tx, g.ty, p->mean, p->rstd, p->act, p->slope, ws, g.chunks);
-      instnorm_bwd_finalize_kernel<<<cdiv(total, 256), 256, 0, stream>>>(ws, g.chunks, p->S, p->C, p->styles, gp, total);
-      instnorm_bwd_apply_kernel<T, 1><<<grid, NORM_THREADS, 0, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, (T*)p->dx,
-                                                                          p->lddx, (T*)p->dres, p->lddres, p->S, p->C, g.cv, g.tx, g.ty, p->mean, p->rstd,
-                                                                          p->styles, sp, p->act, p->slope, ws, g.chunks);
-    } else {
-      constexpr int V = Vec16<T>::N;
-      instnorm_bwd_reduce_kernel<T, V><<<grid, NORM_THREADS, sh, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, p->S, p->C,
-                                                                            g.cv, g.tx, g.ty, p->mean, p->rstd, p->act, p->slope, ws, g.chunks);
-      instnorm_bwd_finalize_kernel<<<cdiv(total, 256), 256, 0, stream>>>(ws, g.chunks, p->S, p->C, p->styles, gp, total);
-      instnorm_bwd_apply_kernel<T, V><<<grid, NORM_THREADS, 0, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, (T*)p->dx,
-                                                                          p->lddx, (T*)p->dres, p->lddres, p->S, p->C, g.cv, g.tx, g.ty, p->mean, p->rstd,
-                                                                          p->styles, sp, p->act, p->slope, ws, g.chunks);
-    }
+#define BWD_LAUNCH(VV)                                                                                                                                          \
+    instnorm_bwd_reduce_kernel<T, VV><<<grid, NORM_THREADS, sh, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, p->S, p->C,  \
+                                                                           g.cv, g.tx, g.ty, g.rpb, stat, p->eps, p->act, p->slope, dstat);                           \
+    if (any_param) instnorm_bwd_param_kernel<<<cdiv(total, 256), 256, 0, stream>>>(dstat, p->C, p->styles, gp, total);                                          \
+    instnorm_bwd_apply_kernel<T, VV><<<grid, NORM_THREADS, 0, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, (T*)p->dx,    \
+                                                                         p->lddx, (T*)p->dres, p->lddres, p->S, p->C, g.cv, g.tx, g.ty, g.rpb, stat, p->eps, p->styles, \
+                                                                         sp, p->act, p->slope, dstat);
+    if (g.vec == 1) { BWD_LAUNCH(1) } else { BWD_LAUNCH(V) }
+#undef BWD_LAUNCH
     MISEG_LAUNCH_CHECK("instnorm_bwd");
     return MISEG_OK;
   });

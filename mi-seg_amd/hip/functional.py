@@ -71,18 +71,18 @@ class _InstNorm(Function):
     def forward(ctx, x, res, styles_dev, styles_host, num_styles, affine, act, slope, eps, *params):
         B = x.shape[0]
         S = ops.rows(x)[1] // B
-        mean, rstd = ops.instnorm_stats(x, B, S, eps)
+        stat = ops.instnorm_stats(x, B, S)
         gammas = list(params[0::2]) if affine else None
         betas = list(params[1::2]) if affine else None
-        y = ops.instnorm_apply(x, B, S, mean, rstd, styles_dev, gammas, betas, res=res, act=act, slope=slope)
-        ctx.meta = (B, S, styles_host, num_styles, affine, act, slope, res is not None)
-        ctx.save_for_backward(x, y if act != L.ACT_NONE else None, mean, rstd, styles_dev, *(gammas or []))
+        y = ops.instnorm_apply(x, B, S, stat, styles_dev, gammas, betas, res=res, act=act, slope=slope, eps=eps)
+        ctx.meta = (B, S, styles_host, num_styles, affine, act, slope, res is not None, eps)
+        ctx.save_for_backward(x, y if act != L.ACT_NONE else None, stat, styles_dev, *(gammas or []))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        B, S, styles_host, num_styles, affine, act, slope, has_res = ctx.meta
-        x, y, mean, rstd, styles_dev, *gammas = ctx.saved_tensors
+        B, S, styles_host, num_styles, affine, act, slope, has_res, eps = ctx.meta
+        x, y, stat, styles_dev, *gammas = ctx.saved_tensors
         dy = _rv(dy)
         C = x.shape[-1]
         present = sorted(set(styles_host)) if styles_host is not None else [0]
@@ -92,7 +92,7 @@ class _InstNorm(Function):
             # parameters of a style absent from the batch get no gradient (reference: grad is None)
             dgam = [buf[s, 0] if s in present else None for s in range(num_styles)]
             dbet = [buf[s, 1] if s in present else None for s in range(num_styles)]
-        dx, dres = ops.instnorm_bwd(dy, y, x, B, S, mean, rstd, styles_dev, gammas if affine else None, dgam, dbet, act=act, slope=slope,
+        dx, dres = ops.instnorm_bwd(dy, y, x, B, S, stat, styles_dev, gammas if affine else None, dgam, dbet, act=act, slope=slope, eps=eps,
                                     want_dres=has_res and ctx.needs_input_grad[1])
         pg = []
         if affine:

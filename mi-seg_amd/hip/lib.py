@@ -24,17 +24,16 @@ def _struct(name, fields):
     return type(name, (C.Structure,), {"_fields_": fields})
 
 
-InstnormStats = _struct("InstnormStats", [("x", vp), ("ldx", i64), ("B", i32), ("S", i32), ("C", i32), ("dtype", i32),
-                                          ("eps", f32), ("mean", vp), ("rstd", vp), ("workspace", vp)])
+InstnormStats = _struct("InstnormStats", [("x", vp), ("ldx", i64), ("B", i32), ("S", i32), ("C", i32), ("dtype", i32), ("stat", vp)])
 InstnormApply = _struct("InstnormApply", [("x", vp), ("ldx", i64), ("res", vp), ("ldres", i64), ("y", vp), ("ldy", i64),
-                                          ("B", i32), ("S", i32), ("C", i32), ("dtype", i32), ("mean", vp), ("rstd", vp),
+                                          ("B", i32), ("S", i32), ("C", i32), ("dtype", i32), ("stat", vp), ("eps", f32),
                                           ("styles", vp), ("num_styles", i32), ("gamma", fp4), ("beta", fp4),
                                           ("act", i32), ("slope", f32)])
 InstnormBwd = _struct("InstnormBwd", [("dy", vp), ("lddy", i64), ("y", vp), ("ldy", i64), ("x", vp), ("ldx", i64),
                                       ("dx", vp), ("lddx", i64), ("dres", vp), ("lddres", i64),
-                                      ("B", i32), ("S", i32), ("C", i32), ("dtype", i32), ("mean", vp), ("rstd", vp),
+                                      ("B", i32), ("S", i32), ("C", i32), ("dtype", i32), ("stat", vp), ("eps", f32), ("dstat", vp),
                                       ("styles", vp), ("num_styles", i32), ("gamma", fp4), ("dgamma", fp4), ("dbeta", fp4),
-                                      ("act", i32), ("slope", f32), ("workspace", vp)])
+                                      ("act", i32), ("slope", f32)])
 LayernormFwd = _struct("LayernormFwd", [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32),
                                         ("dtype", i32), ("eps", f32), ("gamma", vp), ("beta", vp), ("mean", vp), ("rstd", vp)])
 LayernormBwd = _struct("LayernormBwd", [("dy", vp), ("lddy", i64), ("x", vp), ("ldx", i64), ("dx", vp), ("lddx", i64),
@@ -45,7 +44,7 @@ Gemm = _struct("Gemm", [("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", 
                         ("accumulate", i32), ("split_k", i32)])
 Colsum = _struct("Colsum", [("x", vp), ("ldx", i64), ("rows", i64), ("C", i32), ("dtype", i32), ("out", vp), ("accumulate", i32)])
 Conv3 = _struct("Conv3", [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("wpk", vp), ("B", i32), ("D", i32), ("H", i32),
-                          ("W", i32), ("Cin", i32), ("Cout", i32), ("dtype", i32)])
+                          ("W", i32), ("Cin", i32), ("Cout", i32), ("dtype", i32), ("workspace", vp)])
 PackConv3 = _struct("PackConv3", [("w", vp), ("fwd_pack", vp), ("bwd_pack", vp), ("Cin", i32), ("Cout", i32), ("dtype", i32)])
 Conv3Wgrad = _struct("Conv3Wgrad", [("x", vp), ("ldx", i64), ("dy", vp), ("lddy", i64), ("dw", vp), ("B", i32), ("D", i32),
                                     ("H", i32), ("W", i32), ("Cin", i32), ("Cout", i32), ("dtype", i32), ("accumulate", i32),
@@ -83,7 +82,7 @@ PROTOS = {
     "miseg_abi_version": (i32, []),
     "miseg_last_error": (C.c_char_p, []),
     "miseg_device_arch": (i32, [C.c_char_p, C.c_size_t]),
-    "miseg_instnorm_workspace_bytes": (C.c_size_t, [i32, i32, i32]),
+    "miseg_instnorm_stat_bytes": (C.c_size_t, [i32, i32]),
     "miseg_instnorm_stats": (i32, [C.POINTER(InstnormStats), vp]),
     "miseg_instnorm_apply": (i32, [C.POINTER(InstnormApply), vp]),
     "miseg_instnorm_bwd": (i32, [C.POINTER(InstnormBwd), vp]),
@@ -92,6 +91,7 @@ PROTOS = {
     "miseg_gemm": (i32, [C.POINTER(Gemm), vp]),
     "miseg_permute3": (i32, [vp, vp, i32, i32, i32, i64, i64, i64, i32, vp]),
     "miseg_colsum": (i32, [C.POINTER(Colsum), vp]),
+    "miseg_conv3_fwd_workspace_bytes": (C.c_size_t, [i32, i32, i32, i32, i32, i32, i32]),
     "miseg_conv3_fwd": (i32, [C.POINTER(Conv3), vp]),
     "miseg_pack_conv3_weight": (i32, [C.POINTER(PackConv3), vp]),
     "miseg_conv3_wgrad_workspace_bytes": (C.c_size_t, [i32, i32, i32, i32, i32, i32]),

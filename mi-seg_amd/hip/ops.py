@@ -67,16 +67,45 @@ def _call(fn_name, params, prof=None):
 
 
 # ------------------------------------------------------------------------------------------ instance norm
-def instnorm_stats(x, B, S, eps=1e-5):
-    """x: rows view of [B*S, C].  Returns (mean, rstd) fp32 [B, C]."""
+class _ZeroPool:
+    """fp64 statistics buffers of a step come from one pre-zeroed pool (one fill instead of ~100 small memsets)."""
+
+    def __init__(self, numel=1 << 20):
+        self.numel, self.buf, self.off = numel, None, 0
+
+    def take(self, n, device):
+        n = (n + 1) & ~1
+        if self.buf is None or self.buf.device != device or self.off + n > self.buf.numel():
+            self.buf = torch.empty(max(self.numel, n), dtype=torch.float64, device=device)
+            lib = L.load()
+            L.check(lib.miseg_fill32(_ptr(self.buf), 0, self.buf.numel() * 2, _stream()), "fill32")
+            self.off = 0
+        t = self.buf[self.off:self.off + n]
+        self.off += n
+        return t
+
+    def begin_step(self):
+        """call once per training step, after the previous step's backward has been enqueued: recycles the pool."""
+        if self.buf is not None and self.off > 0:
+            lib = L.load()
+            L.check(lib.miseg_fill32(_ptr(self.buf), 0, self.off * 2, _stream()), "fill32")
+            self.off = 0
+
+
+STAT_POOL = _ZeroPool()
+
+
+def begin_step():
+    STAT_POOL.begin_step()
+
+
+def instnorm_stats(x, B, S):
+    """x: rows view of [B*S, C].  Returns stat: float64 [B, C, 2] = (sum x, sum x^2)."""
     ld, n, Cc = rows(x)
     assert n == B * S, (n, B, S)
-    lib = L.load()
-    ws = torch.empty(max(1, lib.miseg_instnorm_workspace_bytes(B, S, Cc) // 4), dtype=torch.float32, device=x.device)
-    mean = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
-    rstd = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
-    _call("miseg_instnorm_stats", L.InstnormStats(_ptr(x), ld, B, S, Cc, _dt(x), eps, _ptr(mean), _ptr(rstd), _ptr(ws)))
-    return mean, rstd
+    stat = STAT_POOL.take(B * Cc * 2, x.device).view(B, Cc, 2)
+    _call("miseg_instnorm_stats", L.InstnormStats(_ptr(x), ld, B, S, Cc, _dt(x), _ptr(stat)))
+    return stat
 
 
 def _style_arrays(tensors, n):
@@ -86,29 +115,28 @@ def _style_arrays(tensors, n):
     return arr
 
 
-def instnorm_apply(x, B, S, mean, rstd, styles, gammas, betas, res=None, act=L.ACT_NONE, slope=0.01, out=None):
+def instnorm_apply(x, B, S, stat, styles, gammas, betas, res=None, act=L.ACT_NONE, slope=0.01, eps=1e-5, out=None):
     ld, n, Cc = rows(x)
     y = out if out is not None else torch.empty(x.shape, dtype=x.dtype, device=x.device)
     ldy, ny, Cy = rows(y)
     assert ny == n and Cy == Cc
     ldr = rows(res)[0] if res is not None else 0
     ns = len(gammas) if gammas is not None else 1
-    p = L.InstnormApply(_ptr(x), ld, _ptr(res), ldr, _ptr(y), ldy, B, S, Cc, _dt(x), _ptr(mean), _ptr(rstd), _ptr(styles), ns,
+    p = L.InstnormApply(_ptr(x), ld, _ptr(res), ldr, _ptr(y), ldy, B, S, Cc, _dt(x), _ptr(stat), eps, _ptr(styles), ns,
                         _style_arrays(gammas, ns), _style_arrays(betas, ns), act, slope)
     _call("miseg_instnorm_apply", p)
     return y
 
 
-def instnorm_bwd(dy, y, x, B, S, mean, rstd, styles, gammas, dgammas, dbetas, act=L.ACT_NONE, slope=0.01, want_dres=False):
+def instnorm_bwd(dy, y, x, B, S, stat, styles, gammas, dgammas, dbetas, act=L.ACT_NONE, slope=0.01, eps=1e-5, want_dres=False):
     ld, n, Cc = rows(x)
     dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     dres = torch.empty(x.shape, dtype=x.dtype, device=x.device) if want_dres else None
-    lib = L.load()
-    ws = torch.empty(max(1, lib.miseg_instnorm_workspace_bytes(B, S, Cc) // 4), dtype=torch.float32, device=x.device)
+    dstat = STAT_POOL.take(B * Cc * 2, x.device)
     ns = len(gammas) if gammas is not None else 1
     p = L.InstnormBwd(_ptr(dy), rows(dy)[0], _ptr(y), rows(y)[0] if y is not None else 0, _ptr(x), ld, _ptr(dx), rows(dx)[0],
-                      _ptr(dres), rows(dres)[0] if dres is not None else 0, B, S, Cc, _dt(x), _ptr(mean), _ptr(rstd), _ptr(styles), ns,
-                      _style_arrays(gammas, ns), _style_arrays(dgammas, ns), _style_arrays(dbetas, ns), act, slope, _ptr(ws))
+                      _ptr(dres), rows(dres)[0] if dres is not None else 0, B, S, Cc, _dt(x), _ptr(stat), eps, _ptr(dstat), _ptr(styles), ns,
+                      _style_arrays(gammas, ns), _style_arrays(dgammas, ns), _style_arrays(dbetas, ns), act, slope)
     _call("miseg_instnorm_bwd", p)
     return dx, dres
 
@@ -158,7 +186,7 @@ def gemm_tn(a, b, out=None, accumulate=False, split_k=0):
     assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == M * N
     if split_k <= 0:
         tiles = ((M + 63) // 64) * ((N + 63) // 64)
-        split_k = max(1, min((K + 255) // 256, 1024 // max(1, tiles)))
+        split_k = max(1, min((K + 511) // 512, 1024 // max(1, tiles)))
     p = L.Gemm(_ptr(a), lda, _ptr(b), ldb, _ptr(out), N, M, N, K, 1, 1, _dt(a), L.F32, None, L.ACT_NONE, int(accumulate), split_k)
     _call("miseg_gemm", p)
     return out
@@ -209,20 +237,19 @@ def _vol(x):
     return x.shape[0], x.shape[1], x.shape[2], x.shape[3]
 
 
-def _conv_nt(Cout):
-    """mirror of the tile choice in csrc/conv3d.hip::conv3_fwd_launch"""
-    return 1 if Cout <= 16 else 2 if Cout <= 32 else 3 if Cout <= 48 else 4 if Cout <= 64 else (6 if (Cout % 96 == 0 or Cout > 128) else 4)
-
-
 def conv3_fwd(x, wpk, Cout, out=None):
     """x [B,D,H,W,Cin] rows view; wpk [Cout][27][CinP]."""
     B, D, H, W = _vol(x)
     ld, n, Cin = rows(x)
     if out is None:
         out = torch.empty(B, D, H, W, Cout, dtype=x.dtype, device=x.device)
+    lib = L.load()
+    wsb = lib.miseg_conv3_fwd_workspace_bytes(B, D, H, W, Cin, Cout, _dt(x))
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device) if wsb else None
     flops = 2.0 * B * D * H * W * 27 * Cin * Cout
-    _call("miseg_conv3_fwd", L.Conv3(_ptr(x), ld, _ptr(out), rows(out)[0], _ptr(wpk), B, D, H, W, Cin, Cout, _dt(x)),
-          prof=(f"conv3_fwd_kernel<{'bf16' if x.dtype == torch.bfloat16 else 'f32'},NT={_conv_nt(Cout)}>", flops))
+    fast = (wpk.shape[-1] * x.element_size()) % 96 == 0
+    name = f"conv3_fwd{'96' if fast else ''}_kernel<{'bf16' if x.dtype == torch.bfloat16 else 'f32'}>"
+    _call("miseg_conv3_fwd", L.Conv3(_ptr(x), ld, _ptr(out), rows(out)[0], _ptr(wpk), B, D, H, W, Cin, Cout, _dt(x), _ptr(ws)), prof=(name, flops))
     return out
 
 

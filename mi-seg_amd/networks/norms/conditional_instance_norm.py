@@ -19,7 +19,12 @@ __all__ = ["ConditionalInstanceNorm1d", "ConditionalInstanceNorm2d", "Conditiona
 
 
 def styles_to_device(styles, device, batch):
-    """-> (int32 device tensor [B], python tuple) ; at most one host sync when `styles` lives on the device."""
+    """-> (int32 device tensor [B], python tuple) ; at most one host sync when `styles` lives on the device.
+    A ready-made (device tensor, host tuple) pair is passed through (hipGraph capture: no host traffic)."""
+    if isinstance(styles, tuple) and len(styles) == 2 and isinstance(styles[0], Tensor) and isinstance(styles[1], tuple):
+        if len(styles[1]) != batch:
+            raise ValueError("Expected number of styles as batch size.")
+        return styles
     if isinstance(styles, Tensor):
         host = tuple(int(s) for s in styles.reshape(-1).tolist())
     elif isinstance(styles, int):

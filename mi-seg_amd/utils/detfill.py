@@ -49,3 +49,24 @@ def fill_module_(module) -> None:
 def det_input(seed: int, shape) -> torch.Tensor:
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g, dtype=torch.float32)
+
+
+def block_labels(shape, n_classes: int, block: int = 16) -> torch.Tensor:
+    """deterministic piecewise-constant label volume [B, D, H, W]: class = (d//block + h//block + w//block + b) % n_classes."""
+    B, D, H, W = shape
+    d = torch.arange(D).view(1, D, 1, 1) // block
+    h = torch.arange(H).view(1, 1, H, 1) // block
+    w = torch.arange(W).view(1, 1, 1, W) // block
+    b = torch.arange(B).view(B, 1, 1, 1)
+    return (d + h + w + b) % n_classes
+
+
+def ce_cotangent(logits: torch.Tensor) -> torch.Tensor:
+    """d(mean voxel cross-entropy against block_labels)/d(logits) = (softmax - onehot) / n_voxels.  A spatially coherent
+    cotangent: unlike white noise it does not make every parameter gradient a sqrt(N)-cancelling random sum, so it is the
+    one used to judge the bf16 path."""
+    B, C = logits.shape[0], logits.shape[1]
+    lab = block_labels((B,) + tuple(logits.shape[2:]), C).to(logits.device)
+    p = torch.softmax(logits.detach().float(), dim=1)
+    onehot = torch.nn.functional.one_hot(lab, C).movedim(-1, 1).to(p.dtype)
+    return (p - onehot) / float(lab.numel())

@@ -36,7 +36,7 @@ import torch  # noqa: E402
 import __graft_entry__ as ge  # noqa: E402
 
 ge.load_package()
-from mi_seg_amd.utils.detfill import det_input, fill_module_  # noqa: E402
+from mi_seg_amd.utils.detfill import ce_cotangent, det_input, fill_module_  # noqa: E402
 
 from networks.blocks.dynunet_block import UnetResBlock  # noqa: E402  (reference)
 from networks.blocks.patch_merging import PatchMerging, PatchMergingV2  # noqa: E402
@@ -281,16 +281,21 @@ def gen_transformer_block():
     save("transformer_block", arrays, meta)
 
 
-def whole_net(tag, model, xshape, modalities, meta_extra, full_grads, unpinned, arrays_out, meta_out):
+def whole_net(tag, model, xshape, modalities, meta_extra, full_grads, unpinned, arrays_out, meta_out, second=False):
     fill_module_(model)
     x = det_input(1234, xshape)
     t0 = time.time()
     y = model(x, modalities)
     t1 = time.time()
     g = det_input(4321, tuple(y.shape))
-    y.backward(g)
+    y.backward(g, retain_graph=second)
     t2 = time.time()
     gr, none = grads_of(model, full=full_grads)
+    if second:   # same forward, spatially coherent cotangent (mean cross-entropy against block labels)
+        model.zero_grad(set_to_none=True)
+        y.backward(ce_cotangent(y))
+        gr2, _ = grads_of(model, full=False)
+        arrays_out.update({f"{tag}/{k.replace('grad:', 'grad2:').replace('gnorm:', 'gnorm2:')}": v for k, v in gr2.items()})
     arrays_out.update({f"{tag}/logits_samples": sample(y), f"{tag}/logits_l2": np.float64(y.double().norm().item())})
     if y.numel() <= 200_000:
         arrays_out[f"{tag}/logits"] = np32(y)
@@ -329,7 +334,7 @@ def gen_swin_unetr_c2():
         whole_net(tag, m, (1, 1, 96, 96, 96), mods, {"feature_size": 48, "downsample": "merging",
                                                       "vit_norm": "instance_cond", "encoder_norm": "instance_cond",
                                                       "decoder_norm": "instance"},
-                  False, ["swinViT.*.mlp (MONAI MLPBlock stand-in)"], arrays, meta)
+                  False, ["swinViT.*.mlp (MONAI MLPBlock stand-in)"], arrays, meta, second=(tag == "c2_m0"))
     save("swin_unetr_c2", arrays, meta)
 
 

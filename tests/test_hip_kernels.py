@@ -52,8 +52,9 @@ def test_instnorm_fwd_bwd(dtype, B, S, C):
     bet = [rnd(C, seed=5) * 0.1, rnd(C, seed=6) * 0.1]
     styles_h = [(i + 1) % 2 for i in range(B)]
     styles = torch.tensor(styles_h, dtype=torch.int32, device=DEV)
-    mean, rstd = ops.instnorm_stats(x, B, S)
-    y = ops.instnorm_apply(x, B, S, mean, rstd, styles, gam, bet, res=res, act=L.ACT_LEAKY, slope=0.01)
+    stat = ops.instnorm_stats(x, B, S)
+    mean = (stat[..., 0] / S).float()
+    y = ops.instnorm_apply(x, B, S, stat, styles, gam, bet, res=res, act=L.ACT_LEAKY, slope=0.01)
     # reference (fp32 on device)
     xf = x.double().requires_grad_(True)
     rf = res.double().requires_grad_(True)
@@ -72,7 +73,7 @@ def test_instnorm_fwd_bwd(dtype, B, S, C):
     yr.backward(dy.double())
     dg = [torch.zeros(C, device=DEV) for _ in range(2)]
     db = [torch.zeros(C, device=DEV) for _ in range(2)]
-    dx, dres = ops.instnorm_bwd(dy, y, x, B, S, mean, rstd, styles, gam, dg, db, act=L.ACT_LEAKY, slope=0.01, want_dres=True)
+    dx, dres = ops.instnorm_bwd(dy, y, x, B, S, stat, styles, gam, dg, db, act=L.ACT_LEAKY, slope=0.01, want_dres=True)
     tol = TOL[dtype] * (3 if dtype == torch.bfloat16 else 1)
     assert rel_err(dx, xf.grad) < tol
     assert rel_err(dres, rf.grad) < tol

@@ -208,3 +208,22 @@ def test_c2_state_layout(golden):
     assert c["n_state"] == 273 and c["n_params"] == 62218200
     assert len(c["grad_none"]) == 62          # all norms.1.* when the batch holds modality 0 only (A6)
     assert all(".norms.1." in k for k in c["grad_none"])
+
+
+@pytest.mark.parametrize("tag", ["c2_m0"])
+def test_swin_unetr_c2_full(golden, tag):
+    """Headline config at full size on the CPU oracle (about 40 s): both cotangents of the fixture."""
+    from mi_seg_amd.utils.detfill import ce_cotangent, det_input
+    G = golden("swin_unetr_c2")
+    case = G.meta["cases"][tag]
+    sd = state_from_meta(case)
+    y = ON.swin_unetr_forward(sd, det_input(1234, case["x"]), case["modalities"], ON.swin_unetr_cfg(feature_size=48))
+    assert rel_err(sample(y), G.t(f"{tag}/logits_samples")) < 5e-5
+    y.backward(det_input(4321, tuple(y.shape)), retain_graph=True)
+    for k, g in G.grads(tag).items():
+        assert rel_err(sample(sd[k].grad), g) < 1e-3, k
+    for v in sd.values():
+        v.grad = None
+    y.backward(ce_cotangent(y))
+    for k, g in G.grads2(tag).items():
+        assert rel_err(sample(sd[k].grad), g) < 1e-3, k
