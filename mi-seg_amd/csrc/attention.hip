@@ -4,6 +4,7 @@
 // gathered from a per-head LDS copy of the table with idx = code[i] - code[j] + centre, and the shift mask is
 // derived from 27 region labels of the rolled grid (reference: swin_utils.py:107-143, window_attention.py:99-119).
 #include "common.h"
+#include <stdlib.h>
 
 namespace miseg {
 
@@ -62,6 +63,7 @@ struct AttnSmem {
   int* label;    // [n]
   int* code;     // [n]
   int* row;      // [n]
+  float* padb;   // [3*HD] bias gradient of zero-padded tokens (bwd)
 };
 
 template <int HD4>
@@ -77,12 +79,13 @@ __device__ __forceinline__ AttnSmem carve(char* base, int n, int tsize, bool bwd
   s.delta = f; f += n;
   s.label = reinterpret_cast<int*>(f); f += n;
   s.code = reinterpret_cast<int*>(f); f += n;
-  s.row = reinterpret_cast<int*>(f);
+  s.row = reinterpret_cast<int*>(f); f += n;
+  s.padb = f;
   return s;
 }
 
 static size_t attn_smem_bytes(int n, int hd, int tsize, bool bwd) {
-  return ((size_t)2 * n * hd + (size_t)tsize * (bwd ? 2 : 1) + (size_t)5 * n) * sizeof(float);
+  return ((size_t)2 * n * hd + (size_t)tsize * (bwd ? 2 : 1) + (size_t)5 * n + (size_t)3 * hd) * sizeof(float);
 }
 
 template <class T, int HD4>
@@ -197,6 +200,7 @@ __global__ void __launch_bounds__(384) winattn_bwd_kernel(const T* __restrict__ 
     s.table[i] = bias_table ? bias_table[(int64_t)i * g.heads + head] : 0.f;
     s.dtable[i] = 0.f;
   }
+  for (int i = t; i < 3 * HD; i += blockDim.x) s.padb[i] = 0.f;
   __syncthreads();
   // ---------------- phase A: lane = query i  ->  dq_i, dbias
   if (t < n) {
@@ -235,7 +239,7 @@ __global__ void __launch_bounds__(384) winattn_bwd_kernel(const T* __restrict__ 
       for (int d = 0; d < HD; ++d) p[d] = from_f32<T>(dq[d] * g.scale);
     } else if (dqkv_bias) {
 #pragma unroll
-      for (int d = 0; d < HD; ++d) atomicAdd(dqkv_bias + head * HD + d, dq[d] * g.scale);
+      for (int d = 0; d < HD; ++d) atomicAdd(&s.padb[d], dq[d] * g.scale);
     }
   }
   __syncthreads();
@@ -290,18 +294,369 @@ __global__ void __launch_bounds__(384) winattn_bwd_kernel(const T* __restrict__ 
     } else if (dqkv_bias) {
 #pragma unroll
       for (int d = 0; d < HD; ++d) {
-        atomicAdd(dqkv_bias + C + head * HD + d, dk[d]);
-        atomicAdd(dqkv_bias + 2 * C + head * HD + d, dv[d]);
+        atomicAdd(&s.padb[HD + d], dk[d]);
+        atomicAdd(&s.padb[2 * HD + d], dv[d]);
       }
     }
   }
+  __syncthreads();
   if (dbias_table) {
-    __syncthreads();
     for (int i = t; i < tsize; i += blockDim.x) {
       const float v = s.dtable[i];
       if (v != 0.f) atomicAdd(dbias_table + (int64_t)i * g.heads + head, v);
     }
   }
+  if (dqkv_bias)
+    for (int i = t; i < 3 * HD; i += blockDim.x) {
+      const float v = s.padb[i];
+      if (v != 0.f) atomicAdd(dqkv_bias + (i / HD) * C + head * HD + i % HD, v);
+    }
+}
+
+// =====================================================================================================================
+// MFMA path (bf16, head_dim 16): S^T = K Q^T on v_mfma_f32_32x32x16_bf16 with the QUERY on the lane, so the softmax
+// statistics are lane-local (+ one exchange with lane^32) and the exponentiated tile is directly the B operand of
+// O^T += V^T P^T (accumulator-as-operand, no LDS round trip).  One workgroup = (window, head), 4 waves, each wave owns
+// query tiles of 32; keys are walked in tiles of 32.
+// =====================================================================================================================
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+static constexpr int ATT_MAXT = 11;                 // ceil(343 / 32) tiles
+static constexpr int ATT_NP = ATT_MAXT * 32;        // 352 padded tokens
+static constexpr int ATT_VT_LD = ATT_NP + 8;        // row stride (elements) of the dim-major copies
+
+__device__ __forceinline__ int att_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// key/query info word: code (12 bits) | label << 12 (5 bits) | valid << 20
+__device__ __forceinline__ int att_pack(int code, int label, bool valid) { return code | (label << 12) | ((int)valid << 20); }
+
+__device__ __forceinline__ bf16x8 cvt8(const float* p) {
+  return bf16x8{(bf16)p[0], (bf16)p[1], (bf16)p[2], (bf16)p[3], (bf16)p[4], (bf16)p[5], (bf16)p[6], (bf16)p[7]};
+}
+
+// dim-major operand (V^T, dO^T, Q^T, K^T) fragment for the accumulator-as-B products: lane (r = dim, h) element j is
+// tok = t0 + 16*s + 8*(j>>2) + 4*h + (j&3); dims >= 16 are zero rows.
+__device__ __forceinline__ bf16x8 att_dimmajor_frag(const bf16* base /*[16][ATT_VT_LD]*/, int r, int h, int t0, int s) {
+  bf16x8 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (bf16)0.f;
+  if (r < 16) {
+    const bf16* p = base + r * ATT_VT_LD + t0 + 16 * s + 4 * h;
+    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(p);
+    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(p + 8);
+    f = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  }
+  return f;
+}
+
+__global__ void __launch_bounds__(256) winattn_fwd_mfma_kernel(const bf16* __restrict__ qkv, int64_t ldq, bf16* __restrict__ out, int64_t ldo,
+                                                               const float* __restrict__ qkv_bias, const float* __restrict__ bias_table,
+                                                               float* __restrict__ lse_out, WinGeom g, int tsize) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* Qs = reinterpret_cast<bf16*>(smem);                 // [NP][16]  (pre-scaled)
+  bf16* Ks = Qs + ATT_NP * 16;                              // [NP][16]
+  bf16* Vt = Ks + ATT_NP * 16;                              // [16][ATT_VT_LD]
+  int* info = reinterpret_cast<int*>(Vt + 16 * ATT_VT_LD);  // [NP]
+  int* rowq = info + ATT_NP;                                // [NP]
+  float* table = reinterpret_cast<float*>(rowq + ATT_NP);   // [tsize]
+  const int win = blockIdx.x, head = blockIdx.y, tid = threadIdx.x;
+  const int n = g.n, C = g.C, ntiles = (n + 31) / 32;
+  const bool use_mask = (g.sd | g.sh | g.sw) != 0;
+  for (int t = tid; t < ntiles * 32; t += 256) {
+    int row = -1, label = 0, code = 0;
+    float q[16], k[16], v[16];
+    if (t < n) {
+      token_info(g, win, t, row, label, code);
+      load_head_row<bf16, 4>(qkv, ldq, row, head * 16, qkv_bias, q);
+      load_head_row<bf16, 4>(qkv, ldq, row, C + head * 16, qkv_bias, k);
+      load_head_row<bf16, 4>(qkv, ldq, row, 2 * C + head * 16, qkv_bias, v);
+    } else {
+#pragma unroll
+      for (int d = 0; d < 16; ++d) q[d] = k[d] = v[d] = 0.f;
+    }
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+      Qs[t * 16 + d] = (bf16)(q[d] * g.scale);
+      Ks[t * 16 + d] = (bf16)k[d];
+      Vt[d * ATT_VT_LD + t] = (bf16)v[d];
+    }
+    info[t] = att_pack(code, label, t < n);
+    rowq[t] = row;
+  }
+  for (int i = tid; i < tsize; i += 256) table[i] = bias_table[(int64_t)i * g.heads + head];
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int tb = 2 * g.tw - 1;
+  const int centre = ((g.tw - 1) * tb + (g.tw - 1)) * tb + (g.tw - 1);
+  for (int qt = wave; qt < ntiles; qt += 4) {
+    const int qi = qt * 32 + r;
+    const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + qi * 16 + 8 * h);
+    const int qinfo = info[qi];
+    const int cq = (qinfo & 0xfff) + centre, lq = (qinfo >> 12) & 31;
+    float m = -INFINITY, l = 0.f;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int kt = 0; kt < ntiles; ++kt) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + r) * 16 + 8 * h);
+      f32x16 sacc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, sacc, 0, 0, 0);   // rows = keys, col = this lane's query
+      float sv[16];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int4 ki = *reinterpret_cast<const int4*>(info + kt * 32 + 8 * gq + 4 * h);
+        const int kiv[4] = {ki.x, ki.y, ki.z, ki.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int w = kiv[e];
+          float sc = sacc[4 * gq + e] + table[cq - (w & 0xfff)];
+          if (use_mask && ((w >> 12) & 31) != lq) sc -= 100.f;
+          if (!(w >> 20)) sc = -INFINITY;
+          sv[4 * gq + e] = sc;
+          mx = fmaxf(mx, sc);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m, mx);
+      const float alpha = __expf(m - mn);
+      float ls = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { sv[i] = __expf(sv[i] - mn); ls += sv[i]; }
+      ls += __shfl_xor(ls, 32, 64);
+      l = l * alpha + ls;
+      m = mn;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] *= alpha;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = cvt8(sv + 8 * s2);
+        const bf16x8 vf = att_dimmajor_frag(Vt, r, h, kt * 32, s2);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, acc, 0, 0, 0);     // O^T[dim][query] += V^T P^T
+      }
+    }
+    const float inv = 1.f / l;
+    const int row = rowq[qi];
+    if (qi < n) {
+      if (h == 0) lse_out[((int64_t)win * g.heads + head) * n + qi] = m + __logf(l);
+      if (row >= 0) {
+        bf16* op = out + (int64_t)row * ldo + head * 16;
+        *reinterpret_cast<bf16x4*>(op + 4 * h) = bf16x4{(bf16)(acc[0] * inv), (bf16)(acc[1] * inv), (bf16)(acc[2] * inv), (bf16)(acc[3] * inv)};
+        *reinterpret_cast<bf16x4*>(op + 8 + 4 * h) = bf16x4{(bf16)(acc[4] * inv), (bf16)(acc[5] * inv), (bf16)(acc[6] * inv), (bf16)(acc[7] * inv)};
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// MFMA backward (bf16, head_dim 16): the KEY sits on the lane (S = Q K^T, dP = dO V^T), so the recomputed P and dS tiles
+// are directly the B operands of dV^T += dO^T P and dK^T += Q^T dS; dS crosses LDS once (per-wave 32x32 tile) for
+// dQ^T = K^T dS^T, which is accumulated over key tiles in an fp32 LDS buffer.  A wave owns key tiles and walks all
+// query tiles; rel-pos bias gradients are LDS atomics flushed once per workgroup.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) winattn_bwd_mfma_kernel(const bf16* __restrict__ qkv, int64_t ldq, const bf16* __restrict__ out, int64_t ldo,
+                                                               const bf16* __restrict__ dout, int64_t lddo, bf16* __restrict__ dqkv, int64_t lddq,
+                                                               const float* __restrict__ qkv_bias, const float* __restrict__ bias_table,
+                                                               const float* __restrict__ lse_in, float* __restrict__ dqkv_bias,
+                                                               float* __restrict__ dbias_table, WinGeom g, int tsize, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* Qs = reinterpret_cast<bf16*>(smem);          // [NP][16] scaled
+  bf16* Ks = Qs + ATT_NP * 16;
+  bf16* Vs = Ks + ATT_NP * 16;
+  bf16* Gs = Vs + ATT_NP * 16;                       // dO
+  bf16* Qt = Gs + ATT_NP * 16;                       // [16][LD] scaled
+  bf16* Gt = Qt + 16 * ATT_VT_LD;
+  bf16* Kt = Gt + 16 * ATT_VT_LD;
+  int* info = reinterpret_cast<int*>(Kt + 16 * ATT_VT_LD);
+  int* rowq = info + ATT_NP;
+  float* lse = reinterpret_cast<float*>(rowq + ATT_NP);
+  float* delta = lse + ATT_NP;
+  float* table = delta + ATT_NP;
+  float* dtable = table + tsize;
+  float* padb = dtable + tsize;                      // [48]: q/k/v bias gradient from zero-padded tokens of this window
+  const int win = blockIdx.x, head = blockIdx.y, tid = threadIdx.x;
+  const int n = g.n, C = g.C, ntiles = (n + 31) / 32;
+  const bool use_mask = (g.sd | g.sh | g.sw) != 0;
+  if (tid < 48) padb[tid] = 0.f;
+  for (int t = tid; t < ntiles * 32; t += 256) {
+    int row = -1, label = 0, code = 0;
+    float q[16], k[16], v[16], go[16];
+    float dl = 0.f, ls = 0.f;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) q[d] = k[d] = v[d] = go[d] = 0.f;
+    if (t < n) {
+      token_info(g, win, t, row, label, code);
+      load_head_row<bf16, 4>(qkv, ldq, row, head * 16, qkv_bias, q);
+      load_head_row<bf16, 4>(qkv, ldq, row, C + head * 16, qkv_bias, k);
+      load_head_row<bf16, 4>(qkv, ldq, row, 2 * C + head * 16, qkv_bias, v);
+      ls = lse_in[((int64_t)win * g.heads + head) * n + t];
+      if (row >= 0) {
+        const bf16* gp = dout + (int64_t)row * lddo + head * 16;
+        const bf16* op = out + (int64_t)row * ldo + head * 16;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) { go[d] = to_f32(gp[d]); dl = fmaf(go[d], to_f32(op[d]), dl); }
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+      const bf16 qs = (bf16)(q[d] * g.scale);
+      Qs[t * 16 + d] = qs;  Qt[d * ATT_VT_LD + t] = qs;
+      Ks[t * 16 + d] = (bf16)k[d];  Kt[d * ATT_VT_LD + t] = (bf16)k[d];
+      Vs[t * 16 + d] = (bf16)v[d];
+      Gs[t * 16 + d] = (bf16)go[d];  Gt[d * ATT_VT_LD + t] = (bf16)go[d];
+    }
+    info[t] = att_pack(code, label, t < n);
+    rowq[t] = row;
+    lse[t] = ls;
+    delta[t] = dl;
+  }
+  for (int i = tid; i < tsize; i += 256) { table[i] = bias_table[(int64_t)i * g.heads + head]; dtable[i] = 0.f; }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int tb = 2 * g.tw - 1;
+  const int centre = ((g.tw - 1) * tb + (g.tw - 1)) * tb + (g.tw - 1);
+  for (int kt = wave; kt < ntiles; kt += 4) {
+    const int ki = kt * 32 + r;
+    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + ki * 16 + 8 * h);     // B operand: [k=dim][col=key]
+    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + ki * 16 + 8 * h);
+    const int kinfo = info[ki];
+    const int ck = (kinfo & 0xfff) - centre, lk = (kinfo >> 12) & 31;
+    const bool kvalid = (kinfo >> 20) != 0;
+    f32x16 dvt, dkt;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dvt[i] = dkt[i] = 0.f;
+    for (int qt = 0; qt < ntiles; ++qt) {
+      const int qi = qt * 32 + r;
+      const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + qi * 16 + 8 * h);   // A operand: [row=query][k=dim]
+      const bf16x8 gf = *reinterpret_cast<const bf16x8*>(Gs + qi * 16 + 8 * h);
+      f32x16 sacc, pacc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sacc[i] = pacc[i] = 0.f;
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf, sacc, 0, 0, 0);      // rows = queries, col = this lane's key
+      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, vf, pacc, 0, 0, 0);      // dP
+      float pv[16], dsv[16];
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int q0 = qt * 32 + 8 * gq + 4 * h;
+        const int4 qi4 = *reinterpret_cast<const int4*>(info + q0);
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse + q0);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta + q0);
+        const int qiv[4] = {qi4.x, qi4.y, qi4.z, qi4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int w = qiv[e];
+          const int bidx = (w & 0xfff) - ck;
+          float sc = sacc[4 * gq + e] + table[bidx];
+          if (use_mask && ((w >> 12) & 31) != lk) sc -= 100.f;
+          float p = __expf(sc - l4[e]);
+          if (!kvalid || !(w >> 20)) p = 0.f;
+          const float ds = p * (pacc[4 * gq + e] - d4[e]);
+          pv[4 * gq + e] = p;
+          dsv[4 * gq + e] = ds;
+          if (dbias_table && p != 0.f && !(dbg & 1)) atomicAdd(&dtable[bidx], ds);
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = cvt8(pv + 8 * s2), df = cvt8(dsv + 8 * s2);
+        dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_dimmajor_frag(Gt, r, h, qt * 32, s2), pf, dvt, 0, 0, 0);   // dV^T += dO^T P
+        dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_dimmajor_frag(Qt, r, h, qt * 32, s2), df, dkt, 0, 0, 0);   // dK^T += Q^T dS
+      }
+    }
+    // dK, dV of key ki: dims 4h..4h+3 (regs 0-3) and 8+4h..+3 (regs 4-7)
+    if (ki < n) {
+      const int row = rowq[ki];
+      if (row >= 0) {
+        bf16* pk = dqkv + (int64_t)row * lddq + C + head * 16;
+        bf16* pv2 = dqkv + (int64_t)row * lddq + 2 * C + head * 16;
+        *reinterpret_cast<bf16x4*>(pk + 4 * h) = bf16x4{(bf16)dkt[0], (bf16)dkt[1], (bf16)dkt[2], (bf16)dkt[3]};
+        *reinterpret_cast<bf16x4*>(pk + 8 + 4 * h) = bf16x4{(bf16)dkt[4], (bf16)dkt[5], (bf16)dkt[6], (bf16)dkt[7]};
+        *reinterpret_cast<bf16x4*>(pv2 + 4 * h) = bf16x4{(bf16)dvt[0], (bf16)dvt[1], (bf16)dvt[2], (bf16)dvt[3]};
+        *reinterpret_cast<bf16x4*>(pv2 + 8 + 4 * h) = bf16x4{(bf16)dvt[4], (bf16)dvt[5], (bf16)dvt[6], (bf16)dvt[7]};
+      } else if (dqkv_bias) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int d = (i & 3) + 8 * (i >> 2) + 4 * h;
+          atomicAdd(&padb[16 + d], dkt[i]);
+          atomicAdd(&padb[32 + d], dvt[i]);
+        }
+      }
+    }
+  }
+  // ---------------- pass B: the QUERY on the lane (S^T = K Q^T, dP^T = V dO^T) -> dQ^T += K^T dS^T in registers
+  for (int qt = wave; qt < ntiles; qt += 4) {
+    const int qi = qt * 32 + r;
+    const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + qi * 16 + 8 * h);     // B operand [k=dim][col=query]
+    const bf16x8 gf = *reinterpret_cast<const bf16x8*>(Gs + qi * 16 + 8 * h);
+    const int qinfo = info[qi];
+    const int cq = (qinfo & 0xfff) + centre, lq = (qinfo >> 12) & 31;
+    const bool qvalid = (qinfo >> 20) != 0;
+    const float lse_q = lse[qi], delta_q = delta[qi];
+    f32x16 dq;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dq[i] = 0.f;
+    for (int kt = 0; kt < ntiles; ++kt) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + r) * 16 + 8 * h);   // A operand [row=key][k=dim]
+      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + (kt * 32 + r) * 16 + 8 * h);
+      f32x16 sacc, pacc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sacc[i] = pacc[i] = 0.f;
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, sacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, gf, pacc, 0, 0, 0);
+      float dsv[16];
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int4 ki4 = *reinterpret_cast<const int4*>(info + kt * 32 + 8 * gq + 4 * h);
+        const int kiv[4] = {ki4.x, ki4.y, ki4.z, ki4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int w = kiv[e];
+          float sc = sacc[4 * gq + e] + table[cq - (w & 0xfff)];
+          if (use_mask && ((w >> 12) & 31) != lq) sc -= 100.f;
+          float p = __expf(sc - lse_q);
+          if (!qvalid || !(w >> 20)) p = 0.f;
+          dsv[4 * gq + e] = p * (pacc[4 * gq + e] - delta_q);
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_dimmajor_frag(Kt, r, h, kt * 32, s2), cvt8(dsv + 8 * s2), dq, 0, 0, 0);
+    }
+    if (qi < n) {
+      const int row = rowq[qi];
+      if (row >= 0) {
+        bf16* pq = dqkv + (int64_t)row * lddq + head * 16;
+        *reinterpret_cast<bf16x4*>(pq + 4 * h) = bf16x4{(bf16)(dq[0] * g.scale), (bf16)(dq[1] * g.scale), (bf16)(dq[2] * g.scale), (bf16)(dq[3] * g.scale)};
+        *reinterpret_cast<bf16x4*>(pq + 8 + 4 * h) = bf16x4{(bf16)(dq[4] * g.scale), (bf16)(dq[5] * g.scale), (bf16)(dq[6] * g.scale), (bf16)(dq[7] * g.scale)};
+      } else if (dqkv_bias) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(&padb[(i & 3) + 8 * (i >> 2) + 4 * h], dq[i] * g.scale);
+      }
+    }
+  }
+  __syncthreads();
+  if (dbias_table)
+    for (int i = tid; i < tsize; i += 256) {
+      const float v = dtable[i];
+      if (v != 0.f) atomicAdd(dbias_table + (int64_t)i * g.heads + head, v);
+    }
+  if (dqkv_bias) {   // one global atomic per (q/k/v, dim) per workgroup instead of one per padded token
+    __syncthreads();
+    if (tid < 48) {
+      const float v = padb[tid];
+      if (v != 0.f) atomicAdd(dqkv_bias + (tid >> 4) * C + head * 16 + (tid & 15), v);
+    }
+  }
+}
+
+static size_t attn_mfma_bwd_smem(int tsize) {
+  return (size_t)(4 * ATT_NP * 16 + 3 * 16 * ATT_VT_LD) * 2 + (size_t)4 * ATT_NP * 4 + (size_t)2 * tsize * 4 + 48 * 4;
+}
+
+static size_t attn_mfma_fwd_smem(int tsize) {
+  return (size_t)(2 * ATT_NP * 16 + 16 * ATT_VT_LD) * 2 + (size_t)2 * ATT_NP * 4 + (size_t)tsize * 4;
 }
 
 }  // namespace miseg
@@ -349,6 +704,13 @@ extern "C" int miseg_winattn_fwd(const miseg_winattn_params* p, miseg_stream_t s
   MISEG_REQUIRE(sh <= 160 * 1024, MISEG_E_UNSUPPORTED, "winattn_fwd: %zu bytes of LDS needed", sh);
   dim3 grid(g.B * g.nwd * g.nwh * g.nww, g.heads);
   const int threads = cdiv(g.n, 64) * 64;
+  if (p->dtype == MISEG_BF16 && g.hd == 16 && g.n <= ATT_NP && p->bias_table && ((uintptr_t)p->out % 8 == 0) && p->ldo % 4 == 0) {
+    const size_t shm = attn_mfma_fwd_smem(tsize);
+    hipFuncSetAttribute((const void*)winattn_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    winattn_fwd_mfma_kernel<<<grid, 256, shm, s>>>((const bf16*)p->qkv, p->ldq, (bf16*)p->out, p->ldo, p->qkv_bias, p->bias_table, p->lse, g, tsize);
+    MISEG_LAUNCH_CHECK("winattn_fwd_mfma");
+    return MISEG_OK;
+  }
   return dispatch_dtype(p->dtype, [&](auto* tag) -> int {
     typedef typename std::remove_pointer<decltype(tag)>::type T;
     HD_SWITCH(g.hd / 4, {
@@ -371,6 +733,15 @@ extern "C" int miseg_winattn_bwd(const miseg_winattn_bwd_params* p, miseg_stream
   MISEG_REQUIRE(sh <= 160 * 1024, MISEG_E_UNSUPPORTED, "winattn_bwd: %zu bytes of LDS needed", sh);
   dim3 grid(g.B * g.nwd * g.nwh * g.nww, g.heads);
   const int threads = cdiv(g.n, 64) * 64;
+  if (p->f.dtype == MISEG_BF16 && g.hd == 16 && g.n <= ATT_NP && p->f.bias_table && ((uintptr_t)p->dqkv % 8 == 0) && p->lddq % 4 == 0) {
+    const size_t shm = attn_mfma_bwd_smem(tsize);
+    hipFuncSetAttribute((const void*)winattn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    winattn_bwd_mfma_kernel<<<grid, 256, shm, s>>>((const bf16*)p->f.qkv, p->f.ldq, (const bf16*)p->f.out, p->f.ldo, (const bf16*)p->dout, p->lddo, (bf16*)p->dqkv,
+                                                   p->lddq, p->f.qkv_bias, p->f.bias_table, p->f.lse, p->dqkv_bias, p->dbias_table, g, tsize,
+                                                   getenv("MISEG_ATT_DEBUG") ? atoi(getenv("MISEG_ATT_DEBUG")) : 0);
+    MISEG_LAUNCH_CHECK("winattn_bwd_mfma");
+    return MISEG_OK;
+  }
   return dispatch_dtype(p->f.dtype, [&](auto* tag) -> int {
     typedef typename std::remove_pointer<decltype(tag)>::type T;
     HD_SWITCH(g.hd / 4, {

@@ -261,3 +261,68 @@ def test_space_channel_im2col_misc(dtype):
     assert rel_err(ops.colsum(big), big.float().sum(0)) < TOL[dtype]
     w = rnd(37, 53, seed=76)
     assert torch.equal(ops.cast_matrix(w, dtype, transpose=True), w.t().contiguous().to(dtype))
+
+
+def _ref_window_attention(qkv, qkv_bias, table, heads, ws, ss, tw, scale):
+    """plain PyTorch fp32 reference of the fused attention core (pad with the bias row, roll, partition, softmax(QK^T+bias+mask)V,
+    reverse, roll back, crop) built from the oracle's helpers."""
+    from oracle.functional import compute_mask, relative_position_index, window_partition, window_reverse
+    B, D, H, W, C3 = qkv.shape
+    C = C3 // 3
+    hd = C // heads
+    pd, ph, pw = (-D) % ws[0], (-H) % ws[1], (-W) % ws[2]
+    x = qkv
+    if pd or ph or pw:
+        full = qkv_bias.view(1, 1, 1, 1, C3).expand(B, D + pd, H + ph, W + pw, C3).clone()
+        full[:, :D, :H, :W] = qkv
+        x = full
+    Dp, Hp, Wp = x.shape[1:4]
+    mask = None
+    if any(ss):
+        x = torch.roll(x, shifts=tuple(-s for s in ss), dims=(1, 2, 3))
+        mask = compute_mask((Dp, Hp, Wp), ws, ss).to(qkv.device)
+    win = window_partition(x, ws)
+    b, n, _ = win.shape
+    q, k, v = win.reshape(b, n, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    attn = (q * scale) @ k.transpose(-2, -1)
+    idx = relative_position_index((tw, tw, tw)).to(qkv.device)[:n, :n].reshape(-1)
+    attn = attn + table[idx].reshape(n, n, -1).permute(2, 0, 1).unsqueeze(0)
+    if mask is not None:
+        nw = mask.shape[0]
+        attn = (attn.view(b // nw, nw, heads, n, n) + mask.unsqueeze(1).unsqueeze(0)).view(-1, heads, n, n)
+    o = (attn.softmax(-1) @ v).transpose(1, 2).reshape(b, n, C)
+    o = window_reverse(o.view(-1, *ws, C), ws, (B, Dp, Hp, Wp))
+    if any(ss):
+        o = torch.roll(o, shifts=ss, dims=(1, 2, 3))
+    return o[:, :D, :H, :W].contiguous()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dims,ws,ss,heads,C", [((14, 14, 14), (7, 7, 7), (3, 3, 3), 3, 48), ((10, 9, 8), (7, 7, 7), (0, 0, 0), 3, 48),
+                                                ((10, 9, 8), (7, 7, 7), (3, 3, 3), 2, 32), ((6, 6, 6), (6, 6, 6), (0, 0, 0), 3, 48),
+                                                ((7, 7, 7), (7, 7, 7), (0, 0, 0), 3, 12)])
+def test_window_attention_core(dtype, dims, ws, ss, heads, C):
+    ops = _ops()
+    B = 2
+    qkv = rnd(B, *dims, 3 * C, dtype=dtype, seed=81)
+    qb = rnd(3 * C, seed=82) * 0.3
+    table = rnd(2197, heads, seed=83) * 0.5
+    scale = (C // heads) ** -0.5
+    out, lse = ops.winattn_fwd(qkv, qb, table, heads, ws, ss, 7, scale)
+    qr = qkv.float().clone().requires_grad_(True)
+    qbr, tr = qb.clone().requires_grad_(True), table.clone().requires_grad_(True)
+    ref = _ref_window_attention(qr, qbr, tr, heads, ws, ss, 7, scale)
+    assert rel_err(out, ref) < TOL[dtype]
+    g = rnd(*out.shape, dtype=dtype, seed=84)
+    ref.backward(g.float())
+    dqb, dtab = torch.zeros_like(qb), torch.zeros_like(table)
+    dqkv = ops.winattn_bwd(qkv, out, lse, g, qb, table, heads, ws, ss, 7, scale, dqb, dtab)
+    tol = TOL[dtype] * (2 if dtype == torch.bfloat16 else 1)
+    assert rel_err(dqkv, qr.grad) < tol
+    assert rel_err(dtab, tr.grad) < tol
+    # the Linear's own bias gradient is not part of the fused core: only padded tokens contribute here
+    pad_tokens = any((-d) % w for d, w in zip(dims, ws))
+    if pad_tokens:
+        assert rel_err(dqb, qbr.grad) < 2 * tol
+    else:
+        assert float(dqb.abs().max()) == 0.0
