@@ -1,0 +1,68 @@
+"""Multi-process (gloo, world_size 2, CPU) tests of the N>1 path: flat gradient arena mean all-reduce with the
+"no gradient on any rank => stays None" rule, and the interleaved CT/MR rank sharding."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    ge.load_package()
+    from mi_seg_amd.data.sampler import concat_modalities, rank_indices
+    from mi_seg_amd.parallel.ddp import allreduce_gradients
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    # a toy "conditional" parameter set: shared weight, style-0 rows, style-1 rows, a never-used parameter
+    shared = torch.nn.Parameter(torch.zeros(5, 3))
+    s0 = torch.nn.Parameter(torch.zeros(4))
+    s1 = torch.nn.Parameter(torch.zeros(4))
+    unused = torch.nn.Parameter(torch.zeros(2))
+    params = [shared, s0, s1, unused]
+    shared.grad = torch.full((5, 3), float(rank + 1))
+    if rank == 0:
+        s0.grad = torch.full((4,), 2.0)      # rank 0 saw a CT patch
+    else:
+        s1.grad = torch.full((4,), 6.0)      # rank 1 saw an MR patch
+    allreduce_gradients(params, world)
+    ok = True
+    ok &= torch.allclose(shared.grad, torch.full((5, 3), 1.5))
+    ok &= torch.allclose(s0.grad, torch.full((4,), 1.0))       # (2 + 0) / 2: absent on rank 1 -> zero slot
+    ok &= torch.allclose(s1.grad, torch.full((4,), 3.0))
+    ok &= unused.grad is None                                   # unused on every rank: untouched by the optimiser
+    # second step reuses the arena
+    shared.grad = torch.full((5, 3), 4.0)
+    s0.grad, s1.grad, unused.grad = None, None, None
+    allreduce_gradients(params, world)
+    ok &= torch.allclose(shared.grad, torch.full((5, 3), 4.0)) and s0.grad is None and s1.grad is None
+    # rank sharding: disjoint cover of the concatenated CT+MR index range
+    mine = rank_indices(32, world, rank, epoch=1, seed=0)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    ok &= sorted(sum(gathered, [])) == list(range(32))
+    mods = concat_modalities(16, 16)
+    ok &= set(mods[i] for i in mine) <= {0, 1}
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_gradient_arena_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=100) for _ in range(2))
+    for p in procs:
+        p.join(30)
+    assert res == {0: True, 1: True}

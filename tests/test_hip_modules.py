@@ -204,3 +204,35 @@ def test_swin_unetr_c2_headline(golden, tag, dtype, tol, ce):
     m = SwinUNETR((96, 96, 96), 1, 6, feature_size=48, num_heads=(3, 6, 12, 24), vit_norm_name=_norm("instance_cond"),
                   encoder_norm_name=_norm("instance_cond"), decoder_norm_name=_norm("instance"))
     _whole(G, tag, m, tol, dtype, ce)
+
+
+@pytest.mark.parametrize("tag", ["cond", "layer_bias"])
+def test_transformer_block(golden, tag):
+    from mi_seg_amd.networks.blocks.transformer_block import TransformerBlock
+    G = golden("transformer_block")
+    case = G.meta["cases"][tag]
+    m = _fill(TransformerBlock(case["hidden"], case["mlp"], case["heads"], 0.0, case["qkv_bias"], norm_type=_norm(case["norm"])))
+    x = G.t(f"{tag}/x").to(DEV).requires_grad_(True)
+    y = m(x, _styles(case["modalities"], 2), (3, 3, 3))
+    y.backward(G.t(f"{tag}/g").to(DEV))
+    assert rel_err(y, G.t(f"{tag}/y")) < TOL
+    assert rel_err(x.grad, G.t(f"{tag}/dx")) < TOL
+    _check_param_grads(m, G.grads(tag), case["grad_none"], TOL)
+
+
+def test_unetr_small(golden):
+    from mi_seg_amd.networks.nets.unetr import UNETR
+    G = golden("unetr_small")
+    m = UNETR(1, 6, (32, 32, 32), feature_size=8, hidden_size=48, mlp_dim=96, num_heads=4, pos_embed="perceptron", vit_norm_name=_norm("instance_cond"),
+              encoder_norm_name=_norm("instance_cond"), decoder_norm_name=_norm("instance"))
+    _whole(G, "small_32", m, TOL)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL)])
+def test_unetr_c3(golden, dtype, tol):
+    """BASELINE configs[2]: C-UNETR (ViT-B/16 encoder, instance_cond), 96^3."""
+    from mi_seg_amd.networks.nets.unetr import UNETR
+    G = golden("unetr_c3")
+    m = UNETR(1, 6, (96, 96, 96), feature_size=16, hidden_size=768, mlp_dim=3072, num_heads=12, pos_embed="perceptron",
+              vit_norm_name=_norm("instance_cond"), encoder_norm_name=_norm("instance_cond"), decoder_norm_name=_norm("instance"))
+    _whole(G, "c3_m1", m, tol, dtype)

@@ -1,0 +1,163 @@
+"""CPU tests of the host-side drop-in surface: parser defaults, model factory, state_dict layouts, error conventions, C-ABI symbol
+table, rank sharding, sliding-window geometry.  No GPU compute is launched."""
+import argparse
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _args(extra=()):
+    from mi_seg_amd.utils.parser import add_data_argparse_args, add_model_argparse_args, add_tune_argparse_args
+    p = argparse.ArgumentParser()
+    add_tune_argparse_args(add_data_argparse_args(add_model_argparse_args(p)))
+    return p.parse_args(list(extra))
+
+
+def test_parser_defaults_match_reference():
+    a = _args()
+    assert (a.model_name, a.roi_x, a.feature_size, a.hidden_size, a.mlp_dim, a.num_heads, a.pos_embed) == ("unetr", 96, [16], 768, 3072, 12, "perceptron")
+    assert (a.vit_norm_name, a.encoder_norm_name, a.decoder_norm_name, a.num_styles, a.depth_swin_block, a.downsample) == \
+        ("layer", "instance", "instance", 2, [2], "merging")
+    assert (a.num_layers, a.strides, a.num_res_units, a.activation, a.criterion, a.optim_name, a.lr, a.reg_weight) == \
+        (4, [2, 2, 2], 2, "prelu", "dice_focal", "adamw", 1e-4, 1e-5)
+    assert (a.infer_overlap, a.sw_batch_size, a.scheduler, a.iters_to_accumulate) == (0.5, 1, "reduce_on_plateau", 1)
+
+
+def test_model_factory_headline_config(golden):
+    """README.md:170-173 recipe -> SwinUNETR with the reference's 273-entry state_dict."""
+    from mi_seg_amd.networks.utils.utils import model_from_argparse_args
+    a = _args(["--model_name=swin_unetr", "--out_channels=6", "--feature_size=48", "--num_heads=3", "--encoder_norm_name=instance_cond",
+               "--vit_norm_name=instance_cond"])
+    m = model_from_argparse_args(a)
+    case = golden("swin_unetr_c2").meta["cases"]["c2_m0"]
+    assert list(m.state_dict().keys()) == case["state_keys"]
+    assert [list(v.shape) for v in m.state_dict().values()] == case["state_shapes"]
+    assert sum(p.numel() for p in m.parameters()) == 62218200
+    with pytest.raises(ValueError):
+        model_from_argparse_args(_args(["--model_name=nope"]))
+
+
+def test_unetr_and_unet_layouts(golden):
+    from mi_seg_amd.networks.utils.utils import model_from_argparse_args
+    m = model_from_argparse_args(_args(["--model_name=unetr", "--out_channels=6", "--encoder_norm_name=instance_cond", "--vit_norm_name=instance_cond"]))
+    case = golden("unetr_c3").meta["cases"]["c3_m1"]
+    assert list(m.state_dict().keys()) == case["state_keys"] and sum(p.numel() for p in m.parameters()) == 92824966
+    u = model_from_argparse_args(_args(["--model_name=unet", "--out_channels=6"]))
+    case = golden("unet").meta["cases"]["c1_64"]
+    assert list(u.state_dict().keys()) == case["state_keys"] and sum(p.numel() for p in u.parameters()) == 4749969
+    assert u.channels == [32, 64, 128, 256]                 # fs * 2**i, i = 1..num_layers (reference unet.py:218-219)
+    with pytest.raises(NotImplementedError):
+        u(torch.zeros(1, 1, 8, 8, 8))
+
+
+def test_constructor_errors():
+    from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
+    from mi_seg_amd.networks.norms.utils import parse_normalization
+    with pytest.raises(ValueError):
+        SwinUNETR((96, 96, 96), 1, 6, feature_size=50)
+    with pytest.raises(ValueError):
+        SwinUNETR((100, 96, 96), 1, 6, feature_size=48)
+    with pytest.raises(ValueError):
+        SwinUNETR((96, 96, 96), 1, 6, feature_size=48, encoder_norm_name="layer")
+    with pytest.raises(ValueError):
+        parse_normalization("nope", True)
+    assert parse_normalization("instance_cond", True, 4, 2) == ("instance_cond", {"num_styles": 2, "affine": True})
+
+
+def test_no_cpu_fallback():
+    """the product path fails loudly without a HIP device instead of computing on the CPU."""
+    from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
+    m = SwinUNETR((64, 64, 64), 1, 6, feature_size=12)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 1, 64, 64, 64), None)
+    from mi_seg_amd.hip import lib, ops
+    with pytest.raises(lib.MisegHipError):
+        ops.rows(torch.zeros(4, 4))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """every function prototype of include/miseg_hip.h is exported by the shared object and bound in hip/lib.py."""
+    from mi_seg_amd.hip import lib
+    hdr = open(os.path.join(ROOT, "include", "miseg_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(miseg_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    assert os.path.exists(lib.LIB_PATH), "run `python __graft_entry__.py` first"
+    so = ctypes.CDLL(lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(so, name), f"{name} declared in include/miseg_hip.h but not exported"
+        assert name in lib.PROTOS, f"{name} has no ctypes prototype in hip/lib.py"
+    assert set(lib.PROTOS) <= declared
+    so.miseg_abi_version.restype = ctypes.c_int
+    assert so.miseg_abi_version() == 1
+
+
+def test_rank_sharding_matches_distributed_sampler():
+    from torch.utils.data import DistributedSampler
+
+    from mi_seg_amd.data.sampler import concat_modalities, rank_indices
+    n = 16 + 16
+    for world in (1, 2, 4, 8):
+        seen = []
+        for r in range(world):
+            s = DistributedSampler(list(range(n)), num_replicas=world, rank=r, shuffle=True, seed=0)
+            s.set_epoch(3)
+            mine = rank_indices(n, world, r, epoch=3, seed=0)
+            assert list(iter(s)) == mine
+            seen += mine
+        assert sorted(seen) == list(range(n))
+    mods = concat_modalities(16, 16)
+    stream = [mods[i] for i in rank_indices(n, 8, 0, epoch=0)]
+    assert set(stream) <= {0, 1}
+
+
+def test_sliding_window_geometry_and_stitching():
+    from mi_seg_amd.training.inferer import sliding_window_inference, window_grid
+    grid = window_grid((512, 512, 363), (96, 96, 96), 0.5)
+    assert len(grid) == 700                                   # BASELINE config 5: 10 x 10 x 7 windows
+    assert max(g[2] for g in grid) == 363 - 96 and max(g[0] for g in grid) == 512 - 96
+    x = torch.randn(2, 1, 40, 37, 20)
+    calls = []
+
+    def predictor(win, mods):
+        calls.append((tuple(win.shape), list(mods)))
+        return torch.cat([win * 2.0, win + 1.0], 1)
+
+    out = sliding_window_inference(x, (16, 16, 16), 4, predictor, overlap=0.5, modalities=torch.tensor([1, 0]))
+    assert torch.allclose(out[:, 0:1], 2 * x, atol=1e-5) and torch.allclose(out[:, 1:2], x + 1, atol=1e-5)
+    assert all(len(set(m)) == 1 for _, m in calls) and calls[0][1][0] == 1 and calls[-1][1][0] == 0
+    small = sliding_window_inference(torch.randn(1, 1, 10, 12, 16), (16, 16, 16), 1, lambda w, m: w, modalities=[0])
+    assert small.shape == (1, 1, 10, 12, 16)
+
+
+def test_losses_and_metric_semantics():
+    from mi_seg_amd.training.losses import DiceCELoss, DiceFocalLoss
+    from mi_seg_amd.training.metrics import as_discrete_argmax_onehot, as_discrete_onehot, dice_metric
+    torch.manual_seed(0)
+    label = torch.randint(0, 3, (2, 1, 6, 6, 6))
+    perfect = as_discrete_onehot(label, 3) * 40.0 - 20.0
+    lf = DiceFocalLoss(include_background=True, to_onehot_y=True, softmax=True, squared_pred=True, smooth_nr=0.0, smooth_dr=1e-6)
+    assert float(lf(perfect, label)) < 1e-3
+    assert float(lf(-perfect, label)) > 1.0
+    lc = DiceCELoss(include_background=False, to_onehot_y=True, softmax=True)
+    assert float(lc(perfect, label)) < 1e-3
+    d = dice_metric(as_discrete_argmax_onehot(perfect, 3), as_discrete_onehot(label, 3))
+    assert torch.allclose(d, torch.ones_like(d))
+    lab2 = torch.zeros(1, 1, 4, 4, 4, dtype=torch.long)
+    d2 = dice_metric(as_discrete_onehot(lab2, 3), as_discrete_onehot(lab2, 3))
+    assert float(d2[0, 0]) == 1.0 and torch.isnan(d2[0, 1])   # NaN when the class is absent from the label
+
+
+def test_litmonai_surface():
+    from mi_seg_amd.networks.lightning_monai import LitMonai
+    a = _args(["--model_name=swin_unetr", "--out_channels=6", "--feature_size=12", "--num_heads=3", "--roi_x=64", "--roi_y=64", "--roi_z=64"])
+    lit = LitMonai.from_argparse_args(a)
+    conf = lit.configure_optimizers()
+    assert isinstance(conf["optimizer"], torch.optim.AdamW) and conf["lr_scheduler"]["monitor"] == "val/loss/avg"
+    with pytest.raises(ValueError):
+        LitMonai(lit.model, 6, criterion="nope")
