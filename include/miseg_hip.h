@@ -151,8 +151,10 @@ typedef struct {
 size_t miseg_conv3_fwd_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int dtype);
 int miseg_conv3_fwd(const miseg_conv3_params* p, miseg_stream_t stream);
 
-/* w: fp32 torch layout [Cout][Cin][3][3][3].  fwd_pack: [Cout][27][Cin]; bwd_pack: [Cin][27][Cout] with taps
- * mirrored (either may be NULL). */
+/* w: fp32 torch layout [Cout][Cin][3][3][3].  fwd_pack feeds miseg_conv3_fwd on x, bwd_pack (taps mirrored, channels swapped) feeds it
+ * on dy; either may be NULL.  The layout is internal (row-major [Cout][27][CinP] or planar [27][CinP/k][CoutP16][k], by channel count);
+ * buffers hold miseg_pack_conv3_elems(Cin, Cout, dtype, which) elements of `dtype` (which: 0 = fwd, 1 = bwd). */
+size_t miseg_pack_conv3_elems(int Cin, int Cout, int dtype, int which);
 typedef struct { const float* w; void* fwd_pack; void* bwd_pack; int Cin, Cout, dtype; } miseg_pack_conv3_params;
 int miseg_pack_conv3_weight(const miseg_pack_conv3_params* p, miseg_stream_t stream);
 

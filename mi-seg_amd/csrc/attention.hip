@@ -4,7 +4,6 @@
 // gathered from a per-head LDS copy of the table with idx = code[i] - code[j] + centre, and the shift mask is
 // derived from 27 region labels of the rolled grid (reference: swin_utils.py:107-143, window_attention.py:99-119).
 #include "common.h"
-#include <stdlib.h>
 
 namespace miseg {
 
@@ -460,7 +459,7 @@ __global__ void __launch_bounds__(256) winattn_bwd_mfma_kernel(const bf16* __res
                                                                const bf16* __restrict__ dout, int64_t lddo, bf16* __restrict__ dqkv, int64_t lddq,
                                                                const float* __restrict__ qkv_bias, const float* __restrict__ bias_table,
                                                                const float* __restrict__ lse_in, float* __restrict__ dqkv_bias,
-                                                               float* __restrict__ dbias_table, WinGeom g, int tsize, int dbg) {
+                                                               float* __restrict__ dbias_table, WinGeom g, int tsize) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16* Qs = reinterpret_cast<bf16*>(smem);          // [NP][16] scaled
   bf16* Ks = Qs + ATT_NP * 16;
@@ -555,7 +554,7 @@ __global__ void __launch_bounds__(256) winattn_bwd_mfma_kernel(const bf16* __res
           const float ds = p * (pacc[4 * gq + e] - d4[e]);
           pv[4 * gq + e] = p;
           dsv[4 * gq + e] = ds;
-          if (dbias_table && p != 0.f && !(dbg & 1)) atomicAdd(&dtable[bidx], ds);
+          if (dbias_table && p != 0.f) atomicAdd(&dtable[bidx], ds);
         }
       }
 #pragma unroll
@@ -737,8 +736,7 @@ extern "C" int miseg_winattn_bwd(const miseg_winattn_bwd_params* p, miseg_stream
     const size_t shm = attn_mfma_bwd_smem(tsize);
     hipFuncSetAttribute((const void*)winattn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     winattn_bwd_mfma_kernel<<<grid, 256, shm, s>>>((const bf16*)p->f.qkv, p->f.ldq, (const bf16*)p->f.out, p->f.ldo, (const bf16*)p->dout, p->lddo, (bf16*)p->dqkv,
-                                                   p->lddq, p->f.qkv_bias, p->f.bias_table, p->f.lse, p->dqkv_bias, p->dbias_table, g, tsize,
-                                                   getenv("MISEG_ATT_DEBUG") ? atoi(getenv("MISEG_ATT_DEBUG")) : 0);
+                                                   p->lddq, p->f.qkv_bias, p->f.bias_table, p->f.lse, p->dqkv_bias, p->dbias_table, g, tsize);
     MISEG_LAUNCH_CHECK("winattn_bwd_mfma");
     return MISEG_OK;
   }

@@ -152,138 +152,175 @@ __global__ void __launch_bounds__(256) conv3_fwd_kernel(const T* __restrict__ x,
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// forward, fast path: channel chunks of exactly 96 bytes (6 groups per tap: 48 bf16 / 24 fp32 channels), weights
-// staged through LDS in phases of 2 taps (12 groups = 3 MFMA k-steps) shared by the 4 waves, next phase's weights
-// prefetched into registers while the current phase computes.  LDS: halo 600 x 112 B + weights 16NT x 208 B.
+// forward, fast path: channel chunks of exactly 96 bytes (6 groups per tap: 48 bf16 / 24 fp32 channels).
+//   brick 4(d) x 4(h) x 16(w): wave = d, M-tile = h, lane&15 = w  -> the 16 lanes of an operand read touch 16 consecutive
+//   halo rows.  LDS images are PLANAR so that bank = row mod 16 whatever the channel group:
+//     halo    [6 channel groups][656 rows (648 used)][16 B]   (plane stride = 0 mod 16 rows)
+//     weights [12 k-groups of the phase][16*NT out-channels][16 B]
+//   => same-(tap,group) operand reads are conflict-free (SQ_LDS_BANK_CONFLICT was 57 % of LDS cycles with row-major
+//   112-byte rows).  Weights come from the planar pack [tap][group][CoutP16][16 B], staged per phase of 2 taps with a
+//   linear copy, next phase prefetched into registers during the MFMAs.
 // ---------------------------------------------------------------------------------------------------------
+static constexpr int FBD = 4, FBH = 4, FBW = 16;
+static constexpr int FHH = FBH + 2, FHW = FBW + 2;
+static constexpr int FHROWS = (FBD + 2) * FHH * FHW;      // 648
+static constexpr int FPS = 656;                            // plane stride in rows (multiple of 16)
+
 template <class T, int NT>
 __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, const T* __restrict__ wpk,
-                                                             ConvGeom g, int Cin, int CinP, int Cout, bool vec_x, float* __restrict__ scratch,
-                                                             int chunks_per_split) {
+                                                             ConvGeom g, int Cin, int CinP, int Cout, int CoP, bool vec_x, bool vec_y,
+                                                             float* __restrict__ scratch, int chunks_per_split) {
   typedef typename Vec16<T>::type VT;
   constexpr int KPC = MmaC<T>::KPC;
-  constexpr int GPT = 6, CHUNK = GPT * KPC;          // elements per chunk
-  constexpr int ROWB = 112, WROWB = 208;               // padded LDS row strides (bytes)
-  constexpr int HROWS = (BD + 2) * HH * HW;
+  constexpr int GPT = 6, CHUNK = GPT * KPC;
   constexpr int NROWS = 16 * NT;
-  constexpr int WLOADS = (NROWS * 12 + 255) / 256;     // 16-byte weight loads per thread per phase
+  constexpr int WITEMS = 12 * NROWS;                       // 16-byte items of one weight phase
+  constexpr int WLOADS = (WITEMS + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  char* lh = lds;                    // halo
-  char* lw = lds + HROWS * ROWB;     // weights of the current phase
+  char* lh = lds;                                          // [6][FPS][16]
+  char* lw = lds + GPT * FPS * 16;                         // 2 x [12][NROWS][16] (double buffer)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int bid = blockIdx.x;
   const int bw = bid % g.nbw; bid /= g.nbw;
   const int bh = bid % g.nbh; bid /= g.nbh;
   const int bd = bid % g.nbd;
   const int b = bid / g.nbd;
-  const int d0 = bd * BD, h0 = bh * BH, w0 = bw * BW;
+  const int d0 = bd * FBD, h0 = bh * FBH, w0 = bw * FBW;
   const int n0 = blockIdx.y * NROWS;
   const int fi = lane & 15, fq = lane >> 4;
+  const int NCG = CinP / KPC;
 
   int vbase[4];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) vbase[mt] = ((wave * HH + 2 * mt + (fi >> 3)) * HW + (fi & 7)) * ROWB;
+  for (int mt = 0; mt < 4; ++mt) vbase[mt] = ((wave * FHH + mt) * FHW + fi) * 16;
   f32x4 acc[4][NT];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // per-thread weight-load slots of a phase: idx -> (row, grp)
-  int wrow[WLOADS], wgrp[WLOADS];
-  const T* wsrc[WLOADS];
+  VT wreg[WLOADS];
+  // per-thread weight item offsets (in 16-byte units) relative to (tap 2*phase, chunk group cg0), computed once
+  int woff[WLOADS];
+  bool wsecond[WLOADS];
 #pragma unroll
   for (int i = 0; i < WLOADS; ++i) {
     const int idx = tid + 256 * i;
-    wrow[i] = idx / 12;
-    wgrp[i] = idx - wrow[i] * 12;
-    const int co = n0 + wrow[i];
-    const bool ok = idx < NROWS * 12 && co < Cout;
-    // element offset of (tap 0 or 1 of the phase, cg) relative to the phase base
-    wsrc[i] = ok ? wpk + (int64_t)co * 27 * CinP + (wgrp[i] / GPT) * CinP + (wgrp[i] % GPT) * KPC : nullptr;
+    const int gk = idx / NROWS, row = idx - gk * NROWS;
+    wsecond[i] = gk >= GPT;
+    woff[i] = (idx < WITEMS && n0 + row < CoP) ? ((gk / GPT) * NCG + gk % GPT) * CoP + n0 + row : -1;
   }
-  VT wreg[WLOADS];
-  auto wload = [&](int phase, int c0) {
+  auto wload = [&](int phase, int cg0) {
+    const int64_t pbase = ((int64_t)(2 * phase) * NCG + cg0) * CoP;     // wave-uniform
+    const bool last = 2 * phase + 1 >= 27;
 #pragma unroll
     for (int i = 0; i < WLOADS; ++i) {
       VT v;
 #pragma unroll
       for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(0.f);
-      const bool second_tap = wgrp[i] >= GPT;
-      if (wsrc[i] && !(second_tap && 2 * phase + 1 >= 27)) v = *reinterpret_cast<const VT*>(wsrc[i] + (int64_t)(2 * phase) * CinP + c0);
+      if (woff[i] >= 0 && !(last && wsecond[i])) v = *reinterpret_cast<const VT*>(wpk + (pbase + woff[i]) * KPC);
       wreg[i] = v;
     }
   };
-  auto wstore = [&]() {
+  auto wstore = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < WLOADS; ++i)
-      if (tid + 256 * i < NROWS * 12) *reinterpret_cast<VT*>(lw + wrow[i] * WROWB + wgrp[i] * 16) = wreg[i];
+      if (tid + 256 * i < WITEMS) *reinterpret_cast<VT*>(lw + (buf * WITEMS + tid + 256 * i) * 16) = wreg[i];
   };
-  // static per-lane k-step geometry inside a phase: group gi = 4*s + fq -> (tap select, byte offset of its channel group)
-  const int sel1 = fq >= 2;                      // step 1: groups 4..7 -> tap0 cg 4,5 | tap1 cg 0,1
-  const int cgo0 = fq * 16;                      // step 0: tap0 cg 0..3
-  const int cgo1 = (sel1 ? fq - 2 : fq + 4) * 16;
-  const int cgo2 = (fq + 2) * 16;                // step 2: tap1 cg 2..5
+  // per-lane k-step geometry inside a phase: group gi = 4*s + fq -> (tap select, channel-group plane)
+  const int sel1 = fq >= 2;
+  const int cgo0 = fq * FPS * 16;
+  const int cgo1 = (sel1 ? fq - 2 : fq + 4) * FPS * 16;
+  const int cgo2 = (fq + 2) * FPS * 16;
+  const int wfrag = fi * 16;
 
+  int* rowoff = reinterpret_cast<int*>(lw + WITEMS * 16);   // aliases weight buffer 1 (rewritten by phase 1 => rebuilt per chunk)
   const int cbeg = blockIdx.z * chunks_per_split * CHUNK, cend = min(CinP, cbeg + chunks_per_split * CHUNK);
   for (int c0 = cbeg; c0 < cend; c0 += CHUNK) {
-    wload(0, c0);
-    __syncthreads();   // previous chunk's readers are done with halo + weights
-    for (int idx = tid; idx < HROWS * GPT; idx += 256) {
-      const int row = idx / GPT, cg = idx - row * GPT;
-      const int hd = row / (HH * HW), rem = row - hd * (HH * HW);
-      const int hh = rem / HW, hw = rem - hh * HW;
+    wload(0, c0 / KPC);
+    // halo row -> voxel index (or -1 outside the volume = zero padding)
+    for (int row = tid; row < FHROWS; row += 256) {
+      const int hd = row / (FHH * FHW), rem = row - hd * (FHH * FHW);
+      const int hh = rem / FHW, hw = rem - hh * FHW;
       const int d = d0 - 1 + hd, h = h0 - 1 + hh, w = w0 - 1 + hw;
-      VT v;
-#pragma unroll
-      for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(0.f);
-      if (d >= 0 && d < g.D && h >= 0 && h < g.H && w >= 0 && w < g.W) {
-        const int c = c0 + cg * KPC;
-        const T* p = x + ((((int64_t)b * g.D + d) * g.H + h) * g.W + w) * ldx + c;
-        if (vec_x && c + KPC <= Cin) v = *reinterpret_cast<const VT*>(p);
-        else {
-#pragma unroll
-          for (int e = 0; e < KPC; ++e)
-            if (c + e < Cin) v[e] = p[e];
-        }
-      }
-      *reinterpret_cast<VT*>(lh + row * ROWB + cg * 16) = v;
+      rowoff[row] = (d >= 0 && d < g.D && h >= 0 && h < g.H && w >= 0 && w < g.W) ? (((b * g.D + d) * g.H + h) * g.W + w) : -1;
     }
-    wstore();
     __syncthreads();
+    // halo: items ordered so that 8 consecutive lanes write 8 consecutive rows of one plane (conflict-free ds_write_b128)
+    // while 48 consecutive lanes read 8 voxels x 96 contiguous bytes from HBM; all 16 loads of a lane are issued before
+    // the first LDS write (row -> global offset comes from the table built once per workgroup)
+    {
+      constexpr int NIT = (FHROWS * GPT + 255) / 256;      // 16
+      VT hv[NIT];
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int idx = tid + 256 * i;
+        const int blk = idx / 48, j = idx - blk * 48;
+        const int cg = j >> 3, row = blk * 8 + (j & 7);
+        VT v;
+#pragma unroll
+        for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(0.f);
+        const int64_t ro = idx < FHROWS * GPT ? rowoff[row] : -1;
+        if (ro >= 0) {
+          const int c = c0 + cg * KPC;
+          const T* p = x + ro * ldx + c;
+          if (vec_x && c + KPC <= Cin) v = *reinterpret_cast<const VT*>(p);
+          else {
+#pragma unroll
+            for (int e = 0; e < KPC; ++e)
+              if (c + e < Cin) v[e] = p[e];
+          }
+        }
+        hv[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int idx = tid + 256 * i;
+        const int blk = idx / 48, j = idx - blk * 48;
+        if (idx < FHROWS * GPT) *reinterpret_cast<VT*>(lh + ((j >> 3) * FPS + blk * 8 + (j & 7)) * 16) = hv[i];
+      }
+    }
+    wstore(0);
+    __syncthreads();
+    auto frags = [&](int phase, int s, VT (&af)[4], VT (&bfr)[NT]) {
+      const int t0 = 2 * phase, t1 = (2 * phase + 1 < 27) ? 2 * phase + 1 : 2 * phase;
+      const int toff0 = (((t0 / 9) * FHH + (t0 / 3) % 3) * FHW + t0 % 3) * 16;
+      const int toff1 = (((t1 / 9) * FHH + (t1 / 3) % 3) * FHW + t1 % 3) * 16;
+      const int aoff = (s == 0 ? toff0 + cgo0 : s == 1 ? (sel1 ? toff1 : toff0) + cgo1 : toff1 + cgo2);
+      const char* wb = lw + ((phase & 1) * WITEMS + (4 * s + fq) * NROWS) * 16 + wfrag;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bfr[nt] = *reinterpret_cast<const VT*>(wb + nt * 256);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const VT*>(lh + vbase[mt] + aoff);
+    };
 #pragma unroll 1
     for (int phase = 0; phase < 14; ++phase) {
-      if (phase + 1 < 14) wload(phase + 1, c0);
-      const int t0 = 2 * phase, t1 = (2 * phase + 1 < 27) ? 2 * phase + 1 : 2 * phase;   // last phase: 2nd tap has zero weights
-      const int toff0 = (((t0 / 9) * HH + (t0 / 3) % 3) * HW + t0 % 3) * ROWB;
-      const int toff1 = (((t1 / 9) * HH + (t1 / 3) % 3) * HW + t1 % 3) * ROWB;
+      if (phase + 1 < 14) wload(phase + 1, c0 / KPC);
       const int nsteps = phase == 13 ? 2 : 3;
+      VT af[2][4], bfr[2][NT];
+      frags(phase, 0, af[0], bfr[0]);
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
         if (s < nsteps) {
-          const int aoff = (s == 0 ? toff0 + cgo0 : s == 1 ? (sel1 ? toff1 : toff0) + cgo1 : toff1 + cgo2);
-          VT bfr[NT], af[4];
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) bfr[nt] = *reinterpret_cast<const VT*>(lw + (nt * 16 + fi) * WROWB + (4 * s + fq) * 16);
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const VT*>(lh + vbase[mt] + aoff);
+          if (s + 1 < nsteps) frags(phase, s + 1, af[(s + 1) & 1], bfr[(s + 1) & 1]);   // next step's operands in flight during the MFMAs
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) MmaC<T>::run(acc[mt][nt], bfr[nt], af[mt]);
+            for (int nt = 0; nt < NT; ++nt) MmaC<T>::run(acc[mt][nt], bfr[s & 1][nt], af[s & 1][mt]);
         }
       }
       if (phase + 1 < 14) {
-        __syncthreads();
-        wstore();
+        wstore((phase + 1) & 1);     // buffer last read in phase - 1: every wave is past that phase's barrier
         __syncthreads();
       }
     }
+    __syncthreads();                 // halo + weight buffers are free for the next chunk
   }
-  const int d = d0 + wave;
+  // epilogue: lane holds channels n0 + 16nt + 4fq .. +3 of voxel (d0 + wave, h0 + mt, w0 + fi)
+  const int d = d0 + wave, w = w0 + fi;
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
-    const int h = h0 + 2 * mt + (fi >> 3), w = w0 + (fi & 7);
+    const int h = h0 + mt;
     if (d < g.D && h < g.H && w < g.W) {
       const int64_t vox = (((int64_t)b * g.D + d) * g.H + h) * g.W + w;
       if (scratch) {   // split over channel chunks: fp32 partial sums, converted by a second kernel
@@ -300,7 +337,7 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int co = n0 + nt * 16 + fq * 4;
-        if (co + 3 < Cout) {
+        if (vec_y && co + 3 < Cout) {
           if constexpr (std::is_same<T, bf16>::value) {
             bf16x4 o{(bf16)acc[mt][nt][0], (bf16)acc[mt][nt][1], (bf16)acc[mt][nt][2], (bf16)acc[mt][nt][3]};
             *reinterpret_cast<bf16x4*>(yr + co) = o;
@@ -324,25 +361,48 @@ __global__ void __launch_bounds__(256) conv3_scratch_to_out_kernel(const float* 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// weight packing:  fwd[co][tap][ciP] = w[co][ci][tap] ; bwd[ci][tap][coP] = w[co][ci][26 - tap]   (zero padded)
+// weight packing.  Row-major packs (generic kernel):   fwd[co][tap][ciP] = w[co][ci][tap] ; bwd[ci][tap][coP] = w[co][ci][26-tap]
+// Planar packs (fast path, chosen when the K-side channel row is a multiple of 96 bytes):
+//   fwd[tap][ci / KPC][coP16][ci % KPC] = w[co][ci][tap]        bwd[tap][co / KPC][ciP16][co % KPC] = w[co][ci][26 - tap]
 // ---------------------------------------------------------------------------------------------------------
 template <class T>
-__global__ void __launch_bounds__(256) pack_conv3_kernel(const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ bwd, int Cin, int Cout, int CinP, int CoutP) {
-  const int64_t nf = (int64_t)Cout * 27 * CinP, nb = (int64_t)Cin * 27 * CoutP;
+__global__ void __launch_bounds__(256) pack_conv3_kernel(const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ bwd, int Cin, int Cout, int CinP, int CoutP,
+                                                         int Cin16, int Cout16, bool fwd_planar, bool bwd_planar) {
+  constexpr int KPC = Vec16<T>::N;
+  const int64_t nf = fwd ? (fwd_planar ? (int64_t)27 * CinP * Cout16 : (int64_t)Cout * 27 * CinP) : 0;
+  const int64_t nb = bwd ? (bwd_planar ? (int64_t)27 * CoutP * Cin16 : (int64_t)Cin * 27 * CoutP) : 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nb; i += (int64_t)gridDim.x * blockDim.x) {
     if (i < nf) {
-      if (!fwd) continue;
-      const int ci = (int)(i % CinP);
-      const int tap = (int)((i / CinP) % 27);
-      const int co = (int)(i / ((int64_t)CinP * 27));
-      fwd[i] = from_f32<T>(ci < Cin ? w[((int64_t)co * Cin + ci) * 27 + tap] : 0.f);
+      int co, ci, tap;
+      if (fwd_planar) {
+        const int e = (int)(i % KPC);
+        int64_t t = i / KPC;
+        co = (int)(t % Cout16); t /= Cout16;
+        const int cgi = (int)(t % (CinP / KPC));
+        tap = (int)(t / (CinP / KPC));
+        ci = cgi * KPC + e;
+      } else {
+        ci = (int)(i % CinP);
+        tap = (int)((i / CinP) % 27);
+        co = (int)(i / ((int64_t)CinP * 27));
+      }
+      fwd[i] = from_f32<T>((ci < Cin && co < Cout) ? w[((int64_t)co * Cin + ci) * 27 + tap] : 0.f);
     } else {
-      if (!bwd) continue;
       const int64_t j = i - nf;
-      const int co = (int)(j % CoutP);
-      const int tap = (int)((j / CoutP) % 27);
-      const int ci = (int)(j / ((int64_t)CoutP * 27));
-      bwd[j] = from_f32<T>(co < Cout ? w[((int64_t)co * Cin + ci) * 27 + (26 - tap)] : 0.f);
+      int co, ci, tap;
+      if (bwd_planar) {
+        const int e = (int)(j % KPC);
+        int64_t t = j / KPC;
+        ci = (int)(t % Cin16); t /= Cin16;
+        const int cgo = (int)(t % (CoutP / KPC));
+        tap = (int)(t / (CoutP / KPC));
+        co = cgo * KPC + e;
+      } else {
+        co = (int)(j % CoutP);
+        tap = (int)((j / CoutP) % 27);
+        ci = (int)(j / ((int64_t)CoutP * 27));
+      }
+      bwd[j] = from_f32<T>((ci < Cin && co < Cout) ? w[((int64_t)co * Cin + ci) * 27 + (26 - tap)] : 0.f);
     }
   }
 }
@@ -572,7 +632,7 @@ extern "C" size_t miseg_conv3_fwd_workspace_bytes(int B, int D, int H, int W, in
   const int rowbytes = round_up(Cin, kpc) * esz;
   if (rowbytes % 96 != 0) return 0;
   int nt, ks;
-  fwd96_plan(B * cdiv(D, BD) * cdiv(H, BH) * cdiv(W, BW), Cout, rowbytes / 96, &nt, &ks);
+  fwd96_plan(B * cdiv(D, FBD) * cdiv(H, FBH) * cdiv(W, FBW), Cout, rowbytes / 96, &nt, &ks);
   return ks > 1 ? (size_t)B * D * H * W * Cout * sizeof(float) : 0;
 }
 
@@ -584,11 +644,14 @@ static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
   ConvGeom g{p->B, p->D, p->H, p->W, cdiv(p->D, BD), cdiv(p->H, BH), cdiv(p->W, BW)};
   const int nbricks = g.B * g.nbd * g.nbh * g.nbw;
   const bool vec_x = ((uintptr_t)p->x % 16 == 0) && (p->ldx % KPC == 0);
-  // ---- fast path: 96-byte channel chunks, weights through LDS (needs 4-channel-aligned stores: ldy % 4)
-  if (rowbytes % 96 == 0 && ((uintptr_t)p->y % 16 == 0) && (p->ldy % KPC == 0) && p->Cout % 4 == 0) {
+  // ---- fast path: 96-byte channel chunks, planar LDS images (weights must come from the planar pack: same predicate
+  // in miseg_pack_conv3_weight)
+  if (rowbytes % 96 == 0) {
+    ConvGeom gf{p->B, p->D, p->H, p->W, cdiv(p->D, FBD), cdiv(p->H, FBH), cdiv(p->W, FBW)};
+    const int nbr = gf.B * gf.nbd * gf.nbh * gf.nbw;
     int nt, ksplit;
     const int nchunks = rowbytes / 96;
-    fwd96_plan(nbricks, p->Cout, nchunks, &nt, &ksplit);
+    fwd96_plan(nbr, p->Cout, nchunks, &nt, &ksplit);
     const int cps = cdiv(nchunks, ksplit);
     ksplit = cdiv(nchunks, cps);
     float* scratch = nullptr;
@@ -598,13 +661,16 @@ static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
       scratch = (float*)p->workspace;
       MISEG_REQUIRE(hipMemsetAsync(scratch, 0, (size_t)nvox * p->Cout * sizeof(float), s) == hipSuccess, MISEG_E_LAUNCH, "conv3_fwd: memset");
     }
-    const size_t lds = (size_t)(BD + 2) * HH * HW * 112 + (size_t)16 * nt * 208;
-    dim3 grid(nbricks, cdiv(p->Cout, 16 * nt), ksplit);
+    const bool vec_y = ((uintptr_t)p->y % 16 == 0) && (p->ldy % KPC == 0);
+    const int CoP = round_up(p->Cout, 16);
+    const size_t lds = (size_t)6 * FPS * 16 + (size_t)2 * 12 * 16 * nt * 16;
+    MISEG_REQUIRE((int64_t)p->B * p->D * p->H * p->W < (1LL << 31), MISEG_E_UNSUPPORTED, "conv3_fwd: more than 2^31 voxels");
+    dim3 grid(nbr, cdiv(p->Cout, 16 * nt), ksplit);
 #define F96_CASE(n)                                                                                                                          \
   case n:                                                                                                                                   \
     hipFuncSetAttribute((const void*)conv3_fwd96_kernel<T, n>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
-    conv3_fwd96_kernel<T, n><<<grid, 256, lds, s>>>((const T*)p->x, p->ldx, (T*)p->y, p->ldy, (const T*)p->wpk, g, p->Cin, CinP, p->Cout, vec_x, \
-                                                    scratch, cps);                                                                          \
+    conv3_fwd96_kernel<T, n><<<grid, 256, lds, s>>>((const T*)p->x, p->ldx, (T*)p->y, p->ldy, (const T*)p->wpk, gf, p->Cin, CinP, p->Cout, CoP, \
+                                                    vec_x, vec_y, scratch, cps);                                                            \
     break;
     switch (nt) { F96_CASE(1) F96_CASE(2) F96_CASE(3) }
 #undef F96_CASE
@@ -646,6 +712,13 @@ extern "C" int miseg_conv3_fwd(const miseg_conv3_params* p, miseg_stream_t s_) {
   return set_error(MISEG_E_BADARG, "conv3_fwd: dtype %d", p->dtype);
 }
 
+extern "C" size_t miseg_pack_conv3_elems(int Cin, int Cout, int dtype, int which) {
+  const int kpc = dtype == MISEG_F32 ? 4 : 8;
+  const int CinP = round_up(Cin, kpc), CoutP = round_up(Cout, kpc);
+  // large enough for either layout
+  return which == 0 ? (size_t)27 * CinP * round_up(Cout, 16) : (size_t)27 * CoutP * round_up(Cin, 16);
+}
+
 extern "C" int miseg_pack_conv3_weight(const miseg_pack_conv3_params* p, miseg_stream_t s_) {
   hipStream_t s = (hipStream_t)s_;
   MISEG_REQUIRE(p && p->w && (p->fwd_pack || p->bwd_pack) && p->Cin > 0 && p->Cout > 0, MISEG_E_BADARG, "pack_conv3_weight: bad args");
@@ -653,10 +726,12 @@ extern "C" int miseg_pack_conv3_weight(const miseg_pack_conv3_params* p, miseg_s
     typedef typename std::remove_pointer<decltype(tag)>::type T;
     constexpr int KPC = Vec16<T>::N;
     const int CinP = round_up(p->Cin, KPC), CoutP = round_up(p->Cout, KPC);
-    const int64_t n = (int64_t)p->Cout * 27 * CinP + (int64_t)p->Cin * 27 * CoutP;
+    const bool fplanar = (CinP * (int)sizeof(T)) % 96 == 0, bplanar = (CoutP * (int)sizeof(T)) % 96 == 0;
+    const int64_t n = (int64_t)miseg_pack_conv3_elems(p->Cin, p->Cout, p->dtype, 0) + (int64_t)miseg_pack_conv3_elems(p->Cin, p->Cout, p->dtype, 1);
     int grid = (int)((n + 255) / 256);
-    if (grid > 4096) grid = 4096;
-    pack_conv3_kernel<T><<<grid, 256, 0, s>>>(p->w, (T*)p->fwd_pack, (T*)p->bwd_pack, p->Cin, p->Cout, CinP, CoutP);
+    if (grid > 8192) grid = 8192;
+    pack_conv3_kernel<T><<<grid, 256, 0, s>>>(p->w, (T*)p->fwd_pack, (T*)p->bwd_pack, p->Cin, p->Cout, CinP, CoutP, round_up(p->Cin, 16), round_up(p->Cout, 16),
+                                              fplanar, bplanar);
     MISEG_LAUNCH_CHECK("pack_conv3_weight");
     return MISEG_OK;
   });

@@ -93,6 +93,7 @@ PROTOS = {
     "miseg_colsum": (i32, [C.POINTER(Colsum), vp]),
     "miseg_conv3_fwd_workspace_bytes": (C.c_size_t, [i32, i32, i32, i32, i32, i32, i32]),
     "miseg_conv3_fwd": (i32, [C.POINTER(Conv3), vp]),
+    "miseg_pack_conv3_elems": (C.c_size_t, [i32, i32, i32, i32]),
     "miseg_pack_conv3_weight": (i32, [C.POINTER(PackConv3), vp]),
     "miseg_conv3_wgrad_workspace_bytes": (C.c_size_t, [i32, i32, i32, i32, i32, i32]),
     "miseg_conv3_wgrad": (i32, [C.POINTER(Conv3Wgrad), vp]),

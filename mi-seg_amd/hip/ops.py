@@ -225,10 +225,11 @@ def _round_up(a, b):
 
 def pack_conv3(w, dtype, want_fwd=True, want_bwd=True):
     Cout, Cin = w.shape[0], w.shape[1]
-    kpc = 4 if dtype == torch.float32 else 8
-    fwd = torch.empty(Cout, 27, _round_up(Cin, kpc), dtype=dtype, device=w.device) if want_fwd else None
-    bwd = torch.empty(Cin, 27, _round_up(Cout, kpc), dtype=dtype, device=w.device) if want_bwd else None
-    _call("miseg_pack_conv3_weight", L.PackConv3(_ptr(_fp32(w)), _ptr(fwd), _ptr(bwd), Cin, Cout, L.F32 if dtype == torch.float32 else L.BF16))
+    lib = L.load()
+    dt = L.F32 if dtype == torch.float32 else L.BF16
+    fwd = torch.empty(lib.miseg_pack_conv3_elems(Cin, Cout, dt, 0), dtype=dtype, device=w.device) if want_fwd else None
+    bwd = torch.empty(lib.miseg_pack_conv3_elems(Cin, Cout, dt, 1), dtype=dtype, device=w.device) if want_bwd else None
+    _call("miseg_pack_conv3_weight", L.PackConv3(_ptr(_fp32(w)), _ptr(fwd), _ptr(bwd), Cin, Cout, dt))
     return fwd, bwd
 
 
@@ -247,7 +248,8 @@ def conv3_fwd(x, wpk, Cout, out=None):
     wsb = lib.miseg_conv3_fwd_workspace_bytes(B, D, H, W, Cin, Cout, _dt(x))
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device) if wsb else None
     flops = 2.0 * B * D * H * W * 27 * Cin * Cout
-    fast = (wpk.shape[-1] * x.element_size()) % 96 == 0
+    kpc = 16 // x.element_size()
+    fast = (_round_up(Cin, kpc) * x.element_size()) % 96 == 0
     name = f"conv3_fwd{'96' if fast else ''}_kernel<{'bf16' if x.dtype == torch.bfloat16 else 'f32'}>"
     _call("miseg_conv3_fwd", L.Conv3(_ptr(x), ld, _ptr(out), rows(out)[0], _ptr(wpk), B, D, H, W, Cin, Cout, _dt(x), _ptr(ws)), prof=(name, flops))
     return out
