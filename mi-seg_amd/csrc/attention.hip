@@ -323,6 +323,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 static constexpr int ATT_MAXT = 11;                 // ceil(343 / 32) tiles
 static constexpr int ATT_NP = ATT_MAXT * 32;        // 352 padded tokens
 static constexpr int ATT_VT_LD = ATT_NP + 8;        // row stride (elements) of the dim-major copies
+static constexpr float ATT_LOG2E = 1.4426950408889634f;   // scores are kept in the log2 domain (v_exp_f32 is exp2)
 
 __device__ __forceinline__ int att_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
@@ -375,14 +376,14 @@ __global__ void __launch_bounds__(256) winattn_fwd_mfma_kernel(const bf16* __res
     }
 #pragma unroll
     for (int d = 0; d < 16; ++d) {
-      Qs[t * 16 + d] = (bf16)(q[d] * g.scale);
+      Qs[t * 16 + d] = (bf16)(q[d] * (g.scale * ATT_LOG2E));
       Ks[t * 16 + d] = (bf16)k[d];
       Vt[d * ATT_VT_LD + t] = (bf16)v[d];
     }
     info[t] = att_pack(code, label, t < n);
     rowq[t] = row;
   }
-  for (int i = tid; i < tsize; i += 256) table[i] = bias_table[(int64_t)i * g.heads + head];
+  for (int i = tid; i < tsize; i += 256) table[i] = bias_table[(int64_t)i * g.heads + head] * ATT_LOG2E;
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int tb = 2 * g.tw - 1;
@@ -412,7 +413,7 @@ __global__ void __launch_bounds__(256) winattn_fwd_mfma_kernel(const bf16* __res
         for (int e = 0; e < 4; ++e) {
           const int w = kiv[e];
           float sc = sacc[4 * gq + e] + table[cq - (w & 0xfff)];
-          if (use_mask && ((w >> 12) & 31) != lq) sc -= 100.f;
+          if (use_mask && ((w >> 12) & 31) != lq) sc -= 100.f * ATT_LOG2E;
           if (!(w >> 20)) sc = -INFINITY;
           sv[4 * gq + e] = sc;
           mx = fmaxf(mx, sc);
@@ -420,10 +421,10 @@ __global__ void __launch_bounds__(256) winattn_fwd_mfma_kernel(const bf16* __res
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mn = fmaxf(m, mx);
-      const float alpha = __expf(m - mn);
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);
       float ls = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { sv[i] = __expf(sv[i] - mn); ls += sv[i]; }
+      for (int i = 0; i < 16; ++i) { sv[i] = __builtin_amdgcn_exp2f(sv[i] - mn); ls += sv[i]; }
       ls += __shfl_xor(ls, 32, 64);
       l = l * alpha + ls;
       m = mn;
@@ -439,7 +440,7 @@ __global__ void __launch_bounds__(256) winattn_fwd_mfma_kernel(const bf16* __res
     const float inv = 1.f / l;
     const int row = rowq[qi];
     if (qi < n) {
-      if (h == 0) lse_out[((int64_t)win * g.heads + head) * n + qi] = m + __logf(l);
+      if (h == 0) lse_out[((int64_t)win * g.heads + head) * n + qi] = (m + __log2f(l)) * 0.6931471805599453f;   // natural-log units
       if (row >= 0) {
         bf16* op = out + (int64_t)row * ldo + head * 16;
         *reinterpret_cast<bf16x4*>(op + 4 * h) = bf16x4{(bf16)(acc[0] * inv), (bf16)(acc[1] * inv), (bf16)(acc[2] * inv), (bf16)(acc[3] * inv)};
@@ -450,208 +451,288 @@ __global__ void __launch_bounds__(256) winattn_fwd_mfma_kernel(const bf16* __res
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// MFMA backward (bf16, head_dim 16): the KEY sits on the lane (S = Q K^T, dP = dO V^T), so the recomputed P and dS tiles
-// are directly the B operands of dV^T += dO^T P and dK^T += Q^T dS; dS crosses LDS once (per-wave 32x32 tile) for
-// dQ^T = K^T dS^T, which is accumulated over key tiles in an fp32 LDS buffer.  A wave owns key tiles and walks all
-// query tiles; rel-pos bias gradients are LDS atomics flushed once per workgroup.
+// MFMA backward (bf16, head_dim 16), single pass over 16x16 (query x key) units on v_mfma_f32_16x16x16_bf16.
+//   * a wave owns key tiles kt = wave, wave+4, ... (<= 6 of 16 keys); their K/V operands and the dK^T/dV^T accumulators
+//     (4 registers each) stay in registers for the whole workgroup; all waves walk the query tiles together.
+//   * S' = Q'K^T - lse' and dP - delta leave the MFMA ready: -lse' and -delta are the initial accumulators
+//     (log2 domain: Q' = q*scale*log2e, table' = table*log2e, p = exp2(S' + table' [+ mask'])).
+//   * key on the lane: the P / dS accumulators are directly the B operands of dV^T += dO^T P and dK^T += Q'^T dS;
+//     dS crosses LDS once (wave-private 16x16 tile, read back transposed) for dQ^T += K^T dS^T, which is summed over a
+//     wave's key tiles in registers and over the 4 waves through a double-buffered LDS tile per query tile.
+//   * A operands that need the token on the k index come from the row-major images by ds_read_b64_tr_b16 (no
+//     dim-major copies); the images swap the 16-byte halves of rows with bit 3 set (conflict-free 8-byte reads).
+//   * rel-pos bias gradients are LDS atomics, flushed once per workgroup.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) winattn_bwd_mfma_kernel(const bf16* __restrict__ qkv, int64_t ldq, const bf16* __restrict__ out, int64_t ldo,
-                                                               const bf16* __restrict__ dout, int64_t lddo, bf16* __restrict__ dqkv, int64_t lddq,
-                                                               const float* __restrict__ qkv_bias, const float* __restrict__ bias_table,
-                                                               const float* __restrict__ lse_in, float* __restrict__ dqkv_bias,
-                                                               float* __restrict__ dbias_table, WinGeom g, int tsize) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16* Qs = reinterpret_cast<bf16*>(smem);          // [NP][16] scaled
-  bf16* Ks = Qs + ATT_NP * 16;
-  bf16* Vs = Ks + ATT_NP * 16;
-  bf16* Gs = Vs + ATT_NP * 16;                       // dO
-  bf16* Qt = Gs + ATT_NP * 16;                       // [16][LD] scaled
-  bf16* Gt = Qt + 16 * ATT_VT_LD;
-  bf16* Kt = Gt + 16 * ATT_VT_LD;
-  int* info = reinterpret_cast<int*>(Kt + 16 * ATT_VT_LD);
-  int* rowq = info + ATT_NP;
-  float* lse = reinterpret_cast<float*>(rowq + ATT_NP);
-  float* delta = lse + ATT_NP;
-  float* table = delta + ATT_NP;
-  float* dtable = table + tsize;
-  float* padb = dtable + tsize;                      // [48]: q/k/v bias gradient from zero-padded tokens of this window
-  const int win = blockIdx.x, head = blockIdx.y, tid = threadIdx.x;
-  const int n = g.n, C = g.C, ntiles = (n + 31) / 32;
-  const bool use_mask = (g.sd | g.sh | g.sw) != 0;
-  if (tid < 48) padb[tid] = 0.f;
-  for (int t = tid; t < ntiles * 32; t += 256) {
-    int row = -1, label = 0, code = 0;
-    float q[16], k[16], v[16], go[16];
-    float dl = 0.f, ls = 0.f;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+#ifndef ATT_ABL
+#define ATT_ABL 0
+#endif
+
+static constexpr int ATT_NI = 6;                        // key tiles per wave (22 tiles of 16 / 4 waves)
+static constexpr int ATT_DS_LD = 48;                    // byte stride of the wave-private dS tile rows (conflict-free)
+
+__device__ __forceinline__ int att_chunk(int t, int c) { return t * 32 + ((c ^ ((t >> 2) & 2)) << 3); }   // byte offset of dims 4c..4c+3
+
+__device__ __forceinline__ s16x4 att_ld4(const bf16* img, int t, int c) {
+  return *reinterpret_cast<const s16x4*>(reinterpret_cast<const char*>(img) + att_chunk(t, c));
+}
+
+__device__ __forceinline__ s16x4 att_tr4(const char* p) {
+  const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
+  return __builtin_bit_cast(s16x4, v);
+}
+
+// lane (i = lane & 15, kg = lane >> 4) -> element [dim i][token t0 + 4kg .. +3] of a row-major image (transposed read)
+__device__ __forceinline__ s16x4 att_tr_rows(const bf16* img, int t0, int fi, int kg) {
+  return att_tr4(reinterpret_cast<const char*>(img) + att_chunk(t0 + 4 * kg + (fi >> 2), fi & 3));
+}
+
+__device__ __forceinline__ void att_store_row(bf16* img, int t, const float* v) {
+  char* p = reinterpret_cast<char*>(img) + t * 32;
+  const int sw = ((t >> 2) & 2) * 8;
+  *reinterpret_cast<bf16x8*>(p + sw) = cvt8(v);
+  *reinterpret_cast<bf16x8*>(p + (16 - sw)) = cvt8(v + 8);
+}
+
+__device__ __forceinline__ void att_load16(const bf16* p, bool vec, float* dst) {
+  if (vec) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p), b = *reinterpret_cast<const bf16x8*>(p + 8);
 #pragma unroll
-    for (int d = 0; d < 16; ++d) q[d] = k[d] = v[d] = go[d] = 0.f;
+    for (int d = 0; d < 8; ++d) { dst[d] = to_f32(a[d]); dst[8 + d] = to_f32(b[d]); }
+  } else {
+#pragma unroll
+    for (int d = 0; d < 16; ++d) dst[d] = to_f32(p[d]);
+  }
+}
+
+template <bool MASK>
+__global__ void __launch_bounds__(256, 2) winattn_bwd_mfma_kernel(const bf16* __restrict__ qkv, int64_t ldq, const bf16* __restrict__ out, int64_t ldo,
+                                                                  const bf16* __restrict__ dout, int64_t lddo, bf16* __restrict__ dqkv, int64_t lddq,
+                                                                  const float* __restrict__ qkv_bias, const float* __restrict__ bias_table,
+                                                                  const float* __restrict__ lse_in, float* __restrict__ dqkv_bias,
+                                                                  float* __restrict__ dbias_table, WinGeom g, int tsize, bool vec) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* Qs = reinterpret_cast<bf16*>(smem);          // [NP][16] q * scale * log2e
+  bf16* Gs = Qs + ATT_NP * 16;                       // dO
+  bf16* Ks = Gs + ATT_NP * 16;
+  int* qcode = reinterpret_cast<int*>(Ks + ATT_NP * 16);
+  int* qlabel = qcode + ATT_NP;
+  int* rowq = qlabel + ATT_NP;
+  float* nlse = reinterpret_cast<float*>(rowq + ATT_NP);   // -lse * log2e  (-inf beyond the window)
+  float* ndelta = nlse + ATT_NP;                            // -rowsum(dO * O)
+  float* dqpart = ndelta + ATT_NP;                          // [2][4 waves][16 queries][16 dims]
+  char* dstile = reinterpret_cast<char*>(dqpart + 2 * 4 * 256);   // [4 waves][16 keys][ATT_DS_LD]
+  float* padb = reinterpret_cast<float*>(dstile + 4 * 16 * ATT_DS_LD);   // [48] + 3 bound words (|dO|^2, |V|^2, |delta| maxima)
+  unsigned* bound = reinterpret_cast<unsigned*>(padb + 48);
+  float* table = padb + 52;                                 // [tsize] * log2e
+  int* dtable = reinterpret_cast<int*>(table + tsize);      // fixed point, see `fscale`
+  const int win = blockIdx.x, head = blockIdx.y, tid = threadIdx.x;
+  const int n = g.n, C = g.C, nt16 = (n + 15) / 16;
+  if (tid < 52) padb[tid] = 0.f;
+  __syncthreads();
+  float mg2 = 0.f, mv2 = 0.f, mda = 0.f;
+  for (int t = tid; t < nt16 * 16; t += 256) {
+    int row = -1, label = 0, code = 0;
+    float q[16], k[16], go[16];
+    float dl = 0.f, ls = INFINITY, g2 = 0.f, v2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) q[d] = k[d] = go[d] = 0.f;
     if (t < n) {
       token_info(g, win, t, row, label, code);
-      load_head_row<bf16, 4>(qkv, ldq, row, head * 16, qkv_bias, q);
-      load_head_row<bf16, 4>(qkv, ldq, row, C + head * 16, qkv_bias, k);
-      load_head_row<bf16, 4>(qkv, ldq, row, 2 * C + head * 16, qkv_bias, v);
       ls = lse_in[((int64_t)win * g.heads + head) * n + t];
+      float v[16];
       if (row >= 0) {
-        const bf16* gp = dout + (int64_t)row * lddo + head * 16;
-        const bf16* op = out + (int64_t)row * ldo + head * 16;
+        float o[16];
+        att_load16(qkv + (int64_t)row * ldq + head * 16, vec, q);
+        att_load16(qkv + (int64_t)row * ldq + C + head * 16, vec, k);
+        att_load16(qkv + (int64_t)row * ldq + 2 * C + head * 16, vec, v);
+        att_load16(dout + (int64_t)row * lddo + head * 16, vec, go);
+        att_load16(out + (int64_t)row * ldo + head * 16, vec, o);
 #pragma unroll
-        for (int d = 0; d < 16; ++d) { go[d] = to_f32(gp[d]); dl = fmaf(go[d], to_f32(op[d]), dl); }
+        for (int d = 0; d < 16; ++d) { dl = fmaf(go[d], o[d], dl); g2 = fmaf(go[d], go[d], g2); }
+      } else {
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+          q[d] = qkv_bias ? qkv_bias[head * 16 + d] : 0.f;
+          k[d] = qkv_bias ? qkv_bias[C + head * 16 + d] : 0.f;
+          v[d] = qkv_bias ? qkv_bias[2 * C + head * 16 + d] : 0.f;
+        }
       }
-    }
 #pragma unroll
-    for (int d = 0; d < 16; ++d) {
-      const bf16 qs = (bf16)(q[d] * g.scale);
-      Qs[t * 16 + d] = qs;  Qt[d * ATT_VT_LD + t] = qs;
-      Ks[t * 16 + d] = (bf16)k[d];  Kt[d * ATT_VT_LD + t] = (bf16)k[d];
-      Vs[t * 16 + d] = (bf16)v[d];
-      Gs[t * 16 + d] = (bf16)go[d];  Gt[d * ATT_VT_LD + t] = (bf16)go[d];
+      for (int d = 0; d < 16; ++d) v2 = fmaf(v[d], v[d], v2);
     }
-    info[t] = att_pack(code, label, t < n);
+    mg2 = fmaxf(mg2, g2); mv2 = fmaxf(mv2, v2); mda = fmaxf(mda, fabsf(dl));
+    const float qs = g.scale * ATT_LOG2E;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) q[d] *= qs;
+    att_store_row(Qs, t, q);
+    att_store_row(Ks, t, k);
+    att_store_row(Gs, t, go);
+    qcode[t] = code;
+    qlabel[t] = label;
     rowq[t] = row;
-    lse[t] = ls;
-    delta[t] = dl;
+    nlse[t] = -ls * ATT_LOG2E;
+    ndelta[t] = -dl;
   }
-  for (int i = tid; i < tsize; i += 256) { table[i] = bias_table[(int64_t)i * g.heads + head]; dtable[i] = 0.f; }
+  // workgroup maxima for the fixed-point scale of the bias-gradient bins (non-negative floats order as unsigned)
+#pragma unroll
+  for (int o2 = 1; o2 < 64; o2 <<= 1) { mg2 = fmaxf(mg2, __shfl_xor(mg2, o2, 64)); mv2 = fmaxf(mv2, __shfl_xor(mv2, o2, 64)); mda = fmaxf(mda, __shfl_xor(mda, o2, 64)); }
+  if ((tid & 63) == 0) { atomicMax(&bound[0], __float_as_uint(mg2)); atomicMax(&bound[1], __float_as_uint(mv2)); atomicMax(&bound[2], __float_as_uint(mda)); }
+  for (int i = tid; i < tsize; i += 256) { table[i] = bias_table[(int64_t)i * g.heads + head] * ATT_LOG2E; dtable[i] = 0; }
   __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  // LDS float atomics cost ~190 cycles per wave-instruction on gfx950 (integer ones 4-8): the rel-pos bias gradient is
+  // binned in fixed point.  |dS_qk| <= p_qk (|dO_q||V_k| + |delta_q|) and a bin receives at most one key per query, so
+  // |bin| <= n * bmax; the scale keeps two bits of headroom for the bf16 rounding of the operands.
+  const float bmax = sqrtf(__uint_as_float(bound[0]) * __uint_as_float(bound[1])) + __uint_as_float(bound[2]);
+  const float fscale = bmax > 0.f ? 536870912.f / ((float)n * bmax) : 0.f;
+  const int lane = tid & 63, wave = tid >> 6, fi = lane & 15, kg = lane >> 4;
   const int tb = 2 * g.tw - 1;
   const int centre = ((g.tw - 1) * tb + (g.tw - 1)) * tb + (g.tw - 1);
-  for (int kt = wave; kt < ntiles; kt += 4) {
-    const int ki = kt * 32 + r;
-    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + ki * 16 + 8 * h);     // B operand: [k=dim][col=key]
-    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + ki * 16 + 8 * h);
-    const int kinfo = info[ki];
-    const int ck = (kinfo & 0xfff) - centre, lk = (kinfo >> 12) & 31;
-    const bool kvalid = (kinfo >> 20) != 0;
-    f32x16 dvt, dkt;
+  constexpr float MASKV = -100.f * ATT_LOG2E;
+
+  // ---- per-wave key tiles
+  s16x4 kfB[ATT_NI], vfB[ATT_NI], kA[ATT_NI];
+  f32x4 dvt[ATT_NI], dkt[ATT_NI];
+  int ck[ATT_NI], lk[ATT_NI];
+  bool kval = true;
+  int itail = -1;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) dvt[i] = dkt[i] = 0.f;
-    for (int qt = 0; qt < ntiles; ++qt) {
-      const int qi = qt * 32 + r;
-      const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + qi * 16 + 8 * h);   // A operand: [row=query][k=dim]
-      const bf16x8 gf = *reinterpret_cast<const bf16x8*>(Gs + qi * 16 + 8 * h);
-      f32x16 sacc, pacc;
+  for (int i = 0; i < ATT_NI; ++i) {
+    const int kt = wave + 4 * i;
+    dvt[i] = dkt[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    kfB[i] = vfB[i] = kA[i] = s16x4{0, 0, 0, 0};
+    ck[i] = lk[i] = 0;
+    if (kt < nt16) {
+      const int ki = kt * 16 + fi;
+      kfB[i] = att_ld4(Ks, ki, kg);                           // B operand of S:  [k = dim 4kg..][col = key]
+      kA[i] = att_tr_rows(Ks, kt * 16, fi, kg);               // A operand of dQ^T: [row = dim][k = key 4kg..]
+      ck[i] = qcode[ki] - centre;
+      lk[i] = qlabel[ki];
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (ki < n) {
+        const int row = rowq[ki];
+        if (row >= 0) {
+          const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(qkv + (int64_t)row * ldq + 2 * C + head * 16 + 4 * kg);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) sacc[i] = pacc[i] = 0.f;
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf, sacc, 0, 0, 0);      // rows = queries, col = this lane's key
-      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, vf, pacc, 0, 0, 0);      // dP
-      float pv[16], dsv[16];
+          for (int e = 0; e < 4; ++e) v[e] = to_f32(t4[e]);
+        } else if (qkv_bias) {
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int q0 = qt * 32 + 8 * gq + 4 * h;
-        const int4 qi4 = *reinterpret_cast<const int4*>(info + q0);
-        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse + q0);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta + q0);
-        const int qiv[4] = {qi4.x, qi4.y, qi4.z, qi4.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int w = qiv[e];
-          const int bidx = (w & 0xfff) - ck;
-          float sc = sacc[4 * gq + e] + table[bidx];
-          if (use_mask && ((w >> 12) & 31) != lk) sc -= 100.f;
-          float p = __expf(sc - l4[e]);
-          if (!kvalid || !(w >> 20)) p = 0.f;
-          const float ds = p * (pacc[4 * gq + e] - d4[e]);
-          pv[4 * gq + e] = p;
-          dsv[4 * gq + e] = ds;
-          if (dbias_table && p != 0.f) atomicAdd(&dtable[bidx], ds);
+          for (int e = 0; e < 4; ++e) v[e] = qkv_bias[2 * C + head * 16 + 4 * kg + e];
         }
       }
+      vfB[i] = __builtin_bit_cast(s16x4, bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]});   // B operand of dP
+      if (kt == nt16 - 1 && (n & 15)) { itail = i; kval = ki < n; }
+    }
+  }
+  char* mytile = dstile + wave * 16 * ATT_DS_LD;
+  char* const ds_w = mytile + fi * ATT_DS_LD + kg * 8;                         // dS[key fi][queries 4kg..]
+  const char* const ds_r = mytile + (4 * kg + (fi >> 2)) * ATT_DS_LD + (fi & 3) * 8;   // transposed read: lane (query fi, keys 4kg..)
+
+  for (int qt = 0; qt < ((ATT_ABL & 2) ? 0 : nt16); ++qt) {
+    const int q0 = qt * 16;
+    const int4 qc4 = *reinterpret_cast<const int4*>(qcode + q0 + 4 * kg);
+    const int qc[4] = {qc4.x, qc4.y, qc4.z, qc4.w};
+    int ql[4] = {0, 0, 0, 0};
+    if (MASK) {
+      const int4 ql4 = *reinterpret_cast<const int4*>(qlabel + q0 + 4 * kg);
+      ql[0] = ql4.x; ql[1] = ql4.y; ql[2] = ql4.z; ql[3] = ql4.w;
+    }
+    const f32x4 nl4 = *reinterpret_cast<const f32x4*>(nlse + q0 + 4 * kg);
+    const f32x4 nd4 = *reinterpret_cast<const f32x4*>(ndelta + q0 + 4 * kg);
+    const s16x4 qfA = att_ld4(Qs, q0 + fi, kg);               // A of S:    [row = query][k = dim 4kg..]
+    const s16x4 gfA = att_ld4(Gs, q0 + fi, kg);               // A of dP
+    const s16x4 qtA = att_tr_rows(Qs, q0, fi, kg);            // A of dK^T: [row = dim][k = query 4kg..]
+    const s16x4 gtA = att_tr_rows(Gs, q0, fi, kg);            // A of dV^T
+    f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 pf = cvt8(pv + 8 * s2), df = cvt8(dsv + 8 * s2);
-        dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_dimmajor_frag(Gt, r, h, qt * 32, s2), pf, dvt, 0, 0, 0);   // dV^T += dO^T P
-        dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_dimmajor_frag(Qt, r, h, qt * 32, s2), df, dkt, 0, 0, 0);   // dK^T += Q^T dS
+    for (int i = 0; i < ATT_NI; ++i) {
+      if (wave + 4 * i < nt16) {
+        const f32x4 sacc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qfA, kfB[i], nl4, 0, 0, 0);   // rows = queries 4kg+e, col = key fi
+        const f32x4 pacc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gfA, vfB[i], nd4, 0, 0, 0);   // dP - delta
+        float pv[4], dsv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int bidx = qc[e] - ck[i];
+          float sc = sacc[e] + ((ATT_ABL & 8) ? 0.f : table[bidx]);
+          if (MASK) sc += (ql[e] != lk[i]) ? MASKV : 0.f;
+          float p = __builtin_amdgcn_exp2f(sc);
+          if (i == itail) p = kval ? p : 0.f;
+          const float ds = p * pacc[e];
+          pv[e] = p;
+          dsv[e] = ds;
+          if (dbias_table && !(ATT_ABL & 1)) atomicAdd(&dtable[bidx], __float2int_rn(ds * fscale));
+        }
+        const bf16x4 pb4 = bf16x4{(bf16)pv[0], (bf16)pv[1], (bf16)pv[2], (bf16)pv[3]};
+        const bf16x4 db4 = bf16x4{(bf16)dsv[0], (bf16)dsv[1], (bf16)dsv[2], (bf16)dsv[3]};
+        const s16x4 pb = __builtin_bit_cast(s16x4, pb4), db = __builtin_bit_cast(s16x4, db4);
+        dvt[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gtA, pb, dvt[i], 0, 0, 0);   // dV^T[dim][key] += dO^T P
+        dkt[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qtA, db, dkt[i], 0, 0, 0);   // dK^T[dim][key] += Q'^T dS
+        if (!(ATT_ABL & 4)) {
+        *reinterpret_cast<bf16x4*>(ds_w) = db4;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const s16x4 dsT = att_tr4(ds_r);                                                 // [k = key 4kg..][col = query fi]
+        dq = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kA[i], dsT, dq, 0, 0, 0);        // dQ^T[dim][query] += K^T dS^T
+        __builtin_amdgcn_wave_barrier();
+        }
       }
     }
-    // dK, dV of key ki: dims 4h..4h+3 (regs 0-3) and 8+4h..+3 (regs 4-7)
-    if (ki < n) {
-      const int row = rowq[ki];
-      if (row >= 0) {
-        bf16* pk = dqkv + (int64_t)row * lddq + C + head * 16;
-        bf16* pv2 = dqkv + (int64_t)row * lddq + 2 * C + head * 16;
-        *reinterpret_cast<bf16x4*>(pk + 4 * h) = bf16x4{(bf16)dkt[0], (bf16)dkt[1], (bf16)dkt[2], (bf16)dkt[3]};
-        *reinterpret_cast<bf16x4*>(pk + 8 + 4 * h) = bf16x4{(bf16)dkt[4], (bf16)dkt[5], (bf16)dkt[6], (bf16)dkt[7]};
-        *reinterpret_cast<bf16x4*>(pv2 + 4 * h) = bf16x4{(bf16)dvt[0], (bf16)dvt[1], (bf16)dvt[2], (bf16)dvt[3]};
-        *reinterpret_cast<bf16x4*>(pv2 + 8 + 4 * h) = bf16x4{(bf16)dvt[4], (bf16)dvt[5], (bf16)dvt[6], (bf16)dvt[7]};
-      } else if (dqkv_bias) {
+    // partial dQ^T of this wave: lane (query fi, dims 4kg..4kg+3)
+    float* part = dqpart + (qt & 1) * 1024;
+    *reinterpret_cast<f32x4*>(part + (wave * 16 + fi) * 16 + 4 * kg) = dq;
+    __syncthreads();
+    if (wave == (qt & 3)) {
+      const int ql_ = lane >> 2, d4 = lane & 3, t = q0 + ql_;
+      f32x4 sum = *reinterpret_cast<const f32x4*>(part + ql_ * 16 + 4 * d4);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int d = (i & 3) + 8 * (i >> 2) + 4 * h;
-          atomicAdd(&padb[16 + d], dkt[i]);
-          atomicAdd(&padb[32 + d], dvt[i]);
+      for (int w = 1; w < 4; ++w) sum += *reinterpret_cast<const f32x4*>(part + (w * 16 + ql_) * 16 + 4 * d4);
+      if (t < n) {
+        const int row = rowq[t];
+        if (row >= 0) {
+          *reinterpret_cast<bf16x4*>(dqkv + (int64_t)row * lddq + head * 16 + 4 * d4) =
+              bf16x4{(bf16)(sum[0] * g.scale), (bf16)(sum[1] * g.scale), (bf16)(sum[2] * g.scale), (bf16)(sum[3] * g.scale)};
+        } else if (dqkv_bias) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) atomicAdd(&padb[4 * d4 + e], sum[e] * g.scale);
         }
       }
     }
   }
-  // ---------------- pass B: the QUERY on the lane (S^T = K Q^T, dP^T = V dO^T) -> dQ^T += K^T dS^T in registers
-  for (int qt = wave; qt < ntiles; qt += 4) {
-    const int qi = qt * 32 + r;
-    const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + qi * 16 + 8 * h);     // B operand [k=dim][col=query]
-    const bf16x8 gf = *reinterpret_cast<const bf16x8*>(Gs + qi * 16 + 8 * h);
-    const int qinfo = info[qi];
-    const int cq = (qinfo & 0xfff) + centre, lq = (qinfo >> 12) & 31;
-    const bool qvalid = (qinfo >> 20) != 0;
-    const float lse_q = lse[qi], delta_q = delta[qi];
-    f32x16 dq;
+  // ---- dK, dV of the wave's keys: lane (key fi, dims 4kg..4kg+3); dK carries 1/log2e from Q'
+  constexpr float LN2 = 0.6931471805599453f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) dq[i] = 0.f;
-    for (int kt = 0; kt < ntiles; ++kt) {
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + r) * 16 + 8 * h);   // A operand [row=key][k=dim]
-      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + (kt * 32 + r) * 16 + 8 * h);
-      f32x16 sacc, pacc;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sacc[i] = pacc[i] = 0.f;
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, sacc, 0, 0, 0);
-      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, gf, pacc, 0, 0, 0);
-      float dsv[16];
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int4 ki4 = *reinterpret_cast<const int4*>(info + kt * 32 + 8 * gq + 4 * h);
-        const int kiv[4] = {ki4.x, ki4.y, ki4.z, ki4.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int w = kiv[e];
-          float sc = sacc[4 * gq + e] + table[cq - (w & 0xfff)];
-          if (use_mask && ((w >> 12) & 31) != lq) sc -= 100.f;
-          float p = __expf(sc - lse_q);
-          if (!qvalid || !(w >> 20)) p = 0.f;
-          dsv[4 * gq + e] = p * (pacc[4 * gq + e] - delta_q);
-        }
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_dimmajor_frag(Kt, r, h, kt * 32, s2), cvt8(dsv + 8 * s2), dq, 0, 0, 0);
-    }
-    if (qi < n) {
-      const int row = rowq[qi];
+  for (int i = 0; i < ATT_NI; ++i) {
+    const int ki = (wave + 4 * i) * 16 + fi;
+    if (wave + 4 * i < nt16 && ki < n) {
+      const int row = rowq[ki];
       if (row >= 0) {
-        bf16* pq = dqkv + (int64_t)row * lddq + head * 16;
-        *reinterpret_cast<bf16x4*>(pq + 4 * h) = bf16x4{(bf16)(dq[0] * g.scale), (bf16)(dq[1] * g.scale), (bf16)(dq[2] * g.scale), (bf16)(dq[3] * g.scale)};
-        *reinterpret_cast<bf16x4*>(pq + 8 + 4 * h) = bf16x4{(bf16)(dq[4] * g.scale), (bf16)(dq[5] * g.scale), (bf16)(dq[6] * g.scale), (bf16)(dq[7] * g.scale)};
+        bf16* pk = dqkv + (int64_t)row * lddq + C + head * 16 + 4 * kg;
+        *reinterpret_cast<bf16x4*>(pk) = bf16x4{(bf16)(dkt[i][0] * LN2), (bf16)(dkt[i][1] * LN2), (bf16)(dkt[i][2] * LN2), (bf16)(dkt[i][3] * LN2)};
+        *reinterpret_cast<bf16x4*>(pk + C) = bf16x4{(bf16)dvt[i][0], (bf16)dvt[i][1], (bf16)dvt[i][2], (bf16)dvt[i][3]};
       } else if (dqkv_bias) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) atomicAdd(&padb[(i & 3) + 8 * (i >> 2) + 4 * h], dq[i] * g.scale);
+        for (int e = 0; e < 4; ++e) {
+          atomicAdd(&padb[16 + 4 * kg + e], dkt[i][e] * LN2);
+          atomicAdd(&padb[32 + 4 * kg + e], dvt[i][e]);
+        }
       }
     }
   }
   __syncthreads();
   if (dbias_table)
     for (int i = tid; i < tsize; i += 256) {
-      const float v = dtable[i];
-      if (v != 0.f) atomicAdd(dbias_table + (int64_t)i * g.heads + head, v);
+      const int v = dtable[i];
+      if (v != 0) atomicAdd(dbias_table + (int64_t)i * g.heads + head, (float)v / fscale);
     }
-  if (dqkv_bias) {   // one global atomic per (q/k/v, dim) per workgroup instead of one per padded token
-    __syncthreads();
-    if (tid < 48) {
-      const float v = padb[tid];
-      if (v != 0.f) atomicAdd(dqkv_bias + (tid >> 4) * C + head * 16 + (tid & 15), v);
-    }
+  if (dqkv_bias && tid < 48) {   // one global atomic per (q/k/v, dim) per workgroup instead of one per padded token
+    const float v = padb[tid];
+    if (v != 0.f) atomicAdd(dqkv_bias + (tid >> 4) * C + head * 16 + (tid & 15), v);
   }
 }
 
 static size_t attn_mfma_bwd_smem(int tsize) {
-  return (size_t)(4 * ATT_NP * 16 + 3 * 16 * ATT_VT_LD) * 2 + (size_t)4 * ATT_NP * 4 + (size_t)2 * tsize * 4 + 48 * 4;
+  return (size_t)3 * ATT_NP * 32 + (size_t)5 * ATT_NP * 4 + (size_t)2 * 4 * 256 * 4 + (size_t)4 * 16 * ATT_DS_LD + 52 * 4 + (size_t)2 * tsize * 4;
 }
 
 static size_t attn_mfma_fwd_smem(int tsize) {
@@ -732,11 +813,18 @@ extern "C" int miseg_winattn_bwd(const miseg_winattn_bwd_params* p, miseg_stream
   MISEG_REQUIRE(sh <= 160 * 1024, MISEG_E_UNSUPPORTED, "winattn_bwd: %zu bytes of LDS needed", sh);
   dim3 grid(g.B * g.nwd * g.nwh * g.nww, g.heads);
   const int threads = cdiv(g.n, 64) * 64;
-  if (p->f.dtype == MISEG_BF16 && g.hd == 16 && g.n <= ATT_NP && p->f.bias_table && ((uintptr_t)p->dqkv % 8 == 0) && p->lddq % 4 == 0) {
+  if (p->f.dtype == MISEG_BF16 && g.hd == 16 && g.n <= ATT_NP && p->f.bias_table && ((uintptr_t)p->dqkv % 8 == 0) && p->lddq % 4 == 0 &&
+      ((uintptr_t)p->f.qkv % 8 == 0) && p->f.ldq % 4 == 0) {
     const size_t shm = attn_mfma_bwd_smem(tsize);
-    hipFuncSetAttribute((const void*)winattn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    winattn_bwd_mfma_kernel<<<grid, 256, shm, s>>>((const bf16*)p->f.qkv, p->f.ldq, (const bf16*)p->f.out, p->f.ldo, (const bf16*)p->dout, p->lddo, (bf16*)p->dqkv,
-                                                   p->lddq, p->f.qkv_bias, p->f.bias_table, p->f.lse, p->dqkv_bias, p->dbias_table, g, tsize);
+    const bool vec = p->f.ldq % 8 == 0 && p->f.ldo % 8 == 0 && p->lddo % 8 == 0 && (uintptr_t)p->f.qkv % 16 == 0 && (uintptr_t)p->f.out % 16 == 0 &&
+                     (uintptr_t)p->dout % 16 == 0;
+#define BWD_MFMA(M)                                                                                                                                     \
+  hipFuncSetAttribute((const void*)winattn_bwd_mfma_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                                  \
+  winattn_bwd_mfma_kernel<M><<<grid, 256, shm, s>>>((const bf16*)p->f.qkv, p->f.ldq, (const bf16*)p->f.out, p->f.ldo, (const bf16*)p->dout, p->lddo,   \
+                                                    (bf16*)p->dqkv, p->lddq, p->f.qkv_bias, p->f.bias_table, p->f.lse, p->dqkv_bias, p->dbias_table, g, \
+                                                    tsize, vec)
+    if ((g.sd | g.sh | g.sw) != 0) { BWD_MFMA(true); } else { BWD_MFMA(false); }
+#undef BWD_MFMA
     MISEG_LAUNCH_CHECK("winattn_bwd_mfma");
     return MISEG_OK;
   }

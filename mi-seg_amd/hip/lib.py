@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(HERE), "csrc", "libmiseg_hip.so")
+LIB_PATH = os.environ.get("MISEG_HIP_LIB") or os.path.join(os.path.dirname(HERE), "csrc", "libmiseg_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_LEAKY, ACT_GELU, ACT_PRELU = 0, 1, 2, 3
