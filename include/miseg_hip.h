@@ -261,6 +261,11 @@ typedef struct {
 } miseg_conv3_thin_wgrad_params;
 int miseg_conv3_thin_wgrad(const miseg_conv3_thin_wgrad_params* p, miseg_stream_t stream);
 
+/* Network input (NCDHW fp32, Cin <= 8 image channels) -> channels-last rows of CP channels (CP = 4 for fp32, 8 for bf16:
+ * one 16-byte vector per voxel), channels >= Cin zero.  Feeds the first encoder convs (dynunet_block.py:55-64 with
+ * in_channels = image channels) to the implicit-GEMM kernels above. */
+int miseg_ncdhw_to_rows(const float* x, void* y, int B, int Cin, int64_t S, int CP, int dtype, miseg_stream_t stream);
+
 /* Output head: Conv3d 1x1x1 + bias from channels-last rows to NCDHW fp32 logits (dynunet_block.py:273-292),
  * and its backward (dx channels-last, dw/dbias accumulated). */
 typedef struct {

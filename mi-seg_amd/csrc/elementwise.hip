@@ -797,6 +797,36 @@ extern "C" int miseg_colsum(const miseg_colsum_params* p, miseg_stream_t s_) {
   });
 }
 
+namespace miseg {
+template <class T>
+__global__ void __launch_bounds__(256) ncdhw_to_rows_kernel(const float* __restrict__ x, T* __restrict__ y, int Cin, int64_t S, int64_t total) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int N = Vec16<T>::N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / S, v = i - b * S;
+    VT o;
+#pragma unroll
+    for (int c = 0; c < N; ++c) o[c] = from_f32<T>(c < Cin ? x[(b * Cin + c) * S + v] : 0.f);
+    *reinterpret_cast<VT*>(y + i * N) = o;
+  }
+}
+}  // namespace miseg
+
+extern "C" int miseg_ncdhw_to_rows(const float* x, void* y, int B, int Cin, int64_t S, int CP, int dtype, miseg_stream_t s_) {
+  MISEG_REQUIRE(x && y && B > 0 && S > 0 && Cin > 0, MISEG_E_BADARG, "ncdhw_to_rows: bad arguments");
+  return dispatch_dtype(dtype, [&](auto* tag) -> int {
+    typedef typename std::remove_pointer<decltype(tag)>::type T;
+    MISEG_REQUIRE(CP == Vec16<T>::N && Cin <= CP, MISEG_E_UNSUPPORTED, "ncdhw_to_rows: CP must be %d and Cin <= CP", Vec16<T>::N);
+    MISEG_REQUIRE((uintptr_t)y % 16 == 0, MISEG_E_BADARG, "ncdhw_to_rows: y must be 16-byte aligned");
+    const int64_t total = (int64_t)B * S;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    miseg::ncdhw_to_rows_kernel<T><<<grid, 256, 0, (hipStream_t)s_>>>(x, (T*)y, Cin, S, total);
+    MISEG_LAUNCH_CHECK("ncdhw_to_rows");
+    return MISEG_OK;
+  });
+}
+
 extern "C" int miseg_fill32(void* dst, uint32_t value, size_t n, miseg_stream_t s_) {
   MISEG_REQUIRE(dst || n == 0, MISEG_E_BADARG, "fill32: null pointer");
   if (n == 0) return MISEG_OK;

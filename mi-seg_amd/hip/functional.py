@@ -209,18 +209,22 @@ def conv3(x, weight):
 
 
 class _Conv3Thin(Function):
-    """stem conv straight from the NCDHW fp32 network input (Cin <= 4)."""
+    """stem conv straight from the NCDHW fp32 network input (Cin <= 4): the image becomes channels-last rows of one
+    16-byte vector per voxel and goes through the implicit-GEMM kernels (the pack zero-pads Cin the same way)."""
 
     @staticmethod
     def forward(ctx, x_ncdhw, weight, dtype):
-        ctx.save_for_backward(x_ncdhw, weight)
-        return ops.conv3_thin_fwd(x_ncdhw, weight, dtype)
+        xr = ops.ncdhw_to_rows(x_ncdhw, dtype)
+        fwdp, _ = ops.pack_conv3(weight, dtype, True, False)
+        ctx.save_for_backward(xr)
+        ctx.wshape = weight.shape
+        return ops.conv3_fwd(xr, fwdp, weight.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
-        dw = ops.conv3_thin_wgrad(x, _rv(dy), ops.zeros_f32(weight.shape, x.device))
-        return None, dw, None
+        (xr,) = ctx.saved_tensors
+        dwp = ops.conv3_wgrad(xr, _rv(dy))                       # [Cout, CP, 3, 3, 3], channels >= Cin are zero
+        return None, dwp[:, : ctx.wshape[1]].contiguous(), None
 
 
 def conv3_thin(x_ncdhw, weight, dtype):

@@ -115,6 +115,7 @@ PROTOS = {
     "miseg_im2col3": (i32, [C.POINTER(Im2col3), vp]),
     "miseg_col2im3": (i32, [C.POINTER(Im2col3), vp]),
     "miseg_fill32": (i32, [vp, C.c_uint32, C.c_size_t, vp]),
+    "miseg_ncdhw_to_rows": (i32, [vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, vp]),
 }
 
 _lib = None

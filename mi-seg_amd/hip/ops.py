@@ -286,6 +286,17 @@ def conv3_thin_wgrad(x_ncdhw, dy, dw):
     return dw
 
 
+def ncdhw_to_rows(x_ncdhw, dtype):
+    """NCDHW fp32 image -> channels-last rows with one 16-byte vector per voxel (channels >= Cin zero)."""
+    B, Cin, D, H, W = x_ncdhw.shape
+    assert x_ncdhw.dtype == torch.float32 and x_ncdhw.is_contiguous()
+    CP = 16 // torch.empty(0, dtype=dtype).element_size()
+    y = torch.empty(B, D, H, W, CP, dtype=dtype, device=x_ncdhw.device)
+    lib = L.load()
+    L.check(lib.miseg_ncdhw_to_rows(_ptr(x_ncdhw), _ptr(y), B, Cin, D * H * W, CP, _dt(y), _stream()), "ncdhw_to_rows")
+    return y
+
+
 def im2col3(x, adjoint=False, C_out=None):
     """forward: x [B,D,H,W,C] -> col [B,D,H,W,27*C];  adjoint: col -> [B,D,H,W,C]."""
     B, D, H, W = _vol(x)
