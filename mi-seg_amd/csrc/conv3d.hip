@@ -365,44 +365,50 @@ __global__ void __launch_bounds__(256) conv3_scratch_to_out_kernel(const float* 
 // Planar packs (fast path, chosen when the K-side channel row is a multiple of 96 bytes):
 //   fwd[tap][ci / KPC][coP16][ci % KPC] = w[co][ci][tap]        bwd[tap][co / KPC][ciP16][co % KPC] = w[co][ci][26 - tap]
 // ---------------------------------------------------------------------------------------------------------
+// One workgroup packs a 16 (co) x 16 (ci) x 27 tile: the torch-layout weight is read in contiguous runs of 16*27 floats
+// into LDS, every pack is written as 16-byte vectors whose fastest index follows the pack's memory order.
+static constexpr int PK_T = 16;
+static constexpr int PK_LD = PK_T * 27 + 1;      // floats per co row of the LDS tile
+
 template <class T>
 __global__ void __launch_bounds__(256) pack_conv3_kernel(const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ bwd, int Cin, int Cout, int CinP, int CoutP,
                                                          int Cin16, int Cout16, bool fwd_planar, bool bwd_planar) {
-  constexpr int KPC = Vec16<T>::N;
-  const int64_t nf = fwd ? (fwd_planar ? (int64_t)27 * CinP * Cout16 : (int64_t)Cout * 27 * CinP) : 0;
-  const int64_t nb = bwd ? (bwd_planar ? (int64_t)27 * CoutP * Cin16 : (int64_t)Cin * 27 * CoutP) : 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nb; i += (int64_t)gridDim.x * blockDim.x) {
-    if (i < nf) {
-      int co, ci, tap;
-      if (fwd_planar) {
-        const int e = (int)(i % KPC);
-        int64_t t = i / KPC;
-        co = (int)(t % Cout16); t /= Cout16;
-        const int cgi = (int)(t % (CinP / KPC));
-        tap = (int)(t / (CinP / KPC));
-        ci = cgi * KPC + e;
-      } else {
-        ci = (int)(i % CinP);
-        tap = (int)((i / CinP) % 27);
-        co = (int)(i / ((int64_t)CinP * 27));
-      }
-      fwd[i] = from_f32<T>((ci < Cin && co < Cout) ? w[((int64_t)co * Cin + ci) * 27 + tap] : 0.f);
-    } else {
-      const int64_t j = i - nf;
-      int co, ci, tap;
-      if (bwd_planar) {
-        const int e = (int)(j % KPC);
-        int64_t t = j / KPC;
-        ci = (int)(t % Cin16); t /= Cin16;
-        const int cgo = (int)(t % (CoutP / KPC));
-        tap = (int)(t / (CoutP / KPC));
-        co = cgo * KPC + e;
-      } else {
-        co = (int)(j % CoutP);
-        tap = (int)((j / CoutP) % 27);
-        ci = (int)(j / ((int64_t)CoutP * 27));
-      }
-      bwd[j] = from_f32<T>((ci < Cin && co < Cout) ? w[((int64_t)co * Cin + ci) * 27 + (26 - tap)] : 0.f);
+  typedef typename Vec16<T>::type VT;
+  constexpr int KPC = Vec16<T>::N, NG = PK_T / KPC;
+  __shared__ float tile[PK_T * PK_LD];
+  const int ci0 = blockIdx.x * PK_T, co0 = blockIdx.y * PK_T;
+  const int nci = min(PK_T, Cin - ci0);
+  for (int i = threadIdx.x; i < PK_T * PK_T * 27; i += 256) {
+    const int co = i / (PK_T * 27), r = i - co * (PK_T * 27);     // r = ci_local * 27 + tap
+    tile[co * PK_LD + r] = (co0 + co < Cout && r < nci * 27) ? w[((int64_t)(co0 + co) * Cin + ci0) * 27 + r] : 0.f;
+  }
+  __syncthreads();
+  if (fwd) {   // K side = ci: vector = KPC consecutive ci of (co, tap)
+    for (int i = threadIdx.x; i < PK_T * 27 * NG; i += 256) {
+      int co, tap, cg;
+      if (fwd_planar) { co = i % PK_T; cg = (i / PK_T) % NG; tap = i / (PK_T * NG); }
+      else { cg = i % NG; tap = (i / NG) % 27; co = i / (NG * 27); }
+      const int cib = ci0 + cg * KPC;
+      if (cib >= CinP || (!fwd_planar && co0 + co >= Cout)) continue;
+      VT v;
+#pragma unroll
+      for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(tile[co * PK_LD + (cg * KPC + e) * 27 + tap]);
+      const int64_t off = fwd_planar ? (((int64_t)tap * (CinP / KPC) + cib / KPC) * Cout16 + co0 + co) * KPC : ((int64_t)(co0 + co) * 27 + tap) * CinP + cib;
+      *reinterpret_cast<VT*>(fwd + off) = v;
+    }
+  }
+  if (bwd) {   // K side = co, taps mirrored: vector = KPC consecutive co of (ci, tap)
+    for (int i = threadIdx.x; i < PK_T * 27 * NG; i += 256) {
+      int ci, tap, cg;
+      if (bwd_planar) { ci = i % PK_T; cg = (i / PK_T) % NG; tap = i / (PK_T * NG); }
+      else { cg = i % NG; tap = (i / NG) % 27; ci = i / (NG * 27); }
+      const int cob = co0 + cg * KPC;
+      if (cob >= CoutP || (!bwd_planar && ci0 + ci >= Cin)) continue;
+      VT v;
+#pragma unroll
+      for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(tile[(cg * KPC + e) * PK_LD + ci * 27 + (26 - tap)]);
+      const int64_t off = bwd_planar ? (((int64_t)tap * (CoutP / KPC) + cob / KPC) * Cin16 + ci0 + ci) * KPC : ((int64_t)(ci0 + ci) * 27 + tap) * CoutP + cob;
+      *reinterpret_cast<VT*>(bwd + off) = v;
     }
   }
 }
@@ -727,9 +733,9 @@ extern "C" int miseg_pack_conv3_weight(const miseg_pack_conv3_params* p, miseg_s
     constexpr int KPC = Vec16<T>::N;
     const int CinP = round_up(p->Cin, KPC), CoutP = round_up(p->Cout, KPC);
     const bool fplanar = (CinP * (int)sizeof(T)) % 96 == 0, bplanar = (CoutP * (int)sizeof(T)) % 96 == 0;
-    const int64_t n = (int64_t)miseg_pack_conv3_elems(p->Cin, p->Cout, p->dtype, 0) + (int64_t)miseg_pack_conv3_elems(p->Cin, p->Cout, p->dtype, 1);
-    int grid = (int)((n + 255) / 256);
-    if (grid > 8192) grid = 8192;
+    MISEG_REQUIRE((!p->fwd_pack || (uintptr_t)p->fwd_pack % 16 == 0) && (!p->bwd_pack || (uintptr_t)p->bwd_pack % 16 == 0), MISEG_E_BADARG,
+                  "pack_conv3_weight: packs must be 16-byte aligned");
+    dim3 grid(cdiv(p->Cin, PK_T), cdiv(p->Cout, PK_T));
     pack_conv3_kernel<T><<<grid, 256, 0, s>>>(p->w, (T*)p->fwd_pack, (T*)p->bwd_pack, p->Cin, p->Cout, CinP, CoutP, round_up(p->Cin, 16), round_up(p->Cout, 16),
                                               fplanar, bplanar);
     MISEG_LAUNCH_CHECK("pack_conv3_weight");
