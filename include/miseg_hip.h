@@ -45,14 +45,16 @@ int miseg_device_arch(char* buf, size_t n);
  *   styles: device int32[B] or NULL (=> row 0); gamma/beta[s]: fp32[C] per style or NULL (no affine).
  *   y = act((x - mean) * rstd * gamma[s] + beta[s] + res)
  * ---------------------------------------------------------------------------------------------- */
-/* statistics are kept as fp64 (sum x, sum x^2) pairs: stat is double[B][C][2] (miseg_instnorm_stat_bytes); the CALLER
- * zero-fills it (the host pools all statistics buffers of a step behind one fill), miseg_instnorm_stats accumulates into it
- * with fp64 atomics; apply / backward derive mean and 1/sqrt(var+eps) from it. */
+/* statistics are kept as fp64 (sum x, sum x^2) pairs in R replicas: stat is double[R][B][C][2] with R * B * C * 16 =
+ * miseg_instnorm_stat_bytes(B, C) bytes; the CALLER zero-fills it (the host pools all statistics buffers of a step behind
+ * one fill), miseg_instnorm_stats adds each workgroup's partial sums to one replica with fp64 atomics (one row of
+ * addresses serialises ~900 workgroups of a 96^3 tensor); apply / backward add the replicas up and derive mean and
+ * 1/sqrt(var+eps). */
 size_t miseg_instnorm_stat_bytes(int B, int C);
 typedef struct {
   const void* x; int64_t ldx;
   int B, S, C, dtype;
-  void* stat;                      /* in/out: double [B][C][2], zero on entry */
+  void* stat;                      /* in/out: miseg_instnorm_stat_bytes(B, C) bytes, zero on entry */
 } miseg_instnorm_stats_params;
 int miseg_instnorm_stats(const miseg_instnorm_stats_params* p, miseg_stream_t stream);
 

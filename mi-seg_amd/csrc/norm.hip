@@ -58,8 +58,13 @@ template <class T, int VEC> struct RowVec {
   }
 };
 
-// block-level reduction over ty of two per-thread vectors, then one fp64 atomic per (channel, which) into
-// stat[b][ch][which] -- no finalize kernel, no workspace.
+// Statistics buffers hold NORM_R replicas of the fp64 (sum, sum of squares) pairs: double [NORM_R][B][C][2].  A block adds
+// its partial sums to replica (chunk mod NORM_R): with one row, the ~900 blocks of a 96^3 tensor queue on 96 addresses and
+// the reduction costs 2x the streaming read (measured 49 us vs 15 us); consumers add the replicas up in their prologue.
+static constexpr int NORM_R = 16;
+
+// block-level reduction over ty of two per-thread vectors, then one fp64 atomic per (channel, which) -- no finalize
+// kernel, no workspace.
 template <int VEC>
 __device__ __forceinline__ void block_reduce_to_stat(float* red, const float* s, const float* q, int tx, int ty, int tx_n, int ty_n, int c0, int C,
                                                      double* stat_b) {
@@ -80,12 +85,28 @@ __device__ __forceinline__ void block_reduce_to_stat(float* red, const float* s,
   }
 }
 
-__device__ __forceinline__ void mean_rstd(const double* stat_bc, int S, float eps, float& m, float& rs) {
-  const double mu = stat_bc[0] / S;
-  double var = stat_bc[1] / S - mu * mu;
+// workgroup prologue of the consumers: sums[(col) * 2 + which] = sum over replicas of stat[r][b][c0*VEC + col][which]
+__device__ __forceinline__ void gather_stat(double* sums, const double* __restrict__ stat, int64_t rstride, int b, int C, int ch0, int ncols) {
+  for (int e = threadIdx.x; e < 2 * ncols; e += NORM_THREADS) {
+    const int ch = ch0 + (e >> 1);
+    double acc = 0.0;
+    if (ch < C) {
+      const double* p = stat + ((int64_t)b * C + ch) * 2 + (e & 1);
+#pragma unroll
+      for (int r = 0; r < NORM_R; ++r) acc += p[r * rstride];
+    }
+    sums[e] = acc;
+  }
+  __syncthreads();
+}
+
+// mean and 1/sqrt(var + eps) of one channel; the variance is formed in fp64 (cancellation), the root in fp32
+__device__ __forceinline__ void mean_rstd(const double* sums2, double invS, float eps, float& m, float& rs) {
+  const double mu = sums2[0] * invS;
+  double var = fma(sums2[1], invS, -mu * mu);
   if (var < 0.0) var = 0.0;
   m = (float)mu;
-  rs = (float)(1.0 / sqrt(var + (double)eps));
+  rs = 1.0f / sqrtf((float)var + eps);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -121,7 +142,7 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_stats_kernel(const T* _
       for (int i = 0; i < VEC; ++i) { s[i] += v.v[i]; q[i] = fmaf(v.v[i], v.v[i], q[i]); }
     }
   }
-  block_reduce_to_stat<VEC>(red, s, q, tx, ty, tx_n, ty_n, c0, C, stat + (int64_t)b * C * 2);
+  block_reduce_to_stat<VEC>(red, s, q, tx, ty, tx_n, ty_n, c0, C, stat + ((int64_t)(chunk % NORM_R) * gridDim.y + b) * C * 2);
 }
 
 struct StylePtrs {
@@ -134,21 +155,24 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_apply_kernel(const T* _
                                                                       T* __restrict__ y, int64_t ldy, int S, int C, int cv, int tx_n, int ty_n, int rpb,
                                                                       const double* __restrict__ stat, float eps, const int32_t* __restrict__ styles,
                                                                       StylePtrs sp, int act, float slope) {
+  extern __shared__ __attribute__((aligned(16))) double sums[];
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
   const int c = blockIdx.z * tx_n + tx;
+  gather_stat(sums, stat, (int64_t)gridDim.y * C * 2, b, C, blockIdx.z * tx_n * VEC, tx_n * VEC);
   if (ty >= ty_n || c >= cv) return;
   const int r0 = chunk * rpb, r1 = min(S, r0 + rpb);
   const int st = styles ? styles[b] : 0;
   const float* g = sp.gamma[st];
   const float* be = sp.beta[st];
   const int64_t boff = (int64_t)b * S;
+  const double invS = 1.0 / S;
   float sc[VEC], sh[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
     const int ch = c * VEC + i;
     float m, rs;
-    mean_rstd(stat + ((int64_t)b * C + ch) * 2, S, eps, m, rs);
+    mean_rstd(sums + (tx * VEC + i) * 2, invS, eps, m, rs);
     const float gg = g ? g[ch] : 1.f, bb = be ? be[ch] : 0.f;
     sc[i] = rs * gg;
     sh[i] = bb - m * sc[i];
@@ -182,18 +206,19 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_bwd_reduce_kernel(const
                                                                            const double* __restrict__ stat, float eps, int act, float slope,
                                                                            double* __restrict__ dstat) {
   extern __shared__ __attribute__((aligned(16))) float red[];
+  double* sums = reinterpret_cast<double*>(red);   // prologue only; the reduction reuses the space after a barrier
   const int b = blockIdx.y, chunk = blockIdx.x, c0 = blockIdx.z * tx_n;
   const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
   const int r0 = chunk * rpb, r1 = min(S, r0 + rpb);
   const int64_t boff = (int64_t)b * S;
   const int c = c0 + tx;
-  float s[VEC], q[VEC];
+  gather_stat(sums, stat, (int64_t)gridDim.y * C * 2, b, C, c0 * VEC, tx_n * VEC);
+  float s[VEC], q[VEC], m[VEC], rs[VEC];
+  const double invS = 1.0 / S;
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) s[i] = q[i] = 0.f;
+  for (int i = 0; i < VEC; ++i) { s[i] = q[i] = 0.f; mean_rstd(sums + (tx * VEC + i) * 2, invS, eps, m[i], rs[i]); }
+  __syncthreads();
   if (ty < ty_n && c < cv) {
-    float m[VEC], rs[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) mean_rstd(stat + ((int64_t)b * C + c * VEC + i) * 2, S, eps, m[i], rs[i]);
 #pragma unroll 4
     for (int r = r0 + ty; r < r1; r += ty_n) {
       RowVec<T, VEC> g, xv;
@@ -212,7 +237,7 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_bwd_reduce_kernel(const
       }
     }
   }
-  block_reduce_to_stat<VEC>(red, s, q, tx, ty, tx_n, ty_n, c0, C, dstat + (int64_t)b * C * 2);
+  block_reduce_to_stat<VEC>(red, s, q, tx, ty, tx_n, ty_n, c0, C, dstat + ((int64_t)(chunk % NORM_R) * gridDim.y + b) * C * 2);
 }
 
 struct StyleGradPtrs {
@@ -225,8 +250,11 @@ __global__ void instnorm_bwd_param_kernel(const double* __restrict__ dstat, int 
   if (i >= total) return;
   const int b = i / C, c = i % C;
   const int st = styles ? styles[b] : 0;
-  if (gp.dgamma[st]) atomicAdd(gp.dgamma[st] + c, (float)dstat[2 * i + 1]);
-  if (gp.dbeta[st]) atomicAdd(gp.dbeta[st] + c, (float)dstat[2 * i]);
+  double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+  for (int r = 0; r < NORM_R; ++r) { s0 += dstat[((int64_t)r * total + i) * 2]; s1 += dstat[((int64_t)r * total + i) * 2 + 1]; }
+  if (gp.dgamma[st]) atomicAdd(gp.dgamma[st] + c, (float)s1);
+  if (gp.dbeta[st]) atomicAdd(gp.dbeta[st] + c, (float)s0);
 }
 
 template <class T, int VEC>
@@ -235,22 +263,27 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_bwd_apply_kernel(const 
                                                                           T* __restrict__ dres, int64_t lddres, int S, int C, int cv, int tx_n, int ty_n, int rpb,
                                                                           const double* __restrict__ stat, float eps, const int32_t* __restrict__ styles,
                                                                           StylePtrs sp, int act, float slope, const double* __restrict__ dstat) {
+  extern __shared__ __attribute__((aligned(16))) double sums[];
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
   const int c = blockIdx.z * tx_n + tx;
+  double* dsums = sums + 2 * tx_n * VEC;
+  gather_stat(sums, stat, (int64_t)gridDim.y * C * 2, b, C, blockIdx.z * tx_n * VEC, tx_n * VEC);
+  gather_stat(dsums, dstat, (int64_t)gridDim.y * C * 2, b, C, blockIdx.z * tx_n * VEC, tx_n * VEC);
   if (ty >= ty_n || c >= cv) return;
   const int r0 = chunk * rpb, r1 = min(S, r0 + rpb);
   const int st = styles ? styles[b] : 0;
   const float* g = sp.gamma[st];
   const int64_t boff = (int64_t)b * S;
+  const double invS = 1.0 / S;
   float m[VEC], rs[VEC], sc[VEC], a[VEC], bq[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
     const int ch = c * VEC + i;
-    mean_rstd(stat + ((int64_t)b * C + ch) * 2, S, eps, m[i], rs[i]);
+    mean_rstd(sums + (tx * VEC + i) * 2, invS, eps, m[i], rs[i]);
     sc[i] = rs[i] * (g ? g[ch] : 1.f);
-    a[i] = (float)(dstat[((int64_t)b * C + ch) * 2] / S);
-    bq[i] = (float)(dstat[((int64_t)b * C + ch) * 2 + 1] / S);
+    a[i] = (float)(dsums[(tx * VEC + i) * 2] * invS);
+    bq[i] = (float)(dsums[(tx * VEC + i) * 2 + 1] * invS);
   }
 #pragma unroll 4
   for (int r = r0 + ty; r < r1; r += ty_n) {
@@ -355,7 +388,7 @@ using namespace miseg;
 
 static bool aligned16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 
-extern "C" size_t miseg_instnorm_stat_bytes(int B, int C) { return (size_t)B * C * 2 * sizeof(double); }
+extern "C" size_t miseg_instnorm_stat_bytes(int B, int C) { return (size_t)NORM_R * B * C * 2 * sizeof(double); }
 
 extern "C" int miseg_instnorm_stats(const miseg_instnorm_stats_params* p, miseg_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -389,11 +422,12 @@ extern "C" int miseg_instnorm_apply(const miseg_instnorm_apply_params* p, miseg_
     StylePtrs sp;
     for (int s = 0; s < MISEG_MAX_STYLES; ++s) { sp.gamma[s] = s < p->num_styles ? p->gamma[s] : nullptr; sp.beta[s] = s < p->num_styles ? p->beta[s] : nullptr; }
     dim3 grid(g.chunks, p->B, g.ctiles);
+    const size_t shd = (size_t)2 * g.tx * g.vec * sizeof(double);
     if (g.vec == 1)
-      instnorm_apply_kernel<T, 1><<<grid, NORM_THREADS, 0, stream>>>((const T*)p->x, p->ldx, (const T*)p->res, p->ldres, (T*)p->y, p->ldy, p->S, p->C, g.cv, g.tx,
+      instnorm_apply_kernel<T, 1><<<grid, NORM_THREADS, shd, stream>>>((const T*)p->x, p->ldx, (const T*)p->res, p->ldres, (T*)p->y, p->ldy, p->S, p->C, g.cv, g.tx,
                                                                       g.ty, g.rpb, (const double*)p->stat, p->eps, p->styles, sp, p->act, p->slope);
     else
-      instnorm_apply_kernel<T, V><<<grid, NORM_THREADS, 0, stream>>>((const T*)p->x, p->ldx, (const T*)p->res, p->ldres, (T*)p->y, p->ldy, p->S, p->C, g.cv, g.tx,
+      instnorm_apply_kernel<T, V><<<grid, NORM_THREADS, shd, stream>>>((const T*)p->x, p->ldx, (const T*)p->res, p->ldres, (T*)p->y, p->ldy, p->S, p->C, g.cv, g.tx,
                                                                       g.ty, g.rpb, (const double*)p->stat, p->eps, p->styles, sp, p->act, p->slope);
     MISEG_LAUNCH_CHECK("instnorm_apply");
     return MISEG_OK;
@@ -423,6 +457,8 @@ extern "C" int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stre
     }
     dim3 grid(g.chunks, p->B, g.ctiles);
     size_t sh = (size_t)g.ty * 2 * g.tx * g.vec * sizeof(float);
+    if (sh < (size_t)2 * g.tx * g.vec * sizeof(double)) sh = (size_t)2 * g.tx * g.vec * sizeof(double);
+    const size_t shd = (size_t)4 * g.tx * g.vec * sizeof(double);
     const double* stat = (const double*)p->stat;
     double* dstat = (double*)p->dstat;
     const int total = p->B * p->C;
@@ -430,7 +466,7 @@ extern "C" int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stre
     instnorm_bwd_reduce_kernel<T, VV><<<grid, NORM_THREADS, sh, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, p->S, p->C,  \
                                                                            g.cv, g.tx, g.ty, g.rpb, stat, p->eps, p->act, p->slope, dstat);                           \
     if (any_param) instnorm_bwd_param_kernel<<<cdiv(total, 256), 256, 0, stream>>>(dstat, p->C, p->styles, gp, total);                                          \
-    instnorm_bwd_apply_kernel<T, VV><<<grid, NORM_THREADS, 0, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, (T*)p->dx,    \
+    instnorm_bwd_apply_kernel<T, VV><<<grid, NORM_THREADS, shd, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, (T*)p->dx,    \
                                                                          p->lddx, (T*)p->dres, p->lddres, p->S, p->C, g.cv, g.tx, g.ty, g.rpb, stat, p->eps, p->styles, \
                                                                          sp, p->act, p->slope, dstat);
     if (g.vec == 1) { BWD_LAUNCH(1) } else { BWD_LAUNCH(V) }

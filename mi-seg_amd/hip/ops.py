@@ -70,7 +70,7 @@ def _call(fn_name, params, prof=None):
 class _ZeroPool:
     """fp64 statistics buffers of a step come from one pre-zeroed pool (one fill instead of ~100 small memsets)."""
 
-    def __init__(self, numel=1 << 20):
+    def __init__(self, numel=1 << 22):
         self.numel, self.buf, self.off = numel, None, 0
 
     def take(self, n, device):
@@ -100,10 +100,10 @@ def begin_step():
 
 
 def instnorm_stats(x, B, S):
-    """x: rows view of [B*S, C].  Returns stat: float64 [B, C, 2] = (sum x, sum x^2)."""
+    """x: rows view of [B*S, C].  Returns stat: float64 [R, B, C, 2]; summed over the R replicas = (sum x, sum x^2)."""
     ld, n, Cc = rows(x)
     assert n == B * S, (n, B, S)
-    stat = STAT_POOL.take(B * Cc * 2, x.device).view(B, Cc, 2)
+    stat = STAT_POOL.take(L.load().miseg_instnorm_stat_bytes(B, Cc) // 8, x.device).view(-1, B, Cc, 2)
     _call("miseg_instnorm_stats", L.InstnormStats(_ptr(x), ld, B, S, Cc, _dt(x), _ptr(stat)))
     return stat
 
@@ -132,7 +132,7 @@ def instnorm_bwd(dy, y, x, B, S, stat, styles, gammas, dgammas, dbetas, act=L.AC
     ld, n, Cc = rows(x)
     dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     dres = torch.empty(x.shape, dtype=x.dtype, device=x.device) if want_dres else None
-    dstat = STAT_POOL.take(B * Cc * 2, x.device)
+    dstat = STAT_POOL.take(L.load().miseg_instnorm_stat_bytes(B, Cc) // 8, x.device)
     ns = len(gammas) if gammas is not None else 1
     p = L.InstnormBwd(_ptr(dy), rows(dy)[0], _ptr(y), rows(y)[0] if y is not None else 0, _ptr(x), ld, _ptr(dx), rows(dx)[0],
                       _ptr(dres), rows(dres)[0] if dres is not None else 0, B, S, Cc, _dt(x), _ptr(stat), eps, _ptr(dstat), _ptr(styles), ns,

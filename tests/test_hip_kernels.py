@@ -53,7 +53,7 @@ def test_instnorm_fwd_bwd(dtype, B, S, C):
     styles_h = [(i + 1) % 2 for i in range(B)]
     styles = torch.tensor(styles_h, dtype=torch.int32, device=DEV)
     stat = ops.instnorm_stats(x, B, S)
-    mean = (stat[..., 0] / S).float()
+    mean = (stat.sum(0)[..., 0] / S).float()
     y = ops.instnorm_apply(x, B, S, stat, styles, gam, bet, res=res, act=L.ACT_LEAKY, slope=0.01)
     # reference (fp32 on device)
     xf = x.double().requires_grad_(True)
