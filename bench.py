@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-arena", action="store_true", help="torch-style per-parameter gradient tensors and per-call weight casts")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -88,15 +89,23 @@ def main():
     cot = torch.randn(1, 6, 96, 96, 96, generator=torch.Generator().manual_seed(4321)).to(dev)
     params = [p for p in model.parameters() if p.requires_grad]
 
+    arena = None
+    if not a.no_arena:
+        from mi_seg_amd.runtime.arena import ParamArena
+        arena = ParamArena(params, dtype)
     graphed = None
     if not a.no_graph:
         from mi_seg_amd.runtime.graph import GraphedStep
-        graphed = GraphedStep(model, (1, 1, 96, 96, 96), (1, 6, 96, 96, 96))
+        graphed = GraphedStep(model, (1, 1, 96, 96, 96), (1, 6, 96, 96, 96), arena=arena)
 
-    def step(i, eager=False):
-        k = order[i % len(order)]
+    def step(i, eager=False, sample=None):
+        k = order[i % len(order)] if sample is None else sample
         if graphed is not None and not eager:
             graphed(pool[k:k + 1], [mods[k]], cot)
+        elif arena is not None:
+            arena.begin_step()
+            model(pool[k:k + 1], [mods[k]]).backward(cot)
+            arena.publish()
         else:
             ops.begin_step()
             for p in params:
@@ -104,8 +113,11 @@ def main():
             y = model(pool[k:k + 1], [mods[k]])
             y.backward(cot)
         if dist is not None:
-            from mi_seg_amd.parallel.ddp import allreduce_gradients
-            allreduce_gradients(params, world)
+            if arena is not None:
+                arena.allreduce(world)
+            else:
+                from mi_seg_amd.parallel.ddp import allreduce_gradients
+                allreduce_gradients(params, world)
 
     # setup (untimed, not part of the W warm-up steps): touch both modalities once so that hipGraph capture / allocator growth of
     # either conditional-norm row set never lands inside the timed region
@@ -114,7 +126,8 @@ def main():
         if graphed is not None:
             graphed(pool[k_:k_ + 1], [m_], cot)
         else:
-            model(pool[k_:k_ + 1], [m_]).backward(cot)
+            for _ in range(2):            # with an arena the first step registers the weight re-layouts, the second uses them
+                step(0, eager=True, sample=k_)
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()

@@ -216,6 +216,17 @@ int miseg_copy2d(const miseg_copy2d_params* p, miseg_stream_t stream);
 typedef struct { const float* src; void* dst; int R, C, dtype, transpose; } miseg_cast_params;
 int miseg_cast_matrix(const miseg_cast_params* p, miseg_stream_t stream);
 
+/* All per-step parameter re-layouts of a model in ONE launch (the per-call form above costs a ~4 us launch per
+ * weight, ~100 per step of C-Swin-UNETR): descriptor i turns the fp32 matrix src [R][C] into dst in `dtype`,
+ *   dst[r][m(c)] (transpose = 0)  or  dst[m(c)][r] (transpose = 1),   m(c) = (c % inner) * outer + c / inner
+ * (inner = 1: identity; inner = 8, outer = Cout: the (co, tap) -> (tap, co) regrouping of ConvTranspose3d k2s2 weights,
+ * unetr_block.py:80).  Descriptors live in device memory, sorted by tile0 = number of 32x32 tiles before them. */
+typedef struct {
+  const float* src; void* dst;
+  int32_t R, C, transpose, inner, outer, tile0;
+} miseg_cast_desc;
+int miseg_param_cast_batch(const miseg_cast_desc* descs_dev, int ndesc, int total_tiles, int dtype, miseg_stream_t stream);
+
 /* GELU (exact, erf): y = gelu(x); backward: dx = dy * gelu'(x)  (MONAI MLPBlock act, swin_transformer_block.py:97) */
 typedef struct { const void* x; int64_t ldx; void* y; int64_t ldy; int64_t rows; int C, dtype; } miseg_gelu_fwd_params;
 int miseg_gelu_fwd(const miseg_gelu_fwd_params* p, miseg_stream_t stream);

@@ -27,6 +27,14 @@ def _rv(t):
         return t.contiguous()
 
 
+def _slot(p):
+    """the arena slot (runtime/arena.py) that the weight-gradient kernels add into for parameter p, or None."""
+    g = getattr(p, "_miseg_grad", None) if p is not None else None
+    if g is not None:
+        p._miseg_used = True
+    return g
+
+
 # ----------------------------------------------------------------------------------------------------------------
 class _Fork(Function):
     """y1 = y2 = x with the gradient sum done by our add kernel instead of the autograd engine's."""
@@ -76,6 +84,7 @@ class _InstNorm(Function):
         betas = list(params[1::2]) if affine else None
         y = ops.instnorm_apply(x, B, S, stat, styles_dev, gammas, betas, res=res, act=act, slope=slope, eps=eps)
         ctx.meta = (B, S, styles_host, num_styles, affine, act, slope, res is not None, eps)
+        ctx.params = params
         ctx.save_for_backward(x, y if act != L.ACT_NONE else None, stat, styles_dev, *(gammas or []))
         return y
 
@@ -87,7 +96,11 @@ class _InstNorm(Function):
         C = x.shape[-1]
         present = sorted(set(styles_host)) if styles_host is not None else [0]
         dgam = dbet = None
-        if affine:
+        in_arena = affine and getattr(ctx.params[0], "_miseg_grad", None) is not None
+        if in_arena:
+            dgam = [_slot(ctx.params[2 * s]) if s in present else None for s in range(num_styles)]
+            dbet = [_slot(ctx.params[2 * s + 1]) if s in present else None for s in range(num_styles)]
+        elif affine:
             buf = ops.zeros_f32((num_styles, 2, C), x.device)
             # parameters of a style absent from the batch get no gradient (reference: grad is None)
             dgam = [buf[s, 0] if s in present else None for s in range(num_styles)]
@@ -97,7 +110,7 @@ class _InstNorm(Function):
         pg = []
         if affine:
             for s in range(num_styles):
-                pg += [dgam[s], dbet[s]]
+                pg += [None, None] if in_arena else [dgam[s], dbet[s]]
         return (dx, dres, None, None, None, None, None, None, None, *pg)
 
 
@@ -118,6 +131,7 @@ class _LayerNorm(Function):
         y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, eps)
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.has_beta = beta is not None
+        ctx.params = (gamma, beta)
         return y
 
     @staticmethod
@@ -125,10 +139,11 @@ class _LayerNorm(Function):
         x, gamma, mean, rstd = ctx.saved_tensors
         dy = _rv(dy)
         C = x.shape[-1]
-        dg = ops.zeros_f32((C,), x.device) if gamma is not None else None
-        db = ops.zeros_f32((C,), x.device) if ctx.has_beta else None
+        sg, sb = _slot(ctx.params[0]), _slot(ctx.params[1])
+        dg = sg if sg is not None else (ops.zeros_f32((C,), x.device) if gamma is not None else None)
+        db = sb if sb is not None else (ops.zeros_f32((C,), x.device) if ctx.has_beta else None)
         dx = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dg, db)
-        return dx, dg, db, None
+        return dx, None if sg is not None else dg, None if sb is not None else db, None
 
 
 def layer_norm(x, gamma, beta, eps=1e-5):
@@ -145,6 +160,7 @@ class _Linear(Function):
         y = ops.gemm_nt(x, w, bias)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
@@ -156,9 +172,17 @@ class _Linear(Function):
             wt = ops.cast_matrix(weight, dy.dtype, transpose=True)      # [K, N]
             dx = ops.gemm_nt(dy, wt)
         if ctx.needs_input_grad[1]:
-            dw = ops.gemm_tn(dy, x).view(weight.shape)
+            slot = _slot(ctx.params[0])
+            if slot is not None:
+                ops.gemm_tn(dy, x, out=slot, accumulate=True)
+            else:
+                dw = ops.gemm_tn(dy, x).view(weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = ops.colsum(dy)
+            slot = _slot(ctx.params[1])
+            if slot is not None:
+                ops.colsum(dy, out=slot, accumulate=True)
+            else:
+                db = ops.colsum(dy)
         return dx, dw, db
 
 
@@ -193,6 +217,7 @@ class _Conv3(Function):
         y = ops.conv3_fwd(x, fwdp, weight.shape[0])
         ctx.save_for_backward(x, bwdp)
         ctx.wshape = weight.shape
+        ctx.params = (weight,)
         return y
 
     @staticmethod
@@ -200,7 +225,13 @@ class _Conv3(Function):
         x, bwdp = ctx.saved_tensors
         dy = _rv(dy)
         dx = ops.conv3_fwd(dy, bwdp, ctx.wshape[1]) if ctx.needs_input_grad[0] else None
-        dw = ops.conv3_wgrad(x, dy) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            slot = _slot(ctx.params[0])
+            if slot is not None:
+                ops.conv3_wgrad(x, dy, dw=slot, accumulate=True)
+            else:
+                dw = ops.conv3_wgrad(x, dy)
         return dx, dw
 
 
@@ -218,12 +249,17 @@ class _Conv3Thin(Function):
         fwdp, _ = ops.pack_conv3(weight, dtype, True, False)
         ctx.save_for_backward(xr)
         ctx.wshape = weight.shape
+        ctx.params = (weight,)
         return ops.conv3_fwd(xr, fwdp, weight.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         (xr,) = ctx.saved_tensors
         dwp = ops.conv3_wgrad(xr, _rv(dy))                       # [Cout, CP, 3, 3, 3], channels >= Cin are zero
+        slot = _slot(ctx.params[0])
+        if slot is not None:
+            slot.add_(dwp[:, : ctx.wshape[1]])
+            return None, None, None
         return None, dwp[:, : ctx.wshape[1]].contiguous(), None
 
 
@@ -238,6 +274,7 @@ class _Conv1(Function):
     def forward(ctx, x, weight):
         w = ops.cast_matrix(weight, x.dtype)
         ctx.save_for_backward(x, weight)
+        ctx.params = (weight,)
         return ops.gemm_nt(x, w)
 
     @staticmethod
@@ -245,7 +282,13 @@ class _Conv1(Function):
         x, weight = ctx.saved_tensors
         dy = _rv(dy)
         dx = ops.gemm_nt(dy, ops.cast_matrix(weight, dy.dtype, transpose=True)) if ctx.needs_input_grad[0] else None
-        dw = ops.gemm_tn(dy, x).view(weight.shape) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            slot = _slot(ctx.params[0])
+            if slot is not None:
+                ops.gemm_tn(dy, x, out=slot, accumulate=True)
+            else:
+                dw = ops.gemm_tn(dy, x).view(weight.shape)
         return dx, dw
 
 
@@ -263,9 +306,7 @@ class _UpCat(Function):
         Cin, Cout = weight.shape[0], weight.shape[1]
         B, d, h, w = x.shape[0], x.shape[1], x.shape[2], x.shape[3]
         dev = x.device
-        wf32 = torch.empty(8 * Cout, Cin, dtype=torch.float32, device=dev)
-        ops.permute3(weight, wf32, (8, Cout, Cin), (1, 8, Cout * 8))                 # [(j,co)][ci]
-        wf = ops.cast_matrix(wf32, x.dtype)
+        wf = ops.cast_matrix(weight, x.dtype, transpose=True, regroup=(8, Cout))     # [(j,co)][ci]
         y8 = ops.gemm_nt(x, wf)
         width = 2 * Cout if skip is not None else Cout
         cat = torch.empty(B, 2 * d, 2 * h, 2 * w, width, dtype=x.dtype, device=dev)
@@ -274,6 +315,7 @@ class _UpCat(Function):
             ops.copy2d(skip, cat[..., Cout:])
         ctx.save_for_backward(x, weight)
         ctx.has_skip = skip is not None
+        ctx.params = (weight,)
         return cat
 
     @staticmethod
@@ -285,13 +327,15 @@ class _UpCat(Function):
         dy8 = ops.space_to_channel(dcat[..., :Cout], STD_OFFSETS)                     # [B,d,h,w,8*Cout]
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            wb32 = torch.empty(Cin, 8 * Cout, dtype=torch.float32, device=x.device)
-            ops.permute3(weight, wb32, (Cin, 8, Cout), (Cout * 8, 1, 8))              # [ci][(j,co)]
-            dx = ops.gemm_nt(dy8, ops.cast_matrix(wb32, x.dtype))
+            dx = ops.gemm_nt(dy8, ops.cast_matrix(weight, x.dtype, regroup=(8, Cout)))   # [ci][(j,co)]
         if ctx.needs_input_grad[2]:
             dwf = ops.gemm_tn(dy8, x)                                                 # [(j,co)][ci]
-            dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
-            ops.permute3(dwf, dw, (Cin, Cout, 8), (1, Cin, Cout * Cin))
+            slot = _slot(ctx.params[0])
+            if slot is not None:
+                ops.permute3(dwf, slot, (Cin, Cout, 8), (1, Cin, Cout * Cin), accumulate=True)
+            else:
+                dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+                ops.permute3(dwf, dw, (Cin, Cout, 8), (1, Cin, Cout * Cin))
         return dx, dskip, dw
 
 
@@ -324,16 +368,19 @@ class _WinAttn(Function):
         out, lse = ops.winattn_fwd(qkv, qkv_bias, table, heads, window, shift, tw, scale)
         ctx.save_for_backward(qkv, out, lse, qkv_bias, table)
         ctx.meta = (heads, window, shift, tw, scale)
+        ctx.params = (qkv_bias, table)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, out, lse, qkv_bias, table = ctx.saved_tensors
         heads, window, shift, tw, scale = ctx.meta
-        dqb = ops.zeros_f32(qkv_bias.shape, qkv.device) if qkv_bias is not None and ctx.needs_input_grad[1] else None
-        dtab = ops.zeros_f32(table.shape, qkv.device) if table is not None and ctx.needs_input_grad[2] else None
+        sq = _slot(ctx.params[0]) if ctx.needs_input_grad[1] else None
+        st = _slot(ctx.params[1]) if ctx.needs_input_grad[2] else None
+        dqb = sq if sq is not None else (ops.zeros_f32(qkv_bias.shape, qkv.device) if qkv_bias is not None and ctx.needs_input_grad[1] else None)
+        dtab = st if st is not None else (ops.zeros_f32(table.shape, qkv.device) if table is not None and ctx.needs_input_grad[2] else None)
         dqkv = ops.winattn_bwd(qkv, out, lse, _rv(dout), qkv_bias, table, heads, window, shift, tw, scale, dqb, dtab)
-        return dqkv, dqb, dtab, None, None, None, None, None
+        return dqkv, None if sq is not None else dqb, None if st is not None else dtab, None, None, None, None, None
 
 
 def window_attention(qkv, qkv_bias, table, heads, window, shift, tw, scale):
@@ -345,15 +392,17 @@ class _PatchEmbed(Function):
     @staticmethod
     def forward(ctx, x_ncdhw, weight, bias, dtype):
         ctx.save_for_backward(x_ncdhw, weight, bias)
+        ctx.params = (weight, bias)
         return ops.patch_embed_fwd(x_ncdhw, weight, bias, dtype)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight, bias = ctx.saved_tensors
-        dw = ops.zeros_f32(weight.shape, x.device)
-        db = ops.zeros_f32(bias.shape, x.device) if bias is not None else None
+        sw, sb = _slot(ctx.params[0]), _slot(ctx.params[1])
+        dw = sw if sw is not None else ops.zeros_f32(weight.shape, x.device)
+        db = sb if sb is not None else (ops.zeros_f32(bias.shape, x.device) if bias is not None else None)
         ops.patch_embed_bwd(x, _rv(dy), dw, db)
-        return None, dw, db, None
+        return None, None if sw is not None else dw, None if sb is not None else db, None
 
 
 def patch_embed(x_ncdhw, weight, bias, dtype):
@@ -367,16 +416,18 @@ class _Head(Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)
         return ops.head_fwd(x, weight, bias)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous().float()
-        dw = ops.zeros_f32(weight.shape, x.device)
-        db = ops.zeros_f32((weight.shape[0],), x.device) if ctx.has_bias else None
+        sw, sb = _slot(ctx.params[0]), _slot(ctx.params[1])
+        dw = sw if sw is not None else ops.zeros_f32(weight.shape, x.device)
+        db = sb if sb is not None else (ops.zeros_f32((weight.shape[0],), x.device) if ctx.has_bias else None)
         dx = ops.head_bwd(x, dy, weight, dw, db, want_dx=ctx.needs_input_grad[0])
-        return dx, dw, db
+        return dx, None if sw is not None else dw, None if sb is not None else db
 
 
 def head(x, weight, bias):

@@ -57,6 +57,7 @@ WinattnBwd = _struct("WinattnBwd", [("f", Winattn), ("dout", vp), ("lddo", i64),
                                     ("dqkv_bias", vp), ("dbias_table", vp)])
 Add = _struct("Add", [("a", vp), ("lda", i64), ("b", vp), ("ldb", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
 Copy2d = _struct("Copy2d", [("src", vp), ("lds", i64), ("sdtype", i32), ("dst", vp), ("ldd", i64), ("ddtype", i32), ("rows", i64), ("C", i32)])
+CastDesc = _struct("CastDesc", [("src", vp), ("dst", vp), ("R", i32), ("C", i32), ("transpose", i32), ("inner", i32), ("outer", i32), ("tile0", i32)])
 Cast = _struct("Cast", [("src", vp), ("dst", vp), ("R", i32), ("C", i32), ("dtype", i32), ("transpose", i32)])
 GeluFwd = _struct("GeluFwd", [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
 GeluBwd = _struct("GeluBwd", [("dy", vp), ("lddy", i64), ("x", vp), ("ldx", i64), ("dx", vp), ("lddx", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
@@ -115,6 +116,7 @@ PROTOS = {
     "miseg_im2col3": (i32, [C.POINTER(Im2col3), vp]),
     "miseg_col2im3": (i32, [C.POINTER(Im2col3), vp]),
     "miseg_fill32": (i32, [vp, C.c_uint32, C.c_size_t, vp]),
+    "miseg_param_cast_batch": (i32, [vp, C.c_int, C.c_int, C.c_int, vp]),
     "miseg_ncdhw_to_rows": (i32, [vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, vp]),
 }
 

@@ -207,12 +207,31 @@ def colsum(x, out=None, accumulate=False):
     return out
 
 
-def cast_matrix(w, dtype, transpose=False):
-    """fp32 [R, C] parameter -> compute dtype, optionally transposed to [C, R]."""
+def cast_matrix(w, dtype, transpose=False, regroup=None):
+    """fp32 [R, C] parameter -> compute dtype, optionally transposed to [C, R].  regroup=(inner, outer) additionally
+    renumbers the C index c -> (c % inner) * outer + c // inner (ConvTranspose3d k2s2 weights: (co, tap) -> (tap, co)).
+    With a training arena (runtime/arena.py) the result is the copy refreshed by the step's batched kernel."""
+    inner, outer = regroup if regroup is not None else (1, 1)
+    if dtype == torch.float32 and not transpose and inner == 1:
+        return _fp32(w).reshape(w.shape[0], -1)
+    arena = getattr(w, "_miseg_arena", None)
+    if arena is not None and arena.dtype == dtype:
+        sh = arena.shadow(w, transpose, inner, outer)
+        if sh is not None:
+            return sh
     w2 = _fp32(w).reshape(w.shape[0], -1)
     R, Cc = w2.shape
-    if dtype == torch.float32 and not transpose:
-        return w2
+    if inner != 1:
+        # one-off path (first step / no arena): regroup in fp32 with the permute kernel, then cast
+        tmp = torch.empty((Cc, R) if transpose else (R, Cc), dtype=torch.float32, device=w.device)
+        if transpose:   # tmp[(j, o)][r] = w2[r][o * inner + j]
+            permute3(w2, tmp, (inner, outer, R), (1, inner, Cc))
+        else:           # tmp[r][(j, o)] = w2[r][o * inner + j]
+            permute3(w2, tmp, (R, inner, outer), (Cc, 1, inner))
+        if dtype == torch.float32:
+            return tmp
+        w2, transpose = tmp, False
+        R, Cc = w2.shape
     out = torch.empty((Cc, R) if transpose else (R, Cc), dtype=dtype, device=w.device)
     _call("miseg_cast_matrix", L.Cast(_ptr(w2), _ptr(out), R, Cc, L.F32 if dtype == torch.float32 else L.BF16, int(transpose)))
     return out

@@ -1,0 +1,124 @@
+"""Per-model training arena: ONE flat fp32 gradient buffer that the weight-gradient kernels accumulate into directly
+(one fill per step instead of one per parameter, and the buffer RCCL all-reduces at N > 1), plus the compute-dtype
+re-layouts of the parameters (bf16 copies, transposes, ConvTranspose regroupings) refreshed by ONE kernel per step.
+
+Without an arena the autograd Functions in hip/functional.py allocate and return each gradient (torch semantics,
+``grad is None`` for parameters that were not used); with one they add into ``p._miseg_grad`` and return None, and
+``publish()`` sets ``p.grad`` to the arena views of the parameters used since the last ``begin_step`` (None otherwise,
+like the reference's find_unused_parameters DDP: tune.py:103-109).  Gradient accumulation over micro-batches:
+``begin_step(zero=False)``.
+"""
+import ctypes as C
+
+import torch
+
+from ..hip import lib as L
+from ..hip import ops
+
+
+class ParamArena:
+    def __init__(self, params, dtype=torch.bfloat16, n_buckets=4):
+        self.params = [p for p in params if p.requires_grad]
+        assert self.params, "no trainable parameters"
+        dev = self.params[0].device
+        offs, off = [], 0
+        for p in self.params:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise ValueError("parameters must be contiguous float32")
+            offs.append(off)
+            off += (p.numel() + 3) & ~3          # 16-byte aligned slots
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.views = [self.flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, self.params)]
+        for p, v in zip(self.params, self.views):
+            p._miseg_grad, p._miseg_arena, p._miseg_used = v, self, False
+        self.dtype = dtype
+        self.epoch = 0
+        self._req = {}          # (id(p), transpose, inner, outer) -> [param, shadow, filled_epoch]
+        self._table = None      # (device descriptor bytes, ndesc, total tiles)
+        self._retired = []      # tables a captured hipGraph may still point at
+        self._dirty = False
+        # all-reduce buckets on slot edges, roughly equal bytes, reduced last-to-first (reverse autograd order)
+        ends = offs[1:] + [off]
+        self.buckets, start, target = [], 0, off / n_buckets
+        for i, e in enumerate(ends):
+            if e - start >= target or i == len(ends) - 1:
+                self.buckets.append((start, e))
+                start = e
+        self.used_dev = torch.zeros(len(self.params), dtype=torch.int32, device=dev)
+
+    # ---------------------------------------------------------------------------------------------- per step
+    def begin_step(self, zero=True):
+        """once per optimisation step, before the forward: recycles the statistics pool, zeroes the gradient arena and
+        refreshes every registered parameter re-layout (safe inside hipGraph capture once the table exists)."""
+        ops.begin_step()
+        self.epoch += 1
+        if zero:
+            ops.fill32(self.flat)
+            for p in self.params:
+                p._miseg_used = False
+        if self._dirty:
+            self._build_table()
+        if self._table is not None:
+            buf, n, tiles = self._table
+            lib = L.load()
+            L.check(lib.miseg_param_cast_batch(buf.data_ptr(), n, tiles, L.F32 if self.dtype == torch.float32 else L.BF16, ops._stream()),
+                    "param_cast_batch")
+            for ent in self._req.values():
+                if ent[3]:
+                    ent[2] = self.epoch
+
+    def shadow(self, p, transpose, inner, outer):
+        """the re-layout of parameter p refreshed this step, or None (first request: registered for the next step)."""
+        key = (id(p), bool(transpose), inner, outer)
+        ent = self._req.get(key)
+        if ent is None:
+            R = p.shape[0]
+            Cc = p.numel() // R
+            dst = torch.empty((Cc, R) if transpose else (R, Cc), dtype=self.dtype, device=p.device)
+            self._req[key] = [p, dst, -1, False]     # param, shadow, epoch of last refresh, in table
+            self._dirty = True
+            return None
+        return ent[1] if ent[2] == self.epoch else None
+
+    def _build_table(self):
+        if torch.cuda.is_current_stream_capturing():
+            return                                   # host->device copy: wait for an eager step
+        descs = (L.CastDesc * len(self._req))()
+        tile0 = 0
+        for i, (key, ent) in enumerate(self._req.items()):
+            p, dst = ent[0], ent[1]
+            R = p.shape[0]
+            Cc = p.numel() // R
+            descs[i] = L.CastDesc(p.data_ptr(), dst.data_ptr(), R, Cc, int(key[1]), key[2], key[3], tile0)
+            tile0 += ((R + 31) // 32) * ((Cc + 31) // 32)
+            ent[3] = True
+        if self._table is not None:
+            self._retired.append(self._table[0])
+        raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.flat.device)
+        self._table = (raw, len(self._req), tile0)
+        self._dirty = False
+
+    # ---------------------------------------------------------------------------------------------- after backward
+    def publish(self):
+        for p, v in zip(self.params, self.views):
+            p.grad = v if p._miseg_used else None
+
+    def allreduce(self, world_size, group=None):
+        """mean all-reduce of the arena over RCCL in n_buckets pieces; parameters unused on EVERY rank keep grad None."""
+        import torch.distributed as dist
+        self.used_dev.copy_(torch.tensor([int(p._miseg_used) for p in self.params], dtype=torch.int32), non_blocking=True)
+        works = [dist.all_reduce(self.used_dev, op=dist.ReduceOp.MAX, group=group, async_op=True)]
+        for lo, hi in reversed(self.buckets):
+            works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True))
+        for w in works:
+            w.wait()
+        self.flat.mul_(1.0 / world_size)
+        for p, u in zip(self.params, self.used_dev.tolist()):
+            p._miseg_used = bool(u)
+        self.publish()
+
+    def detach(self):
+        for p in self.params:
+            for a in ("_miseg_grad", "_miseg_arena", "_miseg_used"):
+                if hasattr(p, a):
+                    delattr(p, a)

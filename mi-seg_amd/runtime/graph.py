@@ -14,8 +14,11 @@ from ..hip import ops
 
 
 class GraphedStep:
-    def __init__(self, model: torch.nn.Module, batch_shape: Sequence[int], out_shape: Sequence[int], warmup: int = 2):
+    def __init__(self, model: torch.nn.Module, batch_shape: Sequence[int], out_shape: Sequence[int], warmup: int = 2, arena=None):
+        """arena: optional runtime.arena.ParamArena of the model (gradients accumulate in its flat buffer, parameter
+        re-layouts are refreshed by one kernel per step); without it every gradient is a tensor of the graph's pool."""
         self.model = model
+        self.arena = arena
         self.params = [p for p in model.parameters() if p.requires_grad]
         dev = self.params[0].device
         self.x = torch.zeros(*batch_shape, dtype=torch.float32, device=dev)
@@ -25,9 +28,12 @@ class GraphedStep:
         self.graphs: Dict[Tuple[int, ...], Tuple[torch.cuda.CUDAGraph, List, torch.Tensor]] = {}
 
     def _run(self, host):
-        for p in self.params:
-            p.grad = None
-        ops.begin_step()
+        if self.arena is not None:
+            self.arena.begin_step()
+        else:
+            for p in self.params:
+                p.grad = None
+            ops.begin_step()
         y = self.model(self.x, (self.styles, host))
         y.backward(self.cot)
         return y
@@ -36,7 +42,7 @@ class GraphedStep:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            for _ in range(self.warmup):
+            for _ in range(max(self.warmup, 2 if self.arena is not None else 0)):   # arena: step 1 registers the re-layouts
                 self._run(host)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
@@ -45,7 +51,10 @@ class GraphedStep:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             y = self._run(host)
-        grads = [p.grad for p in self.params]
+        if self.arena is not None:
+            grads = [bool(p._miseg_used) for p in self.arena.params]       # which slots this graph writes
+        else:
+            grads = [p.grad for p in self.params]
         return g, grads, y
 
     def __call__(self, x, modalities: Sequence[int], cot):
@@ -59,6 +68,11 @@ class GraphedStep:
             self.graphs[key] = self._capture(host)
         g, grads, y = self.graphs[key]
         g.replay()
-        for p, gr in zip(self.params, grads):
-            p.grad = gr
+        if self.arena is not None:
+            for p, used in zip(self.arena.params, grads):
+                p._miseg_used = used
+            self.arena.publish()
+        else:
+            for p, gr in zip(self.params, grads):
+                p.grad = gr
         return y
