@@ -115,8 +115,9 @@ int miseg_layernorm_bwd(const miseg_layernorm_bwd_params* p, miseg_stream_t stre
  *   ta == 0: A is [M][K] (lda)   ta == 1: A is stored [K][M] (lda)   -- likewise tb for B: 0 => [N][K], 1 => [K][N]
  *   only (ta,tb) = (0,0) "NT" and (1,1) "TN" are implemented (weights are re-packed once per step).
  *   out_dtype: dtype of C (MISEG_F32 for weight gradients).  accumulate != 0: C += result (fp32 C only).
- *   split_k > 1 partitions K over workgroups and reduces with fp32 atomics into a zero-filled or
- *   accumulate-mode C (fp32 C only).
+ *   split_k = 0 lets the library choose kernel and split (TN: tall token streams are reduced through per-workgroup
+ *   partial sums in `workspace` and a second kernel, no atomics); split_k > 1 partitions K over workgroups and reduces with
+ *   fp32 atomics into a zero-filled or accumulate-mode C (fp32 C only).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
   const void* A; int64_t lda; const void* B; int64_t ldb; void* C; int64_t ldc;
@@ -125,7 +126,9 @@ typedef struct {
   int dtype, out_dtype;
   const float* bias; int act;
   int accumulate, split_k;
+  void* workspace;   /* miseg_gemm_workspace_bytes(p) bytes of scratch (uninitialised) or NULL when that is 0 */
 } miseg_gemm_params;
+size_t miseg_gemm_workspace_bytes(const miseg_gemm_params* p);
 int miseg_gemm(const miseg_gemm_params* p, miseg_stream_t stream);
 
 /* fp32 re-layout: dst[i0][i1][i2] (+)= src[i0*s0 + i1*s1 + i2*s2]  (weight-gradient unpacking) */

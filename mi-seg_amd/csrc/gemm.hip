@@ -141,6 +141,96 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const T* __restrict__ A, i
       store_out4<TO>(C, ldc, m0 + wave * 32 + mt * 16 + fi, n0 + nt * 16 + fq * 4, M, N, acc[mt][nt], b_eff, act, mode);
 }
 
+// ------------------------------------------------------------------------------------------------ NT, streaming
+// Tall activations x small weight (the Swin linears of the high-resolution stages, 1x1x1 convs, the ConvTranspose GEMM):
+// M ~ 1e5..1e6 rows, K <= 192, N <= ~400.  HBM-bound: every byte of A is read ONCE (all N columns are produced by the
+// wave that loaded the rows), the whole weight sits in LDS for the lifetime of a persistent workgroup, a wave streams
+// 32-row tiles with the next tile's operands already in flight.  A fragments go global -> registers directly (a lane's
+// MFMA operand is 16 contiguous bytes of its row), so the only LDS traffic is the weight fragments.
+typedef __attribute__((ext_vector_type(4))) short s16x4_g;
+
+template <int K16, bool GELU>
+__global__ void __launch_bounds__(256, 2) gemm_nt_stream_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ W, int64_t ldw,
+                                                                bf16* __restrict__ C, int64_t ldc, int M, int N, const float* __restrict__ bias) {
+  constexpr int K = K16 * 16, KS32 = K / 32, TAIL = K16 & 1;
+  constexpr int ROWB = K * 2 + 16;   // weight row stride in LDS: conflict-free 16-byte fragment reads
+  constexpr int NCH = 12;            // n-tiles per accumulator chunk
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float* lbias = reinterpret_cast<float*>(lds + (size_t)N * ROWB);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, kg = lane >> 4;
+  for (int c = tid; c < N * (K / 8); c += 256) {
+    const int row = c / (K / 8), ch = c - row * (K / 8);
+    *reinterpret_cast<bf16x8*>(lds + row * ROWB + ch * 16) = *reinterpret_cast<const bf16x8*>(W + (int64_t)row * ldw + ch * 8);
+  }
+  for (int n = tid; n < N; n += 256) lbias[n] = bias ? bias[n] : 0.f;
+  __syncthreads();
+  const int ntiles = N / 16, mtiles = (M + 31) / 32, nwaves = gridDim.x * 4;
+  bf16x8 cur[2][KS32 > 0 ? KS32 : 1], nxt[2][KS32 > 0 ? KS32 : 1];
+  bf16x4 curt[2], nxtt[2];
+  auto loadA = [&](int tile, bf16x8 (&f)[2][KS32 > 0 ? KS32 : 1], bf16x4 (&t)[2]) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int row = min(tile * 32 + mt * 16 + fi, M - 1);
+      const bf16* p = A + (int64_t)row * lda;
+#pragma unroll
+      for (int ks = 0; ks < KS32; ++ks) f[mt][ks] = *reinterpret_cast<const bf16x8*>(p + ks * 32 + 8 * kg);
+      if (TAIL) t[mt] = *reinterpret_cast<const bf16x4*>(p + KS32 * 32 + 4 * kg);
+    }
+  };
+  int tile = blockIdx.x * 4 + wave;
+  if (tile < mtiles) loadA(tile, cur, curt);
+  for (; tile < mtiles; tile += nwaves) {
+    if (tile + nwaves < mtiles) loadA(tile + nwaves, nxt, nxtt);
+    for (int nc = 0; nc < ntiles; nc += NCH) {
+      const int ncnt = min(NCH, ntiles - nc);
+      f32x4 acc[2][NCH];
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) acc[0][j] = acc[1][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        if (j < ncnt) {
+          const char* wrow = lds + ((nc + j) * 16 + fi) * ROWB;
+#pragma unroll
+          for (int ks = 0; ks < KS32; ++ks) {
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + ks * 64 + kg * 16);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, cur[0][ks], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, cur[1][ks], acc[1][j], 0, 0, 0);
+          }
+          if (TAIL) {
+            const s16x4_g wt = *reinterpret_cast<const s16x4_g*>(wrow + KS32 * 64 + kg * 8);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wt, __builtin_bit_cast(s16x4_g, curt[0]), acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wt, __builtin_bit_cast(s16x4_g, curt[1]), acc[1][j], 0, 0, 0);
+          }
+        }
+      }
+      // lane (fi = row, kg): columns (nc + j) * 16 + 4kg .. +3
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int row = tile * 32 + mt * 16 + fi;
+        if (row < M) {
+          bf16* crow = C + (int64_t)row * ldc;
+#pragma unroll
+          for (int j = 0; j < NCH; ++j) {
+            if (j < ncnt) {
+              const int n = (nc + j) * 16 + 4 * kg;
+              const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbias + n);
+              f32x4 v = acc[mt][j] + b4;
+              if (GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+              *reinterpret_cast<bf16x4*>(crow + n) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int ks = 0; ks < KS32; ++ks) cur[mt][ks] = nxt[mt][ks];
+      curt[mt] = nxtt[mt];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ TN
 // A stored [K][M] (lda), B stored [K][N] (ldb).  Tile 64 x 64, 4 waves as 2(M) x 2(N), each 32 x 32.
 template <class T> struct TnFrag;
@@ -247,6 +337,146 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const T* __restrict__ A, i
       store_out4<TO>(C, ldc, m0 + wm * 32 + mt * 16 + fi, n0 + wn * 32 + nt * 16 + fq * 4, M, N, acc[mt][nt], nullptr, MISEG_ACT_NONE, mode);
 }
 
+// ------------------------------------------------------------------------------------------------ TN, streaming
+// Weight gradients of the tall layers: C[M][N] (+)= sum over ~1e5..1e6 tokens of A[t][m] B[t][n] with M, N multiples of 48.
+// HBM-bound on the two token streams.  A workgroup owns a (wm x wn) arrangement of 48x48 wave tiles and a contiguous
+// token range; 64-token stages are double-buffered in LDS (one barrier per stage, the next stage's 16-byte chunks in
+// registers while the current one feeds the MFMAs through transposed LDS reads), few token splits so that the fp32
+// atomics of the epilogue stay a small fraction of the stream.
+__global__ void __launch_bounds__(256, 2) gemm_tn_stream_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B, int64_t ldb,
+                                                                float* __restrict__ C, int64_t ldc, int M, int N, int T, int wm, int wn, int tps, int mode,
+                                                                float* __restrict__ partial) {
+  constexpr int BK = 64, MAXC = 8;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int BM = wm * 48, BN = wn * 48, RA = BM * 2 + 16, RB = BN * 2 + 16;
+  const int stage_bytes = BK * (RA + RB);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int t0 = blockIdx.z * tps, t1 = min(T, t0 + tps);
+  const int wmi = wave % wm, wni = wave / wm;
+  const bool active = (m0 + wmi * 48 < M) && (n0 + wni * 48 < N);
+  // per-thread copy slots (fixed across stages)
+  const int cpa = BM / 8, cpr = (BM + BN) / 8, total = BK * cpr;
+  int64_t goff[MAXC];      // element offset from the stage's first token row; -1: always zero
+  int loff[MAXC], lrow[MAXC];
+  bool isb[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = tid + i * 256;
+    goff[i] = -1; loff[i] = -1; lrow[i] = 0; isb[i] = false;
+    if (c < total) {
+      const int row = c / cpr, ch = c - row * cpr;
+      lrow[i] = row;
+      if (ch < cpa) {
+        const int col = m0 + ch * 8;
+        loff[i] = row * RA + ch * 16;
+        if (col < M) goff[i] = (int64_t)row * lda + col;
+      } else {
+        const int col = n0 + (ch - cpa) * 8;
+        isb[i] = true;
+        loff[i] = BK * RA + row * RB + (ch - cpa) * 16;
+        if (col < N) goff[i] = (int64_t)row * ldb + col;
+      }
+    }
+  }
+  bf16x8 r[MAXC];
+  auto gload = [&](int tk) {
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+      if (goff[i] >= 0 && tk + lrow[i] < t1) v = *reinterpret_cast<const bf16x8*>((isb[i] ? B + (int64_t)tk * ldb : A + (int64_t)tk * lda) + goff[i]);
+      r[i] = v;
+    }
+  };
+  auto lstore = [&](char* b) {
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+      if (loff[i] >= 0) *reinterpret_cast<bf16x8*>(b + loff[i]) = r[i];
+  };
+  f32x4 acc[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  gload(t0);
+  lstore(lds);
+  __syncthreads();
+  int s = 0;
+  for (int tk = t0; tk < t1; tk += BK, s ^= 1) {
+    const bool more = tk + BK < t1;
+    if (more) gload(tk + BK);
+    if (active) {
+      const char* bA = lds + s * stage_bytes;
+      const char* bB = bA + BK * RA;
+#pragma unroll
+      for (int ks = 0; ks < BK / 32; ++ks) {
+        bf16x8 af[3], bfr[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          af[t] = TnFrag<bf16>::load(bA + ks * 32 * RA, RA, wmi * 48 + t * 16, lane);
+          bfr[t] = TnFrag<bf16>::load(bB + ks * 32 * RB, RB, wni * 48 + t * 16, lane);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 3; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[mt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+    if (more) lstore(lds + (s ^ 1) * stage_bytes);   // last read one iteration ago: every wave is past that barrier
+    __syncthreads();
+  }
+  if (active) {
+    const int fi = lane & 15, fq = lane >> 4;
+    if (partial) {   // partial[split][M][N]: 16-byte stores, summed by gemm_tn_partial_reduce_kernel
+      float* pp = partial + (int64_t)blockIdx.z * M * N;
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+          *reinterpret_cast<f32x4*>(pp + (int64_t)(m0 + wmi * 48 + mt * 16 + fi) * N + n0 + wni * 48 + nt * 16 + fq * 4) = acc[mt][nt];
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+          store_out4<float>(C, ldc, m0 + wmi * 48 + mt * 16 + fi, n0 + wni * 48 + nt * 16 + fq * 4, M, N, acc[mt][nt], nullptr, MISEG_ACT_NONE, mode);
+    }
+  }
+}
+
+// C[m][n] (+)= sum over splits of partial[s][m][n]; one thread per 4 consecutive n and per group of TN_RG splits
+// (blockIdx.y); with more than one group the groups meet in fp32 atomics on a zero-filled / accumulate-mode C.
+static constexpr int TN_RG = 16;
+__global__ void __launch_bounds__(256) gemm_tn_partial_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C, int64_t ldc, int M, int N, int splits,
+                                                                     int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;   // over M * N / 4
+  if (i >= M * (N / 4)) return;
+  const int m = i / (N / 4), n = (i - m * (N / 4)) * 4;
+  const int s0 = blockIdx.y * TN_RG, s1 = min(splits, s0 + TN_RG);
+  const float* p = partial + (int64_t)m * N + n;
+  const int64_t stride = (int64_t)M * N;
+  f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  int s = s0;
+  for (; s + 3 < s1; s += 4) {
+    a0 += *reinterpret_cast<const f32x4*>(p + (s + 0) * stride);
+    a1 += *reinterpret_cast<const f32x4*>(p + (s + 1) * stride);
+    a2 += *reinterpret_cast<const f32x4*>(p + (s + 2) * stride);
+    a3 += *reinterpret_cast<const f32x4*>(p + (s + 3) * stride);
+  }
+  for (; s < s1; ++s) a0 += *reinterpret_cast<const f32x4*>(p + s * stride);
+  const f32x4 v = (a0 + a1) + (a2 + a3);
+  float* c = C + (int64_t)m * ldc + n;
+  if (gridDim.y > 1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(c + r, v[r]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = accumulate ? c[r] + v[r] : v[r];
+  }
+}
+
 // dst[i0][i1][i2] (+)= src[i0*s0 + i1*s1 + i2*s2]   (fp32; weight-gradient re-layout)
 __global__ void __launch_bounds__(256) permute3_kernel(const float* __restrict__ src, float* __restrict__ dst, int n0, int n1, int n2, int64_t s0, int64_t s1,
                                                        int64_t s2, int accumulate) {
@@ -263,6 +493,31 @@ __global__ void __launch_bounds__(256) permute3_kernel(const float* __restrict__
 }  // namespace miseg
 
 using namespace miseg;
+
+struct TnStreamPlan { int wm, wn, gx, gy, splits, tps; };
+
+// streaming TN path: bf16 operands, fp32 C, channel counts in multiples of 48, >= 2048 tokens, library-chosen split
+static bool tn_stream_plan(const miseg_gemm_params* p, TnStreamPlan* pl) {
+  if (!(p->ta == 1 && p->tb == 1 && p->dtype == MISEG_BF16 && p->out_dtype == MISEG_F32 && p->split_k == 0)) return false;
+  if (!(p->M % 48 == 0 && p->N % 48 == 0 && p->K >= 2048)) return false;
+  if (((uintptr_t)p->A % 16) || ((uintptr_t)p->B % 16) || (p->lda % 8) || (p->ldb % 8)) return false;
+  if (p->N <= 48) { pl->wm = 4; pl->wn = 1; } else if (p->M <= 48) { pl->wm = 1; pl->wn = 4; } else { pl->wm = 2; pl->wn = 2; }
+  pl->gx = cdiv(p->M, pl->wm * 48);
+  pl->gy = cdiv(p->N, pl->wn * 48);
+  int splits = cdiv(512, pl->gx * pl->gy);
+  const int max_splits = cdiv(p->K, 4 * 64);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  pl->tps = cdiv(cdiv(p->K, splits), 64) * 64;
+  pl->splits = cdiv(p->K, pl->tps);
+  return true;
+}
+
+extern "C" size_t miseg_gemm_workspace_bytes(const miseg_gemm_params* p) {
+  TnStreamPlan pl;
+  if (!p || !tn_stream_plan(p, &pl) || pl.splits <= 1) return 0;
+  return (size_t)pl.splits * p->M * p->N * sizeof(float);
+}
 
 template <class T, class TO>
 static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
@@ -284,6 +539,29 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
       else if (hipMemset2DAsync(p->C, p->ldc * sizeof(float), 0, (size_t)p->N * sizeof(float), p->M, s) != hipSuccess) return set_error(MISEG_E_LAUNCH, "gemm: memset2d");
     }
     if (split > 1 && p->act != MISEG_ACT_NONE) return set_error(MISEG_E_BADARG, "gemm: activation with split_k");
+    if (split > 1 && p->act != MISEG_ACT_NONE) return set_error(MISEG_E_BADARG, "gemm: activation with split_k");
+    if constexpr (std::is_same<T, bf16>::value && std::is_same<TO, bf16>::value) {
+      // tall-skinny streaming path (see gemm_nt_stream_kernel)
+      const size_t lds = (size_t)p->N * (p->K * 2 + 16) + (size_t)p->N * 4;
+      const bool st_ok = split == 1 && !p->accumulate && (p->K == 48 || p->K == 96 || p->K == 192) && p->N % 16 == 0 && p->M >= 4096 && lds <= 96 * 1024 &&
+                         al_a && al_b && ((uintptr_t)p->C % 8 == 0) && p->ldc % 4 == 0;
+      if (st_ok) {
+        const int mtiles = cdiv(p->M, 32);
+        int blocks = cdiv(mtiles, 4);
+        const int cap = lds > 80 * 1024 ? 256 : 512;
+        if (blocks > cap) blocks = cap;
+#define ST_CASE(k16, g)                                                                                                                       \
+  hipFuncSetAttribute((const void*)gemm_nt_stream_kernel<k16, g>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
+  gemm_nt_stream_kernel<k16, g><<<blocks, 256, lds, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, p->bias)
+        const bool ge = p->act == MISEG_ACT_GELU;
+        if (p->K == 48) { if (ge) { ST_CASE(3, true); } else { ST_CASE(3, false); } }
+        else if (p->K == 96) { if (ge) { ST_CASE(6, true); } else { ST_CASE(6, false); } }
+        else { if (ge) { ST_CASE(12, true); } else { ST_CASE(12, false); } }
+#undef ST_CASE
+        MISEG_LAUNCH_CHECK("gemm_nt_stream");
+        return MISEG_OK;
+      }
+    }
     const int nt = (p->N % 64 == 0) ? 4 : (p->N % 48 == 0) ? 3 : (p->N <= 16) ? 1 : (p->N <= 32) ? 2 : (p->N <= 48) ? 3 : 4;
     dim3 grid(cdiv(p->M, 128), cdiv(p->N, 16 * nt), split);
 #define NT_CASE(n)                                                                                                                          \
@@ -295,7 +573,39 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
 #undef NT_CASE
   } else if (p->ta == 1 && p->tb == 1) {
     if (p->bias || p->act != MISEG_ACT_NONE) return set_error(MISEG_E_UNSUPPORTED, "gemm TN: no bias/act epilogue");
+    if constexpr (std::is_same<T, bf16>::value && std::is_same<TO, float>::value) {
+      // streaming path for tall token streams (see gemm_tn_stream_kernel); K is the token count here
+      TnStreamPlan pl;
+      if (tn_stream_plan(p, &pl)) {
+        float* partial = nullptr;
+        if (pl.splits > 1) {
+          MISEG_REQUIRE(p->workspace, MISEG_E_BADARG, "gemm: workspace required (miseg_gemm_workspace_bytes)");
+          partial = (float*)p->workspace;
+        }
+        const int BM = pl.wm * 48, BN = pl.wn * 48;
+        const size_t lds = (size_t)2 * 64 * (BM * 2 + BN * 2 + 32);
+        hipFuncSetAttribute((const void*)gemm_tn_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        gemm_tn_stream_kernel<<<dim3(pl.gx, pl.gy, pl.splits), 256, lds, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (float*)p->C, p->ldc, p->M, p->N,
+                                                                             p->K, pl.wm, pl.wn, pl.tps, p->accumulate ? 1 : 0, partial);
+        if (partial) {
+          const int groups = cdiv(pl.splits, TN_RG);
+          if (groups > 1 && !p->accumulate) {   // the groups meet in atomics
+            if (p->ldc == p->N) { if (hipMemsetAsync(p->C, 0, (size_t)p->M * p->N * sizeof(float), s) != hipSuccess) return set_error(MISEG_E_LAUNCH, "gemm: memset"); }
+            else if (hipMemset2DAsync(p->C, p->ldc * sizeof(float), 0, (size_t)p->N * sizeof(float), p->M, s) != hipSuccess) return set_error(MISEG_E_LAUNCH, "gemm: memset2d");
+          }
+          gemm_tn_partial_reduce_kernel<<<dim3(cdiv(p->M * (p->N / 4), 256), groups), 256, 0, s>>>(partial, (float*)p->C, p->ldc, p->M, p->N, pl.splits, p->accumulate);
+        }
+        MISEG_LAUNCH_CHECK("gemm_tn_stream");
+        return MISEG_OK;
+      }
+    }
     constexpr int TN_BK = std::is_same<T, bf16>::value ? 128 : 64;
+    if (p->split_k == 0) {   // auto: enough workgroups for the chip, >= 512 reduction rows each
+      const int tiles = cdiv(p->M, 64) * cdiv(p->N, 64);
+      split = cdiv(p->K, 512);
+      if (split > 1024 / tiles) split = 1024 / tiles;
+      if (split < 1) split = 1;
+    }
     int kps = cdiv(cdiv(p->K, split), TN_BK) * TN_BK;
     split = cdiv(p->K, kps);
     mode = split > 1 ? 2 : (p->accumulate ? 1 : 0);

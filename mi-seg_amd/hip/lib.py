@@ -41,7 +41,7 @@ LayernormBwd = _struct("LayernormBwd", [("dy", vp), ("lddy", i64), ("x", vp), ("
                                         ("dgamma", vp), ("dbeta", vp)])
 Gemm = _struct("Gemm", [("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32),
                         ("K", i32), ("ta", i32), ("tb", i32), ("dtype", i32), ("out_dtype", i32), ("bias", vp), ("act", i32),
-                        ("accumulate", i32), ("split_k", i32)])
+                        ("accumulate", i32), ("split_k", i32), ("workspace", vp)])
 Colsum = _struct("Colsum", [("x", vp), ("ldx", i64), ("rows", i64), ("C", i32), ("dtype", i32), ("out", vp), ("accumulate", i32)])
 Conv3 = _struct("Conv3", [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("wpk", vp), ("B", i32), ("D", i32), ("H", i32),
                           ("W", i32), ("Cin", i32), ("Cout", i32), ("dtype", i32), ("workspace", vp)])
@@ -89,6 +89,7 @@ PROTOS = {
     "miseg_instnorm_bwd": (i32, [C.POINTER(InstnormBwd), vp]),
     "miseg_layernorm_fwd": (i32, [C.POINTER(LayernormFwd), vp]),
     "miseg_layernorm_bwd": (i32, [C.POINTER(LayernormBwd), vp]),
+    "miseg_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(Gemm)]),
     "miseg_gemm": (i32, [C.POINTER(Gemm), vp]),
     "miseg_permute3": (i32, [vp, vp, i32, i32, i32, i64, i64, i64, i32, vp]),
     "miseg_colsum": (i32, [C.POINTER(Colsum), vp]),

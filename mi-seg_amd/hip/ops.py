@@ -170,7 +170,7 @@ def gemm_nt(a, w, bias=None, act=L.ACT_NONE, out=None, out_dtype=None, split_k=1
         out = torch.empty(a.shape[:-1] + (N,), dtype=odt, device=a.device)
     ldc, Mo, No = rows(out)
     assert Mo == M and No == N
-    p = L.Gemm(_ptr(a), lda, _ptr(w), K, _ptr(out), ldc, M, N, K, 0, 0, _dt(a), _dt(out), _ptr(_fp32(bias)), act, 0, split_k)
+    p = L.Gemm(_ptr(a), lda, _ptr(w), K, _ptr(out), ldc, M, N, K, 0, 0, _dt(a), _dt(out), _ptr(_fp32(bias)), act, 0, split_k, None)
     _call("miseg_gemm", p)
     return out
 
@@ -184,10 +184,12 @@ def gemm_tn(a, b, out=None, accumulate=False, split_k=0):
         out = torch.empty(M, N, dtype=torch.float32, device=a.device)
         accumulate = False
     assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == M * N
-    if split_k <= 0:
-        tiles = ((M + 63) // 64) * ((N + 63) // 64)
-        split_k = max(1, min((K + 511) // 512, 1024 // max(1, tiles)))
-    p = L.Gemm(_ptr(a), lda, _ptr(b), ldb, _ptr(out), N, M, N, K, 1, 1, _dt(a), L.F32, None, L.ACT_NONE, int(accumulate), split_k)
+    split_k = max(0, split_k)          # 0: the library picks the kernel and the split over the reduction rows
+    p = L.Gemm(_ptr(a), lda, _ptr(b), ldb, _ptr(out), N, M, N, K, 1, 1, _dt(a), L.F32, None, L.ACT_NONE, int(accumulate), split_k, None)
+    wsb = L.load().miseg_gemm_workspace_bytes(C.byref(p))
+    if wsb:
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=a.device)
+        p.workspace = ws.data_ptr()
     _call("miseg_gemm", p)
     return out
 

@@ -112,6 +112,21 @@ def test_gemm_nt(dtype, M, N, K):
     assert rel_err(y2, F.gelu(yr)) < TOL[dtype]
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 48, 48), (5003, 144, 48), (4100, 192, 48), (4097, 48, 192), (6000, 384, 96), (4099, 96, 96), (4300, 16, 96)])
+def test_gemm_nt_streaming_path(M, N, K):
+    """tall-skinny bf16 GEMMs take the weight-resident streaming kernel (M >= 4096, K in 48/96/192): ragged M, the K=48
+    half k-step, N beyond one accumulator chunk, bias + GELU epilogue; exact on small integers."""
+    ops, L = _ops(), _L()
+    dtype = torch.bfloat16
+    a, w, bias = rnd(M, K, dtype=dtype, seed=21), rnd(N, K, dtype=dtype, seed=22) / K ** 0.5, rnd(N, seed=23)
+    yr = a.float() @ w.float().t() + bias
+    assert rel_err(ops.gemm_nt(a, w, bias), yr) < TOL[dtype]
+    assert rel_err(ops.gemm_nt(a, w, bias, act=L.ACT_GELU), F.gelu(yr)) < TOL[dtype]
+    ai = (torch.arange(M * K, device=DEV).reshape(M, K) % 7 - 3).to(dtype)
+    wi = (torch.arange(N * K, device=DEV).reshape(N, K) % 5 - 2).to(dtype)
+    assert torch.equal(ops.gemm_nt(ai, wi).float(), (ai.float() @ wi.float().t()).to(dtype).float())
+
+
 def test_gemm_nt_exact_integers():
     """asymmetric small-integer operands: catches transposed / permuted MFMA fragment maps exactly."""
     ops = _ops()
