@@ -485,6 +485,221 @@ __global__ void __launch_bounds__(256) head_bwd_dw_kernel(const T* __restrict__ 
   }
 }
 
+// ----------------------------------------------------------------------------- head / patch-embed, row-team kernels
+// Vector variants of the four kernels above for channel counts that are multiples of the 16-byte vector: a voxel row is
+// read by Cin/VEC lanes with one 16-byte load each (coalesced), weights come from LDS as float4, and the reductions over
+// voxels keep [R][VEC] register accumulators per lane that meet in LDS once per workgroup.
+
+// sum over ty of acc[R][VEC] -> atomicAdd(out[r * ostride + (tx * VEC + i)]); red: [ty_n][R * tx_n * VEC] floats
+template <int R, int VEC>
+__device__ __forceinline__ void team_reduce_atomic(float* red, const float (&acc)[R][VEC], int tx, int ty, int tx_n, int ty_n, float* out, int ostride, int nrows,
+                                                   int ncols) {
+  const int width = R * tx_n * VEC;
+  __syncthreads();
+  if (ty < ty_n) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) red[ty * width + (r * tx_n + tx) * VEC + i] = acc[r][i];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < width; e += blockDim.x) {
+    float a = 0.f;
+    for (int y = 0; y < ty_n; ++y) a += red[y * width + e];
+    const int r = e / (tx_n * VEC), col = e - r * (tx_n * VEC);
+    if (r < nrows && col < ncols) atomicAdd(out + r * ostride + col, a);
+  }
+}
+
+// y[b][co][s] = sum_ci x[v][ci] w[co][ci] + bias[co]: 256-voxel tiles staged in LDS (padded rows), one lane per voxel
+template <class T, int VEC>
+__global__ void __launch_bounds__(256) head_fwd_tile_kernel(const T* __restrict__ x, int64_t ldx, float* __restrict__ y, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, int B, int S, int Cin, int Cout) {
+  typedef typename Vec16<T>::type VT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int cv = Cin / VEC, rowb = Cin * (int)sizeof(T) + 16;
+  float* ws = reinterpret_cast<float*>(smem);          // [Cout][Cin] + bias[Cout]
+  char* xt = smem + ((Cout * Cin + Cout + 3) & ~3) * 4; // [256][rowb]
+  for (int i = threadIdx.x; i < Cout * Cin; i += 256) ws[i] = w[i];
+  for (int i = threadIdx.x; i < Cout; i += 256) ws[Cout * Cin + i] = bias ? bias[i] : 0.f;
+  const int64_t nv = (int64_t)B * S;
+  for (int64_t v0 = (int64_t)blockIdx.x * 256; v0 < nv; v0 += (int64_t)gridDim.x * 256) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256 * cv; i += 256) {
+      const int r = i / cv, c = i - r * cv;
+      if (v0 + r < nv) *reinterpret_cast<VT*>(xt + r * rowb + c * 16) = *reinterpret_cast<const VT*>(x + (v0 + r) * ldx + c * VEC);
+    }
+    __syncthreads();
+    const int64_t v = v0 + threadIdx.x;
+    if (v < nv) {
+      float acc[16];
+#pragma unroll
+      for (int co = 0; co < 16; ++co) acc[co] = co < Cout ? ws[Cout * Cin + co] : 0.f;
+      for (int c = 0; c < cv; ++c) {
+        const VT xv = *reinterpret_cast<const VT*>(xt + threadIdx.x * rowb + c * 16);
+        float xf[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) xf[k] = to_f32(xv[k]);
+#pragma unroll
+        for (int co = 0; co < 16; ++co) {
+          if (co < Cout) {
+#pragma unroll
+            for (int k4 = 0; k4 < VEC / 4; ++k4) {
+              const f32x4 w4 = *reinterpret_cast<const f32x4*>(ws + co * Cin + c * VEC + 4 * k4);
+              acc[co] = fmaf(xf[4 * k4 + 0], w4[0], acc[co]); acc[co] = fmaf(xf[4 * k4 + 1], w4[1], acc[co]);
+              acc[co] = fmaf(xf[4 * k4 + 2], w4[2], acc[co]); acc[co] = fmaf(xf[4 * k4 + 3], w4[3], acc[co]);
+            }
+          }
+        }
+      }
+      const int b = (int)(v / S);
+      const int64_t sidx = v - (int64_t)b * S;
+#pragma unroll
+      for (int co = 0; co < 16; ++co)
+        if (co < Cout) y[((int64_t)b * Cout + co) * S + sidx] = acc[co];
+    }
+  }
+}
+
+// dx[v][ci] = sum_co dy[b][co][s] w[co][ci]: one lane per (voxel, 16-byte channel vector)
+template <class T, int VEC>
+__global__ void __launch_bounds__(256) head_bwd_dx_team_kernel(const float* __restrict__ dy, T* __restrict__ dx, int64_t lddx, const float* __restrict__ w, int B, int S,
+                                                               int Cin, int Cout) {
+  extern __shared__ __attribute__((aligned(16))) float ws[];  // [Cout][Cin]
+  for (int i = threadIdx.x; i < Cout * Cin; i += 256) ws[i] = w[i];
+  __syncthreads();
+  const int cv = Cin / VEC;
+  const int64_t total = (int64_t)B * S * cv;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t v = i / cv;
+    const int c = (int)(i - v * cv);
+    const int b = (int)(v / S);
+    const int64_t sidx = v - (int64_t)b * S;
+    V<T, VEC> o;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) o.v[k] = 0.f;
+#pragma unroll
+    for (int co = 0; co < 16; ++co) {
+      if (co < Cout) {
+        const float g = dy[((int64_t)b * Cout + co) * S + sidx];
+#pragma unroll
+        for (int k4 = 0; k4 < VEC / 4; ++k4) {
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(ws + co * Cin + c * VEC + 4 * k4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o.v[4 * k4 + e] = fmaf(g, w4[e], o.v[4 * k4 + e]);
+        }
+      }
+    }
+    o.store(dx + v * lddx + c * VEC);
+  }
+}
+
+// dw[co][ci] += sum_v dy[b][co][s] x[v][ci], dbias[co] += sum_v dy: lane = (row ty, channel vector tx), CO <= 8 per pass
+template <class T, int VEC>
+__global__ void __launch_bounds__(256) head_bwd_dw_team_kernel(const T* __restrict__ x, int64_t ldx, const float* __restrict__ dy, float* __restrict__ dw,
+                                                               float* __restrict__ dbias, int B, int S, int Cin, int Cout, int co0, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int tx_n = Cin / VEC, ty_n = 256 / tx_n;
+  const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
+  const int64_t nv = (int64_t)B * S;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(nv, r0 + rows_per_block);
+  float acc[8][VEC], bsum[8];
+#pragma unroll
+  for (int co = 0; co < 8; ++co)
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[co][k] = 0.f;
+#pragma unroll
+  for (int co = 0; co < 8; ++co) bsum[co] = 0.f;
+  const int nco = min(8, Cout - co0);
+  if (ty < ty_n) {
+    for (int64_t v = r0 + ty; v < r1; v += ty_n) {
+      V<T, VEC> xv;
+      xv.load(x + v * ldx + tx * VEC);
+      const int b = (int)(v / S);
+      const int64_t sidx = v - (int64_t)b * S;
+#pragma unroll
+      for (int co = 0; co < 8; ++co) {
+        if (co < nco) {
+          const float g = dy[((int64_t)b * Cout + co0 + co) * S + sidx];
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) acc[co][k] = fmaf(g, xv.v[k], acc[co][k]);
+          bsum[co] += g;
+        }
+      }
+    }
+  }
+  team_reduce_atomic<8, VEC>(red, acc, tx, ty, tx_n, ty_n, dw + (int64_t)co0 * Cin, Cin, nco, Cin);
+  if (dbias) {   // every lane of a row holds the same sums: take lane tx == 0
+    __syncthreads();
+    if (tx == 0 && ty < ty_n) {
+#pragma unroll
+      for (int co = 0; co < 8; ++co) red[ty * 8 + co] = bsum[co];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nco) {
+      float a = 0.f;
+      for (int yy = 0; yy < ty_n; ++yy) a += red[yy * 8 + threadIdx.x];
+      atomicAdd(dbias + co0 + threadIdx.x, a);
+    }
+  }
+}
+
+// dw[co][ci][a][b][c] += sum over coarse voxels of dy[cv][co] x[b][ci][2d+a][2h+b][2w+c], dbias[co] += sum dy[cv][co]
+// lane = (coarse voxel row ty, output-channel vector tx); one input channel per pass (blockIdx.y)
+template <class T, int VEC>
+__global__ void __launch_bounds__(256) patch_embed_bwd_team_kernel(const float* __restrict__ x, const T* __restrict__ dy, int64_t lddy, float* __restrict__ dw,
+                                                                   float* __restrict__ dbias, int B, int Cin, int D, int H, int W, int Cout, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int tx_n = Cout / VEC, ty_n = 256 / tx_n;
+  const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
+  const int ci = blockIdx.y;
+  const int D2 = D / 2, H2 = H / 2, W2 = W / 2;
+  const int64_t nv = (int64_t)B * D2 * H2 * W2;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(nv, r0 + rows_per_block);
+  float acc[9][VEC];   // 8 taps + the bias row
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[t][k] = 0.f;
+  if (ty < ty_n) {
+    for (int64_t v = r0 + ty; v < r1; v += ty_n) {
+      V<T, VEC> g;
+      g.load(dy + v * lddy + tx * VEC);
+      int64_t t = v;
+      const int w2 = (int)(t % W2); t /= W2;
+      const int h2 = (int)(t % H2); t /= H2;
+      const int d2 = (int)(t % D2);
+      const int b = (int)(t / D2);
+      const float* xp = x + ((((int64_t)b * Cin + ci) * D + 2 * d2) * H + 2 * h2) * W + 2 * w2;
+#pragma unroll
+      for (int tap = 0; tap < 8; ++tap) {
+        const float xv = xp[((int64_t)(tap >> 2) * H + ((tap >> 1) & 1)) * W + (tap & 1)];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[tap][k] = fmaf(xv, g.v[k], acc[tap][k]);
+      }
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[8][k] += g.v[k];
+    }
+  }
+  // out[tap][co] lives at dw[(co * Cin + ci) * 8 + tap]: reduce into LDS, then scatter
+  const int width = 9 * tx_n * VEC;
+  __syncthreads();
+  if (ty < ty_n) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) red[ty * width + (t * tx_n + tx) * VEC + k] = acc[t][k];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < width; e += 256) {
+    float a = 0.f;
+    for (int yy = 0; yy < ty_n; ++yy) a += red[yy * width + e];
+    const int tap = e / (tx_n * VEC), co = e - tap * (tx_n * VEC);
+    if (tap < 8) atomicAdd(dw + ((int64_t)co * Cin + ci) * 8 + tap, a);
+    else if (dbias && ci == 0) atomicAdd(dbias + co, a);
+  }
+}
+
 // ----------------------------------------------------------------------------- im2col / col2im (3x3x3 pad 1)
 template <class T, int VEC>
 __global__ void __launch_bounds__(256) im2col3_kernel(const T* src, int64_t lds, T* dst, int64_t ldd, int B, int D, int H, int W, int C) {
@@ -687,9 +902,21 @@ extern "C" int miseg_patch_embed_bwd(const miseg_patch_embed_bwd_params* p, mise
   MISEG_REQUIRE(p->Cout * (p->Cin * 8 + 1) <= 2048, MISEG_E_UNSUPPORTED, "patch_embed_bwd: Cout*(8Cin+1) > 2048");
   DT(p, {
     const int64_t nv = (int64_t)p->B * (p->D / 2) * (p->H / 2) * (p->W / 2);
-    const int vpb = 1024;
-    size_t sh = ((size_t)64 * (p->Cin * 8 + 1) + 64 * p->Cout) * sizeof(float);
-    patch_embed_bwd_kernel<T><<<cdiv(nv, vpb), 256, sh, s>>>(p->x, (const T*)p->dy, p->lddy, p->dw, p->dbias, p->B, p->Cin, p->D, p->H, p->W, p->Cout, vpb);
+    constexpr int N = Vec16<T>::N;
+    const int tx_n = p->Cout / N;
+    if (p->Cout % N == 0 && p->lddy % N == 0 && al16(p->dy) && tx_n >= 1 && tx_n <= 64) {
+      const int ty_n = 256 / tx_n;
+      int rpb = (int)((nv + 255) / 256);
+      if (rpb < 4 * ty_n) rpb = 4 * ty_n;
+      const size_t sh = (size_t)ty_n * 9 * tx_n * N * sizeof(float);
+      hipFuncSetAttribute((const void*)patch_embed_bwd_team_kernel<T, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      patch_embed_bwd_team_kernel<T, N><<<dim3(cdiv(nv, rpb), p->Cin), 256, sh, s>>>(p->x, (const T*)p->dy, p->lddy, p->dw, p->dbias, p->B, p->Cin, p->D, p->H, p->W,
+                                                                                     p->Cout, rpb);
+    } else {
+      const int vpb = 1024;
+      size_t sh = ((size_t)64 * (p->Cin * 8 + 1) + 64 * p->Cout) * sizeof(float);
+      patch_embed_bwd_kernel<T><<<cdiv(nv, vpb), 256, sh, s>>>(p->x, (const T*)p->dy, p->lddy, p->dw, p->dbias, p->B, p->Cin, p->D, p->H, p->W, p->Cout, vpb);
+    }
     MISEG_LAUNCH_CHECK("patch_embed_bwd");
   });
 }
@@ -726,9 +953,14 @@ extern "C" int miseg_head_fwd(const miseg_head_params* p, miseg_stream_t s_) {
   DT(p, {
     size_t sh = ((size_t)p->Cin * p->Cout + p->Cout) * sizeof(float);
     constexpr int N = Vec16<T>::N;
-    if (p->Cin % N == 0 && p->ldx % N == 0 && al16(p->x))
-      head_fwd_kernel<T, N><<<ew_grid((int64_t)p->B * p->S), 256, sh, s>>>((const T*)p->x, p->ldx, p->y, p->w, p->bias, p->B, p->S, p->Cin, p->Cout);
-    else
+    if (p->Cin % N == 0 && p->ldx % N == 0 && al16(p->x)) {
+      const int64_t nv = (int64_t)p->B * p->S;
+      const size_t sh2 = (size_t)((p->Cout * p->Cin + p->Cout + 3) & ~3) * 4 + (size_t)256 * (p->Cin * sizeof(T) + 16);
+      int grid = (int)((nv + 255) / 256);
+      if (grid > 2048) grid = 2048;
+      hipFuncSetAttribute((const void*)head_fwd_tile_kernel<T, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2);
+      head_fwd_tile_kernel<T, N><<<grid, 256, sh2, s>>>((const T*)p->x, p->ldx, p->y, p->w, p->bias, p->B, p->S, p->Cin, p->Cout);
+    } else
       head_fwd_kernel<T, 1><<<ew_grid((int64_t)p->B * p->S), 256, sh, s>>>((const T*)p->x, p->ldx, p->y, p->w, p->bias, p->B, p->S, p->Cin, p->Cout);
     MISEG_LAUNCH_CHECK("head_fwd");
   });
@@ -740,18 +972,29 @@ extern "C" int miseg_head_bwd(const miseg_head_bwd_params* p, miseg_stream_t s_)
   MISEG_REQUIRE(p->Cout <= 16 && p->Cout * (p->Cin + 1) <= 1024, MISEG_E_UNSUPPORTED, "head_bwd: Cout %d Cin %d", p->Cout, p->Cin);
   DT(p, {
     const int64_t nv = (int64_t)p->B * p->S;
+    constexpr int N = Vec16<T>::N;
     if (p->dx) {
       size_t sh = (size_t)p->Cin * p->Cout * sizeof(float);
-      constexpr int N = Vec16<T>::N;
       if (p->Cin % N == 0 && p->lddx % N == 0 && al16(p->dx))
-        head_bwd_dx_kernel<T, N><<<ew_grid(nv), 256, sh, s>>>(p->dy, (T*)p->dx, p->lddx, p->w, p->B, p->S, p->Cin, p->Cout);
+        head_bwd_dx_team_kernel<T, N><<<ew_grid(nv * (p->Cin / N)), 256, sh, s>>>(p->dy, (T*)p->dx, p->lddx, p->w, p->B, p->S, p->Cin, p->Cout);
       else
         head_bwd_dx_kernel<T, 1><<<ew_grid(nv), 256, sh, s>>>(p->dy, (T*)p->dx, p->lddx, p->w, p->B, p->S, p->Cin, p->Cout);
     }
     if (p->dw) {
-      const int vpb = 2048;
-      size_t sh = ((size_t)64 * (p->Cin + 1) + (size_t)p->Cout * 64) * sizeof(float);
-      head_bwd_dw_kernel<T><<<cdiv(nv, vpb), 256, sh, s>>>((const T*)p->x, p->ldx, p->dy, p->dw, p->dbias, p->B, p->S, p->Cin, p->Cout, vpb);
+      const int tx_n = p->Cin / N;
+      if (p->Cin % N == 0 && p->ldx % N == 0 && al16(p->x) && tx_n >= 1 && tx_n <= 64) {
+        const int ty_n = 256 / tx_n;
+        int rpb = (int)((nv + 511) / 512);
+        if (rpb < 4 * ty_n) rpb = 4 * ty_n;
+        const size_t sh = (size_t)ty_n * 8 * tx_n * N * sizeof(float);
+        hipFuncSetAttribute((const void*)head_bwd_dw_team_kernel<T, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        for (int co0 = 0; co0 < p->Cout; co0 += 8)
+          head_bwd_dw_team_kernel<T, N><<<cdiv(nv, rpb), 256, sh, s>>>((const T*)p->x, p->ldx, p->dy, p->dw, p->dbias, p->B, p->S, p->Cin, p->Cout, co0, rpb);
+      } else {
+        const int vpb = 2048;
+        size_t sh = ((size_t)64 * (p->Cin + 1) + (size_t)p->Cout * 64) * sizeof(float);
+        head_bwd_dw_kernel<T><<<cdiv(nv, vpb), 256, sh, s>>>((const T*)p->x, p->ldx, p->dy, p->dw, p->dbias, p->B, p->S, p->Cin, p->Cout, vpb);
+      }
     }
     MISEG_LAUNCH_CHECK("head_bwd");
   });
