@@ -231,6 +231,62 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_stream_kernel(const bf16* __re
   }
 }
 
+// ------------------------------------------------------------------------------------------------ NT, small
+// Linears of the deep stages (a few hundred to a few thousand tokens, K up to 3072): too little work per output tile to
+// amortise an LDS pipeline, so the time is the dependent global->LDS->MFMA chain of each K stage.  Here a workgroup owns
+// one 16 x (16*NTW) output tile, its four waves split K, and every lane's operands (16 contiguous bytes of a row each) go
+// straight from global memory (L2) to registers in batches of four k-steps, all loads of a batch in flight together;
+// the four partial tiles meet in LDS.
+template <int NTW, bool GELU>
+__global__ void __launch_bounds__(256) gemm_nt_small_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ W, int64_t ldw, bf16* __restrict__ C,
+                                                            int64_t ldc, int M, int N, int K, const float* __restrict__ bias) {
+  __shared__ __attribute__((aligned(16))) float part[4][NTW][64][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, kg = lane >> 4;
+  const int m0 = blockIdx.x * 16, n0 = blockIdx.y * 16 * NTW;
+  const int ksteps = K / 32, kpw = (ksteps + 3) / 4;
+  const int ks0 = wave * kpw, ks1 = min(ksteps, ks0 + kpw);
+  const bf16* arow = A + (int64_t)min(m0 + fi, M - 1) * lda + 8 * kg;
+  const bf16* wrow[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) wrow[nt] = W + (int64_t)min(n0 + nt * 16 + fi, N - 1) * ldw + 8 * kg;
+  f32x4 acc[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int ks = ks0; ks < ks1; ks += 4) {
+    bf16x8 af[4], wf[4][NTW];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (ks + u < ks1) {
+        af[u] = *reinterpret_cast<const bf16x8*>(arow + (ks + u) * 32);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) wf[u][nt] = *reinterpret_cast<const bf16x8*>(wrow[nt] + (ks + u) * 32);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (ks + u < ks1) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][nt], af[u], acc[nt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) *reinterpret_cast<f32x4*>(&part[wave][nt][lane][0]) = acc[nt];
+  __syncthreads();
+  // wave w finishes n-tiles w, w + 4, ...: lane (fi = row, kg): columns n0 + nt * 16 + 4kg .. +3
+  for (int nt = wave; nt < NTW; nt += 4) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(&part[0][nt][lane][0]);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(&part[w][nt][lane][0]);
+    const int m = m0 + fi, n = n0 + nt * 16 + 4 * kg;
+    if (m < M && n < N) {
+      if (bias) { v[0] += bias[n]; v[1] += bias[n + 1]; v[2] += bias[n + 2]; v[3] += bias[n + 3]; }
+      if (GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+      *reinterpret_cast<bf16x4*>(C + (int64_t)m * ldc + n) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ TN
 // A stored [K][M] (lda), B stored [K][N] (ldb).  Tile 64 x 64, 4 waves as 2(M) x 2(N), each 32 x 32.
 template <class T> struct TnFrag;
@@ -541,6 +597,21 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
     if (split > 1 && p->act != MISEG_ACT_NONE) return set_error(MISEG_E_BADARG, "gemm: activation with split_k");
     if (split > 1 && p->act != MISEG_ACT_NONE) return set_error(MISEG_E_BADARG, "gemm: activation with split_k");
     if constexpr (std::is_same<T, bf16>::value && std::is_same<TO, bf16>::value) {
+      // deep-stage linears (see gemm_nt_small_kernel)
+      if (split == 1 && !p->accumulate && p->M <= 2048 && p->K % 32 == 0 && p->N % 16 == 0 && al_a && al_b && ((uintptr_t)p->C % 8 == 0) && p->ldc % 4 == 0) {
+        const int ntw = (p->N % 64 == 0 && (int64_t)cdiv(p->M, 16) * (p->N / 64) >= 256) ? 4 : (p->N % 32 == 0 && (int64_t)cdiv(p->M, 16) * (p->N / 32) >= 256) ? 2 : 1;
+        dim3 grid(cdiv(p->M, 16), p->N / (16 * ntw));
+        const bool ge = p->act == MISEG_ACT_GELU;
+#define SM_CASE(n)                                                                                                                              \
+  case n:                                                                                                                                       \
+    if (ge) gemm_nt_small_kernel<n, true><<<grid, 256, 0, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, p->K, p->bias); \
+    else gemm_nt_small_kernel<n, false><<<grid, 256, 0, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, p->K, p->bias); \
+    break;
+        switch (ntw) { SM_CASE(1) SM_CASE(2) SM_CASE(4) }
+#undef SM_CASE
+        MISEG_LAUNCH_CHECK("gemm_nt_small");
+        return MISEG_OK;
+      }
       // tall-skinny streaming path (see gemm_nt_stream_kernel)
       const size_t lds = (size_t)p->N * (p->K * 2 + 16) + (size_t)p->N * 4;
       const bool st_ok = split == 1 && !p->accumulate && (p->K == 48 || p->K == 96 || p->K == 192) && p->N % 16 == 0 && p->M >= 4096 && lds <= 96 * 1024 &&

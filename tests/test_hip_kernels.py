@@ -127,6 +127,22 @@ def test_gemm_nt_streaming_path(M, N, K):
     assert torch.equal(ops.gemm_nt(ai, wi).float(), (ai.float() @ wi.float().t()).to(dtype).float())
 
 
+@pytest.mark.parametrize("M,N,K", [(216, 1536, 384), (216, 384, 1536), (27, 3072, 768), (1728, 768, 192), (1727, 192, 768), (215, 1152, 384), (100, 16, 32),
+                                   (2048, 48, 96)])
+def test_gemm_nt_small_path(M, N, K):
+    """deep-stage linears (M <= 2048, K % 32 == 0) take the register-direct kernel with K split over the four waves."""
+    ops, L = _ops(), _L()
+    dtype = torch.bfloat16
+    a, w, bias = rnd(M, K, dtype=dtype, seed=21), rnd(N, K, dtype=dtype, seed=22) / K ** 0.5, rnd(N, seed=23)
+    yr = a.float() @ w.float().t() + bias
+    assert rel_err(ops.gemm_nt(a, w, bias), yr) < TOL[dtype]
+    assert rel_err(ops.gemm_nt(a, w, bias, act=L.ACT_GELU), F.gelu(yr)) < TOL[dtype]
+    assert rel_err(ops.gemm_nt(a, w), yr - bias) < TOL[dtype]
+    ai = (torch.arange(M * K, device=DEV).reshape(M, K) % 7 - 3).to(dtype)
+    wi = (torch.arange(N * K, device=DEV).reshape(N, K) % 5 - 2).to(dtype)
+    assert torch.equal(ops.gemm_nt(ai, wi).float(), (ai.float() @ wi.float().t()).to(dtype).float())
+
+
 def test_gemm_nt_exact_integers():
     """asymmetric small-integer operands: catches transposed / permuted MFMA fragment maps exactly."""
     ops = _ops()
