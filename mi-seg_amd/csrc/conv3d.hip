@@ -561,7 +561,8 @@ __global__ void __launch_bounds__(WG_THREADS) conv3_wgrad_kernel(const T* __rest
       }
     }
   }
-  // slab[pair][split][tap][co 48][ci 48]; swapped operands => lane holds ci = 16nt + 4fq + r, co = 16mt + fi
+  // slab[pair][split][co 48][tap 27][ci 48] (a reducing workgroup reads one contiguous 5 KB run per split);
+  // swapped operands => lane holds ci = 16nt + 4fq + r, co = 16mt + fi
   float* slab = slabs + ((int64_t)pair * nsplit + blockIdx.x) * 27 * WG_CB * WG_CB;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -571,36 +572,33 @@ __global__ void __launch_bounds__(WG_THREADS) conv3_wgrad_kernel(const T* __rest
       for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt)
-          *reinterpret_cast<f32x4*>(slab + ((int64_t)tap * WG_CB + mt * 16 + fi) * WG_CB + nt * 16 + fq * 4) = acc[t][mt][nt];
+          *reinterpret_cast<f32x4*>(slab + ((int64_t)(mt * 16 + fi) * 27 + tap) * WG_CB + nt * 16 + fq * 4) = acc[t][mt][nt];
     }
   }
 }
 
-// dw[co][ci0..+48][tap] += sum over this group's splits of slab[pair][split][tap][co%48][0..48).
-// block = (co, ci block, split group): slab reads are 192-byte runs, the 48x27 result is transposed through LDS so the
-// atomics land on one contiguous 5 KB run of the torch-layout gradient.
+// dw[co][ci0..+48][tap] += sum over this group's splits of slab[pair][split][co%48][tap][0..48).
+// block = (co, ci-block, split group): one contiguous 5 KB slab run per split, the 27x48 result is transposed through LDS
+// so the atomics land on one contiguous 5 KB run of the torch-layout gradient.
 __global__ void __launch_bounds__(256) conv3_wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int Cin, int Cout, int ncib, int nsplit,
                                                                  int splits_per_group) {
   __shared__ float tile[WG_CB * 28];
   constexpr int64_t SLAB = 27 * WG_CB * WG_CB;
-  constexpr int NE = 27 * WG_CB;            // elements of one (co, ci-block) tile
+  constexpr int NE = 27 * WG_CB;            // elements of one (co, ci-block) tile, (tap, cil) with cil fastest
   const int co = blockIdx.x / ncib, cib = blockIdx.x % ncib;
   const int pair = (co / WG_CB) * ncib + cib;
   const int k0 = blockIdx.y * splits_per_group, k1 = min(nsplit, k0 + splits_per_group);
-  const float* base = slabs + (int64_t)pair * nsplit * SLAB + (int64_t)(co % WG_CB) * WG_CB;
+  const float* base = slabs + (int64_t)pair * nsplit * SLAB + (int64_t)(co % WG_CB) * NE;
   float acc[6];
-  int off[6];
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const int e = threadIdx.x + 256 * j;   // (tap, cil) with cil fastest
-    acc[j] = 0.f;
-    off[j] = e < NE ? (e / WG_CB) * WG_CB * WG_CB + e % WG_CB : -1;
-  }
+  for (int j = 0; j < 6; ++j) acc[j] = 0.f;
   for (int k = k0; k < k1; ++k) {
     const float* s = base + (int64_t)k * SLAB;
 #pragma unroll
-    for (int j = 0; j < 6; ++j)
-      if (off[j] >= 0) acc[j] += s[off[j]];
+    for (int j = 0; j < 6; ++j) {
+      const int e = threadIdx.x + 256 * j;
+      if (e < NE) acc[j] += s[e];
+    }
   }
 #pragma unroll
   for (int j = 0; j < 6; ++j) {

@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_apply_kernel(const T* _
 }
 
 // ---------------------------------------------------------------------------------------------------
-// backward: reduce (sum dz, sum dz*xhat) -> dstat (fp64 atomics) ; param kernel ; apply
+// backward: reduce (sum dz, sum dz*xhat) -> dstat (fp64 atomics) ; apply (its chunk-0 workgroups also add the affine gradients)
 // ---------------------------------------------------------------------------------------------------
 template <class T, int VEC>
 __global__ void __launch_bounds__(NORM_THREADS) instnorm_bwd_reduce_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ yact, int64_t ldy,
@@ -245,24 +245,12 @@ struct StyleGradPtrs {
   float* dbeta[MISEG_MAX_STYLES];
 };
 
-__global__ void instnorm_bwd_param_kernel(const double* __restrict__ dstat, int C, const int32_t* __restrict__ styles, StyleGradPtrs gp, int total) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int b = i / C, c = i % C;
-  const int st = styles ? styles[b] : 0;
-  double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-  for (int r = 0; r < NORM_R; ++r) { s0 += dstat[((int64_t)r * total + i) * 2]; s1 += dstat[((int64_t)r * total + i) * 2 + 1]; }
-  if (gp.dgamma[st]) atomicAdd(gp.dgamma[st] + c, (float)s1);
-  if (gp.dbeta[st]) atomicAdd(gp.dbeta[st] + c, (float)s0);
-}
-
 template <class T, int VEC>
 __global__ void __launch_bounds__(NORM_THREADS) instnorm_bwd_apply_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ yact, int64_t ldy,
                                                                           const T* __restrict__ x, int64_t ldx, T* __restrict__ dx, int64_t lddx,
                                                                           T* __restrict__ dres, int64_t lddres, int S, int C, int cv, int tx_n, int ty_n, int rpb,
                                                                           const double* __restrict__ stat, float eps, const int32_t* __restrict__ styles,
-                                                                          StylePtrs sp, int act, float slope, const double* __restrict__ dstat) {
+                                                                          StylePtrs sp, int act, float slope, const double* __restrict__ dstat, StyleGradPtrs gp) {
   extern __shared__ __attribute__((aligned(16))) double sums[];
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
@@ -270,6 +258,16 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_bwd_apply_kernel(const 
   double* dsums = sums + 2 * tx_n * VEC;
   gather_stat(sums, stat, (int64_t)gridDim.y * C * 2, b, C, blockIdx.z * tx_n * VEC, tx_n * VEC);
   gather_stat(dsums, dstat, (int64_t)gridDim.y * C * 2, b, C, blockIdx.z * tx_n * VEC, tx_n * VEC);
+  if (chunk == 0) {   // the affine gradients of this (sample, channel tile): dgamma = sum dz*xhat, dbeta = sum dz
+    const int st0 = styles ? styles[b] : 0;
+    for (int e = threadIdx.x; e < tx_n * VEC; e += NORM_THREADS) {
+      const int ch = blockIdx.z * tx_n * VEC + e;
+      if (ch < C) {
+        if (gp.dgamma[st0]) atomicAdd(gp.dgamma[st0] + ch, (float)dsums[2 * e + 1]);
+        if (gp.dbeta[st0]) atomicAdd(gp.dbeta[st0] + ch, (float)dsums[2 * e]);
+      }
+    }
+  }
   if (ty >= ty_n || c >= cv) return;
   const int r0 = chunk * rpb, r1 = min(S, r0 + rpb);
   const int st = styles ? styles[b] : 0;
@@ -447,13 +445,11 @@ extern "C" int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stre
     NormGeom g = norm_geom(p->S, p->C, al, V);
     StylePtrs sp;
     StyleGradPtrs gp;
-    bool any_param = false;
     for (int s = 0; s < MISEG_MAX_STYLES; ++s) {
       sp.gamma[s] = s < p->num_styles ? p->gamma[s] : nullptr;
       sp.beta[s] = nullptr;
       gp.dgamma[s] = s < p->num_styles ? p->dgamma[s] : nullptr;
       gp.dbeta[s] = s < p->num_styles ? p->dbeta[s] : nullptr;
-      any_param = any_param || gp.dgamma[s] || gp.dbeta[s];
     }
     dim3 grid(g.chunks, p->B, g.ctiles);
     size_t sh = (size_t)g.ty * 2 * g.tx * g.vec * sizeof(float);
@@ -461,14 +457,12 @@ extern "C" int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stre
     const size_t shd = (size_t)4 * g.tx * g.vec * sizeof(double);
     const double* stat = (const double*)p->stat;
     double* dstat = (double*)p->dstat;
-    const int total = p->B * p->C;
 #define BWD_LAUNCH(VV)                                                                                                                                          \
     instnorm_bwd_reduce_kernel<T, VV><<<grid, NORM_THREADS, sh, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, p->S, p->C,  \
                                                                            g.cv, g.tx, g.ty, g.rpb, stat, p->eps, p->act, p->slope, dstat);                           \
-    if (any_param) instnorm_bwd_param_kernel<<<cdiv(total, 256), 256, 0, stream>>>(dstat, p->C, p->styles, gp, total);                                          \
     instnorm_bwd_apply_kernel<T, VV><<<grid, NORM_THREADS, shd, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, (T*)p->dx,    \
                                                                          p->lddx, (T*)p->dres, p->lddres, p->S, p->C, g.cv, g.tx, g.ty, g.rpb, stat, p->eps, p->styles, \
-                                                                         sp, p->act, p->slope, dstat);
+                                                                         sp, p->act, p->slope, dstat, gp);
     if (g.vec == 1) { BWD_LAUNCH(1) } else { BWD_LAUNCH(V) }
 #undef BWD_LAUNCH
     MISEG_LAUNCH_CHECK("instnorm_bwd");
