@@ -54,14 +54,22 @@ def _fp32(t):
 PROFILE_HOOK = None   # bench.py roofline leg: list collecting (kernel, start_event, end_event, flops)
 
 
+PROFILE_REPS = 5      # launches per timed interval in the roofline leg (event packets cost several us each)
+
+
 def _call(fn_name, params, prof=None):
     lib = L.load()
     if PROFILE_HOOK is not None and prof is not None:
+        # roofline leg only: the launch is repeated back to back between two events on the launch stream, so the interval is
+        # PROFILE_REPS kernel durations and not one duration plus the event packets; the step's results are discarded
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn = getattr(lib, fn_name)
+        L.check(fn(C.byref(params), _stream()), fn_name)          # warm (weights / L2 state as in a normal step)
         e0.record()
-        L.check(getattr(lib, fn_name)(C.byref(params), _stream()), fn_name)
+        for _ in range(PROFILE_REPS):
+            L.check(fn(C.byref(params), _stream()), fn_name)
         e1.record()
-        PROFILE_HOOK.append((prof[0], e0, e1, prof[1]))
+        PROFILE_HOOK.append((prof[0], e0, e1, prof[1], prof[2] if len(prof) > 2 else 0.0))
         return
     L.check(getattr(lib, fn_name)(C.byref(params), _stream()), fn_name)
 
@@ -272,7 +280,8 @@ def conv3_fwd(x, wpk, Cout, out=None):
     kpc = 16 // x.element_size()
     fast = (_round_up(Cin, kpc) * x.element_size()) % 96 == 0
     name = f"conv3_fwd{'96' if fast else ''}_kernel<{'bf16' if x.dtype == torch.bfloat16 else 'f32'}>"
-    _call("miseg_conv3_fwd", L.Conv3(_ptr(x), ld, _ptr(out), rows(out)[0], _ptr(wpk), B, D, H, W, Cin, Cout, _dt(x), _ptr(ws)), prof=(name, flops))
+    nbytes = float(x.element_size()) * (B * D * H * W * (Cin + Cout) + wpk.numel())      # x read once, y written once, the weight pack
+    _call("miseg_conv3_fwd", L.Conv3(_ptr(x), ld, _ptr(out), rows(out)[0], _ptr(wpk), B, D, H, W, Cin, Cout, _dt(x), _ptr(ws)), prof=(name, flops, nbytes))
     return out
 
 

@@ -1,6 +1,12 @@
 """roofline leg of bench.py: per-launch device time of the conv3 implicit-GEMM kernels measured with HIP events on the
-launch stream during one extra profiled forward+backward step, priced against the dense MFMA peak of the compute dtype
-(MI355X_MICROARCH.md: bf16 ~2.5 PFLOP/s dense, fp32 matrix 157.3 TFLOP/s)."""
+launch stream during one extra profiled forward+backward step (each launch repeated ops.PROFILE_REPS times between the two
+events), priced against the dense MFMA peak of the compute dtype (MI355X_MICROARCH.md: bf16 ~2.5 PFLOP/s dense, fp32 matrix
+157.3 TFLOP/s).  `traffic` is the HBM bytes per launch of the same kernel from the committed rocprofv3 PMC passes
+(profiles/*_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled on gfx950), null when absent."""
+import glob
+import json
+import os
+
 import torch
 
 from ..hip import ops
@@ -18,21 +24,35 @@ def profile_step(step_fn):
     finally:
         ops.PROFILE_HOOK = None
     out = {}
-    for name, e0, e1, flops in rec:
-        out.setdefault(name, []).append((e0.elapsed_time(e1), flops))
+    for name, e0, e1, flops, nbytes in rec:
+        out.setdefault(name, []).append((e0.elapsed_time(e1) / ops.PROFILE_REPS, flops, nbytes))
     return out
+
+
+def _pmc_traffic(kernel):
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles")
+    files = sorted(glob.glob(os.path.join(root, "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    data = json.load(open(files[-1]))
+    for k, v in data.get("kernels", {}).items():
+        if kernel.startswith(k):
+            return v["hbm_bytes_per_launch"], os.path.relpath(files[-1], os.path.dirname(root))
+    return None, None
 
 
 def summarize(prof, dtype):
     best = None
     for name, lst in prof.items():
-        tot_ms = sum(t for t, _ in lst)
+        tot_ms = sum(t[0] for t in lst)
         if best is None or tot_ms > best[1]:
             best = (name, tot_ms, lst)
     name, tot_ms, lst = best
-    flops = sum(f for _, f in lst)
+    flops = sum(t[1] for t in lst)
     achieved = flops / (tot_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[dtype]
+    traffic, src = _pmc_traffic(name)
     return {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "traffic": None, "launches_per_step": len(lst), "avg_launch_ms": tot_ms / len(lst),
-            "flops_per_step": flops, "all_kernels_ms": {k: sum(t for t, _ in v) for k, v in prof.items()}}
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": src,
+            "algorithmic_bytes_per_launch": sum(t[2] for t in lst) / len(lst), "launches_per_step": len(lst), "avg_launch_ms": tot_ms / len(lst),
+            "flops_per_step": flops, "all_kernels_ms": {k: sum(t[0] for t in v) for k, v in prof.items()}}
