@@ -162,6 +162,10 @@ int miseg_conv3_fwd(const miseg_conv3_params* p, miseg_stream_t stream);
 size_t miseg_pack_conv3_elems(int Cin, int Cout, int dtype, int which);
 typedef struct { const float* w; void* fwd_pack; void* bwd_pack; int Cin, Cout, dtype; } miseg_pack_conv3_params;
 int miseg_pack_conv3_weight(const miseg_pack_conv3_params* p, miseg_stream_t stream);
+/* every 3x3x3 weight of a model in ONE launch: `descs` is a DEVICE array of n descriptors sorted by tile0 = number of 16x16
+ * (co, ci) tiles before the descriptor; total_tiles = the sum over descriptors of ceil(Cin/16) * ceil(Cout/16). */
+typedef struct { const float* w; void* fwd_pack; void* bwd_pack; int32_t Cin, Cout, tile0, pad_; } miseg_pack_conv3_desc;
+int miseg_pack_conv3_batch(const miseg_pack_conv3_desc* descs_dev, int n, int total_tiles, int dtype, miseg_stream_t stream);
 
 /* weight gradient: dw[Cout][Cin][27] (fp32, torch layout) (+)= sum_v dy[v][co] * x[v + tap][ci] */
 typedef struct {

@@ -371,12 +371,12 @@ static constexpr int PK_T = 16;
 static constexpr int PK_LD = PK_T * 27 + 1;      // floats per co row of the LDS tile
 
 template <class T>
-__global__ void __launch_bounds__(256) pack_conv3_kernel(const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ bwd, int Cin, int Cout, int CinP, int CoutP,
-                                                         int Cin16, int Cout16, bool fwd_planar, bool bwd_planar) {
+__device__ __forceinline__ void pack_conv3_tile(const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ bwd, int Cin, int Cout, int CinP, int CoutP,
+                                                int Cin16, int Cout16, bool fwd_planar, bool bwd_planar, int bx, int by) {
   typedef typename Vec16<T>::type VT;
   constexpr int KPC = Vec16<T>::N, NG = PK_T / KPC;
   __shared__ float tile[PK_T * PK_LD];
-  const int ci0 = blockIdx.x * PK_T, co0 = blockIdx.y * PK_T;
+  const int ci0 = bx * PK_T, co0 = by * PK_T;
   const int nci = min(PK_T, Cin - ci0);
   for (int i = threadIdx.x; i < PK_T * PK_T * 27; i += 256) {
     const int co = i / (PK_T * 27), r = i - co * (PK_T * 27);     // r = ci_local * 27 + tap
@@ -411,6 +411,27 @@ __global__ void __launch_bounds__(256) pack_conv3_kernel(const float* __restrict
       *reinterpret_cast<VT*>(bwd + off) = v;
     }
   }
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) pack_conv3_kernel(const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ bwd, int Cin, int Cout, int CinP, int CoutP,
+                                                         int Cin16, int Cout16, bool fwd_planar, bool bwd_planar) {
+  pack_conv3_tile<T>(w, fwd, bwd, Cin, Cout, CinP, CoutP, Cin16, Cout16, fwd_planar, bwd_planar, blockIdx.x, blockIdx.y);
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) pack_conv3_batch_kernel(const miseg_pack_conv3_desc* __restrict__ descs, int n) {
+  constexpr int KPC = Vec16<T>::N;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {   // last descriptor with tile0 <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const miseg_pack_conv3_desc d = descs[lo];
+  const int t = blockIdx.x - d.tile0, tci = (d.Cin + PK_T - 1) / PK_T;
+  const int CinP = (d.Cin + KPC - 1) / KPC * KPC, CoutP = (d.Cout + KPC - 1) / KPC * KPC;
+  pack_conv3_tile<T>(d.w, (T*)d.fwd_pack, (T*)d.bwd_pack, d.Cin, d.Cout, CinP, CoutP, (d.Cin + 15) / 16 * 16, (d.Cout + 15) / 16 * 16,
+                     (CinP * (int)sizeof(T)) % 96 == 0, (CoutP * (int)sizeof(T)) % 96 == 0, t % tci, t / tci);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -737,6 +758,16 @@ extern "C" int miseg_pack_conv3_weight(const miseg_pack_conv3_params* p, miseg_s
     pack_conv3_kernel<T><<<grid, 256, 0, s>>>(p->w, (T*)p->fwd_pack, (T*)p->bwd_pack, p->Cin, p->Cout, CinP, CoutP, round_up(p->Cin, 16), round_up(p->Cout, 16),
                                               fplanar, bplanar);
     MISEG_LAUNCH_CHECK("pack_conv3_weight");
+    return MISEG_OK;
+  });
+}
+
+extern "C" int miseg_pack_conv3_batch(const miseg_pack_conv3_desc* descs, int n, int total_tiles, int dtype, miseg_stream_t s_) {
+  MISEG_REQUIRE(descs && n > 0 && total_tiles > 0, MISEG_E_BADARG, "pack_conv3_batch: bad args");
+  return dispatch_dtype(dtype, [&](auto* tag) -> int {
+    typedef typename std::remove_pointer<decltype(tag)>::type T;
+    pack_conv3_batch_kernel<T><<<total_tiles, 256, 0, (hipStream_t)s_>>>(descs, n);
+    MISEG_LAUNCH_CHECK("pack_conv3_batch");
     return MISEG_OK;
   });
 }

@@ -45,6 +45,7 @@ Gemm = _struct("Gemm", [("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", 
 Colsum = _struct("Colsum", [("x", vp), ("ldx", i64), ("rows", i64), ("C", i32), ("dtype", i32), ("out", vp), ("accumulate", i32)])
 Conv3 = _struct("Conv3", [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("wpk", vp), ("B", i32), ("D", i32), ("H", i32),
                           ("W", i32), ("Cin", i32), ("Cout", i32), ("dtype", i32), ("workspace", vp)])
+PackConv3Desc = _struct("PackConv3Desc", [("w", vp), ("fwd_pack", vp), ("bwd_pack", vp), ("Cin", i32), ("Cout", i32), ("tile0", i32), ("pad_", i32)])
 PackConv3 = _struct("PackConv3", [("w", vp), ("fwd_pack", vp), ("bwd_pack", vp), ("Cin", i32), ("Cout", i32), ("dtype", i32)])
 Conv3Wgrad = _struct("Conv3Wgrad", [("x", vp), ("ldx", i64), ("dy", vp), ("lddy", i64), ("dw", vp), ("B", i32), ("D", i32),
                                     ("H", i32), ("W", i32), ("Cin", i32), ("Cout", i32), ("dtype", i32), ("accumulate", i32),
@@ -97,6 +98,7 @@ PROTOS = {
     "miseg_conv3_fwd": (i32, [C.POINTER(Conv3), vp]),
     "miseg_pack_conv3_elems": (C.c_size_t, [i32, i32, i32, i32]),
     "miseg_pack_conv3_weight": (i32, [C.POINTER(PackConv3), vp]),
+    "miseg_pack_conv3_batch": (i32, [vp, i32, i32, i32, vp]),
     "miseg_conv3_wgrad_workspace_bytes": (C.c_size_t, [i32, i32, i32, i32, i32, i32]),
     "miseg_conv3_wgrad": (i32, [C.POINTER(Conv3Wgrad), vp]),
     "miseg_winattn_fwd": (i32, [C.POINTER(Winattn), vp]),

@@ -253,6 +253,13 @@ def _round_up(a, b):
 
 
 def pack_conv3(w, dtype, want_fwd=True, want_bwd=True):
+    """packs of a 3x3x3 weight for the forward (x side) and data-gradient (dy side) kernels; with a training arena the
+    packs refreshed by the step's batched kernel (runtime/arena.py)."""
+    arena = getattr(w, "_miseg_arena", None)
+    if arena is not None and arena.dtype == dtype:
+        pk = arena.conv_packs(w)
+        if pk is not None:
+            return pk
     Cout, Cin = w.shape[0], w.shape[1]
     lib = L.load()
     dt = L.F32 if dtype == torch.float32 else L.BF16

@@ -36,6 +36,9 @@ class ParamArena:
         self._req = {}          # (id(p), transpose, inner, outer) -> [param, shadow, filled_epoch]
         self._table = None      # (device descriptor bytes, ndesc, total tiles)
         self._retired = []      # tables a captured hipGraph may still point at
+        self._packs = {}        # id(p) -> [param, fwd pack, bwd pack, filled_epoch, in table]   (3x3x3 conv weights)
+        self._ptable = None
+        self._pdirty = False
         self._dirty = False
         # all-reduce buckets on slot edges, roughly equal bytes, reduced last-to-first (reverse autograd order)
         ends = offs[1:] + [off]
@@ -66,6 +69,16 @@ class ParamArena:
             for ent in self._req.values():
                 if ent[3]:
                     ent[2] = self.epoch
+        if self._pdirty:
+            self._build_pack_table()
+        if self._ptable is not None:
+            buf, n, tiles = self._ptable
+            lib = L.load()
+            L.check(lib.miseg_pack_conv3_batch(buf.data_ptr(), n, tiles, L.F32 if self.dtype == torch.float32 else L.BF16, ops._stream()),
+                    "pack_conv3_batch")
+            for ent in self._packs.values():
+                if ent[4]:
+                    ent[3] = self.epoch
 
     def shadow(self, p, transpose, inner, outer):
         """the re-layout of parameter p refreshed this step, or None (first request: registered for the next step)."""
@@ -79,6 +92,37 @@ class ParamArena:
             self._dirty = True
             return None
         return ent[1] if ent[2] == self.epoch else None
+
+    def conv_packs(self, p):
+        """(fwd pack, bwd pack) of the 3x3x3 weight p refreshed this step, or None (first request: registered)."""
+        ent = self._packs.get(id(p))
+        if ent is None:
+            lib = L.load()
+            dt = L.F32 if self.dtype == torch.float32 else L.BF16
+            Cout, Cin = p.shape[0], p.shape[1]
+            fwd = torch.empty(lib.miseg_pack_conv3_elems(Cin, Cout, dt, 0), dtype=self.dtype, device=p.device)
+            bwd = torch.empty(lib.miseg_pack_conv3_elems(Cin, Cout, dt, 1), dtype=self.dtype, device=p.device)
+            self._packs[id(p)] = [p, fwd, bwd, -1, False]
+            self._pdirty = True
+            return None
+        return (ent[1], ent[2]) if ent[3] == self.epoch else None
+
+    def _build_pack_table(self):
+        if torch.cuda.is_current_stream_capturing():
+            return
+        descs = (L.PackConv3Desc * len(self._packs))()
+        tile0 = 0
+        for i, ent in enumerate(self._packs.values()):
+            p = ent[0]
+            Cout, Cin = p.shape[0], p.shape[1]
+            descs[i] = L.PackConv3Desc(p.data_ptr(), ent[1].data_ptr(), ent[2].data_ptr(), Cin, Cout, tile0, 0)
+            tile0 += ((Cin + 15) // 16) * ((Cout + 15) // 16)
+            ent[4] = True
+        if self._ptable is not None:
+            self._retired.append(self._ptable[0])
+        raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.flat.device)
+        self._ptable = (raw, len(self._packs), tile0)
+        self._pdirty = False
 
     def _build_table(self):
         if torch.cuda.is_current_stream_capturing():
