@@ -69,6 +69,8 @@ typedef struct {
   int act; float slope;            /* MISEG_ACT_NONE | MISEG_ACT_LEAKY */
 } miseg_instnorm_apply_params;
 int miseg_instnorm_apply(const miseg_instnorm_apply_params* p, miseg_stream_t stream);
+/* statistics (into the zero-filled p->stat) + apply in one call; tensors of <= 512 rows per sample take ONE fused launch */
+int miseg_instnorm_fwd(const miseg_instnorm_apply_params* p, miseg_stream_t stream);
 
 /* backward of the fused op above.  dy is the gradient w.r.t. y; when act != NONE, y (the saved output)
  * supplies the sign for the activation gradient.  Outputs: dx, optionally dres (= gradient flowing to the

@@ -305,6 +305,169 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_bwd_apply_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Small tensors (the deep stages: <= 512 rows per sample): statistics and normalisation in ONE launch, one workgroup per
+// (sample, tile of tx_n channel vectors) that walks all rows twice (the second pass hits L1/L2).  A launch costs ~4 us
+// on this chip whatever it does, so the 2 + 2 launches of forward + backward become 1 + 1.
+// ---------------------------------------------------------------------------------------------------
+// per-column totals of two per-thread vectors over the ty rows of the workgroup -> tot[(tx * VEC + i) * 2 + which] (double)
+template <int VEC>
+__device__ __forceinline__ void team_totals(float* red, double* tot, const float* s, const float* q, int tx, int ty, int tx_n, int ty_n) {
+  if (ty < ty_n) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      red[(ty * 2 + 0) * tx_n * VEC + tx * VEC + i] = s[i];
+      red[(ty * 2 + 1) * tx_n * VEC + tx * VEC + i] = q[i];
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * tx_n * VEC; e += NORM_THREADS) {
+    const int which = e / (tx_n * VEC), col = e % (tx_n * VEC);
+    double acc = 0.0;
+    for (int y = 0; y < ty_n; ++y) acc += (double)red[(y * 2 + which) * tx_n * VEC + col];
+    tot[col * 2 + which] = acc;
+  }
+  __syncthreads();
+}
+
+template <class T, int VEC>
+__global__ void __launch_bounds__(NORM_THREADS) instnorm_fused_fwd_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ res, int64_t ldres,
+                                                                          T* __restrict__ y, int64_t ldy, int S, int C, int cv, int tx_n, int ty_n,
+                                                                          double* __restrict__ stat, float eps, const int32_t* __restrict__ styles, StylePtrs sp,
+                                                                          int act, float slope) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  double* tot = reinterpret_cast<double*>(red + ty_n * 2 * tx_n * VEC);
+  const int b = blockIdx.y;
+  const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
+  const int c = blockIdx.x * tx_n + tx;
+  const bool live = ty < ty_n && c < cv;
+  const int64_t boff = (int64_t)b * S;
+  float s[VEC], q[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s[i] = q[i] = 0.f;
+  if (live) {
+#pragma unroll 4
+    for (int r = ty; r < S; r += ty_n) {
+      RowVec<T, VEC> v;
+      v.load(x + (boff + r) * ldx + c * VEC);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { s[i] += v.v[i]; q[i] = fmaf(v.v[i], v.v[i], q[i]); }
+    }
+  }
+  team_totals<VEC>(red, tot, s, q, tx, ty, tx_n, ty_n);
+  // replica 0 of the statistics buffer (the others stay zero): the backward reads it like any other
+  for (int e = threadIdx.x; e < 2 * tx_n * VEC; e += NORM_THREADS) {
+    const int ch = blockIdx.x * tx_n * VEC + (e >> 1);
+    if (ch < C) stat[((int64_t)b * C + ch) * 2 + (e & 1)] = tot[e];
+  }
+  if (!live) return;
+  const int st = styles ? styles[b] : 0;
+  const float* g = sp.gamma[st];
+  const float* be = sp.beta[st];
+  const double invS = 1.0 / S;
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int ch = c * VEC + i;
+    float m, rs;
+    mean_rstd(tot + (tx * VEC + i) * 2, invS, eps, m, rs);
+    sc[i] = rs * (g ? g[ch] : 1.f);
+    sh[i] = (be ? be[ch] : 0.f) - m * sc[i];
+  }
+#pragma unroll 4
+  for (int r = ty; r < S; r += ty_n) {
+    RowVec<T, VEC> v, o;
+    v.load(x + (boff + r) * ldx + c * VEC);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o.v[i] = fmaf(v.v[i], sc[i], sh[i]);
+    if (res) {
+      RowVec<T, VEC> rr;
+      rr.load(res + (boff + r) * ldres + c * VEC);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o.v[i] += rr.v[i];
+    }
+    if (act == MISEG_ACT_LEAKY) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o.v[i] = o.v[i] > 0.f ? o.v[i] : o.v[i] * slope;
+    }
+    o.store(y + (boff + r) * ldy + c * VEC);
+  }
+}
+
+template <class T, int VEC>
+__global__ void __launch_bounds__(NORM_THREADS) instnorm_fused_bwd_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ yact, int64_t ldy,
+                                                                          const T* __restrict__ x, int64_t ldx, T* __restrict__ dx, int64_t lddx,
+                                                                          T* __restrict__ dres, int64_t lddres, int S, int C, int cv, int tx_n, int ty_n,
+                                                                          const double* __restrict__ stat, float eps, const int32_t* __restrict__ styles,
+                                                                          StylePtrs sp, StyleGradPtrs gp, int act, float slope) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  double* tot = reinterpret_cast<double*>(red + ty_n * 2 * tx_n * VEC);   // dstat totals
+  double* sums = tot + 2 * tx_n * VEC;                                   // forward statistics
+  const int b = blockIdx.y;
+  const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
+  const int c = blockIdx.x * tx_n + tx;
+  const bool live = ty < ty_n && c < cv;
+  const int64_t boff = (int64_t)b * S;
+  gather_stat(sums, stat, (int64_t)gridDim.y * C * 2, b, C, blockIdx.x * tx_n * VEC, tx_n * VEC);
+  const double invS = 1.0 / S;
+  float s[VEC], q[VEC], m[VEC], rs[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { s[i] = q[i] = 0.f; mean_rstd(sums + (tx * VEC + i) * 2, invS, eps, m[i], rs[i]); }
+  if (live) {
+#pragma unroll 4
+    for (int r = ty; r < S; r += ty_n) {
+      RowVec<T, VEC> g, xv;
+      g.load(dy + (boff + r) * lddy + c * VEC);
+      xv.load(x + (boff + r) * ldx + c * VEC);
+      if (act == MISEG_ACT_LEAKY) {
+        RowVec<T, VEC> yv;
+        yv.load(yact + (boff + r) * ldy + c * VEC);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) g.v[i] = yv.v[i] > 0.f ? g.v[i] : g.v[i] * slope;
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { s[i] += g.v[i]; q[i] = fmaf(g.v[i], (xv.v[i] - m[i]) * rs[i], q[i]); }
+    }
+  }
+  team_totals<VEC>(red, tot, s, q, tx, ty, tx_n, ty_n);
+  const int st = styles ? styles[b] : 0;
+  for (int e = threadIdx.x; e < tx_n * VEC; e += NORM_THREADS) {
+    const int ch = blockIdx.x * tx_n * VEC + e;
+    if (ch < C) {
+      if (gp.dgamma[st]) atomicAdd(gp.dgamma[st] + ch, (float)tot[2 * e + 1]);
+      if (gp.dbeta[st]) atomicAdd(gp.dbeta[st] + ch, (float)tot[2 * e]);
+    }
+  }
+  if (!live) return;
+  const float* g = sp.gamma[st];
+  float sc[VEC], a[VEC], bq[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    sc[i] = rs[i] * (g ? g[c * VEC + i] : 1.f);
+    a[i] = (float)(tot[(tx * VEC + i) * 2] * invS);
+    bq[i] = (float)(tot[(tx * VEC + i) * 2 + 1] * invS);
+  }
+#pragma unroll 4
+  for (int r = ty; r < S; r += ty_n) {
+    RowVec<T, VEC> gv, xv, o;
+    gv.load(dy + (boff + r) * lddy + c * VEC);
+    xv.load(x + (boff + r) * ldx + c * VEC);
+    if (act == MISEG_ACT_LEAKY) {
+      RowVec<T, VEC> yv;
+      yv.load(yact + (boff + r) * ldy + c * VEC);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) gv.v[i] = yv.v[i] > 0.f ? gv.v[i] : gv.v[i] * slope;
+    }
+    if (dres) gv.store(dres + (boff + r) * lddres + c * VEC);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float xh = (xv.v[i] - m[i]) * rs[i];
+      o.v[i] = sc[i] * (gv.v[i] - a[i] - xh * bq[i]);
+    }
+    o.store(dx + (boff + r) * lddx + c * VEC);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // LayerNorm over C per row: one wave per row (C <= 8192)
 // ---------------------------------------------------------------------------------------------------
 template <class T>
@@ -432,6 +595,41 @@ extern "C" int miseg_instnorm_apply(const miseg_instnorm_apply_params* p, miseg_
   });
 }
 
+static constexpr int NORM_FUSED_MAX_ROWS = 512;    // 1728 rows x 384 channels: 12 workgroups walking 110 KB twice lose to the chunked pair
+
+// statistics + normalisation: the two kernels above, or one fused launch for the small tensors of the deep stages
+extern "C" int miseg_instnorm_fwd(const miseg_instnorm_apply_params* p, miseg_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  MISEG_REQUIRE(p && p->x && p->y && p->stat, MISEG_E_BADARG, "instnorm_fwd: null pointer");
+  if (p->S > NORM_FUSED_MAX_ROWS) {
+    miseg_instnorm_stats_params sp_{p->x, p->ldx, p->B, p->S, p->C, p->dtype, const_cast<void*>(p->stat)};
+    const int rc = miseg_instnorm_stats(&sp_, stream_);
+    return rc ? rc : miseg_instnorm_apply(p, stream_);
+  }
+  MISEG_REQUIRE(p->num_styles >= 1 && p->num_styles <= MISEG_MAX_STYLES, MISEG_E_BADARG, "instnorm_fwd: num_styles %d", p->num_styles);
+  MISEG_REQUIRE(p->act == MISEG_ACT_NONE || p->act == MISEG_ACT_LEAKY, MISEG_E_UNSUPPORTED, "instnorm_fwd: act %d", p->act);
+  return dispatch_dtype(p->dtype, [&](auto* tag) -> int {
+    typedef typename std::remove_pointer<decltype(tag)>::type T;
+    constexpr int V = Vec16<T>::N;
+    const int64_t ldor = p->ldx | p->ldy | (p->res ? p->ldres : 0);
+    const bool al = aligned16(p->x) && aligned16(p->y) && (!p->res || aligned16(p->res)) && ldor % V == 0 && p->C % V == 0;
+    const int vec = al ? V : 1, cv = p->C / vec;
+    const int tx = cv < 4 ? cv : 4, ty = NORM_THREADS / tx;
+    StylePtrs sp;
+    for (int s = 0; s < MISEG_MAX_STYLES; ++s) { sp.gamma[s] = s < p->num_styles ? p->gamma[s] : nullptr; sp.beta[s] = s < p->num_styles ? p->beta[s] : nullptr; }
+    dim3 grid(cdiv(cv, tx), p->B);
+    const size_t sh = (size_t)ty * 2 * tx * vec * sizeof(float) + (size_t)2 * tx * vec * sizeof(double);
+    if (vec == 1)
+      instnorm_fused_fwd_kernel<T, 1><<<grid, NORM_THREADS, sh, stream>>>((const T*)p->x, p->ldx, (const T*)p->res, p->ldres, (T*)p->y, p->ldy, p->S, p->C, cv, tx, ty,
+                                                                          (double*)p->stat, p->eps, p->styles, sp, p->act, p->slope);
+    else
+      instnorm_fused_fwd_kernel<T, V><<<grid, NORM_THREADS, sh, stream>>>((const T*)p->x, p->ldx, (const T*)p->res, p->ldres, (T*)p->y, p->ldy, p->S, p->C, cv, tx, ty,
+                                                                          (double*)p->stat, p->eps, p->styles, sp, p->act, p->slope);
+    MISEG_LAUNCH_CHECK("instnorm_fwd");
+    return MISEG_OK;
+  });
+}
+
 extern "C" int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   MISEG_REQUIRE(p && p->dy && p->x && p->dx && p->stat && p->dstat, MISEG_E_BADARG, "instnorm_bwd: null pointer");
@@ -450,6 +648,22 @@ extern "C" int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stre
       sp.beta[s] = nullptr;
       gp.dgamma[s] = s < p->num_styles ? p->dgamma[s] : nullptr;
       gp.dbeta[s] = s < p->num_styles ? p->dbeta[s] : nullptr;
+    }
+    if (p->S <= NORM_FUSED_MAX_ROWS) {
+      const int vec = g.vec, cv = p->C / vec;
+      const int tx = cv < 4 ? cv : 4, ty = NORM_THREADS / tx;
+      dim3 fgrid(cdiv(cv, tx), p->B);
+      const size_t fsh = (size_t)ty * 2 * tx * vec * sizeof(float) + (size_t)4 * tx * vec * sizeof(double);
+      if (vec == 1)
+        instnorm_fused_bwd_kernel<T, 1><<<fgrid, NORM_THREADS, fsh, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, (T*)p->dx,
+                                                                              p->lddx, (T*)p->dres, p->lddres, p->S, p->C, cv, tx, ty, (const double*)p->stat, p->eps,
+                                                                              p->styles, sp, gp, p->act, p->slope);
+      else
+        instnorm_fused_bwd_kernel<T, V><<<fgrid, NORM_THREADS, fsh, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, (T*)p->dx,
+                                                                              p->lddx, (T*)p->dres, p->lddres, p->S, p->C, cv, tx, ty, (const double*)p->stat, p->eps,
+                                                                              p->styles, sp, gp, p->act, p->slope);
+      MISEG_LAUNCH_CHECK("instnorm_bwd");
+      return MISEG_OK;
     }
     dim3 grid(g.chunks, p->B, g.ctiles);
     size_t sh = (size_t)g.ty * 2 * g.tx * g.vec * sizeof(float);

@@ -79,10 +79,9 @@ class _InstNorm(Function):
     def forward(ctx, x, res, styles_dev, styles_host, num_styles, affine, act, slope, eps, *params):
         B = x.shape[0]
         S = ops.rows(x)[1] // B
-        stat = ops.instnorm_stats(x, B, S)
         gammas = list(params[0::2]) if affine else None
         betas = list(params[1::2]) if affine else None
-        y = ops.instnorm_apply(x, B, S, stat, styles_dev, gammas, betas, res=res, act=act, slope=slope, eps=eps)
+        y, stat = ops.instnorm_fwd(x, B, S, styles_dev, gammas, betas, res=res, act=act, slope=slope, eps=eps)
         ctx.meta = (B, S, styles_host, num_styles, affine, act, slope, res is not None, eps)
         ctx.params = params
         ctx.save_for_backward(x, y if act != L.ACT_NONE else None, stat, styles_dev, *(gammas or []))

@@ -87,6 +87,7 @@ PROTOS = {
     "miseg_instnorm_stat_bytes": (C.c_size_t, [i32, i32]),
     "miseg_instnorm_stats": (i32, [C.POINTER(InstnormStats), vp]),
     "miseg_instnorm_apply": (i32, [C.POINTER(InstnormApply), vp]),
+    "miseg_instnorm_fwd": (i32, [C.POINTER(InstnormApply), vp]),
     "miseg_instnorm_bwd": (i32, [C.POINTER(InstnormBwd), vp]),
     "miseg_layernorm_fwd": (i32, [C.POINTER(LayernormFwd), vp]),
     "miseg_layernorm_bwd": (i32, [C.POINTER(LayernormBwd), vp]),

@@ -136,6 +136,20 @@ def instnorm_apply(x, B, S, stat, styles, gammas, betas, res=None, act=L.ACT_NON
     return y
 
 
+def instnorm_fwd(x, B, S, styles, gammas, betas, res=None, act=L.ACT_NONE, slope=0.01, eps=1e-5):
+    """statistics + normalisation (one fused launch for tensors of <= 512 rows per sample); returns (y, stat)."""
+    ld, n, Cc = rows(x)
+    assert n == B * S, (n, B, S)
+    stat = STAT_POOL.take(L.load().miseg_instnorm_stat_bytes(B, Cc) // 8, x.device).view(-1, B, Cc, 2)
+    y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    ldr = rows(res)[0] if res is not None else 0
+    ns = len(gammas) if gammas is not None else 1
+    p = L.InstnormApply(_ptr(x), ld, _ptr(res), ldr, _ptr(y), rows(y)[0], B, S, Cc, _dt(x), _ptr(stat), eps, _ptr(styles), ns,
+                        _style_arrays(gammas, ns), _style_arrays(betas, ns), act, slope)
+    _call("miseg_instnorm_fwd", p)
+    return y, stat
+
+
 def instnorm_bwd(dy, y, x, B, S, stat, styles, gammas, dgammas, dbetas, act=L.ACT_NONE, slope=0.01, eps=1e-5, want_dres=False):
     ld, n, Cc = rows(x)
     dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)

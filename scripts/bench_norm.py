@@ -30,10 +30,11 @@ def run(S, C, dtype=torch.bfloat16, act=L.ACT_LEAKY):
     stat = ops.instnorm_stats(x, B, S)
     y = ops.instnorm_apply(x, B, S, stat, styles, gam, bet, act=act)
     keep = stat.clone()
+    t_f = timed(lambda: ops.instnorm_fwd(x, B, S, styles, gam, bet, act=act))
     t_s = timed(lambda: ops.instnorm_stats(x, B, S))
     t_a = timed(lambda: ops.instnorm_apply(x, B, S, keep, styles, gam, bet, act=act, out=y))
     t_b = timed(lambda: ops.instnorm_bwd(dy, y, x, B, S, keep, styles, gam, dg, db, act=act))
-    print(f"S {S:7d} C {C:4d}: stats {t_s:7.1f} us ({nb/t_s/1e6:5.2f} TB/s)  apply {t_a:7.1f} us ({2*nb/t_a/1e6:5.2f} TB/s)  "
+    print(f"S {S:7d} C {C:4d}: fwd {t_f:6.1f} us | stats {t_s:7.1f} us ({nb/t_s/1e6:5.2f} TB/s)  apply {t_a:7.1f} us ({2*nb/t_a/1e6:5.2f} TB/s)  "
           f"bwd {t_b:7.1f} us ({7*nb/t_b/1e6:5.2f} TB/s of 7N)", flush=True)
 
 for S, C in [(96**3, 48), (48**3, 96), (48**3, 48), (24**3, 192), (24**3, 96), (12**3, 384), (6**3, 768), (27, 768)]:

@@ -357,3 +357,38 @@ def test_window_attention_core(dtype, dims, ws, ss, heads, C):
         assert rel_err(dqb, qbr.grad) < 2 * tol
     else:
         assert float(dqb.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,S,C", [(2, 216, 768), (1, 27, 768), (2, 1728, 384), (2, 210, 6), (1, 512, 48), (2, 513, 48)])
+def test_instnorm_fused_small(dtype, B, S, C):
+    """tensors of <= 512 rows per sample take the one-launch forward / backward kernels; same numbers as the reference
+    formula (and as the chunked kernels just above the threshold)."""
+    ops, L = _ops(), _L()
+    x = rnd(B, S, C, dtype=dtype, seed=5) * 2 + 0.5
+    res = rnd(B, S, C, dtype=dtype, seed=6)
+    dy = rnd(B, S, C, dtype=dtype, seed=7)
+    styles = torch.tensor([1, 0][:B], dtype=torch.int32, device=DEV)
+    gam = [rnd(C, seed=8) * 0.2 + 1, rnd(C, seed=9) * 0.2 + 1]
+    bet = [rnd(C, seed=10) * 0.2, rnd(C, seed=11) * 0.2]
+    ops.begin_step()
+    y, stat = ops.instnorm_fwd(x, B, S, styles, gam, bet, res=res, act=L.ACT_LEAKY, slope=0.01)
+    dg, db = [torch.zeros(C, device=DEV) for _ in range(2)], [torch.zeros(C, device=DEV) for _ in range(2)]
+    dx, dres = ops.instnorm_bwd(dy, y, x, B, S, stat, styles, gam, dg, db, act=L.ACT_LEAKY, slope=0.01, want_dres=True)
+    xf = x.double().clone().requires_grad_(True)
+    rf = res.double().clone().requires_grad_(True)
+    gp = [g.double().clone().requires_grad_(True) for g in gam]
+    bp = [b_.double().clone().requires_grad_(True) for b_ in bet]
+    mu = xf.mean(1, keepdim=True)
+    var = ((xf - mu) ** 2).mean(1, keepdim=True)
+    xh = (xf - mu) / torch.sqrt(var + 1e-5)
+    G = torch.stack([gp[int(s)] for s in styles.tolist()])[:, None]
+    Bt = torch.stack([bp[int(s)] for s in styles.tolist()])[:, None]
+    yr = F.leaky_relu(xh * G + Bt + rf, 0.01)
+    yr.backward(dy.double())
+    tol = 4 * TOL[dtype]
+    assert rel_err(y, yr.float()) < tol
+    assert rel_err(dx, xf.grad.float()) < tol and rel_err(dres, rf.grad.float()) < tol
+    for s_ in set(styles.tolist()):
+        assert rel_err(dg[s_], gp[s_].grad.float()) < tol and rel_err(db[s_], bp[s_].grad.float()) < tol
