@@ -129,6 +129,12 @@ typedef struct {
   const float* bias; int act;
   int accumulate, split_k;
   void* workspace;   /* miseg_gemm_workspace_bytes(p) bytes of scratch (uninitialised) or NULL when that is 0 */
+  /* NT epilogue extras (all [M][N] row views in out_dtype): C = act(z) + res with z = A*B + bias;
+   * epi_mode 1: aux = z (the pre-activation a GELU backward needs), 2: z *= gelu'(aux) (the GELU backward folded into the
+   * data-gradient GEMM of the layer behind it).  MLP: swin_transformer_block.py:97, residuals :241-252. */
+  const void* res; int64_t ldres;
+  void* aux; int64_t ldaux;
+  int epi_mode;
 } miseg_gemm_params;
 size_t miseg_gemm_workspace_bytes(const miseg_gemm_params* p);
 int miseg_gemm(const miseg_gemm_params* p, miseg_stream_t stream);

@@ -24,6 +24,46 @@ template <> struct Mma<float> {
 };
 
 __device__ __forceinline__ float gelu_erf(float t) { return 0.5f * t * (1.f + erff(t * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float t) {
+  return 0.5f * (1.f + erff(t * 0.70710678118654752f)) + t * 0.39894228040143268f * __expf(-0.5f * t * t);
+}
+
+// epilogue of the NT kernels: z = acc + bias ; mode 2: z *= gelu'(aux) ; mode 1: aux = z (the pre-activation, for the backward) ;
+// act ; + res.  aux / res are [M][N] row views in the output dtype.
+struct Epi {
+  const float* bias; int act;
+  const void* res; int64_t ldres;
+  void* aux; int64_t ldaux;
+  int mode;
+};
+
+template <class TO>
+__device__ __forceinline__ float epi_one(float x, int m, int n, const Epi& e) {
+  if (e.bias) x += e.bias[n];
+  if (e.mode == 2) x *= gelu_erf_grad(to_f32(reinterpret_cast<const TO*>(e.aux)[(int64_t)m * e.ldaux + n]));
+  if (e.mode == 1) reinterpret_cast<TO*>(e.aux)[(int64_t)m * e.ldaux + n] = from_f32<TO>(x);
+  if (e.act == MISEG_ACT_GELU) x = gelu_erf(x);
+  if (e.res) x += to_f32(reinterpret_cast<const TO*>(e.res)[(int64_t)m * e.ldres + n]);
+  return x;
+}
+
+// 4 consecutive columns n..n+3 of row m (bf16 output, 8-byte aligned views): bias already added by the caller
+__device__ __forceinline__ f32x4 epi_vec4_bf16(f32x4 v, int m, int n, const Epi& e, bool gelu) {
+  if (e.mode == 2) {
+    const bf16x4 h = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(e.aux) + (int64_t)m * e.ldaux + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)h[r]);
+  }
+  if (e.mode == 1)
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(e.aux) + (int64_t)m * e.ldaux + n) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+  if (gelu) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+  if (e.res) {
+    const bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(e.res) + (int64_t)m * e.ldres + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+  }
+  return v;
+}
 
 // 16-byte chunk of k for row `row` starting at element k: zero-filled outside [0,rows) x [0,K)
 template <class T>
@@ -46,14 +86,12 @@ __device__ __forceinline__ typename Vec16<T>::type load_chunk(const T* base, int
 }
 
 template <class TO>
-__device__ __forceinline__ void store_out4(TO* C, int64_t ldc, int m, int n, int M, int N, f32x4 v, const float* bias, int act, int mode /*0 store,1 add,2 atomic*/) {
+__device__ __forceinline__ void store_out4(TO* C, int64_t ldc, int m, int n, int M, int N, f32x4 v, const Epi& e, int mode /*0 store,1 add,2 atomic*/) {
   if (m >= M) return;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     if (n + r < N) {
-      float x = v[r];
-      if (bias) x += bias[n + r];
-      if (act == MISEG_ACT_GELU) x = gelu_erf(x);
+      const float x = epi_one<TO>(v[r], m, n + r, e);
       TO* p = C + (int64_t)m * ldc + n + r;
       if constexpr (std::is_same<TO, float>::value) {
         if (mode == 2) atomicAdd(p, x);
@@ -69,7 +107,7 @@ __device__ __forceinline__ void store_out4(TO* C, int64_t ldc, int m, int n, int
 // ------------------------------------------------------------------------------------------------ NT
 template <class T, class TO, int NT>
 __global__ void __launch_bounds__(256) gemm_nt_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, TO* __restrict__ C, int64_t ldc,
-                                                      int M, int N, int K, const float* __restrict__ bias, int act, int mode, bool vec_a, bool vec_b,
+                                                      int M, int N, int K, Epi epi, int mode, bool vec_a, bool vec_b,
                                                       int k_per_split) {
   typedef typename Vec16<T>::type VT;
   constexpr int KPC = Mma<T>::KPC;
@@ -133,12 +171,12 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const T* __restrict__ A, i
         for (int nt = 0; nt < NT; ++nt) Mma<T>::run(acc[mt][nt], bfr[nt], af[mt]);
     }
   }
-  const float* b_eff = (blockIdx.z == 0) ? bias : nullptr;
+  if (blockIdx.z != 0) epi.bias = nullptr;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
-      store_out4<TO>(C, ldc, m0 + wave * 32 + mt * 16 + fi, n0 + nt * 16 + fq * 4, M, N, acc[mt][nt], b_eff, act, mode);
+      store_out4<TO>(C, ldc, m0 + wave * 32 + mt * 16 + fi, n0 + nt * 16 + fq * 4, M, N, acc[mt][nt], epi, mode);
 }
 
 // ------------------------------------------------------------------------------------------------ NT, streaming
@@ -151,7 +189,8 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_g;
 
 template <int K16, bool GELU>
 __global__ void __launch_bounds__(256, 2) gemm_nt_stream_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ W, int64_t ldw,
-                                                                bf16* __restrict__ C, int64_t ldc, int M, int N, const float* __restrict__ bias) {
+                                                                bf16* __restrict__ C, int64_t ldc, int M, int N, Epi epi) {
+  const float* bias = epi.bias;
   constexpr int K = K16 * 16, KS32 = K / 32, TAIL = K16 & 1;
   constexpr int ROWB = K * 2 + 16;   // weight row stride in LDS: conflict-free 16-byte fragment reads
   constexpr int NCH = 12;            // n-tiles per accumulator chunk
@@ -214,8 +253,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_stream_kernel(const bf16* __re
             if (j < ncnt) {
               const int n = (nc + j) * 16 + 4 * kg;
               const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbias + n);
-              f32x4 v = acc[mt][j] + b4;
-              if (GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+              const f32x4 v = epi_vec4_bf16(acc[mt][j] + b4, row, n, epi, GELU);
               *reinterpret_cast<bf16x4*>(crow + n) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
             }
           }
@@ -239,7 +277,8 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_stream_kernel(const bf16* __re
 // the four partial tiles meet in LDS.
 template <int NTW, bool GELU>
 __global__ void __launch_bounds__(256) gemm_nt_small_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ W, int64_t ldw, bf16* __restrict__ C,
-                                                            int64_t ldc, int M, int N, int K, const float* __restrict__ bias) {
+                                                            int64_t ldc, int M, int N, int K, Epi epi) {
+  const float* bias = epi.bias;
   __shared__ __attribute__((aligned(16))) float part[4][NTW][64][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, kg = lane >> 4;
   const int m0 = blockIdx.x * 16, n0 = blockIdx.y * 16 * NTW;
@@ -281,7 +320,7 @@ __global__ void __launch_bounds__(256) gemm_nt_small_kernel(const bf16* __restri
     const int m = m0 + fi, n = n0 + nt * 16 + 4 * kg;
     if (m < M && n < N) {
       if (bias) { v[0] += bias[n]; v[1] += bias[n + 1]; v[2] += bias[n + 2]; v[3] += bias[n + 3]; }
-      if (GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+      v = epi_vec4_bf16(v, m, n, epi, GELU);
       *reinterpret_cast<bf16x4*>(C + (int64_t)m * ldc + n) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
     }
   }
@@ -390,7 +429,7 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const T* __restrict__ A, i
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
-      store_out4<TO>(C, ldc, m0 + wm * 32 + mt * 16 + fi, n0 + wn * 32 + nt * 16 + fq * 4, M, N, acc[mt][nt], nullptr, MISEG_ACT_NONE, mode);
+      store_out4<TO>(C, ldc, m0 + wm * 32 + mt * 16 + fi, n0 + wn * 32 + nt * 16 + fq * 4, M, N, acc[mt][nt], Epi{nullptr, MISEG_ACT_NONE, nullptr, 0, nullptr, 0, 0}, mode);
 }
 
 // ------------------------------------------------------------------------------------------------ TN, streaming
@@ -497,7 +536,7 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_stream_kernel(const bf16* __re
       for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt)
-          store_out4<float>(C, ldc, m0 + wmi * 48 + mt * 16 + fi, n0 + wni * 48 + nt * 16 + fq * 4, M, N, acc[mt][nt], nullptr, MISEG_ACT_NONE, mode);
+          store_out4<float>(C, ldc, m0 + wmi * 48 + mt * 16 + fi, n0 + wni * 48 + nt * 16 + fq * 4, M, N, acc[mt][nt], Epi{nullptr, MISEG_ACT_NONE, nullptr, 0, nullptr, 0, 0}, mode);
     }
   }
 }
@@ -585,7 +624,11 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
   if (split > 1 && !f32out) return set_error(MISEG_E_BADARG, "gemm: split_k needs fp32 output");
   if (p->accumulate && !f32out) return set_error(MISEG_E_BADARG, "gemm: accumulate needs fp32 output");
   int mode = split > 1 ? 2 : (p->accumulate ? 1 : 0);
+  const Epi epi{p->bias, p->act, p->res, p->ldres, p->aux, p->ldaux, p->epi_mode};
+  const bool epi_vec_ok = (!p->res || (((uintptr_t)p->res % 8 == 0) && p->ldres % 4 == 0)) && (!p->epi_mode || (((uintptr_t)p->aux % 8 == 0) && p->ldaux % 4 == 0));
   if (p->ta == 0 && p->tb == 0) {
+    if ((p->res || p->epi_mode) && (split > 1 || p->accumulate)) return set_error(MISEG_E_BADARG, "gemm: residual / auxiliary epilogue with split_k or accumulate");
+    if (p->epi_mode && !p->aux) return set_error(MISEG_E_BADARG, "gemm: epi_mode %d needs aux", p->epi_mode);
     const int kstage = 8 * N16;
     int kps = cdiv(cdiv(p->K, split), kstage) * kstage;
     split = cdiv(p->K, kps);
@@ -598,14 +641,14 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
     if (split > 1 && p->act != MISEG_ACT_NONE) return set_error(MISEG_E_BADARG, "gemm: activation with split_k");
     if constexpr (std::is_same<T, bf16>::value && std::is_same<TO, bf16>::value) {
       // deep-stage linears (see gemm_nt_small_kernel)
-      if (split == 1 && !p->accumulate && p->M <= 2048 && p->K % 32 == 0 && p->N % 16 == 0 && al_a && al_b && ((uintptr_t)p->C % 8 == 0) && p->ldc % 4 == 0) {
+      if (split == 1 && !p->accumulate && p->M <= 2048 && p->K % 32 == 0 && p->N % 16 == 0 && al_a && al_b && ((uintptr_t)p->C % 8 == 0) && p->ldc % 4 == 0 && epi_vec_ok) {
         const int ntw = (p->N % 64 == 0 && (int64_t)cdiv(p->M, 16) * (p->N / 64) >= 256) ? 4 : (p->N % 32 == 0 && (int64_t)cdiv(p->M, 16) * (p->N / 32) >= 256) ? 2 : 1;
         dim3 grid(cdiv(p->M, 16), p->N / (16 * ntw));
         const bool ge = p->act == MISEG_ACT_GELU;
 #define SM_CASE(n)                                                                                                                              \
   case n:                                                                                                                                       \
-    if (ge) gemm_nt_small_kernel<n, true><<<grid, 256, 0, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, p->K, p->bias); \
-    else gemm_nt_small_kernel<n, false><<<grid, 256, 0, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, p->K, p->bias); \
+    if (ge) gemm_nt_small_kernel<n, true><<<grid, 256, 0, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, p->K, epi); \
+    else gemm_nt_small_kernel<n, false><<<grid, 256, 0, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, p->K, epi); \
     break;
         switch (ntw) { SM_CASE(1) SM_CASE(2) SM_CASE(4) }
 #undef SM_CASE
@@ -615,7 +658,7 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
       // tall-skinny streaming path (see gemm_nt_stream_kernel)
       const size_t lds = (size_t)p->N * (p->K * 2 + 16) + (size_t)p->N * 4;
       const bool st_ok = split == 1 && !p->accumulate && (p->K == 48 || p->K == 96 || p->K == 192) && p->N % 16 == 0 && p->M >= 4096 && lds <= 96 * 1024 &&
-                         al_a && al_b && ((uintptr_t)p->C % 8 == 0) && p->ldc % 4 == 0;
+                         al_a && al_b && ((uintptr_t)p->C % 8 == 0) && p->ldc % 4 == 0 && epi_vec_ok;
       if (st_ok) {
         const int mtiles = cdiv(p->M, 32);
         int blocks = cdiv(mtiles, 4);
@@ -623,7 +666,7 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
         if (blocks > cap) blocks = cap;
 #define ST_CASE(k16, g)                                                                                                                       \
   hipFuncSetAttribute((const void*)gemm_nt_stream_kernel<k16, g>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
-  gemm_nt_stream_kernel<k16, g><<<blocks, 256, lds, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, p->bias)
+  gemm_nt_stream_kernel<k16, g><<<blocks, 256, lds, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, epi)
         const bool ge = p->act == MISEG_ACT_GELU;
         if (p->K == 48) { if (ge) { ST_CASE(3, true); } else { ST_CASE(3, false); } }
         else if (p->K == 96) { if (ge) { ST_CASE(6, true); } else { ST_CASE(6, false); } }
@@ -637,8 +680,8 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
     dim3 grid(cdiv(p->M, 128), cdiv(p->N, 16 * nt), split);
 #define NT_CASE(n)                                                                                                                          \
   case n:                                                                                                                                   \
-    gemm_nt_kernel<T, TO, n><<<grid, 256, 0, s>>>((const T*)p->A, p->lda, (const T*)p->B, p->ldb, (TO*)p->C, p->ldc, p->M, p->N, p->K, p->bias, \
-                                                  p->act, mode, al_a, al_b, kps);                                                          \
+    gemm_nt_kernel<T, TO, n><<<grid, 256, 0, s>>>((const T*)p->A, p->lda, (const T*)p->B, p->ldb, (TO*)p->C, p->ldc, p->M, p->N, p->K, epi, \
+                                                  mode, al_a, al_b, kps);                                                          \
     break;
     switch (nt) { NT_CASE(1) NT_CASE(2) NT_CASE(3) NT_CASE(4) }
 #undef NT_CASE

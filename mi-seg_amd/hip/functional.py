@@ -151,12 +151,13 @@ def layer_norm(x, gamma, beta, eps=1e-5):
 
 # ----------------------------------------------------------------------------------------------------------------
 class _Linear(Function):
-    """y = x W^T + b on the matrix cores (NT GEMM); dX via the transposed pack, dW via the TN GEMM."""
+    """y = x W^T + b (+ res) on the matrix cores (NT GEMM, the residual add rides in its epilogue); dX via the transposed
+    pack, dW via the TN GEMM."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, res):
         w = ops.cast_matrix(weight, x.dtype)
-        y = ops.gemm_nt(x, w, bias)
+        y = ops.gemm_nt(x, w, bias, res=res)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.params = (weight, bias)
@@ -182,11 +183,54 @@ class _Linear(Function):
                 ops.colsum(dy, out=slot, accumulate=True)
             else:
                 db = ops.colsum(dy)
-        return dx, dw, db
+        return dx, dw, db, (dy if ctx.needs_input_grad[3] else None)
 
 
-def linear(x, weight, bias=None):
-    return _Linear.apply(x, weight, bias)
+def linear(x, weight, bias=None, res=None):
+    return _Linear.apply(x, weight, bias, res)
+
+
+class _Mlp(Function):
+    """y = W2 gelu(W1 x + b1) + b2 (+ res)   (MONAI MLPBlock, swin_transformer_block.py:97 / transformer_block.py:58).
+    Forward: the first GEMM writes the pre-activation h and gelu(h) from one epilogue, the second adds the residual in its
+    epilogue.  Backward: the GELU derivative is the epilogue of the data-gradient GEMM behind it (dh = (dy W2) * gelu'(h))."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, res):
+        h = torch.empty(x.shape[:-1] + (w1.shape[0],), dtype=x.dtype, device=x.device)
+        a = ops.gemm_nt(x, ops.cast_matrix(w1, x.dtype), b1, act=L.ACT_GELU, preact_out=h)
+        y = ops.gemm_nt(a, ops.cast_matrix(w2, x.dtype), b2, res=res)
+        ctx.save_for_backward(x, h, a, w1, w2)
+        ctx.params = (w1, b1, w2, b2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, h, a, w1, w2 = ctx.saved_tensors
+        pw1, pb1, pw2, pb2 = ctx.params
+        dy = _rv(dy)
+        dh = ops.gemm_nt(dy, ops.cast_matrix(w2, dy.dtype, transpose=True), gelu_grad_of=h)
+        dx = ops.gemm_nt(dh, ops.cast_matrix(w1, dy.dtype, transpose=True)) if ctx.needs_input_grad[0] else None
+        out = [dx, None, None, None, None, dy if ctx.needs_input_grad[5] else None]
+        for i, (p, act, g) in enumerate(((pw1, x, dh), (pw2, a, dy))):
+            if ctx.needs_input_grad[1 + 2 * i]:
+                slot = _slot(p)
+                if slot is not None:
+                    ops.gemm_tn(g, act, out=slot, accumulate=True)
+                else:
+                    out[1 + 2 * i] = ops.gemm_tn(g, act).view(p.shape)
+        for i, (p, g) in enumerate(((pb1, dh), (pb2, dy))):
+            if p is not None and ctx.needs_input_grad[2 + 2 * i]:
+                slot = _slot(p)
+                if slot is not None:
+                    ops.colsum(g, out=slot, accumulate=True)
+                else:
+                    out[2 + 2 * i] = ops.colsum(g)
+        return tuple(out)
+
+
+def mlp(x, w1, b1, w2, b2, res=None):
+    return _Mlp.apply(x, w1, b1, w2, b2, res)
 
 
 class _Gelu(Function):

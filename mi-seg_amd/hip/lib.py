@@ -41,7 +41,8 @@ LayernormBwd = _struct("LayernormBwd", [("dy", vp), ("lddy", i64), ("x", vp), ("
                                         ("dgamma", vp), ("dbeta", vp)])
 Gemm = _struct("Gemm", [("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32),
                         ("K", i32), ("ta", i32), ("tb", i32), ("dtype", i32), ("out_dtype", i32), ("bias", vp), ("act", i32),
-                        ("accumulate", i32), ("split_k", i32), ("workspace", vp)])
+                        ("accumulate", i32), ("split_k", i32), ("workspace", vp), ("res", vp), ("ldres", i64), ("aux", vp), ("ldaux", i64),
+                        ("epi_mode", i32)])
 Colsum = _struct("Colsum", [("x", vp), ("ldx", i64), ("rows", i64), ("C", i32), ("dtype", i32), ("out", vp), ("accumulate", i32)])
 Conv3 = _struct("Conv3", [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("wpk", vp), ("B", i32), ("D", i32), ("H", i32),
                           ("W", i32), ("Cin", i32), ("Cout", i32), ("dtype", i32), ("workspace", vp)])

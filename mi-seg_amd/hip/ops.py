@@ -181,8 +181,10 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta):
 
 
 # ------------------------------------------------------------------------------------------ GEMM family
-def gemm_nt(a, w, bias=None, act=L.ACT_NONE, out=None, out_dtype=None, split_k=1):
-    """out[M,N] = a[M,K] @ w[N,K]^T (+bias) ; a rows view, w contiguous [N,K] in a.dtype."""
+def gemm_nt(a, w, bias=None, act=L.ACT_NONE, out=None, out_dtype=None, split_k=1, res=None, preact_out=None, gelu_grad_of=None):
+    """out[M,N] = act(a[M,K] @ w[N,K]^T + bias) + res ; a rows view, w contiguous [N,K] in a.dtype.
+    preact_out: tensor that receives the pre-activation z (for a later GELU backward); gelu_grad_of: pre-activation h of the
+    layer in front, the result is multiplied by gelu'(h) (GELU backward folded into this data-gradient GEMM)."""
     lda, M, K = rows(a)
     N, Kw = w.shape
     if not (Kw == K and w.is_contiguous() and w.dtype == a.dtype):
@@ -192,7 +194,16 @@ def gemm_nt(a, w, bias=None, act=L.ACT_NONE, out=None, out_dtype=None, split_k=1
         out = torch.empty(a.shape[:-1] + (N,), dtype=odt, device=a.device)
     ldc, Mo, No = rows(out)
     assert Mo == M and No == N
-    p = L.Gemm(_ptr(a), lda, _ptr(w), K, _ptr(out), ldc, M, N, K, 0, 0, _dt(a), _dt(out), _ptr(_fp32(bias)), act, 0, split_k, None)
+    assert preact_out is None or gelu_grad_of is None
+    aux = preact_out if preact_out is not None else gelu_grad_of
+    for t in (res, aux):
+        if t is not None:
+            _, Mt, Nt = rows(t)
+            if Mt != M or Nt != N or t.dtype != out.dtype:
+                raise ValueError("gemm_nt: res / aux must be [M, N] row views in the output dtype")
+    p = L.Gemm(_ptr(a), lda, _ptr(w), K, _ptr(out), ldc, M, N, K, 0, 0, _dt(a), _dt(out), _ptr(_fp32(bias)), act, 0, split_k, None,
+               _ptr(res), rows(res)[0] if res is not None else 0, _ptr(aux), rows(aux)[0] if aux is not None else 0,
+               1 if preact_out is not None else 2 if gelu_grad_of is not None else 0)
     _call("miseg_gemm", p)
     return out
 
@@ -207,7 +218,7 @@ def gemm_tn(a, b, out=None, accumulate=False, split_k=0):
         accumulate = False
     assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == M * N
     split_k = max(0, split_k)          # 0: the library picks the kernel and the split over the reduction rows
-    p = L.Gemm(_ptr(a), lda, _ptr(b), ldb, _ptr(out), N, M, N, K, 1, 1, _dt(a), L.F32, None, L.ACT_NONE, int(accumulate), split_k, None)
+    p = L.Gemm(_ptr(a), lda, _ptr(b), ldb, _ptr(out), N, M, N, K, 1, 1, _dt(a), L.F32, None, L.ACT_NONE, int(accumulate), split_k, None, None, 0, None, 0, 0)
     wsb = L.load().miseg_gemm_workspace_bytes(C.byref(p))
     if wsb:
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=a.device)

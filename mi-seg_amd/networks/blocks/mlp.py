@@ -18,6 +18,6 @@ class MLPBlock(nn.Module):
         self.linear1 = nn.Linear(hidden_size, mlp_dim)
         self.linear2 = nn.Linear(mlp_dim, hidden_size)
 
-    def forward(self, x):
-        h = HF.gelu(HF.linear(x, self.linear1.weight, self.linear1.bias))
-        return HF.linear(h, self.linear2.weight, self.linear2.bias)
+    def forward(self, x, res=None):
+        """res: optional residual added in the second GEMM's epilogue (the caller's `x + mlp(norm(x))`)."""
+        return HF.mlp(x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, res)

@@ -49,7 +49,6 @@ class SwinTransformerBlock(nn.Module):
         _, d, h, w, _ = x.shape
         window, shift = get_window_size((d, h, w), self.window_size, self.shift_size)
         xa, xs = HF.fork(x)
-        y = self.attn(apply_norm(self.norm1, xa, styles), window, shift)
-        x = HF.add(xs, y)
+        x = self.attn(apply_norm(self.norm1, xa, styles), window, shift, res=xs)     # x + attn(norm1(x)): add in the proj epilogue
         xa, xs = HF.fork(x)
-        return HF.add(xs, self.mlp(apply_norm(self.norm2, xa, styles)))
+        return self.mlp(apply_norm(self.norm2, xa, styles), res=xs)                  # x + mlp(norm2(x)): add in the fc2 epilogue

@@ -143,6 +143,23 @@ def test_gemm_nt_small_path(M, N, K):
     assert torch.equal(ops.gemm_nt(ai, wi).float(), (ai.float() @ wi.float().t()).to(dtype).float())
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(5000, 192, 48), (216, 1536, 384), (300, 144, 40), (13824, 96, 384)])
+def test_gemm_nt_epilogues(dtype, M, N, K):
+    """residual add, pre-activation side output and GELU-derivative epilogues on every NT kernel (streaming, small, generic)."""
+    ops, L = _ops(), _L()
+    a, w, bias = rnd(M, K, dtype=dtype, seed=21), rnd(N, K, dtype=dtype, seed=22) / K ** 0.5, rnd(N, seed=23)
+    res, h = rnd(M, N, dtype=dtype, seed=24), rnd(M, N, dtype=dtype, seed=25)
+    z = a.float() @ w.float().t() + bias
+    assert rel_err(ops.gemm_nt(a, w, bias, res=res), z + res.float()) < TOL[dtype]
+    pre = torch.empty(M, N, dtype=dtype, device=DEV)
+    y = ops.gemm_nt(a, w, bias, act=L.ACT_GELU, preact_out=pre, res=res)
+    assert rel_err(pre, z) < TOL[dtype] and rel_err(y, F.gelu(z) + res.float()) < TOL[dtype]
+    hf = h.float().clone().requires_grad_(True)
+    F.gelu(hf).backward(torch.ones_like(hf))
+    assert rel_err(ops.gemm_nt(a, w, None, gelu_grad_of=h), (z - bias) * hf.grad) < 2 * TOL[dtype]
+
+
 def test_gemm_nt_exact_integers():
     """asymmetric small-integer operands: catches transposed / permuted MFMA fragment maps exactly."""
     ops = _ops()
