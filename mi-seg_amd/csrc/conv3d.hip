@@ -613,7 +613,22 @@ __global__ void __launch_bounds__(256) conv3_wgrad_reduce_kernel(const float* __
   float acc[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) acc[j] = 0.f;
-  for (int k = k0; k < k1; ++k) {
+  int k = k0;
+  for (; k + 3 < k1; k += 4) {     // 24 independent loads in flight per lane
+    float v[4][6];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* s = base + (int64_t)(k + u) * SLAB;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int e = threadIdx.x + 256 * j;
+        v[u][j] = e < NE ? s[e] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[j] += (v[0][j] + v[1][j]) + (v[2][j] + v[3][j]);
+  }
+  for (; k < k1; ++k) {
     const float* s = base + (int64_t)k * SLAB;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -808,7 +823,7 @@ static int conv3_wgrad_launch(const miseg_conv3_wgrad_params* p, hipStream_t s) 
   const int64_t total = (int64_t)p->Cout * p->Cin * 27;
   if (!p->accumulate) MISEG_REQUIRE(hipMemsetAsync(p->dw, 0, (size_t)total * sizeof(float), s) == hipSuccess, MISEG_E_LAUNCH, "conv3_wgrad: memset");
   const int tiles = p->Cout * ncib;
-  int groups = cdiv(1024, tiles);
+  int groups = cdiv(2048, tiles);
   if (groups > nsplit) groups = nsplit;
   const int spg = cdiv(nsplit, groups);
   groups = cdiv(nsplit, spg);
