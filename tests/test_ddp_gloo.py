@@ -42,6 +42,26 @@ def _worker(rank, world, port, q):
     s0.grad, s1.grad, unused.grad = None, None, None
     allreduce_gradients(params, world)
     ok &= torch.allclose(shared.grad, torch.full((5, 3), 4.0)) and s0.grad is None and s1.grad is None
+    # the training arena (what bench.py uses at N > 1): kernels have already summed into the flat buffer, `_miseg_used` says which slots
+    from mi_seg_amd.runtime.arena import ParamArena
+    for p in params:
+        p.grad = None
+    arena = ParamArena(params, torch.float32)
+    for it in range(2):
+        arena.flat.zero_()
+        for p in params:
+            p._miseg_used = False
+        shared._miseg_grad.fill_(float(rank + 1) + it)
+        shared._miseg_used = True
+        mine_p = s0 if rank == 0 else s1
+        mine_p._miseg_grad.fill_(2.0 if rank == 0 else 6.0)
+        mine_p._miseg_used = True
+        arena.allreduce(world)
+        ok &= torch.allclose(shared.grad, torch.full((5, 3), 1.5 + it))
+        ok &= torch.allclose(s0.grad, torch.full((4,), 1.0)) and torch.allclose(s1.grad, torch.full((4,), 3.0))
+        ok &= unused.grad is None
+        ok &= shared.grad.data_ptr() == shared._miseg_grad.data_ptr()      # p.grad IS the arena slot (no copies)
+    arena.detach()
     # rank sharding: disjoint cover of the concatenated CT+MR index range
     mine = rank_indices(32, world, rank, epoch=1, seed=0)
     gathered = [None] * world
