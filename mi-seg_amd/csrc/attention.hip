@@ -464,9 +464,6 @@ __global__ void __launch_bounds__(256) winattn_fwd_mfma_kernel(const bf16* __res
 //   * rel-pos bias gradients are LDS atomics, flushed once per workgroup.
 // ---------------------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) short s16x4;
-#ifndef ATT_ABL
-#define ATT_ABL 0
-#endif
 
 static constexpr int ATT_NI = 6;                        // key tiles per wave (22 tiles of 16 / 4 waves)
 static constexpr int ATT_DS_LD = 48;                    // byte stride of the wave-private dS tile rows (conflict-free)
@@ -505,7 +502,7 @@ __device__ __forceinline__ void att_load16(const bf16* p, bool vec, float* dst) 
   }
 }
 
-template <bool MASK>
+template <bool MASK, bool DT /* rel-pos table gradient wanted: no per-element branch around its atomics */>
 __global__ void __launch_bounds__(256, 2) winattn_bwd_mfma_kernel(const bf16* __restrict__ qkv, int64_t ldq, const bf16* __restrict__ out, int64_t ldo,
                                                                   const bf16* __restrict__ dout, int64_t lddo, bf16* __restrict__ dqkv, int64_t lddq,
                                                                   const float* __restrict__ qkv_bias, const float* __restrict__ bias_table,
@@ -585,7 +582,7 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd_mfma_kernel(const bf16* __
   // |bin| <= n * bmax; the scale keeps two bits of headroom for the bf16 rounding of the operands.
   const float bmax = sqrtf(__uint_as_float(bound[0]) * __uint_as_float(bound[1])) + __uint_as_float(bound[2]);
   const float fscale = bmax > 0.f ? 536870912.f / ((float)n * bmax) : 0.f;
-  const int lane = tid & 63, wave = tid >> 6, fi = lane & 15, kg = lane >> 4;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fi = lane & 15, kg = lane >> 4;   // wave: scalar, so the per-tile guards are scalar branches
   const int tb = 2 * g.tw - 1;
   const int centre = ((g.tw - 1) * tb + (g.tw - 1)) * tb + (g.tw - 1);
   constexpr float MASKV = -100.f * ATT_LOG2E;
@@ -628,7 +625,7 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd_mfma_kernel(const bf16* __
   char* const ds_w = mytile + fi * ATT_DS_LD + kg * 8;                         // dS[key fi][queries 4kg..]
   const char* const ds_r = mytile + (4 * kg + (fi >> 2)) * ATT_DS_LD + (fi & 3) * 8;   // transposed read: lane (query fi, keys 4kg..)
 
-  for (int qt = 0; qt < ((ATT_ABL & 2) ? 0 : nt16); ++qt) {
+  for (int qt = 0; qt < nt16; ++qt) {
     const int q0 = qt * 16;
     const int4 qc4 = *reinterpret_cast<const int4*>(qcode + q0 + 4 * kg);
     const int qc[4] = {qc4.x, qc4.y, qc4.z, qc4.w};
@@ -649,25 +646,27 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd_mfma_kernel(const bf16* __
       if (wave + 4 * i < nt16) {
         const f32x4 sacc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qfA, kfB[i], nl4, 0, 0, 0);   // rows = queries 4kg+e, col = key fi
         const f32x4 pacc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gfA, vfB[i], nd4, 0, 0, 0);   // dP - delta
-        float pv[4], dsv[4];
+        float pv[4], dsv[4], tbv[4];
+        int bidx[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {      // all four bias gathers first: an LDS read issued behind one of the bin atomics would wait for it
+          bidx[e] = qc[e] - ck[i];
+          tbv[e] = table[bidx[e]];
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int bidx = qc[e] - ck[i];
-          float sc = sacc[e] + ((ATT_ABL & 8) ? 0.f : table[bidx]);
+          float sc = sacc[e] + tbv[e];
           if (MASK) sc += (ql[e] != lk[i]) ? MASKV : 0.f;
           float p = __builtin_amdgcn_exp2f(sc);
           if (i == itail) p = kval ? p : 0.f;
-          const float ds = p * pacc[e];
           pv[e] = p;
-          dsv[e] = ds;
-          if (dbias_table && !(ATT_ABL & 1)) atomicAdd(&dtable[bidx], __float2int_rn(ds * fscale));
+          dsv[e] = p * pacc[e];
         }
         const bf16x4 pb4 = bf16x4{(bf16)pv[0], (bf16)pv[1], (bf16)pv[2], (bf16)pv[3]};
         const bf16x4 db4 = bf16x4{(bf16)dsv[0], (bf16)dsv[1], (bf16)dsv[2], (bf16)dsv[3]};
         const s16x4 pb = __builtin_bit_cast(s16x4, pb4), db = __builtin_bit_cast(s16x4, db4);
         dvt[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gtA, pb, dvt[i], 0, 0, 0);   // dV^T[dim][key] += dO^T P
         dkt[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qtA, db, dkt[i], 0, 0, 0);   // dK^T[dim][key] += Q'^T dS
-        if (!(ATT_ABL & 4)) {
         *reinterpret_cast<bf16x4*>(ds_w) = db4;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -675,6 +674,9 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd_mfma_kernel(const bf16* __
         const s16x4 dsT = att_tr4(ds_r);                                                 // [k = key 4kg..][col = query fi]
         dq = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kA[i], dsT, dq, 0, 0, 0);        // dQ^T[dim][query] += K^T dS^T
         __builtin_amdgcn_wave_barrier();
+        if (DT) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) atomicAdd(&dtable[bidx[e]], __float2int_rn(dsv[e] * fscale));
         }
       }
     }
@@ -818,12 +820,14 @@ extern "C" int miseg_winattn_bwd(const miseg_winattn_bwd_params* p, miseg_stream
     const size_t shm = attn_mfma_bwd_smem(tsize);
     const bool vec = p->f.ldq % 8 == 0 && p->f.ldo % 8 == 0 && p->lddo % 8 == 0 && (uintptr_t)p->f.qkv % 16 == 0 && (uintptr_t)p->f.out % 16 == 0 &&
                      (uintptr_t)p->dout % 16 == 0;
-#define BWD_MFMA(M)                                                                                                                                     \
-  hipFuncSetAttribute((const void*)winattn_bwd_mfma_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                                  \
-  winattn_bwd_mfma_kernel<M><<<grid, 256, shm, s>>>((const bf16*)p->f.qkv, p->f.ldq, (const bf16*)p->f.out, p->f.ldo, (const bf16*)p->dout, p->lddo,   \
-                                                    (bf16*)p->dqkv, p->lddq, p->f.qkv_bias, p->f.bias_table, p->f.lse, p->dqkv_bias, p->dbias_table, g, \
-                                                    tsize, vec)
-    if ((g.sd | g.sh | g.sw) != 0) { BWD_MFMA(true); } else { BWD_MFMA(false); }
+#define BWD_MFMA(M, D)                                                                                                                                  \
+  hipFuncSetAttribute((const void*)winattn_bwd_mfma_kernel<M, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                               \
+  winattn_bwd_mfma_kernel<M, D><<<grid, 256, shm, s>>>((const bf16*)p->f.qkv, p->f.ldq, (const bf16*)p->f.out, p->f.ldo, (const bf16*)p->dout, p->lddo, \
+                                                       (bf16*)p->dqkv, p->lddq, p->f.qkv_bias, p->f.bias_table, p->f.lse, p->dqkv_bias, p->dbias_table, \
+                                                       g, tsize, vec)
+    const bool masked = (g.sd | g.sh | g.sw) != 0;
+    if (p->dbias_table) { if (masked) { BWD_MFMA(true, true); } else { BWD_MFMA(false, true); } }
+    else { if (masked) { BWD_MFMA(true, false); } else { BWD_MFMA(false, false); } }
 #undef BWD_MFMA
     MISEG_LAUNCH_CHECK("winattn_bwd_mfma");
     return MISEG_OK;
