@@ -294,6 +294,24 @@ int miseg_conv3_thin_wgrad(const miseg_conv3_thin_wgrad_params* p, miseg_stream_
  * in_channels = image channels) to the implicit-GEMM kernels above. */
 int miseg_ncdhw_to_rows(const float* x, void* y, int B, int Cin, int64_t S, int CP, int dtype, miseg_stream_t stream);
 
+/* ---- pieces of the MONAI residual UNet (networks/nets/unet.py:169-205, blocks/convolutions.py:173-179,323-329, acti_norm.py:104-110) ----
+ * A stride-2 3x3x3 convolution is the stride-1 kernel followed by `resample2` dir 0 (keep the even voxels); ConvTranspose3d k3 s2 p1 op1 is
+ * `resample2` dir 1 (zero insertion) followed by the stride-1 kernel on the mirrored / channel-swapped pack -- the two directions are each
+ * other's adjoint, so the backward passes are the same two kernels.  D, H, W are the FINE grid; the coarse grid is ceil(./2). */
+typedef struct { const void* x; int64_t ldx; void* y; int64_t ldy; int B, D, H, W, C, dtype, dir; } miseg_resample2_params;
+int miseg_resample2(const miseg_resample2_params* p, miseg_stream_t stream);
+/* y[r][c] = x[r][c] + bias[c]  (Conv3d / ConvTranspose3d bias, convolutions.py:115-139; the gradient is miseg_colsum) */
+typedef struct { const void* x; int64_t ldx; const float* bias; void* y; int64_t ldy; int64_t rows; int C, dtype; } miseg_rowbias_params;
+int miseg_rowbias_add(const miseg_rowbias_params* p, miseg_stream_t stream);
+/* PReLU with ONE learnable slope (torch.nn.PReLU() as built by ADN, acti_norm.py:90-93): y = x > 0 ? x : a x;
+ * backward: dx = dy (x > 0 ? 1 : a), dslope += sum dy x [x <= 0]  (dslope accumulated, may be NULL) */
+typedef struct { const void* x; int64_t ldx; const float* slope; void* y; int64_t ldy; int64_t rows; int C, dtype; } miseg_prelu_fwd_params;
+int miseg_prelu_fwd(const miseg_prelu_fwd_params* p, miseg_stream_t stream);
+typedef struct { const void* dy; int64_t lddy; const void* x; int64_t ldx; const float* slope; void* dx; int64_t lddx; float* dslope; int64_t rows; int C, dtype; } miseg_prelu_bwd_params;
+int miseg_prelu_bwd(const miseg_prelu_bwd_params* p, miseg_stream_t stream);
+/* channels-last rows [B][S][C] (ld) in `dtype`  <->  NCDHW fp32 [B][C][S]: dir 0 rows -> NCDHW (network output), dir 1 NCDHW -> rows */
+int miseg_layout_ncdhw(const void* rows_, int64_t ld, float* ncdhw, int B, int C, int64_t S, int dtype, int dir, miseg_stream_t stream);
+
 /* Output head: Conv3d 1x1x1 + bias from channels-last rows to NCDHW fp32 logits (dynunet_block.py:273-292),
  * and its backward (dx channels-last, dw/dbias accumulated). */
 typedef struct {

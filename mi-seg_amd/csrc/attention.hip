@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(256) winattn_fwd_mfma_kernel(const bf16* __res
   }
   for (int i = tid; i < tsize; i += 256) table[i] = bias_table[(int64_t)i * g.heads + head] * ATT_LOG2E;
   __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
   const int tb = 2 * g.tw - 1;
   const int centre = ((g.tw - 1) * tb + (g.tw - 1)) * tb + (g.tw - 1);
   for (int qt = wave; qt < ntiles; qt += 4) {

@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256) conv3_fwd_kernel(const T* __restrict__ x,
   constexpr int KPC = MmaC<T>::KPC;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   __shared__ int tapoff[32];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bid = blockIdx.x;
   const int bw = bid % g.nbw; bid /= g.nbw;
   const int bh = bid % g.nbh; bid /= g.nbh;
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* lh = lds;                                          // [6][FPS][16]
   char* lw = lds + GPT * FPS * 16;                         // 2 x [12][NROWS][16] (double buffer)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bid = blockIdx.x;
   const int bw = bid % g.nbw; bid /= g.nbw;
   const int bh = bid % g.nbh; bid /= g.nbh;
@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(WG_THREADS) conv3_wgrad_kernel(const T* __rest
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* lx = lds;                          // halo of x : [HROWS][rowb]
   char* ld = lds + HROWS * rowb;           // dy brick  : [NVOX][rowb]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the tap guards around the MFMAs are real branches
   const int pair = blockIdx.y, cob = pair / ncib, cib = pair - cob * ncib;
   const int co0 = cob * WG_CB, ci0 = cib * WG_CB;
   const int fi = lane & 15, fq = lane >> 4;

@@ -1112,6 +1112,178 @@ extern "C" int miseg_param_cast_batch(const miseg_cast_desc* descs, int ndesc, i
   });
 }
 
+namespace miseg {
+// dir 0: y[coarse] = x[2 * coarse]; dir 1: y[fine] = (all coordinates even) ? x[fine / 2] : 0.   One thread per output element vector.
+template <class T, int VEC>
+__global__ void __launch_bounds__(256) resample2_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, int B, int D, int H, int W, int cv,
+                                                        int dir) {
+  const int D2 = (D + 1) / 2, H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+  const int od = dir ? D : D2, oh = dir ? H : H2, ow = dir ? W : W2;
+  const int64_t total = (int64_t)B * od * oh * ow * cv;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % cv) * VEC;
+    int64_t t = i / cv;
+    const int w = (int)(t % ow); t /= ow;
+    const int h = (int)(t % oh); t /= oh;
+    const int d = (int)(t % od);
+    const int b = (int)(t / od);
+    const int64_t orow = ((((int64_t)b * od + d) * oh + h) * ow + w);
+    V<T, VEC> v;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) v.v[k] = 0.f;
+    if (!dir) v.load(x + ((((int64_t)b * D + 2 * d) * H + 2 * h) * W + 2 * w) * ldx + c);
+    else if (!((d | h | w) & 1)) v.load(x + ((((int64_t)b * D2 + d / 2) * H2 + h / 2) * W2 + w / 2) * ldx + c);
+    v.store(y + orow * ldy + c);
+  }
+}
+
+template <class T, int VEC>
+__global__ void __launch_bounds__(256) rowbias_kernel(const T* __restrict__ x, int64_t ldx, const float* __restrict__ bias, T* __restrict__ y, int64_t ldy, int64_t rows,
+                                                      int cv) {
+  const int64_t total = rows * cv;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cv;
+    const int c = (int)(i % cv) * VEC;
+    V<T, VEC> v;
+    v.load(x + r * ldx + c);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) v.v[k] += bias[c + k];
+    v.store(y + r * ldy + c);
+  }
+}
+
+template <class T, int VEC>
+__global__ void __launch_bounds__(256) prelu_fwd_kernel(const T* __restrict__ x, int64_t ldx, const float* __restrict__ slope, T* __restrict__ y, int64_t ldy,
+                                                        int64_t rows, int cv) {
+  const float a = slope[0];
+  const int64_t total = rows * cv;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cv;
+    const int c = (int)(i % cv) * VEC;
+    V<T, VEC> v;
+    v.load(x + r * ldx + c);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) v.v[k] = v.v[k] > 0.f ? v.v[k] : a * v.v[k];
+    v.store(y + r * ldy + c);
+  }
+}
+
+template <class T, int VEC>
+__global__ void __launch_bounds__(256) prelu_bwd_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ x, int64_t ldx, const float* __restrict__ slope,
+                                                        T* __restrict__ dx, int64_t lddx, float* __restrict__ dslope, int64_t rows, int cv) {
+  __shared__ float red[4];
+  const float a = slope[0];
+  const int64_t total = rows * cv;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cv;
+    const int c = (int)(i % cv) * VEC;
+    V<T, VEC> g, xv;
+    g.load(dy + r * lddy + c);
+    xv.load(x + r * ldx + c);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      if (!(xv.v[k] > 0.f)) { acc = fmaf(g.v[k], xv.v[k], acc); g.v[k] *= a; }
+    }
+    g.store(dx + r * lddx + c);
+  }
+  if (dslope) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dslope, (red[0] + red[1]) + (red[2] + red[3]));
+  }
+}
+
+// rows [B][S][C] <-> NCDHW fp32; the tile transpose keeps both sides coalesced
+template <class T>
+__global__ void __launch_bounds__(256) layout_ncdhw_kernel(const T* __restrict__ rows_in, T* __restrict__ rows_out, int64_t ld, const float* __restrict__ nc_in,
+                                                           float* __restrict__ nc_out, int C, int64_t S, int dir) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int64_t s0 = (int64_t)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  if (!dir) {
+    for (int j = ty; j < 32; j += 8)
+      if (s0 + j < S && c0 + tx < C) tile[j][tx] = to_f32(rows_in[((int64_t)b * S + s0 + j) * ld + c0 + tx]);
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+      if (c0 + j < C && s0 + tx < S) nc_out[((int64_t)b * C + c0 + j) * S + s0 + tx] = tile[tx][j];
+  } else {
+    for (int j = ty; j < 32; j += 8)
+      if (c0 + j < C && s0 + tx < S) tile[j][tx] = nc_in[((int64_t)b * C + c0 + j) * S + s0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+      if (s0 + j < S && c0 + tx < C) rows_out[((int64_t)b * S + s0 + j) * ld + c0 + tx] = from_f32<T>(tile[tx][j]);
+  }
+}
+}  // namespace miseg
+
+extern "C" int miseg_resample2(const miseg_resample2_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->x && p->y && p->B > 0 && p->D > 0 && p->H > 0 && p->W > 0 && p->C > 0, MISEG_E_BADARG, "resample2: bad args");
+  DT(p, {
+    constexpr int N = Vec16<T>::N;
+    const bool vec = p->C % N == 0 && p->ldx % N == 0 && p->ldy % N == 0 && al16(p->x) && al16(p->y);
+    const int64_t vox = p->dir ? (int64_t)p->B * p->D * p->H * p->W : (int64_t)p->B * ((p->D + 1) / 2) * ((p->H + 1) / 2) * ((p->W + 1) / 2);
+    if (vec) miseg::resample2_kernel<T, N><<<ew_grid(vox * (p->C / N)), 256, 0, s>>>((const T*)p->x, p->ldx, (T*)p->y, p->ldy, p->B, p->D, p->H, p->W, p->C / N, p->dir);
+    else miseg::resample2_kernel<T, 1><<<ew_grid(vox * p->C), 256, 0, s>>>((const T*)p->x, p->ldx, (T*)p->y, p->ldy, p->B, p->D, p->H, p->W, p->C, p->dir);
+    MISEG_LAUNCH_CHECK("resample2");
+  });
+}
+
+extern "C" int miseg_rowbias_add(const miseg_rowbias_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->x && p->y && p->bias && p->rows > 0 && p->C > 0, MISEG_E_BADARG, "rowbias_add: bad args");
+  DT(p, {
+    constexpr int N = Vec16<T>::N;
+    const bool vec = p->C % N == 0 && p->ldx % N == 0 && p->ldy % N == 0 && al16(p->x) && al16(p->y);
+    if (vec) miseg::rowbias_kernel<T, N><<<ew_grid(p->rows * (p->C / N)), 256, 0, s>>>((const T*)p->x, p->ldx, p->bias, (T*)p->y, p->ldy, p->rows, p->C / N);
+    else miseg::rowbias_kernel<T, 1><<<ew_grid(p->rows * p->C), 256, 0, s>>>((const T*)p->x, p->ldx, p->bias, (T*)p->y, p->ldy, p->rows, p->C);
+    MISEG_LAUNCH_CHECK("rowbias_add");
+  });
+}
+
+extern "C" int miseg_prelu_fwd(const miseg_prelu_fwd_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->x && p->y && p->slope && p->rows > 0 && p->C > 0, MISEG_E_BADARG, "prelu_fwd: bad args");
+  DT(p, {
+    constexpr int N = Vec16<T>::N;
+    const bool vec = p->C % N == 0 && p->ldx % N == 0 && p->ldy % N == 0 && al16(p->x) && al16(p->y);
+    if (vec) miseg::prelu_fwd_kernel<T, N><<<ew_grid(p->rows * (p->C / N)), 256, 0, s>>>((const T*)p->x, p->ldx, p->slope, (T*)p->y, p->ldy, p->rows, p->C / N);
+    else miseg::prelu_fwd_kernel<T, 1><<<ew_grid(p->rows * p->C), 256, 0, s>>>((const T*)p->x, p->ldx, p->slope, (T*)p->y, p->ldy, p->rows, p->C);
+    MISEG_LAUNCH_CHECK("prelu_fwd");
+  });
+}
+
+extern "C" int miseg_prelu_bwd(const miseg_prelu_bwd_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->dy && p->x && p->dx && p->slope && p->rows > 0 && p->C > 0, MISEG_E_BADARG, "prelu_bwd: bad args");
+  DT(p, {
+    constexpr int N = Vec16<T>::N;
+    const bool vec = p->C % N == 0 && p->lddy % N == 0 && p->ldx % N == 0 && p->lddx % N == 0 && al16(p->dy) && al16(p->x) && al16(p->dx);
+    int64_t n = vec ? p->rows * (p->C / N) : p->rows * p->C;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 1024) grid = 1024;       // one atomic per workgroup on the single slope gradient
+    if (vec) miseg::prelu_bwd_kernel<T, N><<<grid, 256, 0, s>>>((const T*)p->dy, p->lddy, (const T*)p->x, p->ldx, p->slope, (T*)p->dx, p->lddx, p->dslope, p->rows, p->C / N);
+    else miseg::prelu_bwd_kernel<T, 1><<<grid, 256, 0, s>>>((const T*)p->dy, p->lddy, (const T*)p->x, p->ldx, p->slope, (T*)p->dx, p->lddx, p->dslope, p->rows, p->C);
+    MISEG_LAUNCH_CHECK("prelu_bwd");
+  });
+}
+
+extern "C" int miseg_layout_ncdhw(const void* rows_, int64_t ld, float* ncdhw, int B, int C, int64_t S, int dtype, int dir, miseg_stream_t s_) {
+  MISEG_REQUIRE(rows_ && ncdhw && B > 0 && C > 0 && S > 0 && ld >= C, MISEG_E_BADARG, "layout_ncdhw: bad args");
+  return dispatch_dtype(dtype, [&](auto* tag) -> int {
+    typedef typename std::remove_pointer<decltype(tag)>::type T;
+    dim3 grid((unsigned)((S + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
+    miseg::layout_ncdhw_kernel<T><<<grid, 256, 0, (hipStream_t)s_>>>((const T*)rows_, (T*)const_cast<void*>(rows_), ld, ncdhw, ncdhw, C, S, dir);
+    MISEG_LAUNCH_CHECK("layout_ncdhw");
+    return MISEG_OK;
+  });
+}
+
 extern "C" int miseg_fill32(void* dst, uint32_t value, size_t n, miseg_stream_t s_) {
   MISEG_REQUIRE(dst || n == 0, MISEG_E_BADARG, "fill32: null pointer");
   if (n == 0) return MISEG_OK;

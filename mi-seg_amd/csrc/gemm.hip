@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const T* __restrict__ A, i
   __shared__ __attribute__((aligned(16))) char lds[(BM + BN) * ROWB];
   char* lA = lds;
   char* lB = lds + BM * ROWB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
   f32x4 acc[2][NT];
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_stream_kernel(const bf16* __re
   constexpr int NCH = 12;            // n-tiles per accumulator chunk
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float* lbias = reinterpret_cast<float*>(lds + (size_t)N * ROWB);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, kg = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fi = lane & 15, kg = lane >> 4;
   for (int c = tid; c < N * (K / 8); c += 256) {
     const int row = c / (K / 8), ch = c - row * (K / 8);
     *reinterpret_cast<bf16x8*>(lds + row * ROWB + ch * 16) = *reinterpret_cast<const bf16x8*>(W + (int64_t)row * ldw + ch * 8);
@@ -280,7 +280,9 @@ __global__ void __launch_bounds__(256) gemm_nt_small_kernel(const bf16* __restri
                                                             int64_t ldc, int M, int N, int K, Epi epi) {
   const float* bias = epi.bias;
   __shared__ __attribute__((aligned(16))) float part[4][NTW][64][4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, kg = lane >> 4;
+  // wave index as a SCALAR: the k-range guards below must be real branches -- an MFMA ignores EXEC, so a guard the compiler
+  // if-converts (it cannot know tid >> 6 is wave-uniform) would let the skipped k-steps accumulate garbage operands
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fi = lane & 15, kg = lane >> 4;
   const int m0 = blockIdx.x * 16, n0 = blockIdx.y * 16 * NTW;
   const int ksteps = K / 32, kpw = (ksteps + 3) / 4;
   const int ks0 = wave * kpw, ks1 = min(ksteps, ks0 + kpw);
@@ -355,7 +357,7 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const T* __restrict__ A, i
   __shared__ __attribute__((aligned(16))) char lds[2 * BK * ROWB];
   char* lA = lds;
   char* lB = lds + BK * ROWB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
@@ -445,7 +447,7 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_stream_kernel(const bf16* __re
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int BM = wm * 48, BN = wn * 48, RA = BM * 2 + 16, RB = BN * 2 + 16;
   const int stage_bytes = BK * (RA + RB);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int t0 = blockIdx.z * tps, t1 = min(T, t0 + tps);
   const int wmi = wave % wm, wni = wave / wm;

@@ -282,6 +282,137 @@ def conv3(x, weight):
     return _Conv3.apply(x, weight)
 
 
+class _Conv3T(Function):
+    """stride-1 3x3x3 convolution with the weight of a ConvTranspose3d ([Cin][Cout][3][3][3]): the forward is the data-gradient
+    kernel of the ordinary convolution whose weight tensor this is (mirrored taps, swapped channels), and vice versa."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        fwdp, bwdp = ops.pack_conv3(weight, x.dtype, ctx.needs_input_grad[0], True)
+        ctx.save_for_backward(x, fwdp)
+        ctx.wshape = weight.shape
+        ctx.params = (weight,)
+        return ops.conv3_fwd(x, bwdp, weight.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, fwdp = ctx.saved_tensors
+        dy = _rv(dy)
+        dx = ops.conv3_fwd(dy, fwdp, ctx.wshape[0]) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            slot = _slot(ctx.params[0])
+            if slot is not None:
+                ops.conv3_wgrad(dy, x, dw=slot, accumulate=True)
+            else:
+                dw = ops.conv3_wgrad(dy, x)          # roles swapped: dw[Cin_t][Cout_t][27]
+        return dx, dw
+
+
+def conv3_transposed_weight(x, weight):
+    return _Conv3T.apply(x, weight)
+
+
+class _Resample2(Function):
+    @staticmethod
+    def forward(ctx, x, up, fine_shape):
+        ctx.up, ctx.fine = up, tuple(x.shape[1:4]) if not up else tuple(fine_shape)
+        return ops.resample2(x, up, fine_shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.resample2(_rv(g), not ctx.up, ctx.fine if not ctx.up else None), None, None
+
+
+def subsample2(x):
+    """x[:, ::2, ::2, ::2, :] -- with conv3 in front: the stride-2 convolution of convolutions.py:131-139."""
+    return _Resample2.apply(x, False, None)
+
+
+def upsample2_zero(x, fine_shape):
+    return _Resample2.apply(x, True, tuple(fine_shape))
+
+
+class _RowBias(Function):
+    @staticmethod
+    def forward(ctx, x, bias):
+        ctx.params = (bias,)
+        return ops.rowbias_add(x, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _rv(g)
+        db = None
+        if ctx.needs_input_grad[1]:
+            slot = _slot(ctx.params[0])
+            if slot is not None:
+                ops.colsum(g, out=slot, accumulate=True)
+            else:
+                db = ops.colsum(g)
+        return g, db
+
+
+def rowbias(x, bias):
+    return x if bias is None else _RowBias.apply(x, bias)
+
+
+class _PReLU(Function):
+    @staticmethod
+    def forward(ctx, x, slope):
+        ctx.save_for_backward(x, slope)
+        ctx.params = (slope,)
+        return ops.prelu_fwd(x, slope)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, slope = ctx.saved_tensors
+        slot = _slot(ctx.params[0]) if ctx.needs_input_grad[1] else None
+        ds = slot if slot is not None else (ops.zeros_f32(slope.shape, x.device) if ctx.needs_input_grad[1] else None)
+        dx = ops.prelu_bwd(_rv(g), x, slope, ds)
+        return dx, None if slot is not None else ds
+
+
+def prelu(x, slope):
+    return _PReLU.apply(x, slope)
+
+
+class _Cat2(Function):
+    """cat([a, b], channel) with our strided-copy kernel; the backward hands out the two halves as views."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ca, cb = a.shape[-1], b.shape[-1]
+        out = torch.empty(a.shape[:-1] + (ca + cb,), dtype=a.dtype, device=a.device)
+        ops.copy2d(a, out[..., :ca])
+        ops.copy2d(b, out[..., ca:])
+        ctx.ca = ca
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _rv(g)
+        return g[..., :ctx.ca], g[..., ctx.ca:]
+
+
+def cat_channels(a, b):
+    return _Cat2.apply(a, b)
+
+
+class _ToNCDHW(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.dtype = x.dtype
+        return ops.rows_to_ncdhw(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.ncdhw_to_rows_exact(g.contiguous().float(), ctx.dtype)
+
+
+def to_ncdhw(x):
+    return _ToNCDHW.apply(x)
+
+
 class _Conv3Thin(Function):
     """stem conv straight from the NCDHW fp32 network input (Cin <= 4): the image becomes channels-last rows of one
     16-byte vector per voxel and goes through the implicit-GEMM kernels (the pack zero-pads Cin the same way)."""

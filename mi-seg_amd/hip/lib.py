@@ -60,6 +60,12 @@ WinattnBwd = _struct("WinattnBwd", [("f", Winattn), ("dout", vp), ("lddo", i64),
 Add = _struct("Add", [("a", vp), ("lda", i64), ("b", vp), ("ldb", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
 Copy2d = _struct("Copy2d", [("src", vp), ("lds", i64), ("sdtype", i32), ("dst", vp), ("ldd", i64), ("ddtype", i32), ("rows", i64), ("C", i32)])
 CastDesc = _struct("CastDesc", [("src", vp), ("dst", vp), ("R", i32), ("C", i32), ("transpose", i32), ("inner", i32), ("outer", i32), ("tile0", i32)])
+Resample2 = _struct("Resample2", [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("B", i32), ("D", i32), ("H", i32), ("W", i32), ("C", i32),
+                                  ("dtype", i32), ("dir", i32)])
+Rowbias = _struct("Rowbias", [("x", vp), ("ldx", i64), ("bias", vp), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
+PreluFwd = _struct("PreluFwd", [("x", vp), ("ldx", i64), ("slope", vp), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
+PreluBwd = _struct("PreluBwd", [("dy", vp), ("lddy", i64), ("x", vp), ("ldx", i64), ("slope", vp), ("dx", vp), ("lddx", i64), ("dslope", vp),
+                                ("rows", i64), ("C", i32), ("dtype", i32)])
 Cast = _struct("Cast", [("src", vp), ("dst", vp), ("R", i32), ("C", i32), ("dtype", i32), ("transpose", i32)])
 GeluFwd = _struct("GeluFwd", [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
 GeluBwd = _struct("GeluBwd", [("dy", vp), ("lddy", i64), ("x", vp), ("ldx", i64), ("dx", vp), ("lddx", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
@@ -122,6 +128,11 @@ PROTOS = {
     "miseg_col2im3": (i32, [C.POINTER(Im2col3), vp]),
     "miseg_fill32": (i32, [vp, C.c_uint32, C.c_size_t, vp]),
     "miseg_param_cast_batch": (i32, [vp, C.c_int, C.c_int, C.c_int, vp]),
+    "miseg_resample2": (i32, [C.POINTER(Resample2), vp]),
+    "miseg_rowbias_add": (i32, [C.POINTER(Rowbias), vp]),
+    "miseg_prelu_fwd": (i32, [C.POINTER(PreluFwd), vp]),
+    "miseg_prelu_bwd": (i32, [C.POINTER(PreluBwd), vp]),
+    "miseg_layout_ncdhw": (i32, [vp, i64, vp, i32, i32, i64, i32, i32, vp]),
     "miseg_ncdhw_to_rows": (i32, [vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, vp]),
 }
 

@@ -359,6 +359,63 @@ def ncdhw_to_rows(x_ncdhw, dtype):
     return y
 
 
+def resample2(x, up, fine_shape=None):
+    """up=False: keep the even voxels of x [B,D,H,W,C] (the stride-2 pick); up=True: zero insertion into a grid of
+    fine_shape = (D, H, W) (ceil(./2) must be x's grid)."""
+    B, d, h, w = _vol(x)
+    ld, n, Cc = rows(x)
+    if up:
+        D, H, W = fine_shape
+        assert ((D + 1) // 2, (H + 1) // 2, (W + 1) // 2) == (d, h, w), (fine_shape, x.shape)
+        out = torch.empty(B, D, H, W, Cc, dtype=x.dtype, device=x.device)
+    else:
+        D, H, W = d, h, w
+        out = torch.empty(B, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2, Cc, dtype=x.dtype, device=x.device)
+    _call("miseg_resample2", L.Resample2(_ptr(x), ld, _ptr(out), rows(out)[0], B, D, H, W, Cc, _dt(x), int(up)))
+    return out
+
+
+def rowbias_add(x, bias):
+    ld, n, Cc = rows(x)
+    y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    _call("miseg_rowbias_add", L.Rowbias(_ptr(x), ld, _ptr(_fp32(bias)), _ptr(y), rows(y)[0], n, Cc, _dt(x)))
+    return y
+
+
+def prelu_fwd(x, slope):
+    ld, n, Cc = rows(x)
+    y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    _call("miseg_prelu_fwd", L.PreluFwd(_ptr(x), ld, _ptr(_fp32(slope)), _ptr(y), rows(y)[0], n, Cc, _dt(x)))
+    return y
+
+
+def prelu_bwd(dy, x, slope, dslope):
+    ld, n, Cc = rows(x)
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    _call("miseg_prelu_bwd", L.PreluBwd(_ptr(dy), rows(dy)[0], _ptr(x), ld, _ptr(_fp32(slope)), _ptr(dx), rows(dx)[0], _ptr(dslope), n, Cc, _dt(x)))
+    return dx
+
+
+def rows_to_ncdhw(x):
+    """channels-last [B,D,H,W,C] in the compute dtype -> NCDHW fp32 (the network output layout)."""
+    B, D, H, W = _vol(x)
+    ld, n, Cc = rows(x)
+    y = torch.empty(B, Cc, D, H, W, dtype=torch.float32, device=x.device)
+    lib = L.load()
+    L.check(lib.miseg_layout_ncdhw(_ptr(x), ld, _ptr(y), B, Cc, D * H * W, _dt(x), 0, _stream()), "layout_ncdhw")
+    return y
+
+
+def ncdhw_to_rows_exact(g, dtype):
+    """NCDHW fp32 -> channels-last rows of exactly C channels in `dtype` (gradient of rows_to_ncdhw)."""
+    B, Cc, D, H, W = g.shape
+    assert g.dtype == torch.float32 and g.is_contiguous()
+    y = torch.empty(B, D, H, W, Cc, dtype=dtype, device=g.device)
+    lib = L.load()
+    L.check(lib.miseg_layout_ncdhw(_ptr(y), Cc, _ptr(g), B, Cc, D * H * W, _dt(y), 1, _stream()), "layout_ncdhw")
+    return y
+
+
 def im2col3(x, adjoint=False, C_out=None):
     """forward: x [B,D,H,W,C] -> col [B,D,H,W,27*C];  adjoint: col -> [B,D,H,W,C]."""
     B, D, H, W = _vol(x)

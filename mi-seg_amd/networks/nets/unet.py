@@ -3,8 +3,13 @@ blocks/acti_norm.py).
 
 BASELINE config 1 is "plumbing, no GPU": constructor, ``from_argparse_args`` (incl. the ``fs * 2**i, i = 1..num_layers`` channel rule
 of unet.py:218-219) and the state_dict layout are reproduced here so checkpoints and the model factory work unchanged; its
-arithmetic is pinned on the CPU oracle (oracle/nets.py::unet_forward, tests/test_oracle_golden.py::test_unet).  The strided 3x3x3 /
-k3-s2 transposed convolutions have no HIP kernel yet, so ``forward`` raises rather than falling back to PyTorch ops."""
+arithmetic is pinned on the CPU oracle (oracle/nets.py::unet_forward, tests/test_oracle_golden.py::test_unet).
+
+The modules below are parameter containers with the reference's child names; ``UNet.forward`` walks them over the HIP kernels on
+channels-last activations: a stride-2 3x3x3 convolution is the stride-1 implicit-GEMM kernel followed by the even-voxel pick
+(``miseg_resample2``), ConvTranspose3d k3 s2 p1 op1 is zero insertion followed by the same kernel on the mirrored / channel-swapped pack
+(exactly each other's adjoints, so the backward passes reuse them); bias, PReLU and the NCDHW output transpose are small row kernels.
+This is the correctness route for the plumbing config, not a tuned one (the strided convolution computes 8x the needed voxels)."""
 import warnings
 from typing import Sequence, Tuple, Union
 
@@ -12,7 +17,9 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ..layers.utils import get_norm_layer
+from ...hip import functional as HF
+from ..layers.utils import apply_norm, get_norm_layer
+from ..norms.conditional_instance_norm import _ConditionalInstanceNorm, styles_to_device
 from ..norms.utils import parse_normalization
 
 __all__ = ["UNet", "Unet"]
@@ -151,9 +158,108 @@ class UNet(nn.Module):
                    norm_down=e, norm_up=d, dropout=args.dropout_rate, bias=not args.no_bias, adn_ordering=args.adn_ordering,
                    freeze_encoder=args.freeze_encoder)
 
+    # ------------------------------------------------------------------------------------------------------------------
+    compute_dtype = torch.float32
+
+    def set_compute_dtype(self, dtype):
+        """torch.float32 (parity mode) or torch.bfloat16 (bf16 activations / MFMA, fp32 statistics and parameters)."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute dtype must be float32 or bfloat16")
+        self.compute_dtype = dtype
+        return self
+
     def forward(self, x: torch.Tensor, modalities=None) -> torch.Tensor:
-        raise NotImplementedError("UNet forward on MI355X needs the strided 3x3x3 / k3-s2 transposed-conv kernels (not built yet); the CPU "
-                                  "plumbing config is served by oracle/nets.py::unet_forward in the tests. No PyTorch fallback is taken.")
+        """x [B, C, D, H, W] float; modalities None | list[int] | int64 Tensor[B].  Returns fp32 logits [B, out, D, H, W]
+        (unet.py:351-353; every grid size must be even wherever a stride-2 layer halves it, as in the reference's configs)."""
+        if not x.is_cuda:
+            raise RuntimeError("UNet (MI355X path) needs a HIP device tensor; there is no CPU fallback")
+        cond = any(isinstance(m, _ConditionalInstanceNorm) for m in self.modules())
+        if cond and modalities is None:
+            raise ValueError("Modalities must be passed to the forward step when a norm type is 'instance_cond'.")
+        styles = styles_to_device(modalities, x.device, x.shape[0]) if modalities is not None else None
+        x = x.float().contiguous()
+        if self.in_channels > 4:
+            raise NotImplementedError("more than 4 image channels")
+        y = _run_block(self.model, None, styles, image=x, dtype=self.compute_dtype)
+        return HF.to_ncdhw(y)
+
+
+def _conv_layer(conv: nn.Module, x, image=None, dtype=None):
+    """nn.Conv3d / nn.ConvTranspose3d container -> channels-last result (convolutions.py:115-139): kernel 3 or 1, stride 1 or 2."""
+    stride = conv.stride[0]
+    k = conv.kernel_size[0]
+    if any(v != stride for v in conv.stride) or any(v != k for v in conv.kernel_size) or stride not in (1, 2) or k not in (1, 3):
+        raise NotImplementedError(f"UNet conv kernel {conv.kernel_size} stride {conv.stride}")
+    if isinstance(conv, nn.ConvTranspose3d):
+        if k != 3:
+            raise NotImplementedError("transposed convolution with kernel != 3")
+        if stride == 2:
+            fine = tuple(2 * v for v in x.shape[1:4])
+            x = HF.upsample2_zero(x, fine)                      # zero insertion, then the stride-1 kernel on the transposed pack
+        y = HF.conv3_transposed_weight(x, conv.weight)
+    else:
+        if image is not None:                                   # first layer: straight from the NCDHW fp32 image
+            y = HF.conv3_thin(image, conv.weight, dtype) if k == 3 else None
+            if y is None:
+                raise NotImplementedError("1x1x1 convolution on the raw image")
+        elif k == 3:
+            y = HF.conv3(x, conv.weight)
+        else:
+            y = HF.conv1(x, conv.weight)
+        if stride == 2:
+            if any(v % 2 for v in y.shape[1:4]):
+                raise NotImplementedError("stride-2 layer on an odd grid")
+            y = HF.subsample2(y)
+    return HF.rowbias(y, conv.bias)
+
+
+def _run_convolution(m: "Convolution", x, styles, image=None, dtype=None):
+    y = _conv_layer(m.conv, x, image, dtype)
+    if hasattr(m, "adn"):
+        for name, child in m.adn.named_children():
+            if name == "N":
+                y = apply_norm(child, y, styles)
+            elif name == "A":
+                y = HF.prelu(y, child.weight)
+            # "D": Dropout(p=0) is the identity (constructors reject p > 0 elsewhere; here p is honoured as 0 only)
+            elif name == "D" and child.p != 0.0:
+                raise NotImplementedError("dropout > 0 is not implemented by the MI355X path")
+    return y
+
+
+def _run_residual_unit(m: "ResidualUnit", x, styles, image=None, dtype=None):
+    if image is not None:
+        res_in = None
+    elif x.requires_grad:
+        x, res_in = HF.fork(x)
+    else:
+        res_in = x
+    cx = x
+    for i, unit in enumerate(m.conv.children()):
+        cx = _run_convolution(unit, cx, styles, image if i == 0 else None, dtype)
+    if isinstance(m.residual, nn.Identity):
+        if image is not None:
+            raise NotImplementedError("identity residual on the raw image")
+        res = res_in
+    else:
+        res = _conv_layer(m.residual, res_in, image, dtype)
+    return HF.add(cx, res)
+
+
+def _run_block(m, x, styles, image=None, dtype=None):
+    """recursive Sequential(down, SkipConnection(sub), up) of unet.py:169-205."""
+    if isinstance(m, ResidualUnit):
+        return _run_residual_unit(m, x, styles, image, dtype)
+    if isinstance(m, Convolution):
+        return _run_convolution(m, x, styles, image, dtype)
+    if isinstance(m, SkipConnection):
+        xa, xs = HF.fork(x) if x.requires_grad else (x, x)
+        return HF.cat_channels(xs, _run_block(m.submodule, xa, styles))          # cat([x, submodule(x)], C) (simplelayers.py:37-38)
+    if isinstance(m, nn.Sequential):
+        for i, child in enumerate(m.children()):
+            x = _run_block(child, x, styles, image if i == 0 else None, dtype)
+        return x
+    raise NotImplementedError(type(m))
 
 
 Unet = UNet

@@ -128,7 +128,7 @@ def test_gemm_nt_streaming_path(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(216, 1536, 384), (216, 384, 1536), (27, 3072, 768), (1728, 768, 192), (1727, 192, 768), (215, 1152, 384), (100, 16, 32),
-                                   (2048, 48, 96)])
+                                   (2048, 48, 96), (512, 256, 128), (512, 256, 96), (512, 256, 64), (2048, 64, 128)])
 def test_gemm_nt_small_path(M, N, K):
     """deep-stage linears (M <= 2048, K % 32 == 0) take the register-direct kernel with K split over the four waves."""
     ops, L = _ops(), _L()

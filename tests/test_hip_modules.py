@@ -206,6 +206,18 @@ def test_swin_unetr_c2_headline(golden, tag, dtype, tol, ce):
     _whole(G, tag, m, tol, dtype, ce)
 
 
+@pytest.mark.parametrize("tag,dtype", [("c1_64", torch.float32), ("cond_32", torch.float32), ("c1_64", torch.bfloat16)])
+def test_unet(golden, tag, dtype):
+    """BASELINE configs[0] on the HIP path: MONAI residual UNet (strided 3^3 convs, ConvTranspose k3 s2, PReLU, biases) fwd + bwd
+    against the fixtures of the reference's own modules."""
+    from mi_seg_amd.networks.nets.unet import UNet
+    G = golden("unet")
+    c = G.meta["cases"][tag]
+    m = UNet(3, 1, 6, channels=c["channels"], strides=c["strides"], num_res_units=c["num_res_units"], act="prelu",
+             norm_down=_norm(c.get("norm_down", "instance")), norm_up=_norm("instance"), dropout=0.0, bias=True, adn_ordering="NDA")
+    _whole(G, tag, m, TOL if dtype == torch.float32 else TOL_BF16, dtype)
+
+
 @pytest.mark.parametrize("tag", ["cond", "layer_bias"])
 def test_transformer_block(golden, tag):
     from mi_seg_amd.networks.blocks.transformer_block import TransformerBlock

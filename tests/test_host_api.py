@@ -51,7 +51,7 @@ def test_unetr_and_unet_layouts(golden):
     case = golden("unet").meta["cases"]["c1_64"]
     assert list(u.state_dict().keys()) == case["state_keys"] and sum(p.numel() for p in u.parameters()) == 4749969
     assert u.channels == [32, 64, 128, 256]                 # fs * 2**i, i = 1..num_layers (reference unet.py:218-219)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):                        # no CPU fallback: the HIP path refuses host tensors
         u(torch.zeros(1, 1, 8, 8, 8))
 
 
