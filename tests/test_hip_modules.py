@@ -240,7 +240,7 @@ def test_unetr_small(golden):
     _whole(G, "small_32", m, TOL)
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL), (torch.bfloat16, TOL_BF16)])
 def test_unetr_c3(golden, dtype, tol):
     """BASELINE configs[2]: C-UNETR (ViT-B/16 encoder, instance_cond), 96^3."""
     from mi_seg_amd.networks.nets.unetr import UNETR
