@@ -349,38 +349,59 @@ __device__ __forceinline__ bf16x8 att_dimmajor_frag(const bf16* base /*[16][ATT_
   return f;
 }
 
+__device__ __forceinline__ void att_load16v(const bf16* p, bool vec, float* dst) {
+  if (vec) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p), b = *reinterpret_cast<const bf16x8*>(p + 8);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { dst[d] = to_f32(a[d]); dst[8 + d] = to_f32(b[d]); }
+  } else {
+#pragma unroll
+    for (int d = 0; d < 16; ++d) dst[d] = to_f32(p[d]);
+  }
+}
+
+template <bool MASK>
 __global__ void __launch_bounds__(256) winattn_fwd_mfma_kernel(const bf16* __restrict__ qkv, int64_t ldq, bf16* __restrict__ out, int64_t ldo,
                                                                const float* __restrict__ qkv_bias, const float* __restrict__ bias_table,
-                                                               float* __restrict__ lse_out, WinGeom g, int tsize) {
+                                                               float* __restrict__ lse_out, WinGeom g, int tsize, bool vec) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16* Qs = reinterpret_cast<bf16*>(smem);                 // [NP][16]  (pre-scaled)
+  bf16* Qs = reinterpret_cast<bf16*>(smem);                 // [NP][16]  (pre-scaled, log2 domain)
   bf16* Ks = Qs + ATT_NP * 16;                              // [NP][16]
   bf16* Vt = Ks + ATT_NP * 16;                              // [16][ATT_VT_LD]
-  int* info = reinterpret_cast<int*>(Vt + 16 * ATT_VT_LD);  // [NP]
-  int* rowq = info + ATT_NP;                                // [NP]
-  float* table = reinterpret_cast<float*>(rowq + ATT_NP);   // [tsize]
+  int* kofs = reinterpret_cast<int*>(Vt + 16 * ATT_VT_LD);  // [NP] rel-pos code * 4 (byte offset into the table)
+  int* klab = kofs + ATT_NP;                                // [NP] region label of the rolled grid
+  int* rowq = klab + ATT_NP;                                // [NP]
+  float* table = reinterpret_cast<float*>(rowq + ATT_NP);   // [tsize] * log2e
   const int win = blockIdx.x, head = blockIdx.y, tid = threadIdx.x;
   const int n = g.n, C = g.C, ntiles = (n + 31) / 32;
-  const bool use_mask = (g.sd | g.sh | g.sw) != 0;
   for (int t = tid; t < ntiles * 32; t += 256) {
     int row = -1, label = 0, code = 0;
     float q[16], k[16], v[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) q[d] = k[d] = v[d] = 0.f;
     if (t < n) {
       token_info(g, win, t, row, label, code);
-      load_head_row<bf16, 4>(qkv, ldq, row, head * 16, qkv_bias, q);
-      load_head_row<bf16, 4>(qkv, ldq, row, C + head * 16, qkv_bias, k);
-      load_head_row<bf16, 4>(qkv, ldq, row, 2 * C + head * 16, qkv_bias, v);
-    } else {
+      if (row >= 0) {
+        const bf16* p = qkv + (int64_t)row * ldq + head * 16;
+        att_load16v(p, vec, q);
+        att_load16v(p + C, vec, k);
+        att_load16v(p + 2 * C, vec, v);
+      } else if (qkv_bias) {
 #pragma unroll
-      for (int d = 0; d < 16; ++d) q[d] = k[d] = v[d] = 0.f;
+        for (int d = 0; d < 16; ++d) { q[d] = qkv_bias[head * 16 + d]; k[d] = qkv_bias[C + head * 16 + d]; v[d] = qkv_bias[2 * C + head * 16 + d]; }
+      }
     }
+    const float qs = g.scale * ATT_LOG2E;
 #pragma unroll
-    for (int d = 0; d < 16; ++d) {
-      Qs[t * 16 + d] = (bf16)(q[d] * (g.scale * ATT_LOG2E));
-      Ks[t * 16 + d] = (bf16)k[d];
-      Vt[d * ATT_VT_LD + t] = (bf16)v[d];
-    }
-    info[t] = att_pack(code, label, t < n);
+    for (int d = 0; d < 16; ++d) q[d] *= qs;
+    *reinterpret_cast<bf16x8*>(Qs + t * 16) = cvt8(q);
+    *reinterpret_cast<bf16x8*>(Qs + t * 16 + 8) = cvt8(q + 8);
+    *reinterpret_cast<bf16x8*>(Ks + t * 16) = cvt8(k);
+    *reinterpret_cast<bf16x8*>(Ks + t * 16 + 8) = cvt8(k + 8);
+#pragma unroll
+    for (int d = 0; d < 16; ++d) Vt[d * ATT_VT_LD + t] = (bf16)v[d];
+    kofs[t] = code * 4;
+    klab[t] = label;
     rowq[t] = row;
   }
   for (int i = tid; i < tsize; i += 256) table[i] = bias_table[(int64_t)i * g.heads + head] * ATT_LOG2E;
@@ -388,11 +409,13 @@ __global__ void __launch_bounds__(256) winattn_fwd_mfma_kernel(const bf16* __res
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
   const int tb = 2 * g.tw - 1;
   const int centre = ((g.tw - 1) * tb + (g.tw - 1)) * tb + (g.tw - 1);
+  const bool ragged = (n & 31) != 0;
+  constexpr float MASKV = -100.f * ATT_LOG2E;
   for (int qt = wave; qt < ntiles; qt += 4) {
     const int qi = qt * 32 + r;
     const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + qi * 16 + 8 * h);
-    const int qinfo = info[qi];
-    const int cq = (qinfo & 0xfff) + centre, lq = (qinfo >> 12) & 31;
+    const char* tq = reinterpret_cast<const char*>(table) + kofs[qi] + 4 * centre;   // table[code_q + centre - code_k]
+    const int lq = klab[qi];
     float m = -INFINITY, l = 0.f;
     f32x16 acc;
 #pragma unroll
@@ -404,21 +427,28 @@ __global__ void __launch_bounds__(256) winattn_fwd_mfma_kernel(const bf16* __res
       for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
       sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, sacc, 0, 0, 0);   // rows = keys, col = this lane's query
       float sv[16];
-      float mx = -INFINITY;
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
-        const int4 ki = *reinterpret_cast<const int4*>(info + kt * 32 + 8 * gq + 4 * h);
-        const int kiv[4] = {ki.x, ki.y, ki.z, ki.w};
+        const int k0 = kt * 32 + 8 * gq + 4 * h;
+        const int4 ko = *reinterpret_cast<const int4*>(kofs + k0);
+        const int kov[4] = {ko.x, ko.y, ko.z, ko.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int w = kiv[e];
-          float sc = sacc[4 * gq + e] + table[cq - (w & 0xfff)];
-          if (use_mask && ((w >> 12) & 31) != lq) sc -= 100.f * ATT_LOG2E;
-          if (!(w >> 20)) sc = -INFINITY;
-          sv[4 * gq + e] = sc;
-          mx = fmaxf(mx, sc);
+        for (int e = 0; e < 4; ++e) sv[4 * gq + e] = sacc[4 * gq + e] + *reinterpret_cast<const float*>(tq - kov[e]);
+        if (MASK) {
+          const int4 kl = *reinterpret_cast<const int4*>(klab + k0);
+          const int klv[4] = {kl.x, kl.y, kl.z, kl.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sv[4 * gq + e] += (klv[e] != lq) ? MASKV : 0.f;
         }
       }
+      if (ragged && kt == ntiles - 1) {      // keys beyond the window (only in the last tile)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (kt * 32 + att_row(i, h) >= n) sv[i] = -INFINITY;
+      }
+      float mx = sv[0];
+#pragma unroll
+      for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sv[i]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mn = fmaxf(m, mx);
       const float alpha = __builtin_amdgcn_exp2f(m - mn);
@@ -738,7 +768,7 @@ static size_t attn_mfma_bwd_smem(int tsize) {
 }
 
 static size_t attn_mfma_fwd_smem(int tsize) {
-  return (size_t)(2 * ATT_NP * 16 + 16 * ATT_VT_LD) * 2 + (size_t)2 * ATT_NP * 4 + (size_t)tsize * 4;
+  return (size_t)(2 * ATT_NP * 16 + 16 * ATT_VT_LD) * 2 + (size_t)3 * ATT_NP * 4 + (size_t)tsize * 4;
 }
 
 }  // namespace miseg
@@ -788,8 +818,14 @@ extern "C" int miseg_winattn_fwd(const miseg_winattn_params* p, miseg_stream_t s
   const int threads = cdiv(g.n, 64) * 64;
   if (p->dtype == MISEG_BF16 && g.hd == 16 && g.n <= ATT_NP && p->bias_table && ((uintptr_t)p->out % 8 == 0) && p->ldo % 4 == 0) {
     const size_t shm = attn_mfma_fwd_smem(tsize);
-    hipFuncSetAttribute((const void*)winattn_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    winattn_fwd_mfma_kernel<<<grid, 256, shm, s>>>((const bf16*)p->qkv, p->ldq, (bf16*)p->out, p->ldo, p->qkv_bias, p->bias_table, p->lse, g, tsize);
+    const bool vec = p->ldq % 8 == 0 && (uintptr_t)p->qkv % 16 == 0;
+    if ((g.sd | g.sh | g.sw) != 0) {
+      hipFuncSetAttribute((const void*)winattn_fwd_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      winattn_fwd_mfma_kernel<true><<<grid, 256, shm, s>>>((const bf16*)p->qkv, p->ldq, (bf16*)p->out, p->ldo, p->qkv_bias, p->bias_table, p->lse, g, tsize, vec);
+    } else {
+      hipFuncSetAttribute((const void*)winattn_fwd_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      winattn_fwd_mfma_kernel<false><<<grid, 256, shm, s>>>((const bf16*)p->qkv, p->ldq, (bf16*)p->out, p->ldo, p->qkv_bias, p->bias_table, p->lse, g, tsize, vec);
+    }
     MISEG_LAUNCH_CHECK("winattn_fwd_mfma");
     return MISEG_OK;
   }
