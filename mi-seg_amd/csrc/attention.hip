@@ -687,11 +687,14 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd_mfma_kernel(const bf16* __
         for (int e = 0; e < 4; ++e) {
           float sc = sacc[e] + tbv[e];
           if (MASK) sc += (ql[e] != lk[i]) ? MASKV : 0.f;
-          float p = __builtin_amdgcn_exp2f(sc);
-          if (i == itail) p = kval ? p : 0.f;
-          pv[e] = p;
-          dsv[e] = p * pacc[e];
+          pv[e] = __builtin_amdgcn_exp2f(sc);
         }
+        if (i == itail) {                  // keys beyond the window: a scalar branch taken by one tile of one wave
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pv[e] = kval ? pv[e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dsv[e] = pv[e] * pacc[e];
         const bf16x4 pb4 = bf16x4{(bf16)pv[0], (bf16)pv[1], (bf16)pv[2], (bf16)pv[3]};
         const bf16x4 db4 = bf16x4{(bf16)dsv[0], (bf16)dsv[1], (bf16)dsv[2], (bf16)dsv[3]};
         const s16x4 pb = __builtin_bit_cast(s16x4, pb4), db = __builtin_bit_cast(s16x4, db4);

@@ -190,35 +190,40 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
   const int fi = lane & 15, fq = lane >> 4;
   const int NCG = CinP / KPC;
 
-  int vbase[4];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) vbase[mt] = ((wave * FHH + mt) * FHW + fi) * 16;
   f32x4 acc[4][NT];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // K walk.  The 27 taps x 6 channel groups of a chunk are enumerated as 54 "combos" c = (kd * 3 + kw) * 6 + cg; a phase
+  // covers combos 4*phase .. +3 (one per MFMA k-group fq) for ALL THREE kh, i.e. 12 (tap, cg) weight groups = 3 MFMA steps.
+  // A lane's combo is fixed for the phase, so its operand for (output row mt, tap row kh) is the halo row mt + kh of ONE
+  // plane: 6 LDS reads serve the 12 (mt, kh) pairs (the tap-major walk needed 12) -- the kernel is LDS-bandwidth bound
+  // (21 ds_read_b128 per 36 MFMAs per wave = 85 % of the LDS peak at the MFMA-bound rate).  Phase 13 holds combos 52, 53 only.
   VT wreg[WLOADS];
-  // per-thread weight item offsets (in 16-byte units) relative to (tap 2*phase, chunk group cg0), computed once
-  int woff[WLOADS];
-  bool wsecond[WLOADS];
+  int wq[WLOADS], wkh[WLOADS], wrow[WLOADS];
 #pragma unroll
   for (int i = 0; i < WLOADS; ++i) {
     const int idx = tid + 256 * i;
     const int gk = idx / NROWS, row = idx - gk * NROWS;
-    wsecond[i] = gk >= GPT;
-    woff[i] = (idx < WITEMS && n0 + row < CoP) ? ((gk / GPT) * NCG + gk % GPT) * CoP + n0 + row : -1;
+    wkh[i] = gk >> 2;
+    wq[i] = gk & 3;
+    wrow[i] = (idx < WITEMS && n0 + row < CoP) ? n0 + row : -1;
   }
   auto wload = [&](int phase, int cg0) {
-    const int64_t pbase = ((int64_t)(2 * phase) * NCG + cg0) * CoP;     // wave-uniform
-    const bool last = 2 * phase + 1 >= 27;
 #pragma unroll
     for (int i = 0; i < WLOADS; ++i) {
       VT v;
 #pragma unroll
       for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(0.f);
-      if (woff[i] >= 0 && !(last && wsecond[i])) v = *reinterpret_cast<const VT*>(wpk + (pbase + woff[i]) * KPC);
+      const int combo = 4 * phase + wq[i];
+      if (wrow[i] >= 0 && combo < 54) {
+        const int kdw = combo / 6, cg = combo - kdw * 6;
+        const int kd = kdw / 3, kw = kdw - kd * 3;
+        const int tap = kd * 9 + wkh[i] * 3 + kw;
+        v = *reinterpret_cast<const VT*>(wpk + (((int64_t)tap * NCG + cg0 + cg) * CoP + wrow[i]) * KPC);
+      }
       wreg[i] = v;
     }
   };
@@ -227,11 +232,6 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
     for (int i = 0; i < WLOADS; ++i)
       if (tid + 256 * i < WITEMS) *reinterpret_cast<VT*>(lw + (buf * WITEMS + tid + 256 * i) * 16) = wreg[i];
   };
-  // per-lane k-step geometry inside a phase: group gi = 4*s + fq -> (tap select, channel-group plane)
-  const int sel1 = fq >= 2;
-  const int cgo0 = fq * FPS * 16;
-  const int cgo1 = (sel1 ? fq - 2 : fq + 4) * FPS * 16;
-  const int cgo2 = (fq + 2) * FPS * 16;
   const int wfrag = fi * 16;
 
   int* rowoff = reinterpret_cast<int*>(lw + WITEMS * 16);   // aliases weight buffer 1 (rewritten by phase 1 => rebuilt per chunk)
@@ -282,32 +282,31 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
     }
     wstore(0);
     __syncthreads();
-    auto frags = [&](int phase, int s, VT (&af)[4], VT (&bfr)[NT]) {
-      const int t0 = 2 * phase, t1 = (2 * phase + 1 < 27) ? 2 * phase + 1 : 2 * phase;
-      const int toff0 = (((t0 / 9) * FHH + (t0 / 3) % 3) * FHW + t0 % 3) * 16;
-      const int toff1 = (((t1 / 9) * FHH + (t1 / 3) % 3) * FHW + t1 % 3) * 16;
-      const int aoff = (s == 0 ? toff0 + cgo0 : s == 1 ? (sel1 ? toff1 : toff0) + cgo1 : toff1 + cgo2);
-      const char* wb = lw + ((phase & 1) * WITEMS + (4 * s + fq) * NROWS) * 16 + wfrag;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bfr[nt] = *reinterpret_cast<const VT*>(wb + nt * 256);
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const VT*>(lh + vbase[mt] + aoff);
-    };
 #pragma unroll 1
     for (int phase = 0; phase < 14; ++phase) {
       if (phase + 1 < 14) wload(phase + 1, c0 / KPC);
-      const int nsteps = phase == 13 ? 2 : 3;
-      VT af[2][4], bfr[2][NT];
-      frags(phase, 0, af[0], bfr[0]);
+      // this lane's combo -> plane and (kd, kw) displacement of its halo rows
+      int combo = 4 * phase + fq;
+      if (combo > 53) combo = 53;                      // the weights of the two missing groups of phase 13 are zero
+      const int kdw = combo / 6, cg = combo - kdw * 6;
+      const int kd = kdw / 3, kw = kdw - kd * 3;
+      const char* abase = lh + (cg * FPS + ((wave + kd) * FHH) * FHW + fi + kw) * 16;
+      const char* wb = lw + ((phase & 1) * WITEMS + fq * NROWS) * 16 + wfrag;
+      VT af[6], bfr[2][NT];
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        if (s < nsteps) {
-          if (s + 1 < nsteps) frags(phase, s + 1, af[(s + 1) & 1], bfr[(s + 1) & 1]);   // next step's operands in flight during the MFMAs
+      for (int nt = 0; nt < NT; ++nt) bfr[0][nt] = *reinterpret_cast<const VT*>(wb + nt * 256);
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt)
+      for (int hh = 0; hh < 6; ++hh) af[hh] = *reinterpret_cast<const VT*>(abase + hh * FHW * 16);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) MmaC<T>::run(acc[mt][nt], bfr[s & 1][nt], af[s & 1][mt]);
+      for (int kh = 0; kh < 3; ++kh) {
+        if (kh + 1 < 3) {   // next step's weight fragments in flight during the MFMAs
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bfr[(kh + 1) & 1][nt] = *reinterpret_cast<const VT*>(wb + ((kh + 1) * 4 * NROWS) * 16 + nt * 256);
         }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) MmaC<T>::run(acc[mt][nt], bfr[kh & 1][nt], af[mt + kh]);
       }
       if (phase + 1 < 14) {
         wstore((phase + 1) & 1);     // buffer last read in phase - 1: every wave is past that phase's barrier
