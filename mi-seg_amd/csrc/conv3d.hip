@@ -252,26 +252,44 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
     {
       constexpr int NIT = (FHROWS * GPT + 255) / 256;      // 16
       VT hv[NIT];
+      int ro[NIT];
 #pragma unroll
-      for (int i = 0; i < NIT; ++i) {
-        const int idx = tid + 256 * i;
+      for (int i = 0; i < NIT; ++i) {                      // the 16 table reads first (in-kernel timestamps: with the read inside the
+        const int idx = tid + 256 * i;                     // load loop every load waited for its own LDS round trip, 4300 cycles)
         const int blk = idx / 48, j = idx - blk * 48;
-        const int cg = j >> 3, row = blk * 8 + (j & 7);
-        VT v;
+        ro[i] = idx < FHROWS * GPT ? rowoff[blk * 8 + (j & 7)] : -1;
+      }
+      if (vec_x && c0 + CHUNK <= Cin) {                    // whole chunk present and 16-byte aligned: branch-free vector loads
 #pragma unroll
-        for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(0.f);
-        const int64_t ro = idx < FHROWS * GPT ? rowoff[row] : -1;
-        if (ro >= 0) {
-          const int c = c0 + cg * KPC;
-          const T* p = x + ro * ldx + c;
-          if (vec_x && c + KPC <= Cin) v = *reinterpret_cast<const VT*>(p);
-          else {
+        for (int i = 0; i < NIT; ++i) {
+          const int idx = tid + 256 * i;
+          const int j = idx % 48;
+          VT v;
 #pragma unroll
-            for (int e = 0; e < KPC; ++e)
-              if (c + e < Cin) v[e] = p[e];
-          }
+          for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(0.f);
+          if (ro[i] >= 0) v = *reinterpret_cast<const VT*>(x + (int64_t)ro[i] * ldx + c0 + (j >> 3) * KPC);
+          hv[i] = v;
         }
-        hv[i] = v;
+      } else {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+          const int idx = tid + 256 * i;
+          const int j = idx % 48;
+          VT v;
+#pragma unroll
+          for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(0.f);
+          if (ro[i] >= 0) {
+            const int c = c0 + (j >> 3) * KPC;
+            const T* p = x + (int64_t)ro[i] * ldx + c;
+            if (vec_x && c + KPC <= Cin) v = *reinterpret_cast<const VT*>(p);
+            else {
+#pragma unroll
+              for (int e = 0; e < KPC; ++e)
+                if (c + e < Cin) v[e] = p[e];
+            }
+          }
+          hv[i] = v;
+        }
       }
 #pragma unroll
       for (int i = 0; i < NIT; ++i) {
