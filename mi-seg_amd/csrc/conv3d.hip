@@ -335,18 +335,20 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
   }
   // epilogue: lane holds channels n0 + 16nt + 4fq .. +3 of voxel (d0 + wave, h0 + mt, w0 + fi)
   const int d = d0 + wave, w = w0 + fi;
+  const int64_t nvox_total = (int64_t)g.B * g.D * g.H * g.W;
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int h = h0 + mt;
     if (d < g.D && h < g.H && w < g.W) {
       const int64_t vox = (((int64_t)b * g.D + d) * g.H + h) * g.W + w;
-      if (scratch) {   // split over channel chunks: fp32 partial sums, converted by a second kernel
+      if (scratch) {   // split over channel chunks: one fp32 partial slab per split (plain stores), summed + converted by a second kernel
+        float* sl = scratch + ((int64_t)blockIdx.z * nvox_total + vox) * Cout;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int co = n0 + nt * 16 + fq * 4;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (co + r < Cout) atomicAdd(scratch + vox * Cout + co + r, acc[mt][nt][r]);
+            if (co + r < Cout) sl[co + r] = acc[mt][nt][r];
         }
         continue;
       }
@@ -372,9 +374,13 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
 }
 
 template <class T>
-__global__ void __launch_bounds__(256) conv3_scratch_to_out_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t ldd, int64_t rows, int C) {
+__global__ void __launch_bounds__(256) conv3_scratch_to_out_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t ldd, int64_t rows, int C, int nslabs) {
   const int64_t total = rows * C;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) dst[(i / C) * ldd + i % C] = from_f32<T>(src[i]);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float a = src[i];
+    for (int z = 1; z < nslabs; ++z) a += src[(int64_t)z * total + i];
+    dst[(i / C) * ldd + i % C] = from_f32<T>(a);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -690,7 +696,7 @@ extern "C" size_t miseg_conv3_fwd_workspace_bytes(int B, int D, int H, int W, in
   if (rowbytes % 96 != 0) return 0;
   int nt, ks;
   fwd96_plan(B * cdiv(D, FBD) * cdiv(H, FBH) * cdiv(W, FBW), Cout, rowbytes / 96, &nt, &ks);
-  return ks > 1 ? (size_t)B * D * H * W * Cout * sizeof(float) : 0;
+  return ks > 1 ? (size_t)ks * B * D * H * W * Cout * sizeof(float) : 0;
 }
 
 template <class T>
@@ -716,7 +722,6 @@ static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
     if (ksplit > 1) {
       MISEG_REQUIRE(p->workspace, MISEG_E_BADARG, "conv3_fwd: workspace required (miseg_conv3_fwd_workspace_bytes)");
       scratch = (float*)p->workspace;
-      MISEG_REQUIRE(hipMemsetAsync(scratch, 0, (size_t)nvox * p->Cout * sizeof(float), s) == hipSuccess, MISEG_E_LAUNCH, "conv3_fwd: memset");
     }
     const bool vec_y = ((uintptr_t)p->y % 16 == 0) && (p->ldy % KPC == 0);
     const int CoP = round_up(p->Cout, 16);
@@ -734,7 +739,7 @@ static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
     if (scratch) {
       int cg = (int)((nvox * p->Cout + 255) / 256);
       if (cg > 4096) cg = 4096;
-      conv3_scratch_to_out_kernel<T><<<cg, 256, 0, s>>>(scratch, (T*)p->y, p->ldy, nvox, p->Cout);
+      conv3_scratch_to_out_kernel<T><<<cg, 256, 0, s>>>(scratch, (T*)p->y, p->ldy, nvox, p->Cout, ksplit);
     }
     MISEG_LAUNCH_CHECK("conv3_fwd96");
     return MISEG_OK;
