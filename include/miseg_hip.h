@@ -146,6 +146,11 @@ int miseg_permute3(const float* src, float* dst, int n0, int n1, int n2, int64_t
 /* column sums: out[c] (+)= sum_r x[r][c]  (bias gradients) */
 typedef struct { const void* x; int64_t ldx; int64_t rows; int C, dtype; float* out; int accumulate; } miseg_colsum_params;
 int miseg_colsum(const miseg_colsum_params* p, miseg_stream_t stream);
+/* up to MISEG_COLSUM_BATCH accumulate-mode column sums (all in `dtype`) in ONE launch: the bias gradients of a backward pass are
+ * small launch-bound reductions, queued by the host and issued together; `descs` is a HOST array (copied into the kernel arguments). */
+#define MISEG_COLSUM_BATCH 32
+typedef struct { const void* x; int64_t ldx; int64_t rows; float* out; int32_t C, block0; } miseg_colsum_desc;
+int miseg_colsum_batch(const miseg_colsum_desc* descs_host, int n, int dtype, miseg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * 3x3x3 convolution, stride 1, zero padding 1, no bias, as an implicit GEMM on the matrix cores.

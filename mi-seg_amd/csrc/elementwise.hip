@@ -787,6 +787,35 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, in
   }
 }
 
+struct ColsumBatch { miseg_colsum_desc d[MISEG_COLSUM_BATCH]; int n; };
+
+// one launch for a list of accumulate-mode column sums: workgroup -> (descriptor, 256-row chunk, tile of 32 channels)
+template <class T>
+__global__ void __launch_bounds__(256) colsum_batch_kernel(ColsumBatch b) {
+  __shared__ float red[8][33];
+  int k = 0;
+  while (k + 1 < b.n && b.d[k + 1].block0 <= (int)blockIdx.x) ++k;
+  const miseg_colsum_desc d = b.d[k];
+  const int ctiles = (d.C + 31) / 32;
+  const int local = blockIdx.x - d.block0;
+  const int ct = local % ctiles;
+  const int64_t r0 = (int64_t)(local / ctiles) * 256, r1 = min(d.rows, r0 + 256);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 channels x 8 row lanes
+  const int c = ct * 32 + tx;
+  const T* x = reinterpret_cast<const T*>(d.x);
+  float acc = 0.f;
+  if (c < d.C)
+    for (int64_t r = r0 + ty; r < r1; r += 8) acc += to_f32(x[r * d.ldx + c]);
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && c < d.C) {
+    float t = 0.f;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) t += red[y][tx];
+    atomicAdd(d.out + c, t);
+  }
+}
+
 }  // namespace miseg
 
 using namespace miseg;
@@ -1280,6 +1309,25 @@ extern "C" int miseg_layout_ncdhw(const void* rows_, int64_t ld, float* ncdhw, i
     dim3 grid((unsigned)((S + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
     miseg::layout_ncdhw_kernel<T><<<grid, 256, 0, (hipStream_t)s_>>>((const T*)rows_, (T*)const_cast<void*>(rows_), ld, ncdhw, ncdhw, C, S, dir);
     MISEG_LAUNCH_CHECK("layout_ncdhw");
+    return MISEG_OK;
+  });
+}
+
+extern "C" int miseg_colsum_batch(const miseg_colsum_desc* descs, int n, int dtype, miseg_stream_t s_) {
+  MISEG_REQUIRE(descs && n > 0 && n <= MISEG_COLSUM_BATCH, MISEG_E_BADARG, "colsum_batch: 1..%d descriptors", MISEG_COLSUM_BATCH);
+  miseg::ColsumBatch b;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    MISEG_REQUIRE(descs[i].x && descs[i].out && descs[i].rows > 0 && descs[i].C > 0, MISEG_E_BADARG, "colsum_batch: descriptor %d", i);
+    b.d[i] = descs[i];
+    b.d[i].block0 = blocks;
+    blocks += (int)((descs[i].rows + 255) / 256) * ((descs[i].C + 31) / 32);
+  }
+  b.n = n;
+  return dispatch_dtype(dtype, [&](auto* tag) -> int {
+    typedef typename std::remove_pointer<decltype(tag)>::type T;
+    miseg::colsum_batch_kernel<T><<<blocks, 256, 0, (hipStream_t)s_>>>(b);
+    MISEG_LAUNCH_CHECK("colsum_batch");
     return MISEG_OK;
   });
 }

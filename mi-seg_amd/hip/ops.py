@@ -233,8 +233,32 @@ def permute3(src, dst, n, strides, accumulate=False):
     return dst
 
 
+COLSUM_QUEUE = None   # list while a training arena defers the bias-gradient reductions of a backward pass (runtime/arena.py)
+
+
+def flush_colsums():
+    """issue the queued accumulate-mode column sums in batches of lib.MISEG_COLSUM_BATCH (one launch each)."""
+    q = COLSUM_QUEUE
+    if not q:
+        return
+    lib = L.load()
+    for dt in {t.dtype for t, _ in q}:
+        items = [(t, o) for t, o in q if t.dtype == dt]
+        for i in range(0, len(items), 32):
+            chunk = items[i:i + 32]
+            descs = (L.ColsumDesc * len(chunk))()
+            for j, (t, o) in enumerate(chunk):
+                ld, n, Cc = rows(t)
+                descs[j] = L.ColsumDesc(_ptr(t), ld, n, _ptr(o), Cc, 0)
+            L.check(lib.miseg_colsum_batch(descs, len(chunk), _dt(chunk[0][0]), _stream()), "colsum_batch")
+    q.clear()
+
+
 def colsum(x, out=None, accumulate=False):
     ld, n, Cc = rows(x)
+    if COLSUM_QUEUE is not None and out is not None and accumulate:
+        COLSUM_QUEUE.append((x, out))          # keeps x alive until the flush
+        return out
     if out is None:
         out = torch.empty(Cc, dtype=torch.float32, device=x.device)
         accumulate = False

@@ -54,6 +54,7 @@ class ParamArena:
         """once per optimisation step, before the forward: recycles the statistics pool, zeroes the gradient arena and
         refreshes every registered parameter re-layout (safe inside hipGraph capture once the table exists)."""
         ops.begin_step()
+        ops.COLSUM_QUEUE = []           # bias-gradient reductions of this step are queued and issued by end_backward()
         self.epoch += 1
         if zero:
             ops.fill32(self.flat)
@@ -143,13 +144,21 @@ class ParamArena:
         self._dirty = False
 
     # ---------------------------------------------------------------------------------------------- after backward
+    def end_backward(self):
+        """issue the queued bias-gradient column sums (one launch per 32); call after loss.backward(), inside the captured
+        region when the step is a hipGraph.  publish() / allreduce() call it too."""
+        ops.flush_colsums()
+        ops.COLSUM_QUEUE = None
+
     def publish(self):
+        self.end_backward()
         for p, v in zip(self.params, self.views):
             p.grad = v if p._miseg_used else None
 
     def allreduce(self, world_size, group=None):
         """mean all-reduce of the arena over RCCL in n_buckets pieces; parameters unused on EVERY rank keep grad None."""
         import torch.distributed as dist
+        self.end_backward()
         self.used_dev.copy_(torch.tensor([int(p._miseg_used) for p in self.params], dtype=torch.int32), non_blocking=True)
         works = [dist.all_reduce(self.used_dev, op=dist.ReduceOp.MAX, group=group, async_op=True)]
         for lo, hi in reversed(self.buckets):
@@ -162,6 +171,7 @@ class ParamArena:
         self.publish()
 
     def detach(self):
+        ops.COLSUM_QUEUE = None
         for p in self.params:
             for a in ("_miseg_grad", "_miseg_arena", "_miseg_used"):
                 if hasattr(p, a):

@@ -36,6 +36,8 @@ class GraphedStep:
             ops.begin_step()
         y = self.model(self.x, (self.styles, host))
         y.backward(self.cot)
+        if self.arena is not None:
+            self.arena.end_backward()
         return y
 
     def _capture(self, host):
