@@ -174,7 +174,8 @@ class _Linear(Function):
         if ctx.needs_input_grad[1]:
             slot = _slot(ctx.params[0])
             if slot is not None:
-                ops.gemm_tn(dy, x, out=slot, accumulate=True)
+                with ops.wgrad_side(dy, x):
+                    ops.gemm_tn(dy, x, out=slot, accumulate=True)
             else:
                 dw = ops.gemm_tn(dy, x).view(weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -216,7 +217,8 @@ class _Mlp(Function):
             if ctx.needs_input_grad[1 + 2 * i]:
                 slot = _slot(p)
                 if slot is not None:
-                    ops.gemm_tn(g, act, out=slot, accumulate=True)
+                    with ops.wgrad_side(g, act):
+                        ops.gemm_tn(g, act, out=slot, accumulate=True)
                 else:
                     out[1 + 2 * i] = ops.gemm_tn(g, act).view(p.shape)
         for i, (p, g) in enumerate(((pb1, dh), (pb2, dy))):
@@ -272,7 +274,8 @@ class _Conv3(Function):
         if ctx.needs_input_grad[1]:
             slot = _slot(ctx.params[0])
             if slot is not None:
-                ops.conv3_wgrad(x, dy, dw=slot, accumulate=True)
+                with ops.wgrad_side(x, dy, kind="conv"):
+                    ops.conv3_wgrad(x, dy, dw=slot, accumulate=True)
             else:
                 dw = ops.conv3_wgrad(x, dy)
         return dx, dw
@@ -303,7 +306,8 @@ class _Conv3T(Function):
         if ctx.needs_input_grad[1]:
             slot = _slot(ctx.params[0])
             if slot is not None:
-                ops.conv3_wgrad(dy, x, dw=slot, accumulate=True)
+                with ops.wgrad_side(x, dy, kind="conv"):
+                    ops.conv3_wgrad(dy, x, dw=slot, accumulate=True)
             else:
                 dw = ops.conv3_wgrad(dy, x)          # roles swapped: dw[Cin_t][Cout_t][27]
         return dx, dw
@@ -429,11 +433,15 @@ class _Conv3Thin(Function):
     @staticmethod
     def backward(ctx, dy):
         (xr,) = ctx.saved_tensors
-        dwp = ops.conv3_wgrad(xr, _rv(dy))                       # [Cout, CP, 3, 3, 3], channels >= Cin are zero
         slot = _slot(ctx.params[0])
         if slot is not None:
-            slot.add_(dwp[:, : ctx.wshape[1]])
+            dy = _rv(dy)
+            with ops.wgrad_side(xr, dy, kind="conv"):
+                dwp = ops.conv3_wgrad(xr, dy)                    # [Cout, CP, 3, 3, 3], channels >= Cin are zero
+                slot.add_(dwp[:, : ctx.wshape[1]])
+                ops._WGRAD_KEEP.append(dwp)
             return None, None, None
+        dwp = ops.conv3_wgrad(xr, _rv(dy))
         return None, dwp[:, : ctx.wshape[1]].contiguous(), None
 
 
@@ -460,7 +468,8 @@ class _Conv1(Function):
         if ctx.needs_input_grad[1]:
             slot = _slot(ctx.params[0])
             if slot is not None:
-                ops.gemm_tn(dy, x, out=slot, accumulate=True)
+                with ops.wgrad_side(dy, x):
+                    ops.gemm_tn(dy, x, out=slot, accumulate=True)
             else:
                 dw = ops.gemm_tn(dy, x).view(weight.shape)
         return dx, dw
@@ -503,11 +512,14 @@ class _UpCat(Function):
         if ctx.needs_input_grad[0]:
             dx = ops.gemm_nt(dy8, ops.cast_matrix(weight, x.dtype, regroup=(8, Cout)))   # [ci][(j,co)]
         if ctx.needs_input_grad[2]:
-            dwf = ops.gemm_tn(dy8, x)                                                 # [(j,co)][ci]
             slot = _slot(ctx.params[0])
             if slot is not None:
-                ops.permute3(dwf, slot, (Cin, Cout, 8), (1, Cin, Cout * Cin), accumulate=True)
+                with ops.wgrad_side(dy8, x):
+                    dwf = ops.gemm_tn(dy8, x)                                             # [(j,co)][ci]
+                    ops.permute3(dwf, slot, (Cin, Cout, 8), (1, Cin, Cout * Cin), accumulate=True)
+                    ops._WGRAD_KEEP.append(dwf)
             else:
+                dwf = ops.gemm_tn(dy8, x)                                                 # [(j,co)][ci]
                 dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
                 ops.permute3(dwf, dw, (Cin, Cout, 8), (1, Cin, Cout * Cin))
         return dx, dskip, dw

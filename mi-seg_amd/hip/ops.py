@@ -233,6 +233,45 @@ def permute3(src, dst, n, strides, accumulate=False):
     return dst
 
 
+WGRAD_STREAM = None   # side HIP stream for the weight-gradient kernels (set by runtime/arena.py); None: launch in line
+WGRAD_KINDS = ("gemm", "conv")
+_WGRAD_KEEP = []      # operands of side-stream launches, kept alive until the join
+
+
+class _Side:
+    """`with ops.wgrad_side(x, dy): <launch a weight-gradient kernel>`: the launch goes to the side stream behind everything
+    already queued on the current one.  Weight gradients only feed the gradient arena, so they are off the critical dX chain
+    of the backward pass and fill the CUs its many small-grid kernels leave idle."""
+
+    def __init__(self, keep, kind):
+        self.side = WGRAD_STREAM if kind in WGRAD_KINDS else None
+        if self.side is not None:
+            _WGRAD_KEEP.extend(keep)
+
+    def __enter__(self):
+        if self.side is not None:
+            self.side.wait_stream(torch.cuda.current_stream())
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.side is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def wgrad_side(*keep, kind="gemm"):
+    return _Side(keep, kind)
+
+
+def join_wgrad():
+    """the current stream waits for the side stream; call once after the backward pass (arena.end_backward)."""
+    if WGRAD_STREAM is not None:
+        torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
+    _WGRAD_KEEP.clear()
+
+
 COLSUM_QUEUE = None   # list while a training arena defers the bias-gradient reductions of a backward pass (runtime/arena.py)
 
 

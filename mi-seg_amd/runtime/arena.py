@@ -17,7 +17,7 @@ from ..hip import ops
 
 
 class ParamArena:
-    def __init__(self, params, dtype=torch.bfloat16, n_buckets=4):
+    def __init__(self, params, dtype=torch.bfloat16, n_buckets=4, overlap_wgrad=False):
         self.params = [p for p in params if p.requires_grad]
         assert self.params, "no trainable parameters"
         dev = self.params[0].device
@@ -32,6 +32,7 @@ class ParamArena:
         for p, v in zip(self.params, self.views):
             p._miseg_grad, p._miseg_arena, p._miseg_used = v, self, False
         self.dtype = dtype
+        self.wgrad_stream = torch.cuda.Stream(device=dev) if (overlap_wgrad and dev.type == "cuda") else None
         self.epoch = 0
         self._req = {}          # (id(p), transpose, inner, outer) -> [param, shadow, filled_epoch]
         self._table = None      # (device descriptor bytes, ndesc, total tiles)
@@ -55,6 +56,8 @@ class ParamArena:
         refreshes every registered parameter re-layout (safe inside hipGraph capture once the table exists)."""
         ops.begin_step()
         ops.COLSUM_QUEUE = []           # bias-gradient reductions of this step are queued and issued by end_backward()
+        ops.WGRAD_STREAM = self.wgrad_stream      # None unless overlap_wgrad: measured SLOWER on one MI355X (93.3 -> 90 patches/s: the
+                                                  # cross-stream edges of the hipGraph cost more than the idle CUs they fill)
         self.epoch += 1
         if zero:
             ops.fill32(self.flat)
@@ -149,6 +152,8 @@ class ParamArena:
         region when the step is a hipGraph.  publish() / allreduce() call it too."""
         ops.flush_colsums()
         ops.COLSUM_QUEUE = None
+        ops.join_wgrad()
+        ops.WGRAD_STREAM = None
 
     def publish(self):
         self.end_backward()
@@ -172,6 +177,8 @@ class ParamArena:
 
     def detach(self):
         ops.COLSUM_QUEUE = None
+        ops.join_wgrad()
+        ops.WGRAD_STREAM = None
         for p in self.params:
             for a in ("_miseg_grad", "_miseg_arena", "_miseg_used"):
                 if hasattr(p, a):
