@@ -139,6 +139,13 @@ typedef struct {
 size_t miseg_gemm_workspace_bytes(const miseg_gemm_params* p);
 int miseg_gemm(const miseg_gemm_params* p, miseg_stream_t stream);
 
+/* up to MISEG_GEMM_GROUP independent TN problems C[M][N] += A[K][M]^T B[K][N] (fp32 C, accumulate mode) in ONE launch: the weight
+ * gradients of the deep stages are a few dozen workgroups each; the host queues them during the backward pass and issues them
+ * together.  `descs` is a HOST array (copied into the kernel arguments). */
+#define MISEG_GEMM_GROUP 24
+typedef struct { const void* A; int64_t lda; const void* B; int64_t ldb; float* C; int64_t ldc; int32_t M, N, K, pad_; } miseg_gemm_tn_desc;
+int miseg_gemm_tn_group(const miseg_gemm_tn_desc* descs_host, int n, int dtype, miseg_stream_t stream);
+
 /* fp32 re-layout: dst[i0][i1][i2] (+)= src[i0*s0 + i1*s1 + i2*s2]  (weight-gradient unpacking) */
 int miseg_permute3(const float* src, float* dst, int n0, int n1, int n2, int64_t s0, int64_t s1, int64_t s2, int accumulate,
                    miseg_stream_t stream);

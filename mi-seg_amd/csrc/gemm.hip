@@ -348,8 +348,8 @@ template <> struct TnFrag<bf16> {
 };
 
 template <class T, class TO>
-__global__ void __launch_bounds__(256) gemm_tn_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, TO* __restrict__ C, int64_t ldc,
-                                                      int M, int N, int K, int mode, bool vec_a, bool vec_b, int k_per_split) {
+__device__ __forceinline__ void gemm_tn_body(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, TO* __restrict__ C, int64_t ldc,
+                                             int M, int N, int K, int mode, bool vec_a, bool vec_b, int k_per_split, int bx, int by, int bz) {
   typedef typename Vec16<T>::type VT;
   constexpr int KPC = Mma<T>::KPC;     // elements per 16-byte chunk (here along m / n)
   constexpr int BM = 64, BN = 64, BK = std::is_same<T, bf16>::value ? 128 : 64;   // k rows per stage
@@ -359,8 +359,8 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const T* __restrict__ A, i
   char* lB = lds + BK * ROWB;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
+  const int m0 = bx * BM, n0 = by * BN;
+  const int kbeg = bz * k_per_split, kend = min(K, kbeg + k_per_split);
   f32x4 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -432,6 +432,29 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const T* __restrict__ A, i
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
       store_out4<TO>(C, ldc, m0 + wm * 32 + mt * 16 + fi, n0 + wn * 32 + nt * 16 + fq * 4, M, N, acc[mt][nt], Epi{nullptr, MISEG_ACT_NONE, nullptr, 0, nullptr, 0, 0}, mode);
+}
+
+template <class T, class TO>
+__global__ void __launch_bounds__(256) gemm_tn_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, TO* __restrict__ C, int64_t ldc,
+                                                      int M, int N, int K, int mode, bool vec_a, bool vec_b, int k_per_split) {
+  gemm_tn_body<T, TO>(A, lda, B, ldb, C, ldc, M, N, K, mode, vec_a, vec_b, k_per_split, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// grouped form: a list of independent TN problems (the weight gradients of the deep stages, a few dozen workgroups each)
+// in ONE launch; descriptors travel in the kernel arguments
+struct TnGroup {
+  struct P { const void* A; int64_t lda; const void* B; int64_t ldb; float* C; int64_t ldc; int M, N, K, kps, gx, gy, block0, mode; bool va, vb; } p[MISEG_GEMM_GROUP];
+  int n;
+};
+
+template <class T>
+__global__ void __launch_bounds__(256) gemm_tn_group_kernel(TnGroup g) {
+  int k = 0;
+  while (k + 1 < g.n && g.p[k + 1].block0 <= (int)blockIdx.x) ++k;
+  const TnGroup::P& q = g.p[k];
+  const int local = blockIdx.x - q.block0;
+  const int bx = local % q.gx, by = (local / q.gx) % q.gy, bz = local / (q.gx * q.gy);
+  gemm_tn_body<T, float>((const T*)q.A, q.lda, (const T*)q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, q.mode, q.va, q.vb, q.kps, bx, by, bz);
 }
 
 // ------------------------------------------------------------------------------------------------ TN, streaming
@@ -747,6 +770,36 @@ extern "C" int miseg_gemm(const miseg_gemm_params* p, miseg_stream_t s_) {
   if (p->dtype == MISEG_BF16 && p->out_dtype == MISEG_BF16) return launch_gemm<bf16, bf16>(p, s);
   if (p->dtype == MISEG_BF16 && p->out_dtype == MISEG_F32) return launch_gemm<bf16, float>(p, s);
   return set_error(MISEG_E_BADARG, "gemm: dtype %d -> %d", p->dtype, p->out_dtype);
+}
+
+extern "C" int miseg_gemm_tn_group(const miseg_gemm_tn_desc* descs, int n, int dtype, miseg_stream_t s_) {
+  MISEG_REQUIRE(descs && n > 0 && n <= MISEG_GEMM_GROUP, MISEG_E_BADARG, "gemm_tn_group: 1..%d problems", MISEG_GEMM_GROUP);
+  MISEG_REQUIRE(dtype == MISEG_BF16 || dtype == MISEG_F32, MISEG_E_BADARG, "gemm_tn_group: dtype %d", dtype);
+  TnGroup g;
+  g.n = n;
+  int blocks = 0;
+  const int n16 = dtype == MISEG_F32 ? 4 : 8, bk = dtype == MISEG_F32 ? 64 : 128;
+  for (int i = 0; i < n; ++i) {
+    const miseg_gemm_tn_desc& d = descs[i];
+    MISEG_REQUIRE(d.A && d.B && d.C && d.M > 0 && d.N > 0 && d.K > 0, MISEG_E_BADARG, "gemm_tn_group: problem %d", i);
+    TnGroup::P& q = g.p[i];
+    q.A = d.A; q.lda = d.lda; q.B = d.B; q.ldb = d.ldb; q.C = d.C; q.ldc = d.ldc; q.M = d.M; q.N = d.N; q.K = d.K;
+    q.gx = cdiv(d.M, 64); q.gy = cdiv(d.N, 64);
+    int split = cdiv(d.K, 512);
+    if (split > 1024 / (q.gx * q.gy)) split = 1024 / (q.gx * q.gy);
+    if (split < 1) split = 1;
+    q.kps = cdiv(cdiv(d.K, split), bk) * bk;
+    split = cdiv(d.K, q.kps);
+    q.mode = split > 1 ? 2 : 1;                      // always accumulate into C: atomics when the reduction is split
+    q.va = ((uintptr_t)d.A % 16 == 0) && (d.lda % n16 == 0);
+    q.vb = ((uintptr_t)d.B % 16 == 0) && (d.ldb % n16 == 0);
+    q.block0 = blocks;
+    blocks += q.gx * q.gy * split;
+  }
+  if (dtype == MISEG_BF16) gemm_tn_group_kernel<bf16><<<blocks, 256, 0, (hipStream_t)s_>>>(g);
+  else gemm_tn_group_kernel<float><<<blocks, 256, 0, (hipStream_t)s_>>>(g);
+  MISEG_LAUNCH_CHECK("gemm_tn_group");
+  return MISEG_OK;
 }
 
 extern "C" int miseg_permute3(const float* src, float* dst, int n0, int n1, int n2, int64_t s0, int64_t s1, int64_t s2, int accumulate, miseg_stream_t s_) {

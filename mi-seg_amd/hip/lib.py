@@ -44,6 +44,7 @@ Gemm = _struct("Gemm", [("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", 
                         ("accumulate", i32), ("split_k", i32), ("workspace", vp), ("res", vp), ("ldres", i64), ("aux", vp), ("ldaux", i64),
                         ("epi_mode", i32)])
 ColsumDesc = _struct("ColsumDesc", [("x", vp), ("ldx", i64), ("rows", i64), ("out", vp), ("C", i32), ("block0", i32)])
+GemmTnDesc = _struct("GemmTnDesc", [("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32), ("K", i32), ("pad_", i32)])
 Colsum = _struct("Colsum", [("x", vp), ("ldx", i64), ("rows", i64), ("C", i32), ("dtype", i32), ("out", vp), ("accumulate", i32)])
 Conv3 = _struct("Conv3", [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("wpk", vp), ("B", i32), ("D", i32), ("H", i32),
                           ("W", i32), ("Cin", i32), ("Cout", i32), ("dtype", i32), ("workspace", vp)])
@@ -103,6 +104,7 @@ PROTOS = {
     "miseg_gemm": (i32, [C.POINTER(Gemm), vp]),
     "miseg_permute3": (i32, [vp, vp, i32, i32, i32, i64, i64, i64, i32, vp]),
     "miseg_colsum": (i32, [C.POINTER(Colsum), vp]),
+    "miseg_gemm_tn_group": (i32, [vp, i32, i32, vp]),
     "miseg_colsum_batch": (i32, [vp, i32, i32, vp]),
     "miseg_conv3_fwd_workspace_bytes": (C.c_size_t, [i32, i32, i32, i32, i32, i32, i32]),
     "miseg_conv3_fwd": (i32, [C.POINTER(Conv3), vp]),

@@ -217,6 +217,9 @@ def gemm_tn(a, b, out=None, accumulate=False, split_k=0):
         out = torch.empty(M, N, dtype=torch.float32, device=a.device)
         accumulate = False
     assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == M * N
+    if GEMM_TN_QUEUE is not None and accumulate and split_k <= 0 and not (M % 48 == 0 and N % 48 == 0 and K >= 2048 and a.dtype == torch.bfloat16):
+        GEMM_TN_QUEUE.append((a, b, out))      # small problem: grouped launch at the end of the backward pass
+        return out
     split_k = max(0, split_k)          # 0: the library picks the kernel and the split over the reduction rows
     p = L.Gemm(_ptr(a), lda, _ptr(b), ldb, _ptr(out), N, M, N, K, 1, 1, _dt(a), L.F32, None, L.ACT_NONE, int(accumulate), split_k, None, None, 0, None, 0, 0)
     wsb = L.load().miseg_gemm_workspace_bytes(C.byref(p))
@@ -273,6 +276,27 @@ def join_wgrad():
 
 
 COLSUM_QUEUE = None   # list while a training arena defers the bias-gradient reductions of a backward pass (runtime/arena.py)
+
+
+GEMM_TN_QUEUE = None   # likewise for the small weight-gradient GEMMs (one grouped launch per 24)
+
+
+def flush_gemm_tn():
+    q = GEMM_TN_QUEUE
+    if not q:
+        return
+    lib = L.load()
+    for dt in {a.dtype for a, _, _ in q}:
+        items = [it for it in q if it[0].dtype == dt]
+        for i in range(0, len(items), 24):
+            chunk = items[i:i + 24]
+            descs = (L.GemmTnDesc * len(chunk))()
+            for j, (a, b, out) in enumerate(chunk):
+                lda, K, M = rows(a)
+                ldb, _, N = rows(b)
+                descs[j] = L.GemmTnDesc(_ptr(a), lda, _ptr(b), ldb, _ptr(out), N, M, N, K, 0)
+            L.check(lib.miseg_gemm_tn_group(descs, len(chunk), _dt(chunk[0][0]), _stream()), "gemm_tn_group")
+    q.clear()
 
 
 def flush_colsums():

@@ -56,6 +56,7 @@ class ParamArena:
         refreshes every registered parameter re-layout (safe inside hipGraph capture once the table exists)."""
         ops.begin_step()
         ops.COLSUM_QUEUE = []           # bias-gradient reductions of this step are queued and issued by end_backward()
+        ops.GEMM_TN_QUEUE = []          # so are the small weight-gradient GEMMs
         ops.WGRAD_STREAM = self.wgrad_stream      # None unless overlap_wgrad: measured SLOWER on one MI355X (93.3 -> 90 patches/s: the
                                                   # cross-stream edges of the hipGraph cost more than the idle CUs they fill)
         self.epoch += 1
@@ -150,6 +151,8 @@ class ParamArena:
     def end_backward(self):
         """issue the queued bias-gradient column sums (one launch per 32); call after loss.backward(), inside the captured
         region when the step is a hipGraph.  publish() / allreduce() call it too."""
+        ops.flush_gemm_tn()
+        ops.GEMM_TN_QUEUE = None
         ops.flush_colsums()
         ops.COLSUM_QUEUE = None
         ops.join_wgrad()
@@ -177,6 +180,7 @@ class ParamArena:
 
     def detach(self):
         ops.COLSUM_QUEUE = None
+        ops.GEMM_TN_QUEUE = None
         ops.join_wgrad()
         ops.WGRAD_STREAM = None
         for p in self.params:
