@@ -135,13 +135,20 @@ typedef struct {
   const void* res; int64_t ldres;
   void* aux; int64_t ldaux;
   int epi_mode;
+  int defer_reduce;  /* TN streaming path only: leave the per-split partial tiles in `workspace`; the caller sums them later with
+                      * miseg_gemm_tn_reduce_batch (miseg_gemm_tn_splits(p) tells how many there are) */
 } miseg_gemm_params;
+int miseg_gemm_tn_splits(const miseg_gemm_params* p);   /* > 1: partial tiles [splits][M][N] fp32 in the workspace */
 size_t miseg_gemm_workspace_bytes(const miseg_gemm_params* p);
 int miseg_gemm(const miseg_gemm_params* p, miseg_stream_t stream);
 
 /* up to MISEG_GEMM_GROUP independent TN problems C[M][N] += A[K][M]^T B[K][N] (fp32 C, accumulate mode) in ONE launch: the weight
  * gradients of the deep stages are a few dozen workgroups each; the host queues them during the backward pass and issues them
  * together.  `descs` is a HOST array (copied into the kernel arguments). */
+typedef struct { const float* partial; float* C; int64_t ldc; int32_t M, N, splits, block0; } miseg_tn_reduce_desc;
+#define MISEG_TN_REDUCE_BATCH 32
+/* C[m][n] += sum over splits of partial[s][m][n] for up to MISEG_TN_REDUCE_BATCH deferred reductions in one launch (HOST descriptors) */
+int miseg_gemm_tn_reduce_batch(const miseg_tn_reduce_desc* descs_host, int n, miseg_stream_t stream);
 #define MISEG_GEMM_GROUP 24
 typedef struct { const void* A; int64_t lda; const void* B; int64_t ldb; float* C; int64_t ldc; int32_t M, N, K, pad_; } miseg_gemm_tn_desc;
 int miseg_gemm_tn_group(const miseg_gemm_tn_desc* descs_host, int n, int dtype, miseg_stream_t stream);

@@ -726,7 +726,7 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
         hipFuncSetAttribute((const void*)gemm_tn_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         gemm_tn_stream_kernel<<<dim3(pl.gx, pl.gy, pl.splits), 256, lds, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (float*)p->C, p->ldc, p->M, p->N,
                                                                              p->K, pl.wm, pl.wn, pl.tps, p->accumulate ? 1 : 0, partial);
-        if (partial) {
+        if (partial && !p->defer_reduce) {
           const int groups = cdiv(pl.splits, TN_RG);
           if (groups > 1 && !p->accumulate) {   // the groups meet in atomics
             if (p->ldc == p->N) { if (hipMemsetAsync(p->C, 0, (size_t)p->M * p->N * sizeof(float), s) != hipSuccess) return set_error(MISEG_E_LAUNCH, "gemm: memset"); }
@@ -770,6 +770,56 @@ extern "C" int miseg_gemm(const miseg_gemm_params* p, miseg_stream_t s_) {
   if (p->dtype == MISEG_BF16 && p->out_dtype == MISEG_BF16) return launch_gemm<bf16, bf16>(p, s);
   if (p->dtype == MISEG_BF16 && p->out_dtype == MISEG_F32) return launch_gemm<bf16, float>(p, s);
   return set_error(MISEG_E_BADARG, "gemm: dtype %d -> %d", p->dtype, p->out_dtype);
+}
+
+extern "C" int miseg_gemm_tn_splits(const miseg_gemm_params* p) {
+  TnStreamPlan pl;
+  return (p && tn_stream_plan(p, &pl)) ? pl.splits : 0;
+}
+
+namespace miseg {
+struct TnReduceBatch { miseg_tn_reduce_desc d[MISEG_TN_REDUCE_BATCH]; int n; };
+// one thread per 4 consecutive n of one problem; C += sum over all splits (single writer per element: no atomics)
+__global__ void __launch_bounds__(256) gemm_tn_reduce_batch_kernel(TnReduceBatch b) {
+  int k = 0;
+  while (k + 1 < b.n && b.d[k + 1].block0 <= (int)blockIdx.x) ++k;
+  const miseg_tn_reduce_desc d = b.d[k];
+  const int i = (blockIdx.x - d.block0) * 256 + threadIdx.x;
+  if (i >= d.M * (d.N / 4)) return;
+  const int m = i / (d.N / 4), n = (i - m * (d.N / 4)) * 4;
+  const float* p = d.partial + (int64_t)m * d.N + n;
+  const int64_t stride = (int64_t)d.M * d.N;
+  f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  int s = 0;
+  for (; s + 3 < d.splits; s += 4) {
+    a0 += *reinterpret_cast<const f32x4*>(p + (s + 0) * stride);
+    a1 += *reinterpret_cast<const f32x4*>(p + (s + 1) * stride);
+    a2 += *reinterpret_cast<const f32x4*>(p + (s + 2) * stride);
+    a3 += *reinterpret_cast<const f32x4*>(p + (s + 3) * stride);
+  }
+  for (; s < d.splits; ++s) a0 += *reinterpret_cast<const f32x4*>(p + s * stride);
+  const f32x4 v = (a0 + a1) + (a2 + a3);
+  float* c = d.C + (int64_t)m * d.ldc + n;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c[r] += v[r];
+}
+}  // namespace miseg
+
+extern "C" int miseg_gemm_tn_reduce_batch(const miseg_tn_reduce_desc* descs, int n, miseg_stream_t s_) {
+  MISEG_REQUIRE(descs && n > 0 && n <= MISEG_TN_REDUCE_BATCH, MISEG_E_BADARG, "gemm_tn_reduce_batch: 1..%d reductions", MISEG_TN_REDUCE_BATCH);
+  miseg::TnReduceBatch b;
+  b.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    MISEG_REQUIRE(descs[i].partial && descs[i].C && descs[i].M > 0 && descs[i].N > 0 && descs[i].N % 4 == 0 && descs[i].splits > 0, MISEG_E_BADARG,
+                  "gemm_tn_reduce_batch: descriptor %d", i);
+    b.d[i] = descs[i];
+    b.d[i].block0 = blocks;
+    blocks += cdiv(descs[i].M * (descs[i].N / 4), 256);
+  }
+  miseg::gemm_tn_reduce_batch_kernel<<<blocks, 256, 0, (hipStream_t)s_>>>(b);
+  MISEG_LAUNCH_CHECK("gemm_tn_reduce_batch");
+  return MISEG_OK;
 }
 
 extern "C" int miseg_gemm_tn_group(const miseg_gemm_tn_desc* descs, int n, int dtype, miseg_stream_t s_) {

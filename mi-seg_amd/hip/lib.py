@@ -42,7 +42,8 @@ LayernormBwd = _struct("LayernormBwd", [("dy", vp), ("lddy", i64), ("x", vp), ("
 Gemm = _struct("Gemm", [("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32),
                         ("K", i32), ("ta", i32), ("tb", i32), ("dtype", i32), ("out_dtype", i32), ("bias", vp), ("act", i32),
                         ("accumulate", i32), ("split_k", i32), ("workspace", vp), ("res", vp), ("ldres", i64), ("aux", vp), ("ldaux", i64),
-                        ("epi_mode", i32)])
+                        ("epi_mode", i32), ("defer_reduce", i32)])
+TnReduceDesc = _struct("TnReduceDesc", [("partial", vp), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32), ("splits", i32), ("block0", i32)])
 ColsumDesc = _struct("ColsumDesc", [("x", vp), ("ldx", i64), ("rows", i64), ("out", vp), ("C", i32), ("block0", i32)])
 GemmTnDesc = _struct("GemmTnDesc", [("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32), ("K", i32), ("pad_", i32)])
 Colsum = _struct("Colsum", [("x", vp), ("ldx", i64), ("rows", i64), ("C", i32), ("dtype", i32), ("out", vp), ("accumulate", i32)])
@@ -104,6 +105,8 @@ PROTOS = {
     "miseg_gemm": (i32, [C.POINTER(Gemm), vp]),
     "miseg_permute3": (i32, [vp, vp, i32, i32, i32, i64, i64, i64, i32, vp]),
     "miseg_colsum": (i32, [C.POINTER(Colsum), vp]),
+    "miseg_gemm_tn_splits": (i32, [C.POINTER(Gemm)]),
+    "miseg_gemm_tn_reduce_batch": (i32, [vp, i32, vp]),
     "miseg_gemm_tn_group": (i32, [vp, i32, i32, vp]),
     "miseg_colsum_batch": (i32, [vp, i32, i32, vp]),
     "miseg_conv3_fwd_workspace_bytes": (C.c_size_t, [i32, i32, i32, i32, i32, i32, i32]),

@@ -203,7 +203,7 @@ def gemm_nt(a, w, bias=None, act=L.ACT_NONE, out=None, out_dtype=None, split_k=1
                 raise ValueError("gemm_nt: res / aux must be [M, N] row views in the output dtype")
     p = L.Gemm(_ptr(a), lda, _ptr(w), K, _ptr(out), ldc, M, N, K, 0, 0, _dt(a), _dt(out), _ptr(_fp32(bias)), act, 0, split_k, None,
                _ptr(res), rows(res)[0] if res is not None else 0, _ptr(aux), rows(aux)[0] if aux is not None else 0,
-               1 if preact_out is not None else 2 if gelu_grad_of is not None else 0)
+               1 if preact_out is not None else 2 if gelu_grad_of is not None else 0, 0)
     _call("miseg_gemm", p)
     return out
 
@@ -221,11 +221,15 @@ def gemm_tn(a, b, out=None, accumulate=False, split_k=0):
         GEMM_TN_QUEUE.append((a, b, out))      # small problem: grouped launch at the end of the backward pass
         return out
     split_k = max(0, split_k)          # 0: the library picks the kernel and the split over the reduction rows
-    p = L.Gemm(_ptr(a), lda, _ptr(b), ldb, _ptr(out), N, M, N, K, 1, 1, _dt(a), L.F32, None, L.ACT_NONE, int(accumulate), split_k, None, None, 0, None, 0, 0)
-    wsb = L.load().miseg_gemm_workspace_bytes(C.byref(p))
+    p = L.Gemm(_ptr(a), lda, _ptr(b), ldb, _ptr(out), N, M, N, K, 1, 1, _dt(a), L.F32, None, L.ACT_NONE, int(accumulate), split_k, None, None, 0, None, 0, 0, 0)
+    lib = L.load()
+    wsb = lib.miseg_gemm_workspace_bytes(C.byref(p))
     if wsb:
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=a.device)
         p.workspace = ws.data_ptr()
+        if TN_REDUCE_QUEUE is not None and accumulate:      # the per-split partial tiles are summed by one batched launch later
+            p.defer_reduce = 1
+            TN_REDUCE_QUEUE.append((ws, out, N, M, N, lib.miseg_gemm_tn_splits(C.byref(p))))
     _call("miseg_gemm", p)
     return out
 
@@ -279,6 +283,21 @@ COLSUM_QUEUE = None   # list while a training arena defers the bias-gradient red
 
 
 GEMM_TN_QUEUE = None   # likewise for the small weight-gradient GEMMs (one grouped launch per 24)
+TN_REDUCE_QUEUE = None   # and for the partial-tile sums of the streaming weight-gradient GEMMs
+
+
+def flush_tn_reduces():
+    q = TN_REDUCE_QUEUE
+    if not q:
+        return
+    lib = L.load()
+    for i in range(0, len(q), 32):
+        chunk = q[i:i + 32]
+        descs = (L.TnReduceDesc * len(chunk))()
+        for j, (ws, out, ldc, M, N, splits) in enumerate(chunk):
+            descs[j] = L.TnReduceDesc(_ptr(ws), _ptr(out), ldc, M, N, splits, 0)
+        L.check(lib.miseg_gemm_tn_reduce_batch(descs, len(chunk), _stream()), "gemm_tn_reduce_batch")
+    q.clear()
 
 
 def flush_gemm_tn():

@@ -57,6 +57,7 @@ class ParamArena:
         ops.begin_step()
         ops.COLSUM_QUEUE = []           # bias-gradient reductions of this step are queued and issued by end_backward()
         ops.GEMM_TN_QUEUE = []          # so are the small weight-gradient GEMMs
+        ops.TN_REDUCE_QUEUE = []        # and the partial-tile sums of the streaming ones
         ops.WGRAD_STREAM = self.wgrad_stream      # None unless overlap_wgrad: measured SLOWER on one MI355X (93.3 -> 90 patches/s: the
                                                   # cross-stream edges of the hipGraph cost more than the idle CUs they fill)
         self.epoch += 1
@@ -153,6 +154,8 @@ class ParamArena:
         region when the step is a hipGraph.  publish() / allreduce() call it too."""
         ops.flush_gemm_tn()
         ops.GEMM_TN_QUEUE = None
+        ops.flush_tn_reduces()
+        ops.TN_REDUCE_QUEUE = None
         ops.flush_colsums()
         ops.COLSUM_QUEUE = None
         ops.join_wgrad()
@@ -181,6 +184,7 @@ class ParamArena:
     def detach(self):
         ops.COLSUM_QUEUE = None
         ops.GEMM_TN_QUEUE = None
+        ops.TN_REDUCE_QUEUE = None
         ops.join_wgrad()
         ops.WGRAD_STREAM = None
         for p in self.params:
