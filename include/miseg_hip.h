@@ -88,6 +88,7 @@ typedef struct {
   const float* gamma[MISEG_MAX_STYLES];
   float* dgamma[MISEG_MAX_STYLES]; float* dbeta[MISEG_MAX_STYLES];
   int act; float slope;
+  const void* gadd; int64_t ldgadd;   /* optional: dx += gadd (the gradient of a skip branch forked off x: the fan-out sum rides here) */
 } miseg_instnorm_bwd_params;
 int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stream_t stream);
 

@@ -250,7 +250,8 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_bwd_apply_kernel(const 
                                                                           const T* __restrict__ x, int64_t ldx, T* __restrict__ dx, int64_t lddx,
                                                                           T* __restrict__ dres, int64_t lddres, int S, int C, int cv, int tx_n, int ty_n, int rpb,
                                                                           const double* __restrict__ stat, float eps, const int32_t* __restrict__ styles,
-                                                                          StylePtrs sp, int act, float slope, const double* __restrict__ dstat, StyleGradPtrs gp) {
+                                                                          StylePtrs sp, int act, float slope, const double* __restrict__ dstat, StyleGradPtrs gp,
+                                                                          const T* __restrict__ gadd, int64_t ldgadd) {
   extern __shared__ __attribute__((aligned(16))) double sums[];
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
@@ -299,6 +300,12 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_bwd_apply_kernel(const 
     for (int i = 0; i < VEC; ++i) {
       const float xh = (xv.v[i] - m[i]) * rs[i];
       o.v[i] = sc[i] * (gv.v[i] - a[i] - xh * bq[i]);
+    }
+    if (gadd) {
+      RowVec<T, VEC> ga;
+      ga.load(gadd + (boff + r) * ldgadd + c * VEC);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o.v[i] += ga.v[i];
     }
     o.store(dx + (boff + r) * lddx + c * VEC);
   }
@@ -398,7 +405,8 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_fused_bwd_kernel(const 
                                                                           const T* __restrict__ x, int64_t ldx, T* __restrict__ dx, int64_t lddx,
                                                                           T* __restrict__ dres, int64_t lddres, int S, int C, int cv, int tx_n, int ty_n,
                                                                           const double* __restrict__ stat, float eps, const int32_t* __restrict__ styles,
-                                                                          StylePtrs sp, StyleGradPtrs gp, int act, float slope) {
+                                                                          StylePtrs sp, StyleGradPtrs gp, int act, float slope, const T* __restrict__ gadd,
+                                                                          int64_t ldgadd) {
   extern __shared__ __attribute__((aligned(16))) float red[];
   double* tot = reinterpret_cast<double*>(red + ty_n * 2 * tx_n * VEC);   // dstat totals
   double* sums = tot + 2 * tx_n * VEC;                                   // forward statistics
@@ -462,6 +470,12 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_fused_bwd_kernel(const 
     for (int i = 0; i < VEC; ++i) {
       const float xh = (xv.v[i] - m[i]) * rs[i];
       o.v[i] = sc[i] * (gv.v[i] - a[i] - xh * bq[i]);
+    }
+    if (gadd) {
+      RowVec<T, VEC> ga;
+      ga.load(gadd + (boff + r) * ldgadd + c * VEC);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o.v[i] += ga.v[i];
     }
     o.store(dx + (boff + r) * lddx + c * VEC);
   }
@@ -638,8 +652,9 @@ extern "C" int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stre
   return dispatch_dtype(p->dtype, [&](auto* tag) -> int {
     typedef typename std::remove_pointer<decltype(tag)>::type T;
     constexpr int V = Vec16<T>::N;
-    const int64_t ldor = p->lddy | p->ldx | p->lddx | (p->act ? p->ldy : 0) | (p->dres ? p->lddres : 0);
-    const bool al = aligned16(p->dy) && aligned16(p->x) && aligned16(p->dx) && (!p->act || aligned16(p->y)) && (!p->dres || aligned16(p->dres)) && ldor % V == 0;
+    const int64_t ldor = p->lddy | p->ldx | p->lddx | (p->act ? p->ldy : 0) | (p->dres ? p->lddres : 0) | (p->gadd ? p->ldgadd : 0);
+    const bool al = aligned16(p->dy) && aligned16(p->x) && aligned16(p->dx) && (!p->act || aligned16(p->y)) && (!p->dres || aligned16(p->dres)) &&
+                    (!p->gadd || aligned16(p->gadd)) && ldor % V == 0;
     NormGeom g = norm_geom(p->S, p->C, al, V);
     StylePtrs sp;
     StyleGradPtrs gp;
@@ -657,11 +672,11 @@ extern "C" int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stre
       if (vec == 1)
         instnorm_fused_bwd_kernel<T, 1><<<fgrid, NORM_THREADS, fsh, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, (T*)p->dx,
                                                                               p->lddx, (T*)p->dres, p->lddres, p->S, p->C, cv, tx, ty, (const double*)p->stat, p->eps,
-                                                                              p->styles, sp, gp, p->act, p->slope);
+                                                                              p->styles, sp, gp, p->act, p->slope, (const T*)p->gadd, p->ldgadd);
       else
         instnorm_fused_bwd_kernel<T, V><<<fgrid, NORM_THREADS, fsh, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, (T*)p->dx,
                                                                               p->lddx, (T*)p->dres, p->lddres, p->S, p->C, cv, tx, ty, (const double*)p->stat, p->eps,
-                                                                              p->styles, sp, gp, p->act, p->slope);
+                                                                              p->styles, sp, gp, p->act, p->slope, (const T*)p->gadd, p->ldgadd);
       MISEG_LAUNCH_CHECK("instnorm_bwd");
       return MISEG_OK;
     }
@@ -676,7 +691,7 @@ extern "C" int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stre
                                                                            g.cv, g.tx, g.ty, g.rpb, stat, p->eps, p->act, p->slope, dstat);                           \
     instnorm_bwd_apply_kernel<T, VV><<<grid, NORM_THREADS, shd, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, (T*)p->dx,    \
                                                                          p->lddx, (T*)p->dres, p->lddres, p->S, p->C, g.cv, g.tx, g.ty, g.rpb, stat, p->eps, p->styles, \
-                                                                         sp, p->act, p->slope, dstat, gp);
+                                                                         sp, p->act, p->slope, dstat, gp, (const T*)p->gadd, p->ldgadd);
     if (g.vec == 1) { BWD_LAUNCH(1) } else { BWD_LAUNCH(V) }
 #undef BWD_LAUNCH
     MISEG_LAUNCH_CHECK("instnorm_bwd");

@@ -76,7 +76,9 @@ class _InstNorm(Function):
     reference: networks/norms/conditional_instance_norm.py:59-68, dynunet_block.py:100-126."""
 
     @staticmethod
-    def forward(ctx, x, res, styles_dev, styles_host, num_styles, affine, act, slope, eps, *params):
+    def forward(ctx, x, res, styles_dev, styles_host, num_styles, affine, act, slope, eps, fork, *params):
+        """fork=True additionally returns x itself (the skip branch of `x + f(norm(x))`): the backward then receives both
+        gradients at once and the fan-out sum rides in the norm-backward kernel instead of a separate add."""
         B = x.shape[0]
         S = ops.rows(x)[1] // B
         gammas = list(params[0::2]) if affine else None
@@ -85,10 +87,10 @@ class _InstNorm(Function):
         ctx.meta = (B, S, styles_host, num_styles, affine, act, slope, res is not None, eps)
         ctx.params = params
         ctx.save_for_backward(x, y if act != L.ACT_NONE else None, stat, styles_dev, *(gammas or []))
-        return y
+        return (y, x.view_as(x)) if fork else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, gskip=None):
         B, S, styles_host, num_styles, affine, act, slope, has_res, eps = ctx.meta
         x, y, stat, styles_dev, *gammas = ctx.saved_tensors
         dy = _rv(dy)
@@ -105,23 +107,24 @@ class _InstNorm(Function):
             dgam = [buf[s, 0] if s in present else None for s in range(num_styles)]
             dbet = [buf[s, 1] if s in present else None for s in range(num_styles)]
         dx, dres = ops.instnorm_bwd(dy, y, x, B, S, stat, styles_dev, gammas if affine else None, dgam, dbet, act=act, slope=slope, eps=eps,
-                                    want_dres=has_res and ctx.needs_input_grad[1])
+                                    want_dres=has_res and ctx.needs_input_grad[1], gadd=_rv(gskip))
         pg = []
         if affine:
             for s in range(num_styles):
                 pg += [None, None] if in_arena else [dgam[s], dbet[s]]
-        return (dx, dres, None, None, None, None, None, None, None, *pg)
+        return (dx, dres, None, None, None, None, None, None, None, None, *pg)
 
 
-def instance_norm(x, params=None, styles_dev=None, styles_host=None, res=None, act=L.ACT_NONE, slope=0.01, eps=1e-5):
-    """params: None (no affine) | [(gamma, beta)] (plain) | [(g0,b0),(g1,b1),...] (conditional, one pair per style)."""
+def instance_norm(x, params=None, styles_dev=None, styles_host=None, res=None, act=L.ACT_NONE, slope=0.01, eps=1e-5, fork=False):
+    """params: None (no affine) | [(gamma, beta)] (plain) | [(g0,b0),(g1,b1),...] (conditional, one pair per style).
+    fork=True returns (norm(x), x): see _InstNorm.forward."""
     flat = []
     n = 1
     if params is not None:
         n = len(params)
         for g, b in params:
             flat += [g, b]
-    return _InstNorm.apply(x, res, styles_dev, styles_host, n, params is not None, act, slope, eps, *flat)
+    return _InstNorm.apply(x, res, styles_dev, styles_host, n, params is not None, act, slope, eps, fork, *flat)
 
 
 class _LayerNorm(Function):

@@ -4,7 +4,7 @@ from typing import Sequence, Tuple, Union
 import torch.nn as nn
 
 from ...hip import functional as HF
-from ..layers.utils import apply_norm, get_norm_layer
+from ..layers.utils import apply_norm, apply_norm_fork, get_norm_layer
 from ..utils.swin_utils import get_window_size
 from .mlp import MLPBlock as Mlp
 from .window_attention import WindowAttention
@@ -48,7 +48,7 @@ class SwinTransformerBlock(nn.Module):
         """x [B, D, H, W, C].  part1 (:99-174) + residual, part2 (:176-205) + residual (:241-252)."""
         _, d, h, w, _ = x.shape
         window, shift = get_window_size((d, h, w), self.window_size, self.shift_size)
-        xa, xs = HF.fork(x)
-        x = self.attn(apply_norm(self.norm1, xa, styles), window, shift, res=xs)     # x + attn(norm1(x)): add in the proj epilogue
-        xa, xs = HF.fork(x)
-        return self.mlp(apply_norm(self.norm2, xa, styles), res=xs)                  # x + mlp(norm2(x)): add in the fc2 epilogue
+        xn, xs = apply_norm_fork(self.norm1, x, styles)
+        x = self.attn(xn, window, shift, res=xs)        # x + attn(norm1(x)): add in the proj epilogue
+        xn, xs = apply_norm_fork(self.norm2, x, styles)
+        return self.mlp(xn, res=xs)                     # x + mlp(norm2(x)): add in the fc2 epilogue

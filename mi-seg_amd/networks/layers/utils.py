@@ -44,6 +44,19 @@ def get_norm_layer(name: Union[Tuple, str], spatial_dims: Optional[int] = 1, cha
     raise ValueError(f"Unsupported option '{norm_name}'")
 
 
+def apply_norm_fork(norm: nn.Module, x, styles=None):
+    """(norm(x), x) for the `x + f(norm(x))` pattern: with an instance norm the two branch gradients are summed inside the
+    norm-backward kernel; other norms fall back to the explicit fork."""
+    if isinstance(norm, _ConditionalInstanceNorm):
+        if styles is None:
+            raise ValueError("Modalities must be passed to the forward step when encoder_norm_type is 'instance_cond'.")
+        return HF.instance_norm(x, norm.style_params(), styles[0], styles[1], eps=norm.eps, fork=True)
+    if isinstance(norm, _INSTANCE):
+        return HF.instance_norm(x, [(norm.weight, norm.bias)] if norm.affine else None, None, None, eps=norm.eps, fork=True)
+    xa, xs = HF.fork(x)
+    return apply_norm(norm, xa, styles), xs
+
+
 def apply_norm(norm: nn.Module, x, styles=None, res=None, act=L.ACT_NONE, slope=0.01):
     """Apply a norm *module* (used as a parameter container) to a channels-last tensor through the HIP kernels.
     ``styles`` is the (device int32 tensor, host tuple) pair from styles_to_device."""
