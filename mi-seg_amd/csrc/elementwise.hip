@@ -789,30 +789,57 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, in
 
 struct ColsumBatch { miseg_colsum_desc d[MISEG_COLSUM_BATCH]; int n; };
 
-// one launch for a list of accumulate-mode column sums: workgroup -> (descriptor, 256-row chunk, tile of 32 channels)
+// one launch for a list of accumulate-mode column sums: workgroup -> (descriptor, 512-row chunk, tile of 64 channels);
+// a lane reads one 16-byte channel vector per row (vec descriptors) or single elements (any C / alignment)
+static constexpr int CSB_ROWS = 512, CSB_CH = 64;
+
 template <class T>
 __global__ void __launch_bounds__(256) colsum_batch_kernel(ColsumBatch b) {
-  __shared__ float red[8][33];
+  typedef typename Vec16<T>::type VT;
+  constexpr int N = Vec16<T>::N;
+  __shared__ float red[32][CSB_CH + 1];
   int k = 0;
   while (k + 1 < b.n && b.d[k + 1].block0 <= (int)blockIdx.x) ++k;
   const miseg_colsum_desc d = b.d[k];
-  const int ctiles = (d.C + 31) / 32;
+  const int ctiles = (d.C + CSB_CH - 1) / CSB_CH;
   const int local = blockIdx.x - d.block0;
-  const int ct = local % ctiles;
-  const int64_t r0 = (int64_t)(local / ctiles) * 256, r1 = min(d.rows, r0 + 256);
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 channels x 8 row lanes
-  const int c = ct * 32 + tx;
+  const int c0 = (local % ctiles) * CSB_CH;
+  const int64_t r0 = (int64_t)(local / ctiles) * CSB_ROWS, r1 = min(d.rows, r0 + CSB_ROWS);
   const T* x = reinterpret_cast<const T*>(d.x);
-  float acc = 0.f;
-  if (c < d.C)
-    for (int64_t r = r0 + ty; r < r1; r += 8) acc += to_f32(x[r * d.ldx + c]);
-  red[ty][tx] = acc;
+  const bool vec = d.C % N == 0 && d.ldx % N == 0 && ((uintptr_t)d.x % 16 == 0);
+  for (int i = threadIdx.x; i < 32 * (CSB_CH + 1); i += 256) (&red[0][0])[i] = 0.f;
   __syncthreads();
-  if (ty == 0 && c < d.C) {
+  if (vec) {
+    constexpr int TX = CSB_CH / N, TY = 256 / TX;     // bf16: 8 x 32, fp32: 16 x 16
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int c = c0 + tx * N;
+    float acc[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) acc[e] = 0.f;
+    if (c < d.C) {
+      for (int64_t r = r0 + ty; r < r1; r += TY) {
+        const VT v = *reinterpret_cast<const VT*>(x + r * d.ldx + c);
+#pragma unroll
+        for (int e = 0; e < N; ++e) acc[e] += to_f32(v[e]);
+      }
+    }
+    // TY <= 32: one row of `red` per ty
+#pragma unroll
+    for (int e = 0; e < N; ++e) red[ty][tx * N + e] = acc[e];
+  } else {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 channels x 4 row lanes
+    const int c = c0 + tx;
+    float acc = 0.f;
+    if (c < d.C)
+      for (int64_t r = r0 + ty; r < r1; r += 4) acc += to_f32(x[r * d.ldx + c]);
+    red[ty][tx] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < CSB_CH && c0 + (int)threadIdx.x < d.C) {
     float t = 0.f;
 #pragma unroll
-    for (int y = 0; y < 8; ++y) t += red[y][tx];
-    atomicAdd(d.out + c, t);
+    for (int y = 0; y < 32; ++y) t += red[y][threadIdx.x];
+    atomicAdd(d.out + c0 + threadIdx.x, t);
   }
 }
 
@@ -1321,7 +1348,7 @@ extern "C" int miseg_colsum_batch(const miseg_colsum_desc* descs, int n, int dty
     MISEG_REQUIRE(descs[i].x && descs[i].out && descs[i].rows > 0 && descs[i].C > 0, MISEG_E_BADARG, "colsum_batch: descriptor %d", i);
     b.d[i] = descs[i];
     b.d[i].block0 = blocks;
-    blocks += (int)((descs[i].rows + 255) / 256) * ((descs[i].C + 31) / 32);
+    blocks += (int)((descs[i].rows + miseg::CSB_ROWS - 1) / miseg::CSB_ROWS) * ((descs[i].C + miseg::CSB_CH - 1) / miseg::CSB_CH);
   }
   b.n = n;
   return dispatch_dtype(dtype, [&](auto* tag) -> int {
