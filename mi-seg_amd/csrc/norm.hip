@@ -19,7 +19,7 @@ struct NormGeom {
   int ctiles;   // channel tiles
 };
 
-static NormGeom norm_geom(int S, int C, bool vec_ok, int vecN) {
+static NormGeom norm_geom(int S, int C, bool vec_ok, int vecN, int target_blocks = 1024) {
   NormGeom g;
   g.vec = (vec_ok && C % vecN == 0) ? vecN : 1;
   g.cv = C / g.vec;
@@ -27,7 +27,9 @@ static NormGeom norm_geom(int S, int C, bool vec_ok, int vecN) {
   g.ty = NORM_THREADS / g.tx;
   g.ctiles = cdiv(g.cv, g.tx);
   // enough workgroups to fill 256 CUs even on the small grids of the deep stages, >= 4 rows per lane
-  int rpb = cdiv(S, 256);
+  // ~4 workgroups per CU for the streaming kernels (one per CU ran the 48^3 tensors at half the HBM rate); the statistics kernel
+  // asks for 256 (fewer fp64 atomics)
+  int rpb = cdiv(S, target_blocks);
   if (rpb < 4 * g.ty) rpb = 4 * g.ty;
   if (rpb > 1024) rpb = 1024;
   g.rpb = rpb;
@@ -573,7 +575,7 @@ extern "C" int miseg_instnorm_stats(const miseg_instnorm_stats_params* p, miseg_
   return dispatch_dtype(p->dtype, [&](auto* tag) -> int {
     typedef typename std::remove_pointer<decltype(tag)>::type T;
     constexpr int V = Vec16<T>::N;
-    NormGeom g = norm_geom(p->S, p->C, aligned16(p->x) && p->ldx % V == 0, V);
+    NormGeom g = norm_geom(p->S, p->C, aligned16(p->x) && p->ldx % V == 0, V, 256);
     dim3 grid(g.chunks, p->B, g.ctiles);
     size_t sh = (size_t)g.ty * 2 * g.tx * g.vec * sizeof(float);
     if (g.vec == 1) instnorm_stats_kernel<T, 1><<<grid, NORM_THREADS, sh, stream>>>((const T*)p->x, p->ldx, p->S, p->C, g.cv, g.tx, g.ty, g.rpb, (double*)p->stat);
