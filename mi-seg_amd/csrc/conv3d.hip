@@ -495,14 +495,74 @@ __global__ void __launch_bounds__(WG_THREADS) conv3_wgrad_kernel(const T* __rest
   }
 
   const int nbricks = g.B * g.nbd * g.nbh * g.nbw;
-  for (int brick = blockIdx.x; brick < nbricks; brick += nsplit) {
+  // staging.  Fast path (whole 48-channel blocks present, 16-byte aligned rows): the 11 16-byte items a lane stages per brick are
+  // all loaded before the first LDS write (the plain loop paid one global round trip per item).  Holding the NEXT brick in
+  // registers across the MFMA loop was tried: 256 VGPRs + spills.
+  constexpr int NXI = (HROWS * GPR + WG_THREADS - 1) / WG_THREADS, NDI = (NVOX * GPR + WG_THREADS - 1) / WG_THREADS;
+  const bool fast = vec_x && vec_dy && ci0 + WG_CB <= Cin && co0 + WG_CB <= Cout;
+  VT rx[NXI], rd[NDI];
+  auto gload = [&](int brick) {
     int bid = brick;
     const int bw = bid % g.nbw; bid /= g.nbw;
     const int bh = bid % g.nbh; bid /= g.nbh;
     const int bd = bid % g.nbd;
     const int b = bid / g.nbd;
     const int d0 = bd * WBD, h0 = bh * BH, w0 = bw * BW;
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+      const int idx = tid + i * WG_THREADS;
+      const int row = idx / GPR, cg = idx - row * GPR;
+      const int hd = row / (HH * HW), rem = row - hd * (HH * HW);
+      const int hh = rem / HW, hw = rem - hh * HW;
+      const int d = d0 - 1 + hd, h = h0 - 1 + hh, w = w0 - 1 + hw;
+      VT v;
+#pragma unroll
+      for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(0.f);
+      if (idx < HROWS * GPR && d >= 0 && d < g.D && h >= 0 && h < g.H && w >= 0 && w < g.W)
+        v = *reinterpret_cast<const VT*>(x + ((((int64_t)b * g.D + d) * g.H + h) * g.W + w) * ldx + ci0 + cg * KPC);
+      rx[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NDI; ++i) {
+      const int idx = tid + i * WG_THREADS;
+      const int row = idx / GPR, cg = idx - row * GPR;
+      const int vd = row / (BH * BW), rem = row - vd * (BH * BW);
+      const int vh = rem / BW, vw = rem - vh * BW;
+      const int d = d0 + vd, h = h0 + vh, w = w0 + vw;
+      VT v;
+#pragma unroll
+      for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(0.f);
+      if (idx < NVOX * GPR && d < g.D && h < g.H && w < g.W)
+        v = *reinterpret_cast<const VT*>(dy + ((((int64_t)b * g.D + d) * g.H + h) * g.W + w) * lddy + co0 + cg * KPC);
+      rd[i] = v;
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+      const int idx = tid + i * WG_THREADS;
+      if (idx < HROWS * GPR) *reinterpret_cast<VT*>(lx + (idx / GPR) * rowb + (idx % GPR) * 16) = rx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NDI; ++i) {
+      const int idx = tid + i * WG_THREADS;
+      if (idx < NVOX * GPR) *reinterpret_cast<VT*>(ld + (idx / GPR) * rowb + (idx % GPR) * 16) = rd[i];
+    }
+  };
+  for (int brick = blockIdx.x; brick < nbricks; brick += nsplit) {
+    if (fast) {
+      gload(brick);            // issued before the barrier: the round trip overlaps the slower waves' last MFMAs
+      __syncthreads();
+      lstore();
+      __syncthreads();
+    } else {
     __syncthreads();
+    int bid = brick;
+    const int bw = bid % g.nbw; bid /= g.nbw;
+    const int bh = bid % g.nbh; bid /= g.nbh;
+    const int bd = bid % g.nbd;
+    const int b = bid / g.nbd;
+    const int d0 = bd * WBD, h0 = bh * BH, w0 = bw * BW;
     for (int idx = tid; idx < HROWS * GPR; idx += WG_THREADS) {
       const int row = idx / GPR, cg = idx - row * GPR;
       const int hd = row / (HH * HW), rem = row - hd * (HH * HW);
@@ -544,6 +604,7 @@ __global__ void __launch_bounds__(WG_THREADS) conv3_wgrad_kernel(const T* __rest
       *reinterpret_cast<VT*>(ld + row * rowb + cg * 16) = v;
     }
     __syncthreads();
+    }
     if constexpr (std::is_same<T, bf16>::value) {
       // k-step = 32 voxels = 4 h-rows x 8 w at one depth; MFMA k-group fq <-> h-row, element j <-> w
       const int qq = fi >> 2, p4 = (fi & 3) * 4;
