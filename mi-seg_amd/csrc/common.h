@@ -47,6 +47,49 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 __host__ __device__ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Word fills are plain kernels, never hipMemset*Async: under stream capture a memset becomes a memset node, and the ROCm 7.2
+// graph runtime was observed to replay such nodes with a stale argument block (the statistics pool came back "zeroed" with
+// the arguments of an unrelated later kernel), which silently corrupts every replay after the first.
+static __global__ void __launch_bounds__(256) fill_words_kernel(uint32_t* __restrict__ dst, uint32_t v, size_t n) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    const size_t n4 = n >> 2;
+    const u32x4 vv = {v, v, v, v};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) reinterpret_cast<u32x4*>(dst)[i] = vv;
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = v;
+  } else {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = v;
+  }
+}
+
+static __global__ void __launch_bounds__(256) fill_words_2d_kernel(uint32_t* __restrict__ dst, size_t pitch, uint32_t v, size_t width, size_t rows) {
+  const size_t total = width * rows;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / width;
+    dst[r * pitch + (i - r * width)] = v;
+  }
+}
+
+// n, pitch, width in 32-bit words
+static inline hipError_t fill_words_async(void* dst, uint32_t v, size_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  size_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  fill_words_kernel<<<(int)blocks, 256, 0, s>>>((uint32_t*)dst, v, n);
+  return hipGetLastError();
+}
+
+static inline hipError_t fill_words_2d_async(void* dst, size_t pitch, uint32_t v, size_t width, size_t rows, hipStream_t s) {
+  if (width == 0 || rows == 0) return hipSuccess;
+  if (pitch == width) return fill_words_async(dst, v, width * rows, s);
+  size_t blocks = (width * rows + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  fill_words_2d_kernel<<<(int)blocks, 256, 0, s>>>((uint32_t*)dst, pitch, v, width, rows);
+  return hipGetLastError();
+}
+
 template <class F> static inline int dispatch_dtype(int dtype, F&& f) {
   if (dtype == MISEG_F32) return f((float*)nullptr);
   if (dtype == MISEG_BF16) return f((bf16*)nullptr);

@@ -904,7 +904,7 @@ static int conv3_wgrad_launch(const miseg_conv3_wgrad_params* p, hipStream_t s) 
   conv3_wgrad_kernel<T, WBD><<<grid, WG_THREADS, lds, s>>>((const T*)p->x, p->ldx, (const T*)p->dy, p->lddy, (float*)p->workspace, g, p->Cin, p->Cout, ncib, nsplit,
                                                            rowb, vec_x, vec_dy);
   const int64_t total = (int64_t)p->Cout * p->Cin * 27;
-  if (!p->accumulate) MISEG_REQUIRE(hipMemsetAsync(p->dw, 0, (size_t)total * sizeof(float), s) == hipSuccess, MISEG_E_LAUNCH, "conv3_wgrad: memset");
+  if (!p->accumulate) MISEG_REQUIRE(fill_words_async(p->dw, 0, (size_t)total, s) == hipSuccess, MISEG_E_LAUNCH, "conv3_wgrad: memset");
   const int tiles = p->Cout * ncib;
   int groups = cdiv(2048, tiles);
   if (groups > nsplit) groups = nsplit;

@@ -1079,7 +1079,7 @@ extern "C" int miseg_colsum(const miseg_colsum_params* p, miseg_stream_t s_) {
   hipStream_t s = (hipStream_t)s_;
   MISEG_REQUIRE(p && p->x && p->out && p->rows > 0 && p->C > 0, MISEG_E_BADARG, "colsum: bad args");
   if (!p->accumulate) {
-    hipError_t e = hipMemsetAsync(p->out, 0, (size_t)p->C * sizeof(float), s);
+    hipError_t e = miseg::fill_words_async(p->out, 0, (size_t)p->C, s);
     MISEG_REQUIRE(e == hipSuccess, MISEG_E_LAUNCH, "colsum: memset failed");
   }
   DT(p, {
@@ -1362,7 +1362,7 @@ extern "C" int miseg_colsum_batch(const miseg_colsum_desc* descs, int n, int dty
 extern "C" int miseg_fill32(void* dst, uint32_t value, size_t n, miseg_stream_t s_) {
   MISEG_REQUIRE(dst || n == 0, MISEG_E_BADARG, "fill32: null pointer");
   if (n == 0) return MISEG_OK;
-  hipError_t e = hipMemsetD32Async((hipDeviceptr_t)dst, (int)value, n, (hipStream_t)s_);
+  hipError_t e = miseg::fill_words_async(dst, value, n, (hipStream_t)s_);
   MISEG_REQUIRE(e == hipSuccess, MISEG_E_LAUNCH, "fill32: %s", hipGetErrorString(e));
   return MISEG_OK;
 }

@@ -659,8 +659,8 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
     split = cdiv(p->K, kps);
     if (split > 1 && !p->accumulate) {
       // atomics need a zeroed destination
-      if (p->ldc == p->N) { if (hipMemsetAsync(p->C, 0, (size_t)p->M * p->N * sizeof(float), s) != hipSuccess) return set_error(MISEG_E_LAUNCH, "gemm: memset"); }
-      else if (hipMemset2DAsync(p->C, p->ldc * sizeof(float), 0, (size_t)p->N * sizeof(float), p->M, s) != hipSuccess) return set_error(MISEG_E_LAUNCH, "gemm: memset2d");
+      if (p->ldc == p->N) { if (fill_words_async(p->C, 0, (size_t)p->M * p->N, s) != hipSuccess) return set_error(MISEG_E_LAUNCH, "gemm: memset"); }
+      else if (fill_words_2d_async(p->C, (size_t)p->ldc, 0, (size_t)p->N, (size_t)p->M, s) != hipSuccess) return set_error(MISEG_E_LAUNCH, "gemm: memset2d");
     }
     if (split > 1 && p->act != MISEG_ACT_NONE) return set_error(MISEG_E_BADARG, "gemm: activation with split_k");
     if (split > 1 && p->act != MISEG_ACT_NONE) return set_error(MISEG_E_BADARG, "gemm: activation with split_k");
@@ -729,8 +729,8 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
         if (partial && !p->defer_reduce) {
           const int groups = cdiv(pl.splits, TN_RG);
           if (groups > 1 && !p->accumulate) {   // the groups meet in atomics
-            if (p->ldc == p->N) { if (hipMemsetAsync(p->C, 0, (size_t)p->M * p->N * sizeof(float), s) != hipSuccess) return set_error(MISEG_E_LAUNCH, "gemm: memset"); }
-            else if (hipMemset2DAsync(p->C, p->ldc * sizeof(float), 0, (size_t)p->N * sizeof(float), p->M, s) != hipSuccess) return set_error(MISEG_E_LAUNCH, "gemm: memset2d");
+            if (p->ldc == p->N) { if (fill_words_async(p->C, 0, (size_t)p->M * p->N, s) != hipSuccess) return set_error(MISEG_E_LAUNCH, "gemm: memset"); }
+            else if (fill_words_2d_async(p->C, (size_t)p->ldc, 0, (size_t)p->N, (size_t)p->M, s) != hipSuccess) return set_error(MISEG_E_LAUNCH, "gemm: memset2d");
           }
           gemm_tn_partial_reduce_kernel<<<dim3(cdiv(p->M * (p->N / 4), 256), groups), 256, 0, s>>>(partial, (float*)p->C, p->ldc, p->M, p->N, pl.splits, p->accumulate);
         }
@@ -749,8 +749,8 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
     split = cdiv(p->K, kps);
     mode = split > 1 ? 2 : (p->accumulate ? 1 : 0);
     if (split > 1 && !p->accumulate) {
-      if (p->ldc == p->N) { if (hipMemsetAsync(p->C, 0, (size_t)p->M * p->N * sizeof(float), s) != hipSuccess) return set_error(MISEG_E_LAUNCH, "gemm: memset"); }
-      else if (hipMemset2DAsync(p->C, p->ldc * sizeof(float), 0, (size_t)p->N * sizeof(float), p->M, s) != hipSuccess) return set_error(MISEG_E_LAUNCH, "gemm: memset2d");
+      if (p->ldc == p->N) { if (fill_words_async(p->C, 0, (size_t)p->M * p->N, s) != hipSuccess) return set_error(MISEG_E_LAUNCH, "gemm: memset"); }
+      else if (fill_words_2d_async(p->C, (size_t)p->ldc, 0, (size_t)p->N, (size_t)p->M, s) != hipSuccess) return set_error(MISEG_E_LAUNCH, "gemm: memset2d");
     }
     dim3 grid(cdiv(p->M, 64), cdiv(p->N, 64), split);
     gemm_tn_kernel<T, TO><<<grid, 256, 0, s>>>((const T*)p->A, p->lda, (const T*)p->B, p->ldb, (TO*)p->C, p->ldc, p->M, p->N, p->K, mode, al_a, al_b, kps);

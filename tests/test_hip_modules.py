@@ -297,3 +297,52 @@ def test_param_arena_matches_plain_autograd(dtype):
         assert arena._table is not None and arena._table[1] > 0
     finally:
         arena.detach()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_arena", [False, True])
+def test_graphed_step_replays_match_eager(use_arena):
+    """every replay of the captured step - not only the first - must reproduce the eager step, for both modalities and with
+    host activity (allocations, host reads) between replays.  Regression: zero fills recorded as memset nodes were replayed
+    with a stale argument block, so from the second replay on the statistics pool was not zero (logits off by 7e-3,
+    some gradients inf)."""
+    from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
+    from mi_seg_amd.runtime.arena import ParamArena
+    from mi_seg_amd.runtime.graph import GraphedStep
+    from mi_seg_amd.utils.detfill import fill_module_, det_input
+    from mi_seg_amd.hip import ops
+    net = SwinUNETR((64, 64, 64), 1, 3, feature_size=12, num_heads=(3, 6, 12, 24), vit_norm_name=_norm("instance_cond"),
+                    encoder_norm_name=_norm("instance_cond"), decoder_norm_name=_norm("instance")).cuda()
+    fill_module_(net)
+    net.set_compute_dtype(torch.bfloat16)
+    x = det_input(3, (1, 1, 64, 64, 64)).cuda()
+    cot = det_input(4, (1, 3, 64, 64, 64)).cuda()
+    params = [p for p in net.parameters() if p.requires_grad]
+    names = [k for k, _ in net.named_parameters()]
+
+    def eager(m):
+        for p in params:
+            p.grad = None
+        ops.begin_step()
+        y = net(x, [m])
+        y.backward(cot)
+        torch.cuda.synchronize()
+        return y.detach().clone(), {k: p.grad.float().cpu() for k, p in zip(names, params) if p.grad is not None}
+
+    ref = {m: eager(m) for m in (0, 1)}
+    arena = ParamArena(params, torch.bfloat16) if use_arena else None
+    try:
+        step = GraphedStep(net, x.shape, cot.shape, arena=arena)
+        for it, m in enumerate([0, 0, 1, 0, 1, 1]):
+            y = step(x, [m], cot)
+            torch.cuda.synchronize()
+            y_ref, g_ref = ref[m]
+            # the inline host-side check is part of the regression: it allocates and launches between two replays
+            assert float((y.detach().float() - y_ref.float()).norm() / y_ref.float().norm()) < 1e-5, f"replay {it} (modality {m}): logits differ from eager"
+            got = {k: p.grad for k, p in zip(names, params) if p.grad is not None}
+            assert set(got) == set(g_ref), f"replay {it}: set of parameters with a gradient differs"
+            assert all(bool(torch.isfinite(g).all()) for g in got.values()), f"replay {it}: non-finite gradient"
+            compare_grads(got, g_ref, 8e-2, pool_small=True)
+    finally:
+        if arena is not None:
+            arena.detach()
