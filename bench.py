@@ -152,6 +152,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    def replay_check():
+        """untimed: the last replays of the captured step against the same step launched eagerly (logits and all gradients)"""
+        k = order[(a.warmup + a.steps) % len(order)]
+        flat = lambda: arena.flat.clone() if arena is not None else torch.cat([p.grad.reshape(-1).float() for p in params if p.grad is not None])
+        y = graphed(pool[k:k + 1], [mods[k]], cot).detach().float().clone()
+        g = flat()
+        if arena is not None:
+            arena.begin_step()
+            ye = model(pool[k:k + 1], [mods[k]])
+            ye.backward(cot)
+            arena.publish()
+        else:
+            ops.begin_step()
+            for p in params:
+                p.grad = None
+            ye = model(pool[k:k + 1], [mods[k]])
+            ye.backward(cot)
+        ge_ = flat()
+        rel = lambda u, v: float((u - v).norm() / v.norm())
+        return {"logits_rel_err": rel(y, ye.detach().float()), "grad_rel_err": rel(g, ge_), "finite": bool(torch.isfinite(g).all())}
+
     out = {
         "metric": "96^3 patches/sec fwd+bwd, C-Swin-UNETR fs=48 6-class", "value": world * a.steps / dt, "unit": "patches/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1000 * dt / a.steps, "higher_is_better": True,
@@ -159,6 +180,11 @@ def main():
         "config": {"workload": "configs[1]: C-Swin-UNETR feature_size=48 heads=(3,6,12,24) instance_cond, 96^3 patch, 6 classes, "
                                "batch 1 per GPU, fwd+bwd (+ gradient all-reduce at N>1)", "global_batch": world},
     }
+    if graphed is not None:
+        check = replay_check()
+        if not check["finite"] or check["logits_rel_err"] > 1e-2 or check["grad_rel_err"] > 5e-2:
+            raise SystemExit(f"hipGraph replay does not reproduce the eager step: {check}")
+        out["replay_check"] = check
     if rank == 0:
         if not a.no_roofline:
             from mi_seg_amd.testing.roofline import profile_step, summarize

@@ -1,0 +1,60 @@
+"""Turn the rocprofv3 outputs of one round into the tracked files under profiles/.
+
+On the GPU box (three separate passes; counters never share a run with traces other than the kernel trace):
+  cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -o s -- python3 $R/bench.py
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -o f -- python3 $R/bench.py --no-graph --steps 3 --warmup 1 --no-cpu-baseline --no-roofline
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -o w -- python3 $R/bench.py --no-graph --steps 3 --warmup 1 --no-cpu-baseline --no-roofline
+Then here:  python scripts/make_profiles.py r01_e
+"""
+import csv, glob, json, os, re, shutil, sys
+from collections import defaultdict
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+out = os.path.join(root, "profiles")
+
+
+def one(pattern):
+    files = glob.glob(os.path.join(root, "gpurun_out", pattern), recursive=True)
+    if not files:
+        raise SystemExit(f"missing {pattern}")
+    return max(files, key=os.path.getmtime)
+
+
+def short(name):
+    m = re.match(r"_ZN5miseg(\d+)", name)
+    if m:                                            # rocprofv3 leaves some template instances mangled
+        return name[m.end():m.end() + int(m.group(1))]
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"^miseg::", "", name)
+    return re.split(r"[<(]", name)[0]
+
+
+def counter(path, which):
+    acc = defaultdict(lambda: [0, 0.0])
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] == which:
+                a = acc[short(r["Kernel_Name"])]
+                a[0] += 1
+                a[1] += float(r["Counter_Value"])
+    return acc
+
+
+shutil.copy(one("prof_stats/**/*kernel_stats.csv"), os.path.join(out, f"{tag}_bench_bf16_kernel_stats.csv"))
+fetch = counter(one("prof_fetch/**/*counter_collection.csv"), "FETCH_SIZE")
+write = counter(one("prof_write/**/*counter_collection.csv"), "WRITE_SIZE")
+kernels = {}
+for k in sorted(set(fetch) & set(write)):
+    if not k.startswith(("conv", "gemm", "winattn", "instnorm", "head", "patch", "colsum", "pack", "param", "ncdhw", "upcat", "copy", "fill")):
+        continue
+    n = fetch[k][0]
+    fb = 2.0 * 1024.0 * fetch[k][1] / n           # KB -> bytes, doubled on gfx950 (MI355X_MICROARCH.md, HBM section)
+    wb = 1024.0 * write[k][1] / write[k][0]
+    kernels[k] = {"launches_profiled": n, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb}
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --no-graph --steps 3 --warmup 1`, all "
+                     "dispatches of each kernel averaged; FETCH_SIZE (KB) doubled per the gfx950 correction of MI355X_MICROARCH.md (HBM "
+                     "section), WRITE_SIZE (KB) as reported", "kernels": kernels},
+          open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+print("wrote", tag, "kernels:", len(kernels))
