@@ -203,6 +203,11 @@ typedef struct {
 } miseg_conv3_wgrad_params;
 size_t miseg_conv3_wgrad_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int miseg_conv3_wgrad(const miseg_conv3_wgrad_params* p, miseg_stream_t stream);
+/* Up to 24 layers of one dtype in one launch (+ one for the partial sums): the small-grid weight gradients of a backward pass
+ * (dynunet_block.py:100-126 at 48^3 and below) fill the chip together instead of one after the other.  `workspace` of the
+ * params is ignored; one shared buffer of miseg_conv3_wgrad_group_workspace_bytes is passed instead (may be NULL when that is 0). */
+size_t miseg_conv3_wgrad_group_workspace_bytes(const miseg_conv3_wgrad_params* layers, int n);
+int miseg_conv3_wgrad_group(const miseg_conv3_wgrad_params* layers, int n, void* workspace, miseg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused 3D (shifted-)window attention core: zero pad -> cyclic roll -> window partition -> per-head

@@ -463,9 +463,14 @@ __global__ void __launch_bounds__(256) pack_conv3_batch_kernel(const miseg_pack_
 static constexpr int WG_THREADS = 512;
 static constexpr int WG_CB = 48;   // channel block (3 MFMA tiles) on both the out- and in-channel side
 
+// One workgroup = one (48 out-channel, 48 in-channel) pair x one share `split` of the bricks, all 27 taps.
+// direct = 0: the 27x48x48 partial goes to its slab (summed by the reduce kernel);
+// direct = 1 (only with nsplit == 1: every dw element has exactly one producer): transposed through LDS and added to
+//             (2: stored into) the torch-layout gradient in contiguous runs - no slab round trip, no second launch.
 template <class T, int WBD /*brick depth*/>
-__global__ void __launch_bounds__(WG_THREADS) conv3_wgrad_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ dy, int64_t lddy, float* __restrict__ slabs,
-                                                                 ConvGeom g, int Cin, int Cout, int ncib, int nsplit, int rowb, bool vec_x, bool vec_dy) {
+__device__ __forceinline__ void conv3_wgrad_body(const T* __restrict__ x, int64_t ldx, const T* __restrict__ dy, int64_t lddy, float* __restrict__ slabs,
+                                                 float* __restrict__ dw, const ConvGeom& g, int Cin, int Cout, int ncib, int nsplit, int rowb, bool vec_x,
+                                                 bool vec_dy, int split, int pair, int direct) {
   typedef typename Vec16<T>::type VT;
   constexpr int KPC = MmaC<T>::KPC;
   constexpr int GPR = WG_CB / KPC;        // 16-byte groups per staged row
@@ -475,7 +480,7 @@ __global__ void __launch_bounds__(WG_THREADS) conv3_wgrad_kernel(const T* __rest
   char* lx = lds;                          // halo of x : [HROWS][rowb]
   char* ld = lds + HROWS * rowb;           // dy brick  : [NVOX][rowb]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the tap guards around the MFMAs are real branches
-  const int pair = blockIdx.y, cob = pair / ncib, cib = pair - cob * ncib;
+  const int cob = pair / ncib, cib = pair - cob * ncib;
   const int co0 = cob * WG_CB, ci0 = cib * WG_CB;
   const int fi = lane & 15, fq = lane >> 4;
 
@@ -549,7 +554,10 @@ __global__ void __launch_bounds__(WG_THREADS) conv3_wgrad_kernel(const T* __rest
       if (idx < NVOX * GPR) *reinterpret_cast<VT*>(ld + (idx / GPR) * rowb + (idx % GPR) * 16) = rd[i];
     }
   };
-  for (int brick = blockIdx.x; brick < nbricks; brick += nsplit) {
+  for (int brick = split; brick < nbricks; brick += nsplit) {
+    int bdh = brick / g.nbw;
+    const int bh0 = (bdh % g.nbh) * BH;
+    const int bd0 = ((bdh / g.nbh) % g.nbd) * WBD;
     if (fast) {
       gload(brick);            // issued before the barrier: the round trip overlaps the slower waves' last MFMAs
       __syncthreads();
@@ -610,6 +618,7 @@ __global__ void __launch_bounds__(WG_THREADS) conv3_wgrad_kernel(const T* __rest
       const int qq = fi >> 2, p4 = (fi & 3) * 4;
 #pragma unroll 1
       for (int ks = 0; ks < NVOX / 32; ++ks) {
+        if (bd0 + (ks >> 1) >= g.D || bh0 + (ks & 1) * 4 >= g.H) continue;   // k-step entirely outside the volume (3^3, 6^3 grids): all zeros
         const int vd = ks >> 1, vh = (ks & 1) * 4 + fq;
         // rows supplied by this lane for the two transposed reads: w = qq and w = 4 + qq
         const int vrow = (vd * BH + vh) * BW + qq;
@@ -668,7 +677,39 @@ __global__ void __launch_bounds__(WG_THREADS) conv3_wgrad_kernel(const T* __rest
   }
   // slab[pair][split][co 48][tap 27][ci 48] (a reducing workgroup reads one contiguous 5 KB run per split);
   // swapped operands => lane holds ci = 16nt + 4fq + r, co = 16mt + fi
-  float* slab = slabs + ((int64_t)pair * nsplit + blockIdx.x) * 27 * WG_CB * WG_CB;
+  if (direct) {
+    // 16 out-channels at a time: tile[co 16][ci 48][tap 27] fp32 (83 KB of the staging LDS), then one contiguous
+    // nci*27-float run of dw per out-channel
+    float* tile = reinterpret_cast<float*>(lds);
+    const int nci = min(WG_CB, Cin - ci0);
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) {
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int tap = wave + 8 * t;
+        if (tap < 27) {
+#pragma unroll
+          for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tile[(fi * WG_CB + nt * 16 + fq * 4 + r) * 27 + tap] = acc[t][mt][nt][r];
+        }
+      }
+      __syncthreads();
+      const int run = nci * 27;
+      for (int idx = tid; idx < 16 * run; idx += WG_THREADS) {
+        const int col = idx / run, o = idx - col * run;
+        const int co = co0 + mt * 16 + col;
+        if (co < Cout) {
+          float* dst = dw + ((int64_t)co * Cin + ci0) * 27 + o;
+          const float v = tile[col * (WG_CB * 27) + o];
+          if (direct == 2) *dst = v; else atomicAdd(dst, v);
+        }
+      }
+    }
+    return;
+  }
+  float* slab = slabs + ((int64_t)pair * nsplit + split) * 27 * WG_CB * WG_CB;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int tap = wave + 8 * t;
@@ -682,17 +723,48 @@ __global__ void __launch_bounds__(WG_THREADS) conv3_wgrad_kernel(const T* __rest
   }
 }
 
+template <class T, int WBD>
+__global__ void __launch_bounds__(WG_THREADS) conv3_wgrad_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ dy, int64_t lddy, float* __restrict__ slabs,
+                                                                 float* __restrict__ dw, ConvGeom g, int Cin, int Cout, int ncib, int nsplit, int rowb, bool vec_x,
+                                                                 bool vec_dy, int direct) {
+  conv3_wgrad_body<T, WBD>(x, ldx, dy, lddy, slabs, dw, g, Cin, Cout, ncib, nsplit, rowb, vec_x, vec_dy, blockIdx.x, blockIdx.y, direct);
+}
+
+// Several layers in one launch (the small-grid weight gradients of a backward pass, queued by the host): descriptors travel
+// in the kernel arguments, a workgroup finds its layer by its index range.
+struct WgradLayer {
+  const void* x; const void* dy; float* slabs; float* dw;
+  int64_t ldx, lddy;
+  ConvGeom g;
+  int Cin, Cout, ncib, nsplit;
+  int wg0, flags;                  // first workgroup; bit0 vec_x, bit1 vec_dy, bits 2-3 direct mode
+  int tiles, groups, spg, rb0;     // reduce launch: (co, ci-block) tiles x split groups, splits per group, first reduce block
+};
+static constexpr int WG_GROUP_MAX = 24;
+struct WgradGroup { WgradLayer l[WG_GROUP_MAX]; int n; };
+
+template <class T, int WBD>
+__global__ void __launch_bounds__(WG_THREADS) conv3_wgrad_group_kernel(const WgradGroup grp, int rowb) {
+  int li = 0;
+  for (int i = 1; i < grp.n; ++i)
+    if ((int)blockIdx.x >= grp.l[i].wg0) li = i;
+  const WgradLayer& L = grp.l[li];
+  const int local = blockIdx.x - L.wg0;
+  conv3_wgrad_body<T, WBD>((const T*)L.x, L.ldx, (const T*)L.dy, L.lddy, L.slabs, L.dw, L.g, L.Cin, L.Cout, L.ncib, L.nsplit, rowb, L.flags & 1, (L.flags >> 1) & 1,
+                           local % L.nsplit, local / L.nsplit, (L.flags >> 2) & 3);
+}
+
 // dw[co][ci0..+48][tap] += sum over this group's splits of slab[pair][split][co%48][tap][0..48).
 // block = (co, ci-block, split group): one contiguous 5 KB slab run per split, the 27x48 result is transposed through LDS
 // so the atomics land on one contiguous 5 KB run of the torch-layout gradient.
-__global__ void __launch_bounds__(256) conv3_wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int Cin, int Cout, int ncib, int nsplit,
-                                                                 int splits_per_group) {
+__device__ __forceinline__ void conv3_wgrad_reduce_body(const float* __restrict__ slabs, float* __restrict__ dw, int Cin, int Cout, int ncib, int nsplit,
+                                                        int splits_per_group, int tile_idx, int group_idx) {
   __shared__ float tile[WG_CB * 28];
   constexpr int64_t SLAB = 27 * WG_CB * WG_CB;
   constexpr int NE = 27 * WG_CB;            // elements of one (co, ci-block) tile, (tap, cil) with cil fastest
-  const int co = blockIdx.x / ncib, cib = blockIdx.x % ncib;
+  const int co = tile_idx / ncib, cib = tile_idx % ncib;
   const int pair = (co / WG_CB) * ncib + cib;
-  const int k0 = blockIdx.y * splits_per_group, k1 = min(nsplit, k0 + splits_per_group);
+  const int k0 = group_idx * splits_per_group, k1 = min(nsplit, k0 + splits_per_group);
   const float* base = slabs + (int64_t)pair * nsplit * SLAB + (int64_t)(co % WG_CB) * NE;
   float acc[6];
 #pragma unroll
@@ -730,6 +802,20 @@ __global__ void __launch_bounds__(256) conv3_wgrad_reduce_kernel(const float* __
   const int nci = min(WG_CB, Cin - ci0);
   float* out = dw + ((int64_t)co * Cin + ci0) * 27;
   for (int o = threadIdx.x; o < nci * 27; o += 256) atomicAdd(out + o, tile[(o / 27) * 28 + o % 27]);
+}
+
+__global__ void __launch_bounds__(256) conv3_wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int Cin, int Cout, int ncib, int nsplit,
+                                                                 int splits_per_group) {
+  conv3_wgrad_reduce_body(slabs, dw, Cin, Cout, ncib, nsplit, splits_per_group, blockIdx.x, blockIdx.y);
+}
+
+__global__ void __launch_bounds__(256) conv3_wgrad_reduce_group_kernel(const WgradGroup grp) {
+  int li = -1;
+  for (int i = 0; i < grp.n; ++i)
+    if (grp.l[i].tiles > 0 && (int)blockIdx.x >= grp.l[i].rb0) li = i;
+  const WgradLayer& L = grp.l[li];
+  const int local = blockIdx.x - L.rb0;
+  conv3_wgrad_reduce_body(L.slabs, L.dw, L.Cin, L.Cout, L.ncib, L.nsplit, L.spg, local % L.tiles, local / L.tiles);
 }
 
 }  // namespace miseg
@@ -899,20 +985,116 @@ static int conv3_wgrad_launch(const miseg_conv3_wgrad_params* p, hipStream_t s) 
   const size_t lds = (size_t)((WBD + 2) * HH * HW + WBD * BH * BW) * rowb;
   const bool vec_x = ((uintptr_t)p->x % 16 == 0) && (p->ldx % KPC == 0);
   const bool vec_dy = ((uintptr_t)p->dy % 16 == 0) && (p->lddy % KPC == 0);
+  const int direct = nsplit == 1 ? (p->accumulate ? 1 : 2) : 0;     // a single producer per element: no slabs, no second launch
   hipFuncSetAttribute((const void*)conv3_wgrad_kernel<T, WBD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   dim3 grid(nsplit, ncob * ncib);
-  conv3_wgrad_kernel<T, WBD><<<grid, WG_THREADS, lds, s>>>((const T*)p->x, p->ldx, (const T*)p->dy, p->lddy, (float*)p->workspace, g, p->Cin, p->Cout, ncib, nsplit,
-                                                           rowb, vec_x, vec_dy);
-  const int64_t total = (int64_t)p->Cout * p->Cin * 27;
-  if (!p->accumulate) MISEG_REQUIRE(fill_words_async(p->dw, 0, (size_t)total, s) == hipSuccess, MISEG_E_LAUNCH, "conv3_wgrad: memset");
-  const int tiles = p->Cout * ncib;
-  int groups = cdiv(2048, tiles);
-  if (groups > nsplit) groups = nsplit;
-  const int spg = cdiv(nsplit, groups);
-  groups = cdiv(nsplit, spg);
-  conv3_wgrad_reduce_kernel<<<dim3(tiles, groups), 256, 0, s>>>((const float*)p->workspace, p->dw, p->Cin, p->Cout, ncib, nsplit, spg);
+  conv3_wgrad_kernel<T, WBD><<<grid, WG_THREADS, lds, s>>>((const T*)p->x, p->ldx, (const T*)p->dy, p->lddy, (float*)p->workspace, p->dw, g, p->Cin, p->Cout, ncib,
+                                                           nsplit, rowb, vec_x, vec_dy, direct);
+  if (!direct) {
+    const int64_t total = (int64_t)p->Cout * p->Cin * 27;
+    if (!p->accumulate) MISEG_REQUIRE(fill_words_async(p->dw, 0, (size_t)total, s) == hipSuccess, MISEG_E_LAUNCH, "conv3_wgrad: fill");
+    const int tiles = p->Cout * ncib;
+    int groups = cdiv(2048, tiles);
+    if (groups > nsplit) groups = nsplit;
+    const int spg = cdiv(nsplit, groups);
+    groups = cdiv(nsplit, spg);
+    conv3_wgrad_reduce_kernel<<<dim3(tiles, groups), 256, 0, s>>>((const float*)p->workspace, p->dw, p->Cin, p->Cout, ncib, nsplit, spg);
+  }
   MISEG_LAUNCH_CHECK("conv3_wgrad");
   return MISEG_OK;
+}
+
+// grouped launch: every layer gets about WG_GROUP_BRICKS bricks per workgroup (the group as a whole fills the chip, so a
+// layer no longer needs 256 workgroups of its own and the slab traffic shrinks with the split count)
+static constexpr int WG_GROUP_BRICKS = 7;
+
+static void wgrad_group_plan(const miseg_conv3_wgrad_params* p, int wbd, int* ncob, int* ncib, int* nsplit) {
+  *ncob = cdiv(p->Cout, WG_CB);
+  *ncib = cdiv(p->Cin, WG_CB);
+  const int nbricks = p->B * cdiv(p->D, wbd) * cdiv(p->H, BH) * cdiv(p->W, BW);
+  *nsplit = cdiv(nbricks, WG_GROUP_BRICKS);
+}
+
+static size_t wgrad_group_slab_floats(const miseg_conv3_wgrad_params* p, int wbd) {
+  int ncob, ncib, nsplit;
+  wgrad_group_plan(p, wbd, &ncob, &ncib, &nsplit);
+  return nsplit == 1 ? 0 : (size_t)ncob * ncib * nsplit * 27 * WG_CB * WG_CB;
+}
+
+extern "C" size_t miseg_conv3_wgrad_group_workspace_bytes(const miseg_conv3_wgrad_params* descs, int n) {
+  size_t total = 0;
+  for (int i = 0; i < n; ++i) total += wgrad_group_slab_floats(descs + i, descs[i].dtype == MISEG_BF16 ? 4 : 2);
+  return total * sizeof(float);
+}
+
+template <class T, int WBD>
+static int conv3_wgrad_group_launch(const miseg_conv3_wgrad_params* descs, int n, float* workspace, hipStream_t s) {
+  constexpr int KPC = Vec16<T>::N;
+  const int rowb = WG_CB * (int)sizeof(T) + 16;
+  const size_t lds = (size_t)((WBD + 2) * HH * HW + WBD * BH * BW) * rowb;
+  // longest workgroups first
+  int order[WG_GROUP_MAX];
+  int weight[WG_GROUP_MAX];
+  for (int i = 0; i < n; ++i) {
+    int ncob, ncib, nsplit;
+    wgrad_group_plan(descs + i, WBD, &ncob, &ncib, &nsplit);
+    const int nbricks = descs[i].B * cdiv(descs[i].D, WBD) * cdiv(descs[i].H, BH) * cdiv(descs[i].W, BW);
+    order[i] = i;
+    weight[i] = cdiv(nbricks, nsplit) * 8 - (descs[i].D < WBD ? 4 : 0) - (descs[i].H <= 4 ? 2 : 0);
+  }
+  for (int i = 1; i < n; ++i)
+    for (int j = i; j > 0 && weight[order[j]] > weight[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+  WgradGroup grp;
+  grp.n = n;
+  int wg = 0, rb = 0;
+  size_t off = 0;
+  for (int k = 0; k < n; ++k) {
+    const miseg_conv3_wgrad_params* p = descs + order[k];
+    WgradLayer& L = grp.l[k];
+    int ncob, ncib, nsplit;
+    wgrad_group_plan(p, WBD, &ncob, &ncib, &nsplit);
+    L.x = p->x; L.dy = p->dy; L.dw = p->dw; L.ldx = p->ldx; L.lddy = p->lddy;
+    L.g = ConvGeom{p->B, p->D, p->H, p->W, cdiv(p->D, WBD), cdiv(p->H, BH), cdiv(p->W, BW)};
+    L.Cin = p->Cin; L.Cout = p->Cout; L.ncib = ncib; L.nsplit = nsplit;
+    const int direct = nsplit == 1 ? (p->accumulate ? 1 : 2) : 0;
+    const bool vec_x = ((uintptr_t)p->x % 16 == 0) && (p->ldx % KPC == 0);
+    const bool vec_dy = ((uintptr_t)p->dy % 16 == 0) && (p->lddy % KPC == 0);
+    L.flags = (vec_x ? 1 : 0) | (vec_dy ? 2 : 0) | (direct << 2);
+    L.wg0 = wg;
+    wg += ncob * ncib * nsplit;
+    L.slabs = workspace + off;
+    L.tiles = 0; L.groups = 0; L.spg = 0; L.rb0 = rb;
+    if (!direct) {
+      off += (size_t)ncob * ncib * nsplit * 27 * WG_CB * WG_CB;
+      if (!p->accumulate)
+        MISEG_REQUIRE(fill_words_async(p->dw, 0, (size_t)p->Cout * p->Cin * 27, s) == hipSuccess, MISEG_E_LAUNCH, "conv3_wgrad_group: fill");
+      L.tiles = p->Cout * ncib;
+      int groups = cdiv(2048, L.tiles);
+      if (groups > nsplit) groups = nsplit;
+      L.spg = cdiv(nsplit, groups);
+      L.groups = cdiv(nsplit, L.spg);
+      rb += L.tiles * L.groups;
+    }
+  }
+  hipFuncSetAttribute((const void*)conv3_wgrad_group_kernel<T, WBD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  conv3_wgrad_group_kernel<T, WBD><<<wg, WG_THREADS, lds, s>>>(grp, rowb);
+  if (rb > 0) conv3_wgrad_reduce_group_kernel<<<rb, 256, 0, s>>>(grp);
+  MISEG_LAUNCH_CHECK("conv3_wgrad_group");
+  return MISEG_OK;
+}
+
+extern "C" int miseg_conv3_wgrad_group(const miseg_conv3_wgrad_params* descs, int n, void* workspace, miseg_stream_t s_) {
+  MISEG_REQUIRE(descs && n > 0 && n <= WG_GROUP_MAX, MISEG_E_BADARG, "conv3_wgrad_group: 1..%d layers per launch", WG_GROUP_MAX);
+  for (int i = 0; i < n; ++i) {
+    const miseg_conv3_wgrad_params* p = descs + i;
+    MISEG_REQUIRE(p->x && p->dy && p->dw, MISEG_E_BADARG, "conv3_wgrad_group: null pointer in layer %d", i);
+    MISEG_REQUIRE(p->B > 0 && p->D > 0 && p->H > 0 && p->W > 0 && p->Cin > 0 && p->Cout > 0, MISEG_E_BADARG, "conv3_wgrad_group: bad shape in layer %d", i);
+    MISEG_REQUIRE(p->dtype == descs[0].dtype, MISEG_E_BADARG, "conv3_wgrad_group: mixed dtypes");
+  }
+  MISEG_REQUIRE(workspace || miseg_conv3_wgrad_group_workspace_bytes(descs, n) == 0, MISEG_E_BADARG, "conv3_wgrad_group: workspace missing");
+  if (descs[0].dtype == MISEG_F32) return conv3_wgrad_group_launch<float, 2>(descs, n, (float*)workspace, (hipStream_t)s_);
+  if (descs[0].dtype == MISEG_BF16) return conv3_wgrad_group_launch<bf16, 4>(descs, n, (float*)workspace, (hipStream_t)s_);
+  return set_error(MISEG_E_BADARG, "conv3_wgrad_group: dtype %d", descs[0].dtype);
 }
 
 extern "C" int miseg_conv3_wgrad(const miseg_conv3_wgrad_params* p, miseg_stream_t s_) {

@@ -116,6 +116,8 @@ PROTOS = {
     "miseg_pack_conv3_batch": (i32, [vp, i32, i32, i32, vp]),
     "miseg_conv3_wgrad_workspace_bytes": (C.c_size_t, [i32, i32, i32, i32, i32, i32]),
     "miseg_conv3_wgrad": (i32, [C.POINTER(Conv3Wgrad), vp]),
+    "miseg_conv3_wgrad_group_workspace_bytes": (C.c_size_t, [C.POINTER(Conv3Wgrad), i32]),
+    "miseg_conv3_wgrad_group": (i32, [C.POINTER(Conv3Wgrad), i32, vp, vp]),
     "miseg_winattn_fwd": (i32, [C.POINTER(Winattn), vp]),
     "miseg_winattn_bwd": (i32, [C.POINTER(WinattnBwd), vp]),
     "miseg_add": (i32, [C.POINTER(Add), vp]),

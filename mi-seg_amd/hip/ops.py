@@ -424,6 +424,31 @@ def conv3_fwd(x, wpk, Cout, out=None):
     return out
 
 
+CONV_WGRAD_QUEUE = None   # list while a training arena defers the small-grid conv weight gradients (one grouped launch at the end)
+CONV_WGRAD_GROUP_VOXELS = 48 ** 3   # layers up to this many voxels are queued: alone they fill a fraction of the chip for 40-85 us each
+
+
+def flush_conv_wgrads():
+    q = CONV_WGRAD_QUEUE
+    if not q:
+        return
+    lib = L.load()
+    for dt in {x.dtype for x, _, _ in q}:
+        items = [it for it in q if it[0].dtype == dt]
+        for i in range(0, len(items), 24):
+            chunk = items[i:i + 24]
+            descs = (L.Conv3Wgrad * len(chunk))()
+            for j, (x, dy, dw) in enumerate(chunk):
+                B, D, H, W = _vol(x)
+                ldx, _, Cin = rows(x)
+                lddy, _, Cout = rows(dy)
+                descs[j] = L.Conv3Wgrad(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), B, D, H, W, Cin, Cout, _dt(x), 1, None)
+            wsb = lib.miseg_conv3_wgrad_group_workspace_bytes(descs, len(chunk))
+            ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32, device=chunk[0][0].device)
+            L.check(lib.miseg_conv3_wgrad_group(descs, len(chunk), _ptr(ws), _stream()), "conv3_wgrad_group")
+    q.clear()
+
+
 def conv3_wgrad(x, dy, dw=None, accumulate=False):
     B, D, H, W = _vol(x)
     ldx, n, Cin = rows(x)
@@ -432,6 +457,9 @@ def conv3_wgrad(x, dy, dw=None, accumulate=False):
     if dw is None:
         dw = torch.empty(Cout, Cin, 3, 3, 3, dtype=torch.float32, device=x.device)
         accumulate = False
+    if CONV_WGRAD_QUEUE is not None and accumulate and PROFILE_HOOK is None and B * D * H * W <= CONV_WGRAD_GROUP_VOXELS:
+        CONV_WGRAD_QUEUE.append((x, dy, dw))      # keeps x and dy alive until the flush
+        return dw
     lib = L.load()
     ws = torch.empty(lib.miseg_conv3_wgrad_workspace_bytes(B, D, H, W, Cin, Cout) // 4, dtype=torch.float32, device=x.device)
     _call("miseg_conv3_wgrad", L.Conv3Wgrad(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), B, D, H, W, Cin, Cout, _dt(x), int(accumulate), _ptr(ws)),

@@ -58,6 +58,7 @@ class ParamArena:
         ops.COLSUM_QUEUE = []           # bias-gradient reductions of this step are queued and issued by end_backward()
         ops.GEMM_TN_QUEUE = []          # so are the small weight-gradient GEMMs
         ops.TN_REDUCE_QUEUE = []        # and the partial-tile sums of the streaming ones
+        ops.CONV_WGRAD_QUEUE = []       # and the conv weight gradients of the 48^3-and-smaller layers (one grouped launch)
         ops.WGRAD_STREAM = self.wgrad_stream      # None unless overlap_wgrad: measured SLOWER on one MI355X (93.3 -> 90 patches/s: the
                                                   # cross-stream edges of the hipGraph cost more than the idle CUs they fill)
         self.epoch += 1
@@ -152,6 +153,8 @@ class ParamArena:
     def end_backward(self):
         """issue the queued bias-gradient column sums (one launch per 32); call after loss.backward(), inside the captured
         region when the step is a hipGraph.  publish() / allreduce() call it too."""
+        ops.flush_conv_wgrads()
+        ops.CONV_WGRAD_QUEUE = None
         ops.flush_gemm_tn()
         ops.GEMM_TN_QUEUE = None
         ops.flush_tn_reduces()
@@ -183,6 +186,7 @@ class ParamArena:
 
     def detach(self):
         ops.COLSUM_QUEUE = None
+        ops.CONV_WGRAD_QUEUE = None
         ops.GEMM_TN_QUEUE = None
         ops.TN_REDUCE_QUEUE = None
         ops.join_wgrad()

@@ -235,6 +235,39 @@ def test_conv3_exact_integers():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv3_wgrad_grouped(dtype):
+    """the queued weight gradients of a backward pass: one grouped launch (direct epilogue for single-split layers, slabs +
+    grouped partial sums for the others) must accumulate exactly what the per-layer launches give, on top of what dw held."""
+    ops = _ops()
+    shapes = [(1, 3, 3, 3, 96, 96), (1, 6, 6, 6, 48, 96), (2, 12, 12, 12, 48, 48), (1, 24, 24, 24, 96, 48), (1, 5, 9, 11, 12, 24),
+              (1, 3, 3, 3, 40, 72), (1, 16, 40, 24, 48, 48)]
+    cases = []
+    for i, (B, D, H, W, Cin, Cout) in enumerate(shapes):
+        x = rnd(B, D, H, W, Cin, dtype=dtype, seed=70 + i)
+        dy = rnd(B, D, H, W, Cout, dtype=dtype, seed=90 + i)
+        base = rnd(Cout, Cin, 3, 3, 3, seed=110 + i)
+        cases.append((x, dy, base))
+    ops.CONV_WGRAD_QUEUE = []
+    try:
+        outs = []
+        for x, dy, base in cases:
+            dw = base.clone()
+            assert ops.conv3_wgrad(x, dy, dw=dw, accumulate=True) is dw
+            outs.append(dw)
+        assert len(ops.CONV_WGRAD_QUEUE) == len(cases)
+        assert all(torch.equal(o, c[2]) for o, c in zip(outs, cases)), "queued launches must not have run yet"
+        ops.flush_conv_wgrads()
+        assert not ops.CONV_WGRAD_QUEUE
+    finally:
+        ops.CONV_WGRAD_QUEUE = None
+    for (x, dy, base), dw in zip(cases, outs):
+        ref = torch.nn.grad.conv3d_weight(x.float().permute(0, 4, 1, 2, 3), base.shape, dy.float().permute(0, 4, 1, 2, 3), padding=1)
+        assert rel_err(dw - base, ref) < TOL[dtype], tuple(x.shape)
+        single = ops.conv3_wgrad(x, dy)
+        assert rel_err(dw - base, single) < 1e-5 if dtype == torch.float32 else 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv3_thin_and_head_and_patch_embed(dtype):
     ops = _ops()
     x = rnd(2, 1, 9, 10, 12, seed=51)
