@@ -460,17 +460,32 @@ __global__ void __launch_bounds__(256) pack_conv3_batch_kernel(const miseg_pack_
 // ---------------------------------------------------------------------------------------------------------
 // weight gradient
 // ---------------------------------------------------------------------------------------------------------
-static constexpr int WG_THREADS = 512;
+static constexpr int WG_THREADS = 256;   // 4 waves, one per SIMD: up to 512 registers each (the 27x9 accumulator tiles live in AGPRs), which
+                                         // leaves the VGPRs to hold the NEXT brick's global loads across the MFMA loop
+static constexpr int WG_WAVES = WG_THREADS / 64;
+static constexpr int WG_TPW = 7;    // taps per wave: wave, wave + 4, ... (27 taps over 4 waves: 7, 7, 7, 6)
 static constexpr int WG_CB = 48;   // channel block (3 MFMA tiles) on both the out- and in-channel side
+
+#ifdef MISEG_WGRAD_STAMPS
+__device__ unsigned long long miseg_wg_stamps[8];   // debug build only (scripts/debug_wgrad_stamps.py): summed s_memrealtime ticks
+#define WG_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
+#define WG_STAMP_ADD(i, a, b) do { if (tid == 0) atomicAdd(&miseg_wg_stamps[i], (b) - (a)); } while (0)
+#else
+#define WG_STAMP(var)
+#define WG_STAMP_ADD(i, a, b)
+#endif
 
 // One workgroup = one (48 out-channel, 48 in-channel) pair x one share `split` of the bricks, all 27 taps.
 // direct = 0: the 27x48x48 partial goes to its slab (summed by the reduce kernel);
 // direct = 1 (only with nsplit == 1: every dw element has exactly one producer): transposed through LDS and added to
 //             (2: stored into) the torch-layout gradient in contiguous runs - no slab round trip, no second launch.
-template <class T, int WBD /*brick depth*/>
+// PIPED (bf16, whole 48-channel blocks, 16-byte aligned rows, D % WBD == 0 and H % BH == 0 so that every k-step of every brick
+// is inside the volume): the software-pipelined MFMA loop.  A separate instantiation, not a branch: with both loops in one
+// body the 252 accumulator registers of the two paths met in PHIs and the kernel spilled 350 VGPRs.
+template <class T, int WBD /*brick depth*/, bool PIPED>
 __device__ __forceinline__ void conv3_wgrad_body(const T* __restrict__ x, int64_t ldx, const T* __restrict__ dy, int64_t lddy, float* __restrict__ slabs,
                                                  float* __restrict__ dw, const ConvGeom& g, int Cin, int Cout, int ncib, int nsplit, int rowb, bool vec_x,
-                                                 bool vec_dy, int split, int pair, int direct) {
+                                                 bool vec_dy, int split, int pair, int direct, bool xcd_map) {
   typedef typename Vec16<T>::type VT;
   constexpr int KPC = MmaC<T>::KPC;
   constexpr int GPR = WG_CB / KPC;        // 16-byte groups per staged row
@@ -484,85 +499,194 @@ __device__ __forceinline__ void conv3_wgrad_body(const T* __restrict__ x, int64_
   const int co0 = cob * WG_CB, ci0 = cib * WG_CB;
   const int fi = lane & 15, fq = lane >> 4;
 
-  // taps owned by this wave: wave, wave+8, wave+16, wave+24
-  f32x4 acc[4][3][3];
+  // taps owned by this wave: wave, wave + 4, ..., wave + 24
+  f32x4 acc[WG_TPW][3][3];
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < WG_TPW; ++t)
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int toff[4];
+  int toff[WG_TPW];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int tap = wave + 8 * t;
+  for (int t = 0; t < WG_TPW; ++t) {
+    const int tap = wave + WG_WAVES * t;
     toff[t] = tap < 27 ? (((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3) : 0;
   }
 
   const int nbricks = g.B * g.nbd * g.nbh * g.nbw;
-  // staging.  Fast path (whole 48-channel blocks present, 16-byte aligned rows): the 11 16-byte items a lane stages per brick are
-  // all loaded before the first LDS write (the plain loop paid one global round trip per item).  Holding the NEXT brick in
-  // registers across the MFMA loop was tried: 256 VGPRs + spills.
+  // staging.  Fast path (whole 48-channel blocks present, 16-byte aligned rows): the 21 16-byte items a lane stages per brick are
+  // loaded for the NEXT brick right before the MFMA loop of the current one and written to LDS after it (in-kernel timestamps of
+  // the un-prefetched version: 54 % of a workgroup's time was the wait for these loads, 44 % the MFMA loop).
   constexpr int NXI = (HROWS * GPR + WG_THREADS - 1) / WG_THREADS, NDI = (NVOX * GPR + WG_THREADS - 1) / WG_THREADS;
-  const bool fast = vec_x && vec_dy && ci0 + WG_CB <= Cin && co0 + WG_CB <= Cout;
+  const bool fast = PIPED || (vec_x && vec_dy && ci0 + WG_CB <= Cin && co0 + WG_CB <= Cout);
   VT rx[NXI], rd[NDI];
-  auto gload = [&](int brick) {
+  // One staged item = 16 bytes of one halo row (j < NXI) or of one dy row.  Loads are unconditional (an item outside the volume
+  // reads the tensor's first bytes instead and is zeroed through `vmask` when it is written to LDS): no branch per item, so
+  // the items can sit between the MFMAs of the k-loop.
+  uint32_t vmask = 0;
+  int nb = 0, nd0 = 0, nh0 = 0, nw0 = 0;
+  bool nok = false;
+  int64_t nmask = 0;
+  int tid_s = tid;      // made opaque once per brick: otherwise the row/column split of all 21 items is hoisted out of the brick loop
+                        // as loop invariants (~100 live VGPRs, 470 spills)
+  auto set_next = [&](int brick, bool ok) {
+    asm volatile("" : "+v"(tid_s));
     int bid = brick;
     const int bw = bid % g.nbw; bid /= g.nbw;
     const int bh = bid % g.nbh; bid /= g.nbh;
-    const int bd = bid % g.nbd;
-    const int b = bid / g.nbd;
-    const int d0 = bd * WBD, h0 = bh * BH, w0 = bw * BW;
-#pragma unroll
-    for (int i = 0; i < NXI; ++i) {
-      const int idx = tid + i * WG_THREADS;
+    nd0 = (bid % g.nbd) * WBD; nb = bid / g.nbd; nh0 = bh * BH; nw0 = bw * BW;
+    nok = ok;
+    nmask = ok ? (int64_t)-1 : 0;     // no next brick: every item re-reads the tensor's first bytes
+    vmask = 0;
+  };
+  auto gitem = [&](int j) {
+    if (j < NXI) {
+      const int idx = tid_s + j * WG_THREADS;
       const int row = idx / GPR, cg = idx - row * GPR;
       const int hd = row / (HH * HW), rem = row - hd * (HH * HW);
       const int hh = rem / HW, hw = rem - hh * HW;
-      const int d = d0 - 1 + hd, h = h0 - 1 + hh, w = w0 - 1 + hw;
-      VT v;
-#pragma unroll
-      for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(0.f);
-      if (idx < HROWS * GPR && d >= 0 && d < g.D && h >= 0 && h < g.H && w >= 0 && w < g.W)
-        v = *reinterpret_cast<const VT*>(x + ((((int64_t)b * g.D + d) * g.H + h) * g.W + w) * ldx + ci0 + cg * KPC);
-      rx[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < NDI; ++i) {
-      const int idx = tid + i * WG_THREADS;
+      const int d = nd0 - 1 + hd, h = nh0 - 1 + hh, w = nw0 - 1 + hw;
+      const bool ok = nok && idx < HROWS * GPR && d >= 0 && d < g.D && h >= 0 && h < g.H && w >= 0 && w < g.W;
+      // clamped coordinates: always a valid address, no select / branch on the 64-bit offset
+      const int dc = min(max(d, 0), g.D - 1), hc = min(max(h, 0), g.H - 1), wc = min(max(w, 0), g.W - 1);
+      const int64_t off = (((((int64_t)nb * g.D + dc) * g.H + hc) * g.W + wc) * ldx + ci0 + cg * KPC) & nmask;
+      rx[j] = *reinterpret_cast<const VT*>(x + off);
+      vmask |= (ok ? 1u : 0u) << j;
+    } else {
+      const int i = j - NXI;
+      const int idx = tid_s + i * WG_THREADS;
       const int row = idx / GPR, cg = idx - row * GPR;
       const int vd = row / (BH * BW), rem = row - vd * (BH * BW);
       const int vh = rem / BW, vw = rem - vh * BW;
-      const int d = d0 + vd, h = h0 + vh, w = w0 + vw;
-      VT v;
+      const int d = nd0 + vd, h = nh0 + vh, w = nw0 + vw;
+      const bool ok = nok && idx < NVOX * GPR && d < g.D && h < g.H && w < g.W;
+      const int dc = min(d, g.D - 1), hc = min(h, g.H - 1), wc = min(w, g.W - 1);
+      const int64_t off = (((((int64_t)nb * g.D + dc) * g.H + hc) * g.W + wc) * lddy + co0 + cg * KPC) & nmask;
+      rd[i] = *reinterpret_cast<const VT*>(dy + off);
+      vmask |= (ok ? 1u : 0u) << j;
+    }
+  };
+  // PIPED: what an item needs per brick is reduced to a handful of VALU operations (one wave per SIMD: index arithmetic between
+  // the MFMAs is not hidden by anybody; the generic form above costs ~70 instructions per item, a quarter of them 64-bit
+  // multiplies).  Per lane and item, constant over the bricks: a 32-bit byte offset from the brick's halo (dy: brick) origin
+  // and 8 "face" bits - which faces of the halo the item sits on (bit 7: lane beyond the item count); per brick, scalar: the two
+  // origins and which faces lie outside the volume.  An item on such a face reads the halo's first interior voxel instead and
+  // is zeroed by vmask.  Needs D % WBD == H % BH == W % BW == 0 (every brick inside the volume).
+  uint32_t ioff[PIPED ? NXI + NDI : 1];
+  uint32_t iface[PIPED ? (NXI + NDI + 3) / 4 : 1];
+  const char* xorg = nullptr;
+  const char* dorg = nullptr;
+  uint32_t bfaces = 0xff, ctr = 0;
+  if constexpr (PIPED) {
 #pragma unroll
-      for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(0.f);
-      if (idx < NVOX * GPR && d < g.D && h < g.H && w < g.W)
-        v = *reinterpret_cast<const VT*>(dy + ((((int64_t)b * g.D + d) * g.H + h) * g.W + w) * lddy + co0 + cg * KPC);
-      rd[i] = v;
+    for (int q = 0; q < (NXI + NDI + 3) / 4; ++q) iface[q] = 0;
+#pragma unroll
+    for (int j = 0; j < NXI + NDI; ++j) {
+      uint32_t f;
+      if (j < NXI) {
+        const int idx = tid + j * WG_THREADS;
+        const int row = idx / GPR, cg = idx - row * GPR;
+        const int hd = row / (HH * HW), rem = row - hd * (HH * HW);
+        const int hh = rem / HW, hw = rem - hh * HW;
+        ioff[j] = (uint32_t)((((int64_t)hd * g.H + hh) * g.W + hw) * ldx + cg * KPC) * (uint32_t)sizeof(T);
+        f = (hd == 0 ? 1u : 0u) | (hd == WBD + 1 ? 2u : 0u) | (hh == 0 ? 4u : 0u) | (hh == HH - 1 ? 8u : 0u) | (hw == 0 ? 16u : 0u) | (hw == HW - 1 ? 32u : 0u) |
+            (idx >= HROWS * GPR ? 128u : 0u);
+      } else {
+        const int idx = tid + (j - NXI) * WG_THREADS;
+        const int row = idx / GPR, cg = idx - row * GPR;
+        const int vd = row / (BH * BW), rem = row - vd * (BH * BW);
+        const int vh = rem / BW, vw = rem - vh * BW;
+        ioff[j] = (uint32_t)((((int64_t)vd * g.H + vh) * g.W + vw) * lddy + cg * KPC) * (uint32_t)sizeof(T);
+        f = idx >= NVOX * GPR ? 128u : 0u;
+      }
+      iface[j >> 2] |= f << ((j & 3) * 8);
+    }
+    ctr = (uint32_t)((((int64_t)g.H + 1) * g.W + 1) * ldx) * (uint32_t)sizeof(T);
+  }
+  auto pset_next = [&](int brick, bool ok) {
+    int bid = brick;
+    const int bw = bid % g.nbw; bid /= g.nbw;
+    const int bh = bid % g.nbh; bid /= g.nbh;
+    const int d0 = (bid % g.nbd) * WBD, b = bid / g.nbd, h0 = bh * BH, w0 = bw * BW;
+    xorg = reinterpret_cast<const char*>(x + ((((int64_t)b * g.D + d0 - 1) * g.H + h0 - 1) * g.W + w0 - 1) * ldx + ci0);
+    dorg = reinterpret_cast<const char*>(dy + ((((int64_t)b * g.D + d0) * g.H + h0) * g.W + w0) * lddy + co0);
+    bfaces = ok ? (128u | (d0 == 0 ? 1u : 0u) | (d0 + WBD >= g.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) | (h0 + BH >= g.H ? 8u : 0u) | (w0 == 0 ? 16u : 0u) |
+                   (w0 + BW >= g.W ? 32u : 0u))
+                : 0xffu;
+    vmask = 0;
+  };
+  auto pitem = [&](int j) {
+#if defined(MISEG_WG_EXP) && MISEG_WG_EXP == 3
+    const bool ok = ((iface[j >> 2] >> ((j & 3) * 8)) & bfaces) == 0x55;      // timing experiment: every item reads the same bytes
+#else
+    const bool ok = ((iface[j >> 2] >> ((j & 3) * 8)) & bfaces) == 0;
+#endif
+    if (j < NXI) rx[j] = *reinterpret_cast<const VT*>(xorg + (ok ? ioff[j] : ctr));
+    else rd[j - NXI] = *reinterpret_cast<const VT*>(dorg + (ok ? ioff[j] : 0u));
+    vmask |= (ok ? 1u : 0u) << j;
+  };
+  auto gload = [&]() {
+#pragma unroll
+    for (int j = 0; j < NXI + NDI; ++j) {
+      if constexpr (PIPED) pitem(j); else gitem(j);
     }
   };
   auto lstore = [&]() {
+    VT zero;
+#pragma unroll
+    for (int e = 0; e < KPC; ++e) zero[e] = from_f32<T>(0.f);
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
       const int idx = tid + i * WG_THREADS;
-      if (idx < HROWS * GPR) *reinterpret_cast<VT*>(lx + (idx / GPR) * rowb + (idx % GPR) * 16) = rx[i];
+      if (idx < HROWS * GPR) *reinterpret_cast<VT*>(lx + (idx / GPR) * rowb + (idx % GPR) * 16) = (vmask >> i) & 1 ? rx[i] : zero;
     }
 #pragma unroll
     for (int i = 0; i < NDI; ++i) {
       const int idx = tid + i * WG_THREADS;
-      if (idx < NVOX * GPR) *reinterpret_cast<VT*>(ld + (idx / GPR) * rowb + (idx % GPR) * 16) = rd[i];
+      if (idx < NVOX * GPR) *reinterpret_cast<VT*>(ld + (idx / GPR) * rowb + (idx % GPR) * 16) = (vmask >> (NXI + i)) & 1 ? rd[i] : zero;
     }
   };
-  for (int brick = split; brick < nbricks; brick += nsplit) {
+  static_assert(NXI + NDI <= 32, "validity mask is one 32-bit word");
+  // which bricks this workgroup walks.  Workgroups are dealt to the 8 XCDs round-robin and every XCD has its own L2: with
+  // xcd_map (nsplit % 8 == 0, first workgroup of the layer on XCD 0) XCD k takes the k-th contiguous eighth of the bricks, so the
+  // halo rows shared by h/w-neighbouring bricks are fetched into one L2 instead of eight (the staged loads were ~3.5 us in
+  // flight with the interleaved order)
+  int b_begin = split, b_end = nbricks, b_step = nsplit;
+  if (xcd_map) {
+    const int per = cdiv(nbricks, 8);
+    b_begin = (split & 7) * per + (split >> 3);
+    b_end = min(((split & 7) + 1) * per, nbricks);
+    b_step = nsplit >> 3;
+  }
+  if (fast && b_begin < b_end) {
+    if constexpr (PIPED) pset_next(b_begin, true); else set_next(b_begin, true);
+    gload();
+  }
+  for (int brick = b_begin; brick < b_end; brick += b_step) {
     int bdh = brick / g.nbw;
     const int bh0 = (bdh % g.nbh) * BH;
     const int bd0 = ((bdh / g.nbh) % g.nbd) * WBD;
-    if (fast) {
-      gload(brick);            // issued before the barrier: the round trip overlaps the slower waves' last MFMAs
-      __syncthreads();
+    // every k-step of the brick inside the volume (always, except on the 12^3-and-smaller grids): the pipelined MFMA loop, which
+    // also issues the next brick's loads between its MFMAs
+    constexpr bool piped = PIPED && std::is_same<T, bf16>::value;
+    WG_STAMP(t_s0);
+    if (PIPED || fast) {
+      __syncthreads();         // every wave is done with the previous brick's LDS image
+      WG_STAMP(t_s1);
+#ifdef MISEG_WGRAD_STAMPS
+      __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) alone: how long the staged items are still in flight after the MFMA loop
+      WG_STAMP(t_s1b);
+      WG_STAMP_ADD(6, t_s1, t_s1b);
+#endif
       lstore();
       __syncthreads();
+      WG_STAMP(t_s2);
+      const bool more = brick + b_step < b_end;
+      if constexpr (PIPED) pset_next(more ? brick + b_step : brick, more); else set_next(more ? brick + b_step : brick, more);
+      if (!piped) gload();     // in flight during the MFMA loop below
+      WG_STAMP_ADD(4, t_s0, t_s1);
+      WG_STAMP_ADD(5, t_s1, t_s2);
     } else {
     __syncthreads();
     int bid = brick;
@@ -613,9 +737,90 @@ __device__ __forceinline__ void conv3_wgrad_body(const T* __restrict__ x, int64_
     }
     __syncthreads();
     }
+    WG_STAMP(t_k0);
+    WG_STAMP_ADD(0, t_s0, t_k0);
     if constexpr (std::is_same<T, bf16>::value) {
       // k-step = 32 voxels = 4 h-rows x 8 w at one depth; MFMA k-group fq <-> h-row, element j <-> w
       const int qq = fi >> 2, p4 = (fi & 3) * 4;
+      if constexpr (piped) {
+        // fully unrolled: the fragments of slot (ks, t + 1) are requested before the MFMAs of slot (ks, t) issue (one wave per
+        // SIMD: nobody else hides the LDS latency), and every other slot carries one of the next brick's global loads
+        constexpr int NKS = NVOX / 32;
+        // per-lane bases; everything that depends on (ks, nt) is a compile-time byte offset (the ds_read immediate field)
+        const char* abase = ld + (fq * BW + qq) * rowb + p4 * 2;
+        const char* bbase[WG_TPW];
+#pragma unroll
+        for (int t = 0; t < WG_TPW; ++t) bbase[t] = lx + (fq * HW + qq + toff[t]) * rowb + p4 * 2;
+        constexpr int ROWB = WG_CB * (int)sizeof(T) + 16;       // == rowb (checked by the launcher)
+        auto load_a = [&](int ks, bf16x8 (&af)[3]) {
+          const int o = (((ks >> 1) * BH + (ks & 1) * 4) * BW) * ROWB;
+#pragma unroll
+          for (int mt = 0; mt < 3; ++mt) {
+            const char* a1 = abase + o + mt * 32;
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1 + 4 * ROWB));
+            af[mt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+        };
+        auto load_b = [&](int ks, int t, bf16x8 (&bf)[3]) {
+          const int o = (((ks >> 1) * HH + (ks & 1) * 4) * HW) * ROWB;
+#pragma unroll
+          for (int nt = 0; nt < 3; ++nt) {
+            const char* a1 = bbase[t] + o + nt * 32;
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1 + 4 * ROWB));
+            bf[nt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+        };
+        // One wave per SIMD: whatever is issued between two MFMA bursts leaves the matrix pipe idle (an MFMA occupies it for 16
+        // cycles, the wave can issue ~3 other instructions meanwhile), so the LDS reads of slot + 2 and the next brick's global
+        // loads are dealt out one piece after each MFMA, and sched_barrier pins that order.
+        bf16x8 afr[2][3], bfr[3][3];
+        constexpr int NSLOT = NKS * WG_TPW;
+        auto frag_a = [&](int ks, int mt) {
+          const char* a1 = abase + (((ks >> 1) * BH + (ks & 1) * 4) * BW) * ROWB + mt * 32;
+          bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1));
+          bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1 + 4 * ROWB));
+          afr[ks & 1][mt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+        auto frag_b = [&](int sl, int nt) {
+          const int ks = sl / WG_TPW, t = sl - ks * WG_TPW;
+          const char* a1 = bbase[t] + (((ks >> 1) * HH + (ks & 1) * 4) * HW) * ROWB + nt * 32;
+          bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1));
+          bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1 + 4 * ROWB));
+          bfr[sl % 3][nt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) { if (sl == 0) frag_a(0, i); frag_b(sl, i); }
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+          for (int t = 0; t < WG_TPW; ++t) {
+            const int slot = ks * WG_TPW + t, nx = slot + 2;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+              const int mt = i / 3, nt = i - 3 * mt;
+              // the accumulators are pinned to AGPRs ("a"): left to the allocator, tiles shuttled between the two register
+              // files (600 v_accvgpr moves per brick) and the staged items spilled
+              asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[t][mt][nt]) : "v"(bfr[slot % 3][nt]), "v"(afr[ks & 1][mt]));
+#if !defined(MISEG_WG_EXP) || MISEG_WG_EXP != 2
+              if (nx < NSLOT) {
+                if (i < 3) frag_b(nx, i);
+                else if (i < 6 && nx % WG_TPW == 0) frag_a(nx / WG_TPW, i - 3);
+              }
+#endif
+#if !defined(MISEG_WG_EXP) || MISEG_WG_EXP != 1
+              if (i == 6 && slot < NXI + NDI) pitem(slot);          // one per slot from the start: the last item gets 35 slots (~3.7 us) of lead
+#endif
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+        static_assert(NKS * WG_TPW >= NXI + NDI, "not enough slots for the staged items");
+      } else
 #pragma unroll 1
       for (int ks = 0; ks < NVOX / 32; ++ks) {
         if (bd0 + (ks >> 1) >= g.D || bh0 + (ks & 1) * 4 >= g.H) continue;   // k-step entirely outside the volume (3^3, 6^3 grids): all zeros
@@ -631,22 +836,22 @@ __device__ __forceinline__ void conv3_wgrad_body(const T* __restrict__ x, int64_
           bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1 + 4 * rowb));
           af[mt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
+        // no guard around a tap slot: the last wave's 7th slot (tap 27) re-computes tap 0 into accumulators nobody stores, which
+        // keeps the k-step one basic block (a guarded slot waited for its own LDS reads before every 9 MFMAs)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          if (wave + 8 * t < 27) {
-            bf16x8 bfr[3];
+        for (int t = 0; t < WG_TPW; ++t) {
+          bf16x8 bfr[3];
 #pragma unroll
-            for (int nt = 0; nt < 3; ++nt) {
-              const char* a1 = lx + (hrow + toff[t]) * rowb + (nt * 16 + p4) * 2;
-              bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1));
-              bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1 + 4 * rowb));
-              bfr[nt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            }
-#pragma unroll
-            for (int mt = 0; mt < 3; ++mt)
-#pragma unroll
-              for (int nt = 0; nt < 3; ++nt) acc[t][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[mt], acc[t][mt][nt], 0, 0, 0);
+          for (int nt = 0; nt < 3; ++nt) {
+            const char* a1 = lx + (hrow + toff[t]) * rowb + (nt * 16 + p4) * 2;
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1 + 4 * rowb));
+            bfr[nt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           }
+#pragma unroll
+          for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) acc[t][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[mt], acc[t][mt][nt], 0, 0, 0);
         }
       }
     } else {
@@ -661,20 +866,22 @@ __device__ __forceinline__ void conv3_wgrad_body(const T* __restrict__ x, int64_
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt) af[mt] = *reinterpret_cast<const float*>(ld + vrow * rowb + (mt * 16 + fi) * 4);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          if (wave + 8 * t < 27) {
-            float bfr[3];
+        for (int t = 0; t < WG_TPW; ++t) {
+          float bfr[3];
 #pragma unroll
-            for (int nt = 0; nt < 3; ++nt) bfr[nt] = *reinterpret_cast<const float*>(lx + (hrow + toff[t]) * rowb + (nt * 16 + fi) * 4);
+          for (int nt = 0; nt < 3; ++nt) bfr[nt] = *reinterpret_cast<const float*>(lx + (hrow + toff[t]) * rowb + (nt * 16 + fi) * 4);
 #pragma unroll
-            for (int mt = 0; mt < 3; ++mt)
+          for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
-              for (int nt = 0; nt < 3; ++nt) acc[t][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[nt], af[mt], acc[t][mt][nt], 0, 0, 0);
-          }
+            for (int nt = 0; nt < 3; ++nt) acc[t][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[nt], af[mt], acc[t][mt][nt], 0, 0, 0);
         }
       }
     }
+    WG_STAMP(t_k1);
+    WG_STAMP_ADD(1, t_k0, t_k1);
+    WG_STAMP_ADD(3, t_k1 - 1, t_k1);
   }
+  WG_STAMP(t_e0);
   // slab[pair][split][co 48][tap 27][ci 48] (a reducing workgroup reads one contiguous 5 KB run per split);
   // swapped operands => lane holds ci = 16nt + 4fq + r, co = 16mt + fi
   if (direct) {
@@ -686,8 +893,8 @@ __device__ __forceinline__ void conv3_wgrad_body(const T* __restrict__ x, int64_
     for (int mt = 0; mt < 3; ++mt) {
       __syncthreads();
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int tap = wave + 8 * t;
+      for (int t = 0; t < WG_TPW; ++t) {
+        const int tap = wave + WG_WAVES * t;
         if (tap < 27) {
 #pragma unroll
           for (int nt = 0; nt < 3; ++nt)
@@ -707,12 +914,14 @@ __device__ __forceinline__ void conv3_wgrad_body(const T* __restrict__ x, int64_
         }
       }
     }
+    WG_STAMP(t_e1);
+    WG_STAMP_ADD(2, t_e0, t_e1);
     return;
   }
   float* slab = slabs + ((int64_t)pair * nsplit + split) * 27 * WG_CB * WG_CB;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int tap = wave + 8 * t;
+  for (int t = 0; t < WG_TPW; ++t) {
+    const int tap = wave + WG_WAVES * t;
     if (tap < 27) {
 #pragma unroll
       for (int mt = 0; mt < 3; ++mt)
@@ -721,13 +930,16 @@ __device__ __forceinline__ void conv3_wgrad_body(const T* __restrict__ x, int64_
           *reinterpret_cast<f32x4*>(slab + ((int64_t)(mt * 16 + fi) * 27 + tap) * WG_CB + nt * 16 + fq * 4) = acc[t][mt][nt];
     }
   }
+  WG_STAMP(t_e2);
+  WG_STAMP_ADD(2, t_e0, t_e2);
 }
 
-template <class T, int WBD>
+template <class T, int WBD, bool PIPED>
 __global__ void __launch_bounds__(WG_THREADS) conv3_wgrad_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ dy, int64_t lddy, float* __restrict__ slabs,
                                                                  float* __restrict__ dw, ConvGeom g, int Cin, int Cout, int ncib, int nsplit, int rowb, bool vec_x,
                                                                  bool vec_dy, int direct) {
-  conv3_wgrad_body<T, WBD>(x, ldx, dy, lddy, slabs, dw, g, Cin, Cout, ncib, nsplit, rowb, vec_x, vec_dy, blockIdx.x, blockIdx.y, direct);
+  conv3_wgrad_body<T, WBD, PIPED>(x, ldx, dy, lddy, slabs, dw, g, Cin, Cout, ncib, nsplit, rowb, vec_x, vec_dy, blockIdx.x, blockIdx.y, direct,
+                                  (nsplit & 7) == 0);
 }
 
 // Several layers in one launch (the small-grid weight gradients of a backward pass, queued by the host): descriptors travel
@@ -737,7 +949,7 @@ struct WgradLayer {
   int64_t ldx, lddy;
   ConvGeom g;
   int Cin, Cout, ncib, nsplit;
-  int wg0, flags;                  // first workgroup; bit0 vec_x, bit1 vec_dy, bits 2-3 direct mode
+  int wg0, flags;                  // first workgroup; bit0 vec_x, bit1 vec_dy, bits 2-3 direct mode, bit 4 pipelined loop
   int tiles, groups, spg, rb0;     // reduce launch: (co, ci-block) tiles x split groups, splits per group, first reduce block
 };
 static constexpr int WG_GROUP_MAX = 24;
@@ -750,8 +962,12 @@ __global__ void __launch_bounds__(WG_THREADS) conv3_wgrad_group_kernel(const Wgr
     if ((int)blockIdx.x >= grp.l[i].wg0) li = i;
   const WgradLayer& L = grp.l[li];
   const int local = blockIdx.x - L.wg0;
-  conv3_wgrad_body<T, WBD>((const T*)L.x, L.ldx, (const T*)L.dy, L.lddy, L.slabs, L.dw, L.g, L.Cin, L.Cout, L.ncib, L.nsplit, rowb, L.flags & 1, (L.flags >> 1) & 1,
-                           local % L.nsplit, local / L.nsplit, (L.flags >> 2) & 3);
+  if (std::is_same<T, bf16>::value && ((L.flags >> 4) & 1))
+    conv3_wgrad_body<T, WBD, true>((const T*)L.x, L.ldx, (const T*)L.dy, L.lddy, L.slabs, L.dw, L.g, L.Cin, L.Cout, L.ncib, L.nsplit, rowb, true, true,
+                                   local % L.nsplit, local / L.nsplit, (L.flags >> 2) & 3, ((L.nsplit | L.wg0) & 7) == 0);
+  else
+    conv3_wgrad_body<T, WBD, false>((const T*)L.x, L.ldx, (const T*)L.dy, L.lddy, L.slabs, L.dw, L.g, L.Cin, L.Cout, L.ncib, L.nsplit, rowb, L.flags & 1,
+                                    (L.flags >> 1) & 1, local % L.nsplit, local / L.nsplit, (L.flags >> 2) & 3, ((L.nsplit | L.wg0) & 7) == 0);
 }
 
 // dw[co][ci0..+48][tap] += sum over this group's splits of slab[pair][split][co%48][tap][0..48).
@@ -976,6 +1192,13 @@ extern "C" size_t miseg_conv3_wgrad_workspace_bytes(int B, int D, int H, int W, 
 }
 
 template <class T, int WBD>
+static bool wgrad_piped(const miseg_conv3_wgrad_params* p, bool vec_x, bool vec_dy) {
+  const int64_t span = (int64_t)(WBD + 2) * p->H * p->W * (p->ldx > p->lddy ? p->ldx : p->lddy) * (int64_t)sizeof(T);   // 32-bit item offsets
+  return std::is_same<T, bf16>::value && vec_x && vec_dy && p->Cin % WG_CB == 0 && p->Cout % WG_CB == 0 && p->D % WBD == 0 && p->H % BH == 0 && p->W % BW == 0 &&
+         span < ((int64_t)1 << 31);
+}
+
+template <class T, int WBD>
 static int conv3_wgrad_launch(const miseg_conv3_wgrad_params* p, hipStream_t s) {
   constexpr int KPC = Vec16<T>::N;
   int ncob, ncib, nsplit;
@@ -986,10 +1209,16 @@ static int conv3_wgrad_launch(const miseg_conv3_wgrad_params* p, hipStream_t s) 
   const bool vec_x = ((uintptr_t)p->x % 16 == 0) && (p->ldx % KPC == 0);
   const bool vec_dy = ((uintptr_t)p->dy % 16 == 0) && (p->lddy % KPC == 0);
   const int direct = nsplit == 1 ? (p->accumulate ? 1 : 2) : 0;     // a single producer per element: no slabs, no second launch
-  hipFuncSetAttribute((const void*)conv3_wgrad_kernel<T, WBD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   dim3 grid(nsplit, ncob * ncib);
-  conv3_wgrad_kernel<T, WBD><<<grid, WG_THREADS, lds, s>>>((const T*)p->x, p->ldx, (const T*)p->dy, p->lddy, (float*)p->workspace, p->dw, g, p->Cin, p->Cout, ncib,
-                                                           nsplit, rowb, vec_x, vec_dy, direct);
+  if (wgrad_piped<T, WBD>(p, vec_x, vec_dy)) {
+    hipFuncSetAttribute((const void*)conv3_wgrad_kernel<T, WBD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    conv3_wgrad_kernel<T, WBD, true><<<grid, WG_THREADS, lds, s>>>((const T*)p->x, p->ldx, (const T*)p->dy, p->lddy, (float*)p->workspace, p->dw, g, p->Cin, p->Cout,
+                                                                   ncib, nsplit, rowb, vec_x, vec_dy, direct);
+  } else {
+    hipFuncSetAttribute((const void*)conv3_wgrad_kernel<T, WBD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    conv3_wgrad_kernel<T, WBD, false><<<grid, WG_THREADS, lds, s>>>((const T*)p->x, p->ldx, (const T*)p->dy, p->lddy, (float*)p->workspace, p->dw, g, p->Cin, p->Cout,
+                                                                    ncib, nsplit, rowb, vec_x, vec_dy, direct);
+  }
   if (!direct) {
     const int64_t total = (int64_t)p->Cout * p->Cin * 27;
     if (!p->accumulate) MISEG_REQUIRE(fill_words_async(p->dw, 0, (size_t)total, s) == hipSuccess, MISEG_E_LAUNCH, "conv3_wgrad: fill");
@@ -1012,7 +1241,9 @@ static void wgrad_group_plan(const miseg_conv3_wgrad_params* p, int wbd, int* nc
   *ncob = cdiv(p->Cout, WG_CB);
   *ncib = cdiv(p->Cin, WG_CB);
   const int nbricks = p->B * cdiv(p->D, wbd) * cdiv(p->H, BH) * cdiv(p->W, BW);
-  *nsplit = cdiv(nbricks, WG_GROUP_BRICKS);
+  int ns = cdiv(nbricks, WG_GROUP_BRICKS);
+  if (ns >= 12 && ns + 7 <= nbricks) ns = (ns + 7) / 8 * 8;       // a multiple of 8: the XCD-contiguous brick order applies
+  *nsplit = ns;
 }
 
 static size_t wgrad_group_slab_floats(const miseg_conv3_wgrad_params* p, int wbd) {
@@ -1059,7 +1290,7 @@ static int conv3_wgrad_group_launch(const miseg_conv3_wgrad_params* descs, int n
     const int direct = nsplit == 1 ? (p->accumulate ? 1 : 2) : 0;
     const bool vec_x = ((uintptr_t)p->x % 16 == 0) && (p->ldx % KPC == 0);
     const bool vec_dy = ((uintptr_t)p->dy % 16 == 0) && (p->lddy % KPC == 0);
-    L.flags = (vec_x ? 1 : 0) | (vec_dy ? 2 : 0) | (direct << 2);
+    L.flags = (vec_x ? 1 : 0) | (vec_dy ? 2 : 0) | (direct << 2) | (wgrad_piped<T, WBD>(p, vec_x, vec_dy) ? 16 : 0);
     L.wg0 = wg;
     wg += ncob * ncib * nsplit;
     L.slabs = workspace + off;
@@ -1082,6 +1313,14 @@ static int conv3_wgrad_group_launch(const miseg_conv3_wgrad_params* descs, int n
   MISEG_LAUNCH_CHECK("conv3_wgrad_group");
   return MISEG_OK;
 }
+
+#ifdef MISEG_WGRAD_STAMPS
+extern "C" int miseg_debug_wgrad_stamps(unsigned long long* out) {   // read and reset
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(miseg::miseg_wg_stamps), sizeof(z)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(miseg::miseg_wg_stamps), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int miseg_conv3_wgrad_group(const miseg_conv3_wgrad_params* descs, int n, void* workspace, miseg_stream_t s_) {
   MISEG_REQUIRE(descs && n > 0 && n <= WG_GROUP_MAX, MISEG_E_BADARG, "conv3_wgrad_group: 1..%d layers per launch", WG_GROUP_MAX);
