@@ -198,7 +198,8 @@ int miseg_pack_conv3_batch(const miseg_pack_conv3_desc* descs_dev, int n, int to
 /* weight gradient: dw[Cout][Cin][27] (fp32, torch layout) (+)= sum_v dy[v][co] * x[v + tap][ci] */
 typedef struct {
   const void* x; int64_t ldx; const void* dy; int64_t lddy; float* dw;
-  int B, D, H, W, Cin, Cout, dtype, accumulate;
+  int B, D, H, W, Cin, Cout, dtype;
+  int accumulate;                  /* 0: dw = result; 1: dw += result; 2: dw is known to be zero on entry (no fill, no read-back) */
   void* workspace;                 /* miseg_conv3_wgrad_workspace_bytes */
 } miseg_conv3_wgrad_params;
 size_t miseg_conv3_wgrad_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout);

@@ -35,6 +35,17 @@ def _slot(p):
     return g
 
 
+def _slot_first(p):
+    """(slot, accumulate mode): 2 when this is the first write of the step into the slot (it still holds the zeros of
+    arena.begin_step, which resets `_miseg_used` together with the fill), else 1."""
+    g = getattr(p, "_miseg_grad", None) if p is not None else None
+    if g is None:
+        return None, 0
+    first = not p._miseg_used
+    p._miseg_used = True
+    return g, 2 if first else 1
+
+
 # ----------------------------------------------------------------------------------------------------------------
 class _Fork(Function):
     """y1 = y2 = x with the gradient sum done by our add kernel instead of the autograd engine's."""
@@ -275,10 +286,10 @@ class _Conv3(Function):
         dx = ops.conv3_fwd(dy, bwdp, ctx.wshape[1]) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
-            slot = _slot(ctx.params[0])
+            slot, mode = _slot_first(ctx.params[0])
             if slot is not None:
                 with ops.wgrad_side(x, dy, kind="conv"):
-                    ops.conv3_wgrad(x, dy, dw=slot, accumulate=True)
+                    ops.conv3_wgrad(x, dy, dw=slot, accumulate=mode)
             else:
                 dw = ops.conv3_wgrad(x, dy)
         return dx, dw

@@ -433,16 +433,16 @@ def flush_conv_wgrads():
     if not q:
         return
     lib = L.load()
-    for dt in {x.dtype for x, _, _ in q}:
+    for dt in {it[0].dtype for it in q}:
         items = [it for it in q if it[0].dtype == dt]
         for i in range(0, len(items), 24):
             chunk = items[i:i + 24]
             descs = (L.Conv3Wgrad * len(chunk))()
-            for j, (x, dy, dw) in enumerate(chunk):
+            for j, (x, dy, dw, acc) in enumerate(chunk):
                 B, D, H, W = _vol(x)
                 ldx, _, Cin = rows(x)
                 lddy, _, Cout = rows(dy)
-                descs[j] = L.Conv3Wgrad(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), B, D, H, W, Cin, Cout, _dt(x), 1, None)
+                descs[j] = L.Conv3Wgrad(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), B, D, H, W, Cin, Cout, _dt(x), acc, None)
             wsb = lib.miseg_conv3_wgrad_group_workspace_bytes(descs, len(chunk))
             ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32, device=chunk[0][0].device)
             L.check(lib.miseg_conv3_wgrad_group(descs, len(chunk), _ptr(ws), _stream()), "conv3_wgrad_group")
@@ -450,6 +450,8 @@ def flush_conv_wgrads():
 
 
 def conv3_wgrad(x, dy, dw=None, accumulate=False):
+    """accumulate: False / True, or 2 = `dw` is known to hold zeros (a fresh arena slot): single-producer layers then store instead
+    of read-modify-write and the others skip their zero fill."""
     B, D, H, W = _vol(x)
     ldx, n, Cin = rows(x)
     lddy, n2, Cout = rows(dy)
@@ -458,7 +460,7 @@ def conv3_wgrad(x, dy, dw=None, accumulate=False):
         dw = torch.empty(Cout, Cin, 3, 3, 3, dtype=torch.float32, device=x.device)
         accumulate = False
     if CONV_WGRAD_QUEUE is not None and accumulate and PROFILE_HOOK is None and B * D * H * W <= CONV_WGRAD_GROUP_VOXELS:
-        CONV_WGRAD_QUEUE.append((x, dy, dw))      # keeps x and dy alive until the flush
+        CONV_WGRAD_QUEUE.append((x, dy, dw, int(accumulate)))      # keeps x and dy alive until the flush
         return dw
     lib = L.load()
     ws = torch.empty(lib.miseg_conv3_wgrad_workspace_bytes(B, D, H, W, Cin, Cout) // 4, dtype=torch.float32, device=x.device)

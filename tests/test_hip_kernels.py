@@ -265,6 +265,20 @@ def test_conv3_wgrad_grouped(dtype):
         assert rel_err(dw - base, ref) < TOL[dtype], tuple(x.shape)
         single = ops.conv3_wgrad(x, dy)
         assert rel_err(dw - base, single) < 1e-5 if dtype == torch.float32 else 1e-3
+    # accumulate mode 2: "dw holds zeros" (a fresh arena slot) - stores instead of read-modify-write, no fill for the slab layers
+    ops.CONV_WGRAD_QUEUE = []
+    try:
+        zs = [torch.zeros_like(c[2]) for c in cases]
+        for (x, dy, _), z in zip(cases, zs):
+            ops.conv3_wgrad(x, dy, dw=z, accumulate=2)
+        ops.flush_conv_wgrads()
+    finally:
+        ops.CONV_WGRAD_QUEUE = None
+    for (x, dy, base), dw, z in zip(cases, outs, zs):
+        assert rel_err(z, dw - base) < 1e-5 if dtype == torch.float32 else 1e-3, tuple(x.shape)
+        z2 = torch.zeros_like(z)
+        ops.conv3_wgrad(x, dy, dw=z2, accumulate=2)
+        assert rel_err(z2, z) < 1e-5 if dtype == torch.float32 else 1e-3, tuple(x.shape)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
