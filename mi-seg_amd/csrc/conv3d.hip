@@ -166,7 +166,10 @@ static constexpr int FHH = FBH + 2, FHW = FBW + 2;
 static constexpr int FHROWS = (FBD + 2) * FHH * FHW;      // 648
 static constexpr int FPS = 656;                            // plane stride in rows (multiple of 16)
 
-template <class T, int NT>
+// WD = how many phases ahead the weights are requested: 1 for the large grids (the other workgroup of the CU hides the round
+// trip), 3 for the small ones (NT == 1: a 3^3 .. 12^3 layer is a chain of 14 phases per workgroup, each waiting ~1 us for weights
+// that only 12 MFMAs per wave cover)
+template <class T, int NT, int WD = 1>
 __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, const T* __restrict__ wpk,
                                                              ConvGeom g, int Cin, int CinP, int Cout, int CoP, bool vec_x, bool vec_y,
                                                              float* __restrict__ scratch, int chunks_per_split) {
@@ -201,7 +204,7 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
   // A lane's combo is fixed for the phase, so its operand for (output row mt, tap row kh) is the halo row mt + kh of ONE
   // plane: 6 LDS reads serve the 12 (mt, kh) pairs (the tap-major walk needed 12) -- the kernel is LDS-bandwidth bound
   // (21 ds_read_b128 per 36 MFMAs per wave = 85 % of the LDS peak at the MFMA-bound rate).  Phase 13 holds combos 52, 53 only.
-  VT wreg[WLOADS];
+  VT wreg[WD][WLOADS];
   int wq[WLOADS], wkh[WLOADS], wrow[WLOADS];
 #pragma unroll
   for (int i = 0; i < WLOADS; ++i) {
@@ -211,7 +214,7 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
     wq[i] = gk & 3;
     wrow[i] = (idx < WITEMS && n0 + row < CoP) ? n0 + row : -1;
   }
-  auto wload = [&](int phase, int cg0) {
+  auto wload = [&](int phase, int cg0, int slot) {
 #pragma unroll
     for (int i = 0; i < WLOADS; ++i) {
       VT v;
@@ -224,20 +227,21 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
         const int tap = kd * 9 + wkh[i] * 3 + kw;
         v = *reinterpret_cast<const VT*>(wpk + (((int64_t)tap * NCG + cg0 + cg) * CoP + wrow[i]) * KPC);
       }
-      wreg[i] = v;
+      wreg[slot][i] = v;
     }
   };
-  auto wstore = [&](int buf) {
+  auto wstore = [&](int buf, int slot) {
 #pragma unroll
     for (int i = 0; i < WLOADS; ++i)
-      if (tid + 256 * i < WITEMS) *reinterpret_cast<VT*>(lw + (buf * WITEMS + tid + 256 * i) * 16) = wreg[i];
+      if (tid + 256 * i < WITEMS) *reinterpret_cast<VT*>(lw + (buf * WITEMS + tid + 256 * i) * 16) = wreg[slot][i];
   };
   const int wfrag = fi * 16;
 
   int* rowoff = reinterpret_cast<int*>(lw + WITEMS * 16);   // aliases weight buffer 1 (rewritten by phase 1 => rebuilt per chunk)
   const int cbeg = blockIdx.z * chunks_per_split * CHUNK, cend = min(CinP, cbeg + chunks_per_split * CHUNK);
   for (int c0 = cbeg; c0 < cend; c0 += CHUNK) {
-    wload(0, c0 / KPC);
+#pragma unroll
+    for (int q = 0; q < WD; ++q) wload(q, c0 / KPC, q);
     // halo row -> voxel index (or -1 outside the volume = zero padding)
     for (int row = tid; row < FHROWS; row += 256) {
       const int hd = row / (FHH * FHW), rem = row - hd * (FHH * FHW);
@@ -298,11 +302,10 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
         if (idx < FHROWS * GPT) *reinterpret_cast<VT*>(lh + ((j >> 3) * FPS + blk * 8 + (j & 7)) * 16) = hv[i];
       }
     }
-    wstore(0);
+    wstore(0, 0);
     __syncthreads();
-#pragma unroll 1
-    for (int phase = 0; phase < 14; ++phase) {
-      if (phase + 1 < 14) wload(phase + 1, c0 / KPC);
+    auto run_phase = [&](int phase, int slot_load, int slot_store) {
+      if (phase + WD < 14) wload(phase + WD, c0 / KPC, slot_load);
       // this lane's combo -> plane and (kd, kw) displacement of its halo rows
       int combo = 4 * phase + fq;
       if (combo > 53) combo = 53;                      // the weights of the two missing groups of phase 13 are zero
@@ -327,9 +330,16 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
           for (int nt = 0; nt < NT; ++nt) MmaC<T>::run(acc[mt][nt], bfr[kh & 1][nt], af[mt + kh]);
       }
       if (phase + 1 < 14) {
-        wstore((phase + 1) & 1);     // buffer last read in phase - 1: every wave is past that phase's barrier
+        wstore((phase + 1) & 1, slot_store);     // buffer last read in phase - 1: every wave is past that phase's barrier
         __syncthreads();
       }
+    };
+    if constexpr (WD == 1) {
+#pragma unroll 1
+      for (int phase = 0; phase < 14; ++phase) run_phase(phase, 0, 0);
+    } else {
+#pragma unroll
+      for (int phase = 0; phase < 14; ++phase) run_phase(phase, phase % WD, (phase + 1) % WD);   // ring slots are compile-time
     }
     __syncthreads();                 // halo + weight buffers are free for the next chunk
   }
@@ -752,26 +762,6 @@ __device__ __forceinline__ void conv3_wgrad_body(const T* __restrict__ x, int64_
 #pragma unroll
         for (int t = 0; t < WG_TPW; ++t) bbase[t] = lx + (fq * HW + qq + toff[t]) * rowb + p4 * 2;
         constexpr int ROWB = WG_CB * (int)sizeof(T) + 16;       // == rowb (checked by the launcher)
-        auto load_a = [&](int ks, bf16x8 (&af)[3]) {
-          const int o = (((ks >> 1) * BH + (ks & 1) * 4) * BW) * ROWB;
-#pragma unroll
-          for (int mt = 0; mt < 3; ++mt) {
-            const char* a1 = abase + o + mt * 32;
-            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1));
-            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1 + 4 * ROWB));
-            af[mt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          }
-        };
-        auto load_b = [&](int ks, int t, bf16x8 (&bf)[3]) {
-          const int o = (((ks >> 1) * HH + (ks & 1) * 4) * HW) * ROWB;
-#pragma unroll
-          for (int nt = 0; nt < 3; ++nt) {
-            const char* a1 = bbase[t] + o + nt * 32;
-            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1));
-            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1 + 4 * ROWB));
-            bf[nt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          }
-        };
         // One wave per SIMD: whatever is issued between two MFMA bursts leaves the matrix pipe idle (an MFMA occupies it for 16
         // cycles, the wave can issue ~3 other instructions meanwhile), so the LDS reads of slot + 2 and the next brick's global
         // loads are dealt out one piece after each MFMA, and sched_barrier pins that order.
@@ -1067,7 +1057,7 @@ static void fwd96_plan(int nbricks, int Cout, int nchunks, int* nt, int* ksplit)
   if (blocks < 256 && *nt > 1) { *nt = 1; blocks = nbricks * cdiv(Cout, 16); }
   int ks = 1;
   if (blocks < 256 && nchunks > 1) {
-    ks = cdiv(512, blocks);
+    ks = cdiv(1024, blocks);      // tiny grids: one 96-byte chunk per workgroup (each chunk is a serial staging + 14-phase chain)
     if (ks > nchunks) ks = nchunks;
   }
   *ksplit = ks;
@@ -1111,13 +1101,13 @@ static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
     const size_t lds = (size_t)6 * FPS * 16 + (size_t)2 * 12 * 16 * nt * 16;
     MISEG_REQUIRE((int64_t)p->B * p->D * p->H * p->W < (1LL << 31), MISEG_E_UNSUPPORTED, "conv3_fwd: more than 2^31 voxels");
     dim3 grid(nbr, cdiv(p->Cout, 16 * nt), ksplit);
-#define F96_CASE(n)                                                                                                                          \
+#define F96_CASE(n, wd)                                                                                                                      \
   case n:                                                                                                                                   \
-    hipFuncSetAttribute((const void*)conv3_fwd96_kernel<T, n>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
-    conv3_fwd96_kernel<T, n><<<grid, 256, lds, s>>>((const T*)p->x, p->ldx, (T*)p->y, p->ldy, (const T*)p->wpk, gf, p->Cin, CinP, p->Cout, CoP, \
-                                                    vec_x, vec_y, scratch, cps);                                                            \
+    (void)hipFuncSetAttribute((const void*)conv3_fwd96_kernel<T, n, wd>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+    conv3_fwd96_kernel<T, n, wd><<<grid, 256, lds, s>>>((const T*)p->x, p->ldx, (T*)p->y, p->ldy, (const T*)p->wpk, gf, p->Cin, CinP, p->Cout, \
+                                                        CoP, vec_x, vec_y, scratch, cps);                                                   \
     break;
-    switch (nt) { F96_CASE(1) F96_CASE(2) F96_CASE(3) }
+    switch (nt) { F96_CASE(1, 3) F96_CASE(2, 1) F96_CASE(3, 1) }
 #undef F96_CASE
     if (scratch) {
       int cg = (int)((nvox * p->Cout + 255) / 256);
