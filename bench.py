@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-arena", action="store_true", help="torch-style per-parameter gradient tensors and per-call weight casts")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: all-reduce after the whole backward pass instead of overlapping the encoder half")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group (and take the N > 1 code path) even with one rank")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -75,9 +77,10 @@ def main():
     dev = torch.device("cuda", local)
     ge.load_package()
     dist = None
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -93,13 +96,33 @@ def main():
     if not a.no_arena:
         from mi_seg_amd.runtime.arena import ParamArena
         arena = ParamArena(params, dtype)
+    # N > 1: the backward pass is split behind the decoder side (autograd runs it first), whose gradients - 87 % of the bytes - are
+    # all-reduced by RCCL while the encoder / Swin half still runs
+    overlap = dist is not None and arena is not None and not a.no_overlap
+    tail = arena.tail_offset(model.late_backward_parameters()) if overlap else None
     graphed = None
     if not a.no_graph:
         from mi_seg_amd.runtime.graph import GraphedStep
-        graphed = GraphedStep(model, (1, 1, 96, 96, 96), (1, 6, 96, 96, 96), arena=arena)
+        graphed = GraphedStep(model, (1, 1, 96, 96, 96), (1, 6, 96, 96, 96), arena=arena, split=overlap)
 
-    def step(i, eager=False, sample=None):
+    def step(i, eager=False, sample=None, comm=True):
         k = order[i % len(order)] if sample is None else sample
+        if overlap and sample is None and comm:
+            works, ub = [], []
+            if graphed is not None and not eager:
+                def between():          # the flags of a replayed graph are known up front: the bitmap exchange starts here as well
+                    ub.append(arena.used_begin())
+                    works.extend(arena.allreduce_begin(tail, arena.flat.numel()))
+                graphed(pool[k:k + 1], [mods[k]], cot, between=between, publish=False)
+            else:
+                arena.begin_step()
+                cut = []
+                model(pool[k:k + 1], [mods[k]], cut=cut).backward(cot)
+                arena.flush()
+                works.extend(arena.allreduce_begin(tail, arena.flat.numel()))
+                torch.autograd.backward([o for o, _ in cut], [l.grad for _, l in cut])
+            arena.allreduce_end(works, world, rest=(0, tail), used_work=ub[0] if ub else None)
+            return
         if graphed is not None and not eager:
             graphed(pool[k:k + 1], [mods[k]], cot)
         elif arena is not None:
@@ -112,7 +135,7 @@ def main():
                 p.grad = None
             y = model(pool[k:k + 1], [mods[k]])
             y.backward(cot)
-        if dist is not None:
+        if dist is not None and comm:
             if arena is not None:
                 arena.allreduce(world)
             else:
@@ -176,7 +199,7 @@ def main():
     out = {
         "metric": "96^3 patches/sec fwd+bwd, C-Swin-UNETR fs=48 6-class", "value": world * a.steps / dt, "unit": "patches/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1000 * dt / a.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic", "launch": "eager" if graphed is None else "hipGraph",
+        "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic", "launch": "eager" if graphed is None else "hipGraph", "allreduce": "overlapped with the encoder half of backward" if overlap else ("after backward" if dist is not None else "none"),
         "config": {"workload": "configs[1]: C-Swin-UNETR feature_size=48 heads=(3,6,12,24) instance_cond, 96^3 patch, 6 classes, "
                                "batch 1 per GPU, fwd+bwd (+ gradient all-reduce at N>1)", "global_batch": world},
     }
@@ -188,7 +211,7 @@ def main():
     if rank == 0:
         if not a.no_roofline:
             from mi_seg_amd.testing.roofline import profile_step, summarize
-            out["roofline"] = summarize(profile_step(lambda: step(a.warmup + a.steps, eager=True)), dtype)
+            out["roofline"] = summarize(profile_step(lambda: step(a.warmup + a.steps, eager=True, comm=False)), dtype)      # rank 0 alone: no collectives
         if world == 1 and not a.no_cpu_baseline:
             from mi_seg_amd.testing.cpu_baseline import cpu_baseline
             out["cpu_baseline"] = cpu_baseline()

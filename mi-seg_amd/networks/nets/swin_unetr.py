@@ -124,8 +124,18 @@ class SwinUNETR(nn.Module):
         sd = {k.replace("module.", "").replace("fc1", "linear1").replace("fc2", "linear2"): v for k, v in weights["state_dict"].items()}
         return self.swinViT.load_state_dict(sd, strict=False)
 
-    def forward(self, x_in, modalities=None):
-        """x_in [B, C, D, H, W] float; modalities None | list[int] | int64 Tensor[B].  Returns fp32 logits [B, out, D, H, W]."""
+    # parameters whose gradients are complete once the decoder side has been back-propagated (autograd runs it first): what a
+    # data-parallel step can start all-reducing while the encoder / Swin half of the backward pass is still running
+    late_backward_prefixes = ("encoder10.", "decoder5.", "decoder4.", "decoder3.", "decoder2.", "decoder1.", "out.")
+
+    def late_backward_parameters(self):
+        return [p for k, p in self.named_parameters() if k.startswith(self.late_backward_prefixes)]
+
+    def forward(self, x_in, modalities=None, cut=None):
+        """x_in [B, C, D, H, W] float; modalities None | list[int] | int64 Tensor[B].  Returns fp32 logits [B, out, D, H, W].
+        cut: optional list; when given, the six tensors that cross from the Swin / encoder side to the decoder side are replaced by
+        detached leaves and (original, leaf) pairs are appended, so that `logits.backward(g)` stops at the leaves and
+        `torch.autograd.backward([o for o, _ in cut], [l.grad for _, l in cut])` finishes the pass (runtime/graph.py)."""
         if not x_in.is_cuda:
             raise RuntimeError("SwinUNETR (MI355X path) needs a HIP device tensor; there is no CPU fallback")
         needs = "instance_cond" in (self.vit_norm_name, self.encoder_norm_name, self.decoder_norm_name)
@@ -139,8 +149,15 @@ class SwinUNETR(nn.Module):
         enc1 = self.encoder2(hs[0], styles)
         enc2 = self.encoder3(hs[1], styles)
         enc3 = self.encoder4(hs[2], styles)
-        dec4 = self.encoder10(hs[4], styles)
-        dec3 = self.decoder5(dec4, hs[3], styles)
+        h4, h3 = hs[4], hs[3]
+        if cut is not None:
+            def leaf(t):
+                l = t.detach().requires_grad_(True)
+                cut.append((t, l))
+                return l
+            h4, h3, enc3, enc2, enc1, enc0 = (leaf(t) for t in (h4, h3, enc3, enc2, enc1, enc0))
+        dec4 = self.encoder10(h4, styles)
+        dec3 = self.decoder5(dec4, h3, styles)
         dec2 = self.decoder4(dec3, enc3, styles)
         dec1 = self.decoder3(dec2, enc2, styles)
         dec0 = self.decoder2(dec1, enc1, styles)

@@ -49,6 +49,7 @@ class ParamArena:
                 self.buckets.append((start, e))
                 start = e
         self.used_dev = torch.zeros(len(self.params), dtype=torch.int32, device=dev)
+        self._offs, self._size = offs, off
 
     # ---------------------------------------------------------------------------------------------- per step
     def begin_step(self, zero=True):
@@ -164,6 +165,13 @@ class ParamArena:
         ops.join_wgrad()
         ops.WGRAD_STREAM = None
 
+    def flush(self):
+        """issue everything queued so far and keep queueing (between the two halves of a split backward pass)."""
+        ops.flush_conv_wgrads()
+        ops.flush_gemm_tn()
+        ops.flush_tn_reduces()
+        ops.flush_colsums()
+
     def publish(self):
         self.end_backward()
         for p, v in zip(self.params, self.views):
@@ -175,14 +183,72 @@ class ParamArena:
         self.end_backward()
         self.used_dev.copy_(torch.tensor([int(p._miseg_used) for p in self.params], dtype=torch.int32), non_blocking=True)
         works = [dist.all_reduce(self.used_dev, op=dist.ReduceOp.MAX, group=group, async_op=True)]
+        avg = self._avg(group)
         for lo, hi in reversed(self.buckets):
-            works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True))
+            works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=group, async_op=True))
         for w in works:
             w.wait()
-        self.flat.mul_(1.0 / world_size)
+        if not avg:
+            self.flat.mul_(1.0 / world_size)
         for p, u in zip(self.params, self.used_dev.tolist()):
             p._miseg_used = bool(u)
         self.publish()
+
+    # ------------------------------------------------------------------ all-reduce overlapped with the rest of the backward pass
+    def tail_offset(self, late_params):
+        """`late_params`: the parameters whose gradients are final after the FIRST half of a split backward pass (the decoder
+        side of the net: its backward runs first).  They must form the tail of the arena; returns the element offset where
+        that tail starts."""
+        late = {id(p) for p in late_params if p.requires_grad}
+        flags = [id(p) in late for p in self.params]
+        first = flags.index(True) if True in flags else len(flags)
+        if not all(flags[first:]) or any(flags[:first]):
+            raise ValueError("the late parameters are not a contiguous tail of the arena (parameter registration order changed?)")
+        return self._offs[first] if first < len(flags) else self._size
+
+    def allreduce_begin(self, lo, hi, group=None, piece=16 << 20):
+        """start the sum all-reduce of flat[lo:hi] (pieces of `piece` elements, last first) behind everything already queued on the
+        current stream; returns the work handles.  RCCL runs them on its own stream: kernels launched afterwards overlap."""
+        import torch.distributed as dist
+        works, e = [], hi
+        while e > lo:
+            b = max(lo, e - piece)
+            works.append(dist.all_reduce(self.flat[b:e], op=dist.ReduceOp.AVG if self._avg(group) else dist.ReduceOp.SUM, group=group, async_op=True))
+            e = b
+        return works
+
+    def used_begin(self, group=None):
+        """start the max all-reduce of the "used on this rank" bitmap (call once the flags of this step are known: for a replayed
+        hipGraph that is before the replay); hand the result to allreduce_end."""
+        import torch.distributed as dist
+        self.used_dev.copy_(torch.tensor([int(p._miseg_used) for p in self.params], dtype=torch.int32), non_blocking=True)
+        return dist.all_reduce(self.used_dev, op=dist.ReduceOp.MAX, group=group, async_op=True)
+
+    def allreduce_end(self, works, world_size, group=None, rest=None, used_work=None):
+        """finish a split exchange: the "used on any rank" bitmap (unless used_begin already started it), then the all-reduce of
+        flat[rest[0]:rest[1]] (the part the second half of the backward pass produced), wait for everything, mean, publish.  The
+        bitmap goes first so that the host read of it (the one host sync of a step, like torch DDP's find_unused_parameters)
+        completes while the rest is still in flight."""
+        self.end_backward()
+        ub = used_work if used_work is not None else self.used_begin(group)
+        works = list(works)
+        if rest is not None:
+            works += self.allreduce_begin(rest[0], rest[1], group)
+        ub.wait()
+        used = self.used_dev.tolist()
+        for w in works:
+            w.wait()
+        if not self._avg(group):
+            self.flat.mul_(1.0 / world_size)
+        for p, u in zip(self.params, used):
+            p._miseg_used = bool(u)
+        self.publish()
+
+    @staticmethod
+    def _avg(group=None):
+        """RCCL averages in the collective (ReduceOp.AVG); gloo (CPU tests) sums and the arena is scaled afterwards"""
+        import torch.distributed as dist
+        return dist.get_backend(group) == "nccl"
 
     def detach(self):
         ops.COLSUM_QUEUE = None

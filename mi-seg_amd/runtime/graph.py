@@ -14,11 +14,17 @@ from ..hip import ops
 
 
 class GraphedStep:
-    def __init__(self, model: torch.nn.Module, batch_shape: Sequence[int], out_shape: Sequence[int], warmup: int = 2, arena=None):
+    def __init__(self, model: torch.nn.Module, batch_shape: Sequence[int], out_shape: Sequence[int], warmup: int = 2, arena=None, split=False):
         """arena: optional runtime.arena.ParamArena of the model (gradients accumulate in its flat buffer, parameter
-        re-layouts are refreshed by one kernel per step); without it every gradient is a tensor of the graph's pool."""
+        re-layouts are refreshed by one kernel per step); without it every gradient is a tensor of the graph's pool.
+        split (needs an arena and a model with `forward(..., cut=)`): the step is recorded as TWO graphs - forward + the decoder
+        side of the backward pass, then the encoder side - and `__call__(..., between=fn)` runs `fn()` between the two replays:
+        the data-parallel step starts the all-reduce of the decoder-side gradients there, so RCCL overlaps the second graph."""
         self.model = model
         self.arena = arena
+        self.split = bool(split)
+        if self.split and arena is None:
+            raise ValueError("a split step needs a ParamArena")
         self.params = [p for p in model.parameters() if p.requires_grad]
         dev = self.params[0].device
         self.x = torch.zeros(*batch_shape, dtype=torch.float32, device=dev)
@@ -40,27 +46,55 @@ class GraphedStep:
             self.arena.end_backward()
         return y
 
+    def _run_first(self, host):
+        """forward + the decoder-side half of the backward pass; everything queued so far is issued, so the late parameters'
+        arena slots are final when this returns"""
+        self.arena.begin_step()
+        cut = []
+        y = self.model(self.x, (self.styles, host), cut=cut)
+        y.backward(self.cot)
+        self.arena.flush()
+        return y, cut
+
+    def _run_second(self, cut):
+        torch.autograd.backward([o for o, _ in cut], [l.grad for _, l in cut])
+        self.arena.end_backward()
+
     def _capture(self, host):
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(max(self.warmup, 2 if self.arena is not None else 0)):   # arena: step 1 registers the re-layouts
-                self._run(host)
+                if self.split:
+                    self._run_second(self._run_first(host)[1])
+                else:
+                    self._run(host)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         for p in self.params:
             p.grad = None
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            y = self._run(host)
+        g2 = None
+        if self.split:
+            with torch.cuda.graph(g):
+                y, cut = self._run_first(host)
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, pool=g.pool()):        # the second graph consumes activations the first one saved: one pool
+                self._run_second(cut)
+            del cut
+        else:
+            with torch.cuda.graph(g):
+                y = self._run(host)
         if self.arena is not None:
             grads = [bool(p._miseg_used) for p in self.arena.params]       # which slots this graph writes
         else:
             grads = [p.grad for p in self.params]
-        return g, grads, y
+        return (g, g2), grads, y
 
-    def __call__(self, x, modalities: Sequence[int], cot):
-        """x [B,C,D,H,W] fp32, cotangent d(loss)/d(logits); returns logits (static buffer) with p.grad populated."""
+    def __call__(self, x, modalities: Sequence[int], cot, between=None, publish=True):
+        """x [B,C,D,H,W] fp32, cotangent d(loss)/d(logits); returns logits (static buffer) with p.grad populated.
+        between: called between the two replays of a split step; publish=False leaves `p.grad` to the caller
+        (arena.allreduce_end does it after the exchange)."""
         host = tuple(int(m) for m in modalities)
         self.x.copy_(x, non_blocking=True)
         self.cot.copy_(cot, non_blocking=True)
@@ -68,12 +102,18 @@ class GraphedStep:
         key = tuple(sorted(set(host))) + (len(host),)
         if key not in self.graphs:
             self.graphs[key] = self._capture(host)
-        g, grads, y = self.graphs[key]
-        g.replay()
+        (g, g2), grads, y = self.graphs[key]
         if self.arena is not None:
-            for p, used in zip(self.arena.params, grads):
-                p._miseg_used = used
-            self.arena.publish()
+            for p, used in zip(self.arena.params, grads):      # static per graph: known before the replay (the split step's hook
+                p._miseg_used = used                           # exchanges the "used" bitmap early)
+        g.replay()
+        if g2 is not None:
+            if between is not None:
+                between()
+            g2.replay()
+        if self.arena is not None:
+            if publish:
+                self.arena.publish()
         else:
             for p, gr in zip(self.params, grads):
                 p.grad = gr

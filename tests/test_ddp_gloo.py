@@ -61,6 +61,29 @@ def _worker(rank, world, port, q):
         ok &= torch.allclose(s0.grad, torch.full((4,), 1.0)) and torch.allclose(s1.grad, torch.full((4,), 3.0))
         ok &= unused.grad is None
         ok &= shared.grad.data_ptr() == shared._miseg_grad.data_ptr()      # p.grad IS the arena slot (no copies)
+    # the overlapped exchange of bench.py at N > 1: the tail of the arena (parameters whose gradients are final after the first half
+    # of the backward pass) starts its all-reduce early, the rest follows after the second half
+    tail = arena.tail_offset([s1, unused])
+    ok &= tail == arena._offs[2]
+    try:
+        arena.tail_offset([s0, unused])
+        ok = False
+    except ValueError:
+        pass
+    for it in range(2):
+        arena.flat.zero_()
+        for p in params:
+            p._miseg_used = False
+        mine_p = s0 if rank == 0 else s1
+        mine_p._miseg_grad.fill_(2.0 if rank == 0 else 6.0)
+        mine_p._miseg_used = True
+        works = arena.allreduce_begin(tail, arena.flat.numel(), piece=3)          # tiny pieces: several collectives per range
+        shared._miseg_grad.fill_(float(rank + 1) + it)                             # "second half of the backward pass"
+        shared._miseg_used = True
+        arena.allreduce_end(works, world, rest=(0, tail))
+        ok &= torch.allclose(shared.grad, torch.full((5, 3), 1.5 + it))
+        ok &= torch.allclose(s0.grad, torch.full((4,), 1.0)) and torch.allclose(s1.grad, torch.full((4,), 3.0))
+        ok &= unused.grad is None
     arena.detach()
     # rank sharding: disjoint cover of the concatenated CT+MR index range
     mine = rank_indices(32, world, rank, epoch=1, seed=0)

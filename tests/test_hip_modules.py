@@ -300,7 +300,7 @@ def test_param_arena_matches_plain_autograd(dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("use_arena", [False, True])
+@pytest.mark.parametrize("use_arena", [False, True, "split"])
 def test_graphed_step_replays_match_eager(use_arena):
     """every replay of the captured step - not only the first - must reproduce the eager step, for both modalities and with
     host activity (allocations, host reads) between replays.  Regression: zero fills recorded as memset nodes were replayed
@@ -332,9 +332,20 @@ def test_graphed_step_replays_match_eager(use_arena):
     ref = {m: eager(m) for m in (0, 1)}
     arena = ParamArena(params, torch.bfloat16) if use_arena else None
     try:
-        step = GraphedStep(net, x.shape, cot.shape, arena=arena)
+        # "split": the data-parallel variant - two graphs (forward + decoder-side backward, then the encoder side) with a hook in
+        # between where bench.py starts the all-reduce of the decoder-side gradients; here the hook checks that those are final
+        split = use_arena == "split"
+        step = GraphedStep(net, x.shape, cot.shape, arena=arena, split=split)
+        late, seen = None, []
+        if split:
+            tail = arena.tail_offset(net.late_backward_parameters())
+            assert 0 < tail < arena.flat.numel()
+            late = lambda: seen.append(arena.flat[tail:].clone())
         for it, m in enumerate([0, 0, 1, 0, 1, 1]):
-            y = step(x, [m], cot)
+            y = step(x, [m], cot, between=late) if split else step(x, [m], cot)
+            if split:
+                torch.cuda.synchronize()
+                assert torch.equal(seen[-1], arena.flat[tail:]), "decoder-side gradients changed after the first graph"
             torch.cuda.synchronize()
             y_ref, g_ref = ref[m]
             # the inline host-side check is part of the regression: it allocates and launches between two replays
