@@ -73,6 +73,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("MISEG_REHEARSE_ONE_GPU"):      # rehearsal of the N > 1 code path with every rank on the one card of a 1-GPU box
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     ge.load_package()
@@ -81,7 +83,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("MISEG_DIST_BACKEND", "nccl"), rank=rank, world_size=world)    # "nccl" is RCCL on ROCm
 
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     model = build_model(dtype)
@@ -196,6 +198,21 @@ def main():
         rel = lambda u, v: float((u - v).norm() / v.norm())
         return {"logits_rel_err": rel(y, ye.detach().float()), "grad_rel_err": rel(g, ge_), "finite": bool(torch.isfinite(g).all())}
 
+    def exchange_check():
+        """untimed, N > 1: the arena after one (overlapped) data-parallel step against the plain mean of the ranks' local gradients"""
+        k = order[(a.warmup + a.steps + 1) % len(order)]
+        if graphed is not None:
+            graphed(pool[k:k + 1], [mods[k]], cot)
+        else:
+            arena.begin_step()
+            model(pool[k:k + 1], [mods[k]]).backward(cot)
+            arena.publish()
+        want = arena.flat.clone()
+        dist.all_reduce(want)
+        want /= world
+        step(a.warmup + a.steps + 1)
+        return {"grad_rel_err_vs_mean_of_ranks": float((arena.flat - want).norm() / want.norm())}
+
     out = {
         "metric": "96^3 patches/sec fwd+bwd, C-Swin-UNETR fs=48 6-class", "value": world * a.steps / dt, "unit": "patches/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1000 * dt / a.steps, "higher_is_better": True,
@@ -208,6 +225,8 @@ def main():
         if not check["finite"] or check["logits_rel_err"] > 1e-2 or check["grad_rel_err"] > 5e-2:
             raise SystemExit(f"hipGraph replay does not reproduce the eager step: {check}")
         out["replay_check"] = check
+    if dist is not None and arena is not None:
+        out["exchange_check"] = exchange_check()
     if rank == 0:
         if not a.no_roofline:
             from mi_seg_amd.testing.roofline import profile_step, summarize
