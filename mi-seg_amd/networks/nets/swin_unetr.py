@@ -128,6 +128,15 @@ class SwinUNETR(nn.Module):
     # data-parallel step can start all-reducing while the encoder / Swin half of the backward pass is still running
     late_backward_prefixes = ("encoder10.", "decoder5.", "decoder4.", "decoder3.", "decoder2.", "decoder1.", "out.")
 
+    overlap_encoder1 = False     # measured on one MI355X (hipGraph): 12 % of the kernel time ran concurrently, the step time did not move (the
+                                 # graph already keeps the chip 98.7 % busy; co-resident kernels just stretch each other) - off
+
+    def _side_stream(self, device):
+        st = getattr(self, "_side", None)
+        if st is None or st.device != device:
+            st = self._side = torch.cuda.Stream(device=device)
+        return st
+
     def late_backward_parameters(self):
         return [p for k, p in self.named_parameters() if k.startswith(self.late_backward_prefixes)]
 
@@ -144,8 +153,21 @@ class SwinUNETR(nn.Module):
         styles = styles_to_device(modalities, x_in.device, x_in.shape[0]) if modalities is not None else None
         x_in = x_in.float().contiguous()
         dt = self.compute_dtype
+        # encoder1 (three 96^3 convolutions) depends on the image only: on a side stream it runs next to the Swin transformer, whose
+        # ~300 short launches per direction leave the chip idle between dependent kernels.  One fork / one join per direction; autograd
+        # replays each backward on the stream of its forward.
+        side = self._side_stream(x_in.device) if self.overlap_encoder1 else None
+        if side is not None:
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                enc0 = self.encoder1(None, styles, image=x_in, dtype=dt)
         hs = self.swinViT(x_in, self.normalize, styles, dt)
-        enc0 = self.encoder1(None, styles, image=x_in, dtype=dt)
+        if side is not None:
+            cur.wait_stream(side)
+            enc0.record_stream(cur)
+        else:
+            enc0 = self.encoder1(None, styles, image=x_in, dtype=dt)
         enc1 = self.encoder2(hs[0], styles)
         enc2 = self.encoder3(hs[1], styles)
         enc3 = self.encoder4(hs[2], styles)
