@@ -179,6 +179,13 @@ typedef struct {
   const void* x; int64_t ldx; void* y; int64_t ldy; const void* wpk;
   int B, D, H, W, Cin, Cout, dtype;
   void* workspace;                 /* miseg_conv3_fwd_workspace_bytes (0 bytes for most shapes: may be NULL then) */
+  /* optional epilogue pieces, only on the 96-byte-chunk path (channel rows of `dtype` a multiple of 96 bytes; else MISEG_E_UNSUPPORTED):
+   * res (ldres): added to the result before rounding (the other gradient of a forked input when this is the data-gradient pass);
+   * stat: fp64 [16][B][Cout][2] (miseg_instnorm_stat_bytes, zero on entry) - per-channel sum / sum of squares of the ROUNDED
+   *       output, i.e. what miseg_instnorm_stats would compute from y (dynunet_block.py:105-107: every conv feeds a norm);
+   *       not with a workspace (split reduction). */
+  const void* res; int64_t ldres;
+  void* stat;
 } miseg_conv3_params;
 /* small grids split the reduction over workgroups and need an fp32 staging buffer of the output */
 size_t miseg_conv3_fwd_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int dtype);

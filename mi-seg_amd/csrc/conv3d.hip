@@ -169,10 +169,12 @@ static constexpr int FPS = 656;                            // plane stride in ro
 // WD = how many phases ahead the weights are requested: 1 for the large grids (the other workgroup of the CU hides the round
 // trip), 3 for the small ones (NT == 1: a 3^3 .. 12^3 layer is a chain of 14 phases per workgroup, each waiting ~1 us for weights
 // that only 12 MFMAs per wave cover)
-template <class T, int NT, int WD = 1>
+// EPI: the optional epilogue pieces (residual add, norm statistics) are compiled in; the plain instantiation carries none of it
+template <class T, int NT, int WD = 1, bool EPI = false>
 __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, const T* __restrict__ wpk,
                                                              ConvGeom g, int Cin, int CinP, int Cout, int CoP, bool vec_x, bool vec_y,
-                                                             float* __restrict__ scratch, int chunks_per_split) {
+                                                             float* __restrict__ scratch, int chunks_per_split, const T* __restrict__ res, int64_t ldres,
+                                                             double* __restrict__ stat) {
   typedef typename Vec16<T>::type VT;
   constexpr int KPC = MmaC<T>::KPC;
   constexpr int GPT = 6, CHUNK = GPT * KPC;
@@ -345,6 +347,12 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
   }
   // epilogue: lane holds channels n0 + 16nt + 4fq .. +3 of voxel (d0 + wave, h0 + mt, w0 + fi)
   const int d = d0 + wave, w = w0 + fi;
+  const bool vec_r = res && (reinterpret_cast<uintptr_t>(res) & 15) == 0 && ldres % KPC == 0;
+  float ssum[NT][4], ssq[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ssum[nt][r] = 0.f; ssq[nt][r] = 0.f; }
   const int64_t nvox_total = (int64_t)g.B * g.D * g.H * g.W;
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
@@ -363,32 +371,82 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
         continue;
       }
       T* yr = y + vox * ldy;
+      const T* rr = (EPI && res) ? res + vox * ldres : nullptr;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int co = n0 + nt * 16 + fq * 4;
+        f32x4 v = acc[mt][nt];
+        if (EPI && rr) {
+          if (vec_r && co + 3 < Cout) {
+            if constexpr (std::is_same<T, bf16>::value) {
+              const bf16x4 q = *reinterpret_cast<const bf16x4*>(rr + co);
+              v += f32x4{(float)q[0], (float)q[1], (float)q[2], (float)q[3]};
+            } else {
+              v += *reinterpret_cast<const f32x4*>(rr + co);
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (co + r < Cout) v[r] += to_f32(rr[co + r]);
+          }
+        }
+        T o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[r] = from_f32<T>(v[r]);
+          if (EPI && co + r < Cout) {               // statistics of the stored (rounded) values
+            const float q = to_f32(o[r]);
+            ssum[nt][r] += q;
+            ssq[nt][r] += q * q;
+          }
+        }
         if (vec_y && co + 3 < Cout) {
           if constexpr (std::is_same<T, bf16>::value) {
-            bf16x4 o{(bf16)acc[mt][nt][0], (bf16)acc[mt][nt][1], (bf16)acc[mt][nt][2], (bf16)acc[mt][nt][3]};
-            *reinterpret_cast<bf16x4*>(yr + co) = o;
+            *reinterpret_cast<bf16x4*>(yr + co) = bf16x4{o[0], o[1], o[2], o[3]};
           } else {
-            *reinterpret_cast<f32x4*>(yr + co) = acc[mt][nt];
+            *reinterpret_cast<f32x4*>(yr + co) = f32x4{o[0], o[1], o[2], o[3]};
           }
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (co + r < Cout) yr[co + r] = from_f32<T>(acc[mt][nt][r]);
+            if (co + r < Cout) yr[co + r] = o[r];
         }
       }
+    }
+  }
+  if (EPI && stat) {   // kernel argument: uniform
+    // every lane's 8 NT partial sums go to LDS ([k][column][wave * 16 + fi], 65-float rows: conflict-free both ways), then one thread
+    // per (column, k) adds the 64 of them: 24 writes + 64 reads instead of ~190 cross-lane shuffles per lane
+    float* red = reinterpret_cast<float*>(lds);      // the staging images are dead (last barrier of the K loop)
+    constexpr int RS = 65;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = nt * 16 + fq * 4 + r;
+        red[(0 * NROWS + col) * RS + wave * 16 + fi] = ssum[nt][r];
+        red[(1 * NROWS + col) * RS + wave * 16 + fi] = ssq[nt][r];
+      }
+    __syncthreads();
+    if (tid < NROWS * 2) {
+      const int k = tid / NROWS, col = tid - k * NROWS;
+      const float* rp = red + (k * NROWS + col) * RS;
+      float tot = 0.f;
+#pragma unroll 16
+      for (int i = 0; i < 64; ++i) tot += rp[i];
+      if (n0 + col < Cout) atomicAdd(stat + (((int64_t)(blockIdx.x & 15) * g.B + b) * Cout + n0 + col) * 2 + k, (double)tot);
     }
   }
 }
 
 template <class T>
-__global__ void __launch_bounds__(256) conv3_scratch_to_out_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t ldd, int64_t rows, int C, int nslabs) {
+__global__ void __launch_bounds__(256) conv3_scratch_to_out_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t ldd, int64_t rows, int C, int nslabs,
+                                                                   const T* __restrict__ res, int64_t ldres) {
   const int64_t total = rows * C;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     float a = src[i];
     for (int z = 1; z < nslabs; ++z) a += src[(int64_t)z * total + i];
+    if (res) a += to_f32(res[(i / C) * ldres + i % C]);
     dst[(i / C) * ldd + i % C] = from_f32<T>(a);
   }
 }
@@ -1092,6 +1150,7 @@ static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
     ksplit = cdiv(nchunks, cps);
     float* scratch = nullptr;
     const int64_t nvox = (int64_t)p->B * p->D * p->H * p->W;
+    MISEG_REQUIRE(!(p->stat && ksplit > 1), MISEG_E_UNSUPPORTED, "conv3_fwd: fused statistics with a split reduction");
     if (ksplit > 1) {
       MISEG_REQUIRE(p->workspace, MISEG_E_BADARG, "conv3_fwd: workspace required (miseg_conv3_fwd_workspace_bytes)");
       scratch = (float*)p->workspace;
@@ -1101,22 +1160,27 @@ static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
     const size_t lds = (size_t)6 * FPS * 16 + (size_t)2 * 12 * 16 * nt * 16;
     MISEG_REQUIRE((int64_t)p->B * p->D * p->H * p->W < (1LL << 31), MISEG_E_UNSUPPORTED, "conv3_fwd: more than 2^31 voxels");
     dim3 grid(nbr, cdiv(p->Cout, 16 * nt), ksplit);
+#define F96_LAUNCH(n, wd, epi)                                                                                                               \
+    (void)hipFuncSetAttribute((const void*)conv3_fwd96_kernel<T, n, wd, epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+    conv3_fwd96_kernel<T, n, wd, epi><<<grid, 256, lds, s>>>((const T*)p->x, p->ldx, (T*)p->y, p->ldy, (const T*)p->wpk, gf, p->Cin, CinP,    \
+                                                             p->Cout, CoP, vec_x, vec_y, scratch, cps, scratch ? nullptr : (const T*)p->res,   \
+                                                             p->ldres, (double*)p->stat)
 #define F96_CASE(n, wd)                                                                                                                      \
   case n:                                                                                                                                   \
-    (void)hipFuncSetAttribute((const void*)conv3_fwd96_kernel<T, n, wd>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
-    conv3_fwd96_kernel<T, n, wd><<<grid, 256, lds, s>>>((const T*)p->x, p->ldx, (T*)p->y, p->ldy, (const T*)p->wpk, gf, p->Cin, CinP, p->Cout, \
-                                                        CoP, vec_x, vec_y, scratch, cps);                                                   \
+    if (!scratch && (p->res || p->stat)) { F96_LAUNCH(n, wd, true); } else { F96_LAUNCH(n, wd, false); }                                    \
     break;
     switch (nt) { F96_CASE(1, 3) F96_CASE(2, 1) F96_CASE(3, 1) }
 #undef F96_CASE
+#undef F96_LAUNCH
     if (scratch) {
       int cg = (int)((nvox * p->Cout + 255) / 256);
       if (cg > 4096) cg = 4096;
-      conv3_scratch_to_out_kernel<T><<<cg, 256, 0, s>>>(scratch, (T*)p->y, p->ldy, nvox, p->Cout, ksplit);
+      conv3_scratch_to_out_kernel<T><<<cg, 256, 0, s>>>(scratch, (T*)p->y, p->ldy, nvox, p->Cout, ksplit, (const T*)p->res, p->ldres);
     }
     MISEG_LAUNCH_CHECK("conv3_fwd96");
     return MISEG_OK;
   }
+  MISEG_REQUIRE(!p->res && !p->stat, MISEG_E_UNSUPPORTED, "conv3_fwd: fused residual / statistics need 96-byte channel chunks");
   int chunk_bytes;
   if (rowbytes <= 128) chunk_bytes = rowbytes;
   else if (rowbytes % 128 == 0) chunk_bytes = 128;

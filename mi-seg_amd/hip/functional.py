@@ -87,14 +87,18 @@ class _InstNorm(Function):
     reference: networks/norms/conditional_instance_norm.py:59-68, dynunet_block.py:100-126."""
 
     @staticmethod
-    def forward(ctx, x, res, styles_dev, styles_host, num_styles, affine, act, slope, eps, fork, *params):
+    def forward(ctx, x, res, styles_dev, styles_host, num_styles, affine, act, slope, eps, fork, stat_in, *params):
         """fork=True additionally returns x itself (the skip branch of `x + f(norm(x))`): the backward then receives both
         gradients at once and the fan-out sum rides in the norm-backward kernel instead of a separate add."""
         B = x.shape[0]
         S = ops.rows(x)[1] // B
         gammas = list(params[0::2]) if affine else None
         betas = list(params[1::2]) if affine else None
-        y, stat = ops.instnorm_fwd(x, B, S, styles_dev, gammas, betas, res=res, act=act, slope=slope, eps=eps)
+        if stat_in is not None:      # statistics already produced by the epilogue of the kernel that wrote x
+            stat = stat_in
+            y = ops.instnorm_apply(x, B, S, stat, styles_dev, gammas, betas, res=res, act=act, slope=slope, eps=eps)
+        else:
+            y, stat = ops.instnorm_fwd(x, B, S, styles_dev, gammas, betas, res=res, act=act, slope=slope, eps=eps)
         ctx.meta = (B, S, styles_host, num_styles, affine, act, slope, res is not None, eps)
         ctx.params = params
         ctx.save_for_backward(x, y if act != L.ACT_NONE else None, stat, styles_dev, *(gammas or []))
@@ -123,10 +127,10 @@ class _InstNorm(Function):
         if affine:
             for s in range(num_styles):
                 pg += [None, None] if in_arena else [dgam[s], dbet[s]]
-        return (dx, dres, None, None, None, None, None, None, None, None, *pg)
+        return (dx, dres, None, None, None, None, None, None, None, None, None, *pg)
 
 
-def instance_norm(x, params=None, styles_dev=None, styles_host=None, res=None, act=L.ACT_NONE, slope=0.01, eps=1e-5, fork=False):
+def instance_norm(x, params=None, styles_dev=None, styles_host=None, res=None, act=L.ACT_NONE, slope=0.01, eps=1e-5, fork=False, stat=None):
     """params: None (no affine) | [(gamma, beta)] (plain) | [(g0,b0),(g1,b1),...] (conditional, one pair per style).
     fork=True returns (norm(x), x): see _InstNorm.forward."""
     flat = []
@@ -135,7 +139,7 @@ def instance_norm(x, params=None, styles_dev=None, styles_host=None, res=None, a
         n = len(params)
         for g, b in params:
             flat += [g, b]
-    return _InstNorm.apply(x, res, styles_dev, styles_host, n, params is not None, act, slope, eps, fork, *flat)
+    return _InstNorm.apply(x, res, styles_dev, styles_host, n, params is not None, act, slope, eps, fork, stat, *flat)
 
 
 class _LayerNorm(Function):
@@ -267,23 +271,37 @@ def gelu(x):
 
 # ----------------------------------------------------------------------------------------------------------------
 class _Conv3(Function):
-    """3x3x3 / s1 / p1 / no bias (dynunet_block.py:295-326) as implicit GEMM; dgrad = same kernel, mirrored pack."""
+    """3x3x3 / s1 / p1 / no bias (dynunet_block.py:295-326) as implicit GEMM; dgrad = same kernel, mirrored pack.
+    want_stat: second output = the instance-norm statistics of y from the kernel's epilogue (None where the kernel path has none).
+    fork: last output = x again (the residual branch of a UnetResBlock); the gradient arriving there is added in the epilogue of the
+    data-gradient kernel instead of by a separate pass."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, want_stat=False, fork=False):
         need_dx = ctx.needs_input_grad[0]
         fwdp, bwdp = ops.pack_conv3(weight, x.dtype, True, need_dx)
-        y = ops.conv3_fwd(x, fwdp, weight.shape[0])
+        y, stat = ops.conv3_fwd(x, fwdp, weight.shape[0], want_stat=True) if want_stat else (ops.conv3_fwd(x, fwdp, weight.shape[0]), None)
         ctx.save_for_backward(x, bwdp)
         ctx.wshape = weight.shape
         ctx.params = (weight,)
-        return y
+        ctx.layout = (want_stat, fork)
+        outs = [y]
+        if want_stat:
+            if stat is not None:
+                ctx.mark_non_differentiable(stat)
+            outs.append(stat)
+        if fork:
+            outs.append(x.view_as(x))
+        return tuple(outs) if len(outs) > 1 else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *rest):
         x, bwdp = ctx.saved_tensors
         dy = _rv(dy)
-        dx = ops.conv3_fwd(dy, bwdp, ctx.wshape[1]) if ctx.needs_input_grad[0] else None
+        gskip = _rv(rest[-1]) if ctx.layout[1] and rest[-1] is not None else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv3_fwd(dy, bwdp, ctx.wshape[1], res=gskip)
         dw = None
         if ctx.needs_input_grad[1]:
             slot, mode = _slot_first(ctx.params[0])
@@ -292,11 +310,11 @@ class _Conv3(Function):
                     ops.conv3_wgrad(x, dy, dw=slot, accumulate=mode)
             else:
                 dw = ops.conv3_wgrad(x, dy)
-        return dx, dw
+        return dx, dw, None, None
 
 
-def conv3(x, weight):
-    return _Conv3.apply(x, weight)
+def conv3(x, weight, want_stat=False, fork=False):
+    return _Conv3.apply(x, weight, want_stat, fork)
 
 
 class _Conv3T(Function):

@@ -48,7 +48,7 @@ ColsumDesc = _struct("ColsumDesc", [("x", vp), ("ldx", i64), ("rows", i64), ("ou
 GemmTnDesc = _struct("GemmTnDesc", [("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32), ("K", i32), ("pad_", i32)])
 Colsum = _struct("Colsum", [("x", vp), ("ldx", i64), ("rows", i64), ("C", i32), ("dtype", i32), ("out", vp), ("accumulate", i32)])
 Conv3 = _struct("Conv3", [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("wpk", vp), ("B", i32), ("D", i32), ("H", i32),
-                          ("W", i32), ("Cin", i32), ("Cout", i32), ("dtype", i32), ("workspace", vp)])
+                          ("W", i32), ("Cin", i32), ("Cout", i32), ("dtype", i32), ("workspace", vp), ("res", vp), ("ldres", i64), ("stat", vp)])
 PackConv3Desc = _struct("PackConv3Desc", [("w", vp), ("fwd_pack", vp), ("bwd_pack", vp), ("Cin", i32), ("Cout", i32), ("tile0", i32), ("pad_", i32)])
 PackConv3 = _struct("PackConv3", [("w", vp), ("fwd_pack", vp), ("bwd_pack", vp), ("Cin", i32), ("Cout", i32), ("dtype", i32)])
 Conv3Wgrad = _struct("Conv3Wgrad", [("x", vp), ("ldx", i64), ("dy", vp), ("lddy", i64), ("dw", vp), ("B", i32), ("D", i32),

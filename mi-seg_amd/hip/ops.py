@@ -406,8 +406,10 @@ def _vol(x):
     return x.shape[0], x.shape[1], x.shape[2], x.shape[3]
 
 
-def conv3_fwd(x, wpk, Cout, out=None):
-    """x [B,D,H,W,Cin] rows view; wpk [Cout][27][CinP]."""
+def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False):
+    """x [B,D,H,W,Cin] rows view; wpk [Cout][27][CinP].  res: rows view added to the result in the epilogue (falls back to a separate
+    add where the kernel path cannot fuse it).  want_stat: returns (out, stat) with stat the instance-norm statistics of `out`
+    ([16, B, Cout, 2] fp64, from the kernel's epilogue) or None where that is not available (the caller's norm then computes them)."""
     B, D, H, W = _vol(x)
     ld, n, Cin = rows(x)
     if out is None:
@@ -420,8 +422,15 @@ def conv3_fwd(x, wpk, Cout, out=None):
     fast = (_round_up(Cin, kpc) * x.element_size()) % 96 == 0
     name = f"conv3_fwd{'96' if fast else ''}_kernel<{'bf16' if x.dtype == torch.bfloat16 else 'f32'}>"
     nbytes = float(x.element_size()) * (B * D * H * W * (Cin + Cout) + wpk.numel())      # x read once, y written once, the weight pack
-    _call("miseg_conv3_fwd", L.Conv3(_ptr(x), ld, _ptr(out), rows(out)[0], _ptr(wpk), B, D, H, W, Cin, Cout, _dt(x), _ptr(ws)), prof=(name, flops, nbytes))
-    return out
+    fuse_res = res is not None and fast and res.dtype == x.dtype
+    stat = None
+    if want_stat and fast and not wsb and PROFILE_HOOK is None:     # (the roofline leg repeats launches: it would accumulate)
+        stat = STAT_POOL.take(lib.miseg_instnorm_stat_bytes(B, Cout) // 8, x.device).view(-1, B, Cout, 2)
+    _call("miseg_conv3_fwd", L.Conv3(_ptr(x), ld, _ptr(out), rows(out)[0], _ptr(wpk), B, D, H, W, Cin, Cout, _dt(x), _ptr(ws),
+                                     _ptr(res) if fuse_res else None, rows(res)[0] if fuse_res else 0, _ptr(stat)), prof=(name, flops, nbytes))
+    if res is not None and not fuse_res:
+        out = add(out, res)
+    return (out, stat) if want_stat else out
 
 
 CONV_WGRAD_QUEUE = None   # list while a training arena defers the small-grid conv weight gradients (one grouped launch at the end)

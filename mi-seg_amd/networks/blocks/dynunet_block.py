@@ -96,15 +96,19 @@ class UnetResBlock(nn.Module):
         if image is not None:
             out = HF.conv3_thin(image, self.conv1.conv.weight, dtype)
             residual = _image_rows(image, dtype)
+            st1 = None
+        elif inp.requires_grad:
+            # conv1 hands its input back as the residual branch (its data-gradient epilogue adds that branch's gradient) and the
+            # statistics of its output come from its epilogue
+            out, st1, residual = HF.conv3(inp, self.conv1.conv.weight, want_stat=True, fork=True)
         else:
-            xa, residual = HF.fork(inp) if inp.requires_grad else (inp, inp)
-            out = HF.conv3(xa, self.conv1.conv.weight)
-        out = apply_norm(self.norm1, out, styles, act=L.ACT_LEAKY, slope=LEAKY_SLOPE)
-        out = HF.conv3(out, self.conv2.conv.weight)
+            (out, st1), residual = HF.conv3(inp, self.conv1.conv.weight, want_stat=True), inp
+        out = apply_norm(self.norm1, out, styles, act=L.ACT_LEAKY, slope=LEAKY_SLOPE, stat=st1)
+        out, st2 = HF.conv3(out, self.conv2.conv.weight, want_stat=True)
         if self.downsample:
             residual = HF.conv1(residual, self.conv3.conv.weight)
             residual = apply_norm(self.norm3, residual, styles)
-        return apply_norm(self.norm2, out, styles, res=residual, act=L.ACT_LEAKY, slope=LEAKY_SLOPE)
+        return apply_norm(self.norm2, out, styles, res=residual, act=L.ACT_LEAKY, slope=LEAKY_SLOPE, stat=st2)
 
 
 class UnetBasicBlock(nn.Module):
@@ -123,10 +127,10 @@ class UnetBasicBlock(nn.Module):
 
     def forward(self, inp, styles=None, image=None, dtype=None):
         _needs_modalities(self.norm1, styles)
-        out = HF.conv3_thin(image, self.conv1.conv.weight, dtype) if image is not None else HF.conv3(inp, self.conv1.conv.weight)
-        out = apply_norm(self.norm1, out, styles, act=L.ACT_LEAKY, slope=LEAKY_SLOPE)
-        out = HF.conv3(out, self.conv2.conv.weight)
-        return apply_norm(self.norm2, out, styles, act=L.ACT_LEAKY, slope=LEAKY_SLOPE)
+        out, st1 = (HF.conv3_thin(image, self.conv1.conv.weight, dtype), None) if image is not None else HF.conv3(inp, self.conv1.conv.weight, want_stat=True)
+        out = apply_norm(self.norm1, out, styles, act=L.ACT_LEAKY, slope=LEAKY_SLOPE, stat=st1)
+        out, st2 = HF.conv3(out, self.conv2.conv.weight, want_stat=True)
+        return apply_norm(self.norm2, out, styles, act=L.ACT_LEAKY, slope=LEAKY_SLOPE, stat=st2)
 
 
 def _image_rows(image, dtype):

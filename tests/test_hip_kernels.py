@@ -218,6 +218,32 @@ def test_conv3_fwd_dgrad_wgrad(dtype, B, D, H, W, Cin, Cout):
     assert rel_err(dw, wr.grad) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,D,H,W,Cin,Cout", [(2, 8, 8, 16, 48, 48), (1, 5, 9, 11, 96, 24), (1, 12, 8, 20, 48, 96)])
+def test_conv3_fused_residual_and_statistics(dtype, B, D, H, W, Cin, Cout):
+    """epilogue pieces of the 96-byte-chunk path: out = conv(x) + res, and the instance-norm statistics of the ROUNDED output
+    (what miseg_instnorm_stats computes from the stored tensor) accumulated into the zeroed fp64 buffer."""
+    ops = _ops()
+    if dtype == torch.float32:
+        Cin = Cin // 2          # 96-byte rows: 24 fp32 channels per chunk
+    x, w = _conv_case(dtype, B, D, H, W, Cin, Cout, seed=7)
+    fwdp, _ = ops.pack_conv3(w, dtype)
+    res = rnd(B, D, H, W, Cout, dtype=dtype, seed=77)
+    plain = ops.conv3_fwd(x, fwdp, Cout)
+    ops.begin_step()
+    y, stat = ops.conv3_fwd(x, fwdp, Cout, res=res, want_stat=True)
+    want = (plain.float() + res.float()).to(dtype)
+    assert rel_err(y.float(), want.float()) < (1e-6 if dtype == torch.float32 else 4e-3)
+    if stat is None:        # split reduction on this shape: the caller's norm computes the statistics itself
+        return
+    s = stat.sum(0)         # [B, Cout, 2]
+    yf = y.double().reshape(B, -1, Cout)
+    assert torch.allclose(s[..., 0], yf.sum(1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s[..., 1], (yf * yf).sum(1), rtol=1e-5, atol=1e-3)
+    ref = ops.instnorm_stats(y, B, D * H * W).sum(0)
+    assert torch.allclose(s, ref, rtol=1e-5, atol=1e-3)
+
+
 def test_conv3_exact_integers():
     ops = _ops()
     for dtype in (torch.float32, torch.bfloat16):
