@@ -179,6 +179,27 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const T* __restrict__ A, i
       store_out4<TO>(C, ldc, m0 + wave * 32 + mt * 16 + fi, n0 + nt * 16 + fq * 4, M, N, acc[mt][nt], epi, mode);
 }
 
+// ------------------------------------------------------------------------------------------------ NT, K == 1
+// The 1x1x1 shortcut convolution of the stem block (dynunet_block.py:89, one input channel): an outer product, one 16-byte store per
+// lane.  The tiled kernel spent 92 us on it (a 64-wide k stage for one k), this is one pass over the output.
+template <class T>
+__global__ void __launch_bounds__(256) gemm_nt_k1_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ W, int64_t ldw, T* __restrict__ C, int64_t ldc,
+                                                         int M, int N, const float* __restrict__ bias) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int VN = Vec16<T>::N;
+  const int nv = N / VN;
+  const int64_t total = (int64_t)M * nv;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / nv;
+    const int n = (int)(i - m * nv) * VN;
+    const float a = to_f32(A[m * lda]);
+    VT o;
+#pragma unroll
+    for (int e = 0; e < VN; ++e) o[e] = from_f32<T>(a * to_f32(W[(int64_t)(n + e) * ldw]) + (bias ? bias[n + e] : 0.f));
+    *reinterpret_cast<VT*>(C + m * ldc + n) = o;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ NT, streaming
 // Tall activations x small weight (the Swin linears of the high-resolution stages, 1x1x1 convs, the ConvTranspose GEMM):
 // M ~ 1e5..1e6 rows, K <= 192, N <= ~400.  HBM-bound: every byte of A is read ONCE (all N columns are produced by the
@@ -187,13 +208,12 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const T* __restrict__ A, i
 // MFMA operand is 16 contiguous bytes of its row), so the only LDS traffic is the weight fragments.
 typedef __attribute__((ext_vector_type(4))) short s16x4_g;
 
-template <int K16, bool GELU>
+template <int K16, bool GELU, int NCH = 12 /* n-tiles per accumulator chunk: fewer for the long rows (K >= 288), whose A fragments fill the registers */>
 __global__ void __launch_bounds__(256, 2) gemm_nt_stream_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ W, int64_t ldw,
                                                                 bf16* __restrict__ C, int64_t ldc, int M, int N, Epi epi) {
   const float* bias = epi.bias;
   constexpr int K = K16 * 16, KS32 = K / 32, TAIL = K16 & 1;
   constexpr int ROWB = K * 2 + 16;   // weight row stride in LDS: conflict-free 16-byte fragment reads
-  constexpr int NCH = 12;            // n-tiles per accumulator chunk
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float* lbias = reinterpret_cast<float*>(lds + (size_t)N * ROWB);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fi = lane & 15, kg = lane >> 4;
@@ -664,6 +684,16 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
     }
     if (split > 1 && p->act != MISEG_ACT_NONE) return set_error(MISEG_E_BADARG, "gemm: activation with split_k");
     if (split > 1 && p->act != MISEG_ACT_NONE) return set_error(MISEG_E_BADARG, "gemm: activation with split_k");
+    if constexpr (std::is_same<T, TO>::value) {
+      if (p->K == 1 && split == 1 && !p->accumulate && p->act == MISEG_ACT_NONE && !p->res && !p->epi_mode && p->N % N16 == 0 && ((uintptr_t)p->C % 16 == 0) &&
+          p->ldc % N16 == 0) {
+        int64_t blocks = ((int64_t)p->M * (p->N / N16) + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        gemm_nt_k1_kernel<T><<<(int)blocks, 256, 0, s>>>((const T*)p->A, p->lda, (const T*)p->B, p->ldb, (T*)p->C, p->ldc, p->M, p->N, p->bias);
+        MISEG_LAUNCH_CHECK("gemm_nt_k1");
+        return MISEG_OK;
+      }
+    }
     if constexpr (std::is_same<T, bf16>::value && std::is_same<TO, bf16>::value) {
       // deep-stage linears (see gemm_nt_small_kernel)
       if (split == 1 && !p->accumulate && p->M <= 2048 && p->K % 32 == 0 && p->N % 16 == 0 && al_a && al_b && ((uintptr_t)p->C % 8 == 0) && p->ldc % 4 == 0 && epi_vec_ok) {
@@ -682,20 +712,23 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
       }
       // tall-skinny streaming path (see gemm_nt_stream_kernel)
       const size_t lds = (size_t)p->N * (p->K * 2 + 16) + (size_t)p->N * 4;
-      const bool st_ok = split == 1 && !p->accumulate && (p->K == 48 || p->K == 96 || p->K == 192) && p->N % 16 == 0 && p->M >= 4096 && lds <= 96 * 1024 &&
+      const bool st_ok = split == 1 && !p->accumulate && (p->K == 48 || p->K == 96 || p->K == 192 || p->K == 144 || p->K == 288 || p->K == 384) && p->N % 16 == 0 && p->M >= 4096 && lds <= 96 * 1024 &&
                          al_a && al_b && ((uintptr_t)p->C % 8 == 0) && p->ldc % 4 == 0 && epi_vec_ok;
       if (st_ok) {
         const int mtiles = cdiv(p->M, 32);
         int blocks = cdiv(mtiles, 4);
         const int cap = lds > 80 * 1024 ? 256 : 512;
         if (blocks > cap) blocks = cap;
-#define ST_CASE(k16, g)                                                                                                                       \
-  hipFuncSetAttribute((const void*)gemm_nt_stream_kernel<k16, g>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
-  gemm_nt_stream_kernel<k16, g><<<blocks, 256, lds, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, epi)
+#define ST_CASE(k16, g, nch)                                                                                                                  \
+  (void)hipFuncSetAttribute((const void*)gemm_nt_stream_kernel<k16, g, nch>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+  gemm_nt_stream_kernel<k16, g, nch><<<blocks, 256, lds, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, epi)
         const bool ge = p->act == MISEG_ACT_GELU;
-        if (p->K == 48) { if (ge) { ST_CASE(3, true); } else { ST_CASE(3, false); } }
-        else if (p->K == 96) { if (ge) { ST_CASE(6, true); } else { ST_CASE(6, false); } }
-        else { if (ge) { ST_CASE(12, true); } else { ST_CASE(12, false); } }
+        if (p->K == 48) { if (ge) { ST_CASE(3, true, 12); } else { ST_CASE(3, false, 12); } }
+        else if (p->K == 96) { if (ge) { ST_CASE(6, true, 12); } else { ST_CASE(6, false, 12); } }
+        else if (p->K == 192) { if (ge) { ST_CASE(12, true, 12); } else { ST_CASE(12, false, 12); } }
+        else if (p->K == 144) { if (ge) { ST_CASE(9, true, 12); } else { ST_CASE(9, false, 12); } }
+        else if (p->K == 288) { if (ge) { ST_CASE(18, true, 6); } else { ST_CASE(18, false, 6); } }
+        else { if (ge) { ST_CASE(24, true, 3); } else { ST_CASE(24, false, 3); } }
 #undef ST_CASE
         MISEG_LAUNCH_CHECK("gemm_nt_stream");
         return MISEG_OK;

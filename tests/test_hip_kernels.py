@@ -112,10 +112,11 @@ def test_gemm_nt(dtype, M, N, K):
     assert rel_err(y2, F.gelu(yr)) < TOL[dtype]
 
 
-@pytest.mark.parametrize("M,N,K", [(4096, 48, 48), (5003, 144, 48), (4100, 192, 48), (4097, 48, 192), (6000, 384, 96), (4099, 96, 96), (4300, 16, 96)])
+@pytest.mark.parametrize("M,N,K", [(4096, 48, 48), (5003, 144, 48), (4100, 192, 48), (4097, 48, 192), (6000, 384, 96), (4099, 96, 96), (4300, 16, 96),
+                                   (4101, 48, 144), (13824, 96, 288), (4200, 96, 384), (5000, 48, 384), (4098, 112, 288)])
 def test_gemm_nt_streaming_path(M, N, K):
-    """tall-skinny bf16 GEMMs take the weight-resident streaming kernel (M >= 4096, K in 48/96/192): ragged M, the K=48
-    half k-step, N beyond one accumulator chunk, bias + GELU epilogue; exact on small integers."""
+    """tall-skinny bf16 GEMMs take the weight-resident streaming kernel (M >= 4096, K in 48/96/144/192/288/384): ragged M, the
+    half k-step of K = 48 / 144, N beyond one accumulator chunk, bias + GELU epilogue; exact on small integers."""
     ops, L = _ops(), _L()
     dtype = torch.bfloat16
     a, w, bias = rnd(M, K, dtype=dtype, seed=21), rnd(N, K, dtype=dtype, seed=22) / K ** 0.5, rnd(N, seed=23)
@@ -125,6 +126,16 @@ def test_gemm_nt_streaming_path(M, N, K):
     ai = (torch.arange(M * K, device=DEV).reshape(M, K) % 7 - 3).to(dtype)
     wi = (torch.arange(N * K, device=DEV).reshape(N, K) % 5 - 2).to(dtype)
     assert torch.equal(ops.gemm_nt(ai, wi).float(), (ai.float() @ wi.float().t()).to(dtype).float())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_nt_rank1(dtype):
+    """K == 1 (the stem block's 1x1x1 shortcut on a one-channel image): the outer-product kernel"""
+    ops = _ops()
+    a, w, bias = rnd(5003, 1, dtype=dtype, seed=31), rnd(48, 1, dtype=dtype, seed=32), rnd(48, seed=33)
+    yr = a.float() @ w.float().t()
+    assert rel_err(ops.gemm_nt(a, w), yr) < TOL[dtype]
+    assert rel_err(ops.gemm_nt(a, w, bias), yr + bias) < TOL[dtype]
 
 
 @pytest.mark.parametrize("M,N,K", [(216, 1536, 384), (216, 384, 1536), (27, 3072, 768), (1728, 768, 192), (1727, 192, 768), (215, 1152, 384), (100, 16, 32),
