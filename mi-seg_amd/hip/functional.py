@@ -82,6 +82,9 @@ def add(a, b):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+_PENDING_OUT = None      # see _InstNorm.forward
+
+
 class _InstNorm(Function):
     """(conditional) instance norm over all rows of each sample, + optional residual, + optional LeakyReLU.
     reference: networks/norms/conditional_instance_norm.py:59-68, dynunet_block.py:100-126."""
@@ -94,9 +97,13 @@ class _InstNorm(Function):
         S = ops.rows(x)[1] // B
         gammas = list(params[0::2]) if affine else None
         betas = list(params[1::2]) if affine else None
-        if stat_in is not None:      # statistics already produced by the epilogue of the kernel that wrote x
-            stat = stat_in
-            y = ops.instnorm_apply(x, B, S, stat, styles_dev, gammas, betas, res=res, act=act, slope=slope, eps=eps)
+        # out: a caller-provided rows view to write into (the skip half of a decoder's concat buffer: no copy later).  It travels
+        # beside the autograd inputs: to autograd the result is an ordinary fresh output, not an aliased / in-place-modified input
+        global _PENDING_OUT
+        out, _PENDING_OUT = _PENDING_OUT, None
+        if stat_in is not None or out is not None:      # statistics already produced by the epilogue of the kernel that wrote x
+            stat = stat_in if stat_in is not None else ops.instnorm_stats(x, B, S)
+            y = ops.instnorm_apply(x, B, S, stat, styles_dev, gammas, betas, res=res, act=act, slope=slope, eps=eps, out=out)
         else:
             y, stat = ops.instnorm_fwd(x, B, S, styles_dev, gammas, betas, res=res, act=act, slope=slope, eps=eps)
         ctx.meta = (B, S, styles_host, num_styles, affine, act, slope, res is not None, eps)
@@ -130,7 +137,7 @@ class _InstNorm(Function):
         return (dx, dres, None, None, None, None, None, None, None, None, None, *pg)
 
 
-def instance_norm(x, params=None, styles_dev=None, styles_host=None, res=None, act=L.ACT_NONE, slope=0.01, eps=1e-5, fork=False, stat=None):
+def instance_norm(x, params=None, styles_dev=None, styles_host=None, res=None, act=L.ACT_NONE, slope=0.01, eps=1e-5, fork=False, stat=None, out=None):
     """params: None (no affine) | [(gamma, beta)] (plain) | [(g0,b0),(g1,b1),...] (conditional, one pair per style).
     fork=True returns (norm(x), x): see _InstNorm.forward."""
     flat = []
@@ -139,6 +146,8 @@ def instance_norm(x, params=None, styles_dev=None, styles_host=None, res=None, a
         n = len(params)
         for g, b in params:
             flat += [g, b]
+    global _PENDING_OUT
+    _PENDING_OUT = out
     return _InstNorm.apply(x, res, styles_dev, styles_host, n, params is not None, act, slope, eps, fork, stat, *flat)
 
 
@@ -524,9 +533,14 @@ class _UpCat(Function):
         wf = ops.cast_matrix(weight, x.dtype, transpose=True, regroup=(8, Cout))     # [(j,co)][ci]
         y8 = ops.gemm_nt(x, wf)
         width = 2 * Cout if skip is not None else Cout
-        cat = torch.empty(B, 2 * d, 2 * h, 2 * w, width, dtype=x.dtype, device=dev)
+        # a skip that its producer already wrote into the right half of a concat buffer (`concat_buffer`) needs no copy
+        cat = getattr(skip, "_miseg_cat", None) if skip is not None else None
+        placed = (cat is not None and tuple(cat.shape) == (B, 2 * d, 2 * h, 2 * w, width) and cat.dtype == x.dtype
+                  and skip.data_ptr() == cat.data_ptr() + Cout * cat.element_size() and skip.stride(-2) == width)
+        if not placed:
+            cat = torch.empty(B, 2 * d, 2 * h, 2 * w, width, dtype=x.dtype, device=dev)
         ops.channel_to_space(y8, STD_OFFSETS, (B, 2 * d, 2 * h, 2 * w, Cout), out=cat[..., :Cout])
-        if skip is not None:
+        if skip is not None and not placed:
             ops.copy2d(skip, cat[..., Cout:])
         ctx.save_for_backward(x, weight)
         ctx.has_skip = skip is not None
@@ -559,6 +573,18 @@ class _UpCat(Function):
 
 def upconv_cat(x, skip, weight):
     return _UpCat.apply(x, skip, weight)
+
+
+def concat_buffer(shape_bdhw, channels, dtype, device):
+    """(buffer [B,D,H,W,2C], its right half as a rows view): hand the view to the block that produces a decoder's skip tensor
+    (`out=`), tag the result with `tag_concat`, and upconv_cat finds the skip already in place."""
+    cat = torch.empty(*shape_bdhw, 2 * channels, dtype=dtype, device=device)
+    return cat, cat[..., channels:]
+
+
+def tag_concat(skip, cat):
+    skip._miseg_cat = cat
+    return skip
 
 
 # ----------------------------------------------------------------------------------------------------------------

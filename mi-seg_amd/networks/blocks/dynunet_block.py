@@ -90,8 +90,9 @@ class UnetResBlock(nn.Module):
             self.norm3 = get_norm_layer(name=norm_name, spatial_dims=spatial_dims, channels=out_channels)
         self.in_channels = in_channels
 
-    def forward(self, inp, styles=None, image=None, dtype=None):
-        """inp: channels-last activation; for a block fed by the raw image pass ``image`` (NCDHW fp32) instead."""
+    def forward(self, inp, styles=None, image=None, dtype=None, out_view=None):
+        """inp: channels-last activation; for a block fed by the raw image pass ``image`` (NCDHW fp32) instead.
+        out_view: rows view the result is written into (HF.concat_buffer)."""
         _needs_modalities(self.norm1, styles)
         if image is not None:
             out = HF.conv3_thin(image, self.conv1.conv.weight, dtype)
@@ -108,7 +109,7 @@ class UnetResBlock(nn.Module):
         if self.downsample:
             residual = HF.conv1(residual, self.conv3.conv.weight)
             residual = apply_norm(self.norm3, residual, styles)
-        return apply_norm(self.norm2, out, styles, res=residual, act=L.ACT_LEAKY, slope=LEAKY_SLOPE, stat=st2)
+        return apply_norm(self.norm2, out, styles, res=residual, act=L.ACT_LEAKY, slope=LEAKY_SLOPE, stat=st2, out=out_view)
 
 
 class UnetBasicBlock(nn.Module):
@@ -125,12 +126,12 @@ class UnetBasicBlock(nn.Module):
         self.norm1 = get_norm_layer(name=norm_name, spatial_dims=spatial_dims, channels=out_channels)
         self.norm2 = get_norm_layer(name=norm_name, spatial_dims=spatial_dims, channels=out_channels)
 
-    def forward(self, inp, styles=None, image=None, dtype=None):
+    def forward(self, inp, styles=None, image=None, dtype=None, out_view=None):
         _needs_modalities(self.norm1, styles)
         out, st1 = (HF.conv3_thin(image, self.conv1.conv.weight, dtype), None) if image is not None else HF.conv3(inp, self.conv1.conv.weight, want_stat=True)
         out = apply_norm(self.norm1, out, styles, act=L.ACT_LEAKY, slope=LEAKY_SLOPE, stat=st1)
         out, st2 = HF.conv3(out, self.conv2.conv.weight, want_stat=True)
-        return apply_norm(self.norm2, out, styles, act=L.ACT_LEAKY, slope=LEAKY_SLOPE, stat=st2)
+        return apply_norm(self.norm2, out, styles, act=L.ACT_LEAKY, slope=LEAKY_SLOPE, stat=st2, out=out_view)
 
 
 def _image_rows(image, dtype):

@@ -72,5 +72,5 @@ class UnetrBasicBlock(nn.Module):
         self.layer = blk(spatial_dims=spatial_dims, in_channels=in_channels, out_channels=out_channels, kernel_size=kernel_size,
                          stride=stride, norm_name=norm_name)
 
-    def forward(self, inp, styles=None, image=None, dtype=None):
-        return self.layer(inp, styles, image=image, dtype=dtype)
+    def forward(self, inp, styles=None, image=None, dtype=None, out_view=None):
+        return self.layer(inp, styles, image=image, dtype=dtype, out_view=out_view)

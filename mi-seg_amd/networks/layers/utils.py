@@ -57,17 +57,17 @@ def apply_norm_fork(norm: nn.Module, x, styles=None):
     return apply_norm(norm, xa, styles), xs
 
 
-def apply_norm(norm: nn.Module, x, styles=None, res=None, act=L.ACT_NONE, slope=0.01, stat=None):
+def apply_norm(norm: nn.Module, x, styles=None, res=None, act=L.ACT_NONE, slope=0.01, stat=None, out=None):
     """Apply a norm *module* (used as a parameter container) to a channels-last tensor through the HIP kernels.
     ``styles`` is the (device int32 tensor, host tuple) pair from styles_to_device; ``stat``: instance-norm statistics of x that the
     producer of x already computed (HF.conv3(..., want_stat=True)), or None."""
     if isinstance(norm, _ConditionalInstanceNorm):
         if styles is None:
             raise ValueError("Modalities must be passed to the forward step when encoder_norm_type is 'instance_cond'.")
-        return HF.instance_norm(x, norm.style_params(), styles[0], styles[1], res=res, act=act, slope=slope, eps=norm.eps, stat=stat)
+        return HF.instance_norm(x, norm.style_params(), styles[0], styles[1], res=res, act=act, slope=slope, eps=norm.eps, stat=stat, out=out)
     if isinstance(norm, _INSTANCE):
         params = [(norm.weight, norm.bias)] if norm.affine else None
-        return HF.instance_norm(x, params, None, None, res=res, act=act, slope=slope, eps=norm.eps, stat=stat)
+        return HF.instance_norm(x, params, None, None, res=res, act=act, slope=slope, eps=norm.eps, stat=stat, out=out)
     if isinstance(norm, nn.LayerNorm):
         if res is not None or act != L.ACT_NONE:
             raise NotImplementedError("LayerNorm with fused residual / activation")

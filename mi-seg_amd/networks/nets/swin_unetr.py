@@ -6,6 +6,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from ...hip import functional as HF
 from ..blocks.dynunet_block import UnetOutBlock
 from ..blocks.patch_merging import PatchMerging, PatchMergingV2
 from ..blocks.unetr_block import UnetrBasicBlock, UnetrUpBlock
@@ -137,6 +138,14 @@ class SwinUNETR(nn.Module):
             st = self._side = torch.cuda.Stream(device=device)
         return st
 
+    @staticmethod
+    def _skip_block(block, inp, styles, shape, channels, dt, **kw):
+        """an encoder block whose output is a decoder's skip tensor: it writes straight into the right half of that decoder's
+        concat buffer (unetr_block.py:80-85 does torch.cat: a copy of the 96^3 x 48 tensor among others)"""
+        dims = tuple(shape[2:5]) if kw.get("image") is not None else tuple(shape[1:4])
+        cat, view = HF.concat_buffer((shape[0],) + dims, channels, dt, (inp if inp is not None else kw["image"]).device)
+        return HF.tag_concat(block(inp, styles, out_view=view, **kw), cat)
+
     def late_backward_parameters(self):
         return [p for k, p in self.named_parameters() if k.startswith(self.late_backward_prefixes)]
 
@@ -167,14 +176,16 @@ class SwinUNETR(nn.Module):
             cur.wait_stream(side)
             enc0.record_stream(cur)
         else:
-            enc0 = self.encoder1(None, styles, image=x_in, dtype=dt)
-        enc1 = self.encoder2(hs[0], styles)
-        enc2 = self.encoder3(hs[1], styles)
-        enc3 = self.encoder4(hs[2], styles)
+            enc0 = self._skip_block(self.encoder1, None, styles, x_in.shape, self.encoder1.layer.conv2.conv.weight.shape[0], dt, image=x_in, dtype=dt)
+        enc1 = self._skip_block(self.encoder2, hs[0], styles, hs[0].shape, hs[0].shape[-1], dt)
+        enc2 = self._skip_block(self.encoder3, hs[1], styles, hs[1].shape, hs[1].shape[-1], dt)
+        enc3 = self._skip_block(self.encoder4, hs[2], styles, hs[2].shape, hs[2].shape[-1], dt)
         h4, h3 = hs[4], hs[3]
         if cut is not None:
             def leaf(t):
                 l = t.detach().requires_grad_(True)
+                if getattr(t, "_miseg_cat", None) is not None:
+                    l._miseg_cat = t._miseg_cat
                 cut.append((t, l))
                 return l
             h4, h3, enc3, enc2, enc1, enc0 = (leaf(t) for t in (h4, h3, enc3, enc2, enc1, enc0))
