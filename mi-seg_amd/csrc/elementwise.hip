@@ -375,6 +375,163 @@ __global__ void __launch_bounds__(256) conv3_thin_wgrad_kernel(const float* __re
   }
 }
 
+// ----------------------------------------------------------------------------- one-channel stem conv, brick form
+// Cin == 1 (the CT / MR image): 27 x Cout multiply-adds per voxel - not matrix-core shaped (K = 27), so it stays on the VALU, but
+// blocked like the implicit-GEMM kernels: a 4x4x16 voxel brick, its 6x6x18 halo of the fp32 image in LDS.
+static constexpr int SB_D = 4, SB_H = 4, SB_W = 16, SH_H = SB_H + 2, SH_W = SB_W + 2, SH_N = (SB_D + 2) * SH_H * SH_W;   // 648
+
+// forward: thread = voxel, its 27 taps in registers, weights [tap][Cout] as LDS broadcasts, 8 output channels per pass
+// (two voxels per thread sharing the weight reads: 87 -> 107 us)
+template <class T>
+__global__ void __launch_bounds__(256) conv3_stem_fwd_kernel(const float* __restrict__ x, T* __restrict__ y, int64_t ldy, const float* __restrict__ w, int B, int D,
+                                                             int H, int W, int Cout, int nbricks) {
+  __shared__ __attribute__((aligned(16))) float ws[27 * 64];
+  __shared__ float xs[SH_N];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 27 * Cout; i += 256) {
+    const int tap = i / Cout, co = i - tap * Cout;
+    ws[i] = w[co * 27 + tap];
+  }
+  const int nbw = cdiv(W, SB_W), nbh = cdiv(H, SB_H), nbd = cdiv(D, SB_D);
+  const int vd = tid >> 6, vh = (tid >> 4) & 3, vw = tid & 15;
+  for (int brick = blockIdx.x; brick < nbricks; brick += gridDim.x) {
+    int bid = brick;
+    const int bw = bid % nbw; bid /= nbw;
+    const int bh = bid % nbh; bid /= nbh;
+    const int bd = bid % nbd;
+    const int b = bid / nbd;
+    const int d0 = bd * SB_D, h0 = bh * SB_H, w0 = bw * SB_W;
+    __syncthreads();
+    for (int i = tid; i < SH_N; i += 256) {
+      const int hd = i / (SH_H * SH_W), rem = i - hd * (SH_H * SH_W), hh = rem / SH_W, hw = rem - hh * SH_W;
+      const int d = d0 - 1 + hd, h = h0 - 1 + hh, ww = w0 - 1 + hw;
+      xs[i] = (d >= 0 && d < D && h >= 0 && h < H && ww >= 0 && ww < W) ? x[(((int64_t)b * D + d) * H + h) * W + ww] : 0.f;
+    }
+    __syncthreads();
+    float xt[27];
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) xt[tap] = xs[((vd + tap / 9) * SH_H + vh + (tap / 3) % 3) * SH_W + vw + tap % 3];
+    const int d = d0 + vd, h = h0 + vh, ww = w0 + vw;
+    if (d < D && h < H && ww < W) {
+      T* yr = y + ((((int64_t)b * D + d) * H + h) * W + ww) * ldy;
+      for (int c0 = 0; c0 < Cout; c0 += 8) {
+        // weights straight from memory at wave-uniform addresses: scalar loads, the multiply-adds take them as SGPR operands
+        // (as LDS broadcasts the 54 reads per pass cost as much as the 216 multiply-adds)
+        float a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = 0.f;
+        const float* wc = w + c0 * 27;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+          for (int tap = 0; tap < 27; ++tap) a[k] = fmaf(xt[tap], wc[k * 27 + tap], a[k]);
+        const f32x4 a0 = {a[0], a[1], a[2], a[3]}, a1 = {a[4], a[5], a[6], a[7]};
+        if constexpr (std::is_same<T, float>::value) {
+          *reinterpret_cast<f32x4*>(yr + c0) = a0;
+          *reinterpret_cast<f32x4*>(yr + c0 + 4) = a1;
+        } else {
+          *reinterpret_cast<bf16x8*>(yr + c0) = bf16x8{(bf16)a0[0], (bf16)a0[1], (bf16)a0[2], (bf16)a0[3], (bf16)a1[0], (bf16)a1[1], (bf16)a1[2], (bf16)a1[3]};
+        }
+      }
+    }
+  }
+}
+
+// weight gradient: dw[co][tap] += sum_v dy[v][co] x[v + tap].  thread = (kd, kh, 8 output channels, depth slice of the brick): one
+// 18-float halo row serves the three kw taps of 16 voxels (384 multiply-adds per 5 + 16 LDS reads); workgroups are persistent and
+// keep their 3 x 8 sums in registers over all their bricks.
+template <class T>
+__global__ void __launch_bounds__(256) conv3_stem_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dy, int64_t lddy, float* __restrict__ dw, int B,
+                                                               int D, int H, int W, int Cout, int nbricks) {
+  extern __shared__ __attribute__((aligned(16))) char stem_sm[];
+  char* sm = stem_sm;
+  float* xs = reinterpret_cast<float*>(sm);                  // [648] (+ pad to 16 B)
+  T* ds = reinterpret_cast<T*>(sm + 2608);                   // [256 voxels][Cout]
+  const int tid = threadIdx.x, ncg = Cout / 8;
+  const int cg = tid % ncg, r = tid / ncg;
+  const int th = r % 3, td = (r / 3) % 3, vd = r / 9;
+  const bool worker = vd < SB_D;
+  float acc[3][8];          // (packed f32x2 accumulators were tried: 156 -> 229 us)
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[t][k] = 0.f;
+  const int nbw = cdiv(W, SB_W), nbh = cdiv(H, SB_H), nbd = cdiv(D, SB_D);
+  constexpr int VN = Vec16<T>::N;
+  const int cvn = Cout / VN;
+  for (int brick = blockIdx.x; brick < nbricks; brick += gridDim.x) {
+    int bid = brick;
+    const int bw = bid % nbw; bid /= nbw;
+    const int bh = bid % nbh; bid /= nbh;
+    const int bd = bid % nbd;
+    const int b = bid / nbd;
+    const int d0 = bd * SB_D, h0 = bh * SB_H, w0 = bw * SB_W;
+    __syncthreads();
+    for (int i = tid; i < SH_N; i += 256) {
+      const int hd = i / (SH_H * SH_W), rem = i - hd * (SH_H * SH_W), hh = rem / SH_W, hw = rem - hh * SH_W;
+      const int d = d0 - 1 + hd, h = h0 - 1 + hh, ww = w0 - 1 + hw;
+      xs[i] = (d >= 0 && d < D && h >= 0 && h < H && ww >= 0 && ww < W) ? x[(((int64_t)b * D + d) * H + h) * W + ww] : 0.f;
+    }
+    for (int i = tid; i < 256 * cvn; i += 256) {
+      const int vi = i / cvn, c = (i - vi * cvn) * VN;
+      const int d = d0 + (vi >> 6), h = h0 + ((vi >> 4) & 3), ww = w0 + (vi & 15);
+      typename Vec16<T>::type v;
+#pragma unroll
+      for (int e = 0; e < VN; ++e) v[e] = from_f32<T>(0.f);
+      if (d < D && h < H && ww < W) v = *reinterpret_cast<const typename Vec16<T>::type*>(dy + ((((int64_t)b * D + d) * H + h) * W + ww) * lddy + c);
+      *reinterpret_cast<typename Vec16<T>::type*>(ds + vi * Cout + c) = v;
+    }
+    __syncthreads();
+    if (worker) {
+#pragma unroll 1
+      for (int vh = 0; vh < SB_H; ++vh) {
+        float xr[SH_W];
+        const float* xrow = xs + ((vd + td) * SH_H + vh + th) * SH_W;
+#pragma unroll
+        for (int i = 0; i < SH_W; ++i) xr[i] = xrow[i];
+        const T* drow = ds + ((vd * SB_H + vh) * SB_W) * Cout + cg * 8;
+#pragma unroll
+        for (int vw = 0; vw < SB_W; ++vw) {
+          float g[8];
+          if constexpr (std::is_same<T, float>::value) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(drow + vw * Cout), g1 = *reinterpret_cast<const f32x4*>(drow + vw * Cout + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { g[k] = g0[k]; g[4 + k] = g1[k]; }
+          } else {
+            const bf16x8 gv = *reinterpret_cast<const bf16x8*>(drow + vw * Cout);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] = (float)gv[k];
+          }
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[t][k] = fmaf(xr[vw + t], g[k], acc[t][k]);
+        }
+      }
+    }
+  }
+  // the four depth slices meet in LDS, then one atomic per (co, tap) per workgroup
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(sm);                 // [256][24]
+  if (worker) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) red[tid * 24 + t * 8 + k] = acc[t][k];
+  }
+  __syncthreads();
+  for (int o = tid; o < 9 * ncg * 24; o += 256) {
+    const int q = o / 24, e = o - q * 24;          // q = (td * 3 + th) * ncg + cg  (the r, cg pair without the depth slice)
+    const int qcg = q % ncg, qr = q / ncg;
+    float a = 0.f;
+#pragma unroll
+    for (int s4 = 0; s4 < SB_D; ++s4) a += red[((s4 * 9 + qr) * ncg + qcg) * 24 + e];
+    const int t = e / 8, k = e - t * 8;
+    const int qth = qr % 3, qtd = qr / 3;
+    atomicAdd(dw + (int64_t)(qcg * 8 + k) * 27 + qtd * 9 + qth * 3 + t, a);
+  }
+}
+
 // ----------------------------------------------------------------------------- output head (1x1x1 + bias -> NCDHW fp32)
 // thread = voxel: the channels-last row is read once in 16-byte pieces; weights [Cout][Cin] are LDS broadcasts.
 template <class T, int VEC>
@@ -1022,6 +1179,12 @@ extern "C" int miseg_conv3_thin_fwd(const miseg_conv3_thin_params* p, miseg_stre
   MISEG_REQUIRE(p->Cin >= 1 && p->Cin <= 4 && p->Cin * 27 * p->Cout <= 15000, MISEG_E_UNSUPPORTED, "conv3_thin_fwd: Cin %d Cout %d", p->Cin, p->Cout);
   DT(p, {
     const int64_t nv = (int64_t)p->B * p->D * p->H * p->W;
+    if (p->Cin == 1 && p->Cout % 8 == 0 && p->Cout <= 64 && p->ldy % 8 == 0 && al16(p->y)) {       // brick kernel (see conv3_stem_fwd_kernel)
+      const int nbricks = p->B * cdiv(p->D, miseg::SB_D) * cdiv(p->H, miseg::SB_H) * cdiv(p->W, miseg::SB_W);
+      conv3_stem_fwd_kernel<T><<<nbricks < 4096 ? nbricks : 4096, 256, 0, s>>>(p->x, (T*)p->y, p->ldy, p->w, p->B, p->D, p->H, p->W, p->Cout, nbricks);
+      MISEG_LAUNCH_CHECK("conv3_stem_fwd");
+      return MISEG_OK;
+    }
     size_t sh = (size_t)p->Cin * 27 * p->Cout * sizeof(float);
     conv3_thin_fwd_kernel<T><<<ew_grid(nv), 256, sh, s>>>(p->x, (T*)p->y, p->ldy, p->w, p->B, p->Cin, p->D, p->H, p->W, p->Cout);
     MISEG_LAUNCH_CHECK("conv3_thin_fwd");
@@ -1033,6 +1196,16 @@ extern "C" int miseg_conv3_thin_wgrad(const miseg_conv3_thin_wgrad_params* p, mi
   MISEG_REQUIRE(p && p->x && p->dy && p->dw, MISEG_E_BADARG, "conv3_thin_wgrad: null pointer");
   MISEG_REQUIRE(p->Cin >= 1 && p->Cin <= 4 && p->Cout <= 64, MISEG_E_UNSUPPORTED, "conv3_thin_wgrad: Cin %d Cout %d", p->Cin, p->Cout);
   DT(p, {
+    constexpr int VN = Vec16<T>::N;
+    if (p->Cin == 1 && p->Cout % 8 == 0 && p->Cout % VN == 0 && p->Cout / 8 * 36 <= 256 && p->lddy % VN == 0 && al16(p->dy)) {   // see conv3_stem_wgrad_kernel
+      const int nbricks = p->B * cdiv(p->D, miseg::SB_D) * cdiv(p->H, miseg::SB_H) * cdiv(p->W, miseg::SB_W);
+      size_t sh = 2608 + (size_t)256 * p->Cout * sizeof(T);
+      if (sh < 256 * 24 * 4) sh = 256 * 24 * 4;
+      (void)hipFuncSetAttribute((const void*)conv3_stem_wgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      conv3_stem_wgrad_kernel<T><<<nbricks < 512 ? nbricks : 512, 256, sh, s>>>(p->x, (const T*)p->dy, p->lddy, p->dw, p->B, p->D, p->H, p->W, p->Cout, nbricks);
+      MISEG_LAUNCH_CHECK("conv3_stem_wgrad");
+      return MISEG_OK;
+    }
     const int nb = p->B * cdiv(p->D, 8) * cdiv(p->H, 8) * cdiv(p->W, 8);
     size_t sh = ((size_t)1000 + 512 * p->Cout) * sizeof(float);
     hipFuncSetAttribute((const void*)conv3_thin_wgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);

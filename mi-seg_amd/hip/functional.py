@@ -464,17 +464,28 @@ class _Conv3Thin(Function):
 
     @staticmethod
     def forward(ctx, x_ncdhw, weight, dtype):
+        ctx.wshape = weight.shape
+        ctx.params = (weight,)
+        # one image channel (CT / MR) and a multiple of 8 output channels: the VALU brick kernels (27 taps are no matrix-core K)
+        ctx.stem = weight.shape[1] == 1 and weight.shape[0] % 8 == 0 and weight.shape[0] <= 56
+        if ctx.stem:
+            ctx.save_for_backward(x_ncdhw)
+            return ops.conv3_thin_fwd(x_ncdhw, weight, dtype)
         xr = ops.ncdhw_to_rows(x_ncdhw, dtype)
         fwdp, _ = ops.pack_conv3(weight, dtype, True, False)
         ctx.save_for_backward(xr)
-        ctx.wshape = weight.shape
-        ctx.params = (weight,)
         return ops.conv3_fwd(xr, fwdp, weight.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         (xr,) = ctx.saved_tensors
         slot = _slot(ctx.params[0])
+        if ctx.stem:
+            dy = _rv(dy)
+            if slot is not None:
+                ops.conv3_thin_wgrad(xr, dy, slot)
+                return None, None, None
+            return None, ops.conv3_thin_wgrad(xr, dy, ops.zeros_f32(ctx.wshape, dy.device)), None
         if slot is not None:
             dy = _rv(dy)
             with ops.wgrad_side(xr, dy, kind="conv"):

@@ -18,6 +18,8 @@ agg = {}
 for r in rows:
     a = agg.setdefault(short(r["Name"]), [0, 0]); a[0] += int(r["Calls"]); a[1] += int(r["TotalDurationNs"])
 tot = sum(v[1] for v in agg.values())
+steps = max(1, agg.get("pack_conv3_batch_kernel", [1])[0])
+print(f"all kernels: {tot/1e6:.2f} ms over ~{steps} steps = {tot/1e6/steps:.3f} ms per step (incl. capture warm-ups and checks)")
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
     print(f"{k:40s} calls {v[0]:6d} total {v[1]/1e6:8.2f} ms  avg {v[1]/v[0]/1e3:7.1f} us {100*v[1]/tot:5.1f}%")
 PY

@@ -330,6 +330,18 @@ def test_conv3_thin_and_head_and_patch_embed(dtype):
     dw = ops.conv3_thin_wgrad(x, dy, torch.zeros_like(w))
     dwr = torch.nn.grad.conv3d_weight(x, w.shape, dy.float().permute(0, 4, 1, 2, 3), padding=1)
     assert rel_err(dw, dwr) < TOL[dtype]
+    # two image channels / 20 output channels: the generic thin kernels (the one-channel case above runs the brick kernels)
+    x2, w2 = rnd(1, 2, 6, 9, 17, seed=57), rnd(20, 2, 3, 3, 3, seed=58) / 7
+    assert rel_err(ops.conv3_thin_fwd(x2, w2, dtype).permute(0, 4, 1, 2, 3), F.conv3d(x2, w2, padding=1)) < TOL[dtype]
+    dy2 = rnd(1, 6, 9, 17, 20, dtype=dtype, seed=59)
+    assert rel_err(ops.conv3_thin_wgrad(x2, dy2, torch.zeros_like(w2)),
+                   torch.nn.grad.conv3d_weight(x2, w2.shape, dy2.float().permute(0, 4, 1, 2, 3), padding=1)) < TOL[dtype]
+    # 48 output channels on a volume with whole bricks (the headline stem) and accumulation on top of existing values
+    x3, w3 = rnd(1, 1, 8, 8, 32, seed=60), rnd(48, 1, 3, 3, 3, seed=61) / 5
+    assert rel_err(ops.conv3_thin_fwd(x3, w3, dtype).permute(0, 4, 1, 2, 3), F.conv3d(x3, w3, padding=1)) < TOL[dtype]
+    dy3, base = rnd(1, 8, 8, 32, 48, dtype=dtype, seed=62), rnd(48, 1, 3, 3, 3, seed=63)
+    got = ops.conv3_thin_wgrad(x3, dy3, base.clone()) - base
+    assert rel_err(got, torch.nn.grad.conv3d_weight(x3, w3.shape, dy3.float().permute(0, 4, 1, 2, 3), padding=1)) < TOL[dtype]
     # head
     xh = rnd(2, 5, 6, 7, 48, dtype=dtype, seed=54)
     wh, bh = rnd(6, 48, 1, 1, 1, seed=55) / 7, rnd(6, seed=56)
