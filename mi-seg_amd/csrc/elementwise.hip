@@ -532,6 +532,149 @@ __global__ void __launch_bounds__(256) conv3_stem_wgrad_kernel(const float* __re
   }
 }
 
+// forward of the one-channel stem conv on the matrix cores (bf16, Cout == 48): y[v][co] = sum_tap X[v][tap] w[co][tap] is ONE k-step
+// of 32 (27 taps + padding) per 16-voxel tile: 12 MFMAs per wave and brick.  The weight fragments live in registers for the whole
+// kernel; a lane builds its X fragment from 8 halo reads (its k-group's 8 taps of voxel w = fi).  Output layout as in the
+// implicit-GEMM kernel: lane holds channels 16nt + 4fq .. +3 of voxel (d0 + wave, h0 + mt, w0 + fi).
+__global__ void __launch_bounds__(256) conv3_stem_fwd_mfma_kernel(const float* __restrict__ x, bf16* __restrict__ y, int64_t ldy, const float* __restrict__ w, int B,
+                                                                  int D, int H, int W, int nbricks) {
+  __shared__ float xs[SH_N];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fi = lane & 15, fq = lane >> 4;
+  bf16x8 wf[3];
+  int toff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int tap = 8 * fq + j;
+    toff[j] = tap < 27 ? ((tap / 9) * SH_H + (tap / 3) % 3) * SH_W + tap % 3 : -1;
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) wf[nt][j] = (bf16)(tap < 27 ? w[(nt * 16 + fi) * 27 + tap] : 0.f);
+  }
+  const int nbw = cdiv(W, SB_W), nbh = cdiv(H, SB_H), nbd = cdiv(D, SB_D);
+  for (int brick = blockIdx.x; brick < nbricks; brick += gridDim.x) {
+    int bid = brick;
+    const int bw = bid % nbw; bid /= nbw;
+    const int bh = bid % nbh; bid /= nbh;
+    const int bd = bid % nbd;
+    const int b = bid / nbd;
+    const int d0 = bd * SB_D, h0 = bh * SB_H, w0 = bw * SB_W;
+    __syncthreads();
+    for (int i = tid; i < SH_N; i += 256) {
+      const int hd = i / (SH_H * SH_W), rem = i - hd * (SH_H * SH_W), hh = rem / SH_W, hw = rem - hh * SH_W;
+      const int d = d0 - 1 + hd, h = h0 - 1 + hh, ww = w0 - 1 + hw;
+      xs[i] = (d >= 0 && d < D && h >= 0 && h < H && ww >= 0 && ww < W) ? x[(((int64_t)b * D + d) * H + h) * W + ww] : 0.f;
+    }
+    __syncthreads();
+    const int d = d0 + wave, ww = w0 + fi;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const float* xp = xs + (wave * SH_H + mt) * SH_W + fi;
+      bf16x8 xf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xf[j] = (bf16)(toff[j] < 0 ? 0.f : xp[toff[j] < 0 ? 0 : toff[j]]);
+      f32x4 acc[3];
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      const int h = h0 + mt;
+      if (d < D && h < H && ww < W) {
+        bf16* yr = y + ((((int64_t)b * D + d) * H + h) * W + ww) * ldy + fq * 4;
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) *reinterpret_cast<bf16x4*>(yr + nt * 16) = bf16x4{(bf16)acc[nt][0], (bf16)acc[nt][1], (bf16)acc[nt][2], (bf16)acc[nt][3]};
+      }
+    }
+  }
+}
+
+// weight gradient of the one-channel stem conv on the matrix cores (bf16): dw[co][tap] = sum_v dy[v][co] X[v][tap] with X the
+// im2col of the image (27 -> 32 columns), i.e. per 4x4x16 brick 8 k-steps of 32 voxels x (3 co tiles x 2 tap tiles) = 48 MFMAs
+// instead of 331 K multiply-adds.  The dy^T operand comes from the staged brick by transposed LDS reads (as in the 3x3x3
+// weight-gradient kernel), the X operand is 8 consecutive floats of a halo row per lane (k-group = (h row, w half), element = w).
+// Each wave takes two of the eight k-steps; the waves' tiles meet in LDS once per workgroup.  Needs Cout == 48.
+__global__ void __launch_bounds__(256) conv3_stem_wgrad_mfma_kernel(const float* __restrict__ x, const bf16* __restrict__ dy, int64_t lddy, float* __restrict__ dw,
+                                                                    int B, int D, int H, int W, int nbricks) {
+  constexpr int Cout = 48, ROWB = Cout * 2 + 16;
+  __shared__ __attribute__((aligned(16))) char ds[256 * ROWB];      // dy brick, padded rows; reused for the final reduction
+  __shared__ float xs[SH_N];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fi = lane & 15, fq = lane >> 4, qq = fi >> 2, p4 = (fi & 3) * 4;
+  f32x4 acc[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // this lane's tap per tap tile (n index = fi): halo displacement, or -1 for the padding columns 27..31
+  int toff[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int tap = nt * 16 + fi;
+    toff[nt] = tap < 27 ? ((tap / 9) * SH_H + (tap / 3) % 3) * SH_W + tap % 3 : -1;
+  }
+  const int nbw = cdiv(W, SB_W), nbh = cdiv(H, SB_H), nbd = cdiv(D, SB_D);
+  for (int brick = blockIdx.x; brick < nbricks; brick += gridDim.x) {
+    int bid = brick;
+    const int bw = bid % nbw; bid /= nbw;
+    const int bh = bid % nbh; bid /= nbh;
+    const int bd = bid % nbd;
+    const int b = bid / nbd;
+    const int d0 = bd * SB_D, h0 = bh * SB_H, w0 = bw * SB_W;
+    __syncthreads();
+    for (int i = tid; i < SH_N; i += 256) {
+      const int hd = i / (SH_H * SH_W), rem = i - hd * (SH_H * SH_W), hh = rem / SH_W, hw = rem - hh * SH_W;
+      const int d = d0 - 1 + hd, h = h0 - 1 + hh, ww = w0 - 1 + hw;
+      xs[i] = (d >= 0 && d < D && h >= 0 && h < H && ww >= 0 && ww < W) ? x[(((int64_t)b * D + d) * H + h) * W + ww] : 0.f;
+    }
+    for (int i = tid; i < 256 * 6; i += 256) {
+      const int vi = i / 6, c = (i - vi * 6) * 8;
+      const int d = d0 + (vi >> 6), h = h0 + ((vi >> 4) & 3), ww = w0 + (vi & 15);
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+      if (d < D && h < H && ww < W) v = *reinterpret_cast<const bf16x8*>(dy + ((((int64_t)b * D + d) * H + h) * W + ww) * lddy + c);
+      *reinterpret_cast<bf16x8*>(ds + vi * ROWB + c * 2) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ks = wave + 4 * kk;                                    // k-step: depth ks >> 1, h rows 2 (ks & 1) .. +1
+      const int vd = ks >> 1, vh = 2 * (ks & 1) + (fq >> 1), wh = 8 * (fq & 1);
+      const int vrow = (vd * SB_H + vh) * SB_W + wh + qq;
+      bf16x8 af[3], bfr[2];
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt) {
+        const char* a1 = ds + vrow * ROWB + (mt * 16 + p4) * 2;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1 + 4 * ROWB));
+        af[mt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const float* xp = xs + (vd * SH_H + vh) * SH_W + wh + (toff[nt] < 0 ? 0 : toff[nt]);
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (bf16)(toff[nt] < 0 ? 0.f : xp[e]);
+        bfr[nt] = v;
+      }
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[mt], acc[mt][nt], 0, 0, 0);
+    }
+  }
+  // lane holds tap = 16nt + 4fq + r, co = 16mt + fi
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(ds);                  // [4 waves][48 co][32 taps]
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+      *reinterpret_cast<f32x4*>(red + ((wave * 48 + mt * 16 + fi) * 32 + nt * 16 + fq * 4)) = acc[mt][nt];
+  __syncthreads();
+  for (int o = tid; o < 48 * 27; o += 256) {
+    const int co = o / 27, tap = o - co * 27;
+    atomicAdd(dw + o, red[(0 * 48 + co) * 32 + tap] + red[(1 * 48 + co) * 32 + tap] + red[(2 * 48 + co) * 32 + tap] + red[(3 * 48 + co) * 32 + tap]);
+  }
+}
+
 // ----------------------------------------------------------------------------- output head (1x1x1 + bias -> NCDHW fp32)
 // thread = voxel: the channels-last row is read once in 16-byte pieces; weights [Cout][Cin] are LDS broadcasts.
 template <class T, int VEC>
@@ -1179,6 +1322,14 @@ extern "C" int miseg_conv3_thin_fwd(const miseg_conv3_thin_params* p, miseg_stre
   MISEG_REQUIRE(p->Cin >= 1 && p->Cin <= 4 && p->Cin * 27 * p->Cout <= 15000, MISEG_E_UNSUPPORTED, "conv3_thin_fwd: Cin %d Cout %d", p->Cin, p->Cout);
   DT(p, {
     const int64_t nv = (int64_t)p->B * p->D * p->H * p->W;
+    if constexpr (std::is_same<T, bf16>::value) {
+      if (p->Cin == 1 && p->Cout == 48 && p->ldy % 4 == 0 && ((uintptr_t)p->y & 7) == 0) {           // matrix-core form (see conv3_stem_fwd_mfma_kernel)
+        const int nbricks = p->B * cdiv(p->D, miseg::SB_D) * cdiv(p->H, miseg::SB_H) * cdiv(p->W, miseg::SB_W);
+        conv3_stem_fwd_mfma_kernel<<<nbricks < 2048 ? nbricks : 2048, 256, 0, s>>>(p->x, (bf16*)p->y, p->ldy, p->w, p->B, p->D, p->H, p->W, nbricks);
+        MISEG_LAUNCH_CHECK("conv3_stem_fwd_mfma");
+        return MISEG_OK;
+      }
+    }
     if (p->Cin == 1 && p->Cout % 8 == 0 && p->Cout <= 64 && p->ldy % 8 == 0 && al16(p->y)) {       // brick kernel (see conv3_stem_fwd_kernel)
       const int nbricks = p->B * cdiv(p->D, miseg::SB_D) * cdiv(p->H, miseg::SB_H) * cdiv(p->W, miseg::SB_W);
       conv3_stem_fwd_kernel<T><<<nbricks < 4096 ? nbricks : 4096, 256, 0, s>>>(p->x, (T*)p->y, p->ldy, p->w, p->B, p->D, p->H, p->W, p->Cout, nbricks);
@@ -1197,6 +1348,14 @@ extern "C" int miseg_conv3_thin_wgrad(const miseg_conv3_thin_wgrad_params* p, mi
   MISEG_REQUIRE(p->Cin >= 1 && p->Cin <= 4 && p->Cout <= 64, MISEG_E_UNSUPPORTED, "conv3_thin_wgrad: Cin %d Cout %d", p->Cin, p->Cout);
   DT(p, {
     constexpr int VN = Vec16<T>::N;
+    if constexpr (std::is_same<T, bf16>::value) {
+      if (p->Cin == 1 && p->Cout == 48 && p->lddy % 8 == 0 && al16(p->dy)) {      // matrix-core form (see conv3_stem_wgrad_mfma_kernel)
+        const int nbricks = p->B * cdiv(p->D, miseg::SB_D) * cdiv(p->H, miseg::SB_H) * cdiv(p->W, miseg::SB_W);
+        conv3_stem_wgrad_mfma_kernel<<<nbricks < 1280 ? nbricks : 1280, 256, 0, s>>>(p->x, (const bf16*)p->dy, p->lddy, p->dw, p->B, p->D, p->H, p->W, nbricks);
+        MISEG_LAUNCH_CHECK("conv3_stem_wgrad_mfma");
+        return MISEG_OK;
+      }
+    }
     if (p->Cin == 1 && p->Cout % 8 == 0 && p->Cout % VN == 0 && p->Cout / 8 * 36 <= 256 && p->lddy % VN == 0 && al16(p->dy)) {   // see conv3_stem_wgrad_kernel
       const int nbricks = p->B * cdiv(p->D, miseg::SB_D) * cdiv(p->H, miseg::SB_H) * cdiv(p->W, miseg::SB_W);
       size_t sh = 2608 + (size_t)256 * p->Cout * sizeof(T);
