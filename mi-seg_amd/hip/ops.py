@@ -422,7 +422,7 @@ def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False):
     fast = (_round_up(Cin, kpc) * x.element_size()) % 96 == 0
     name = f"conv3_fwd{'96' if fast else ''}_kernel<{'bf16' if x.dtype == torch.bfloat16 else 'f32'}>"
     nbytes = float(x.element_size()) * (B * D * H * W * (Cin + Cout) + wpk.numel())      # x read once, y written once, the weight pack
-    fuse_res = res is not None and fast and res.dtype == x.dtype
+    fuse_res = res is not None and fast and res.dtype == x.dtype and PROFILE_HOOK is None     # (the roofline leg times the plain implicit GEMM)
     stat = None
     if want_stat and fast and not wsb and PROFILE_HOOK is None:     # (the roofline leg repeats launches: it would accumulate)
         stat = STAT_POOL.take(lib.miseg_instnorm_stat_bytes(B, Cout) // 8, x.device).view(-1, B, Cout, 2)
