@@ -89,6 +89,9 @@ typedef struct {
   float* dgamma[MISEG_MAX_STYLES]; float* dbeta[MISEG_MAX_STYLES];
   int act; float slope;
   const void* gadd; int64_t ldgadd;   /* optional: dx += gadd (the gradient of a skip branch forked off x: the fan-out sum rides here) */
+  /* y may be NULL with MISEG_ACT_LEAKY when NO residual entered the activation: the sign is then recomputed from x with the forward's
+   * scale / shift (needs beta; saves one read of the tensor in each backward kernel and keeping y alive) */
+  const float* beta[MISEG_MAX_STYLES];
 } miseg_instnorm_bwd_params;
 int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stream_t stream);
 

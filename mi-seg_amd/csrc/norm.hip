@@ -206,7 +206,7 @@ template <class T, int VEC>
 __global__ void __launch_bounds__(NORM_THREADS) instnorm_bwd_reduce_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ yact, int64_t ldy,
                                                                            const T* __restrict__ x, int64_t ldx, int S, int C, int cv, int tx_n, int ty_n, int rpb,
                                                                            const double* __restrict__ stat, float eps, int act, float slope,
-                                                                           double* __restrict__ dstat) {
+                                                                           double* __restrict__ dstat, const int32_t* __restrict__ styles, StylePtrs sp) {
   extern __shared__ __attribute__((aligned(16))) float red[];
   double* sums = reinterpret_cast<double*>(red);   // prologue only; the reduction reuses the space after a barrier
   const int b = blockIdx.y, chunk = blockIdx.x, c0 = blockIdx.z * tx_n;
@@ -219,6 +219,18 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_bwd_reduce_kernel(const
   const double invS = 1.0 / S;
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { s[i] = q[i] = 0.f; mean_rstd(sums + (tx * VEC + i) * 2, invS, eps, m[i], rs[i]); }
+  float zsc[VEC], zsh[VEC];     // the forward's scale / shift (instnorm_apply_kernel): only to recompute the activation's sign
+  {
+    const int st = styles ? styles[b] : 0;
+    const float* gz = sp.gamma[st];
+    const float* bz = sp.beta[st];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const int ch = c * VEC + i;
+      zsc[i] = rs[i] * ((gz && c < cv) ? gz[ch] : 1.f);
+      zsh[i] = ((bz && c < cv) ? bz[ch] : 0.f) - m[i] * zsc[i];
+    }
+  }
   __syncthreads();
   if (ty < ty_n && c < cv) {
 #pragma unroll 4
@@ -227,10 +239,15 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_bwd_reduce_kernel(const
       g.load(dy + (boff + r) * lddy + c * VEC);
       xv.load(x + (boff + r) * ldx + c * VEC);
       if (act == MISEG_ACT_LEAKY) {
-        RowVec<T, VEC> yv;
-        yv.load(yact + (boff + r) * ldy + c * VEC);
+        if (yact) {
+          RowVec<T, VEC> yv;
+          yv.load(yact + (boff + r) * ldy + c * VEC);
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) g.v[i] = yv.v[i] > 0.f ? g.v[i] : g.v[i] * slope;
+          for (int i = 0; i < VEC; ++i) g.v[i] = yv.v[i] > 0.f ? g.v[i] : g.v[i] * slope;
+        } else {   // no residual went into the activation: its sign is the sign of the forward's fma(x, sc, sh), recomputed from x
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) g.v[i] = fmaf(xv.v[i], zsc[i], zsh[i]) > 0.f ? g.v[i] : g.v[i] * slope;
+        }
       }
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
@@ -286,16 +303,27 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_bwd_apply_kernel(const 
     a[i] = (float)(dsums[(tx * VEC + i) * 2] * invS);
     bq[i] = (float)(dsums[(tx * VEC + i) * 2 + 1] * invS);
   }
+  float zsc[VEC], zsh[VEC];
+  {
+    const float* bz = sp.beta[st];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { zsc[i] = sc[i]; zsh[i] = (bz ? bz[c * VEC + i] : 0.f) - m[i] * sc[i]; }
+  }
 #pragma unroll 4
   for (int r = r0 + ty; r < r1; r += ty_n) {
     RowVec<T, VEC> gv, xv, o;
     gv.load(dy + (boff + r) * lddy + c * VEC);
     xv.load(x + (boff + r) * ldx + c * VEC);
     if (act == MISEG_ACT_LEAKY) {
-      RowVec<T, VEC> yv;
-      yv.load(yact + (boff + r) * ldy + c * VEC);
+      if (yact) {
+        RowVec<T, VEC> yv;
+        yv.load(yact + (boff + r) * ldy + c * VEC);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) gv.v[i] = yv.v[i] > 0.f ? gv.v[i] : gv.v[i] * slope;
+        for (int i = 0; i < VEC; ++i) gv.v[i] = yv.v[i] > 0.f ? gv.v[i] : gv.v[i] * slope;
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) gv.v[i] = fmaf(xv.v[i], zsc[i], zsh[i]) > 0.f ? gv.v[i] : gv.v[i] * slope;
+      }
     }
     if (dres) gv.store(dres + (boff + r) * lddres + c * VEC);
 #pragma unroll
@@ -422,6 +450,18 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_fused_bwd_kernel(const 
   float s[VEC], q[VEC], m[VEC], rs[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { s[i] = q[i] = 0.f; mean_rstd(sums + (tx * VEC + i) * 2, invS, eps, m[i], rs[i]); }
+  float zsc[VEC], zsh[VEC];     // the forward's scale / shift: only to recompute the activation's sign when y was not kept
+  {
+    const int stz = styles ? styles[b] : 0;
+    const float* gz = sp.gamma[stz];
+    const float* bz = sp.beta[stz];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const int ch = c * VEC + i;
+      zsc[i] = rs[i] * ((gz && c < cv) ? gz[ch] : 1.f);
+      zsh[i] = ((bz && c < cv) ? bz[ch] : 0.f) - m[i] * zsc[i];
+    }
+  }
   if (live) {
 #pragma unroll 4
     for (int r = ty; r < S; r += ty_n) {
@@ -429,10 +469,15 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_fused_bwd_kernel(const 
       g.load(dy + (boff + r) * lddy + c * VEC);
       xv.load(x + (boff + r) * ldx + c * VEC);
       if (act == MISEG_ACT_LEAKY) {
-        RowVec<T, VEC> yv;
-        yv.load(yact + (boff + r) * ldy + c * VEC);
+        if (yact) {
+          RowVec<T, VEC> yv;
+          yv.load(yact + (boff + r) * ldy + c * VEC);
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) g.v[i] = yv.v[i] > 0.f ? g.v[i] : g.v[i] * slope;
+          for (int i = 0; i < VEC; ++i) g.v[i] = yv.v[i] > 0.f ? g.v[i] : g.v[i] * slope;
+        } else {   // no residual went into the activation: its sign is the sign of the forward's fma(x, sc, sh), recomputed from x
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) g.v[i] = fmaf(xv.v[i], zsc[i], zsh[i]) > 0.f ? g.v[i] : g.v[i] * slope;
+        }
       }
 #pragma unroll
       for (int i = 0; i < VEC; ++i) { s[i] += g.v[i]; q[i] = fmaf(g.v[i], (xv.v[i] - m[i]) * rs[i], q[i]); }
@@ -462,10 +507,15 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_fused_bwd_kernel(const 
     gv.load(dy + (boff + r) * lddy + c * VEC);
     xv.load(x + (boff + r) * ldx + c * VEC);
     if (act == MISEG_ACT_LEAKY) {
-      RowVec<T, VEC> yv;
-      yv.load(yact + (boff + r) * ldy + c * VEC);
+      if (yact) {
+        RowVec<T, VEC> yv;
+        yv.load(yact + (boff + r) * ldy + c * VEC);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) gv.v[i] = yv.v[i] > 0.f ? gv.v[i] : gv.v[i] * slope;
+        for (int i = 0; i < VEC; ++i) gv.v[i] = yv.v[i] > 0.f ? gv.v[i] : gv.v[i] * slope;
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) gv.v[i] = fmaf(xv.v[i], zsc[i], zsh[i]) > 0.f ? gv.v[i] : gv.v[i] * slope;
+      }
     }
     if (dres) gv.store(dres + (boff + r) * lddres + c * VEC);
 #pragma unroll
@@ -649,7 +699,7 @@ extern "C" int miseg_instnorm_fwd(const miseg_instnorm_apply_params* p, miseg_st
 extern "C" int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   MISEG_REQUIRE(p && p->dy && p->x && p->dx && p->stat && p->dstat, MISEG_E_BADARG, "instnorm_bwd: null pointer");
-  MISEG_REQUIRE(p->act == MISEG_ACT_NONE || (p->act == MISEG_ACT_LEAKY && p->y), MISEG_E_BADARG, "instnorm_bwd: act %d needs y", p->act);
+  MISEG_REQUIRE(p->act == MISEG_ACT_NONE || p->act == MISEG_ACT_LEAKY, MISEG_E_BADARG, "instnorm_bwd: act %d", p->act);
   MISEG_REQUIRE(p->num_styles >= 1 && p->num_styles <= MISEG_MAX_STYLES, MISEG_E_BADARG, "instnorm_bwd: num_styles %d", p->num_styles);
   return dispatch_dtype(p->dtype, [&](auto* tag) -> int {
     typedef typename std::remove_pointer<decltype(tag)>::type T;
@@ -662,7 +712,7 @@ extern "C" int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stre
     StyleGradPtrs gp;
     for (int s = 0; s < MISEG_MAX_STYLES; ++s) {
       sp.gamma[s] = s < p->num_styles ? p->gamma[s] : nullptr;
-      sp.beta[s] = nullptr;
+      sp.beta[s] = s < p->num_styles ? p->beta[s] : nullptr;
       gp.dgamma[s] = s < p->num_styles ? p->dgamma[s] : nullptr;
       gp.dbeta[s] = s < p->num_styles ? p->dbeta[s] : nullptr;
     }
@@ -690,7 +740,7 @@ extern "C" int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stre
     double* dstat = (double*)p->dstat;
 #define BWD_LAUNCH(VV)                                                                                                                                          \
     instnorm_bwd_reduce_kernel<T, VV><<<grid, NORM_THREADS, sh, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, p->S, p->C,  \
-                                                                           g.cv, g.tx, g.ty, g.rpb, stat, p->eps, p->act, p->slope, dstat);                           \
+                                                                           g.cv, g.tx, g.ty, g.rpb, stat, p->eps, p->act, p->slope, dstat, p->styles, sp);               \
     instnorm_bwd_apply_kernel<T, VV><<<grid, NORM_THREADS, shd, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, (T*)p->dx,    \
                                                                          p->lddx, (T*)p->dres, p->lddres, p->S, p->C, g.cv, g.tx, g.ty, g.rpb, stat, p->eps, p->styles, \
                                                                          sp, p->act, p->slope, dstat, gp, (const T*)p->gadd, p->ldgadd);

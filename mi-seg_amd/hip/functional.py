@@ -108,13 +108,17 @@ class _InstNorm(Function):
             y, stat = ops.instnorm_fwd(x, B, S, styles_dev, gammas, betas, res=res, act=act, slope=slope, eps=eps)
         ctx.meta = (B, S, styles_host, num_styles, affine, act, slope, res is not None, eps)
         ctx.params = params
-        ctx.save_for_backward(x, y if act != L.ACT_NONE else None, stat, styles_dev, *(gammas or []))
+        # y is kept only where a residual entered the activation: otherwise the backward kernels recompute the LeakyReLU's sign from x
+        keep_y = act != L.ACT_NONE and res is not None
+        ctx.nbeta = len(betas) if (betas and act != L.ACT_NONE and not keep_y) else 0
+        ctx.save_for_backward(x, y if keep_y else None, stat, styles_dev, *(gammas or []), *(betas[:ctx.nbeta] if ctx.nbeta else []))
         return (y, x.view_as(x)) if fork else y
 
     @staticmethod
     def backward(ctx, dy, gskip=None):
         B, S, styles_host, num_styles, affine, act, slope, has_res, eps = ctx.meta
-        x, y, stat, styles_dev, *gammas = ctx.saved_tensors
+        x, y, stat, styles_dev, *gb = ctx.saved_tensors
+        gammas, betas = (gb[:len(gb) - ctx.nbeta], gb[len(gb) - ctx.nbeta:]) if ctx.nbeta else (gb, None)
         dy = _rv(dy)
         C = x.shape[-1]
         present = sorted(set(styles_host)) if styles_host is not None else [0]
@@ -129,7 +133,7 @@ class _InstNorm(Function):
             dgam = [buf[s, 0] if s in present else None for s in range(num_styles)]
             dbet = [buf[s, 1] if s in present else None for s in range(num_styles)]
         dx, dres = ops.instnorm_bwd(dy, y, x, B, S, stat, styles_dev, gammas if affine else None, dgam, dbet, act=act, slope=slope, eps=eps,
-                                    want_dres=has_res and ctx.needs_input_grad[1], gadd=_rv(gskip))
+                                    want_dres=has_res and ctx.needs_input_grad[1], gadd=_rv(gskip), betas=betas)
         pg = []
         if affine:
             for s in range(num_styles):

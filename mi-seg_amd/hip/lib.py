@@ -33,7 +33,7 @@ InstnormBwd = _struct("InstnormBwd", [("dy", vp), ("lddy", i64), ("y", vp), ("ld
                                       ("dx", vp), ("lddx", i64), ("dres", vp), ("lddres", i64),
                                       ("B", i32), ("S", i32), ("C", i32), ("dtype", i32), ("stat", vp), ("eps", f32), ("dstat", vp),
                                       ("styles", vp), ("num_styles", i32), ("gamma", fp4), ("dgamma", fp4), ("dbeta", fp4),
-                                      ("act", i32), ("slope", f32), ("gadd", vp), ("ldgadd", i64)])
+                                      ("act", i32), ("slope", f32), ("gadd", vp), ("ldgadd", i64), ("beta", fp4)])
 LayernormFwd = _struct("LayernormFwd", [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32),
                                         ("dtype", i32), ("eps", f32), ("gamma", vp), ("beta", vp), ("mean", vp), ("rstd", vp)])
 LayernormBwd = _struct("LayernormBwd", [("dy", vp), ("lddy", i64), ("x", vp), ("ldx", i64), ("dx", vp), ("lddx", i64),

@@ -150,7 +150,8 @@ def instnorm_fwd(x, B, S, styles, gammas, betas, res=None, act=L.ACT_NONE, slope
     return y, stat
 
 
-def instnorm_bwd(dy, y, x, B, S, stat, styles, gammas, dgammas, dbetas, act=L.ACT_NONE, slope=0.01, eps=1e-5, want_dres=False, gadd=None):
+def instnorm_bwd(dy, y, x, B, S, stat, styles, gammas, dgammas, dbetas, act=L.ACT_NONE, slope=0.01, eps=1e-5, want_dres=False, gadd=None, betas=None):
+    """y=None with a LeakyReLU: valid when no residual entered the activation; the kernels recompute its sign from x (needs betas)."""
     ld, n, Cc = rows(x)
     dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     dres = torch.empty(x.shape, dtype=x.dtype, device=x.device) if want_dres else None
@@ -159,7 +160,7 @@ def instnorm_bwd(dy, y, x, B, S, stat, styles, gammas, dgammas, dbetas, act=L.AC
     p = L.InstnormBwd(_ptr(dy), rows(dy)[0], _ptr(y), rows(y)[0] if y is not None else 0, _ptr(x), ld, _ptr(dx), rows(dx)[0],
                       _ptr(dres), rows(dres)[0] if dres is not None else 0, B, S, Cc, _dt(x), _ptr(stat), eps, _ptr(dstat), _ptr(styles), ns,
                       _style_arrays(gammas, ns), _style_arrays(dgammas, ns), _style_arrays(dbetas, ns), act, slope,
-                      _ptr(gadd), rows(gadd)[0] if gadd is not None else 0)
+                      _ptr(gadd), rows(gadd)[0] if gadd is not None else 0, _style_arrays(betas, ns))
     _call("miseg_instnorm_bwd", p)
     return dx, dres
 
