@@ -983,6 +983,78 @@ __global__ void __launch_bounds__(256) head_bwd_dw_team_kernel(const T* __restri
   }
 }
 
+// Head weight gradient on the matrix cores (bf16 activations, Cin == 48, Cout <= 16, S % 256 == 0): dw[co][ci] = sum_v dy[co][v] x[v][ci]
+// is a 16 x 48 x V GEMM.  Tiles of 256 voxel rows of x are staged in LDS and read transposed (`ds_read_b64_tr_b16`, as the conv
+// weight-gradient kernels do); dy is already voxel-contiguous per output channel: a lane converts 8 consecutive fp32 values of its
+// channel.  Each wave takes two of a tile's eight 32-voxel k-steps; 3 MFMAs per k-step.  The team kernel (one 16-byte load per lane and
+// row, then 6 x 8 multiply-adds) ran at 1.1 TB/s.
+__global__ void __launch_bounds__(256) head_bwd_dw_mfma_kernel(const bf16* __restrict__ x, int64_t ldx, const float* __restrict__ dy, float* __restrict__ dw,
+                                                               float* __restrict__ dbias, int S, int Cout, int64_t ntiles) {
+  constexpr int Cin = 48, ROWB = Cin * 2 + 16;
+  __shared__ __attribute__((aligned(16))) char xs[256 * ROWB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fi = lane & 15, fq = lane >> 4, qq = fi >> 2, p4 = (fi & 3) * 4;
+  f32x4 acc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  const bool has_co = fi < Cout;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t v0 = tile * 256;
+    const int b = (int)(v0 / S);
+    const int64_t s0 = v0 - (int64_t)b * S;
+    __syncthreads();
+    for (int i = tid; i < 256 * 6; i += 256) {
+      const int r = i / 6, c = (i - r * 6) * 8;
+      *reinterpret_cast<bf16x8*>(xs + r * ROWB + c * 2) = *reinterpret_cast<const bf16x8*>(x + (v0 + r) * ldx + c);
+    }
+    // this lane's dy values of both its k-steps (issued before the barrier: in flight while the tile is staged)
+    f32x4 g[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const float* gp = dy + ((int64_t)b * Cout + (has_co ? fi : 0)) * S + s0 + (wave + 4 * kk) * 32 + fq * 8;
+      g[kk][0] = has_co ? *reinterpret_cast<const f32x4*>(gp) : f32x4{0.f, 0.f, 0.f, 0.f};
+      g[kk][1] = has_co ? *reinterpret_cast<const f32x4*>(gp + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int vrow = (wave + 4 * kk) * 32 + fq * 8 + qq;
+      bf16x8 gf;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { gf[e] = (bf16)g[kk][0][e]; gf[4 + e] = (bf16)g[kk][1][e]; }
+      bsum += (g[kk][0][0] + g[kk][0][1]) + (g[kk][0][2] + g[kk][0][3]) + (g[kk][1][0] + g[kk][1][1]) + (g[kk][1][2] + g[kk][1][3]);
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt) {
+        const char* a1 = xs + vrow * ROWB + (mt * 16 + p4) * 2;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1 + 4 * ROWB));
+        const bf16x8 xf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, xf, acc[mt], 0, 0, 0);      // lane: co = 4fq + r, ci = 16mt + fi
+      }
+    }
+  }
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(xs);          // [4 waves][16 co][48 ci] + [4 waves][64 lanes] bias partials
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(wave * 16 + fq * 4 + r) * 48 + mt * 16 + fi] = acc[mt][r];
+  float* bred = red + 4 * 16 * 48;
+  bred[wave * 64 + lane] = bsum;
+  __syncthreads();
+  for (int o = tid; o < Cout * 48; o += 256) {
+    const int co = o / 48, ci = o - co * 48;
+    atomicAdd(dw + o, red[(0 * 16 + co) * 48 + ci] + red[(1 * 16 + co) * 48 + ci] + red[(2 * 16 + co) * 48 + ci] + red[(3 * 16 + co) * 48 + ci]);
+  }
+  if (dbias && tid < Cout) {
+    float a = 0.f;
+    for (int w4 = 0; w4 < 4; ++w4)
+      for (int q = 0; q < 4; ++q) a += bred[w4 * 64 + q * 16 + tid];
+    atomicAdd(dbias + tid, a);
+  }
+}
+
 // dw[co][ci][a][b][c] += sum over coarse voxels of dy[cv][co] x[b][ci][2d+a][2h+b][2w+c], dbias[co] += sum dy[cv][co]
 // lane = (coarse voxel row ty, output-channel vector tx); one input channel per pass (blockIdx.y)
 template <class T, int VEC>
@@ -1001,6 +1073,7 @@ __global__ void __launch_bounds__(256) patch_embed_bwd_team_kernel(const float* 
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[t][k] = 0.f;
   if (ty < ty_n) {
+#pragma unroll 4
     for (int64_t v = r0 + ty; v < r1; v += ty_n) {
       V<T, VEC> g;
       g.load(dy + v * lddy + tx * VEC);
@@ -1351,7 +1424,7 @@ extern "C" int miseg_conv3_thin_wgrad(const miseg_conv3_thin_wgrad_params* p, mi
     if constexpr (std::is_same<T, bf16>::value) {
       if (p->Cin == 1 && p->Cout == 48 && p->lddy % 8 == 0 && al16(p->dy)) {      // matrix-core form (see conv3_stem_wgrad_mfma_kernel)
         const int nbricks = p->B * cdiv(p->D, miseg::SB_D) * cdiv(p->H, miseg::SB_H) * cdiv(p->W, miseg::SB_W);
-        conv3_stem_wgrad_mfma_kernel<<<nbricks < 1280 ? nbricks : 1280, 256, 0, s>>>(p->x, (const bf16*)p->dy, p->lddy, p->dw, p->B, p->D, p->H, p->W, nbricks);
+        conv3_stem_wgrad_mfma_kernel<<<nbricks < 512 ? nbricks : 512, 256, 0, s>>>(p->x, (const bf16*)p->dy, p->lddy, p->dw, p->B, p->D, p->H, p->W, nbricks);
         MISEG_LAUNCH_CHECK("conv3_stem_wgrad_mfma");
         return MISEG_OK;
       }
@@ -1407,7 +1480,15 @@ extern "C" int miseg_head_bwd(const miseg_head_bwd_params* p, miseg_stream_t s_)
       else
         head_bwd_dx_kernel<T, 1><<<ew_grid(nv), 256, sh, s>>>(p->dy, (T*)p->dx, p->lddx, p->w, p->B, p->S, p->Cin, p->Cout);
     }
-    if (p->dw) {
+    bool dw_done = false;
+    if constexpr (std::is_same<T, bf16>::value) {
+      if (p->dw && p->Cin == 48 && p->Cout <= 16 && p->S % 256 == 0 && p->ldx % 8 == 0 && al16(p->x) && al16(p->dy)) {
+        const int64_t ntiles = nv / 256;
+        head_bwd_dw_mfma_kernel<<<(int)(ntiles < 512 ? ntiles : 512), 256, 0, s>>>((const bf16*)p->x, p->ldx, p->dy, p->dw, p->dbias, p->S, p->Cout, ntiles);
+        dw_done = true;
+      }
+    }
+    if (p->dw && !dw_done) {
       const int tx_n = p->Cin / N;
       if (p->Cin % N == 0 && p->ldx % N == 0 && al16(p->x) && tx_n >= 1 && tx_n <= 64) {
         const int ty_n = 256 / tx_n;

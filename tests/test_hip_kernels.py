@@ -354,6 +354,12 @@ def test_conv3_thin_and_head_and_patch_embed(dtype):
     assert rel_err(dxh.permute(0, 4, 1, 2, 3), torch.nn.grad.conv3d_input(lor.shape[:1] + (48,) + lor.shape[2:], wh, g)) < TOL[dtype]
     assert rel_err(dwh, torch.nn.grad.conv3d_weight(xh.float().permute(0, 4, 1, 2, 3), wh.shape, g)) < TOL[dtype]
     assert rel_err(dbh, g.sum((0, 2, 3, 4))) < 1e-4
+    # 512 voxels per sample (whole 256-row tiles): the bf16 weight gradient runs on the matrix cores; accumulates on top of dw / dbias
+    xh2, g2 = rnd(2, 8, 8, 8, 48, dtype=dtype, seed=64), rnd(2, 6, 8, 8, 8, seed=65)
+    dw2, db2 = wh.clone(), bh.clone()
+    ops.head_bwd(xh2, g2, wh, dw2, db2)
+    assert rel_err(dw2 - wh, torch.nn.grad.conv3d_weight(xh2.float().permute(0, 4, 1, 2, 3), wh.shape, g2)) < TOL[dtype]
+    assert rel_err(db2 - bh, g2.sum((0, 2, 3, 4))) < 1e-4
     # patch embed
     xp = rnd(2, 1, 8, 10, 12, seed=58)
     wp, bp = rnd(24, 1, 2, 2, 2, seed=59) / 3, rnd(24, seed=60)
