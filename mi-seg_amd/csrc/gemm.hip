@@ -88,6 +88,14 @@ __device__ __forceinline__ typename Vec16<T>::type load_chunk(const T* base, int
 template <class TO>
 __device__ __forceinline__ void store_out4(TO* C, int64_t ldc, int m, int n, int M, int N, f32x4 v, const Epi& e, int mode /*0 store,1 add,2 atomic*/) {
   if (m >= M) return;
+  if constexpr (std::is_same<TO, float>::value) {
+    // plain fp32 store / add of four consecutive columns as one 16-byte access (the weight-gradient tiles: no epilogue pieces)
+    if (mode != 2 && !e.bias && !e.res && e.mode == 0 && e.act == MISEG_ACT_NONE && n + 3 < N && (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) {
+      f32x4* p4 = reinterpret_cast<f32x4*>(C + (int64_t)m * ldc + n);
+      *p4 = mode == 1 ? *p4 + v : v;
+      return;
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     if (n + r < N) {
@@ -868,7 +876,9 @@ extern "C" int miseg_gemm_tn_group(const miseg_gemm_tn_desc* descs, int n, int d
     TnGroup::P& q = g.p[i];
     q.A = d.A; q.lda = d.lda; q.B = d.B; q.ldb = d.ldb; q.C = d.C; q.ldc = d.ldc; q.M = d.M; q.N = d.N; q.K = d.K;
     q.gx = cdiv(d.M, 64); q.gy = cdiv(d.N, 64);
-    int split = cdiv(d.K, 512);
+    // split the reduction only when it is long: split partials meet in fp32 atomics, and ~4 M of them (the 12^3-stage problems,
+    // K = 1728, split 4 ways) cost 3x what the whole family takes unsplit (75 -> 25 us); the group as a whole fills the chip
+    int split = cdiv(d.K, 2048);
     if (split > 1024 / (q.gx * q.gy)) split = 1024 / (q.gx * q.gy);
     if (split < 1) split = 1;
     q.kps = cdiv(cdiv(d.K, split), bk) * bk;
