@@ -820,29 +820,45 @@ extern "C" int miseg_gemm_tn_splits(const miseg_gemm_params* p) {
 
 namespace miseg {
 struct TnReduceBatch { miseg_tn_reduce_desc d[MISEG_TN_REDUCE_BATCH]; int n; };
-// one thread per 4 consecutive n of one problem; C += sum over all splits (single writer per element: no atomics)
+// one thread per 4 consecutive n of one problem AND per group of TNB_SG splits (8 loads in flight): a thread that walked all ~400
+// splits of a 48x48 problem alone was a 100-deep dependent chain (78 us for the launch); the groups meet in fp32 atomics (<= 16
+// arrivals per element), a single group adds with one 16-byte read-modify-write
+static constexpr int TNB_SG = 32;
 __global__ void __launch_bounds__(256) gemm_tn_reduce_batch_kernel(TnReduceBatch b) {
   int k = 0;
   while (k + 1 < b.n && b.d[k + 1].block0 <= (int)blockIdx.x) ++k;
   const miseg_tn_reduce_desc d = b.d[k];
-  const int i = (blockIdx.x - d.block0) * 256 + threadIdx.x;
+  const int per = cdiv(d.M * (d.N / 4), 256);                 // blocks per split group
+  const int local = blockIdx.x - d.block0, grp = local / per;
+  const int i = (local - grp * per) * 256 + threadIdx.x;
   if (i >= d.M * (d.N / 4)) return;
   const int m = i / (d.N / 4), n = (i - m * (d.N / 4)) * 4;
   const float* p = d.partial + (int64_t)m * d.N + n;
   const int64_t stride = (int64_t)d.M * d.N;
-  f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
-  int s = 0;
-  for (; s + 3 < d.splits; s += 4) {
-    a0 += *reinterpret_cast<const f32x4*>(p + (s + 0) * stride);
-    a1 += *reinterpret_cast<const f32x4*>(p + (s + 1) * stride);
-    a2 += *reinterpret_cast<const f32x4*>(p + (s + 2) * stride);
-    a3 += *reinterpret_cast<const f32x4*>(p + (s + 3) * stride);
-  }
-  for (; s < d.splits; ++s) a0 += *reinterpret_cast<const f32x4*>(p + s * stride);
-  const f32x4 v = (a0 + a1) + (a2 + a3);
-  float* c = d.C + (int64_t)m * d.ldc + n;
+  const int s0 = grp * TNB_SG, s1 = min(d.splits, s0 + TNB_SG);
+  f32x4 a[8];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) c[r] += v[r];
+  for (int u = 0; u < 8; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int s = s0;
+  for (; s + 7 < s1; s += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += *reinterpret_cast<const f32x4*>(p + (s + u) * stride);
+  }
+  for (; s < s1; ++s) a[0] += *reinterpret_cast<const f32x4*>(p + s * stride);
+  const f32x4 v = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  float* c = d.C + (int64_t)m * d.ldc + n;
+  if (d.splits <= TNB_SG) {
+    if ((d.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(d.C) & 15) == 0) {
+      f32x4* c4 = reinterpret_cast<f32x4*>(c);
+      *c4 = *c4 + v;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[r] += v[r];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(c + r, v[r]);
+  }
 }
 }  // namespace miseg
 
@@ -856,7 +872,7 @@ extern "C" int miseg_gemm_tn_reduce_batch(const miseg_tn_reduce_desc* descs, int
                   "gemm_tn_reduce_batch: descriptor %d", i);
     b.d[i] = descs[i];
     b.d[i].block0 = blocks;
-    blocks += cdiv(descs[i].M * (descs[i].N / 4), 256);
+    blocks += cdiv(descs[i].M * (descs[i].N / 4), 256) * cdiv(descs[i].splits, miseg::TNB_SG);
   }
   miseg::gemm_tn_reduce_batch_kernel<<<blocks, 256, 0, (hipStream_t)s_>>>(b);
   MISEG_LAUNCH_CHECK("gemm_tn_reduce_batch");
