@@ -125,13 +125,15 @@ __global__ void __launch_bounds__(256) gelu_fwd_kernel(const T* x, int64_t ldx, 
 // ----------------------------------------------------------------------------- 2x2x2 space <-> channel
 struct Off8 { int8_t o[24]; };
 
-template <class T, int VEC>
+// IDX: the item index type.  64-bit division is a ~100-instruction software routine on the GPU and these kernels do 4-5 of them per
+// 16-byte item: with fewer than 2^31 items (every shape of the reference configs) the launchers pick the 32-bit instantiation.
+template <class T, int VEC, class IDX = int64_t>
 __global__ void __launch_bounds__(256) s2c_kernel(const T* src, int64_t lds, T* dst, int64_t ldd, int B, int D, int H, int W, int C, Off8 off) {
   const int D2 = (D + 1) / 2, H2 = (H + 1) / 2, W2 = (W + 1) / 2, cv = C / VEC;
-  const int64_t total = (int64_t)B * D2 * H2 * W2 * 8 * cv;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  const IDX total = (IDX)((int64_t)B * D2 * H2 * W2 * 8 * cv);
+  for (IDX i = (IDX)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (IDX)gridDim.x * blockDim.x) {
     const int c = (int)(i % cv) * VEC;
-    int64_t t = i / cv;
+    IDX t = i / cv;
     const int j = (int)(t % 8); t /= 8;
     const int w2 = (int)(t % W2); t /= W2;
     const int h2 = (int)(t % H2); t /= H2;
@@ -148,13 +150,13 @@ __global__ void __launch_bounds__(256) s2c_kernel(const T* src, int64_t lds, T* 
   }
 }
 
-template <class T, int VEC>
+template <class T, int VEC, class IDX = int64_t>
 __global__ void __launch_bounds__(256) c2s_kernel(const T* src, int64_t lds, T* dst, int64_t ldd, int B, int D, int H, int W, int C, Off8 off) {
   const int D2 = (D + 1) / 2, H2 = (H + 1) / 2, W2 = (W + 1) / 2, cv = C / VEC;
-  const int64_t total = (int64_t)B * D * H * W * cv;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  const IDX total = (IDX)((int64_t)B * D * H * W * cv);
+  for (IDX i = (IDX)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (IDX)gridDim.x * blockDim.x) {
     const int c = (int)(i % cv) * VEC;
-    int64_t t = i / cv;
+    IDX t = i / cv;
     const int w = (int)(t % W); t /= W;
     const int h = (int)(t % H); t /= H;
     const int d = (int)(t % D);
@@ -862,27 +864,27 @@ __global__ void __launch_bounds__(256) head_fwd_tile_kernel(const T* __restrict_
 }
 
 // dx[v][ci] = sum_co dy[b][co][s] w[co][ci]: one lane per (voxel, 16-byte channel vector)
-template <class T, int VEC>
+template <class T, int VEC, class IDX = int64_t>
 __global__ void __launch_bounds__(256) head_bwd_dx_team_kernel(const float* __restrict__ dy, T* __restrict__ dx, int64_t lddx, const float* __restrict__ w, int B, int S,
                                                                int Cin, int Cout) {
   extern __shared__ __attribute__((aligned(16))) float ws[];  // [Cout][Cin]
   for (int i = threadIdx.x; i < Cout * Cin; i += 256) ws[i] = w[i];
   __syncthreads();
   const int cv = Cin / VEC;
-  const int64_t total = (int64_t)B * S * cv, stride = (int64_t)gridDim.x * 256;
+  const IDX total = (IDX)((int64_t)B * S * cv), stride = (IDX)gridDim.x * 256;
   constexpr int U = 4;      // items per trip: their dy loads are all in flight before the first FMA
-  for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += U * stride) {
+  for (IDX i0 = (IDX)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += U * stride) {
     float g[U][16];
     int64_t vv[U];
     int cc[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t i = min(i0 + u * stride, total - 1);
-      const int64_t v = i / cv;
-      vv[u] = v;
+      const IDX i = min((IDX)(i0 + u * stride), (IDX)(total - 1));
+      const IDX v = i / cv;
+      vv[u] = (int64_t)v;
       cc[u] = (int)(i - v * cv);
-      const int b = (int)(v / S);
-      const int64_t sidx = v - (int64_t)b * S;
+      const int b = (int)(v / (IDX)S);
+      const int64_t sidx = (int64_t)v - (int64_t)b * S;
 #pragma unroll
       for (int co = 0; co < 16; ++co) g[u][co] = co < Cout ? dy[((int64_t)b * Cout + co) * S + sidx] : 0.f;
     }
@@ -1338,11 +1340,13 @@ static int s2c_common(const miseg_s2c_params* p, hipStream_t s, bool gather) {
     const int D2 = (p->D + 1) / 2, H2 = (p->H + 1) / 2, W2 = (p->W + 1) / 2;
     if (gather) {
       const int64_t tot = (int64_t)p->B * D2 * H2 * W2 * 8;
-      if (vec) s2c_kernel<T, N><<<ew_grid(tot * (p->C / N)), 256, 0, s>>>((const T*)p->src, p->lds, (T*)p->dst, p->ldd, p->B, p->D, p->H, p->W, p->C, off);
+      if (vec && tot * (p->C / N) < (1LL << 30)) s2c_kernel<T, N, unsigned><<<ew_grid(tot * (p->C / N)), 256, 0, s>>>((const T*)p->src, p->lds, (T*)p->dst, p->ldd, p->B, p->D, p->H, p->W, p->C, off);
+      else if (vec) s2c_kernel<T, N><<<ew_grid(tot * (p->C / N)), 256, 0, s>>>((const T*)p->src, p->lds, (T*)p->dst, p->ldd, p->B, p->D, p->H, p->W, p->C, off);
       else s2c_kernel<T, 1><<<ew_grid(tot * p->C), 256, 0, s>>>((const T*)p->src, p->lds, (T*)p->dst, p->ldd, p->B, p->D, p->H, p->W, p->C, off);
     } else {
       const int64_t tot = (int64_t)p->B * p->D * p->H * p->W;
-      if (vec) c2s_kernel<T, N><<<ew_grid(tot * (p->C / N)), 256, 0, s>>>((const T*)p->src, p->lds, (T*)p->dst, p->ldd, p->B, p->D, p->H, p->W, p->C, off);
+      if (vec && tot * (p->C / N) < (1LL << 30)) c2s_kernel<T, N, unsigned><<<ew_grid(tot * (p->C / N)), 256, 0, s>>>((const T*)p->src, p->lds, (T*)p->dst, p->ldd, p->B, p->D, p->H, p->W, p->C, off);
+      else if (vec) c2s_kernel<T, N><<<ew_grid(tot * (p->C / N)), 256, 0, s>>>((const T*)p->src, p->lds, (T*)p->dst, p->ldd, p->B, p->D, p->H, p->W, p->C, off);
       else c2s_kernel<T, 1><<<ew_grid(tot * p->C), 256, 0, s>>>((const T*)p->src, p->lds, (T*)p->dst, p->ldd, p->B, p->D, p->H, p->W, p->C, off);
     }
     MISEG_LAUNCH_CHECK("space/channel");
@@ -1476,7 +1480,10 @@ extern "C" int miseg_head_bwd(const miseg_head_bwd_params* p, miseg_stream_t s_)
     if (p->dx) {
       size_t sh = (size_t)p->Cin * p->Cout * sizeof(float);
       if (p->Cin % N == 0 && p->lddx % N == 0 && al16(p->dx))
-        head_bwd_dx_team_kernel<T, N><<<ew_grid(nv * (p->Cin / N)), 256, sh, s>>>(p->dy, (T*)p->dx, p->lddx, p->w, p->B, p->S, p->Cin, p->Cout);
+        if (nv * (p->Cin / N) < (1LL << 29))      // 32-bit item arithmetic (see s2c_kernel)
+          head_bwd_dx_team_kernel<T, N, unsigned><<<ew_grid(nv * (p->Cin / N)), 256, sh, s>>>(p->dy, (T*)p->dx, p->lddx, p->w, p->B, p->S, p->Cin, p->Cout);
+        else
+          head_bwd_dx_team_kernel<T, N><<<ew_grid(nv * (p->Cin / N)), 256, sh, s>>>(p->dy, (T*)p->dx, p->lddx, p->w, p->B, p->S, p->Cin, p->Cout);
       else
         head_bwd_dx_kernel<T, 1><<<ew_grid(nv), 256, sh, s>>>(p->dy, (T*)p->dx, p->lddx, p->w, p->B, p->S, p->Cin, p->Cout);
     }
