@@ -532,8 +532,10 @@ __device__ __forceinline__ void att_load16(const bf16* p, bool vec, float* dst) 
   }
 }
 
-template <bool MASK, bool DT /* rel-pos table gradient wanted: no per-element branch around its atomics */>
-__global__ void __launch_bounds__(256, 2) winattn_bwd_mfma_kernel(const bf16* __restrict__ qkv, int64_t ldq, const bf16* __restrict__ out, int64_t ldo,
+// NW = waves per workgroup (key tiles are dealt to the waves: 24 / NW each).  4 for the large grids (two workgroups per CU); 8 for the
+// deep stages, whose launch is ONE round of < 256 workgroups: the launch lasts as long as one workgroup, which the extra waves halve.
+template <bool MASK, bool DT /* rel-pos table gradient wanted: no per-element branch around its atomics */, int NW = 4>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) winattn_bwd_mfma_kernel(const bf16* __restrict__ qkv, int64_t ldq, const bf16* __restrict__ out, int64_t ldo,
                                                                   const bf16* __restrict__ dout, int64_t lddo, bf16* __restrict__ dqkv, int64_t lddq,
                                                                   const float* __restrict__ qkv_bias, const float* __restrict__ bias_table,
                                                                   const float* __restrict__ lse_in, float* __restrict__ dqkv_bias,
@@ -547,9 +549,10 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd_mfma_kernel(const bf16* __
   int* rowq = qlabel + ATT_NP;
   float* nlse = reinterpret_cast<float*>(rowq + ATT_NP);   // -lse * log2e  (-inf beyond the window)
   float* ndelta = nlse + ATT_NP;                            // -rowsum(dO * O)
-  float* dqpart = ndelta + ATT_NP;                          // [2][4 waves][16 queries][16 dims]
-  char* dstile = reinterpret_cast<char*>(dqpart + 2 * 4 * 256);   // [4 waves][16 keys][ATT_DS_LD]
-  float* padb = reinterpret_cast<float*>(dstile + 4 * 16 * ATT_DS_LD);   // [48] + 3 bound words (|dO|^2, |V|^2, |delta| maxima)
+  constexpr int NI = 24 / NW, NTHR = NW * 64;
+  float* dqpart = ndelta + ATT_NP;                          // [2][NW waves][16 queries][16 dims]
+  char* dstile = reinterpret_cast<char*>(dqpart + 2 * NW * 256);   // [NW waves][16 keys][ATT_DS_LD]
+  float* padb = reinterpret_cast<float*>(dstile + NW * 16 * ATT_DS_LD);   // [48] + 3 bound words (|dO|^2, |V|^2, |delta| maxima)
   unsigned* bound = reinterpret_cast<unsigned*>(padb + 48);
   float* table = padb + 52;                                 // [tsize] * log2e
   int* dtable = reinterpret_cast<int*>(table + tsize);      // fixed point, see `fscale`
@@ -558,7 +561,7 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd_mfma_kernel(const bf16* __
   if (tid < 52) padb[tid] = 0.f;
   __syncthreads();
   float mg2 = 0.f, mv2 = 0.f, mda = 0.f;
-  for (int t = tid; t < nt16 * 16; t += 256) {
+  for (int t = tid; t < nt16 * 16; t += NTHR) {
     int row = -1, label = 0, code = 0;
     float q[16], k[16], go[16];
     float dl = 0.f, ls = INFINITY, g2 = 0.f, v2 = 0.f;
@@ -605,7 +608,7 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd_mfma_kernel(const bf16* __
 #pragma unroll
   for (int o2 = 1; o2 < 64; o2 <<= 1) { mg2 = fmaxf(mg2, __shfl_xor(mg2, o2, 64)); mv2 = fmaxf(mv2, __shfl_xor(mv2, o2, 64)); mda = fmaxf(mda, __shfl_xor(mda, o2, 64)); }
   if ((tid & 63) == 0) { atomicMax(&bound[0], __float_as_uint(mg2)); atomicMax(&bound[1], __float_as_uint(mv2)); atomicMax(&bound[2], __float_as_uint(mda)); }
-  for (int i = tid; i < tsize; i += 256) { table[i] = bias_table[(int64_t)i * g.heads + head] * ATT_LOG2E; dtable[i] = 0; }
+  for (int i = tid; i < tsize; i += NTHR) { table[i] = bias_table[(int64_t)i * g.heads + head] * ATT_LOG2E; dtable[i] = 0; }
   __syncthreads();
   // LDS float atomics cost ~190 cycles per wave-instruction on gfx950 (integer ones 4-8): the rel-pos bias gradient is
   // binned in fixed point.  |dS_qk| <= p_qk (|dO_q||V_k| + |delta_q|) and a bin receives at most one key per query, so
@@ -618,14 +621,14 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd_mfma_kernel(const bf16* __
   constexpr float MASKV = -100.f * ATT_LOG2E;
 
   // ---- per-wave key tiles
-  s16x4 kfB[ATT_NI], vfB[ATT_NI], kA[ATT_NI];
-  f32x4 dvt[ATT_NI], dkt[ATT_NI];
-  int ck[ATT_NI], lk[ATT_NI];
+  s16x4 kfB[NI], vfB[NI], kA[NI];
+  f32x4 dvt[NI], dkt[NI];
+  int ck[NI], lk[NI];
   bool kval = true;
   int itail = -1;
 #pragma unroll
-  for (int i = 0; i < ATT_NI; ++i) {
-    const int kt = wave + 4 * i;
+  for (int i = 0; i < NI; ++i) {
+    const int kt = wave + NW * i;
     dvt[i] = dkt[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     kfB[i] = vfB[i] = kA[i] = s16x4{0, 0, 0, 0};
     ck[i] = lk[i] = 0;
@@ -672,8 +675,8 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd_mfma_kernel(const bf16* __
     const s16x4 gtA = att_tr_rows(Gs, q0, fi, kg);            // A of dV^T
     f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < ATT_NI; ++i) {
-      if (wave + 4 * i < nt16) {
+    for (int i = 0; i < NI; ++i) {
+      if (wave + NW * i < nt16) {
         const f32x4 sacc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qfA, kfB[i], nl4, 0, 0, 0);   // rows = queries 4kg+e, col = key fi
         const f32x4 pacc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gfA, vfB[i], nd4, 0, 0, 0);   // dP - delta
         float pv[4], dsv[4], tbv[4];
@@ -714,14 +717,14 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd_mfma_kernel(const bf16* __
       }
     }
     // partial dQ^T of this wave: lane (query fi, dims 4kg..4kg+3)
-    float* part = dqpart + (qt & 1) * 1024;
+    float* part = dqpart + (qt & 1) * (NW * 256);
     *reinterpret_cast<f32x4*>(part + (wave * 16 + fi) * 16 + 4 * kg) = dq;
     __syncthreads();
-    if (wave == (qt & 3)) {
+    if (wave == (qt & (NW - 1))) {
       const int ql_ = lane >> 2, d4 = lane & 3, t = q0 + ql_;
       f32x4 sum = *reinterpret_cast<const f32x4*>(part + ql_ * 16 + 4 * d4);
 #pragma unroll
-      for (int w = 1; w < 4; ++w) sum += *reinterpret_cast<const f32x4*>(part + (w * 16 + ql_) * 16 + 4 * d4);
+      for (int w = 1; w < NW; ++w) sum += *reinterpret_cast<const f32x4*>(part + (w * 16 + ql_) * 16 + 4 * d4);
       if (t < n) {
         const int row = rowq[t];
         if (row >= 0) {
@@ -737,9 +740,9 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd_mfma_kernel(const bf16* __
   // ---- dK, dV of the wave's keys: lane (key fi, dims 4kg..4kg+3); dK carries 1/log2e from Q'
   constexpr float LN2 = 0.6931471805599453f;
 #pragma unroll
-  for (int i = 0; i < ATT_NI; ++i) {
-    const int ki = (wave + 4 * i) * 16 + fi;
-    if (wave + 4 * i < nt16 && ki < n) {
+  for (int i = 0; i < NI; ++i) {
+    const int ki = (wave + NW * i) * 16 + fi;
+    if (wave + NW * i < nt16 && ki < n) {
       const int row = rowq[ki];
       if (row >= 0) {
         bf16* pk = dqkv + (int64_t)row * lddq + C + head * 16 + 4 * kg;
@@ -756,7 +759,7 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd_mfma_kernel(const bf16* __
   }
   __syncthreads();
   if (dbias_table)
-    for (int i = tid; i < tsize; i += 256) {
+    for (int i = tid; i < tsize; i += NTHR) {
       const int v = dtable[i];
       if (v != 0) atomicAdd(dbias_table + (int64_t)i * g.heads + head, (float)v / fscale);
     }
@@ -766,8 +769,8 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd_mfma_kernel(const bf16* __
   }
 }
 
-static size_t attn_mfma_bwd_smem(int tsize) {
-  return (size_t)3 * ATT_NP * 32 + (size_t)5 * ATT_NP * 4 + (size_t)2 * 4 * 256 * 4 + (size_t)4 * 16 * ATT_DS_LD + 52 * 4 + (size_t)2 * tsize * 4;
+static size_t attn_mfma_bwd_smem(int tsize, int nw = 4) {
+  return (size_t)3 * ATT_NP * 32 + (size_t)5 * ATT_NP * 4 + (size_t)2 * nw * 256 * 4 + (size_t)nw * 16 * ATT_DS_LD + 52 * 4 + (size_t)2 * tsize * 4;
 }
 
 static size_t attn_mfma_fwd_smem(int tsize) {
@@ -856,17 +859,21 @@ extern "C" int miseg_winattn_bwd(const miseg_winattn_bwd_params* p, miseg_stream
   const int threads = cdiv(g.n, 64) * 64;
   if (p->f.dtype == MISEG_BF16 && g.hd == 16 && g.n <= ATT_NP && p->f.bias_table && ((uintptr_t)p->dqkv % 8 == 0) && p->lddq % 4 == 0 &&
       ((uintptr_t)p->f.qkv % 8 == 0) && p->f.ldq % 4 == 0) {
-    const size_t shm = attn_mfma_bwd_smem(tsize);
     const bool vec = p->f.ldq % 8 == 0 && p->f.ldo % 8 == 0 && p->lddo % 8 == 0 && (uintptr_t)p->f.qkv % 16 == 0 && (uintptr_t)p->f.out % 16 == 0 &&
                      (uintptr_t)p->dout % 16 == 0;
-#define BWD_MFMA(M, D)                                                                                                                                  \
-  hipFuncSetAttribute((const void*)winattn_bwd_mfma_kernel<M, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                               \
-  winattn_bwd_mfma_kernel<M, D><<<grid, 256, shm, s>>>((const bf16*)p->f.qkv, p->f.ldq, (const bf16*)p->f.out, p->f.ldo, (const bf16*)p->dout, p->lddo, \
-                                                       (bf16*)p->dqkv, p->lddq, p->f.qkv_bias, p->f.bias_table, p->f.lse, p->dqkv_bias, p->dbias_table, \
-                                                       g, tsize, vec)
+    // fewer workgroups than CUs (stages 3 and 4): the 8-wave form
+    const bool wide = (int64_t)grid.x * grid.y < 256;
+    const size_t shm = attn_mfma_bwd_smem(tsize, wide ? 8 : 4);
+#define BWD_MFMA(M, D, NWV)                                                                                                                                 \
+  hipFuncSetAttribute((const void*)winattn_bwd_mfma_kernel<M, D, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                              \
+  winattn_bwd_mfma_kernel<M, D, NWV><<<grid, NWV * 64, shm, s>>>((const bf16*)p->f.qkv, p->f.ldq, (const bf16*)p->f.out, p->f.ldo, (const bf16*)p->dout,    \
+                                                                 p->lddo, (bf16*)p->dqkv, p->lddq, p->f.qkv_bias, p->f.bias_table, p->f.lse, p->dqkv_bias, \
+                                                                 p->dbias_table, g, tsize, vec)
+#define BWD_MFMA_W(M, D) do { if (wide) { BWD_MFMA(M, D, 8); } else { BWD_MFMA(M, D, 4); } } while (0)
     const bool masked = (g.sd | g.sh | g.sw) != 0;
-    if (p->dbias_table) { if (masked) { BWD_MFMA(true, true); } else { BWD_MFMA(false, true); } }
-    else { if (masked) { BWD_MFMA(true, false); } else { BWD_MFMA(false, false); } }
+    if (p->dbias_table) { if (masked) BWD_MFMA_W(true, true); else BWD_MFMA_W(false, true); }
+    else { if (masked) BWD_MFMA_W(true, false); else BWD_MFMA_W(false, false); }
+#undef BWD_MFMA_W
 #undef BWD_MFMA
     MISEG_LAUNCH_CHECK("winattn_bwd_mfma");
     return MISEG_OK;
