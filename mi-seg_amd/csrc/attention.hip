@@ -360,8 +360,10 @@ __device__ __forceinline__ void att_load16v(const bf16* p, bool vec, float* dst)
   }
 }
 
-template <bool MASK>
-__global__ void __launch_bounds__(256) winattn_fwd_mfma_kernel(const bf16* __restrict__ qkv, int64_t ldq, bf16* __restrict__ out, int64_t ldo,
+// NW = waves per workgroup; a wave owns whole 32-query tiles (11 of them for a 7^3 window).  4 for the large grids, 11 - one tile per
+// wave - when the launch has fewer workgroups than CUs (stages 3 and 4) and lasts exactly as long as one workgroup.
+template <bool MASK, int NW = 4>
+__global__ void __launch_bounds__(NW * 64) winattn_fwd_mfma_kernel(const bf16* __restrict__ qkv, int64_t ldq, bf16* __restrict__ out, int64_t ldo,
                                                                const float* __restrict__ qkv_bias, const float* __restrict__ bias_table,
                                                                float* __restrict__ lse_out, WinGeom g, int tsize, bool vec) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -374,7 +376,7 @@ __global__ void __launch_bounds__(256) winattn_fwd_mfma_kernel(const bf16* __res
   float* table = reinterpret_cast<float*>(rowq + ATT_NP);   // [tsize] * log2e
   const int win = blockIdx.x, head = blockIdx.y, tid = threadIdx.x;
   const int n = g.n, C = g.C, ntiles = (n + 31) / 32;
-  for (int t = tid; t < ntiles * 32; t += 256) {
+  for (int t = tid; t < ntiles * 32; t += NW * 64) {
     int row = -1, label = 0, code = 0;
     float q[16], k[16], v[16];
 #pragma unroll
@@ -404,14 +406,14 @@ __global__ void __launch_bounds__(256) winattn_fwd_mfma_kernel(const bf16* __res
     klab[t] = label;
     rowq[t] = row;
   }
-  for (int i = tid; i < tsize; i += 256) table[i] = bias_table[(int64_t)i * g.heads + head] * ATT_LOG2E;
+  for (int i = tid; i < tsize; i += NW * 64) table[i] = bias_table[(int64_t)i * g.heads + head] * ATT_LOG2E;
   __syncthreads();
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
   const int tb = 2 * g.tw - 1;
   const int centre = ((g.tw - 1) * tb + (g.tw - 1)) * tb + (g.tw - 1);
   const bool ragged = (n & 31) != 0;
   constexpr float MASKV = -100.f * ATT_LOG2E;
-  for (int qt = wave; qt < ntiles; qt += 4) {
+  for (int qt = wave; qt < ntiles; qt += NW) {
     const int qi = qt * 32 + r;
     const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + qi * 16 + 8 * h);
     const char* tq = reinterpret_cast<const char*>(table) + kofs[qi] + 4 * centre;   // table[code_q + centre - code_k]
@@ -825,13 +827,14 @@ extern "C" int miseg_winattn_fwd(const miseg_winattn_params* p, miseg_stream_t s
   if (p->dtype == MISEG_BF16 && g.hd == 16 && g.n <= ATT_NP && p->bias_table && ((uintptr_t)p->out % 8 == 0) && p->ldo % 4 == 0) {
     const size_t shm = attn_mfma_fwd_smem(tsize);
     const bool vec = p->ldq % 8 == 0 && (uintptr_t)p->qkv % 16 == 0;
-    if ((g.sd | g.sh | g.sw) != 0) {
-      hipFuncSetAttribute((const void*)winattn_fwd_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-      winattn_fwd_mfma_kernel<true><<<grid, 256, shm, s>>>((const bf16*)p->qkv, p->ldq, (bf16*)p->out, p->ldo, p->qkv_bias, p->bias_table, p->lse, g, tsize, vec);
-    } else {
-      hipFuncSetAttribute((const void*)winattn_fwd_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-      winattn_fwd_mfma_kernel<false><<<grid, 256, shm, s>>>((const bf16*)p->qkv, p->ldq, (bf16*)p->out, p->ldo, p->qkv_bias, p->bias_table, p->lse, g, tsize, vec);
-    }
+    const bool wide = (int64_t)grid.x * grid.y < 256;       // fewer workgroups than CUs: one query tile per wave
+#define FWD_MFMA(M, NWV)                                                                                                                       \
+  hipFuncSetAttribute((const void*)winattn_fwd_mfma_kernel<M, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                    \
+  winattn_fwd_mfma_kernel<M, NWV><<<grid, NWV * 64, shm, s>>>((const bf16*)p->qkv, p->ldq, (bf16*)p->out, p->ldo, p->qkv_bias, p->bias_table, \
+                                                              p->lse, g, tsize, vec)
+    if ((g.sd | g.sh | g.sw) != 0) { if (wide) { FWD_MFMA(true, 11); } else { FWD_MFMA(true, 4); } }
+    else { if (wide) { FWD_MFMA(false, 11); } else { FWD_MFMA(false, 4); } }
+#undef FWD_MFMA
     MISEG_LAUNCH_CHECK("winattn_fwd_mfma");
     return MISEG_OK;
   }
