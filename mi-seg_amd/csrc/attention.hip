@@ -360,8 +360,9 @@ __device__ __forceinline__ void att_load16v(const bf16* p, bool vec, float* dst)
   }
 }
 
-// NW = waves per workgroup; a wave owns whole 32-query tiles (11 of them for a 7^3 window).  4 for the large grids, 11 - one tile per
-// wave - when the launch has fewer workgroups than CUs (stages 3 and 4) and lasts exactly as long as one workgroup.
+// NW = waves per workgroup; a wave owns whole 32-query tiles (11 of them for a 7^3 window).  8 for the large grids (measured: 4 -> 8
+// +0.7 % on the step, 11 no better), 11 - one tile per wave - when the launch has fewer workgroups than CUs (stages 3 and 4) and lasts
+// exactly as long as one workgroup.
 template <bool MASK, int NW = 4>
 __global__ void __launch_bounds__(NW * 64) winattn_fwd_mfma_kernel(const bf16* __restrict__ qkv, int64_t ldq, bf16* __restrict__ out, int64_t ldo,
                                                                const float* __restrict__ qkv_bias, const float* __restrict__ bias_table,
@@ -534,10 +535,11 @@ __device__ __forceinline__ void att_load16(const bf16* p, bool vec, float* dst) 
   }
 }
 
-// NW = waves per workgroup (key tiles are dealt to the waves: 24 / NW each).  4 for the large grids (two workgroups per CU); 8 for the
-// deep stages, whose launch is ONE round of < 256 workgroups: the launch lasts as long as one workgroup, which the extra waves halve.
+// NW = waves per workgroup (key tiles are dealt to the waves: 24 / NW each).  8 everywhere: two such workgroups still fit a CU (2 x 81 KB
+// LDS, 118 VGPRs); at the deep stages the launch is ONE round of < 256 workgroups and lasts as long as one workgroup, which the extra
+// waves halve (+1.2 % on the step), the large grids gain another 0.7 %.
 template <bool MASK, bool DT /* rel-pos table gradient wanted: no per-element branch around its atomics */, int NW = 4>
-__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) winattn_bwd_mfma_kernel(const bf16* __restrict__ qkv, int64_t ldq, const bf16* __restrict__ out, int64_t ldo,
+__global__ void __launch_bounds__(NW * 64, 2) winattn_bwd_mfma_kernel(const bf16* __restrict__ qkv, int64_t ldq, const bf16* __restrict__ out, int64_t ldo,
                                                                   const bf16* __restrict__ dout, int64_t lddo, bf16* __restrict__ dqkv, int64_t lddq,
                                                                   const float* __restrict__ qkv_bias, const float* __restrict__ bias_table,
                                                                   const float* __restrict__ lse_in, float* __restrict__ dqkv_bias,
@@ -832,8 +834,8 @@ extern "C" int miseg_winattn_fwd(const miseg_winattn_params* p, miseg_stream_t s
   hipFuncSetAttribute((const void*)winattn_fwd_mfma_kernel<M, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                    \
   winattn_fwd_mfma_kernel<M, NWV><<<grid, NWV * 64, shm, s>>>((const bf16*)p->qkv, p->ldq, (bf16*)p->out, p->ldo, p->qkv_bias, p->bias_table, \
                                                               p->lse, g, tsize, vec)
-    if ((g.sd | g.sh | g.sw) != 0) { if (wide) { FWD_MFMA(true, 11); } else { FWD_MFMA(true, 4); } }
-    else { if (wide) { FWD_MFMA(false, 11); } else { FWD_MFMA(false, 4); } }
+    if ((g.sd | g.sh | g.sw) != 0) { if (wide) { FWD_MFMA(true, 11); } else { FWD_MFMA(true, 8); } }
+    else { if (wide) { FWD_MFMA(false, 11); } else { FWD_MFMA(false, 8); } }
 #undef FWD_MFMA
     MISEG_LAUNCH_CHECK("winattn_fwd_mfma");
     return MISEG_OK;
@@ -865,7 +867,7 @@ extern "C" int miseg_winattn_bwd(const miseg_winattn_bwd_params* p, miseg_stream
     const bool vec = p->f.ldq % 8 == 0 && p->f.ldo % 8 == 0 && p->lddo % 8 == 0 && (uintptr_t)p->f.qkv % 16 == 0 && (uintptr_t)p->f.out % 16 == 0 &&
                      (uintptr_t)p->dout % 16 == 0;
     // fewer workgroups than CUs (stages 3 and 4): the 8-wave form
-    const bool wide = (int64_t)grid.x * grid.y < 256;
+    const bool wide = true;       // 8 waves everywhere: two such workgroups still fit a CU (2 x 81 KB LDS, 118 VGPRs) and every stage gains
     const size_t shm = attn_mfma_bwd_smem(tsize, wide ? 8 : 4);
 #define BWD_MFMA(M, D, NWV)                                                                                                                                 \
   hipFuncSetAttribute((const void*)winattn_bwd_mfma_kernel<M, D, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                              \
