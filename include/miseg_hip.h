@@ -67,6 +67,10 @@ typedef struct {
   const int32_t* styles; int num_styles;
   const float* gamma[MISEG_MAX_STYLES]; const float* beta[MISEG_MAX_STYLES];
   int act; float slope;            /* MISEG_ACT_NONE | MISEG_ACT_LEAKY */
+  /* optional: `res` is the raw input of a second instance norm (the block's shortcut branch, dynunet_block.py:118-124) and is normalised
+   * on the fly with its own statistics (res_stat, layout as stat) and affine rows: y = act(norm(x) + norm_res(res)).  miseg_instnorm_apply only. */
+  const void* res_stat;
+  const float* res_gamma[MISEG_MAX_STYLES]; const float* res_beta[MISEG_MAX_STYLES];
 } miseg_instnorm_apply_params;
 int miseg_instnorm_apply(const miseg_instnorm_apply_params* p, miseg_stream_t stream);
 /* statistics (into the zero-filled p->stat) + apply in one call; tensors of <= 512 rows per sample take ONE fused launch */

@@ -156,12 +156,16 @@ template <class T, int VEC>
 __global__ void __launch_bounds__(NORM_THREADS) instnorm_apply_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ res, int64_t ldres,
                                                                       T* __restrict__ y, int64_t ldy, int S, int C, int cv, int tx_n, int ty_n, int rpb,
                                                                       const double* __restrict__ stat, float eps, const int32_t* __restrict__ styles,
-                                                                      StylePtrs sp, int act, float slope) {
+                                                                      StylePtrs sp, int act, float slope, const double* __restrict__ rstat, StylePtrs rsp) {
+  // rstat != nullptr: `res` is the RAW input of a second (shortcut) instance norm with its own statistics / affine rows and is
+  // normalised on the fly: y = act(norm(x) + norm_r(res)) in one pass (UnetResBlock with a 1x1x1 shortcut conv, dynunet_block.py:118-124)
   extern __shared__ __attribute__((aligned(16))) double sums[];
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
   const int c = blockIdx.z * tx_n + tx;
+  double* rsums = sums + 2 * tx_n * VEC;
   gather_stat(sums, stat, (int64_t)gridDim.y * C * 2, b, C, blockIdx.z * tx_n * VEC, tx_n * VEC);
+  if (rstat) gather_stat(rsums, rstat, (int64_t)gridDim.y * C * 2, b, C, blockIdx.z * tx_n * VEC, tx_n * VEC);
   if (ty >= ty_n || c >= cv) return;
   const int r0 = chunk * rpb, r1 = min(S, r0 + rpb);
   const int st = styles ? styles[b] : 0;
@@ -179,6 +183,21 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_apply_kernel(const T* _
     sc[i] = rs * gg;
     sh[i] = bb - m * sc[i];
   }
+  float rsc[VEC], rsh[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { rsc[i] = 1.f; rsh[i] = 0.f; }
+  if (rstat) {
+    const float* rg = rsp.gamma[st];
+    const float* rb = rsp.beta[st];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const int ch = c * VEC + i;
+      float m, rs;
+      mean_rstd(rsums + (tx * VEC + i) * 2, invS, eps, m, rs);
+      rsc[i] = rs * (rg ? rg[ch] : 1.f);
+      rsh[i] = (rb ? rb[ch] : 0.f) - m * rsc[i];
+    }
+  }
 #pragma unroll 4
   for (int r = r0 + ty; r < r1; r += ty_n) {
     RowVec<T, VEC> v, o;
@@ -189,7 +208,7 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_apply_kernel(const T* _
       RowVec<T, VEC> rr;
       rr.load(res + (boff + r) * ldres + c * VEC);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) o.v[i] += rr.v[i];
+      for (int i = 0; i < VEC; ++i) o.v[i] += fmaf(rr.v[i], rsc[i], rsh[i]);
     }
     if (act == MISEG_ACT_LEAKY) {
 #pragma unroll
@@ -640,6 +659,7 @@ extern "C" int miseg_instnorm_apply(const miseg_instnorm_apply_params* p, miseg_
   MISEG_REQUIRE(p && p->x && p->y && p->stat, MISEG_E_BADARG, "instnorm_apply: null pointer");
   MISEG_REQUIRE(p->num_styles >= 1 && p->num_styles <= MISEG_MAX_STYLES, MISEG_E_BADARG, "instnorm_apply: num_styles %d", p->num_styles);
   MISEG_REQUIRE(p->act == MISEG_ACT_NONE || p->act == MISEG_ACT_LEAKY, MISEG_E_UNSUPPORTED, "instnorm_apply: act %d", p->act);
+  MISEG_REQUIRE(!p->res_stat || p->res, MISEG_E_BADARG, "instnorm_apply: res_stat without res");
   return dispatch_dtype(p->dtype, [&](auto* tag) -> int {
     typedef typename std::remove_pointer<decltype(tag)>::type T;
     constexpr int V = Vec16<T>::N;
@@ -648,14 +668,21 @@ extern "C" int miseg_instnorm_apply(const miseg_instnorm_apply_params* p, miseg_
     NormGeom g = norm_geom(p->S, p->C, al, V);
     StylePtrs sp;
     for (int s = 0; s < MISEG_MAX_STYLES; ++s) { sp.gamma[s] = s < p->num_styles ? p->gamma[s] : nullptr; sp.beta[s] = s < p->num_styles ? p->beta[s] : nullptr; }
+    StylePtrs rsp;
+    for (int s = 0; s < MISEG_MAX_STYLES; ++s) {
+      rsp.gamma[s] = (p->res_stat && s < p->num_styles) ? p->res_gamma[s] : nullptr;
+      rsp.beta[s] = (p->res_stat && s < p->num_styles) ? p->res_beta[s] : nullptr;
+    }
     dim3 grid(g.chunks, p->B, g.ctiles);
-    const size_t shd = (size_t)2 * g.tx * g.vec * sizeof(double);
+    const size_t shd = (size_t)4 * g.tx * g.vec * sizeof(double);
     if (g.vec == 1)
       instnorm_apply_kernel<T, 1><<<grid, NORM_THREADS, shd, stream>>>((const T*)p->x, p->ldx, (const T*)p->res, p->ldres, (T*)p->y, p->ldy, p->S, p->C, g.cv, g.tx,
-                                                                      g.ty, g.rpb, (const double*)p->stat, p->eps, p->styles, sp, p->act, p->slope);
+                                                                      g.ty, g.rpb, (const double*)p->stat, p->eps, p->styles, sp, p->act, p->slope,
+                                                                      (const double*)p->res_stat, rsp);
     else
       instnorm_apply_kernel<T, V><<<grid, NORM_THREADS, shd, stream>>>((const T*)p->x, p->ldx, (const T*)p->res, p->ldres, (T*)p->y, p->ldy, p->S, p->C, g.cv, g.tx,
-                                                                      g.ty, g.rpb, (const double*)p->stat, p->eps, p->styles, sp, p->act, p->slope);
+                                                                      g.ty, g.rpb, (const double*)p->stat, p->eps, p->styles, sp, p->act, p->slope,
+                                                                      (const double*)p->res_stat, rsp);
     MISEG_LAUNCH_CHECK("instnorm_apply");
     return MISEG_OK;
   });
@@ -667,6 +694,7 @@ static constexpr int NORM_FUSED_MAX_ROWS = 512;    // 1728 rows x 384 channels: 
 extern "C" int miseg_instnorm_fwd(const miseg_instnorm_apply_params* p, miseg_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   MISEG_REQUIRE(p && p->x && p->y && p->stat, MISEG_E_BADARG, "instnorm_fwd: null pointer");
+  MISEG_REQUIRE(!p->res_stat, MISEG_E_UNSUPPORTED, "instnorm_fwd: res_stat (shortcut norm on the fly) is a miseg_instnorm_apply feature");
   if (p->S > NORM_FUSED_MAX_ROWS) {
     miseg_instnorm_stats_params sp_{p->x, p->ldx, p->B, p->S, p->C, p->dtype, const_cast<void*>(p->stat)};
     const int rc = miseg_instnorm_stats(&sp_, stream_);

@@ -141,6 +141,79 @@ class _InstNorm(Function):
         return (dx, dres, None, None, None, None, None, None, None, None, None, *pg)
 
 
+class _ResNormPair(Function):
+    """y = LeakyReLU(norm_a(xa) + norm_b(xb)): the tail of a UnetResBlock with a 1x1x1 shortcut conv (dynunet_block.py:118-124) in ONE
+    apply pass - the shortcut branch is normalised on the fly instead of being written and read back.  Backward: the two ordinary
+    instance-norm backward passes (the first hands the activation-masked gradient to the second)."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, styles_dev, styles_host, num_styles, affine, slope, eps_a, eps_b, stat_a, *params):
+        B = xa.shape[0]
+        S = ops.rows(xa)[1] // B
+        global _PENDING_OUT
+        out, _PENDING_OUT = _PENDING_OUT, None
+        na = 2 * num_styles if affine else 0
+        pa, pb = params[:na], params[na:]
+        ga, ba = (list(pa[0::2]), list(pa[1::2])) if affine else (None, None)
+        gb, bb = (list(pb[0::2]), list(pb[1::2])) if affine else (None, None)
+        if eps_a != eps_b:
+            raise ValueError("the two norms of a residual pair must share eps")
+        sa = stat_a if stat_a is not None else ops.instnorm_stats(xa, B, S)
+        sb = ops.instnorm_stats(xb, B, S)
+        y = ops.instnorm_apply(xa, B, S, sa, styles_dev, ga, ba, res=xb, act=L.ACT_LEAKY, slope=slope, eps=eps_a, out=out, res_stat=sb,
+                               res_gammas=gb, res_betas=bb)
+        ctx.meta = (B, S, styles_host, num_styles, affine, slope, eps_a)
+        ctx.params = params
+        ctx.save_for_backward(xa, xb, y, sa, sb, styles_dev, *(ga or []), *(gb or []))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, S, styles_host, num_styles, affine, slope, eps = ctx.meta
+        xa, xb, y, sa, sb, styles_dev, *gg = ctx.saved_tensors
+        ga, gb = (gg[:num_styles], gg[num_styles:]) if affine else (None, None)
+        dy = _rv(dy)
+        C = xa.shape[-1]
+        present = sorted(set(styles_host)) if styles_host is not None else [0]
+        na = 2 * num_styles if affine else 0
+        pa, pb = ctx.params[:na], ctx.params[na:]
+
+        def grads(ps):
+            if not affine:
+                return None, None, False, None
+            in_arena = getattr(ps[0], "_miseg_grad", None) is not None
+            if in_arena:
+                return ([_slot(ps[2 * s]) if s in present else None for s in range(num_styles)],
+                        [_slot(ps[2 * s + 1]) if s in present else None for s in range(num_styles)], True, None)
+            buf = ops.zeros_f32((num_styles, 2, C), xa.device)
+            return ([buf[s, 0] if s in present else None for s in range(num_styles)],
+                    [buf[s, 1] if s in present else None for s in range(num_styles)], False, buf)
+
+        dga, dba, arena_a, _ = grads(pa)
+        dgb, dbb, arena_b, _ = grads(pb)
+        dxa, dres = ops.instnorm_bwd(dy, y, xa, B, S, sa, styles_dev, ga, dga, dba, act=L.ACT_LEAKY, slope=slope, eps=eps, want_dres=True)
+        dxb, _ = ops.instnorm_bwd(dres, None, xb, B, S, sb, styles_dev, gb, dgb, dbb, act=L.ACT_NONE, eps=eps)
+        pg = []
+        if affine:
+            for dg_, db_, ar in ((dga, dba, arena_a), (dgb, dbb, arena_b)):
+                for s in range(num_styles):
+                    pg += [None, None] if ar else [dg_[s], db_[s]]
+        return (dxa, dxb, None, None, None, None, None, None, None, None, *pg)
+
+
+def res_norm_pair(xa, xb, params_a, params_b, styles_dev=None, styles_host=None, slope=0.01, eps_a=1e-5, eps_b=1e-5, stat_a=None, out=None):
+    """LeakyReLU(norm_a(xa) + norm_b(xb)); params_*: None (both affine-less) or lists of (gamma, beta) pairs, one per style."""
+    global _PENDING_OUT
+    flat, n = [], 1
+    if params_a is not None:
+        n = len(params_a)
+        for ps in (params_a, params_b):
+            for g, b in ps:
+                flat += [g, b]
+    _PENDING_OUT = out
+    return _ResNormPair.apply(xa, xb, styles_dev, styles_host, n, params_a is not None, slope, eps_a, eps_b, stat_a, *flat)
+
+
 def instance_norm(x, params=None, styles_dev=None, styles_host=None, res=None, act=L.ACT_NONE, slope=0.01, eps=1e-5, fork=False, stat=None, out=None):
     """params: None (no affine) | [(gamma, beta)] (plain) | [(g0,b0),(g1,b1),...] (conditional, one pair per style).
     fork=True returns (norm(x), x): see _InstNorm.forward."""

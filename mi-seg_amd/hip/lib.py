@@ -28,7 +28,7 @@ InstnormStats = _struct("InstnormStats", [("x", vp), ("ldx", i64), ("B", i32), (
 InstnormApply = _struct("InstnormApply", [("x", vp), ("ldx", i64), ("res", vp), ("ldres", i64), ("y", vp), ("ldy", i64),
                                           ("B", i32), ("S", i32), ("C", i32), ("dtype", i32), ("stat", vp), ("eps", f32),
                                           ("styles", vp), ("num_styles", i32), ("gamma", fp4), ("beta", fp4),
-                                          ("act", i32), ("slope", f32)])
+                                          ("act", i32), ("slope", f32), ("res_stat", vp), ("res_gamma", fp4), ("res_beta", fp4)])
 InstnormBwd = _struct("InstnormBwd", [("dy", vp), ("lddy", i64), ("y", vp), ("ldy", i64), ("x", vp), ("ldx", i64),
                                       ("dx", vp), ("lddx", i64), ("dres", vp), ("lddres", i64),
                                       ("B", i32), ("S", i32), ("C", i32), ("dtype", i32), ("stat", vp), ("eps", f32), ("dstat", vp),

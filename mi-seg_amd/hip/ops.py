@@ -123,7 +123,9 @@ def _style_arrays(tensors, n):
     return arr
 
 
-def instnorm_apply(x, B, S, stat, styles, gammas, betas, res=None, act=L.ACT_NONE, slope=0.01, eps=1e-5, out=None):
+def instnorm_apply(x, B, S, stat, styles, gammas, betas, res=None, act=L.ACT_NONE, slope=0.01, eps=1e-5, out=None, res_stat=None,
+                   res_gammas=None, res_betas=None):
+    """res_stat: `res` is the RAW input of a second instance norm (statistics res_stat, affine rows res_gammas / res_betas) applied on the fly."""
     ld, n, Cc = rows(x)
     y = out if out is not None else torch.empty(x.shape, dtype=x.dtype, device=x.device)
     ldy, ny, Cy = rows(y)
@@ -131,7 +133,8 @@ def instnorm_apply(x, B, S, stat, styles, gammas, betas, res=None, act=L.ACT_NON
     ldr = rows(res)[0] if res is not None else 0
     ns = len(gammas) if gammas is not None else 1
     p = L.InstnormApply(_ptr(x), ld, _ptr(res), ldr, _ptr(y), ldy, B, S, Cc, _dt(x), _ptr(stat), eps, _ptr(styles), ns,
-                        _style_arrays(gammas, ns), _style_arrays(betas, ns), act, slope)
+                        _style_arrays(gammas, ns), _style_arrays(betas, ns), act, slope, _ptr(res_stat), _style_arrays(res_gammas, ns),
+                        _style_arrays(res_betas, ns))
     _call("miseg_instnorm_apply", p)
     return y
 

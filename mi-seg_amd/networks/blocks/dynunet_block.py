@@ -13,7 +13,7 @@ import torch.nn as nn
 from ...hip import functional as HF
 from ...hip import lib as L
 from ...hip import ops
-from ..layers.utils import apply_norm, get_norm_layer
+from ..layers.utils import apply_norm, apply_res_norm_pair, get_norm_layer
 from ..norms.conditional_instance_norm import _ConditionalInstanceNorm
 
 LEAKY_SLOPE = 0.01
@@ -108,6 +108,9 @@ class UnetResBlock(nn.Module):
         out, st2 = HF.conv3(out, self.conv2.conv.weight, want_stat=True)
         if self.downsample:
             residual = HF.conv1(residual, self.conv3.conv.weight)
+            y = apply_res_norm_pair(self.norm2, out, self.norm3, residual, styles, slope=LEAKY_SLOPE, stat_a=st2, out=out_view)
+            if y is not None:           # the shortcut's norm rides in the final apply pass
+                return y
             residual = apply_norm(self.norm3, residual, styles)
         return apply_norm(self.norm2, out, styles, res=residual, act=L.ACT_LEAKY, slope=LEAKY_SLOPE, stat=st2, out=out_view)
 

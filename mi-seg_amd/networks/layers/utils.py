@@ -57,6 +57,26 @@ def apply_norm_fork(norm: nn.Module, x, styles=None):
     return apply_norm(norm, xa, styles), xs
 
 
+def apply_res_norm_pair(norm_a: nn.Module, xa, norm_b: nn.Module, xb, styles=None, slope=0.01, stat_a=None, out=None):
+    """LeakyReLU(norm_a(xa) + norm_b(xb)) in one apply pass (HF.res_norm_pair) where both norms are instance norms of the same kind and
+    the tensors have more than 512 rows per sample (below that the single-launch fused norms win); None where that does not apply."""
+    rows_per_sample = xa.numel() // (xa.shape[0] * xa.shape[-1])
+    if rows_per_sample <= 512 or xa.shape != xb.shape:
+        return None
+    if isinstance(norm_a, _ConditionalInstanceNorm) and isinstance(norm_b, _ConditionalInstanceNorm):
+        if styles is None:
+            raise ValueError("Modalities must be passed to the forward step when encoder_norm_type is 'instance_cond'.")
+        if norm_a.num_styles != norm_b.num_styles:
+            return None
+        return HF.res_norm_pair(xa, xb, norm_a.style_params(), norm_b.style_params(), styles[0], styles[1], slope=slope, eps_a=norm_a.eps,
+                                eps_b=norm_b.eps, stat_a=stat_a, out=out)
+    if isinstance(norm_a, _INSTANCE) and isinstance(norm_b, _INSTANCE) and norm_a.affine == norm_b.affine and norm_a.eps == norm_b.eps:
+        pa = [(norm_a.weight, norm_a.bias)] if norm_a.affine else None
+        pb = [(norm_b.weight, norm_b.bias)] if norm_b.affine else None
+        return HF.res_norm_pair(xa, xb, pa, pb, None, None, slope=slope, eps_a=norm_a.eps, eps_b=norm_b.eps, stat_a=stat_a, out=out)
+    return None
+
+
 def apply_norm(norm: nn.Module, x, styles=None, res=None, act=L.ACT_NONE, slope=0.01, stat=None, out=None):
     """Apply a norm *module* (used as a parameter container) to a channels-last tensor through the HIP kernels.
     ``styles`` is the (device int32 tensor, host tuple) pair from styles_to_device; ``stat``: instance-norm statistics of x that the
