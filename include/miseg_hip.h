@@ -99,6 +99,23 @@ typedef struct {
 } miseg_instnorm_bwd_params;
 int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stream_t stream);
 
+/* Backward of y = LeakyReLU(norm_a(xa) + norm_b(xb)) (miseg_instnorm_apply with res_stat; dynunet_block.py:118-126): one reduction and one
+ * apply pass for both norms.  dstat_a / dstat_b: scratch like miseg_instnorm_bwd's dstat (zero on entry); dgamma / dbeta accumulate. */
+typedef struct {
+  const void* dy; int64_t lddy;
+  const void* y; int64_t ldy;
+  const void* xa; int64_t ldxa; const void* xb; int64_t ldxb;
+  void* dxa; int64_t lddxa; void* dxb; int64_t lddxb;
+  int B, S, C, dtype;
+  const void* stat_a; const void* stat_b; float eps; void* dstat_a; void* dstat_b;
+  const int32_t* styles; int num_styles;
+  const float* gamma_a[MISEG_MAX_STYLES]; const float* gamma_b[MISEG_MAX_STYLES];
+  float* dgamma_a[MISEG_MAX_STYLES]; float* dbeta_a[MISEG_MAX_STYLES];
+  float* dgamma_b[MISEG_MAX_STYLES]; float* dbeta_b[MISEG_MAX_STYLES];
+  float slope;
+} miseg_instnorm_pair_bwd_params;
+int miseg_instnorm_pair_bwd(const miseg_instnorm_pair_bwd_params* p, miseg_stream_t stream);
+
 /* LayerNorm over the channel dim of channels-last rows (vit_norm_name="layer", the reference default:
  * networks/blocks/swin_transformer_block.py:104-105, transformer_block.py:82-83).  gamma/beta may be NULL. */
 typedef struct {

@@ -385,6 +385,125 @@ __device__ __forceinline__ void team_totals(float* red, double* tot, const float
   __syncthreads();
 }
 
+// ---- backward of y = LeakyReLU(norm_a(xa) + norm_b(xb)) (instnorm_apply_kernel with rstat): both norms see the same activation-
+// masked gradient g, so ONE reduction pass yields sum g, sum g*xhat_a, sum g*xhat_b and ONE apply pass writes both input gradients
+// (10 passes over the tensor instead of the 13 of two chained norm backwards, no `dres` tensor, two launches instead of four).
+template <class T, int VEC>
+__global__ void __launch_bounds__(NORM_THREADS) instnorm_pair_bwd_reduce_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ yact, int64_t ldy,
+                                                                                const T* __restrict__ xa, int64_t ldxa, const T* __restrict__ xb, int64_t ldxb,
+                                                                                int S, int C, int cv, int tx_n, int ty_n, int rpb,
+                                                                                const double* __restrict__ stat_a, const double* __restrict__ stat_b, float eps,
+                                                                                float slope, double* __restrict__ dstat_a, double* __restrict__ dstat_b) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  double* sums_a = reinterpret_cast<double*>(red);   // prologue only; the reductions reuse the space after a barrier
+  double* sums_b = sums_a + 2 * tx_n * VEC;
+  const int b = blockIdx.y, chunk = blockIdx.x, c0 = blockIdx.z * tx_n;
+  const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
+  const int r0 = chunk * rpb, r1 = min(S, r0 + rpb);
+  const int64_t boff = (int64_t)b * S;
+  const int c = c0 + tx;
+  gather_stat(sums_a, stat_a, (int64_t)gridDim.y * C * 2, b, C, c0 * VEC, tx_n * VEC);
+  gather_stat(sums_b, stat_b, (int64_t)gridDim.y * C * 2, b, C, c0 * VEC, tx_n * VEC);
+  float s[VEC], qa[VEC], qb[VEC], ma[VEC], rsa[VEC], mb[VEC], rsb[VEC];
+  const double invS = 1.0 / S;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    s[i] = qa[i] = qb[i] = 0.f;
+    mean_rstd(sums_a + (tx * VEC + i) * 2, invS, eps, ma[i], rsa[i]);
+    mean_rstd(sums_b + (tx * VEC + i) * 2, invS, eps, mb[i], rsb[i]);
+  }
+  __syncthreads();
+  if (ty < ty_n && c < cv) {
+#pragma unroll 4
+    for (int r = r0 + ty; r < r1; r += ty_n) {
+      RowVec<T, VEC> g, yv, va, vb;
+      g.load(dy + (boff + r) * lddy + c * VEC);
+      yv.load(yact + (boff + r) * ldy + c * VEC);
+      va.load(xa + (boff + r) * ldxa + c * VEC);
+      vb.load(xb + (boff + r) * ldxb + c * VEC);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float gi = yv.v[i] > 0.f ? g.v[i] : g.v[i] * slope;
+        s[i] += gi;
+        qa[i] = fmaf(gi, (va.v[i] - ma[i]) * rsa[i], qa[i]);
+        qb[i] = fmaf(gi, (vb.v[i] - mb[i]) * rsb[i], qb[i]);
+      }
+    }
+  }
+  block_reduce_to_stat<VEC>(red, s, qa, tx, ty, tx_n, ty_n, c0, C, dstat_a + ((int64_t)(chunk % NORM_R) * gridDim.y + b) * C * 2);
+  __syncthreads();
+  block_reduce_to_stat<VEC>(red, s, qb, tx, ty, tx_n, ty_n, c0, C, dstat_b + ((int64_t)(chunk % NORM_R) * gridDim.y + b) * C * 2);
+}
+
+template <class T, int VEC>
+__global__ void __launch_bounds__(NORM_THREADS) instnorm_pair_bwd_apply_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ yact, int64_t ldy,
+                                                                               const T* __restrict__ xa, int64_t ldxa, const T* __restrict__ xb, int64_t ldxb,
+                                                                               T* __restrict__ dxa, int64_t lddxa, T* __restrict__ dxb, int64_t lddxb, int S, int C,
+                                                                               int cv, int tx_n, int ty_n, int rpb, const double* __restrict__ stat_a,
+                                                                               const double* __restrict__ stat_b, float eps, const int32_t* __restrict__ styles,
+                                                                               StylePtrs spa, StylePtrs spb, float slope, const double* __restrict__ dstat_a,
+                                                                               const double* __restrict__ dstat_b, StyleGradPtrs gpa, StyleGradPtrs gpb) {
+  extern __shared__ __attribute__((aligned(16))) double sums[];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
+  const int c = blockIdx.z * tx_n + tx;
+  const int nc = 2 * tx_n * VEC;
+  double* sa = sums;
+  double* sb = sums + nc;
+  double* da = sums + 2 * nc;
+  double* db = sums + 3 * nc;
+  gather_stat(sa, stat_a, (int64_t)gridDim.y * C * 2, b, C, blockIdx.z * tx_n * VEC, tx_n * VEC);
+  gather_stat(sb, stat_b, (int64_t)gridDim.y * C * 2, b, C, blockIdx.z * tx_n * VEC, tx_n * VEC);
+  gather_stat(da, dstat_a, (int64_t)gridDim.y * C * 2, b, C, blockIdx.z * tx_n * VEC, tx_n * VEC);
+  gather_stat(db, dstat_b, (int64_t)gridDim.y * C * 2, b, C, blockIdx.z * tx_n * VEC, tx_n * VEC);
+  const int st = styles ? styles[b] : 0;
+  if (chunk == 0) {   // the affine gradients of this (sample, channel tile), both norms
+    for (int e = threadIdx.x; e < tx_n * VEC; e += NORM_THREADS) {
+      const int ch = blockIdx.z * tx_n * VEC + e;
+      if (ch < C) {
+        if (gpa.dgamma[st]) atomicAdd(gpa.dgamma[st] + ch, (float)da[2 * e + 1]);
+        if (gpa.dbeta[st]) atomicAdd(gpa.dbeta[st] + ch, (float)da[2 * e]);
+        if (gpb.dgamma[st]) atomicAdd(gpb.dgamma[st] + ch, (float)db[2 * e + 1]);
+        if (gpb.dbeta[st]) atomicAdd(gpb.dbeta[st] + ch, (float)db[2 * e]);
+      }
+    }
+  }
+  if (ty >= ty_n || c >= cv) return;
+  const int r0 = chunk * rpb, r1 = min(S, r0 + rpb);
+  const float* ga = spa.gamma[st];
+  const float* gb = spb.gamma[st];
+  const int64_t boff = (int64_t)b * S;
+  const double invS = 1.0 / S;
+  float ma[VEC], rsa[VEC], sca[VEC], aa[VEC], bqa[VEC], mb[VEC], rsb[VEC], scb[VEC], bqb[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int ch = c * VEC + i;
+    mean_rstd(sa + (tx * VEC + i) * 2, invS, eps, ma[i], rsa[i]);
+    mean_rstd(sb + (tx * VEC + i) * 2, invS, eps, mb[i], rsb[i]);
+    sca[i] = rsa[i] * (ga ? ga[ch] : 1.f);
+    scb[i] = rsb[i] * (gb ? gb[ch] : 1.f);
+    aa[i] = (float)(da[(tx * VEC + i) * 2] * invS);          // mean of g: the same for both norms
+    bqa[i] = (float)(da[(tx * VEC + i) * 2 + 1] * invS);
+    bqb[i] = (float)(db[(tx * VEC + i) * 2 + 1] * invS);
+  }
+#pragma unroll 4
+  for (int r = r0 + ty; r < r1; r += ty_n) {
+    RowVec<T, VEC> g, yv, va, vb, oa, ob;
+    g.load(dy + (boff + r) * lddy + c * VEC);
+    yv.load(yact + (boff + r) * ldy + c * VEC);
+    va.load(xa + (boff + r) * ldxa + c * VEC);
+    vb.load(xb + (boff + r) * ldxb + c * VEC);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float gi = yv.v[i] > 0.f ? g.v[i] : g.v[i] * slope;
+      oa.v[i] = sca[i] * (gi - aa[i] - (va.v[i] - ma[i]) * rsa[i] * bqa[i]);
+      ob.v[i] = scb[i] * (gi - aa[i] - (vb.v[i] - mb[i]) * rsb[i] * bqb[i]);
+    }
+    oa.store(dxa + (boff + r) * lddxa + c * VEC);
+    ob.store(dxb + (boff + r) * lddxb + c * VEC);
+  }
+}
+
 template <class T, int VEC>
 __global__ void __launch_bounds__(NORM_THREADS) instnorm_fused_fwd_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ res, int64_t ldres,
                                                                           T* __restrict__ y, int64_t ldy, int S, int C, int cv, int tx_n, int ty_n,
@@ -775,6 +894,47 @@ extern "C" int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stre
     if (g.vec == 1) { BWD_LAUNCH(1) } else { BWD_LAUNCH(V) }
 #undef BWD_LAUNCH
     MISEG_LAUNCH_CHECK("instnorm_bwd");
+    return MISEG_OK;
+  });
+}
+
+extern "C" int miseg_instnorm_pair_bwd(const miseg_instnorm_pair_bwd_params* p, miseg_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  MISEG_REQUIRE(p && p->dy && p->y && p->xa && p->xb && p->dxa && p->dxb && p->stat_a && p->stat_b && p->dstat_a && p->dstat_b, MISEG_E_BADARG,
+                "instnorm_pair_bwd: null pointer");
+  MISEG_REQUIRE(p->num_styles >= 1 && p->num_styles <= MISEG_MAX_STYLES, MISEG_E_BADARG, "instnorm_pair_bwd: num_styles %d", p->num_styles);
+  return dispatch_dtype(p->dtype, [&](auto* tag) -> int {
+    typedef typename std::remove_pointer<decltype(tag)>::type T;
+    constexpr int V = Vec16<T>::N;
+    const int64_t ldor = p->lddy | p->ldy | p->ldxa | p->ldxb | p->lddxa | p->lddxb;
+    const bool al = aligned16(p->dy) && aligned16(p->y) && aligned16(p->xa) && aligned16(p->xb) && aligned16(p->dxa) && aligned16(p->dxb) && ldor % V == 0;
+    NormGeom g = norm_geom(p->S, p->C, al, V);
+    StylePtrs spa, spb;
+    StyleGradPtrs gpa, gpb;
+    for (int s = 0; s < MISEG_MAX_STYLES; ++s) {
+      const bool on = s < p->num_styles;
+      spa.gamma[s] = on ? p->gamma_a[s] : nullptr; spa.beta[s] = nullptr;
+      spb.gamma[s] = on ? p->gamma_b[s] : nullptr; spb.beta[s] = nullptr;
+      gpa.dgamma[s] = on ? p->dgamma_a[s] : nullptr; gpa.dbeta[s] = on ? p->dbeta_a[s] : nullptr;
+      gpb.dgamma[s] = on ? p->dgamma_b[s] : nullptr; gpb.dbeta[s] = on ? p->dbeta_b[s] : nullptr;
+    }
+    dim3 grid(g.chunks, p->B, g.ctiles);
+    size_t sh = (size_t)g.ty * 2 * g.tx * g.vec * sizeof(float);
+    if (sh < (size_t)4 * g.tx * g.vec * sizeof(double)) sh = (size_t)4 * g.tx * g.vec * sizeof(double);
+    const size_t shd = (size_t)8 * g.tx * g.vec * sizeof(double);
+#define PAIR_LAUNCH(VV)                                                                                                                                          \
+    instnorm_pair_bwd_reduce_kernel<T, VV><<<grid, NORM_THREADS, sh, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->xa, p->ldxa,         \
+                                                                               (const T*)p->xb, p->ldxb, p->S, p->C, g.cv, g.tx, g.ty, g.rpb,                    \
+                                                                               (const double*)p->stat_a, (const double*)p->stat_b, p->eps, p->slope,            \
+                                                                               (double*)p->dstat_a, (double*)p->dstat_b);                                       \
+    instnorm_pair_bwd_apply_kernel<T, VV><<<grid, NORM_THREADS, shd, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->xa, p->ldxa,         \
+                                                                               (const T*)p->xb, p->ldxb, (T*)p->dxa, p->lddxa, (T*)p->dxb, p->lddxb, p->S, p->C, \
+                                                                               g.cv, g.tx, g.ty, g.rpb, (const double*)p->stat_a, (const double*)p->stat_b,     \
+                                                                               p->eps, p->styles, spa, spb, p->slope, (const double*)p->dstat_a,               \
+                                                                               (const double*)p->dstat_b, gpa, gpb);
+    if (g.vec == 1) { PAIR_LAUNCH(1) } else { PAIR_LAUNCH(V) }
+#undef PAIR_LAUNCH
+    MISEG_LAUNCH_CHECK("instnorm_pair_bwd");
     return MISEG_OK;
   });
 }

@@ -191,8 +191,7 @@ class _ResNormPair(Function):
 
         dga, dba, arena_a, _ = grads(pa)
         dgb, dbb, arena_b, _ = grads(pb)
-        dxa, dres = ops.instnorm_bwd(dy, y, xa, B, S, sa, styles_dev, ga, dga, dba, act=L.ACT_LEAKY, slope=slope, eps=eps, want_dres=True)
-        dxb, _ = ops.instnorm_bwd(dres, None, xb, B, S, sb, styles_dev, gb, dgb, dbb, act=L.ACT_NONE, eps=eps)
+        dxa, dxb = ops.instnorm_pair_bwd(dy, y, xa, xb, B, S, sa, sb, styles_dev, ga, gb, dga, dba, dgb, dbb, slope=slope, eps=eps)
         pg = []
         if affine:
             for dg_, db_, ar in ((dga, dba, arena_a), (dgb, dbb, arena_b)):

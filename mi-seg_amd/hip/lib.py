@@ -34,6 +34,11 @@ InstnormBwd = _struct("InstnormBwd", [("dy", vp), ("lddy", i64), ("y", vp), ("ld
                                       ("B", i32), ("S", i32), ("C", i32), ("dtype", i32), ("stat", vp), ("eps", f32), ("dstat", vp),
                                       ("styles", vp), ("num_styles", i32), ("gamma", fp4), ("dgamma", fp4), ("dbeta", fp4),
                                       ("act", i32), ("slope", f32), ("gadd", vp), ("ldgadd", i64), ("beta", fp4)])
+InstnormPairBwd = _struct("InstnormPairBwd", [("dy", vp), ("lddy", i64), ("y", vp), ("ldy", i64), ("xa", vp), ("ldxa", i64), ("xb", vp), ("ldxb", i64),
+                                              ("dxa", vp), ("lddxa", i64), ("dxb", vp), ("lddxb", i64), ("B", i32), ("S", i32), ("C", i32), ("dtype", i32),
+                                              ("stat_a", vp), ("stat_b", vp), ("eps", f32), ("dstat_a", vp), ("dstat_b", vp), ("styles", vp),
+                                              ("num_styles", i32), ("gamma_a", fp4), ("gamma_b", fp4), ("dgamma_a", fp4), ("dbeta_a", fp4),
+                                              ("dgamma_b", fp4), ("dbeta_b", fp4), ("slope", f32)])
 LayernormFwd = _struct("LayernormFwd", [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32),
                                         ("dtype", i32), ("eps", f32), ("gamma", vp), ("beta", vp), ("mean", vp), ("rstd", vp)])
 LayernormBwd = _struct("LayernormBwd", [("dy", vp), ("lddy", i64), ("x", vp), ("ldx", i64), ("dx", vp), ("lddx", i64),
@@ -99,6 +104,7 @@ PROTOS = {
     "miseg_instnorm_apply": (i32, [C.POINTER(InstnormApply), vp]),
     "miseg_instnorm_fwd": (i32, [C.POINTER(InstnormApply), vp]),
     "miseg_instnorm_bwd": (i32, [C.POINTER(InstnormBwd), vp]),
+    "miseg_instnorm_pair_bwd": (i32, [C.POINTER(InstnormPairBwd), vp]),
     "miseg_layernorm_fwd": (i32, [C.POINTER(LayernormFwd), vp]),
     "miseg_layernorm_bwd": (i32, [C.POINTER(LayernormBwd), vp]),
     "miseg_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(Gemm)]),

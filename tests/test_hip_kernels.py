@@ -83,6 +83,48 @@ def test_instnorm_fwd_bwd(dtype, B, S, C):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,S,C", [(2, 700, 24), (1, 4096 + 17, 48), (3, 530, 10)])
+def test_instnorm_residual_pair(dtype, B, S, C):
+    """y = LeakyReLU(norm_a(xa) + norm_b(xb)) in one apply pass (the shortcut norm rides as `res_stat`) and its joint backward (one
+    reduction + one apply launch for both norms): against fp64 autograd of the composition, per-sample styles."""
+    ops, L = _ops(), _L()
+    xa = rnd(B, S, C, dtype=dtype, seed=31) * 1.5 + 0.3
+    xb = rnd(B, S, C, dtype=dtype, seed=32) * 0.7 - 0.2
+    gam = [[rnd(C, seed=33 + 4 * k + s) * 0.2 + 1 for s in range(2)] for k in range(2)]
+    bet = [[rnd(C, seed=35 + 4 * k + s) * 0.1 for s in range(2)] for k in range(2)]
+    styles_h = [(i + 1) % 2 for i in range(B)]
+    styles = torch.tensor(styles_h, dtype=torch.int32, device=DEV)
+    sa, sb = ops.instnorm_stats(xa, B, S), ops.instnorm_stats(xb, B, S)
+    y = ops.instnorm_apply(xa, B, S, sa, styles, gam[0], bet[0], res=xb, act=L.ACT_LEAKY, slope=0.01, res_stat=sb, res_gammas=gam[1], res_betas=bet[1])
+    xs = [xa.double().requires_grad_(True), xb.double().requires_grad_(True)]
+    gp = [[g.double().requires_grad_(True) for g in gam[k]] for k in range(2)]
+    bp = [[b.double().requires_grad_(True) for b in bet[k]] for k in range(2)]
+    outs = []
+    for i in range(B):
+        s = styles_h[i]
+        tot = 0
+        for k in range(2):
+            mu = xs[k][i].mean(0, keepdim=True)
+            var = xs[k][i].var(0, unbiased=False, keepdim=True)
+            tot = tot + (xs[k][i] - mu) / torch.sqrt(var + 1e-5) * gp[k][s] + bp[k][s]
+        outs.append(tot)
+    yr = F.leaky_relu(torch.stack(outs), 0.01)
+    assert rel_err(y, yr) < TOL[dtype]
+    dy = rnd(B, S, C, dtype=dtype, seed=47)
+    yr.backward(dy.double())
+    dg = [[torch.zeros(C, device=DEV) for _ in range(2)] for _ in range(2)]
+    db = [[torch.zeros(C, device=DEV) for _ in range(2)] for _ in range(2)]
+    dxa, dxb = ops.instnorm_pair_bwd(dy, y, xa, xb, B, S, sa, sb, styles, gam[0], gam[1], dg[0], db[0], dg[1], db[1], slope=0.01)
+    tol = TOL[dtype] * (3 if dtype == torch.bfloat16 else 1)
+    assert rel_err(dxa, xs[0].grad) < tol
+    assert rel_err(dxb, xs[1].grad) < tol
+    for k in range(2):
+        for s in set(styles_h):
+            assert rel_err(dg[k][s], gp[k][s].grad) < tol
+            assert rel_err(db[k][s], bp[k][s].grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_layernorm(dtype):
     ops = _ops()
     x = rnd(777, 96, dtype=dtype, seed=11)
