@@ -162,7 +162,11 @@ typedef struct {
   int epi_mode;
   int defer_reduce;  /* TN streaming path only: leave the per-split partial tiles in `workspace`; the caller sums them later with
                       * miseg_gemm_tn_reduce_batch (miseg_gemm_tn_splits(p) tells how many there are) */
+  void* stat;        /* NT, optional: fp64 [16][1][N][2] (miseg_instnorm_stat_bytes(1, N), zero on entry): instance-norm statistics of the rounded
+                      * output when all M rows are ONE sample and miseg_gemm_fuses_stat(p) says so (the tall-skinny bf16 path, N <= 96) -
+                      * the linears / 1x1x1 convs whose output feeds an instance norm (swin_transformer_block.py:241-252, dynunet_block.py:118-124) */
 } miseg_gemm_params;
+int miseg_gemm_fuses_stat(const miseg_gemm_params* p);  /* 1: miseg_gemm(p) with p->stat set is supported for this problem */
 int miseg_gemm_tn_splits(const miseg_gemm_params* p);   /* > 1: partial tiles [splits][M][N] fp32 in the workspace */
 size_t miseg_gemm_workspace_bytes(const miseg_gemm_params* p);
 int miseg_gemm(const miseg_gemm_params* p, miseg_stream_t stream);

@@ -48,6 +48,7 @@ struct Epi {
   const void* res; int64_t ldres;
   void* aux; int64_t ldaux;
   int mode;
+  double* stat;      // streaming kernel, STAT instantiation: instance-norm statistics of the (rounded) output, one sample (M rows)
 };
 
 template <class TO>
@@ -229,7 +230,11 @@ __global__ void __launch_bounds__(256) gemm_nt_k1_kernel(const T* __restrict__ A
 // MFMA operand is 16 contiguous bytes of its row), so the only LDS traffic is the weight fragments.
 typedef __attribute__((ext_vector_type(4))) short s16x4_g;
 
-template <int K16, bool GELU, int NCH = 12 /* n-tiles per accumulator chunk: fewer for the long rows (K >= 288), whose A fragments fill the registers */>
+// STAT (N <= 16 * NCH, one sample): per-column sum / sum of squares of the rounded output accumulate in registers over all the tiles of
+// a wave and are added once per workgroup to the replicated fp64 statistics buffer of the instance norm that consumes the output
+// (proj + residual and fc2 + residual feed norm2 / the next block's norm1, the 1x1x1 shortcut conv feeds norm3): no separate pass.
+template <int K16, bool GELU, int NCH = 12 /* n-tiles per accumulator chunk: fewer for the long rows (K >= 288), whose A fragments fill the registers */,
+          bool STAT = false>
 __global__ void __launch_bounds__(256, 2) gemm_nt_stream_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ W, int64_t ldw,
                                                                 bf16* __restrict__ C, int64_t ldc, int M, int N, Epi epi) {
   const float* bias = epi.bias;
@@ -257,6 +262,11 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_stream_kernel(const bf16* __re
       if (TAIL) t[mt] = *reinterpret_cast<const bf16x4*>(p + KS32 * 32 + 4 * kg);
     }
   };
+  float ssum[STAT ? NCH : 1][4], ssq[STAT ? NCH : 1][4];
+#pragma unroll
+  for (int j = 0; j < (STAT ? NCH : 1); ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ssum[j][r] = 0.f; ssq[j][r] = 0.f; }
   int tile = blockIdx.x * 4 + wave;
   if (tile < mtiles) loadA(tile, cur, curt);
   for (; tile < mtiles; tile += nwaves) {
@@ -295,7 +305,12 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_stream_kernel(const bf16* __re
               const int n = (nc + j) * 16 + 4 * kg;
               const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbias + n);
               const f32x4 v = epi_vec4_bf16(acc[mt][j] + b4, row, n, epi, GELU);
-              *reinterpret_cast<bf16x4*>(crow + n) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+              const bf16x4 o4 = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+              *reinterpret_cast<bf16x4*>(crow + n) = o4;
+              if constexpr (STAT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float q = (float)o4[r]; ssum[j][r] += q; ssq[j][r] = fmaf(q, q, ssq[j][r]); }
+              }
             }
           }
         }
@@ -306,6 +321,33 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_stream_kernel(const bf16* __re
 #pragma unroll
       for (int ks = 0; ks < KS32; ++ks) cur[mt][ks] = nxt[mt][ks];
       curt[mt] = nxtt[mt];
+    }
+  }
+  if constexpr (STAT) {
+    // lane (fi = row, kg) holds columns j * 16 + 4 kg + r: every lane's partials go to LDS ([k][column][wave * 16 + fi], 65-float rows),
+    // one thread per (column, k) adds the 64 of them; the weight image is dead once every wave is past its last tile
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);
+    constexpr int RS = 65;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      if (j < ntiles) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = j * 16 + kg * 4 + r;
+          red[(0 * N + col) * RS + wave * 16 + fi] = ssum[j][r];
+          red[(1 * N + col) * RS + wave * 16 + fi] = ssq[j][r];
+        }
+      }
+    }
+    __syncthreads();
+    for (int o = tid; o < 2 * N; o += 256) {
+      const int k = o / N, col = o - k * N;
+      const float* rp = red + (k * N + col) * RS;
+      float tot = 0.f;
+#pragma unroll 16
+      for (int i = 0; i < 64; ++i) tot += rp[i];
+      atomicAdd(epi.stat + ((int64_t)(blockIdx.x & 15) * N + col) * 2 + k, (double)tot);      // [16 replicas][B = 1][N][2]
     }
   }
 }
@@ -472,7 +514,7 @@ __device__ __forceinline__ void gemm_tn_body(const T* __restrict__ A, int64_t ld
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
-      store_out4<TO>(C, ldc, m0 + wm * 32 + mt * 16 + fi, n0 + wn * 32 + nt * 16 + fq * 4, M, N, acc[mt][nt], Epi{nullptr, MISEG_ACT_NONE, nullptr, 0, nullptr, 0, 0}, mode);
+      store_out4<TO>(C, ldc, m0 + wm * 32 + mt * 16 + fi, n0 + wn * 32 + nt * 16 + fq * 4, M, N, acc[mt][nt], Epi{nullptr, MISEG_ACT_NONE, nullptr, 0, nullptr, 0, 0, nullptr}, mode);
 }
 
 template <class T, class TO>
@@ -602,7 +644,7 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_stream_kernel(const bf16* __re
       for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt)
-          store_out4<float>(C, ldc, m0 + wmi * 48 + mt * 16 + fi, n0 + wni * 48 + nt * 16 + fq * 4, M, N, acc[mt][nt], Epi{nullptr, MISEG_ACT_NONE, nullptr, 0, nullptr, 0, 0}, mode);
+          store_out4<float>(C, ldc, m0 + wmi * 48 + mt * 16 + fi, n0 + wni * 48 + nt * 16 + fq * 4, M, N, acc[mt][nt], Epi{nullptr, MISEG_ACT_NONE, nullptr, 0, nullptr, 0, 0, nullptr}, mode);
     }
   }
 }
@@ -674,11 +716,22 @@ static bool tn_stream_plan(const miseg_gemm_params* p, TnStreamPlan* pl) {
   return true;
 }
 
+extern "C" int miseg_gemm_fuses_stat(const miseg_gemm_params* p) {
+  if (!p || p->ta || p->tb || p->dtype != MISEG_BF16 || p->out_dtype != MISEG_BF16) return 0;
+  const size_t lds = (size_t)p->N * (p->K * 2 + 16) + (size_t)p->N * 4;
+  const bool al_a = ((uintptr_t)p->A % 16 == 0) && (p->lda % 8 == 0), al_b = ((uintptr_t)p->B % 16 == 0) && (p->ldb % 8 == 0);
+  const bool epi_vec_ok = (!p->res || (((uintptr_t)p->res % 8 == 0) && p->ldres % 4 == 0)) && (!p->epi_mode || (((uintptr_t)p->aux % 8 == 0) && p->ldaux % 4 == 0));
+  return p->split_k <= 1 && !p->accumulate && p->act == MISEG_ACT_NONE && (p->K == 48 || p->K == 96 || p->K == 192) && p->N % 16 == 0 && p->N <= 96 &&
+         p->M >= 4096 && lds <= 96 * 1024 && al_a && al_b && ((uintptr_t)p->C % 8 == 0) && p->ldc % 4 == 0 && epi_vec_ok;
+}
+
 extern "C" size_t miseg_gemm_workspace_bytes(const miseg_gemm_params* p) {
   TnStreamPlan pl;
   if (!p || !tn_stream_plan(p, &pl) || pl.splits <= 1) return 0;
   return (size_t)pl.splits * p->M * p->N * sizeof(float);
 }
+
+extern "C" int miseg_gemm_fuses_stat(const miseg_gemm_params* p);
 
 template <class T, class TO>
 static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
@@ -690,8 +743,9 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
   if (split > 1 && !f32out) return set_error(MISEG_E_BADARG, "gemm: split_k needs fp32 output");
   if (p->accumulate && !f32out) return set_error(MISEG_E_BADARG, "gemm: accumulate needs fp32 output");
   int mode = split > 1 ? 2 : (p->accumulate ? 1 : 0);
-  const Epi epi{p->bias, p->act, p->res, p->ldres, p->aux, p->ldaux, p->epi_mode};
+  const Epi epi{p->bias, p->act, p->res, p->ldres, p->aux, p->ldaux, p->epi_mode, (double*)p->stat};
   const bool epi_vec_ok = (!p->res || (((uintptr_t)p->res % 8 == 0) && p->ldres % 4 == 0)) && (!p->epi_mode || (((uintptr_t)p->aux % 8 == 0) && p->ldaux % 4 == 0));
+  if (p->stat && !miseg_gemm_fuses_stat(p)) return set_error(MISEG_E_UNSUPPORTED, "gemm: fused statistics on this shape / path (ask miseg_gemm_fuses_stat first)");
   if (p->ta == 0 && p->tb == 0) {
     if ((p->res || p->epi_mode) && (split > 1 || p->accumulate)) return set_error(MISEG_E_BADARG, "gemm: residual / auxiliary epilogue with split_k or accumulate");
     if (p->epi_mode && !p->aux) return set_error(MISEG_E_BADARG, "gemm: epi_mode %d needs aux", p->epi_mode);
@@ -735,6 +789,22 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
       const size_t lds = (size_t)p->N * (p->K * 2 + 16) + (size_t)p->N * 4;
       const bool st_ok = split == 1 && !p->accumulate && (p->K == 48 || p->K == 96 || p->K == 192 || p->K == 144 || p->K == 288 || p->K == 384) && p->N % 16 == 0 && p->M >= 4096 && lds <= 96 * 1024 &&
                          al_a && al_b && ((uintptr_t)p->C % 8 == 0) && p->ldc % 4 == 0 && epi_vec_ok;
+      const bool stat_ok = st_ok && p->act == MISEG_ACT_NONE && p->N <= 96 && (p->K == 48 || p->K == 96 || p->K == 192);
+      if (p->stat && !stat_ok) return set_error(MISEG_E_UNSUPPORTED, "gemm: fused statistics on this shape / path (ask miseg_gemm_fuses_stat first)");
+      if (st_ok && p->stat) {
+        const int mtiles = cdiv(p->M, 32);
+        int blocks = cdiv(mtiles, 4);
+        if (blocks > 512) blocks = 512;
+        size_t lds2 = (size_t)2 * p->N * 65 * sizeof(float);
+        if (lds2 < lds) lds2 = lds;
+#define STS_CASE(k16)                                                                                                                        \
+  (void)hipFuncSetAttribute((const void*)gemm_nt_stream_kernel<k16, false, 6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+  gemm_nt_stream_kernel<k16, false, 6, true><<<blocks, 256, lds2, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, epi)
+        if (p->K == 48) { STS_CASE(3); } else if (p->K == 96) { STS_CASE(6); } else { STS_CASE(12); }
+#undef STS_CASE
+        MISEG_LAUNCH_CHECK("gemm_nt_stream(stat)");
+        return MISEG_OK;
+      }
       if (st_ok) {
         const int mtiles = cdiv(p->M, 32);
         int blocks = cdiv(mtiles, 4);
@@ -755,6 +825,7 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
         return MISEG_OK;
       }
     }
+    if (p->stat) return set_error(MISEG_E_UNSUPPORTED, "gemm: fused statistics on this shape / path (ask miseg_gemm_fuses_stat first)");
     const int nt = (p->N % 64 == 0) ? 4 : (p->N % 48 == 0) ? 3 : (p->N <= 16) ? 1 : (p->N <= 32) ? 2 : (p->N <= 48) ? 3 : 4;
     dim3 grid(cdiv(p->M, 128), cdiv(p->N, 16 * nt), split);
 #define NT_CASE(n)                                                                                                                          \

@@ -147,7 +147,7 @@ class _ResNormPair(Function):
     instance-norm backward passes (the first hands the activation-masked gradient to the second)."""
 
     @staticmethod
-    def forward(ctx, xa, xb, styles_dev, styles_host, num_styles, affine, slope, eps_a, eps_b, stat_a, *params):
+    def forward(ctx, xa, xb, styles_dev, styles_host, num_styles, affine, slope, eps_a, eps_b, stat_a, stat_b, *params):
         B = xa.shape[0]
         S = ops.rows(xa)[1] // B
         global _PENDING_OUT
@@ -159,7 +159,7 @@ class _ResNormPair(Function):
         if eps_a != eps_b:
             raise ValueError("the two norms of a residual pair must share eps")
         sa = stat_a if stat_a is not None else ops.instnorm_stats(xa, B, S)
-        sb = ops.instnorm_stats(xb, B, S)
+        sb = stat_b if stat_b is not None else ops.instnorm_stats(xb, B, S)
         y = ops.instnorm_apply(xa, B, S, sa, styles_dev, ga, ba, res=xb, act=L.ACT_LEAKY, slope=slope, eps=eps_a, out=out, res_stat=sb,
                                res_gammas=gb, res_betas=bb)
         ctx.meta = (B, S, styles_host, num_styles, affine, slope, eps_a)
@@ -197,7 +197,15 @@ class _ResNormPair(Function):
             for dg_, db_, ar in ((dga, dba, arena_a), (dgb, dbb, arena_b)):
                 for s in range(num_styles):
                     pg += [None, None] if ar else [dg_[s], db_[s]]
-        return (dxa, dxb, None, None, None, None, None, None, None, None, *pg)
+        return (dxa, dxb, None, None, None, None, None, None, None, None, None, *pg)
+
+
+def _carried_stat(x):
+    """statistics the GEMM that produced x left on it (linear / mlp / conv1 with want_stat): valid for exactly this tensor"""
+    st = getattr(x, "_miseg_stat", None)
+    if st is not None and x.shape[0] == 1 and st.shape[1] == 1 and st.shape[2] == x.shape[-1]:
+        return st
+    return None
 
 
 def res_norm_pair(xa, xb, params_a, params_b, styles_dev=None, styles_host=None, slope=0.01, eps_a=1e-5, eps_b=1e-5, stat_a=None, out=None):
@@ -210,7 +218,7 @@ def res_norm_pair(xa, xb, params_a, params_b, styles_dev=None, styles_host=None,
             for g, b in ps:
                 flat += [g, b]
     _PENDING_OUT = out
-    return _ResNormPair.apply(xa, xb, styles_dev, styles_host, n, params_a is not None, slope, eps_a, eps_b, stat_a, *flat)
+    return _ResNormPair.apply(xa, xb, styles_dev, styles_host, n, params_a is not None, slope, eps_a, eps_b, stat_a, _carried_stat(xb), *flat)
 
 
 def instance_norm(x, params=None, styles_dev=None, styles_host=None, res=None, act=L.ACT_NONE, slope=0.01, eps=1e-5, fork=False, stat=None, out=None):
@@ -224,6 +232,8 @@ def instance_norm(x, params=None, styles_dev=None, styles_host=None, res=None, a
             flat += [g, b]
     global _PENDING_OUT
     _PENDING_OUT = out
+    if stat is None:
+        stat = _carried_stat(x)
     return _InstNorm.apply(x, res, styles_dev, styles_host, n, params is not None, act, slope, eps, fork, stat, *flat)
 
 
@@ -258,9 +268,9 @@ class _Linear(Function):
     pack, dW via the TN GEMM."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, res):
+    def forward(ctx, x, weight, bias, res, want_stat=False):
         w = ops.cast_matrix(weight, x.dtype)
-        y = ops.gemm_nt(x, w, bias, res=res)
+        y = ops.gemm_nt(x, w, bias, res=res, want_stat=want_stat)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.params = (weight, bias)
@@ -287,11 +297,26 @@ class _Linear(Function):
                 ops.colsum(dy, out=slot, accumulate=True)
             else:
                 db = ops.colsum(dy)
-        return dx, dw, db, (dy if ctx.needs_input_grad[3] else None)
+        return dx, dw, db, (dy if ctx.needs_input_grad[3] else None), None
 
 
-def linear(x, weight, bias=None, res=None):
-    return _Linear.apply(x, weight, bias, res)
+def _one_sample(x):
+    return x.dim() >= 3 and x.shape[0] == 1
+
+
+def _tag_stat(y):
+    st = ops.pop_gemm_stat(y)
+    if st is not None:
+        y._miseg_stat = st
+    return y
+
+
+def linear(x, weight, bias=None, res=None, want_stat=False):
+    """want_stat: the output feeds an instance norm - where the GEMM can (one sample, tall-skinny bf16 path) its epilogue leaves the
+    statistics on the result (`_miseg_stat`), which instance_norm() picks up instead of running its statistics pass."""
+    want = want_stat and _one_sample(x)
+    y = _Linear.apply(x, weight, bias, res, want)
+    return _tag_stat(y) if want else y
 
 
 class _Mlp(Function):
@@ -300,10 +325,10 @@ class _Mlp(Function):
     epilogue.  Backward: the GELU derivative is the epilogue of the data-gradient GEMM behind it (dh = (dy W2) * gelu'(h))."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, res):
+    def forward(ctx, x, w1, b1, w2, b2, res, want_stat=False):
         h = torch.empty(x.shape[:-1] + (w1.shape[0],), dtype=x.dtype, device=x.device)
         a = ops.gemm_nt(x, ops.cast_matrix(w1, x.dtype), b1, act=L.ACT_GELU, preact_out=h)
-        y = ops.gemm_nt(a, ops.cast_matrix(w2, x.dtype), b2, res=res)
+        y = ops.gemm_nt(a, ops.cast_matrix(w2, x.dtype), b2, res=res, want_stat=want_stat)
         ctx.save_for_backward(x, h, a, w1, w2)
         ctx.params = (w1, b1, w2, b2)
         return y
@@ -315,7 +340,7 @@ class _Mlp(Function):
         dy = _rv(dy)
         dh = ops.gemm_nt(dy, ops.cast_matrix(w2, dy.dtype, transpose=True), gelu_grad_of=h)
         dx = ops.gemm_nt(dh, ops.cast_matrix(w1, dy.dtype, transpose=True)) if ctx.needs_input_grad[0] else None
-        out = [dx, None, None, None, None, dy if ctx.needs_input_grad[5] else None]
+        out = [dx, None, None, None, None, dy if ctx.needs_input_grad[5] else None, None]
         for i, (p, act, g) in enumerate(((pw1, x, dh), (pw2, a, dy))):
             if ctx.needs_input_grad[1 + 2 * i]:
                 slot = _slot(p)
@@ -334,8 +359,10 @@ class _Mlp(Function):
         return tuple(out)
 
 
-def mlp(x, w1, b1, w2, b2, res=None):
-    return _Mlp.apply(x, w1, b1, w2, b2, res)
+def mlp(x, w1, b1, w2, b2, res=None, want_stat=False):
+    want = want_stat and _one_sample(x)
+    y = _Mlp.apply(x, w1, b1, w2, b2, res, want)
+    return _tag_stat(y) if want else y
 
 
 class _Gelu(Function):
@@ -581,11 +608,11 @@ class _Conv1(Function):
     """1x1x1 conv, no bias (ResBlock shortcut dynunet_block.py:87-97) == Linear over the channel dim."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, want_stat=False):
         w = ops.cast_matrix(weight, x.dtype)
         ctx.save_for_backward(x, weight)
         ctx.params = (weight,)
-        return ops.gemm_nt(x, w)
+        return ops.gemm_nt(x, w, want_stat=want_stat)
 
     @staticmethod
     def backward(ctx, dy):
@@ -600,11 +627,13 @@ class _Conv1(Function):
                     ops.gemm_tn(dy, x, out=slot, accumulate=True)
             else:
                 dw = ops.gemm_tn(dy, x).view(weight.shape)
-        return dx, dw
+        return dx, dw, None
 
 
-def conv1(x, weight):
-    return _Conv1.apply(x, weight)
+def conv1(x, weight, want_stat=False):
+    want = want_stat and _one_sample(x)
+    y = _Conv1.apply(x, weight, want)
+    return _tag_stat(y) if want else y
 
 
 class _UpCat(Function):

@@ -4,6 +4,7 @@ Activations are "channels-last rows": any tensor whose last dim is the channel d
 dims collapse to one uniform row stride (e.g. a contiguous [B, D, H, W, C] tensor or a channel slice of one).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -202,7 +203,17 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta):
 
 
 # ------------------------------------------------------------------------------------------ GEMM family
-def gemm_nt(a, w, bias=None, act=L.ACT_NONE, out=None, out_dtype=None, split_k=1, res=None, preact_out=None, gelu_grad_of=None):
+LAST_GEMM_STAT = None      # (data_ptr of the output, statistics tensor) of the last gemm_nt(want_stat=True) that fused them
+
+
+def pop_gemm_stat(y):
+    """the instance-norm statistics the last gemm_nt produced for `y` in its epilogue, or None"""
+    global LAST_GEMM_STAT
+    st, LAST_GEMM_STAT = LAST_GEMM_STAT, None
+    return st[1] if st is not None and st[0] == y.data_ptr() else None
+
+
+def gemm_nt(a, w, bias=None, act=L.ACT_NONE, out=None, out_dtype=None, split_k=1, res=None, preact_out=None, gelu_grad_of=None, want_stat=False):
     """out[M,N] = act(a[M,K] @ w[N,K]^T + bias) + res ; a rows view, w contiguous [N,K] in a.dtype.
     preact_out: tensor that receives the pre-activation z (for a later GELU backward); gelu_grad_of: pre-activation h of the
     layer in front, the result is multiplied by gelu'(h) (GELU backward folded into this data-gradient GEMM)."""
@@ -224,7 +235,14 @@ def gemm_nt(a, w, bias=None, act=L.ACT_NONE, out=None, out_dtype=None, split_k=1
                 raise ValueError("gemm_nt: res / aux must be [M, N] row views in the output dtype")
     p = L.Gemm(_ptr(a), lda, _ptr(w), K, _ptr(out), ldc, M, N, K, 0, 0, _dt(a), _dt(out), _ptr(_fp32(bias)), act, 0, split_k, None,
                _ptr(res), rows(res)[0] if res is not None else 0, _ptr(aux), rows(aux)[0] if aux is not None else 0,
-               1 if preact_out is not None else 2 if gelu_grad_of is not None else 0, 0)
+               1 if preact_out is not None else 2 if gelu_grad_of is not None else 0, 0, None)
+    global LAST_GEMM_STAT
+    LAST_GEMM_STAT = None
+    if want_stat and PROFILE_HOOK is None and not os.environ.get("MISEG_NO_GEMM_STAT") and L.load().miseg_gemm_fuses_stat(C.byref(p)):
+        # all M rows are one sample (the caller checked): the kernel leaves the norm statistics of the output in `stat`
+        stat = STAT_POOL.take(L.load().miseg_instnorm_stat_bytes(1, N) // 8, a.device).view(-1, 1, N, 2)
+        p.stat = stat.data_ptr()
+        LAST_GEMM_STAT = (out.data_ptr(), stat)
     _call("miseg_gemm", p)
     return out
 

@@ -18,6 +18,7 @@ class MLPBlock(nn.Module):
         self.linear1 = nn.Linear(hidden_size, mlp_dim)
         self.linear2 = nn.Linear(mlp_dim, hidden_size)
 
-    def forward(self, x, res=None):
-        """res: optional residual added in the second GEMM's epilogue (the caller's `x + mlp(norm(x))`)."""
-        return HF.mlp(x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, res)
+    def forward(self, x, res=None, want_stat=False):
+        """res: optional residual added in the second GEMM's epilogue (the caller's `x + mlp(norm(x))`).
+        want_stat: the result feeds an instance norm (see HF.linear)."""
+        return HF.mlp(x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, res, want_stat)

@@ -48,7 +48,8 @@ class SwinTransformerBlock(nn.Module):
         """x [B, D, H, W, C].  part1 (:99-174) + residual, part2 (:176-205) + residual (:241-252)."""
         _, d, h, w, _ = x.shape
         window, shift = get_window_size((d, h, w), self.window_size, self.shift_size)
+        inst = self.norm_type.startswith("instance")    # the GEMM that feeds an instance norm also produces its statistics
         xn, xs = apply_norm_fork(self.norm1, x, styles)
-        x = self.attn(xn, window, shift, res=xs)        # x + attn(norm1(x)): add in the proj epilogue
+        x = self.attn(xn, window, shift, res=xs, want_stat=inst)        # x + attn(norm1(x)): add in the proj epilogue
         xn, xs = apply_norm_fork(self.norm2, x, styles)
-        return self.mlp(xn, res=xs)                     # x + mlp(norm2(x)): add in the fc2 epilogue
+        return self.mlp(xn, res=xs, want_stat=inst)                     # x + mlp(norm2(x)): add in the fc2 epilogue

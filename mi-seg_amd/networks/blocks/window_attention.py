@@ -41,9 +41,9 @@ class WindowAttention(nn.Module):
         if not (ws[0] == ws[1] == ws[2]):
             raise NotImplementedError("non-cubic table windows")
 
-    def forward(self, x, window, shift, res=None):
+    def forward(self, x, window, shift, res=None, want_stat=False):
         """x: normalised tokens on the unpadded grid [B, D, H, W, C]; window/shift already clamped."""
         qkv = HF.linear(x, self.qkv.weight, self.qkv.bias)
         o = HF.window_attention(qkv, self.qkv.bias, self.relative_position_bias_table, self.num_heads, window, shift,
                                 self.window_size[0], self.scale)
-        return HF.linear(o, self.proj.weight, self.proj.bias, res)     # res: the block's residual, added in the GEMM epilogue
+        return HF.linear(o, self.proj.weight, self.proj.bias, res, want_stat)     # res: the block's residual, added in the GEMM epilogue

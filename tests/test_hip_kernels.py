@@ -170,6 +170,35 @@ def test_gemm_nt_streaming_path(M, N, K):
     assert torch.equal(ops.gemm_nt(ai, wi).float(), (ai.float() @ wi.float().t()).to(dtype).float())
 
 
+@pytest.mark.parametrize("M,N,K,with_res", [(4096, 48, 48, False), (13825, 48, 192, True), (110592, 96, 96, True), (5003, 48, 96, False), (4101, 96, 192, True),
+                                            (4099, 32, 48, False)])
+def test_gemm_nt_streaming_statistics(M, N, K, with_res):
+    """want_stat: the streaming kernel's epilogue leaves the instance-norm statistics (one sample = all M rows) of its ROUNDED output
+    (bias and residual included) in the replicated fp64 buffer - against the separate statistics pass over the same output; a
+    shape the path does not cover (N = 144, GELU) leaves no statistics and the caller falls back."""
+    ops, L = _ops(), _L()
+    dtype = torch.bfloat16
+    a, w, bias = rnd(M, K, dtype=dtype, seed=21), rnd(N, K, dtype=dtype, seed=22) / K ** 0.5, rnd(N, seed=23)
+    res = rnd(M, N, dtype=dtype, seed=24) if with_res else None
+    ops.begin_step()
+    y = ops.gemm_nt(a, w, bias, res=res, want_stat=True)
+    st = ops.pop_gemm_stat(y)
+    assert st is not None and st.shape[1:] == (1, N, 2)
+    assert ops.pop_gemm_stat(y) is None                          # handed over once
+    plain = ops.gemm_nt(a, w, bias, res=res)
+    assert torch.equal(y, plain)                                 # same output as the plain instantiation
+    got = st.sum(0)[0]                                           # [N, 2]
+    yf = y.double()
+    want = torch.stack([yf.sum(0), (yf * yf).sum(0)], -1)
+    assert torch.allclose(got, want, rtol=2e-6, atol=1e-3), (got - want).abs().max()
+    ref = ops.instnorm_stats(y.view(1, M, N), 1, M).sum(0)[0]
+    assert torch.allclose(got, ref, rtol=2e-6, atol=1e-3)
+    y2 = ops.gemm_nt(a, rnd(144, K, dtype=dtype, seed=25), want_stat=True)
+    assert ops.pop_gemm_stat(y2) is None
+    y3 = ops.gemm_nt(a, w, bias, act=L.ACT_GELU, want_stat=True)
+    assert ops.pop_gemm_stat(y3) is None
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_nt_rank1(dtype):
     """K == 1 (the stem block's 1x1x1 shortcut on a one-channel image): the outer-product kernel"""
