@@ -397,6 +397,8 @@ class _Conv3(Function):
         ctx.wshape = weight.shape
         ctx.params = (weight,)
         ctx.layout = (want_stat, fork)
+        # the statistics output never gets a gradient: without this autograd would materialise a zero tensor for it (a fill launch)
+        ctx.set_materialize_grads(False)
         outs = [y]
         if want_stat:
             if stat is not None:
