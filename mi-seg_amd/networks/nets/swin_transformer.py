@@ -93,9 +93,14 @@ class SwinTransformer(nn.Module):
         x0 = self.patch_embed(x, styles, dtype)
         outs = []
         cur = x0
+        inst = normalize and self.norm_type in ("instance", "instance_cond")
         for layers in (self.layers1, self.layers2, self.layers3, self.layers4):
-            a, cur = HF.fork(cur)
-            outs.append(self.proj_out(a, normalize))
+            if inst:        # (norm(x), x): the norm-backward kernel sums the gradients of the two branches, no separate add
+                a, cur = HF.instance_norm(cur, None, fork=True)
+                outs.append(a)
+            else:
+                a, cur = HF.fork(cur)
+                outs.append(self.proj_out(a, normalize))
             cur = layers[0](cur, styles)
         outs.append(self.proj_out(cur, normalize))
         return outs
