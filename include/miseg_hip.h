@@ -113,6 +113,8 @@ typedef struct {
   float* dgamma_a[MISEG_MAX_STYLES]; float* dbeta_a[MISEG_MAX_STYLES];
   float* dgamma_b[MISEG_MAX_STYLES]; float* dbeta_b[MISEG_MAX_STYLES];
   float slope;
+  /* y == NULL: the activation's sign is recomputed from xa / xb (then the betas of both norms are read; NULL rows = 0) */
+  const float* beta_a[MISEG_MAX_STYLES]; const float* beta_b[MISEG_MAX_STYLES];
 } miseg_instnorm_pair_bwd_params;
 int miseg_instnorm_pair_bwd(const miseg_instnorm_pair_bwd_params* p, miseg_stream_t stream);
 

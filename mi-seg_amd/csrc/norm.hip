@@ -388,12 +388,34 @@ __device__ __forceinline__ void team_totals(float* red, double* tot, const float
 // ---- backward of y = LeakyReLU(norm_a(xa) + norm_b(xb)) (instnorm_apply_kernel with rstat): both norms see the same activation-
 // masked gradient g, so ONE reduction pass yields sum g, sum g*xhat_a, sum g*xhat_b and ONE apply pass writes both input gradients
 // (10 passes over the tensor instead of the 13 of two chained norm backwards, no `dres` tensor, two launches instead of four).
+// the pre-activation of the residual norm pair exactly as instnorm_apply_kernel forms it (same operations in the same order: the
+// recomputed sign must be the sign the forward pass saw)
+__device__ __forceinline__ float pair_preact(float xa, float sca, float sha, float xb, float scb, float shb) {
+  float o = fmaf(xa, sca, sha);
+  o += fmaf(xb, scb, shb);
+  return o;
+}
+__device__ __forceinline__ void pair_preact_coeffs(const StylePtrs& spa, const StylePtrs& spb, int st, int ch, float ma, float rsa, float mb, float rsb,
+                                                   float& sca, float& sha, float& scb, float& shb) {
+  const float* ga = spa.gamma[st];
+  const float* ba = spa.beta[st];
+  const float* gb = spb.gamma[st];
+  const float* bb = spb.beta[st];
+  sca = rsa * (ga ? ga[ch] : 1.f);
+  sha = (ba ? ba[ch] : 0.f) - ma * sca;
+  scb = rsb * (gb ? gb[ch] : 1.f);
+  shb = (bb ? bb[ch] : 0.f) - mb * scb;
+}
+
 template <class T, int VEC>
 __global__ void __launch_bounds__(NORM_THREADS) instnorm_pair_bwd_reduce_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ yact, int64_t ldy,
                                                                                 const T* __restrict__ xa, int64_t ldxa, const T* __restrict__ xb, int64_t ldxb,
                                                                                 int S, int C, int cv, int tx_n, int ty_n, int rpb,
                                                                                 const double* __restrict__ stat_a, const double* __restrict__ stat_b, float eps,
-                                                                                float slope, double* __restrict__ dstat_a, double* __restrict__ dstat_b) {
+                                                                                float slope, double* __restrict__ dstat_a, double* __restrict__ dstat_b,
+                                                                                const int32_t* __restrict__ styles, StylePtrs spa, StylePtrs spb) {
+  // yact == nullptr: the LeakyReLU's sign is recomputed from the two inputs with the forward pass's own expression (instnorm_apply_kernel:
+  // fmaf(xa, sc_a, sh_a) + fmaf(xb, sc_b, sh_b), identical operands) - one tensor less to read in both passes
   extern __shared__ __attribute__((aligned(16))) float red[];
   double* sums_a = reinterpret_cast<double*>(red);   // prologue only; the reductions reuse the space after a barrier
   double* sums_b = sums_a + 2 * tx_n * VEC;
@@ -404,13 +426,16 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_pair_bwd_reduce_kernel(
   const int c = c0 + tx;
   gather_stat(sums_a, stat_a, (int64_t)gridDim.y * C * 2, b, C, c0 * VEC, tx_n * VEC);
   gather_stat(sums_b, stat_b, (int64_t)gridDim.y * C * 2, b, C, c0 * VEC, tx_n * VEC);
-  float s[VEC], qa[VEC], qb[VEC], ma[VEC], rsa[VEC], mb[VEC], rsb[VEC];
+  float s[VEC], qa[VEC], qb[VEC], ma[VEC], rsa[VEC], mb[VEC], rsb[VEC], zsa[VEC], zha[VEC], zsb[VEC], zhb[VEC];
   const double invS = 1.0 / S;
+  const int st = styles ? styles[b] : 0;
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
     s[i] = qa[i] = qb[i] = 0.f;
     mean_rstd(sums_a + (tx * VEC + i) * 2, invS, eps, ma[i], rsa[i]);
     mean_rstd(sums_b + (tx * VEC + i) * 2, invS, eps, mb[i], rsb[i]);
+    const int ch = min(c * VEC + i, C - 1);
+    pair_preact_coeffs(spa, spb, st, ch, ma[i], rsa[i], mb[i], rsb[i], zsa[i], zha[i], zsb[i], zhb[i]);
   }
   __syncthreads();
   if (ty < ty_n && c < cv) {
@@ -418,12 +443,13 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_pair_bwd_reduce_kernel(
     for (int r = r0 + ty; r < r1; r += ty_n) {
       RowVec<T, VEC> g, yv, va, vb;
       g.load(dy + (boff + r) * lddy + c * VEC);
-      yv.load(yact + (boff + r) * ldy + c * VEC);
+      if (yact) yv.load(yact + (boff + r) * ldy + c * VEC);
       va.load(xa + (boff + r) * ldxa + c * VEC);
       vb.load(xb + (boff + r) * ldxb + c * VEC);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
-        const float gi = yv.v[i] > 0.f ? g.v[i] : g.v[i] * slope;
+        const float pre = yact ? yv.v[i] : pair_preact(va.v[i], zsa[i], zha[i], vb.v[i], zsb[i], zhb[i]);
+        const float gi = pre > 0.f ? g.v[i] : g.v[i] * slope;
         s[i] += gi;
         qa[i] = fmaf(gi, (va.v[i] - ma[i]) * rsa[i], qa[i]);
         qb[i] = fmaf(gi, (vb.v[i] - mb[i]) * rsb[i], qb[i]);
@@ -474,7 +500,7 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_pair_bwd_apply_kernel(c
   const float* gb = spb.gamma[st];
   const int64_t boff = (int64_t)b * S;
   const double invS = 1.0 / S;
-  float ma[VEC], rsa[VEC], sca[VEC], aa[VEC], bqa[VEC], mb[VEC], rsb[VEC], scb[VEC], bqb[VEC];
+  float ma[VEC], rsa[VEC], sca[VEC], aa[VEC], bqa[VEC], mb[VEC], rsb[VEC], scb[VEC], bqb[VEC], zsa[VEC], zha[VEC], zsb[VEC], zhb[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
     const int ch = c * VEC + i;
@@ -482,6 +508,7 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_pair_bwd_apply_kernel(c
     mean_rstd(sb + (tx * VEC + i) * 2, invS, eps, mb[i], rsb[i]);
     sca[i] = rsa[i] * (ga ? ga[ch] : 1.f);
     scb[i] = rsb[i] * (gb ? gb[ch] : 1.f);
+    pair_preact_coeffs(spa, spb, st, ch, ma[i], rsa[i], mb[i], rsb[i], zsa[i], zha[i], zsb[i], zhb[i]);
     aa[i] = (float)(da[(tx * VEC + i) * 2] * invS);          // mean of g: the same for both norms
     bqa[i] = (float)(da[(tx * VEC + i) * 2 + 1] * invS);
     bqb[i] = (float)(db[(tx * VEC + i) * 2 + 1] * invS);
@@ -490,12 +517,13 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_pair_bwd_apply_kernel(c
   for (int r = r0 + ty; r < r1; r += ty_n) {
     RowVec<T, VEC> g, yv, va, vb, oa, ob;
     g.load(dy + (boff + r) * lddy + c * VEC);
-    yv.load(yact + (boff + r) * ldy + c * VEC);
+    if (yact) yv.load(yact + (boff + r) * ldy + c * VEC);
     va.load(xa + (boff + r) * ldxa + c * VEC);
     vb.load(xb + (boff + r) * ldxb + c * VEC);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      const float gi = yv.v[i] > 0.f ? g.v[i] : g.v[i] * slope;
+      const float pre = yact ? yv.v[i] : pair_preact(va.v[i], zsa[i], zha[i], vb.v[i], zsb[i], zhb[i]);
+      const float gi = pre > 0.f ? g.v[i] : g.v[i] * slope;
       oa.v[i] = sca[i] * (gi - aa[i] - (va.v[i] - ma[i]) * rsa[i] * bqa[i]);
       ob.v[i] = scb[i] * (gi - aa[i] - (vb.v[i] - mb[i]) * rsb[i] * bqb[i]);
     }
@@ -900,21 +928,21 @@ extern "C" int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stre
 
 extern "C" int miseg_instnorm_pair_bwd(const miseg_instnorm_pair_bwd_params* p, miseg_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  MISEG_REQUIRE(p && p->dy && p->y && p->xa && p->xb && p->dxa && p->dxb && p->stat_a && p->stat_b && p->dstat_a && p->dstat_b, MISEG_E_BADARG,
+  MISEG_REQUIRE(p && p->dy && p->xa && p->xb && p->dxa && p->dxb && p->stat_a && p->stat_b && p->dstat_a && p->dstat_b, MISEG_E_BADARG,
                 "instnorm_pair_bwd: null pointer");
   MISEG_REQUIRE(p->num_styles >= 1 && p->num_styles <= MISEG_MAX_STYLES, MISEG_E_BADARG, "instnorm_pair_bwd: num_styles %d", p->num_styles);
   return dispatch_dtype(p->dtype, [&](auto* tag) -> int {
     typedef typename std::remove_pointer<decltype(tag)>::type T;
     constexpr int V = Vec16<T>::N;
-    const int64_t ldor = p->lddy | p->ldy | p->ldxa | p->ldxb | p->lddxa | p->lddxb;
-    const bool al = aligned16(p->dy) && aligned16(p->y) && aligned16(p->xa) && aligned16(p->xb) && aligned16(p->dxa) && aligned16(p->dxb) && ldor % V == 0;
+    const int64_t ldor = p->lddy | (p->y ? p->ldy : 0) | p->ldxa | p->ldxb | p->lddxa | p->lddxb;
+    const bool al = aligned16(p->dy) && (!p->y || aligned16(p->y)) && aligned16(p->xa) && aligned16(p->xb) && aligned16(p->dxa) && aligned16(p->dxb) && ldor % V == 0;
     NormGeom g = norm_geom(p->S, p->C, al, V);
     StylePtrs spa, spb;
     StyleGradPtrs gpa, gpb;
     for (int s = 0; s < MISEG_MAX_STYLES; ++s) {
       const bool on = s < p->num_styles;
-      spa.gamma[s] = on ? p->gamma_a[s] : nullptr; spa.beta[s] = nullptr;
-      spb.gamma[s] = on ? p->gamma_b[s] : nullptr; spb.beta[s] = nullptr;
+      spa.gamma[s] = on ? p->gamma_a[s] : nullptr; spa.beta[s] = on ? p->beta_a[s] : nullptr;      // betas: only read when y is absent
+      spb.gamma[s] = on ? p->gamma_b[s] : nullptr; spb.beta[s] = on ? p->beta_b[s] : nullptr;
       gpa.dgamma[s] = on ? p->dgamma_a[s] : nullptr; gpa.dbeta[s] = on ? p->dbeta_a[s] : nullptr;
       gpb.dgamma[s] = on ? p->dgamma_b[s] : nullptr; gpb.dbeta[s] = on ? p->dbeta_b[s] : nullptr;
     }
@@ -926,7 +954,7 @@ extern "C" int miseg_instnorm_pair_bwd(const miseg_instnorm_pair_bwd_params* p, 
     instnorm_pair_bwd_reduce_kernel<T, VV><<<grid, NORM_THREADS, sh, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->xa, p->ldxa,         \
                                                                                (const T*)p->xb, p->ldxb, p->S, p->C, g.cv, g.tx, g.ty, g.rpb,                    \
                                                                                (const double*)p->stat_a, (const double*)p->stat_b, p->eps, p->slope,            \
-                                                                               (double*)p->dstat_a, (double*)p->dstat_b);                                       \
+                                                                               (double*)p->dstat_a, (double*)p->dstat_b, p->styles, spa, spb);                  \
     instnorm_pair_bwd_apply_kernel<T, VV><<<grid, NORM_THREADS, shd, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->xa, p->ldxa,         \
                                                                                (const T*)p->xb, p->ldxb, (T*)p->dxa, p->lddxa, (T*)p->dxb, p->lddxb, p->S, p->C, \
                                                                                g.cv, g.tx, g.ty, g.rpb, (const double*)p->stat_a, (const double*)p->stat_b,     \

@@ -164,14 +164,15 @@ class _ResNormPair(Function):
                                res_gammas=gb, res_betas=bb)
         ctx.meta = (B, S, styles_host, num_styles, affine, slope, eps_a)
         ctx.params = params
-        ctx.save_for_backward(xa, xb, y, sa, sb, styles_dev, *(ga or []), *(gb or []))
+        # y is not kept: the backward kernels recompute the LeakyReLU's sign from xa / xb (the forward's own expression), hence the betas
+        ctx.save_for_backward(xa, xb, sa, sb, styles_dev, *(ga or []), *(gb or []), *(ba or []), *(bb or []))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         B, S, styles_host, num_styles, affine, slope, eps = ctx.meta
-        xa, xb, y, sa, sb, styles_dev, *gg = ctx.saved_tensors
-        ga, gb = (gg[:num_styles], gg[num_styles:]) if affine else (None, None)
+        xa, xb, sa, sb, styles_dev, *gg = ctx.saved_tensors
+        ga, gb, ba, bb = (gg[i * num_styles:(i + 1) * num_styles] for i in range(4)) if affine else (None, None, None, None)
         dy = _rv(dy)
         C = xa.shape[-1]
         present = sorted(set(styles_host)) if styles_host is not None else [0]
@@ -191,7 +192,7 @@ class _ResNormPair(Function):
 
         dga, dba, arena_a, _ = grads(pa)
         dgb, dbb, arena_b, _ = grads(pb)
-        dxa, dxb = ops.instnorm_pair_bwd(dy, y, xa, xb, B, S, sa, sb, styles_dev, ga, gb, dga, dba, dgb, dbb, slope=slope, eps=eps)
+        dxa, dxb = ops.instnorm_pair_bwd(dy, None, xa, xb, B, S, sa, sb, styles_dev, ga, gb, dga, dba, dgb, dbb, slope=slope, eps=eps, betas_a=ba, betas_b=bb)
         pg = []
         if affine:
             for dg_, db_, ar in ((dga, dba, arena_a), (dgb, dbb, arena_b)):

@@ -38,7 +38,7 @@ InstnormPairBwd = _struct("InstnormPairBwd", [("dy", vp), ("lddy", i64), ("y", v
                                               ("dxa", vp), ("lddxa", i64), ("dxb", vp), ("lddxb", i64), ("B", i32), ("S", i32), ("C", i32), ("dtype", i32),
                                               ("stat_a", vp), ("stat_b", vp), ("eps", f32), ("dstat_a", vp), ("dstat_b", vp), ("styles", vp),
                                               ("num_styles", i32), ("gamma_a", fp4), ("gamma_b", fp4), ("dgamma_a", fp4), ("dbeta_a", fp4),
-                                              ("dgamma_b", fp4), ("dbeta_b", fp4), ("slope", f32)])
+                                              ("dgamma_b", fp4), ("dbeta_b", fp4), ("slope", f32), ("beta_a", fp4), ("beta_b", fp4)])
 LayernormFwd = _struct("LayernormFwd", [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32),
                                         ("dtype", i32), ("eps", f32), ("gamma", vp), ("beta", vp), ("mean", vp), ("rstd", vp)])
 LayernormBwd = _struct("LayernormBwd", [("dy", vp), ("lddy", i64), ("x", vp), ("ldx", i64), ("dx", vp), ("lddx", i64),

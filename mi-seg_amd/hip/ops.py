@@ -169,18 +169,20 @@ def instnorm_bwd(dy, y, x, B, S, stat, styles, gammas, dgammas, dbetas, act=L.AC
     return dx, dres
 
 
-def instnorm_pair_bwd(dy, y, xa, xb, B, S, stat_a, stat_b, styles, gammas_a, gammas_b, dgammas_a, dbetas_a, dgammas_b, dbetas_b, slope=0.01, eps=1e-5):
-    """backward of LeakyReLU(norm_a(xa) + norm_b(xb)): (dxa, dxb) in one reduction + one apply launch"""
+def instnorm_pair_bwd(dy, y, xa, xb, B, S, stat_a, stat_b, styles, gammas_a, gammas_b, dgammas_a, dbetas_a, dgammas_b, dbetas_b, slope=0.01, eps=1e-5,
+                      betas_a=None, betas_b=None):
+    """backward of LeakyReLU(norm_a(xa) + norm_b(xb)): (dxa, dxb) in one reduction + one apply launch.
+    y=None: the kernels recompute the activation's sign from xa / xb (needs the betas of affine norms)."""
     ld, n, Cc = rows(xa)
     dxa = torch.empty(xa.shape, dtype=xa.dtype, device=xa.device)
     dxb = torch.empty(xb.shape, dtype=xb.dtype, device=xb.device)
     nb = L.load().miseg_instnorm_stat_bytes(B, Cc) // 8
     dsa, dsb = STAT_POOL.take(nb, xa.device), STAT_POOL.take(nb, xa.device)
     ns = len(gammas_a) if gammas_a is not None else 1
-    p = L.InstnormPairBwd(_ptr(dy), rows(dy)[0], _ptr(y), rows(y)[0], _ptr(xa), ld, _ptr(xb), rows(xb)[0], _ptr(dxa), rows(dxa)[0], _ptr(dxb), rows(dxb)[0],
+    p = L.InstnormPairBwd(_ptr(dy), rows(dy)[0], _ptr(y), rows(y)[0] if y is not None else 0, _ptr(xa), ld, _ptr(xb), rows(xb)[0], _ptr(dxa), rows(dxa)[0], _ptr(dxb), rows(dxb)[0],
                           B, S, Cc, _dt(xa), _ptr(stat_a), _ptr(stat_b), eps, _ptr(dsa), _ptr(dsb), _ptr(styles), ns,
                           _style_arrays(gammas_a, ns), _style_arrays(gammas_b, ns), _style_arrays(dgammas_a, ns), _style_arrays(dbetas_a, ns),
-                          _style_arrays(dgammas_b, ns), _style_arrays(dbetas_b, ns), slope)
+                          _style_arrays(dgammas_b, ns), _style_arrays(dbetas_b, ns), slope, _style_arrays(betas_a, ns), _style_arrays(betas_b, ns))
     _call("miseg_instnorm_pair_bwd", p)
     return dxa, dxb
 

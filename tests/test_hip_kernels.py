@@ -122,6 +122,15 @@ def test_instnorm_residual_pair(dtype, B, S, C):
         for s in set(styles_h):
             assert rel_err(dg[k][s], gp[k][s].grad) < tol
             assert rel_err(db[k][s], bp[k][s].grad) < tol
+    # without y the kernels recompute the activation's sign from xa / xb with the forward's own expression: the same bits
+    dg2 = [[torch.zeros(C, device=DEV) for _ in range(2)] for _ in range(2)]
+    db2 = [[torch.zeros(C, device=DEV) for _ in range(2)] for _ in range(2)]
+    dxa2, dxb2 = ops.instnorm_pair_bwd(dy, None, xa, xb, B, S, sa, sb, styles, gam[0], gam[1], dg2[0], db2[0], dg2[1], db2[1], slope=0.01,
+                                       betas_a=bet[0], betas_b=bet[1])
+    assert torch.equal(dxa2, dxa) and torch.equal(dxb2, dxb)
+    for k in range(2):
+        for s in set(styles_h):
+            assert rel_err(dg2[k][s], dg[k][s]) < 1e-6 and rel_err(db2[k][s], db[k][s]) < 1e-6
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
