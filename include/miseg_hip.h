@@ -167,8 +167,14 @@ typedef struct {
   void* stat;        /* NT, optional: fp64 [16][1][N][2] (miseg_instnorm_stat_bytes(1, N), zero on entry): instance-norm statistics of the rounded
                       * output when all M rows are ONE sample and miseg_gemm_fuses_stat(p) says so (the tall-skinny bf16 path, N <= 96) -
                       * the linears / 1x1x1 convs whose output feeds an instance norm (swin_transformer_block.py:241-252, dynunet_block.py:118-124) */
+  /* NT, optional (scat_cout > 0): the GEMM of a ConvTranspose3d(k2, s2) (unetr_block.py:80-85) stores straight into the upsampled tensor.
+   * Rows are the voxels of a [.., scat_d, scat_h, scat_w] grid, the N = 8 * scat_cout columns are (j, co) with j = 4 jd + 2 jh + jw; element
+   * (voxel (d,h,w), j, co) goes to row (2d+jd, 2h+jh, 2w+jw) of the [.., 2 scat_d, 2 scat_h, 2 scat_w] grid, column co, of C (row stride ldc -
+   * e.g. the left half of a concat buffer).  Only where miseg_gemm_fuses_scatter(p) says so. */
+  int scat_d, scat_h, scat_w, scat_cout;
 } miseg_gemm_params;
 int miseg_gemm_fuses_stat(const miseg_gemm_params* p);  /* 1: miseg_gemm(p) with p->stat set is supported for this problem */
+int miseg_gemm_fuses_scatter(const miseg_gemm_params* p);  /* 1: miseg_gemm(p) with the scat_* fields set is supported for this problem */
 int miseg_gemm_tn_splits(const miseg_gemm_params* p);   /* > 1: partial tiles [splits][M][N] fp32 in the workspace */
 size_t miseg_gemm_workspace_bytes(const miseg_gemm_params* p);
 int miseg_gemm(const miseg_gemm_params* p, miseg_stream_t stream);

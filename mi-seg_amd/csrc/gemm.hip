@@ -49,6 +49,8 @@ struct Epi {
   void* aux; int64_t ldaux;
   int mode;
   double* stat;      // streaming kernel, STAT instantiation: instance-norm statistics of the (rounded) output, one sample (M rows)
+  int sd, sh, sw, sco;   // streaming kernel, SCAT instantiation: rows are the voxels of a [.., sd, sh, sw] grid, columns are (j, co) with
+                         // j = 4 jd + 2 jh + jw: element (voxel, j, co) goes to row ((2d+jd), (2h+jh), (2w+jw)) of the doubled grid, column co
 };
 
 template <class TO>
@@ -234,7 +236,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_g;
 // a wave and are added once per workgroup to the replicated fp64 statistics buffer of the instance norm that consumes the output
 // (proj + residual and fc2 + residual feed norm2 / the next block's norm1, the 1x1x1 shortcut conv feeds norm3): no separate pass.
 template <int K16, bool GELU, int NCH = 12 /* n-tiles per accumulator chunk: fewer for the long rows (K >= 288), whose A fragments fill the registers */,
-          bool STAT = false>
+          bool STAT = false, bool SCAT = false>
 __global__ void __launch_bounds__(256, 2) gemm_nt_stream_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ W, int64_t ldw,
                                                                 bf16* __restrict__ C, int64_t ldc, int M, int N, Epi epi) {
   const float* bias = epi.bias;
@@ -299,6 +301,11 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_stream_kernel(const bf16* __re
         const int row = tile * 32 + mt * 16 + fi;
         if (row < M) {
           bf16* crow = C + (int64_t)row * ldc;
+          int64_t srow = 0;      // SCAT: row of voxel (2d, 2h, 2w) in the doubled grid
+          if constexpr (SCAT) {
+            const int w = row % epi.sw, t1 = row / epi.sw, h = t1 % epi.sh, t2 = t1 / epi.sh;      // t2 = b * sd + d
+            srow = ((int64_t)t2 * 2 * (2 * epi.sh) + 2 * h) * (2 * epi.sw) + 2 * w;
+          }
 #pragma unroll
           for (int j = 0; j < NCH; ++j) {
             if (j < ncnt) {
@@ -306,7 +313,13 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_stream_kernel(const bf16* __re
               const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbias + n);
               const f32x4 v = epi_vec4_bf16(acc[mt][j] + b4, row, n, epi, GELU);
               const bf16x4 o4 = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-              *reinterpret_cast<bf16x4*>(crow + n) = o4;
+              if constexpr (SCAT) {
+                const int jj = n / epi.sco, co = n - jj * epi.sco;
+                const int64_t drow = srow + ((int64_t)(jj >> 2) * (2 * epi.sh) + ((jj >> 1) & 1)) * (2 * epi.sw) + (jj & 1);
+                *reinterpret_cast<bf16x4*>(C + drow * ldc + co) = o4;
+              } else {
+                *reinterpret_cast<bf16x4*>(crow + n) = o4;
+              }
               if constexpr (STAT) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const float q = (float)o4[r]; ssum[j][r] += q; ssq[j][r] = fmaf(q, q, ssq[j][r]); }
@@ -725,6 +738,15 @@ extern "C" int miseg_gemm_fuses_stat(const miseg_gemm_params* p) {
          p->M >= 4096 && lds <= 96 * 1024 && al_a && al_b && ((uintptr_t)p->C % 8 == 0) && p->ldc % 4 == 0 && epi_vec_ok;
 }
 
+extern "C" int miseg_gemm_fuses_scatter(const miseg_gemm_params* p) {
+  if (!p || p->ta || p->tb || p->dtype != MISEG_BF16 || p->out_dtype != MISEG_BF16 || p->scat_cout <= 0) return 0;
+  const size_t lds = (size_t)p->N * (p->K * 2 + 16) + (size_t)p->N * 4;
+  const bool al_a = ((uintptr_t)p->A % 16 == 0) && (p->lda % 8 == 0), al_b = ((uintptr_t)p->B % 16 == 0) && (p->ldb % 8 == 0);
+  return p->split_k <= 1 && !p->accumulate && p->act == MISEG_ACT_NONE && !p->res && !p->epi_mode && !p->stat && (p->K == 48 || p->K == 96) &&
+         p->N == 8 * p->scat_cout && p->scat_cout % 4 == 0 && p->N % 16 == 0 && p->scat_d > 0 && p->scat_h > 0 && p->scat_w > 0 &&
+         p->M % (p->scat_d * p->scat_h * p->scat_w) == 0 && p->M >= 4096 && lds <= 96 * 1024 && al_a && al_b && ((uintptr_t)p->C % 8 == 0) && p->ldc % 4 == 0;
+}
+
 extern "C" size_t miseg_gemm_workspace_bytes(const miseg_gemm_params* p) {
   TnStreamPlan pl;
   if (!p || !tn_stream_plan(p, &pl) || pl.splits <= 1) return 0;
@@ -732,6 +754,7 @@ extern "C" size_t miseg_gemm_workspace_bytes(const miseg_gemm_params* p) {
 }
 
 extern "C" int miseg_gemm_fuses_stat(const miseg_gemm_params* p);
+extern "C" int miseg_gemm_fuses_scatter(const miseg_gemm_params* p);
 
 template <class T, class TO>
 static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
@@ -743,8 +766,9 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
   if (split > 1 && !f32out) return set_error(MISEG_E_BADARG, "gemm: split_k needs fp32 output");
   if (p->accumulate && !f32out) return set_error(MISEG_E_BADARG, "gemm: accumulate needs fp32 output");
   int mode = split > 1 ? 2 : (p->accumulate ? 1 : 0);
-  const Epi epi{p->bias, p->act, p->res, p->ldres, p->aux, p->ldaux, p->epi_mode, (double*)p->stat};
+  const Epi epi{p->bias, p->act, p->res, p->ldres, p->aux, p->ldaux, p->epi_mode, (double*)p->stat, p->scat_d, p->scat_h, p->scat_w, p->scat_cout};
   const bool epi_vec_ok = (!p->res || (((uintptr_t)p->res % 8 == 0) && p->ldres % 4 == 0)) && (!p->epi_mode || (((uintptr_t)p->aux % 8 == 0) && p->ldaux % 4 == 0));
+  if (p->scat_cout && !miseg_gemm_fuses_scatter(p)) return set_error(MISEG_E_UNSUPPORTED, "gemm: scattered (transposed-conv) store on this shape / path (ask miseg_gemm_fuses_scatter first)");
   if (p->stat && !miseg_gemm_fuses_stat(p)) return set_error(MISEG_E_UNSUPPORTED, "gemm: fused statistics on this shape / path (ask miseg_gemm_fuses_stat first)");
   if (p->ta == 0 && p->tb == 0) {
     if ((p->res || p->epi_mode) && (split > 1 || p->accumulate)) return set_error(MISEG_E_BADARG, "gemm: residual / auxiliary epilogue with split_k or accumulate");
@@ -791,6 +815,19 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
                          al_a && al_b && ((uintptr_t)p->C % 8 == 0) && p->ldc % 4 == 0 && epi_vec_ok;
       const bool stat_ok = st_ok && p->act == MISEG_ACT_NONE && p->N <= 96 && (p->K == 48 || p->K == 96 || p->K == 192);
       if (p->stat && !stat_ok) return set_error(MISEG_E_UNSUPPORTED, "gemm: fused statistics on this shape / path (ask miseg_gemm_fuses_stat first)");
+      if (p->scat_cout) {        // miseg_gemm_fuses_scatter held: st_ok, K in {48, 96}
+        const int mtiles = cdiv(p->M, 32);
+        int blocks = cdiv(mtiles, 4);
+        const int cap = lds > 80 * 1024 ? 256 : 512;
+        if (blocks > cap) blocks = cap;
+#define SC_CASE(k16)                                                                                                                         \
+  (void)hipFuncSetAttribute((const void*)gemm_nt_stream_kernel<k16, false, 12, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+  gemm_nt_stream_kernel<k16, false, 12, false, true><<<blocks, 256, lds, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, epi)
+        if (p->K == 48) { SC_CASE(3); } else { SC_CASE(6); }
+#undef SC_CASE
+        MISEG_LAUNCH_CHECK("gemm_nt_stream(scatter)");
+        return MISEG_OK;
+      }
       if (st_ok && p->stat) {
         const int mtiles = cdiv(p->M, 32);
         int blocks = cdiv(mtiles, 4);

@@ -650,7 +650,6 @@ class _UpCat(Function):
         B, d, h, w = x.shape[0], x.shape[1], x.shape[2], x.shape[3]
         dev = x.device
         wf = ops.cast_matrix(weight, x.dtype, transpose=True, regroup=(8, Cout))     # [(j,co)][ci]
-        y8 = ops.gemm_nt(x, wf)
         width = 2 * Cout if skip is not None else Cout
         # a skip that its producer already wrote into the right half of a concat buffer (`concat_buffer`) needs no copy
         cat = getattr(skip, "_miseg_cat", None) if skip is not None else None
@@ -658,7 +657,9 @@ class _UpCat(Function):
                   and skip.data_ptr() == cat.data_ptr() + Cout * cat.element_size() and skip.stride(-2) == width)
         if not placed:
             cat = torch.empty(B, 2 * d, 2 * h, 2 * w, width, dtype=x.dtype, device=dev)
-        ops.channel_to_space(y8, STD_OFFSETS, (B, 2 * d, 2 * h, 2 * w, Cout), out=cat[..., :Cout])
+        # the tall layers store the 2x2x2 scatter straight from the GEMM's epilogue; the others go through [voxels, 8*Cout]
+        if not ops.gemm_nt_scatter(x, wf, cat[..., :Cout], (B, d, h, w)):
+            ops.channel_to_space(ops.gemm_nt(x, wf), STD_OFFSETS, (B, 2 * d, 2 * h, 2 * w, Cout), out=cat[..., :Cout])
         if skip is not None and not placed:
             ops.copy2d(skip, cat[..., Cout:])
         ctx.save_for_backward(x, weight)

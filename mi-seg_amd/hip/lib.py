@@ -47,7 +47,8 @@ LayernormBwd = _struct("LayernormBwd", [("dy", vp), ("lddy", i64), ("x", vp), ("
 Gemm = _struct("Gemm", [("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32),
                         ("K", i32), ("ta", i32), ("tb", i32), ("dtype", i32), ("out_dtype", i32), ("bias", vp), ("act", i32),
                         ("accumulate", i32), ("split_k", i32), ("workspace", vp), ("res", vp), ("ldres", i64), ("aux", vp), ("ldaux", i64),
-                        ("epi_mode", i32), ("defer_reduce", i32), ("stat", vp)])
+                        ("epi_mode", i32), ("defer_reduce", i32), ("stat", vp), ("scat_d", i32), ("scat_h", i32), ("scat_w", i32),
+                        ("scat_cout", i32)])
 TnReduceDesc = _struct("TnReduceDesc", [("partial", vp), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32), ("splits", i32), ("block0", i32)])
 ColsumDesc = _struct("ColsumDesc", [("x", vp), ("ldx", i64), ("rows", i64), ("out", vp), ("C", i32), ("block0", i32)])
 GemmTnDesc = _struct("GemmTnDesc", [("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32), ("K", i32), ("pad_", i32)])
@@ -108,6 +109,7 @@ PROTOS = {
     "miseg_layernorm_fwd": (i32, [C.POINTER(LayernormFwd), vp]),
     "miseg_layernorm_bwd": (i32, [C.POINTER(LayernormBwd), vp]),
     "miseg_gemm_fuses_stat": (i32, [C.POINTER(Gemm)]),
+    "miseg_gemm_fuses_scatter": (i32, [C.POINTER(Gemm)]),
     "miseg_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(Gemm)]),
     "miseg_gemm": (i32, [C.POINTER(Gemm), vp]),
     "miseg_permute3": (i32, [vp, vp, i32, i32, i32, i64, i64, i64, i32, vp]),

@@ -249,6 +249,24 @@ def gemm_nt(a, w, bias=None, act=L.ACT_NONE, out=None, out_dtype=None, split_k=1
     return out
 
 
+def gemm_nt_scatter(a, w, dst, grid):
+    """The GEMM of a ConvTranspose3d(k2, s2) with its 2x2x2 scatter as the store: a = the voxels of `grid` = (B, d, h, w) as rows [.., Cin],
+    w = [(j, co)][ci] (j = 4 jd + 2 jh + jw), dst = rows view [B, 2d, 2h, 2w, co] (e.g. the left half of a concat buffer).
+    Returns False where the kernel path has no scattered store (caller: gemm_nt + channel_to_space)."""
+    lda, M, K = rows(a)
+    N, Kw = w.shape
+    ldc, Md, Cout = rows(dst)
+    B, d, h, wd = grid
+    if not (Kw == K and w.is_contiguous() and w.dtype == a.dtype and dst.dtype == a.dtype and N == 8 * Cout and Md == 8 * M and M == B * d * h * wd):
+        raise ValueError("gemm_nt_scatter: operand shapes")
+    p = L.Gemm(_ptr(a), lda, _ptr(w), K, _ptr(dst), ldc, M, N, K, 0, 0, _dt(a), _dt(dst), None, L.ACT_NONE, 0, 1, None, None, 0, None, 0, 0, 0, None,
+               d, h, wd, Cout)
+    if not L.load().miseg_gemm_fuses_scatter(C.byref(p)):
+        return False
+    _call("miseg_gemm", p)
+    return True
+
+
 def gemm_tn(a, b, out=None, accumulate=False, split_k=0):
     """out[M,N] (fp32) (+)= a[K,M]^T @ b[K,N]; a, b row views sharing the row count K (weight gradients)."""
     lda, K, M = rows(a)

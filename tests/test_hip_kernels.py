@@ -208,6 +208,30 @@ def test_gemm_nt_streaming_statistics(M, N, K, with_res):
     assert ops.pop_gemm_stat(y3) is None
 
 
+@pytest.mark.parametrize("grid,Cin,Cout", [((1, 17, 16, 16), 48, 48), ((2, 12, 14, 13), 96, 48), ((1, 16, 16, 16), 48, 24), ((1, 6, 6, 6), 96, 48)])
+def test_gemm_nt_scatter_is_the_transposed_conv_store(grid, Cin, Cout):
+    """the ConvTranspose3d(k2, s2) GEMM with the 2x2x2 scatter as its store (left half of a concat buffer) against the two-step path
+    (GEMM to [voxels, 8*Cout], then channel_to_space): the same bits; a grid below the streaming path's size reports False."""
+    ops = _ops()
+    from mi_seg_amd.hip.functional import STD_OFFSETS
+    dtype = torch.bfloat16
+    B, d, h, w = grid
+    x = rnd(B, d, h, w, Cin, dtype=dtype, seed=61)
+    wf = rnd(8 * Cout, Cin, dtype=dtype, seed=62) / Cin ** 0.5
+    cat = torch.full((B, 2 * d, 2 * h, 2 * w, 2 * Cout), 7.0, dtype=dtype, device=DEV)
+    done = ops.gemm_nt_scatter(x, wf, cat[..., :Cout], grid)
+    assert done == (B * d * h * w >= 4096)
+    if not done:
+        return
+    ref = torch.full_like(cat, 7.0)
+    ops.channel_to_space(ops.gemm_nt(x, wf), STD_OFFSETS, (B, 2 * d, 2 * h, 2 * w, Cout), out=ref[..., :Cout])
+    assert torch.equal(cat, ref)                      # the right half (the skip's place) untouched
+    # and against the definition: out[b, 2d+jd, 2h+jh, 2w+jw, co] = sum_ci x[b,d,h,w,ci] * wf[(j,co), ci]
+    y = (x.float().reshape(-1, Cin) @ wf.float().t()).reshape(B, d, h, w, 2, 2, 2, Cout)
+    y = y.permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(B, 2 * d, 2 * h, 2 * w, Cout)
+    assert rel_err(cat[..., :Cout], y) < TOL[dtype]
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_nt_rank1(dtype):
     """K == 1 (the stem block's 1x1x1 shortcut on a one-channel image): the outer-product kernel"""
