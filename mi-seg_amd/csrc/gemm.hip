@@ -224,6 +224,49 @@ __global__ void __launch_bounds__(256) gemm_nt_k1_kernel(const T* __restrict__ A
   }
 }
 
+// the same with the instance-norm statistics of the rounded output (one sample = all M rows, N <= 128, no bias needed by the caller but
+// honoured): a thread keeps one 16-byte column group, walks rows, and its partial sums meet in LDS; one fp64 atomic per column and workgroup
+template <class T>
+__global__ void __launch_bounds__(256) gemm_nt_k1_stat_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ W, int64_t ldw, T* __restrict__ C, int64_t ldc,
+                                                              int M, int N, const float* __restrict__ bias, double* __restrict__ stat) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int VN = Vec16<T>::N;
+  __shared__ float red[2][256][VN + 1];
+  const int nv = N / VN, rpt = 256 / nv;          // column groups per row, rows per block pass
+  const int cg = threadIdx.x % nv, rl = threadIdx.x / nv;
+  const bool live = rl < rpt;
+  float wv[VN], bv[VN], ssum[VN], ssq[VN];
+#pragma unroll
+  for (int e = 0; e < VN; ++e) {
+    wv[e] = to_f32(W[(int64_t)(cg * VN + e) * ldw]);
+    bv[e] = bias ? bias[cg * VN + e] : 0.f;
+    ssum[e] = ssq[e] = 0.f;
+  }
+  if (live) {
+    for (int64_t m = (int64_t)blockIdx.x * rpt + rl; m < M; m += (int64_t)gridDim.x * rpt) {
+      const float a = to_f32(A[m * lda]);
+      VT o;
+#pragma unroll
+      for (int e = 0; e < VN; ++e) {
+        o[e] = from_f32<T>(a * wv[e] + bv[e]);
+        const float q = to_f32(o[e]);
+        ssum[e] += q;
+        ssq[e] = fmaf(q, q, ssq[e]);
+      }
+      *reinterpret_cast<VT*>(C + m * ldc + cg * VN) = o;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VN; ++e) { red[0][threadIdx.x][e] = ssum[e]; red[1][threadIdx.x][e] = ssq[e]; }
+  __syncthreads();
+  for (int o = threadIdx.x; o < 2 * N; o += 256) {
+    const int k = o / N, col = o - k * N, g = col / VN, e = col - g * VN;
+    float tot = 0.f;
+    for (int r = 0; r < rpt; ++r) tot += red[k][r * nv + g][e];
+    atomicAdd(stat + ((int64_t)(blockIdx.x & 15) * N + col) * 2 + k, (double)tot);       // [16 replicas][B = 1][N][2]
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ NT, streaming
 // Tall activations x small weight (the Swin linears of the high-resolution stages, 1x1x1 convs, the ConvTranspose GEMM):
 // M ~ 1e5..1e6 rows, K <= 192, N <= ~400.  HBM-bound: every byte of A is read ONCE (all N columns are produced by the
@@ -730,6 +773,11 @@ static bool tn_stream_plan(const miseg_gemm_params* p, TnStreamPlan* pl) {
 }
 
 extern "C" int miseg_gemm_fuses_stat(const miseg_gemm_params* p) {
+  if (p && !p->ta && !p->tb && p->dtype == p->out_dtype && p->K == 1) {      // the rank-1 kernel (stem shortcut), either dtype
+    const int n16 = p->dtype == MISEG_BF16 ? 8 : 4;
+    return p->split_k <= 1 && !p->accumulate && p->act == MISEG_ACT_NONE && !p->res && !p->epi_mode && p->N % n16 == 0 && p->N <= 128 &&
+           ((uintptr_t)p->C % 16 == 0) && p->ldc % n16 == 0 && !p->scat_cout;
+  }
   if (!p || p->ta || p->tb || p->dtype != MISEG_BF16 || p->out_dtype != MISEG_BF16) return 0;
   const size_t lds = (size_t)p->N * (p->K * 2 + 16) + (size_t)p->N * 4;
   const bool al_a = ((uintptr_t)p->A % 16 == 0) && (p->lda % 8 == 0), al_b = ((uintptr_t)p->B % 16 == 0) && (p->ldb % 8 == 0);
@@ -786,6 +834,13 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
     if constexpr (std::is_same<T, TO>::value) {
       if (p->K == 1 && split == 1 && !p->accumulate && p->act == MISEG_ACT_NONE && !p->res && !p->epi_mode && p->N % N16 == 0 && ((uintptr_t)p->C % 16 == 0) &&
           p->ldc % N16 == 0) {
+        if (p->stat) {
+          int sb = cdiv(p->M, 256 / (p->N / N16));
+          if (sb > 2048) sb = 2048;
+          gemm_nt_k1_stat_kernel<T><<<sb, 256, 0, s>>>((const T*)p->A, p->lda, (const T*)p->B, p->ldb, (T*)p->C, p->ldc, p->M, p->N, p->bias, (double*)p->stat);
+          MISEG_LAUNCH_CHECK("gemm_nt_k1(stat)");
+          return MISEG_OK;
+        }
         int64_t blocks = ((int64_t)p->M * (p->N / N16) + 255) / 256;
         if (blocks > 8192) blocks = 8192;
         gemm_nt_k1_kernel<T><<<(int)blocks, 256, 0, s>>>((const T*)p->A, p->lda, (const T*)p->B, p->ldb, (T*)p->C, p->ldc, p->M, p->N, p->bias);

@@ -240,6 +240,15 @@ def test_gemm_nt_rank1(dtype):
     yr = a.float() @ w.float().t()
     assert rel_err(ops.gemm_nt(a, w), yr) < TOL[dtype]
     assert rel_err(ops.gemm_nt(a, w, bias), yr + bias) < TOL[dtype]
+    # with the instance-norm statistics of the rounded output from the same launch (the stem block's shortcut feeds norm3)
+    ops.begin_step()
+    for b_ in (None, bias):
+        y = ops.gemm_nt(a, w, b_, want_stat=True)
+        st = ops.pop_gemm_stat(y)
+        assert st is not None and torch.equal(y, ops.gemm_nt(a, w, b_))
+        yd = y.double()
+        want = torch.stack([yd.sum(0), (yd * yd).sum(0)], -1)
+        assert torch.allclose(st.sum(0)[0], want, rtol=2e-6, atol=1e-3)
 
 
 @pytest.mark.parametrize("M,N,K", [(216, 1536, 384), (216, 384, 1536), (27, 3072, 768), (1728, 768, 192), (1727, 192, 768), (215, 1152, 384), (100, 16, 32),
