@@ -71,6 +71,10 @@ typedef struct {
    * on the fly with its own statistics (res_stat, layout as stat) and affine rows: y = act(norm(x) + norm_res(res)).  miseg_instnorm_apply only. */
   const void* res_stat;
   const float* res_gamma[MISEG_MAX_STYLES]; const float* res_beta[MISEG_MAX_STYLES];
+  /* optional, with res_stat and res == NULL: the shortcut branch is the 1x1x1 convolution of a ONE-channel image (the stem block,
+   * dynunet_block.py:87-97) and is never stored: res[row][c] = round(r1x[row] * r1w[c]) in the compute dtype.  r1x: [B*S] rows of one
+   * element (row stride ldr1x), r1w: [C] in the compute dtype; res_stat from miseg_rank1_stats.  miseg_instnorm_apply only. */
+  const void* r1x; int64_t ldr1x; const void* r1w;
 } miseg_instnorm_apply_params;
 int miseg_instnorm_apply(const miseg_instnorm_apply_params* p, miseg_stream_t stream);
 /* statistics (into the zero-filled p->stat) + apply in one call; tensors of <= 512 rows per sample take ONE fused launch */
@@ -115,6 +119,10 @@ typedef struct {
   float slope;
   /* y == NULL: the activation's sign is recomputed from xa / xb (then the betas of both norms are read; NULL rows = 0) */
   const float* beta_a[MISEG_MAX_STYLES]; const float* beta_b[MISEG_MAX_STYLES];
+  /* rank-1 shortcut (the stem block, dynunet_block.py:87-97 with one input channel): xb[row][c] = round(r1x[row] * r1w[c]) is not stored
+   * (xb = dxb = y = NULL); r1x: [B*S] rows of one element (row stride ldr1x), r1w: [C] in the compute dtype; the weight gradient of that
+   * 1x1x1 convolution, sum over rows of dxb[row][c] * r1x[row], is ADDED to r1dw [C] fp32 */
+  const void* r1x; int64_t ldr1x; const void* r1w; float* r1dw;
 } miseg_instnorm_pair_bwd_params;
 int miseg_instnorm_pair_bwd(const miseg_instnorm_pair_bwd_params* p, miseg_stream_t stream);
 
@@ -174,6 +182,10 @@ typedef struct {
   int scat_d, scat_h, scat_w, scat_cout;
 } miseg_gemm_params;
 int miseg_gemm_fuses_stat(const miseg_gemm_params* p);  /* 1: miseg_gemm(p) with p->stat set is supported for this problem */
+/* instance-norm statistics (layout of miseg_instnorm_stats, one sample = all M rows, zero on entry) of the rank-1 product
+ * round(x[m] * w[n]) WITHOUT storing it: the stem block's shortcut convolution (dynunet_block.py:87-97), consumed through the r1x / r1w
+ * fields of miseg_instnorm_apply / miseg_instnorm_pair_bwd.  x: [M] rows of one element (stride ldx), w: [N] (stride ldw), N <= 128 */
+int miseg_rank1_stats(const void* x, int64_t ldx, const void* w, int64_t ldw, int M, int N, int dtype, void* stat, miseg_stream_t stream);
 int miseg_gemm_fuses_scatter(const miseg_gemm_params* p);  /* 1: miseg_gemm(p) with the scat_* fields set is supported for this problem */
 int miseg_gemm_tn_splits(const miseg_gemm_params* p);   /* > 1: partial tiles [splits][M][N] fp32 in the workspace */
 size_t miseg_gemm_workspace_bytes(const miseg_gemm_params* p);

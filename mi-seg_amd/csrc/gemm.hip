@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(256) gemm_nt_k1_stat_kernel(const T* __restric
         ssum[e] += q;
         ssq[e] = fmaf(q, q, ssq[e]);
       }
-      *reinterpret_cast<VT*>(C + m * ldc + cg * VN) = o;
+      if (C) *reinterpret_cast<VT*>(C + m * ldc + cg * VN) = o;       // C == nullptr: statistics only (miseg_rank1_stats)
     }
   }
 #pragma unroll
@@ -784,6 +784,21 @@ extern "C" int miseg_gemm_fuses_stat(const miseg_gemm_params* p) {
   const bool epi_vec_ok = (!p->res || (((uintptr_t)p->res % 8 == 0) && p->ldres % 4 == 0)) && (!p->epi_mode || (((uintptr_t)p->aux % 8 == 0) && p->ldaux % 4 == 0));
   return p->split_k <= 1 && !p->accumulate && p->act == MISEG_ACT_NONE && (p->K == 48 || p->K == 96 || p->K == 192) && p->N % 16 == 0 && p->N <= 96 &&
          p->M >= 4096 && lds <= 96 * 1024 && al_a && al_b && ((uintptr_t)p->C % 8 == 0) && p->ldc % 4 == 0 && epi_vec_ok;
+}
+
+extern "C" int miseg_rank1_stats(const void* x, int64_t ldx, const void* w, int64_t ldw, int M, int N, int dtype, void* stat, miseg_stream_t stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  MISEG_REQUIRE(x && w && stat && M > 0 && N > 0 && N <= 128, MISEG_E_BADARG, "rank1_stats: bad args");
+  return dispatch_dtype(dtype, [&](auto* tag) -> int {
+    typedef typename std::remove_pointer<decltype(tag)>::type T;
+    constexpr int N16 = Vec16<T>::N;
+    MISEG_REQUIRE(N % N16 == 0, MISEG_E_UNSUPPORTED, "rank1_stats: N %d is not a multiple of %d", N, N16);
+    int sb = cdiv(M, 256 / (N / N16));
+    if (sb > 2048) sb = 2048;
+    gemm_nt_k1_stat_kernel<T><<<sb, 256, 0, s>>>((const T*)x, ldx, (const T*)w, ldw, (T*)nullptr, 0, M, N, nullptr, (double*)stat);
+    MISEG_LAUNCH_CHECK("rank1_stats");
+    return MISEG_OK;
+  });
 }
 
 extern "C" int miseg_gemm_fuses_scatter(const miseg_gemm_params* p) {

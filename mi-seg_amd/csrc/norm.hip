@@ -156,9 +156,12 @@ template <class T, int VEC>
 __global__ void __launch_bounds__(NORM_THREADS) instnorm_apply_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ res, int64_t ldres,
                                                                       T* __restrict__ y, int64_t ldy, int S, int C, int cv, int tx_n, int ty_n, int rpb,
                                                                       const double* __restrict__ stat, float eps, const int32_t* __restrict__ styles,
-                                                                      StylePtrs sp, int act, float slope, const double* __restrict__ rstat, StylePtrs rsp) {
+                                                                      StylePtrs sp, int act, float slope, const double* __restrict__ rstat, StylePtrs rsp,
+                                                                      const T* __restrict__ r1x, int64_t ldr1x, const T* __restrict__ r1w) {
   // rstat != nullptr: `res` is the RAW input of a second (shortcut) instance norm with its own statistics / affine rows and is
   // normalised on the fly: y = act(norm(x) + norm_r(res)) in one pass (UnetResBlock with a 1x1x1 shortcut conv, dynunet_block.py:118-124)
+  // r1x != nullptr (with rstat, res == nullptr): that raw input is the 1x1x1 convolution of a ONE-channel image (the stem block) and is
+  // not stored at all: res[row][c] = round(r1x[row] * r1w[c]), formed here exactly as the rank-1 GEMM would have rounded it
   extern __shared__ __attribute__((aligned(16))) double sums[];
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
@@ -198,15 +201,24 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_apply_kernel(const T* _
       rsh[i] = (rb ? rb[ch] : 0.f) - m * rsc[i];
     }
   }
+  float r1wv[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) r1wv[i] = r1x ? to_f32(r1w[c * VEC + i]) : 0.f;
 #pragma unroll 4
   for (int r = r0 + ty; r < r1; r += ty_n) {
     RowVec<T, VEC> v, o;
     v.load(x + (boff + r) * ldx + c * VEC);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) o.v[i] = fmaf(v.v[i], sc[i], sh[i]);
-    if (res) {
+    if (res || r1x) {
       RowVec<T, VEC> rr;
-      rr.load(res + (boff + r) * ldres + c * VEC);
+      if (res) {
+        rr.load(res + (boff + r) * ldres + c * VEC);
+      } else {
+        const float xs = to_f32(r1x[(boff + r) * ldr1x]);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) rr.v[i] = to_f32(from_f32<T>(xs * r1wv[i]));
+      }
 #pragma unroll
       for (int i = 0; i < VEC; ++i) o.v[i] += fmaf(rr.v[i], rsc[i], rsh[i]);
     }
@@ -413,7 +425,9 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_pair_bwd_reduce_kernel(
                                                                                 int S, int C, int cv, int tx_n, int ty_n, int rpb,
                                                                                 const double* __restrict__ stat_a, const double* __restrict__ stat_b, float eps,
                                                                                 float slope, double* __restrict__ dstat_a, double* __restrict__ dstat_b,
-                                                                                const int32_t* __restrict__ styles, StylePtrs spa, StylePtrs spb) {
+                                                                                const int32_t* __restrict__ styles, StylePtrs spa, StylePtrs spb,
+                                                                                const T* __restrict__ r1x, int64_t ldr1x, const T* __restrict__ r1w) {
+  // r1x != nullptr: xb is not stored - xb[row][c] = round(r1x[row] * r1w[c]) (see instnorm_apply_kernel)
   // yact == nullptr: the LeakyReLU's sign is recomputed from the two inputs with the forward pass's own expression (instnorm_apply_kernel:
   // fmaf(xa, sc_a, sh_a) + fmaf(xb, sc_b, sh_b), identical operands) - one tensor less to read in both passes
   extern __shared__ __attribute__((aligned(16))) float red[];
@@ -437,6 +451,9 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_pair_bwd_reduce_kernel(
     const int ch = min(c * VEC + i, C - 1);
     pair_preact_coeffs(spa, spb, st, ch, ma[i], rsa[i], mb[i], rsb[i], zsa[i], zha[i], zsb[i], zhb[i]);
   }
+  float r1wv[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) r1wv[i] = r1x ? to_f32(r1w[min(c * VEC + i, C - 1)]) : 0.f;
   __syncthreads();
   if (ty < ty_n && c < cv) {
 #pragma unroll 4
@@ -445,7 +462,13 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_pair_bwd_reduce_kernel(
       g.load(dy + (boff + r) * lddy + c * VEC);
       if (yact) yv.load(yact + (boff + r) * ldy + c * VEC);
       va.load(xa + (boff + r) * ldxa + c * VEC);
-      vb.load(xb + (boff + r) * ldxb + c * VEC);
+      if (r1x) {
+        const float xs = to_f32(r1x[(boff + r) * ldr1x]);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) vb.v[i] = to_f32(from_f32<T>(xs * r1wv[i]));
+      } else {
+        vb.load(xb + (boff + r) * ldxb + c * VEC);
+      }
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         const float pre = yact ? yv.v[i] : pair_preact(va.v[i], zsa[i], zha[i], vb.v[i], zsb[i], zhb[i]);
@@ -468,7 +491,11 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_pair_bwd_apply_kernel(c
                                                                                int cv, int tx_n, int ty_n, int rpb, const double* __restrict__ stat_a,
                                                                                const double* __restrict__ stat_b, float eps, const int32_t* __restrict__ styles,
                                                                                StylePtrs spa, StylePtrs spb, float slope, const double* __restrict__ dstat_a,
-                                                                               const double* __restrict__ dstat_b, StyleGradPtrs gpa, StyleGradPtrs gpb) {
+                                                                               const double* __restrict__ dstat_b, StyleGradPtrs gpa, StyleGradPtrs gpb,
+                                                                               const T* __restrict__ r1x, int64_t ldr1x, const T* __restrict__ r1w,
+                                                                               float* __restrict__ r1dw) {
+  // r1x != nullptr: xb = round(r1x[row] * r1w[c]) is not stored (see instnorm_apply_kernel) and neither is its gradient: the only consumer
+  // is the weight gradient of that 1x1x1 convolution, dW[c] += sum over rows of round(dxb[row][c]) * r1x[row], reduced here
   extern __shared__ __attribute__((aligned(16))) double sums[];
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
@@ -494,7 +521,12 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_pair_bwd_apply_kernel(c
       }
     }
   }
-  if (ty >= ty_n || c >= cv) return;
+  const bool live = ty < ty_n && c < cv;
+  if (!live && !r1x) return;
+  float dwacc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) dwacc[i] = 0.f;
+  if (live) {
   const int r0 = chunk * rpb, r1 = min(S, r0 + rpb);
   const float* ga = spa.gamma[st];
   const float* gb = spb.gamma[st];
@@ -513,13 +545,23 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_pair_bwd_apply_kernel(c
     bqa[i] = (float)(da[(tx * VEC + i) * 2 + 1] * invS);
     bqb[i] = (float)(db[(tx * VEC + i) * 2 + 1] * invS);
   }
+  float r1wv[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) r1wv[i] = r1x ? to_f32(r1w[c * VEC + i]) : 0.f;
 #pragma unroll 4
   for (int r = r0 + ty; r < r1; r += ty_n) {
     RowVec<T, VEC> g, yv, va, vb, oa, ob;
     g.load(dy + (boff + r) * lddy + c * VEC);
     if (yact) yv.load(yact + (boff + r) * ldy + c * VEC);
     va.load(xa + (boff + r) * ldxa + c * VEC);
-    vb.load(xb + (boff + r) * ldxb + c * VEC);
+    float xs = 0.f;
+    if (r1x) {
+      xs = to_f32(r1x[(boff + r) * ldr1x]);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) vb.v[i] = to_f32(from_f32<T>(xs * r1wv[i]));
+    } else {
+      vb.load(xb + (boff + r) * ldxb + c * VEC);
+    }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       const float pre = yact ? yv.v[i] : pair_preact(va.v[i], zsa[i], zha[i], vb.v[i], zsb[i], zhb[i]);
@@ -528,7 +570,28 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_pair_bwd_apply_kernel(c
       ob.v[i] = scb[i] * (gi - aa[i] - (vb.v[i] - mb[i]) * rsb[i] * bqb[i]);
     }
     oa.store(dxa + (boff + r) * lddxa + c * VEC);
-    ob.store(dxb + (boff + r) * lddxb + c * VEC);
+    if (r1x) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) dwacc[i] = fmaf(to_f32(from_f32<T>(ob.v[i])), xs, dwacc[i]);
+    } else {
+      ob.store(dxb + (boff + r) * lddxb + c * VEC);
+    }
+  }
+  }
+  if (r1x) {     // every thread of the workgroup is here: column sums of dwacc over ty, one fp32 atomic per channel and workgroup
+    float* redf = reinterpret_cast<float*>(sums);
+    __syncthreads();       // the statistics in `sums` have been read by everyone
+    if (ty < ty_n) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) redf[(ty * tx_n + tx) * VEC + i] = dwacc[i];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < tx_n * VEC; e += NORM_THREADS) {
+      const int ch = blockIdx.z * tx_n * VEC + e;
+      float tot = 0.f;
+      for (int t = 0; t < ty_n; ++t) tot += redf[t * tx_n * VEC + e];
+      if (ch < C) atomicAdd(r1dw + ch, tot);
+    }
   }
 }
 
@@ -806,7 +869,8 @@ extern "C" int miseg_instnorm_apply(const miseg_instnorm_apply_params* p, miseg_
   MISEG_REQUIRE(p && p->x && p->y && p->stat, MISEG_E_BADARG, "instnorm_apply: null pointer");
   MISEG_REQUIRE(p->num_styles >= 1 && p->num_styles <= MISEG_MAX_STYLES, MISEG_E_BADARG, "instnorm_apply: num_styles %d", p->num_styles);
   MISEG_REQUIRE(p->act == MISEG_ACT_NONE || p->act == MISEG_ACT_LEAKY, MISEG_E_UNSUPPORTED, "instnorm_apply: act %d", p->act);
-  MISEG_REQUIRE(!p->res_stat || p->res, MISEG_E_BADARG, "instnorm_apply: res_stat without res");
+  MISEG_REQUIRE(!p->res_stat || p->res || p->r1x, MISEG_E_BADARG, "instnorm_apply: res_stat without res");
+  MISEG_REQUIRE(!p->r1x || (p->res_stat && !p->res && p->r1w), MISEG_E_BADARG, "instnorm_apply: r1x needs res_stat and r1w, and excludes res");
   return dispatch_dtype(p->dtype, [&](auto* tag) -> int {
     typedef typename std::remove_pointer<decltype(tag)>::type T;
     constexpr int V = Vec16<T>::N;
@@ -825,11 +889,11 @@ extern "C" int miseg_instnorm_apply(const miseg_instnorm_apply_params* p, miseg_
     if (g.vec == 1)
       instnorm_apply_kernel<T, 1><<<grid, NORM_THREADS, shd, stream>>>((const T*)p->x, p->ldx, (const T*)p->res, p->ldres, (T*)p->y, p->ldy, p->S, p->C, g.cv, g.tx,
                                                                       g.ty, g.rpb, (const double*)p->stat, p->eps, p->styles, sp, p->act, p->slope,
-                                                                      (const double*)p->res_stat, rsp);
+                                                                      (const double*)p->res_stat, rsp, (const T*)p->r1x, p->ldr1x, (const T*)p->r1w);
     else
       instnorm_apply_kernel<T, V><<<grid, NORM_THREADS, shd, stream>>>((const T*)p->x, p->ldx, (const T*)p->res, p->ldres, (T*)p->y, p->ldy, p->S, p->C, g.cv, g.tx,
                                                                       g.ty, g.rpb, (const double*)p->stat, p->eps, p->styles, sp, p->act, p->slope,
-                                                                      (const double*)p->res_stat, rsp);
+                                                                      (const double*)p->res_stat, rsp, (const T*)p->r1x, p->ldr1x, (const T*)p->r1w);
     MISEG_LAUNCH_CHECK("instnorm_apply");
     return MISEG_OK;
   });
@@ -928,14 +992,16 @@ extern "C" int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stre
 
 extern "C" int miseg_instnorm_pair_bwd(const miseg_instnorm_pair_bwd_params* p, miseg_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  MISEG_REQUIRE(p && p->dy && p->xa && p->xb && p->dxa && p->dxb && p->stat_a && p->stat_b && p->dstat_a && p->dstat_b, MISEG_E_BADARG,
-                "instnorm_pair_bwd: null pointer");
+  MISEG_REQUIRE(p && p->dy && p->xa && p->dxa && p->stat_a && p->stat_b && p->dstat_a && p->dstat_b, MISEG_E_BADARG, "instnorm_pair_bwd: null pointer");
+  MISEG_REQUIRE(p->r1x ? (p->r1w && p->r1dw && !p->xb && !p->dxb && !p->y) : (p->xb && p->dxb), MISEG_E_BADARG,
+                "instnorm_pair_bwd: either xb / dxb, or the rank-1 shortcut (r1x, r1w, r1dw; no y)");
   MISEG_REQUIRE(p->num_styles >= 1 && p->num_styles <= MISEG_MAX_STYLES, MISEG_E_BADARG, "instnorm_pair_bwd: num_styles %d", p->num_styles);
   return dispatch_dtype(p->dtype, [&](auto* tag) -> int {
     typedef typename std::remove_pointer<decltype(tag)>::type T;
     constexpr int V = Vec16<T>::N;
-    const int64_t ldor = p->lddy | (p->y ? p->ldy : 0) | p->ldxa | p->ldxb | p->lddxa | p->lddxb;
-    const bool al = aligned16(p->dy) && (!p->y || aligned16(p->y)) && aligned16(p->xa) && aligned16(p->xb) && aligned16(p->dxa) && aligned16(p->dxb) && ldor % V == 0;
+    const int64_t ldor = p->lddy | (p->y ? p->ldy : 0) | p->ldxa | (p->xb ? p->ldxb | p->lddxb : 0) | p->lddxa;
+    const bool al = aligned16(p->dy) && (!p->y || aligned16(p->y)) && aligned16(p->xa) && (!p->xb || (aligned16(p->xb) && aligned16(p->dxb))) && aligned16(p->dxa) &&
+                    ldor % V == 0 && (!p->r1x || p->C % V == 0);
     NormGeom g = norm_geom(p->S, p->C, al, V);
     StylePtrs spa, spb;
     StyleGradPtrs gpa, gpb;
@@ -949,17 +1015,20 @@ extern "C" int miseg_instnorm_pair_bwd(const miseg_instnorm_pair_bwd_params* p, 
     dim3 grid(g.chunks, p->B, g.ctiles);
     size_t sh = (size_t)g.ty * 2 * g.tx * g.vec * sizeof(float);
     if (sh < (size_t)4 * g.tx * g.vec * sizeof(double)) sh = (size_t)4 * g.tx * g.vec * sizeof(double);
-    const size_t shd = (size_t)8 * g.tx * g.vec * sizeof(double);
+    size_t shd = (size_t)8 * g.tx * g.vec * sizeof(double);
+    if (p->r1x && shd < (size_t)NORM_THREADS * g.vec * sizeof(float)) shd = (size_t)NORM_THREADS * g.vec * sizeof(float);
 #define PAIR_LAUNCH(VV)                                                                                                                                          \
     instnorm_pair_bwd_reduce_kernel<T, VV><<<grid, NORM_THREADS, sh, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->xa, p->ldxa,         \
                                                                                (const T*)p->xb, p->ldxb, p->S, p->C, g.cv, g.tx, g.ty, g.rpb,                    \
                                                                                (const double*)p->stat_a, (const double*)p->stat_b, p->eps, p->slope,            \
-                                                                               (double*)p->dstat_a, (double*)p->dstat_b, p->styles, spa, spb);                  \
+                                                                               (double*)p->dstat_a, (double*)p->dstat_b, p->styles, spa, spb,                   \
+                                                                               (const T*)p->r1x, p->ldr1x, (const T*)p->r1w);                                   \
     instnorm_pair_bwd_apply_kernel<T, VV><<<grid, NORM_THREADS, shd, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->xa, p->ldxa,         \
                                                                                (const T*)p->xb, p->ldxb, (T*)p->dxa, p->lddxa, (T*)p->dxb, p->lddxb, p->S, p->C, \
                                                                                g.cv, g.tx, g.ty, g.rpb, (const double*)p->stat_a, (const double*)p->stat_b,     \
                                                                                p->eps, p->styles, spa, spb, p->slope, (const double*)p->dstat_a,               \
-                                                                               (const double*)p->dstat_b, gpa, gpb);
+                                                                               (const double*)p->dstat_b, gpa, gpb, (const T*)p->r1x, p->ldr1x,                 \
+                                                                               (const T*)p->r1w, p->r1dw);
     if (g.vec == 1) { PAIR_LAUNCH(1) } else { PAIR_LAUNCH(V) }
 #undef PAIR_LAUNCH
     MISEG_LAUNCH_CHECK("instnorm_pair_bwd");

@@ -147,7 +147,10 @@ class _ResNormPair(Function):
     instance-norm backward passes (the first hands the activation-masked gradient to the second)."""
 
     @staticmethod
-    def forward(ctx, xa, xb, styles_dev, styles_host, num_styles, affine, slope, eps_a, eps_b, stat_a, stat_b, *params):
+    def forward(ctx, xa, xb, w1, styles_dev, styles_host, num_styles, affine, slope, eps_a, eps_b, stat_a, stat_b, *params):
+        """w1 (rank-1 mode, one sample): xb is the ONE-channel image [1, D, H, W, 1] and w1 the weight [C, 1, 1, 1, 1] of the 1x1x1 shortcut
+        convolution in front of norm_b (the stem block): the convolution's output round(xb * w1[c]) is formed inside the norm kernels and
+        never stored, neither is its gradient - the backward kernel reduces the weight gradient itself."""
         B = xa.shape[0]
         S = ops.rows(xa)[1] // B
         global _PENDING_OUT
@@ -159,11 +162,20 @@ class _ResNormPair(Function):
         if eps_a != eps_b:
             raise ValueError("the two norms of a residual pair must share eps")
         sa = stat_a if stat_a is not None else ops.instnorm_stats(xa, B, S)
-        sb = stat_b if stat_b is not None else ops.instnorm_stats(xb, B, S)
-        y = ops.instnorm_apply(xa, B, S, sa, styles_dev, ga, ba, res=xb, act=L.ACT_LEAKY, slope=slope, eps=eps_a, out=out, res_stat=sb,
-                               res_gammas=gb, res_betas=bb)
+        if w1 is not None:
+            if B != 1 or xb.shape[-1] != 1 or xb.requires_grad:
+                raise ValueError("rank-1 shortcut: one sample, a one-channel image without gradient")
+            wb = ops.cast_matrix(w1, xa.dtype)
+            sb = ops.rank1_stats(xb, wb)
+            y = ops.instnorm_apply(xa, B, S, sa, styles_dev, ga, ba, act=L.ACT_LEAKY, slope=slope, eps=eps_a, out=out, res_stat=sb,
+                                   res_gammas=gb, res_betas=bb, r1=(xb, wb))
+        else:
+            sb = stat_b if stat_b is not None else ops.instnorm_stats(xb, B, S)
+            y = ops.instnorm_apply(xa, B, S, sa, styles_dev, ga, ba, res=xb, act=L.ACT_LEAKY, slope=slope, eps=eps_a, out=out, res_stat=sb,
+                                   res_gammas=gb, res_betas=bb)
         ctx.meta = (B, S, styles_host, num_styles, affine, slope, eps_a)
         ctx.params = params
+        ctx.w1 = w1
         # y is not kept: the backward kernels recompute the LeakyReLU's sign from xa / xb (the forward's own expression), hence the betas
         ctx.save_for_backward(xa, xb, sa, sb, styles_dev, *(ga or []), *(gb or []), *(ba or []), *(bb or []))
         return y
@@ -192,13 +204,22 @@ class _ResNormPair(Function):
 
         dga, dba, arena_a, _ = grads(pa)
         dgb, dbb, arena_b, _ = grads(pb)
-        dxa, dxb = ops.instnorm_pair_bwd(dy, None, xa, xb, B, S, sa, sb, styles_dev, ga, gb, dga, dba, dgb, dbb, slope=slope, eps=eps, betas_a=ba, betas_b=bb)
+        dw1 = None
+        if ctx.w1 is not None:
+            slot = _slot(ctx.w1)
+            dwb = slot if slot is not None else ops.zeros_f32((C,), xa.device)
+            dxa, dxb = ops.instnorm_pair_bwd(dy, None, xa, None, B, S, sa, sb, styles_dev, ga, gb, dga, dba, dgb, dbb, slope=slope, eps=eps, betas_a=ba,
+                                             betas_b=bb, r1=(xb, ops.cast_matrix(ctx.w1, xa.dtype), dwb))
+            dw1 = None if slot is not None else dwb.view(ctx.w1.shape)
+        else:
+            dxa, dxb = ops.instnorm_pair_bwd(dy, None, xa, xb, B, S, sa, sb, styles_dev, ga, gb, dga, dba, dgb, dbb, slope=slope, eps=eps, betas_a=ba,
+                                             betas_b=bb)
         pg = []
         if affine:
             for dg_, db_, ar in ((dga, dba, arena_a), (dgb, dbb, arena_b)):
                 for s in range(num_styles):
                     pg += [None, None] if ar else [dg_[s], db_[s]]
-        return (dxa, dxb, None, None, None, None, None, None, None, None, None, *pg)
+        return (dxa, dxb, dw1, None, None, None, None, None, None, None, None, None, *pg)
 
 
 def _carried_stat(x):
@@ -209,8 +230,9 @@ def _carried_stat(x):
     return None
 
 
-def res_norm_pair(xa, xb, params_a, params_b, styles_dev=None, styles_host=None, slope=0.01, eps_a=1e-5, eps_b=1e-5, stat_a=None, out=None):
-    """LeakyReLU(norm_a(xa) + norm_b(xb)); params_*: None (both affine-less) or lists of (gamma, beta) pairs, one per style."""
+def res_norm_pair(xa, xb, params_a, params_b, styles_dev=None, styles_host=None, slope=0.01, eps_a=1e-5, eps_b=1e-5, stat_a=None, out=None, w1=None):
+    """LeakyReLU(norm_a(xa) + norm_b(xb)); params_*: None (both affine-less) or lists of (gamma, beta) pairs, one per style.
+    w1: LeakyReLU(norm_a(xa) + norm_b(conv1x1x1(xb; w1))) with a one-channel xb (see _ResNormPair.forward)."""
     global _PENDING_OUT
     flat, n = [], 1
     if params_a is not None:
@@ -219,7 +241,8 @@ def res_norm_pair(xa, xb, params_a, params_b, styles_dev=None, styles_host=None,
             for g, b in ps:
                 flat += [g, b]
     _PENDING_OUT = out
-    return _ResNormPair.apply(xa, xb, styles_dev, styles_host, n, params_a is not None, slope, eps_a, eps_b, stat_a, _carried_stat(xb), *flat)
+    return _ResNormPair.apply(xa, xb, w1, styles_dev, styles_host, n, params_a is not None, slope, eps_a, eps_b, stat_a,
+                              _carried_stat(xb) if w1 is None else None, *flat)
 
 
 def instance_norm(x, params=None, styles_dev=None, styles_host=None, res=None, act=L.ACT_NONE, slope=0.01, eps=1e-5, fork=False, stat=None, out=None):

@@ -28,7 +28,8 @@ InstnormStats = _struct("InstnormStats", [("x", vp), ("ldx", i64), ("B", i32), (
 InstnormApply = _struct("InstnormApply", [("x", vp), ("ldx", i64), ("res", vp), ("ldres", i64), ("y", vp), ("ldy", i64),
                                           ("B", i32), ("S", i32), ("C", i32), ("dtype", i32), ("stat", vp), ("eps", f32),
                                           ("styles", vp), ("num_styles", i32), ("gamma", fp4), ("beta", fp4),
-                                          ("act", i32), ("slope", f32), ("res_stat", vp), ("res_gamma", fp4), ("res_beta", fp4)])
+                                          ("act", i32), ("slope", f32), ("res_stat", vp), ("res_gamma", fp4), ("res_beta", fp4),
+                                          ("r1x", vp), ("ldr1x", i64), ("r1w", vp)])
 InstnormBwd = _struct("InstnormBwd", [("dy", vp), ("lddy", i64), ("y", vp), ("ldy", i64), ("x", vp), ("ldx", i64),
                                       ("dx", vp), ("lddx", i64), ("dres", vp), ("lddres", i64),
                                       ("B", i32), ("S", i32), ("C", i32), ("dtype", i32), ("stat", vp), ("eps", f32), ("dstat", vp),
@@ -38,7 +39,8 @@ InstnormPairBwd = _struct("InstnormPairBwd", [("dy", vp), ("lddy", i64), ("y", v
                                               ("dxa", vp), ("lddxa", i64), ("dxb", vp), ("lddxb", i64), ("B", i32), ("S", i32), ("C", i32), ("dtype", i32),
                                               ("stat_a", vp), ("stat_b", vp), ("eps", f32), ("dstat_a", vp), ("dstat_b", vp), ("styles", vp),
                                               ("num_styles", i32), ("gamma_a", fp4), ("gamma_b", fp4), ("dgamma_a", fp4), ("dbeta_a", fp4),
-                                              ("dgamma_b", fp4), ("dbeta_b", fp4), ("slope", f32), ("beta_a", fp4), ("beta_b", fp4)])
+                                              ("dgamma_b", fp4), ("dbeta_b", fp4), ("slope", f32), ("beta_a", fp4), ("beta_b", fp4),
+                                              ("r1x", vp), ("ldr1x", i64), ("r1w", vp), ("r1dw", vp)])
 LayernormFwd = _struct("LayernormFwd", [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32),
                                         ("dtype", i32), ("eps", f32), ("gamma", vp), ("beta", vp), ("mean", vp), ("rstd", vp)])
 LayernormBwd = _struct("LayernormBwd", [("dy", vp), ("lddy", i64), ("x", vp), ("ldx", i64), ("dx", vp), ("lddx", i64),
@@ -110,6 +112,7 @@ PROTOS = {
     "miseg_layernorm_bwd": (i32, [C.POINTER(LayernormBwd), vp]),
     "miseg_gemm_fuses_stat": (i32, [C.POINTER(Gemm)]),
     "miseg_gemm_fuses_scatter": (i32, [C.POINTER(Gemm)]),
+    "miseg_rank1_stats": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, vp]),
     "miseg_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(Gemm)]),
     "miseg_gemm": (i32, [C.POINTER(Gemm), vp]),
     "miseg_permute3": (i32, [vp, vp, i32, i32, i32, i64, i64, i64, i32, vp]),

@@ -124,9 +124,20 @@ def _style_arrays(tensors, n):
     return arr
 
 
+def rank1_stats(x1, w):
+    """instance-norm statistics of round(x1[row] * w[c]) without storing it (one sample): x1 rows view [.., 1], w [C] / [C, 1] in x1.dtype"""
+    ld, n, one = rows(x1)
+    assert one == 1 and w.dtype == x1.dtype and w.is_contiguous()
+    Cc = w.numel()
+    stat = STAT_POOL.take(L.load().miseg_instnorm_stat_bytes(1, Cc) // 8, x1.device).view(-1, 1, Cc, 2)
+    L.check(L.load().miseg_rank1_stats(_ptr(x1), ld, _ptr(w), 1, n, Cc, _dt(x1), _ptr(stat), _stream()), "rank1_stats")
+    return stat
+
+
 def instnorm_apply(x, B, S, stat, styles, gammas, betas, res=None, act=L.ACT_NONE, slope=0.01, eps=1e-5, out=None, res_stat=None,
-                   res_gammas=None, res_betas=None):
-    """res_stat: `res` is the RAW input of a second instance norm (statistics res_stat, affine rows res_gammas / res_betas) applied on the fly."""
+                   res_gammas=None, res_betas=None, r1=None):
+    """res_stat: `res` is the RAW input of a second instance norm (statistics res_stat, affine rows res_gammas / res_betas) applied on the fly.
+    r1 = (x1, w): that raw input is round(x1[row] * w[c]) and is not stored (res=None; res_stat from rank1_stats)."""
     ld, n, Cc = rows(x)
     y = out if out is not None else torch.empty(x.shape, dtype=x.dtype, device=x.device)
     ldy, ny, Cy = rows(y)
@@ -136,6 +147,9 @@ def instnorm_apply(x, B, S, stat, styles, gammas, betas, res=None, act=L.ACT_NON
     p = L.InstnormApply(_ptr(x), ld, _ptr(res), ldr, _ptr(y), ldy, B, S, Cc, _dt(x), _ptr(stat), eps, _ptr(styles), ns,
                         _style_arrays(gammas, ns), _style_arrays(betas, ns), act, slope, _ptr(res_stat), _style_arrays(res_gammas, ns),
                         _style_arrays(res_betas, ns))
+    if r1 is not None:
+        assert res is None and rows(r1[0])[1] == n and r1[1].numel() == Cc and r1[1].dtype == x.dtype
+        p.r1x, p.ldr1x, p.r1w = _ptr(r1[0]), rows(r1[0])[0], _ptr(r1[1])
     _call("miseg_instnorm_apply", p)
     return y
 
@@ -170,19 +184,24 @@ def instnorm_bwd(dy, y, x, B, S, stat, styles, gammas, dgammas, dbetas, act=L.AC
 
 
 def instnorm_pair_bwd(dy, y, xa, xb, B, S, stat_a, stat_b, styles, gammas_a, gammas_b, dgammas_a, dbetas_a, dgammas_b, dbetas_b, slope=0.01, eps=1e-5,
-                      betas_a=None, betas_b=None):
+                      betas_a=None, betas_b=None, r1=None):
     """backward of LeakyReLU(norm_a(xa) + norm_b(xb)): (dxa, dxb) in one reduction + one apply launch.
     y=None: the kernels recompute the activation's sign from xa / xb (needs the betas of affine norms)."""
     ld, n, Cc = rows(xa)
     dxa = torch.empty(xa.shape, dtype=xa.dtype, device=xa.device)
-    dxb = torch.empty(xb.shape, dtype=xb.dtype, device=xb.device)
+    # r1 = (x1, w, dw): xb = round(x1[row] * w[c]) is not stored (xb = y = None), dw [C] fp32 receives (+=) the 1x1x1 weight gradient
+    dxb = torch.empty(xb.shape, dtype=xb.dtype, device=xb.device) if r1 is None else None
     nb = L.load().miseg_instnorm_stat_bytes(B, Cc) // 8
     dsa, dsb = STAT_POOL.take(nb, xa.device), STAT_POOL.take(nb, xa.device)
     ns = len(gammas_a) if gammas_a is not None else 1
-    p = L.InstnormPairBwd(_ptr(dy), rows(dy)[0], _ptr(y), rows(y)[0] if y is not None else 0, _ptr(xa), ld, _ptr(xb), rows(xb)[0], _ptr(dxa), rows(dxa)[0], _ptr(dxb), rows(dxb)[0],
+    p = L.InstnormPairBwd(_ptr(dy), rows(dy)[0], _ptr(y), rows(y)[0] if y is not None else 0, _ptr(xa), ld, _ptr(xb), rows(xb)[0] if xb is not None else 0,
+                          _ptr(dxa), rows(dxa)[0], _ptr(dxb), rows(dxb)[0] if dxb is not None else 0,
                           B, S, Cc, _dt(xa), _ptr(stat_a), _ptr(stat_b), eps, _ptr(dsa), _ptr(dsb), _ptr(styles), ns,
                           _style_arrays(gammas_a, ns), _style_arrays(gammas_b, ns), _style_arrays(dgammas_a, ns), _style_arrays(dbetas_a, ns),
                           _style_arrays(dgammas_b, ns), _style_arrays(dbetas_b, ns), slope, _style_arrays(betas_a, ns), _style_arrays(betas_b, ns))
+    if r1 is not None:
+        assert xb is None and y is None and rows(r1[0])[1] == n and r1[1].numel() == Cc and r1[2].numel() == Cc and r1[2].dtype == torch.float32
+        p.r1x, p.ldr1x, p.r1w, p.r1dw = _ptr(r1[0]), rows(r1[0])[0], _ptr(r1[1]), _ptr(r1[2])
     _call("miseg_instnorm_pair_bwd", p)
     return dxa, dxb
 

@@ -107,6 +107,11 @@ class UnetResBlock(nn.Module):
         out = apply_norm(self.norm1, out, styles, act=L.ACT_LEAKY, slope=LEAKY_SLOPE, stat=st1)
         out, st2 = HF.conv3(out, self.conv2.conv.weight, want_stat=True)
         if self.downsample:
+            if image is not None:       # one-channel image: the shortcut convolution is a rank-1 product, formed inside the norm kernels
+                y = apply_res_norm_pair(self.norm2, out, self.norm3, residual, styles, slope=LEAKY_SLOPE, stat_a=st2, out=out_view,
+                                        w1=self.conv3.conv.weight)
+                if y is not None:
+                    return y
             residual = HF.conv1(residual, self.conv3.conv.weight, want_stat=True)
             y = apply_res_norm_pair(self.norm2, out, self.norm3, residual, styles, slope=LEAKY_SLOPE, stat_a=st2, out=out_view)
             if y is not None:           # the shortcut's norm rides in the final apply pass

@@ -57,11 +57,13 @@ def apply_norm_fork(norm: nn.Module, x, styles=None):
     return apply_norm(norm, xa, styles), xs
 
 
-def apply_res_norm_pair(norm_a: nn.Module, xa, norm_b: nn.Module, xb, styles=None, slope=0.01, stat_a=None, out=None):
+def apply_res_norm_pair(norm_a: nn.Module, xa, norm_b: nn.Module, xb, styles=None, slope=0.01, stat_a=None, out=None, w1=None):
     """LeakyReLU(norm_a(xa) + norm_b(xb)) in one apply pass (HF.res_norm_pair) where both norms are instance norms of the same kind and
-    the tensors have more than 512 rows per sample (below that the single-launch fused norms win); None where that does not apply."""
+    the tensors have more than 512 rows per sample (below that the single-launch fused norms win); None where that does not apply.
+    w1: xb is a one-channel image and norm_b sees conv1x1x1(xb; w1), which is then never materialised (one sample, bf16 / fp32 rows)."""
     rows_per_sample = xa.numel() // (xa.shape[0] * xa.shape[-1])
-    if rows_per_sample <= 512 or xa.shape != xb.shape:
+    if rows_per_sample <= 512 or (xa.shape != xb.shape if w1 is None else (xa.shape[:-1] != xb.shape[:-1] or xb.shape[-1] != 1 or xa.shape[0] != 1
+                                                                          or xb.requires_grad or xa.shape[-1] % 8 != 0)):
         return None
     if isinstance(norm_a, _ConditionalInstanceNorm) and isinstance(norm_b, _ConditionalInstanceNorm):
         if styles is None:
@@ -69,11 +71,11 @@ def apply_res_norm_pair(norm_a: nn.Module, xa, norm_b: nn.Module, xb, styles=Non
         if norm_a.num_styles != norm_b.num_styles:
             return None
         return HF.res_norm_pair(xa, xb, norm_a.style_params(), norm_b.style_params(), styles[0], styles[1], slope=slope, eps_a=norm_a.eps,
-                                eps_b=norm_b.eps, stat_a=stat_a, out=out)
+                                eps_b=norm_b.eps, stat_a=stat_a, out=out, w1=w1)
     if isinstance(norm_a, _INSTANCE) and isinstance(norm_b, _INSTANCE) and norm_a.affine == norm_b.affine and norm_a.eps == norm_b.eps:
         pa = [(norm_a.weight, norm_a.bias)] if norm_a.affine else None
         pb = [(norm_b.weight, norm_b.bias)] if norm_b.affine else None
-        return HF.res_norm_pair(xa, xb, pa, pb, None, None, slope=slope, eps_a=norm_a.eps, eps_b=norm_b.eps, stat_a=stat_a, out=out)
+        return HF.res_norm_pair(xa, xb, pa, pb, None, None, slope=slope, eps_a=norm_a.eps, eps_b=norm_b.eps, stat_a=stat_a, out=out, w1=w1)
     return None
 
 

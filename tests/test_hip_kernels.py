@@ -134,6 +134,45 @@ def test_instnorm_residual_pair(dtype, B, S, C):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("S,C", [(4096 + 17, 48), (3000, 24), (2100, 16)])
+def test_instnorm_residual_pair_rank1_shortcut(dtype, S, C):
+    """the stem block's shortcut conv1x1x1(one-channel image) is never materialised: its product is formed inside the pair's apply and
+    backward kernels (r1x / r1w) and its weight gradient is reduced by the backward kernel - against the materialised path: the same
+    bits for y and dxa (the product is rounded exactly as the rank-1 GEMM rounds it), the weight gradient against the TN GEMM."""
+    ops, L = _ops(), _L()
+    B = 1
+    xa = rnd(B, S, C, dtype=dtype, seed=71) * 1.5 + 0.3
+    x1 = rnd(B, S, 1, dtype=dtype, seed=72)
+    w = (rnd(C, 1, dtype=dtype, seed=73) * 0.8).contiguous()
+    gam = [[rnd(C, seed=33 + 4 * k + s) * 0.2 + 1 for s in range(2)] for k in range(2)]
+    bet = [[rnd(C, seed=35 + 4 * k + s) * 0.1 for s in range(2)] for k in range(2)]
+    styles = torch.tensor([1], dtype=torch.int32, device=DEV)
+    ops.begin_step()
+    xb = ops.gemm_nt(x1, w)                                        # the materialised shortcut
+    sa, sb = ops.instnorm_stats(xa, B, S), ops.instnorm_stats(xb, B, S)
+    y_ref = ops.instnorm_apply(xa, B, S, sa, styles, gam[0], bet[0], res=xb, act=L.ACT_LEAKY, slope=0.01, res_stat=sb, res_gammas=gam[1], res_betas=bet[1])
+    sb1 = ops.rank1_stats(x1, w)
+    assert torch.allclose(sb1.sum(0), sb.sum(0), rtol=2e-6, atol=1e-3)
+    y = ops.instnorm_apply(xa, B, S, sa, styles, gam[0], bet[0], act=L.ACT_LEAKY, slope=0.01, res_stat=sb, res_gammas=gam[1], res_betas=bet[1], r1=(x1, w))
+    assert torch.equal(y, y_ref)
+    dy = rnd(B, S, C, dtype=dtype, seed=47)
+
+    def zeros():
+        return [[torch.zeros(C, device=DEV) for _ in range(2)] for _ in range(2)]
+    dg, db, dg2, db2 = zeros(), zeros(), zeros(), zeros()
+    dxa_ref, dxb_ref = ops.instnorm_pair_bwd(dy, None, xa, xb, B, S, sa, sb, styles, gam[0], gam[1], dg[0], db[0], dg[1], db[1], slope=0.01,
+                                             betas_a=bet[0], betas_b=bet[1])
+    dw = torch.zeros(C, device=DEV)
+    dxa, none = ops.instnorm_pair_bwd(dy, None, xa, None, B, S, sa, sb, styles, gam[0], gam[1], dg2[0], db2[0], dg2[1], db2[1], slope=0.01,
+                                      betas_a=bet[0], betas_b=bet[1], r1=(x1, w, dw))
+    assert none is None and torch.equal(dxa, dxa_ref)
+    for k in range(2):
+        assert rel_err(dg2[k][1], dg[k][1]) < 1e-5 and rel_err(db2[k][1], db[k][1]) < 1e-5
+    dw_ref = (dxb_ref.double().reshape(S, C) * x1.double().reshape(S, 1)).sum(0)
+    assert rel_err(dw, dw_ref) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_layernorm(dtype):
     ops = _ops()
     x = rnd(777, 96, dtype=dtype, seed=11)
