@@ -354,7 +354,10 @@ int miseg_patch_embed_fwd(const miseg_patch_embed_params* p, miseg_stream_t stre
 typedef struct {
   const float* x; const void* dy; int64_t lddy; float* dw; float* dbias;   /* accumulated */
   int B, Cin, D, H, W, Cout, dtype;
+  void* workspace;   /* optional, miseg_patch_embed_bwd_workspace_bytes(p): per-workgroup partial sums + a second small launch instead of
+                      * fp32 atomics from every workgroup onto the 9 * Cout outputs (46 of 53 us on the headline patch) */
 } miseg_patch_embed_bwd_params;
+size_t miseg_patch_embed_bwd_workspace_bytes(const miseg_patch_embed_bwd_params* p);
 int miseg_patch_embed_bwd(const miseg_patch_embed_bwd_params* p, miseg_stream_t stream);
 
 /* First encoder conv: 3x3x3, Cin in {1..4} NCDHW fp32 input -> channels-last Cout (dynunet_block.py:55-64 with

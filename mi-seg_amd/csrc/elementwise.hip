@@ -1061,7 +1061,10 @@ __global__ void __launch_bounds__(256) head_bwd_dw_mfma_kernel(const bf16* __res
 // lane = (coarse voxel row ty, output-channel vector tx); one input channel per pass (blockIdx.y)
 template <class T, int VEC>
 __global__ void __launch_bounds__(256) patch_embed_bwd_team_kernel(const float* __restrict__ x, const T* __restrict__ dy, int64_t lddy, float* __restrict__ dw,
-                                                                   float* __restrict__ dbias, int B, int Cin, int D, int H, int W, int Cout, int rows_per_block) {
+                                                                   float* __restrict__ dbias, int B, int Cin, int D, int H, int W, int Cout, int rows_per_block,
+                                                                   float* __restrict__ partial) {
+  // partial != nullptr: the workgroup's 9 * Cout sums go to partial[ci][block][tap][co] (plain stores) and patch_embed_bwd_reduce_kernel adds
+  // them up: 256 workgroups x 432 fp32 atomics onto 14 cache lines cost 46 of this kernel's 53 us
   extern __shared__ __attribute__((aligned(16))) float red[];
   const int tx_n = Cout / VEC, ty_n = 256 / tx_n;
   const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
@@ -1109,8 +1112,32 @@ __global__ void __launch_bounds__(256) patch_embed_bwd_team_kernel(const float* 
     float a = 0.f;
     for (int yy = 0; yy < ty_n; ++yy) a += red[yy * width + e];
     const int tap = e / (tx_n * VEC), co = e - tap * (tx_n * VEC);
-    if (tap < 8) atomicAdd(dw + ((int64_t)co * Cin + ci) * 8 + tap, a);
+    if (partial) partial[((int64_t)ci * gridDim.x + blockIdx.x) * width + e] = a;
+    else if (tap < 8) atomicAdd(dw + ((int64_t)co * Cin + ci) * 8 + tap, a);
     else if (dbias && ci == 0) atomicAdd(dbias + co, a);
+  }
+}
+
+// sums partial[ci][nblk][9 * Cout] over the workgroups: a workgroup = 32 consecutive elements x 8 slices of the workgroup list
+__global__ void __launch_bounds__(256) patch_embed_bwd_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ dbias, int Cin,
+                                                                     int Cout, int nblk) {
+  __shared__ float red[8][32];
+  const int width = 9 * Cout, ci = blockIdx.y;
+  const int e = blockIdx.x * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;
+  float a = 0.f;
+  if (e < width) {
+    const float* p = partial + (int64_t)ci * nblk * width + e;
+#pragma unroll 8
+    for (int b = sl; b < nblk; b += 8) a += p[(int64_t)b * width];
+  }
+  red[sl][threadIdx.x & 31] = a;
+  __syncthreads();
+  if (sl == 0 && e < width) {
+#pragma unroll
+    for (int i = 1; i < 8; ++i) a += red[i][threadIdx.x];
+    const int tap = e / Cout, co = e - tap * Cout;
+    if (tap < 8) dw[((int64_t)co * Cin + ci) * 8 + tap] += a;        // single writer per element
+    else if (dbias && ci == 0) dbias[co] += a;
   }
 }
 
@@ -1368,6 +1395,11 @@ extern "C" int miseg_patch_embed_fwd(const miseg_patch_embed_params* p, miseg_st
   });
 }
 
+extern "C" size_t miseg_patch_embed_bwd_workspace_bytes(const miseg_patch_embed_bwd_params* p) {
+  if (!p) return 0;
+  return (size_t)256 * p->Cin * 9 * p->Cout * sizeof(float);       // at most 256 workgroups per input channel
+}
+
 extern "C" int miseg_patch_embed_bwd(const miseg_patch_embed_bwd_params* p, miseg_stream_t s_) {
   hipStream_t s = (hipStream_t)s_;
   MISEG_REQUIRE(p && p->x && p->dy && p->dw, MISEG_E_BADARG, "patch_embed_bwd: null pointer");
@@ -1382,8 +1414,11 @@ extern "C" int miseg_patch_embed_bwd(const miseg_patch_embed_bwd_params* p, mise
       if (rpb < 4 * ty_n) rpb = 4 * ty_n;
       const size_t sh = (size_t)ty_n * 9 * tx_n * N * sizeof(float);
       hipFuncSetAttribute((const void*)patch_embed_bwd_team_kernel<T, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-      patch_embed_bwd_team_kernel<T, N><<<dim3(cdiv(nv, rpb), p->Cin), 256, sh, s>>>(p->x, (const T*)p->dy, p->lddy, p->dw, p->dbias, p->B, p->Cin, p->D, p->H, p->W,
-                                                                                     p->Cout, rpb);
+      const int nblk = cdiv(nv, rpb);
+      float* part = (p->workspace && nblk >= 16) ? (float*)p->workspace : nullptr;
+      patch_embed_bwd_team_kernel<T, N><<<dim3(nblk, p->Cin), 256, sh, s>>>(p->x, (const T*)p->dy, p->lddy, p->dw, p->dbias, p->B, p->Cin, p->D, p->H, p->W,
+                                                                            p->Cout, rpb, part);
+      if (part) patch_embed_bwd_reduce_kernel<<<dim3(cdiv(9 * p->Cout, 32), p->Cin), 256, 0, s>>>(part, p->dw, p->dbias, p->Cin, p->Cout, nblk);
     } else {
       const int vpb = 1024;
       size_t sh = ((size_t)64 * (p->Cin * 8 + 1) + 64 * p->Cout) * sizeof(float);

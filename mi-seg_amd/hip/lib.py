@@ -85,7 +85,7 @@ S2C = _struct("S2C", [("src", vp), ("lds", i64), ("dst", vp), ("ldd", i64), ("B"
 PatchEmbed = _struct("PatchEmbed", [("x", vp), ("y", vp), ("ldy", i64), ("w", vp), ("bias", vp), ("B", i32), ("Cin", i32), ("D", i32),
                                     ("H", i32), ("W", i32), ("Cout", i32), ("dtype", i32)])
 PatchEmbedBwd = _struct("PatchEmbedBwd", [("x", vp), ("dy", vp), ("lddy", i64), ("dw", vp), ("dbias", vp), ("B", i32), ("Cin", i32),
-                                          ("D", i32), ("H", i32), ("W", i32), ("Cout", i32), ("dtype", i32)])
+                                          ("D", i32), ("H", i32), ("W", i32), ("Cout", i32), ("dtype", i32), ("workspace", vp)])
 Conv3Thin = _struct("Conv3Thin", [("x", vp), ("y", vp), ("ldy", i64), ("w", vp), ("B", i32), ("Cin", i32), ("D", i32), ("H", i32),
                                   ("W", i32), ("Cout", i32), ("dtype", i32)])
 Conv3ThinWgrad = _struct("Conv3ThinWgrad", [("x", vp), ("dy", vp), ("lddy", i64), ("dw", vp), ("B", i32), ("Cin", i32), ("D", i32),
@@ -140,6 +140,7 @@ PROTOS = {
     "miseg_space_to_channel": (i32, [C.POINTER(S2C), vp]),
     "miseg_channel_to_space": (i32, [C.POINTER(S2C), vp]),
     "miseg_patch_embed_fwd": (i32, [C.POINTER(PatchEmbed), vp]),
+    "miseg_patch_embed_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(PatchEmbedBwd)]),
     "miseg_patch_embed_bwd": (i32, [C.POINTER(PatchEmbedBwd), vp]),
     "miseg_conv3_thin_fwd": (i32, [C.POINTER(Conv3Thin), vp]),
     "miseg_conv3_thin_wgrad": (i32, [C.POINTER(Conv3ThinWgrad), vp]),

@@ -750,7 +750,10 @@ def patch_embed_fwd(x_ncdhw, w, bias, dtype):
 def patch_embed_bwd(x_ncdhw, dy, dw, dbias):
     B, Cin, D, H, W = x_ncdhw.shape
     Cout = dy.shape[-1]
-    _call("miseg_patch_embed_bwd", L.PatchEmbedBwd(_ptr(x_ncdhw), _ptr(dy), rows(dy)[0], _ptr(dw), _ptr(dbias), B, Cin, D, H, W, Cout, _dt(dy)))
+    p = L.PatchEmbedBwd(_ptr(x_ncdhw), _ptr(dy), rows(dy)[0], _ptr(dw), _ptr(dbias), B, Cin, D, H, W, Cout, _dt(dy), None)
+    ws = torch.empty(L.load().miseg_patch_embed_bwd_workspace_bytes(C.byref(p)) // 4, dtype=torch.float32, device=dy.device)
+    p.workspace = ws.data_ptr()
+    _call("miseg_patch_embed_bwd", p)
 
 
 def head_fwd(x, w, bias):

@@ -523,6 +523,14 @@ def test_conv3_thin_and_head_and_patch_embed(dtype):
     ops.patch_embed_bwd(xp, gp, dwp, dbp)
     assert rel_err(dwp, torch.nn.grad.conv3d_weight(xp, wp.shape, gp.float().permute(0, 4, 1, 2, 3), stride=2)) < TOL[dtype]
     assert rel_err(dbp, gp.float().sum((0, 1, 2, 3))) < TOL[dtype]
+    # enough coarse voxels for the partial-sum path (per-workgroup sums + a reduce launch instead of atomics), on top of existing values
+    xq, wq = rnd(1, 1, 44, 40, 36, seed=65), rnd(48, 1, 2, 2, 2, seed=66) / 3
+    gq = rnd(1, 22, 20, 18, 48, dtype=dtype, seed=67)
+    base_w, base_b = rnd(48, 1, 2, 2, 2, seed=68), rnd(48, seed=69)
+    dwq, dbq = base_w.clone(), base_b.clone()
+    ops.patch_embed_bwd(xq, gq, dwq, dbq)
+    assert rel_err(dwq - base_w, torch.nn.grad.conv3d_weight(xq, wq.shape, gq.float().permute(0, 4, 1, 2, 3), stride=2)) < TOL[dtype]
+    assert rel_err(dbq - base_b, gq.float().sum((0, 1, 2, 3))) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
