@@ -370,7 +370,10 @@ int miseg_conv3_thin_fwd(const miseg_conv3_thin_params* p, miseg_stream_t stream
 typedef struct {
   const float* x; const void* dy; int64_t lddy; float* dw;
   int B, Cin, D, H, W, Cout, dtype;
+  void* workspace;   /* optional, miseg_conv3_thin_wgrad_workspace_bytes(p) (0: not used by this shape): per-workgroup partial sums + a second
+                      * small launch instead of fp32 atomics from every workgroup onto the 27 * Cout outputs */
 } miseg_conv3_thin_wgrad_params;
+size_t miseg_conv3_thin_wgrad_workspace_bytes(const miseg_conv3_thin_wgrad_params* p);
 int miseg_conv3_thin_wgrad(const miseg_conv3_thin_wgrad_params* p, miseg_stream_t stream);
 
 /* Network input (NCDHW fp32, Cin <= 8 image channels) -> channels-last rows of CP channels (CP = 4 for fp32, 8 for bf16:

@@ -592,8 +592,27 @@ __global__ void __launch_bounds__(256) conv3_stem_fwd_mfma_kernel(const float* _
 // instead of 331 K multiply-adds.  The dy^T operand comes from the staged brick by transposed LDS reads (as in the 3x3x3
 // weight-gradient kernel), the X operand is 8 consecutive floats of a halo row per lane (k-group = (h row, w half), element = w).
 // Each wave takes two of the eight k-steps; the waves' tiles meet in LDS once per workgroup.  Needs Cout == 48.
+// out[e] += sum over b of partial[b][e]: the second launch of the kernels whose workgroups leave partial sums instead of adding fp32 atomics
+// onto a small output (a workgroup = 32 consecutive elements x 8 slices of the workgroup list)
+__global__ void __launch_bounds__(256) partial_sum_add_kernel(const float* __restrict__ partial, float* __restrict__ out, int n, int nblk) {
+  __shared__ float red[8][32];
+  const int e = blockIdx.x * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;
+  float a = 0.f;
+  if (e < n) {
+#pragma unroll 8
+    for (int b = sl; b < nblk; b += 8) a += partial[(int64_t)b * n + e];
+  }
+  red[sl][threadIdx.x & 31] = a;
+  __syncthreads();
+  if (sl == 0 && e < n) {
+#pragma unroll
+    for (int i = 1; i < 8; ++i) a += red[i][threadIdx.x];
+    out[e] += a;
+  }
+}
+
 __global__ void __launch_bounds__(256) conv3_stem_wgrad_mfma_kernel(const float* __restrict__ x, const bf16* __restrict__ dy, int64_t lddy, float* __restrict__ dw,
-                                                                    int B, int D, int H, int W, int nbricks) {
+                                                                    int B, int D, int H, int W, int nbricks, float* __restrict__ partial) {
   constexpr int Cout = 48, ROWB = Cout * 2 + 16;
   __shared__ __attribute__((aligned(16))) char ds[256 * ROWB];      // dy brick, padded rows; reused for the final reduction
   __shared__ float xs[SH_N];
@@ -673,7 +692,9 @@ __global__ void __launch_bounds__(256) conv3_stem_wgrad_mfma_kernel(const float*
   __syncthreads();
   for (int o = tid; o < 48 * 27; o += 256) {
     const int co = o / 27, tap = o - co * 27;
-    atomicAdd(dw + o, red[(0 * 48 + co) * 32 + tap] + red[(1 * 48 + co) * 32 + tap] + red[(2 * 48 + co) * 32 + tap] + red[(3 * 48 + co) * 32 + tap]);
+    const float v = red[(0 * 48 + co) * 32 + tap] + red[(1 * 48 + co) * 32 + tap] + red[(2 * 48 + co) * 32 + tap] + red[(3 * 48 + co) * 32 + tap];
+    if (partial) partial[(int64_t)blockIdx.x * (48 * 27) + o] = v;      // summed by partial_sum_add_kernel
+    else atomicAdd(dw + o, v);
   }
 }
 
@@ -1454,6 +1475,10 @@ extern "C" int miseg_conv3_thin_fwd(const miseg_conv3_thin_params* p, miseg_stre
   });
 }
 
+extern "C" size_t miseg_conv3_thin_wgrad_workspace_bytes(const miseg_conv3_thin_wgrad_params* p) {
+  return (p && p->dtype == MISEG_BF16 && p->Cin == 1 && p->Cout == 48) ? (size_t)512 * 48 * 27 * sizeof(float) : 0;      // the matrix-core form only
+}
+
 extern "C" int miseg_conv3_thin_wgrad(const miseg_conv3_thin_wgrad_params* p, miseg_stream_t s_) {
   hipStream_t s = (hipStream_t)s_;
   MISEG_REQUIRE(p && p->x && p->dy && p->dw, MISEG_E_BADARG, "conv3_thin_wgrad: null pointer");
@@ -1463,7 +1488,10 @@ extern "C" int miseg_conv3_thin_wgrad(const miseg_conv3_thin_wgrad_params* p, mi
     if constexpr (std::is_same<T, bf16>::value) {
       if (p->Cin == 1 && p->Cout == 48 && p->lddy % 8 == 0 && al16(p->dy)) {      // matrix-core form (see conv3_stem_wgrad_mfma_kernel)
         const int nbricks = p->B * cdiv(p->D, miseg::SB_D) * cdiv(p->H, miseg::SB_H) * cdiv(p->W, miseg::SB_W);
-        conv3_stem_wgrad_mfma_kernel<<<nbricks < 512 ? nbricks : 512, 256, 0, s>>>(p->x, (const bf16*)p->dy, p->lddy, p->dw, p->B, p->D, p->H, p->W, nbricks);
+        const int nblk = nbricks < 512 ? nbricks : 512;
+        float* part = (p->workspace && nblk >= 16) ? (float*)p->workspace : nullptr;
+        conv3_stem_wgrad_mfma_kernel<<<nblk, 256, 0, s>>>(p->x, (const bf16*)p->dy, p->lddy, p->dw, p->B, p->D, p->H, p->W, nbricks, part);
+        if (part) partial_sum_add_kernel<<<cdiv(48 * 27, 32), 256, 0, s>>>(part, p->dw, 48 * 27, nblk);
         MISEG_LAUNCH_CHECK("conv3_stem_wgrad_mfma");
         return MISEG_OK;
       }

@@ -89,7 +89,7 @@ PatchEmbedBwd = _struct("PatchEmbedBwd", [("x", vp), ("dy", vp), ("lddy", i64), 
 Conv3Thin = _struct("Conv3Thin", [("x", vp), ("y", vp), ("ldy", i64), ("w", vp), ("B", i32), ("Cin", i32), ("D", i32), ("H", i32),
                                   ("W", i32), ("Cout", i32), ("dtype", i32)])
 Conv3ThinWgrad = _struct("Conv3ThinWgrad", [("x", vp), ("dy", vp), ("lddy", i64), ("dw", vp), ("B", i32), ("Cin", i32), ("D", i32),
-                                            ("H", i32), ("W", i32), ("Cout", i32), ("dtype", i32)])
+                                            ("H", i32), ("W", i32), ("Cout", i32), ("dtype", i32), ("workspace", vp)])
 Head = _struct("Head", [("x", vp), ("ldx", i64), ("y", vp), ("w", vp), ("bias", vp), ("B", i32), ("S", i32), ("Cin", i32),
                         ("Cout", i32), ("dtype", i32)])
 HeadBwd = _struct("HeadBwd", [("x", vp), ("ldx", i64), ("dy", vp), ("dx", vp), ("lddx", i64), ("w", vp), ("dw", vp), ("dbias", vp),
@@ -143,6 +143,7 @@ PROTOS = {
     "miseg_patch_embed_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(PatchEmbedBwd)]),
     "miseg_patch_embed_bwd": (i32, [C.POINTER(PatchEmbedBwd), vp]),
     "miseg_conv3_thin_fwd": (i32, [C.POINTER(Conv3Thin), vp]),
+    "miseg_conv3_thin_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(Conv3ThinWgrad)]),
     "miseg_conv3_thin_wgrad": (i32, [C.POINTER(Conv3ThinWgrad), vp]),
     "miseg_head_fwd": (i32, [C.POINTER(Head), vp]),
     "miseg_head_bwd": (i32, [C.POINTER(HeadBwd), vp]),

@@ -567,7 +567,11 @@ def conv3_thin_fwd(x_ncdhw, w, dtype):
 def conv3_thin_wgrad(x_ncdhw, dy, dw):
     B, Cin, D, H, W = x_ncdhw.shape
     Cout = dy.shape[-1]
-    _call("miseg_conv3_thin_wgrad", L.Conv3ThinWgrad(_ptr(x_ncdhw), _ptr(dy), rows(dy)[0], _ptr(dw), B, Cin, D, H, W, Cout, _dt(dy)))
+    p = L.Conv3ThinWgrad(_ptr(x_ncdhw), _ptr(dy), rows(dy)[0], _ptr(dw), B, Cin, D, H, W, Cout, _dt(dy), None)
+    nb = L.load().miseg_conv3_thin_wgrad_workspace_bytes(C.byref(p))
+    ws = torch.empty(nb // 4, dtype=torch.float32, device=dy.device) if nb else None
+    p.workspace = _ptr(ws)
+    _call("miseg_conv3_thin_wgrad", p)
     return dw
 
 

@@ -494,6 +494,10 @@ def test_conv3_thin_and_head_and_patch_embed(dtype):
     dy3, base = rnd(1, 8, 8, 32, 48, dtype=dtype, seed=62), rnd(48, 1, 3, 3, 3, seed=63)
     got = ops.conv3_thin_wgrad(x3, dy3, base.clone()) - base
     assert rel_err(got, torch.nn.grad.conv3d_weight(x3, w3.shape, dy3.float().permute(0, 4, 1, 2, 3), padding=1)) < TOL[dtype]
+    # enough bricks for the partial-sum path of the matrix-core form (per-workgroup sums + a reduce launch instead of atomics); ragged volume
+    x4, dy4 = rnd(1, 1, 18, 15, 33, seed=70), rnd(1, 18, 15, 33, 48, dtype=dtype, seed=71)
+    got4 = ops.conv3_thin_wgrad(x4, dy4, base.clone()) - base
+    assert rel_err(got4, torch.nn.grad.conv3d_weight(x4, w3.shape, dy4.float().permute(0, 4, 1, 2, 3), padding=1)) < TOL[dtype]
     # head
     xh = rnd(2, 5, 6, 7, 48, dtype=dtype, seed=54)
     wh, bh = rnd(6, 48, 1, 1, 1, seed=55) / 7, rnd(6, seed=56)
