@@ -30,6 +30,8 @@ enum { MISEG_OK = 0, MISEG_E_BADARG = -1, MISEG_E_UNSUPPORTED = -2, MISEG_E_LAUN
 enum { MISEG_ACT_NONE = 0, MISEG_ACT_LEAKY = 1, MISEG_ACT_GELU = 2, MISEG_ACT_PRELU = 3 };
 #define MISEG_MAX_STYLES 4
 
+/* bumped on EVERY change of a struct layout or prototype; bindings must refuse a library whose version differs from the header they mirror */
+#define MISEG_ABI_VERSION 2
 int miseg_abi_version(void);
 const char* miseg_last_error(void);
 /* writes e.g. "gfx950" for the code objects embedded in the library */
@@ -420,6 +422,89 @@ int miseg_col2im3(const miseg_im2col3_params* p, miseg_stream_t stream);
 
 /* fill a buffer of n 32-bit words with a value (gradient arenas, accumulators) */
 int miseg_fill32(void* dst, uint32_t value, size_t n, miseg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * After the path, every training step: segmentation loss + d(loss)/d(logits), Dice metric,
+ * multi-tensor optimiser step over the gradient arena, sliding-window stitching.  MONAI 1.1.0 arithmetic restated from its
+ * public API (the reference calls it at networks/lightning_monai.py:46-67,68-79,86-93,190-195,255-278; MONAI itself is a
+ * pinned dependency that is not vendored: PARITY UNPINNED by any reference test).
+ * ---------------------------------------------------------------------------------------------- */
+enum { MISEG_LABEL_F32 = 0, MISEG_LABEL_I32 = 1, MISEG_LABEL_I64 = 2, MISEG_LABEL_U8 = 3 };
+enum { MISEG_LOSS_DICE_FOCAL = 0, MISEG_LOSS_DICE_CE = 1 };
+/* DiceFocalLoss / DiceCELoss(to_onehot_y=True, softmax=True) on fp32 NCDHW logits [B][C][S] and class-id labels [B][1][S]
+ * (lightning_monai.py:48-65, training_step :149-166).
+ *   dice_focal, include_background = 0: channel 0 is stripped from logits AND target first, the softmax of the Dice term runs over the C-1
+ *     foreground logits, the focal term (sigmoid form on raw logits, gamma) over the same channels;  = 1: all C channels.
+ *   dice_ce: softmax over all C channels, Dice over channels >= (include_background ? 0 : 1), cross-entropy over all channels.
+ *   Dice per (b, c): 1 - (2 sum(p t) + smooth_nr) / (sum(t) + sum(p^2 or p) + smooth_dr), mean over (b, c); focal: mean over (b, c, s); CE: mean over (b, s).
+ * miseg_seg_loss_fwd: one pass over logits + labels -> per-workgroup fp64 partial sums in `workspace`, summed in a FIXED order by a
+ *   one-workgroup launch (bit-reproducible) into sums[B][C][3] (sum p t, sum p^2|p, sum t) + sums[3 B C] (focal / CE total) and the scalar loss.
+ * miseg_seg_loss_bwd: second pass -> dlogits [B][C][S] fp32 = gscale * d(loss)/d(logits) (gscale: device scalar or NULL = 1), from the saved sums. */
+typedef struct {
+  uint32_t struct_size;            /* sizeof(miseg_seg_loss_params): checked against the library's own */
+  int kind;                        /* MISEG_LOSS_* */
+  const float* logits; const void* label; int label_dtype;
+  int B, C; int64_t S;
+  int include_background, squared_pred;
+  float smooth_nr, smooth_dr, gamma, lambda_dice, lambda_other;
+  void* workspace;                 /* miseg_seg_loss_workspace_bytes(B, C, S) bytes, uninitialised */
+  double* sums;                    /* out (fwd) / in (bwd): 3 B C + 1 doubles */
+  float* loss;                     /* out (fwd): scalar */
+  const float* gscale; float* dlogits;   /* bwd only */
+} miseg_seg_loss_params;
+size_t miseg_seg_loss_workspace_bytes(int B, int C, int64_t S);
+int miseg_seg_loss_fwd(const miseg_seg_loss_params* p, miseg_stream_t stream);
+int miseg_seg_loss_bwd(const miseg_seg_loss_params* p, miseg_stream_t stream);
+
+/* DiceMetric(include_background=True, get_not_nans=True) after AsDiscrete(argmax=True, to_onehot=C) (lightning_monai.py:68-79,190-195):
+ * dice[b][c] = 2 |pred == c & label == c| / (|pred == c| + |label == c|), NaN where |label == c| == 0; argmax takes the FIRST maximum.
+ * counts: uint64 [B][C][3] scratch (zeroed by the call; integer atomics: bit-reproducible). */
+typedef struct {
+  uint32_t struct_size;
+  const float* logits; const void* label; int label_dtype;
+  int B, C; int64_t S;
+  uint64_t* counts; float* dice;   /* out fp32 [B][C] */
+} miseg_dice_metric_params;
+int miseg_dice_metric(const miseg_dice_metric_params* p, miseg_stream_t stream);
+
+/* One optimiser step for every parameter of a model in ONE launch (lightning_monai.py:255-278: AdamW / Adam / SGD-nesterov), over the flat
+ * fp32 gradient arena the weight-gradient kernels accumulate into.  Descriptor i: parameter tensor `param` of n elements whose gradient, and
+ * whose two state slots, live at element offset `off` of grad / state1 / state2 (state2 unused by SGD).  used[i] == 0 => the parameter had no
+ * gradient this step (`grad is None`: an absent style's norm rows) and is skipped entirely - no update, no weight decay, no step count -
+ * exactly like torch.optim skips `p.grad is None`.  steps[i] (int32, device) counts the updates of parameter i (Adam bias correction).
+ * Descriptors live in device memory sorted by block0 = number of 4096-element blocks before them. */
+enum { MISEG_OPT_ADAMW = 0, MISEG_OPT_ADAM = 1, MISEG_OPT_SGD_NESTEROV = 2 };
+typedef struct { float* param; int64_t off; int32_t n, block0; } miseg_opt_desc;
+typedef struct {
+  uint32_t struct_size;
+  int kind;
+  const miseg_opt_desc* descs_dev; int ndesc, total_blocks;
+  const float* grad; float* state1; float* state2;
+  const int32_t* used; int32_t* steps;
+  float lr, beta1, beta2, eps, weight_decay, momentum;
+  const float* lr_dev;             /* optional device scalar overriding lr (schedulers under hipGraph replay) */
+} miseg_opt_step_params;
+int miseg_opt_step(const miseg_opt_step_params* p, miseg_stream_t stream);
+
+/* Sliding-window stitching (MONAI sliding_window_inference, mode="constant", as used at lightning_monai.py:86-93,187): every window's logits
+ * stay resident (win: fp32 [nd*nh*nw][C][rd][rh][rw], window (id, ih, iw) at index (id*nh + ih)*nw + iw, origin (start_d[id], start_h[ih],
+ * start_w[iw]); 700 windows x 6 x 96^3 = 14.9 GB of the 288), and ONE gather pass writes out[c][d][h][w] = (sum over the windows covering the
+ * voxel, in window-index order = the order MONAI accumulates them) / count.  No atomics, no read-modify-write of the 2.3 GB accumulator.
+ * starts: HOST int32 arrays (copied into the kernel arguments; at most MISEG_STITCH_MAX_WINDOWS per axis); count (optional): uint16 [D][H][W]. */
+#define MISEG_STITCH_MAX_WINDOWS 32
+typedef struct {
+  uint32_t struct_size;
+  const float* win; float* out; uint16_t* count;
+  int C, D, H, W, rd, rh, rw, nd, nh, nw;
+  const int32_t* start_d; const int32_t* start_h; const int32_t* start_w;
+} miseg_stitch_params;
+int miseg_stitch_windows(const miseg_stitch_params* p, miseg_stream_t stream);
+
+/* sizeof() of a params struct as this library was compiled ("miseg_gemm_params", ...), 0 for an unknown name: bindings compare it with
+ * their own mirror at load time (together with miseg_abi_version) so that header and binding cannot drift silently. */
+size_t miseg_abi_struct_size(const char* struct_name);
+/* MISEG_OK when HIP device `device` runs the code objects embedded in this library (gcnArchName starts with miseg_device_arch) */
+int miseg_device_check(int device);
 
 #ifdef __cplusplus
 }

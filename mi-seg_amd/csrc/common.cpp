@@ -2,6 +2,10 @@
 #include "common.h"
 #include <string.h>
 
+#ifndef MISEG_COMPILED_ARCH
+#define MISEG_COMPILED_ARCH "gfx950"
+#endif
+
 namespace miseg {
 static thread_local char g_err[512] = "";
 
@@ -14,11 +18,40 @@ int set_error(int code, const char* fmt, ...) {
 }
 }  // namespace miseg
 
-extern "C" int miseg_abi_version(void) { return 1; }
+extern "C" int miseg_abi_version(void) { return MISEG_ABI_VERSION; }
+
+// sizeof() of every params / descriptor struct of include/miseg_hip.h as compiled into this library (tests/test_abi.py and
+// hip/lib.py::load compare them with the ctypes mirror)
+extern "C" size_t miseg_abi_struct_size(const char* name) {
+  if (!name) return 0;
+#define MISEG_SZ(T) if (strcmp(name, #T) == 0) return sizeof(T);
+  MISEG_SZ(miseg_instnorm_stats_params) MISEG_SZ(miseg_instnorm_apply_params) MISEG_SZ(miseg_instnorm_bwd_params) MISEG_SZ(miseg_instnorm_pair_bwd_params)
+  MISEG_SZ(miseg_layernorm_fwd_params) MISEG_SZ(miseg_layernorm_bwd_params) MISEG_SZ(miseg_gemm_params) MISEG_SZ(miseg_tn_reduce_desc) MISEG_SZ(miseg_gemm_tn_desc)
+  MISEG_SZ(miseg_colsum_params) MISEG_SZ(miseg_colsum_desc) MISEG_SZ(miseg_conv3_params) MISEG_SZ(miseg_pack_conv3_params) MISEG_SZ(miseg_pack_conv3_desc)
+  MISEG_SZ(miseg_conv3_wgrad_params) MISEG_SZ(miseg_winattn_params) MISEG_SZ(miseg_winattn_bwd_params) MISEG_SZ(miseg_add_params) MISEG_SZ(miseg_copy2d_params)
+  MISEG_SZ(miseg_cast_params) MISEG_SZ(miseg_cast_desc) MISEG_SZ(miseg_gelu_fwd_params) MISEG_SZ(miseg_gelu_bwd_params) MISEG_SZ(miseg_s2c_params)
+  MISEG_SZ(miseg_patch_embed_params) MISEG_SZ(miseg_patch_embed_bwd_params) MISEG_SZ(miseg_conv3_thin_params) MISEG_SZ(miseg_conv3_thin_wgrad_params)
+  MISEG_SZ(miseg_resample2_params) MISEG_SZ(miseg_rowbias_params) MISEG_SZ(miseg_prelu_fwd_params) MISEG_SZ(miseg_prelu_bwd_params) MISEG_SZ(miseg_head_params)
+  MISEG_SZ(miseg_head_bwd_params) MISEG_SZ(miseg_im2col3_params) MISEG_SZ(miseg_seg_loss_params) MISEG_SZ(miseg_dice_metric_params) MISEG_SZ(miseg_opt_desc)
+  MISEG_SZ(miseg_opt_step_params) MISEG_SZ(miseg_stitch_params)
+#undef MISEG_SZ
+  return 0;
+}
 extern "C" const char* miseg_last_error(void) { return miseg::g_err; }
 extern "C" int miseg_device_arch(char* buf, size_t n) {
   if (!buf || n == 0) return MISEG_E_BADARG;
-  strncpy(buf, "gfx950", n);
+  strncpy(buf, MISEG_COMPILED_ARCH, n);      // the only code objects in this library (build.py: --offload-arch)
   buf[n - 1] = 0;
+  return MISEG_OK;
+}
+
+extern "C" int miseg_device_check(int device) {
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    (void)hipGetLastError();
+    return miseg::set_error(MISEG_E_BADARG, "device_check: no HIP device %d", device);
+  }
+  if (strncmp(prop.gcnArchName, MISEG_COMPILED_ARCH, strlen(MISEG_COMPILED_ARCH)) != 0)
+    return miseg::set_error(MISEG_E_UNSUPPORTED, "device %d is %s; this library holds %s code objects only", device, prop.gcnArchName, MISEG_COMPILED_ARCH);
   return MISEG_OK;
 }

@@ -1,0 +1,555 @@
+// What runs right after the hot path every training / validation step, all HBM-bound:
+//   * DiceFocal / DiceCE loss: one pass for the per-(b,c) sums + loss, one pass for d(loss)/d(logits)      (lightning_monai.py:46-67)
+//   * Dice metric after argmax / one-hot                                                                     (lightning_monai.py:68-79,190-195)
+//   * AdamW / Adam / SGD-nesterov step of EVERY parameter in one launch over the gradient arena              (lightning_monai.py:255-278)
+//   * sliding-window stitching as one gather over resident window logits                                     (lightning_monai.py:86-93,187)
+// MONAI 1.1.0 arithmetic restated from its public API (parity unpinned by any reference test).
+#include "common.h"
+#include <math.h>
+
+namespace miseg {
+
+constexpr int LOSS_MAXC = 16;          // channels kept in registers per voxel
+constexpr int LOSS_VPB = 2048;         // voxels per workgroup (256 threads x 2 float4 groups)
+
+template <class L> __device__ __forceinline__ int label_at(const L* lab, int64_t i) { return (int)lab[i]; }
+
+__device__ __forceinline__ float softplus_neg(float x) {      // log(1 + exp(-x)), stable
+  return fmaxf(-x, 0.f) + log1pf(__expf(-fabsf(x)));
+}
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
+
+struct LossGeom {
+  int B, C, kind, c0, sq;
+  int64_t S;
+  float gamma;
+};
+
+// value of the per-element focal term and its derivative w.r.t. x (MONAI 1.1.0 FocalLoss, sigmoid form on raw logits):
+//   ce = x - x t + softplus(-x);   w = exp(gamma * logsigmoid(-x z)), z = 2 t - 1;   f = w ce
+__device__ __forceinline__ void focal_term(float x, float t, float gamma, float& f, float& df) {
+  const float z = 2.f * t - 1.f;
+  const float ce = x - x * t + softplus_neg(x);
+  const float ls = -softplus_neg(-x * z);            // logsigmoid(-x z) = -softplus(x z) = -log(1 + exp(x z))
+  const float w = __expf(gamma * ls);
+  f = w * ce;
+  df = w * (-gamma * z * sigmoidf(x * z) * ce + sigmoidf(x) - t);
+}
+
+// softmax over channels [c0s, C) of x -> p (p[c < c0s] = 0); returns log-sum-exp
+template <int MAXC> __device__ __forceinline__ float softmax_from(const float (&x)[MAXC], float (&p)[MAXC], int c0s, int C) {
+  float mx = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) if (c >= c0s && c < C) mx = fmaxf(mx, x[c]);
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    p[c] = (c >= c0s && c < C) ? __expf(x[c] - mx) : 0.f;
+    sum += p[c];
+  }
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) p[c] *= inv;
+  return mx + __logf(sum);
+}
+
+// grid (blocks per sample, B).  part: double [B][nblk][3 C + 1]
+template <class L, int MAXC, int VEC>
+__global__ void __launch_bounds__(256) seg_loss_fwd_kernel(const float* __restrict__ logits, const L* __restrict__ label, LossGeom g, double* __restrict__ part) {
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int c0d = g.c0, c0s = g.kind == MISEG_LOSS_DICE_CE ? 0 : g.c0;
+  const float* xb = logits + (int64_t)b * g.C * g.S;
+  const L* lb = label + (int64_t)b * g.S;
+  float aI[MAXC], aP[MAXC], aT[MAXC], aO = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) aI[c] = aP[c] = aT[c] = 0.f;
+  const int64_t base = (int64_t)blockIdx.x * LOSS_VPB;
+  for (int it = 0; it < LOSS_VPB / (256 * VEC); ++it) {
+    const int64_t s0 = base + ((int64_t)it * 256 + tid) * VEC;
+    if (s0 >= g.S) break;
+    float xv[MAXC][VEC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      if (c < g.C) {
+        if constexpr (VEC == 4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(xb + (int64_t)c * g.S + s0);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) xv[c][v] = t[v];
+        } else xv[c][0] = xb[(int64_t)c * g.S + s0];
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) xv[c][v] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      if (s0 + v >= g.S) break;
+      const int lab = label_at(lb, s0 + v);
+      float x[MAXC], p[MAXC];
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) x[c] = xv[c][v];
+      const float lse = softmax_from<MAXC>(x, p, c0s, g.C);
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) {
+        if (c >= c0d && c < g.C) {
+          const float t = (lab == c) ? 1.f : 0.f;
+          aI[c] += p[c] * t;
+          aP[c] += g.sq ? p[c] * p[c] : p[c];
+          aT[c] += t;
+          if (g.kind == MISEG_LOSS_DICE_FOCAL) {
+            float f, df;
+            focal_term(x[c], t, g.gamma, f, df);
+            aO += f;
+          }
+        }
+      }
+      if (g.kind == MISEG_LOSS_DICE_CE) {
+        float xl = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) if (c == lab) xl = x[c];
+        aO += lse - xl;
+      }
+    }
+  }
+  __shared__ float red[4][3 * MAXC + 1];
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    if (c < g.C) {       // uniform branch
+      const float i = wave_sum(aI[c]), pp = wave_sum(aP[c]), t = wave_sum(aT[c]);
+      if (lane == 0) { red[wave][3 * c] = i; red[wave][3 * c + 1] = pp; red[wave][3 * c + 2] = t; }
+    }
+  }
+  const float o = wave_sum(aO);
+  if (lane == 0) red[wave][3 * MAXC] = o;
+  __syncthreads();
+  const int nv = 3 * g.C + 1;
+  if (tid < nv) {
+    const int src = tid < 3 * g.C ? tid : 3 * MAXC;
+    const double v = ((double)red[0][src] + (double)red[1][src]) + ((double)red[2][src] + (double)red[3][src]);
+    part[((int64_t)b * gridDim.x + blockIdx.x) * nv + tid] = v;
+  }
+}
+
+// one workgroup: sums[b][c][k] = sum over blocks (fixed order), sums[3 B C] = total of the focal / CE term, loss scalar
+static __global__ void __launch_bounds__(256) seg_loss_finalize_kernel(const double* __restrict__ part, int nblk, LossGeom g, float nr, float dr, float ld, float lo,
+                                                                    double* __restrict__ sums, float* __restrict__ loss) {
+  const int nv = 3 * g.C + 1, tid = threadIdx.x;
+  __shared__ double sh[256];
+  __shared__ double other[64];
+  for (int b = 0; b < g.B; ++b) {
+    for (int v = 0; v < nv; ++v) {
+      double a = 0.0;
+      for (int k = tid; k < nblk; k += 256) a += part[((int64_t)b * nblk + k) * nv + v];
+      sh[tid] = a;
+      __syncthreads();
+      for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) sh[tid] += sh[tid + o];
+        __syncthreads();
+      }
+      if (tid == 0) {
+        if (v < 3 * g.C) sums[(int64_t)b * 3 * g.C + v] = sh[0];
+        else other[b] = sh[0];
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) {
+    double tot_o = 0.0, dice = 0.0;
+    for (int b = 0; b < g.B; ++b) {
+      tot_o += other[b];
+      for (int c = g.c0; c < g.C; ++c) {
+        const double* q = sums + ((int64_t)b * g.C + c) * 3;
+        dice += 1.0 - (2.0 * q[0] + nr) / (q[2] + q[1] + dr);
+      }
+    }
+    const int cn = g.C - g.c0;
+    sums[(int64_t)3 * g.B * g.C] = tot_o;
+    const double o_mean = g.kind == MISEG_LOSS_DICE_FOCAL ? tot_o / ((double)g.B * cn * g.S) : tot_o / ((double)g.B * g.S);
+    *loss = (float)(ld * dice / ((double)g.B * cn) + lo * o_mean);
+  }
+}
+
+template <class L, int MAXC, int VEC>
+__global__ void __launch_bounds__(256) seg_loss_bwd_kernel(const float* __restrict__ logits, const L* __restrict__ label, LossGeom g, float nr, float dr, float ld, float lo,
+                                                           const double* __restrict__ sums, const float* __restrict__ gscale, float* __restrict__ dlogits) {
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int c0d = g.c0, c0s = g.kind == MISEG_LOSS_DICE_CE ? 0 : g.c0;
+  const int cn = g.C - g.c0;
+  const float gs = gscale ? *gscale : 1.f;
+  // per-channel Dice coefficients: dD/dp = ca t + cb p (squared) | ca t + cb (plain)
+  float ca[MAXC], cb[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    ca[c] = cb[c] = 0.f;
+    if (c >= c0d && c < g.C) {
+      const double* q = sums + ((int64_t)b * g.C + c) * 3;
+      const double den = q[2] + q[1] + dr, num = 2.0 * q[0] + nr, k = (double)ld * gs / ((double)g.B * cn);
+      ca[c] = (float)(-2.0 * k / den);
+      cb[c] = (float)((g.sq ? 2.0 : 1.0) * k * num / (den * den));
+    }
+  }
+  const float ko = g.kind == MISEG_LOSS_DICE_FOCAL ? lo * gs / ((float)g.B * cn * (float)g.S) : lo * gs / ((float)g.B * (float)g.S);
+  const float* xb = logits + (int64_t)b * g.C * g.S;
+  float* db = dlogits + (int64_t)b * g.C * g.S;
+  const L* lb = label + (int64_t)b * g.S;
+  const int64_t base = (int64_t)blockIdx.x * LOSS_VPB;
+  for (int it = 0; it < LOSS_VPB / (256 * VEC); ++it) {
+    const int64_t s0 = base + ((int64_t)it * 256 + tid) * VEC;
+    if (s0 >= g.S) break;
+    float xv[MAXC][VEC], dv[MAXC][VEC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      if (c < g.C) {
+        if constexpr (VEC == 4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(xb + (int64_t)c * g.S + s0);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) xv[c][v] = t[v];
+        } else xv[c][0] = xb[(int64_t)c * g.S + s0];
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) xv[c][v] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const int lab = (s0 + v < g.S) ? label_at(lb, s0 + v) : 0;
+      float x[MAXC], p[MAXC], G[MAXC];
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) x[c] = xv[c][v];
+      softmax_from<MAXC>(x, p, c0s, g.C);
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) {
+        const float t = (lab == c) ? 1.f : 0.f;
+        G[c] = ca[c] * t + (g.sq ? cb[c] * p[c] : cb[c]);       // zero outside the Dice channels (ca = cb = 0)
+        dot += G[c] * p[c];
+      }
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) {
+        const float t = (lab == c) ? 1.f : 0.f;
+        float d = p[c] * (G[c] - dot);                            // softmax Jacobian; p = 0 outside the softmax support
+        if (g.kind == MISEG_LOSS_DICE_FOCAL) {
+          if (c >= c0d && c < g.C) {
+            float f, df;
+            focal_term(x[c], t, g.gamma, f, df);
+            d += ko * df;
+          }
+        } else if (c < g.C) d += ko * (p[c] - t);                 // CE: softmax over all channels is p itself (c0s = 0)
+        dv[c][v] = d;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      if (c < g.C) {
+        if constexpr (VEC == 4) {
+          f32x4 t;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) t[v] = dv[c][v];
+          *reinterpret_cast<f32x4*>(db + (int64_t)c * g.S + s0) = t;
+        } else db[(int64_t)c * g.S + s0] = dv[c][0];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ Dice metric
+template <class L, int MAXC>
+__global__ void __launch_bounds__(256) dice_count_kernel(const float* __restrict__ logits, const L* __restrict__ label, int C, int64_t S, unsigned long long* __restrict__ counts) {
+  __shared__ int cnt[3 * MAXC];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  if (tid < 3 * MAXC) cnt[tid] = 0;
+  __syncthreads();
+  const float* xb = logits + (int64_t)b * C * S;
+  const L* lb = label + (int64_t)b * S;
+  for (int64_t s = (int64_t)blockIdx.x * 256 + tid; s < S; s += (int64_t)gridDim.x * 256) {
+    int arg = 0;
+    float mx = xb[s];
+    for (int c = 1; c < C; ++c) {
+      const float v = xb[(int64_t)c * S + s];
+      if (v > mx) { mx = v; arg = c; }            // strict: the FIRST maximum wins (torch.argmax)
+    }
+    const int lab = label_at(lb, s);
+    atomicAdd(&cnt[3 * arg + 1], 1);
+    if (lab >= 0 && lab < C) {
+      atomicAdd(&cnt[3 * lab + 2], 1);
+      if (lab == arg) atomicAdd(&cnt[3 * arg], 1);
+    }
+  }
+  __syncthreads();
+  if (tid < 3 * C && cnt[tid]) atomicAdd(&counts[(int64_t)b * 3 * C + tid], (unsigned long long)cnt[tid]);
+}
+
+static __global__ void dice_finalize_kernel(const unsigned long long* __restrict__ counts, int n, float* __restrict__ dice) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double inter = (double)counts[3 * i], np = (double)counts[3 * i + 1], nl = (double)counts[3 * i + 2];
+  dice[i] = nl > 0 ? (float)(2.0 * inter / (np + nl)) : __int_as_float(0x7fc00000);
+}
+
+// ------------------------------------------------------------------------------------------------ optimiser
+constexpr int OPT_BLOCK = 4096;     // elements per workgroup (256 threads x 4 float4)
+
+static __global__ void __launch_bounds__(256) opt_step_kernel(const miseg_opt_desc* __restrict__ descs, int ndesc, int kind, const float* __restrict__ grad, float* __restrict__ s1,
+                                                            float* __restrict__ s2, const int32_t* __restrict__ used, int32_t* __restrict__ steps, float lr, float b1, float b2,
+                                                            float eps, float wd, float mom, const float* __restrict__ lr_dev) {
+  // descriptor of this workgroup: the last one with block0 <= blockIdx.x
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const miseg_opt_desc d = descs[lo];
+  if (used && !used[lo]) return;
+  if (lr_dev) lr = *lr_dev;
+  const int blk = blockIdx.x - d.block0;
+  const int step = steps[lo] + 1;                    // read by every workgroup of the tensor; written back by a separate tiny launch
+  float bc1 = 1.f, bc2s = 1.f;
+  if (kind != MISEG_OPT_SGD_NESTEROV) {
+    bc1 = 1.f - powf(b1, (float)step);
+    bc2s = sqrtf(1.f - powf(b2, (float)step));
+  }
+  const float step_size = lr / bc1;
+  float* p = d.param;
+  const float* gp = grad + d.off;
+  float* m = s1 + d.off;
+  float* v = s2 ? s2 + d.off : nullptr;
+  const int e0 = blk * OPT_BLOCK;
+  const bool vec = (((uintptr_t)p) & 15) == 0;      // arena slots are 16-byte aligned; a parameter view may not be
+  for (int it = 0; it < 4; ++it) {
+    const int e = e0 + (it * 256 + threadIdx.x) * 4;
+    if (e >= d.n) break;
+    const int cnt = d.n - e < 4 ? d.n - e : 4;
+    float pv[4], gv[4], mv[4], vv[4];
+    if (vec && cnt == 4) {
+      const f32x4 tp = *reinterpret_cast<const f32x4*>(p + e), tg = *reinterpret_cast<const f32x4*>(gp + e), tm = *reinterpret_cast<const f32x4*>(m + e);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { pv[k] = tp[k]; gv[k] = tg[k]; mv[k] = tm[k]; }
+      if (v) {
+        const f32x4 tv = *reinterpret_cast<const f32x4*>(v + e);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vv[k] = tv[k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool ok = k < cnt;
+        pv[k] = ok ? p[e + k] : 0.f; gv[k] = ok ? gp[e + k] : 0.f; mv[k] = ok ? m[e + k] : 0.f; vv[k] = (ok && v) ? v[e + k] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float g = gv[k], w = pv[k];
+      if (kind == MISEG_OPT_ADAMW) {
+        w *= 1.f - lr * wd;
+      } else {
+        g += wd * w;                                  // Adam / SGD: L2 term folded into the gradient
+      }
+      if (kind == MISEG_OPT_SGD_NESTEROV) {
+        const float buf = step == 1 ? g : mom * mv[k] + g;      // torch.optim.SGD: the first momentum buffer is the gradient itself
+        mv[k] = buf;
+        w -= lr * (g + mom * buf);
+      } else {
+        mv[k] = mv[k] + (1.f - b1) * (g - mv[k]);               // torch: exp_avg.lerp_(grad, 1 - beta1)
+        vv[k] = b2 * vv[k] + (1.f - b2) * g * g;
+        const float denom = sqrtf(vv[k]) / bc2s + eps;
+        w -= step_size * (mv[k] / denom);
+      }
+      pv[k] = w;
+    }
+    if (vec && cnt == 4) {
+      f32x4 tp, tm, tv;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { tp[k] = pv[k]; tm[k] = mv[k]; tv[k] = vv[k]; }
+      *reinterpret_cast<f32x4*>(p + e) = tp;
+      *reinterpret_cast<f32x4*>(m + e) = tm;
+      if (v) *reinterpret_cast<f32x4*>(v + e) = tv;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < cnt) { p[e + k] = pv[k]; m[e + k] = mv[k]; if (v) v[e + k] = vv[k]; }
+    }
+  }
+}
+
+static __global__ void opt_count_kernel(const int32_t* __restrict__ used, int32_t* __restrict__ steps, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && (!used || used[i])) steps[i] += 1;
+}
+
+// ------------------------------------------------------------------------------------------------ stitching
+struct StitchArgs {
+  int C, D, H, W, rd, rh, rw, nd, nh, nw;
+  int sd[MISEG_STITCH_MAX_WINDOWS], sh[MISEG_STITCH_MAX_WINDOWS], sw[MISEG_STITCH_MAX_WINDOWS];
+};
+
+// windows of one axis covering coordinate x: starts are non-decreasing, so they form a contiguous index range [lo, hi]
+__device__ __forceinline__ void cover(const int* st, int n, int r, int x, int& lo, int& hi) {
+  lo = n; hi = -1;
+  for (int i = 0; i < n; ++i)
+    if (st[i] <= x && x < st[i] + r) { if (lo == n) lo = i; hi = i; }
+}
+
+// grid (ceil(W/64 / 4)..., H, D): thread = one voxel; channels looped (C small).  Reads of a window row are contiguous along w.
+static __global__ void __launch_bounds__(256) stitch_kernel(const float* __restrict__ win, float* __restrict__ out, uint16_t* __restrict__ count, StitchArgs a) {
+  const int w = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y, d = blockIdx.z;
+  if (w >= a.W) return;
+  int dl, dh_, hl, hh, wl, wh;
+  cover(a.sd, a.nd, a.rd, d, dl, dh_);
+  cover(a.sh, a.nh, a.rh, h, hl, hh);
+  cover(a.sw, a.nw, a.rw, w, wl, wh);
+  const int n = (dh_ - dl + 1) * (hh - hl + 1) * (wh - wl + 1);
+  const int64_t rvol = (int64_t)a.rd * a.rh * a.rw, vox = (int64_t)a.D * a.H * a.W;
+  const int64_t o = ((int64_t)d * a.H + h) * a.W + w;
+  if (count) count[o] = (uint16_t)n;
+  for (int c = 0; c < a.C; ++c) {
+    float acc = 0.f;
+    for (int id = dl; id <= dh_; ++id)
+      for (int ih = hl; ih <= hh; ++ih)
+        for (int iw = wl; iw <= wh; ++iw) {
+          const int64_t wi = ((int64_t)id * a.nh + ih) * a.nw + iw;
+          acc += win[(wi * a.C + c) * rvol + ((int64_t)(d - a.sd[id]) * a.rh + (h - a.sh[ih])) * a.rw + (w - a.sw[iw])];
+        }
+    out[(int64_t)c * vox + o] = acc / (float)n;         // MONAI: output_image / count_map (a true division: bit-identical)
+  }
+}
+
+template <class F> static int dispatch_label(int dt, F&& f) {
+  switch (dt) {
+    case MISEG_LABEL_F32: return f((const float*)nullptr);
+    case MISEG_LABEL_I32: return f((const int32_t*)nullptr);
+    case MISEG_LABEL_I64: return f((const int64_t*)nullptr);
+    case MISEG_LABEL_U8: return f((const uint8_t*)nullptr);
+  }
+  return set_error(MISEG_E_BADARG, "unknown label dtype %d", dt);
+}
+
+static int loss_check(const miseg_seg_loss_params* p, const char* what) {
+  MISEG_REQUIRE(p && p->struct_size == sizeof(miseg_seg_loss_params), MISEG_E_BADARG, "%s: struct_size %u != %zu (header / binding drift)", what,
+                p ? p->struct_size : 0u, sizeof(miseg_seg_loss_params));
+  MISEG_REQUIRE(p->logits && p->label && p->sums && p->workspace, MISEG_E_BADARG, "%s: null pointer", what);
+  MISEG_REQUIRE(p->B > 0 && p->B <= 64 && p->C >= 2 && p->C <= LOSS_MAXC && p->S > 0, MISEG_E_UNSUPPORTED, "%s: B %d (<= 64), C %d (2..%d)", what, p->B, p->C, LOSS_MAXC);
+  MISEG_REQUIRE(p->kind == MISEG_LOSS_DICE_FOCAL || p->kind == MISEG_LOSS_DICE_CE, MISEG_E_BADARG, "%s: kind %d", what, p->kind);
+  return MISEG_OK;
+}
+
+static LossGeom loss_geom(const miseg_seg_loss_params* p) {
+  LossGeom g;
+  g.B = p->B; g.C = p->C; g.kind = p->kind; g.c0 = p->include_background ? 0 : 1; g.sq = p->squared_pred ? 1 : 0; g.S = p->S; g.gamma = p->gamma;
+  return g;
+}
+
+}  // namespace miseg
+
+using namespace miseg;
+
+extern "C" size_t miseg_seg_loss_workspace_bytes(int B, int C, int64_t S) {
+  return (size_t)B * (size_t)cdiv(S, LOSS_VPB) * (3 * C + 1) * sizeof(double);
+}
+
+extern "C" int miseg_seg_loss_fwd(const miseg_seg_loss_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (int rc = loss_check(p, "seg_loss_fwd")) return rc;
+  MISEG_REQUIRE(p->loss, MISEG_E_BADARG, "seg_loss_fwd: null loss pointer");
+  const LossGeom g = loss_geom(p);
+  const int nblk = cdiv(p->S, LOSS_VPB);
+  const bool vec = p->S % 4 == 0 && ((uintptr_t)p->logits & 15) == 0;
+  return dispatch_label(p->label_dtype, [&](auto* tag) -> int {
+    typedef typename std::remove_const<typename std::remove_pointer<decltype(tag)>::type>::type L;
+    dim3 grid(nblk, p->B);
+    if (p->C <= 8) {
+      if (vec) seg_loss_fwd_kernel<L, 8, 4><<<grid, 256, 0, s>>>(p->logits, (const L*)p->label, g, (double*)p->workspace);
+      else seg_loss_fwd_kernel<L, 8, 1><<<grid, 256, 0, s>>>(p->logits, (const L*)p->label, g, (double*)p->workspace);
+    } else {
+      seg_loss_fwd_kernel<L, LOSS_MAXC, 1><<<grid, 256, 0, s>>>(p->logits, (const L*)p->label, g, (double*)p->workspace);
+    }
+    MISEG_LAUNCH_CHECK("seg_loss_fwd");
+    seg_loss_finalize_kernel<<<1, 256, 0, s>>>((const double*)p->workspace, nblk, g, p->smooth_nr, p->smooth_dr, p->lambda_dice, p->lambda_other, p->sums, p->loss);
+    MISEG_LAUNCH_CHECK("seg_loss_finalize");
+    return MISEG_OK;
+  });
+}
+
+extern "C" int miseg_seg_loss_bwd(const miseg_seg_loss_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  if (int rc = loss_check(p, "seg_loss_bwd")) return rc;
+  MISEG_REQUIRE(p->dlogits, MISEG_E_BADARG, "seg_loss_bwd: null dlogits pointer");
+  const LossGeom g = loss_geom(p);
+  const int nblk = cdiv(p->S, LOSS_VPB);
+  const bool vec = p->S % 4 == 0 && ((uintptr_t)p->logits & 15) == 0 && ((uintptr_t)p->dlogits & 15) == 0;
+  return dispatch_label(p->label_dtype, [&](auto* tag) -> int {
+    typedef typename std::remove_const<typename std::remove_pointer<decltype(tag)>::type>::type L;
+    dim3 grid(nblk, p->B);
+#define MISEG_LB(MAXC, VEC) seg_loss_bwd_kernel<L, MAXC, VEC><<<grid, 256, 0, s>>>(p->logits, (const L*)p->label, g, p->smooth_nr, p->smooth_dr, p->lambda_dice, \
+                                                                                    p->lambda_other, p->sums, p->gscale, p->dlogits)
+    if (p->C <= 8) {
+      if (vec) MISEG_LB(8, 4); else MISEG_LB(8, 1);
+    } else MISEG_LB(LOSS_MAXC, 1);
+#undef MISEG_LB
+    MISEG_LAUNCH_CHECK("seg_loss_bwd");
+    return MISEG_OK;
+  });
+}
+
+extern "C" int miseg_dice_metric(const miseg_dice_metric_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->struct_size == sizeof(miseg_dice_metric_params), MISEG_E_BADARG, "dice_metric: struct_size %u != %zu", p ? p->struct_size : 0u,
+                sizeof(miseg_dice_metric_params));
+  MISEG_REQUIRE(p->logits && p->label && p->counts && p->dice, MISEG_E_BADARG, "dice_metric: null pointer");
+  MISEG_REQUIRE(p->B > 0 && p->C >= 1 && p->C <= 64 && p->S > 0, MISEG_E_UNSUPPORTED, "dice_metric: C %d (1..64)", p->C);
+  if (fill_words_async(p->counts, 0, (size_t)p->B * p->C * 3 * 2, s) != hipSuccess) return set_error(MISEG_E_LAUNCH, "dice_metric: fill");
+  return dispatch_label(p->label_dtype, [&](auto* tag) -> int {
+    typedef typename std::remove_const<typename std::remove_pointer<decltype(tag)>::type>::type L;
+    int gx = cdiv(p->S, 256 * 8);
+    if (gx > 2048) gx = 2048;
+    dice_count_kernel<L, 64><<<dim3(gx, p->B), 256, 0, s>>>(p->logits, (const L*)p->label, p->C, p->S, (unsigned long long*)p->counts);
+    MISEG_LAUNCH_CHECK("dice_count");
+    dice_finalize_kernel<<<cdiv(p->B * p->C, 64), 64, 0, s>>>((const unsigned long long*)p->counts, p->B * p->C, p->dice);
+    MISEG_LAUNCH_CHECK("dice_finalize");
+    return MISEG_OK;
+  });
+}
+
+extern "C" int miseg_opt_step(const miseg_opt_step_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->struct_size == sizeof(miseg_opt_step_params), MISEG_E_BADARG, "opt_step: struct_size %u != %zu", p ? p->struct_size : 0u,
+                sizeof(miseg_opt_step_params));
+  MISEG_REQUIRE(p->descs_dev && p->grad && p->state1 && p->steps && p->ndesc > 0 && p->total_blocks > 0, MISEG_E_BADARG, "opt_step: null pointer / empty table");
+  MISEG_REQUIRE(p->kind == MISEG_OPT_ADAMW || p->kind == MISEG_OPT_ADAM || p->kind == MISEG_OPT_SGD_NESTEROV, MISEG_E_BADARG, "opt_step: kind %d", p->kind);
+  MISEG_REQUIRE(p->kind == MISEG_OPT_SGD_NESTEROV || p->state2, MISEG_E_BADARG, "opt_step: Adam needs state2");
+  opt_step_kernel<<<p->total_blocks, 256, 0, s>>>(p->descs_dev, p->ndesc, p->kind, p->grad, p->state1, p->kind == MISEG_OPT_SGD_NESTEROV ? nullptr : p->state2, p->used,
+                                                 p->steps, p->lr, p->beta1, p->beta2, p->eps, p->weight_decay, p->momentum, p->lr_dev);
+  MISEG_LAUNCH_CHECK("opt_step");
+  opt_count_kernel<<<cdiv(p->ndesc, 256), 256, 0, s>>>(p->used, p->steps, p->ndesc);
+  MISEG_LAUNCH_CHECK("opt_count");
+  return MISEG_OK;
+}
+
+extern "C" int miseg_stitch_windows(const miseg_stitch_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->struct_size == sizeof(miseg_stitch_params), MISEG_E_BADARG, "stitch_windows: struct_size %u != %zu", p ? p->struct_size : 0u,
+                sizeof(miseg_stitch_params));
+  MISEG_REQUIRE(p->win && p->out && p->start_d && p->start_h && p->start_w, MISEG_E_BADARG, "stitch_windows: null pointer");
+  MISEG_REQUIRE(p->nd > 0 && p->nh > 0 && p->nw > 0 && p->nd <= MISEG_STITCH_MAX_WINDOWS && p->nh <= MISEG_STITCH_MAX_WINDOWS && p->nw <= MISEG_STITCH_MAX_WINDOWS,
+                MISEG_E_UNSUPPORTED, "stitch_windows: %d x %d x %d windows (max %d per axis)", p->nd, p->nh, p->nw, MISEG_STITCH_MAX_WINDOWS);
+  MISEG_REQUIRE(p->C > 0 && p->D > 0 && p->H > 0 && p->W > 0 && p->H <= 65535 && p->D <= 65535, MISEG_E_BADARG, "stitch_windows: bad volume");
+  StitchArgs a;
+  a.C = p->C; a.D = p->D; a.H = p->H; a.W = p->W; a.rd = p->rd; a.rh = p->rh; a.rw = p->rw; a.nd = p->nd; a.nh = p->nh; a.nw = p->nw;
+  const int* src[3] = {p->start_d, p->start_h, p->start_w};
+  int* dst[3] = {a.sd, a.sh, a.sw};
+  const int n[3] = {p->nd, p->nh, p->nw}, r[3] = {p->rd, p->rh, p->rw}, size[3] = {p->D, p->H, p->W};
+  for (int ax = 0; ax < 3; ++ax) {
+    for (int i = 0; i < MISEG_STITCH_MAX_WINDOWS; ++i) dst[ax][i] = i < n[ax] ? src[ax][i] : 0;
+    // every coordinate must be covered, windows inside the volume, starts non-decreasing: checked here, on the host, before any launch
+    int reach = 0;
+    for (int i = 0; i < n[ax]; ++i) {
+      MISEG_REQUIRE(src[ax][i] >= 0 && src[ax][i] + r[ax] <= size[ax] && (i == 0 || src[ax][i] >= src[ax][i - 1]) && src[ax][i] <= reach, MISEG_E_BADARG,
+                    "stitch_windows: axis %d window %d start %d (roi %d, size %d) leaves a gap or leaves the volume", ax, i, src[ax][i], r[ax], size[ax]);
+      reach = src[ax][i] + r[ax];
+    }
+    MISEG_REQUIRE(reach == size[ax], MISEG_E_BADARG, "stitch_windows: axis %d is covered up to %d of %d", ax, reach, size[ax]);
+  }
+  stitch_kernel<<<dim3(cdiv(p->W, 256), p->H, p->D), 256, 0, s>>>(p->win, p->out, p->count, a);
+  MISEG_LAUNCH_CHECK("stitch_windows");
+  return MISEG_OK;
+}

@@ -20,82 +20,108 @@ class _S(C.Structure):
     pass
 
 
-def _struct(name, fields):
-    return type(name, (C.Structure,), {"_fields_": fields})
+ABI_VERSION = 2          # == MISEG_ABI_VERSION of include/miseg_hip.h; load() refuses a library that reports another
+C_NAMES = {}             # ctypes mirror -> name of the C struct it mirrors (tests/test_abi.py checks sizeof / offsetof of every field)
 
 
-InstnormStats = _struct("InstnormStats", [("x", vp), ("ldx", i64), ("B", i32), ("S", i32), ("C", i32), ("dtype", i32), ("stat", vp)])
-InstnormApply = _struct("InstnormApply", [("x", vp), ("ldx", i64), ("res", vp), ("ldres", i64), ("y", vp), ("ldy", i64),
+def _struct(name, fields, cname=None):
+    t = type(name, (C.Structure,), {"_fields_": fields})
+    C_NAMES[t] = cname
+    return t
+
+
+InstnormStats = _struct("InstnormStats", cname="miseg_instnorm_stats_params", fields=[("x", vp), ("ldx", i64), ("B", i32), ("S", i32), ("C", i32), ("dtype", i32), ("stat", vp)])
+InstnormApply = _struct("InstnormApply", cname="miseg_instnorm_apply_params", fields=[("x", vp), ("ldx", i64), ("res", vp), ("ldres", i64), ("y", vp), ("ldy", i64),
                                           ("B", i32), ("S", i32), ("C", i32), ("dtype", i32), ("stat", vp), ("eps", f32),
                                           ("styles", vp), ("num_styles", i32), ("gamma", fp4), ("beta", fp4),
                                           ("act", i32), ("slope", f32), ("res_stat", vp), ("res_gamma", fp4), ("res_beta", fp4),
                                           ("r1x", vp), ("ldr1x", i64), ("r1w", vp)])
-InstnormBwd = _struct("InstnormBwd", [("dy", vp), ("lddy", i64), ("y", vp), ("ldy", i64), ("x", vp), ("ldx", i64),
+InstnormBwd = _struct("InstnormBwd", cname="miseg_instnorm_bwd_params", fields=[("dy", vp), ("lddy", i64), ("y", vp), ("ldy", i64), ("x", vp), ("ldx", i64),
                                       ("dx", vp), ("lddx", i64), ("dres", vp), ("lddres", i64),
                                       ("B", i32), ("S", i32), ("C", i32), ("dtype", i32), ("stat", vp), ("eps", f32), ("dstat", vp),
                                       ("styles", vp), ("num_styles", i32), ("gamma", fp4), ("dgamma", fp4), ("dbeta", fp4),
                                       ("act", i32), ("slope", f32), ("gadd", vp), ("ldgadd", i64), ("beta", fp4)])
-InstnormPairBwd = _struct("InstnormPairBwd", [("dy", vp), ("lddy", i64), ("y", vp), ("ldy", i64), ("xa", vp), ("ldxa", i64), ("xb", vp), ("ldxb", i64),
+InstnormPairBwd = _struct("InstnormPairBwd", cname="miseg_instnorm_pair_bwd_params", fields=[("dy", vp), ("lddy", i64), ("y", vp), ("ldy", i64), ("xa", vp), ("ldxa", i64), ("xb", vp), ("ldxb", i64),
                                               ("dxa", vp), ("lddxa", i64), ("dxb", vp), ("lddxb", i64), ("B", i32), ("S", i32), ("C", i32), ("dtype", i32),
                                               ("stat_a", vp), ("stat_b", vp), ("eps", f32), ("dstat_a", vp), ("dstat_b", vp), ("styles", vp),
                                               ("num_styles", i32), ("gamma_a", fp4), ("gamma_b", fp4), ("dgamma_a", fp4), ("dbeta_a", fp4),
                                               ("dgamma_b", fp4), ("dbeta_b", fp4), ("slope", f32), ("beta_a", fp4), ("beta_b", fp4),
                                               ("r1x", vp), ("ldr1x", i64), ("r1w", vp), ("r1dw", vp)])
-LayernormFwd = _struct("LayernormFwd", [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32),
+LayernormFwd = _struct("LayernormFwd", cname="miseg_layernorm_fwd_params", fields=[("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32),
                                         ("dtype", i32), ("eps", f32), ("gamma", vp), ("beta", vp), ("mean", vp), ("rstd", vp)])
-LayernormBwd = _struct("LayernormBwd", [("dy", vp), ("lddy", i64), ("x", vp), ("ldx", i64), ("dx", vp), ("lddx", i64),
+LayernormBwd = _struct("LayernormBwd", cname="miseg_layernorm_bwd_params", fields=[("dy", vp), ("lddy", i64), ("x", vp), ("ldx", i64), ("dx", vp), ("lddx", i64),
                                         ("rows", i64), ("C", i32), ("dtype", i32), ("gamma", vp), ("mean", vp), ("rstd", vp),
                                         ("dgamma", vp), ("dbeta", vp)])
-Gemm = _struct("Gemm", [("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32),
+Gemm = _struct("Gemm", cname="miseg_gemm_params", fields=[("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32),
                         ("K", i32), ("ta", i32), ("tb", i32), ("dtype", i32), ("out_dtype", i32), ("bias", vp), ("act", i32),
                         ("accumulate", i32), ("split_k", i32), ("workspace", vp), ("res", vp), ("ldres", i64), ("aux", vp), ("ldaux", i64),
                         ("epi_mode", i32), ("defer_reduce", i32), ("stat", vp), ("scat_d", i32), ("scat_h", i32), ("scat_w", i32),
                         ("scat_cout", i32)])
-TnReduceDesc = _struct("TnReduceDesc", [("partial", vp), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32), ("splits", i32), ("block0", i32)])
-ColsumDesc = _struct("ColsumDesc", [("x", vp), ("ldx", i64), ("rows", i64), ("out", vp), ("C", i32), ("block0", i32)])
-GemmTnDesc = _struct("GemmTnDesc", [("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32), ("K", i32), ("pad_", i32)])
-Colsum = _struct("Colsum", [("x", vp), ("ldx", i64), ("rows", i64), ("C", i32), ("dtype", i32), ("out", vp), ("accumulate", i32)])
-Conv3 = _struct("Conv3", [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("wpk", vp), ("B", i32), ("D", i32), ("H", i32),
+TnReduceDesc = _struct("TnReduceDesc", cname="miseg_tn_reduce_desc", fields=[("partial", vp), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32), ("splits", i32), ("block0", i32)])
+ColsumDesc = _struct("ColsumDesc", cname="miseg_colsum_desc", fields=[("x", vp), ("ldx", i64), ("rows", i64), ("out", vp), ("C", i32), ("block0", i32)])
+GemmTnDesc = _struct("GemmTnDesc", cname="miseg_gemm_tn_desc", fields=[("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32), ("K", i32), ("pad_", i32)])
+Colsum = _struct("Colsum", cname="miseg_colsum_params", fields=[("x", vp), ("ldx", i64), ("rows", i64), ("C", i32), ("dtype", i32), ("out", vp), ("accumulate", i32)])
+Conv3 = _struct("Conv3", cname="miseg_conv3_params", fields=[("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("wpk", vp), ("B", i32), ("D", i32), ("H", i32),
                           ("W", i32), ("Cin", i32), ("Cout", i32), ("dtype", i32), ("workspace", vp), ("res", vp), ("ldres", i64), ("stat", vp)])
-PackConv3Desc = _struct("PackConv3Desc", [("w", vp), ("fwd_pack", vp), ("bwd_pack", vp), ("Cin", i32), ("Cout", i32), ("tile0", i32), ("pad_", i32)])
-PackConv3 = _struct("PackConv3", [("w", vp), ("fwd_pack", vp), ("bwd_pack", vp), ("Cin", i32), ("Cout", i32), ("dtype", i32)])
-Conv3Wgrad = _struct("Conv3Wgrad", [("x", vp), ("ldx", i64), ("dy", vp), ("lddy", i64), ("dw", vp), ("B", i32), ("D", i32),
+PackConv3Desc = _struct("PackConv3Desc", cname="miseg_pack_conv3_desc", fields=[("w", vp), ("fwd_pack", vp), ("bwd_pack", vp), ("Cin", i32), ("Cout", i32), ("tile0", i32), ("pad_", i32)])
+PackConv3 = _struct("PackConv3", cname="miseg_pack_conv3_params", fields=[("w", vp), ("fwd_pack", vp), ("bwd_pack", vp), ("Cin", i32), ("Cout", i32), ("dtype", i32)])
+Conv3Wgrad = _struct("Conv3Wgrad", cname="miseg_conv3_wgrad_params", fields=[("x", vp), ("ldx", i64), ("dy", vp), ("lddy", i64), ("dw", vp), ("B", i32), ("D", i32),
                                     ("H", i32), ("W", i32), ("Cin", i32), ("Cout", i32), ("dtype", i32), ("accumulate", i32),
                                     ("workspace", vp)])
-Winattn = _struct("Winattn", [("qkv", vp), ("ldq", i64), ("out", vp), ("ldo", i64), ("qkv_bias", vp), ("bias_table", vp),
+Winattn = _struct("Winattn", cname="miseg_winattn_params", fields=[("qkv", vp), ("ldq", i64), ("out", vp), ("ldo", i64), ("qkv_bias", vp), ("bias_table", vp),
                               ("lse", vp), ("B", i32), ("D", i32), ("H", i32), ("W", i32), ("C", i32), ("heads", i32),
                               ("dtype", i32), ("wd", i32), ("wh", i32), ("ww", i32), ("sd", i32), ("sh", i32), ("sw", i32),
                               ("tw", i32), ("scale", f32)])
-WinattnBwd = _struct("WinattnBwd", [("f", Winattn), ("dout", vp), ("lddo", i64), ("dqkv", vp), ("lddq", i64),
+WinattnBwd = _struct("WinattnBwd", cname="miseg_winattn_bwd_params", fields=[("f", Winattn), ("dout", vp), ("lddo", i64), ("dqkv", vp), ("lddq", i64),
                                     ("dqkv_bias", vp), ("dbias_table", vp)])
-Add = _struct("Add", [("a", vp), ("lda", i64), ("b", vp), ("ldb", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
-Copy2d = _struct("Copy2d", [("src", vp), ("lds", i64), ("sdtype", i32), ("dst", vp), ("ldd", i64), ("ddtype", i32), ("rows", i64), ("C", i32)])
-CastDesc = _struct("CastDesc", [("src", vp), ("dst", vp), ("R", i32), ("C", i32), ("transpose", i32), ("inner", i32), ("outer", i32), ("tile0", i32)])
-Resample2 = _struct("Resample2", [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("B", i32), ("D", i32), ("H", i32), ("W", i32), ("C", i32),
+Add = _struct("Add", cname="miseg_add_params", fields=[("a", vp), ("lda", i64), ("b", vp), ("ldb", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
+Copy2d = _struct("Copy2d", cname="miseg_copy2d_params", fields=[("src", vp), ("lds", i64), ("sdtype", i32), ("dst", vp), ("ldd", i64), ("ddtype", i32), ("rows", i64), ("C", i32)])
+CastDesc = _struct("CastDesc", cname="miseg_cast_desc", fields=[("src", vp), ("dst", vp), ("R", i32), ("C", i32), ("transpose", i32), ("inner", i32), ("outer", i32), ("tile0", i32)])
+Resample2 = _struct("Resample2", cname="miseg_resample2_params", fields=[("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("B", i32), ("D", i32), ("H", i32), ("W", i32), ("C", i32),
                                   ("dtype", i32), ("dir", i32)])
-Rowbias = _struct("Rowbias", [("x", vp), ("ldx", i64), ("bias", vp), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
-PreluFwd = _struct("PreluFwd", [("x", vp), ("ldx", i64), ("slope", vp), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
-PreluBwd = _struct("PreluBwd", [("dy", vp), ("lddy", i64), ("x", vp), ("ldx", i64), ("slope", vp), ("dx", vp), ("lddx", i64), ("dslope", vp),
+Rowbias = _struct("Rowbias", cname="miseg_rowbias_params", fields=[("x", vp), ("ldx", i64), ("bias", vp), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
+PreluFwd = _struct("PreluFwd", cname="miseg_prelu_fwd_params", fields=[("x", vp), ("ldx", i64), ("slope", vp), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
+PreluBwd = _struct("PreluBwd", cname="miseg_prelu_bwd_params", fields=[("dy", vp), ("lddy", i64), ("x", vp), ("ldx", i64), ("slope", vp), ("dx", vp), ("lddx", i64), ("dslope", vp),
                                 ("rows", i64), ("C", i32), ("dtype", i32)])
-Cast = _struct("Cast", [("src", vp), ("dst", vp), ("R", i32), ("C", i32), ("dtype", i32), ("transpose", i32)])
-GeluFwd = _struct("GeluFwd", [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
-GeluBwd = _struct("GeluBwd", [("dy", vp), ("lddy", i64), ("x", vp), ("ldx", i64), ("dx", vp), ("lddx", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
-S2C = _struct("S2C", [("src", vp), ("lds", i64), ("dst", vp), ("ldd", i64), ("B", i32), ("D", i32), ("H", i32), ("W", i32),
+Cast = _struct("Cast", cname="miseg_cast_params", fields=[("src", vp), ("dst", vp), ("R", i32), ("C", i32), ("dtype", i32), ("transpose", i32)])
+GeluFwd = _struct("GeluFwd", cname="miseg_gelu_fwd_params", fields=[("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
+GeluBwd = _struct("GeluBwd", cname="miseg_gelu_bwd_params", fields=[("dy", vp), ("lddy", i64), ("x", vp), ("ldx", i64), ("dx", vp), ("lddx", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
+S2C = _struct("S2C", cname="miseg_s2c_params", fields=[("src", vp), ("lds", i64), ("dst", vp), ("ldd", i64), ("B", i32), ("D", i32), ("H", i32), ("W", i32),
                       ("C", i32), ("dtype", i32), ("offsets", C.c_int8 * 24)])
-PatchEmbed = _struct("PatchEmbed", [("x", vp), ("y", vp), ("ldy", i64), ("w", vp), ("bias", vp), ("B", i32), ("Cin", i32), ("D", i32),
+PatchEmbed = _struct("PatchEmbed", cname="miseg_patch_embed_params", fields=[("x", vp), ("y", vp), ("ldy", i64), ("w", vp), ("bias", vp), ("B", i32), ("Cin", i32), ("D", i32),
                                     ("H", i32), ("W", i32), ("Cout", i32), ("dtype", i32)])
-PatchEmbedBwd = _struct("PatchEmbedBwd", [("x", vp), ("dy", vp), ("lddy", i64), ("dw", vp), ("dbias", vp), ("B", i32), ("Cin", i32),
+PatchEmbedBwd = _struct("PatchEmbedBwd", cname="miseg_patch_embed_bwd_params", fields=[("x", vp), ("dy", vp), ("lddy", i64), ("dw", vp), ("dbias", vp), ("B", i32), ("Cin", i32),
                                           ("D", i32), ("H", i32), ("W", i32), ("Cout", i32), ("dtype", i32), ("workspace", vp)])
-Conv3Thin = _struct("Conv3Thin", [("x", vp), ("y", vp), ("ldy", i64), ("w", vp), ("B", i32), ("Cin", i32), ("D", i32), ("H", i32),
+Conv3Thin = _struct("Conv3Thin", cname="miseg_conv3_thin_params", fields=[("x", vp), ("y", vp), ("ldy", i64), ("w", vp), ("B", i32), ("Cin", i32), ("D", i32), ("H", i32),
                                   ("W", i32), ("Cout", i32), ("dtype", i32)])
-Conv3ThinWgrad = _struct("Conv3ThinWgrad", [("x", vp), ("dy", vp), ("lddy", i64), ("dw", vp), ("B", i32), ("Cin", i32), ("D", i32),
+Conv3ThinWgrad = _struct("Conv3ThinWgrad", cname="miseg_conv3_thin_wgrad_params", fields=[("x", vp), ("dy", vp), ("lddy", i64), ("dw", vp), ("B", i32), ("Cin", i32), ("D", i32),
                                             ("H", i32), ("W", i32), ("Cout", i32), ("dtype", i32), ("workspace", vp)])
-Head = _struct("Head", [("x", vp), ("ldx", i64), ("y", vp), ("w", vp), ("bias", vp), ("B", i32), ("S", i32), ("Cin", i32),
+Head = _struct("Head", cname="miseg_head_params", fields=[("x", vp), ("ldx", i64), ("y", vp), ("w", vp), ("bias", vp), ("B", i32), ("S", i32), ("Cin", i32),
                         ("Cout", i32), ("dtype", i32)])
-HeadBwd = _struct("HeadBwd", [("x", vp), ("ldx", i64), ("dy", vp), ("dx", vp), ("lddx", i64), ("w", vp), ("dw", vp), ("dbias", vp),
+HeadBwd = _struct("HeadBwd", cname="miseg_head_bwd_params", fields=[("x", vp), ("ldx", i64), ("dy", vp), ("dx", vp), ("lddx", i64), ("w", vp), ("dw", vp), ("dbias", vp),
                               ("B", i32), ("S", i32), ("Cin", i32), ("Cout", i32), ("dtype", i32)])
-Im2col3 = _struct("Im2col3", [("src", vp), ("lds", i64), ("dst", vp), ("ldd", i64), ("B", i32), ("D", i32), ("H", i32), ("W", i32),
+Im2col3 = _struct("Im2col3", cname="miseg_im2col3_params", fields=[("src", vp), ("lds", i64), ("dst", vp), ("ldd", i64), ("B", i32), ("D", i32), ("H", i32), ("W", i32),
                               ("C", i32), ("dtype", i32)])
+
+u32, u64p = C.c_uint32, C.POINTER(C.c_uint64)
+SegLoss = _struct("SegLoss", cname="miseg_seg_loss_params", fields=[
+    ("struct_size", u32), ("kind", i32), ("logits", vp), ("label", vp), ("label_dtype", i32), ("B", i32), ("C", i32), ("S", i64),
+    ("include_background", i32), ("squared_pred", i32), ("smooth_nr", f32), ("smooth_dr", f32), ("gamma", f32), ("lambda_dice", f32),
+    ("lambda_other", f32), ("workspace", vp), ("sums", vp), ("loss", vp), ("gscale", vp), ("dlogits", vp)])
+DiceMetric = _struct("DiceMetric", cname="miseg_dice_metric_params", fields=[
+    ("struct_size", u32), ("logits", vp), ("label", vp), ("label_dtype", i32), ("B", i32), ("C", i32), ("S", i64), ("counts", vp), ("dice", vp)])
+OptDesc = _struct("OptDesc", cname="miseg_opt_desc", fields=[("param", vp), ("off", i64), ("n", i32), ("block0", i32)])
+OptStep = _struct("OptStep", cname="miseg_opt_step_params", fields=[
+    ("struct_size", u32), ("kind", i32), ("descs_dev", vp), ("ndesc", i32), ("total_blocks", i32), ("grad", vp), ("state1", vp), ("state2", vp),
+    ("used", vp), ("steps", vp), ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("momentum", f32), ("lr_dev", vp)])
+Stitch = _struct("Stitch", cname="miseg_stitch_params", fields=[
+    ("struct_size", u32), ("win", vp), ("out", vp), ("count", vp), ("C", i32), ("D", i32), ("H", i32), ("W", i32), ("rd", i32), ("rh", i32), ("rw", i32),
+    ("nd", i32), ("nh", i32), ("nw", i32), ("start_d", vp), ("start_h", vp), ("start_w", vp)])
+LABEL_F32, LABEL_I32, LABEL_I64, LABEL_U8 = 0, 1, 2, 3
+LOSS_DICE_FOCAL, LOSS_DICE_CE = 0, 1
+OPT_ADAMW, OPT_ADAM, OPT_SGD_NESTEROV = 0, 1, 2
+OPT_BLOCK = 4096
+STITCH_MAX_WINDOWS = 32
 
 # symbol -> (restype, argtypes); every prototype of include/miseg_hip.h appears here (checked by tests/test_abi.py)
 PROTOS = {
@@ -157,6 +183,14 @@ PROTOS = {
     "miseg_prelu_bwd": (i32, [C.POINTER(PreluBwd), vp]),
     "miseg_layout_ncdhw": (i32, [vp, i64, vp, i32, i32, i64, i32, i32, vp]),
     "miseg_ncdhw_to_rows": (i32, [vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, vp]),
+    "miseg_seg_loss_workspace_bytes": (C.c_size_t, [i32, i32, i64]),
+    "miseg_seg_loss_fwd": (i32, [C.POINTER(SegLoss), vp]),
+    "miseg_seg_loss_bwd": (i32, [C.POINTER(SegLoss), vp]),
+    "miseg_dice_metric": (i32, [C.POINTER(DiceMetric), vp]),
+    "miseg_opt_step": (i32, [C.POINTER(OptStep), vp]),
+    "miseg_stitch_windows": (i32, [C.POINTER(Stitch), vp]),
+    "miseg_abi_struct_size": (C.c_size_t, [C.c_char_p]),
+    "miseg_device_check": (i32, [i32]),
 }
 
 _lib = None
@@ -178,8 +212,19 @@ def load():
     for name, (res, args) in PROTOS.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.restype, fn.argtypes = res, args
+    # header / library / binding drift is an error at load time, not a kernel reading past a struct later
+    if lib.miseg_abi_version() != ABI_VERSION:
+        raise MisegHipError(f"{LIB_PATH} reports ABI version {lib.miseg_abi_version()}, this binding mirrors version {ABI_VERSION}: rebuild (build())")
+    for t, cname in C_NAMES.items():
+        if cname is not None and lib.miseg_abi_struct_size(cname.encode()) != C.sizeof(t):
+            raise MisegHipError(f"sizeof({cname}) is {lib.miseg_abi_struct_size(cname.encode())} in the library, {C.sizeof(t)} in hip/lib.py")
     _lib = lib
     return lib
+
+
+def check_device(index=0):
+    """raise unless HIP device `index` is the architecture the library's code objects were built for"""
+    check(load().miseg_device_check(index), "device_check")
 
 
 def check(rc, what=""):

@@ -77,20 +77,33 @@ def _call(fn_name, params, prof=None):
 
 # ------------------------------------------------------------------------------------------ instance norm
 class _ZeroPool:
-    """fp64 statistics buffers of a step come from one pre-zeroed pool (one fill instead of ~100 small memsets)."""
+    """fp64 statistics buffers of a step come from one pre-zeroed pool (one fill instead of ~100 small memsets).
 
-    def __init__(self, numel=1 << 22):
-        self.numel, self.buf, self.off = numel, None, 0
+    Lifetime rules.  Every statistics tensor handed out is a VIEW of a chunk, so a chunk lives as long as anything (an autograd node's
+    saved tensors) still uses it; the pool itself only decides where the NEXT buffers come from:
+      * `begin_step()` (a training arena / GraphedStep owns the step and has enqueued the previous backward pass): the current chunk is
+        zero-filled in place and reused - captured hipGraphs rely on these fixed addresses, so a chunk that a graph was captured on is
+        never dropped (`pin()`; GraphedStep pins what it captured);
+      * `fresh()` (a model forward that nobody manages - LitMonai's eager loop, sliding-window validation, unit tests): the pool lets go
+        of its chunk and starts a new one sized by the high-water mark, so earlier forwards whose backward is still pending keep their
+        statistics, and 700 inference windows do not grow anything;
+      * overflow inside a step: a new chunk is started; the old one stays alive through its views and through `_pinned`."""
+
+    def __init__(self, numel=1 << 20):
+        self.numel, self.buf, self.off, self.high = numel, None, 0, 0
+        self._pinned = []
 
     def take(self, n, device):
         n = (n + 1) & ~1
         if self.buf is None or self.buf.device != device or self.off + n > self.buf.numel():
-            self.buf = torch.empty(max(self.numel, n), dtype=torch.float64, device=device)
+            self.high = max(self.high, self.off + n)
+            self.buf = torch.empty(max(self.numel, n, int(self.high * 1.5)), dtype=torch.float64, device=device)
             lib = L.load()
             L.check(lib.miseg_fill32(_ptr(self.buf), 0, self.buf.numel() * 2, _stream()), "fill32")
             self.off = 0
         t = self.buf[self.off:self.off + n]
         self.off += n
+        self.high = max(self.high, self.off)
         return t
 
     def begin_step(self):
@@ -100,12 +113,42 @@ class _ZeroPool:
             L.check(lib.miseg_fill32(_ptr(self.buf), 0, self.off * 2, _stream()), "fill32")
             self.off = 0
 
+    def fresh(self):
+        """start the next forward on a new chunk (unless the current one is untouched); see the class docstring"""
+        if self.buf is not None and self.off > 0 and not torch.cuda.is_current_stream_capturing():
+            self.buf, self.off = None, 0
+
+    def pin(self):
+        """keep the current chunk alive for good: a captured hipGraph holds raw pointers into it"""
+        if self.buf is not None and not any(b is self.buf for b in self._pinned):
+            self._pinned.append(self.buf)
+
 
 STAT_POOL = _ZeroPool()
 
 
 def begin_step():
-    STAT_POOL.begin_step()
+    """start of a training step whose previous backward pass has been enqueued.  Under hipGraph capture the current chunk is recycled in
+    place (fixed addresses are what a graph replays); eagerly the step simply moves to a fresh chunk, so statistics that some other
+    pending autograd graph still holds are never zero-filled under it."""
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        STAT_POOL.begin_step()
+    else:
+        STAT_POOL.fresh()
+
+
+def begin_forward(params=()):
+    """called by the nets at the top of `forward`: when no training arena manages the step (its begin_step() recycles the pool), the
+    statistics of this forward go to a fresh chunk, so an un-managed loop neither grows the pool nor clobbers statistics that an earlier,
+    not yet back-propagated forward still needs."""
+    if torch.cuda.is_current_stream_capturing():
+        return
+    if torch.is_grad_enabled():
+        for p in params:
+            if getattr(p, "_miseg_arena", None) is not None:
+                return
+            break
+    STAT_POOL.fresh()
 
 
 def instnorm_stats(x, B, S):
@@ -789,3 +832,92 @@ def fill32(t, word=0):
 
 def zeros_f32(shape, device):
     return fill32(torch.empty(shape, dtype=torch.float32, device=device))
+
+
+# ------------------------------------------------------------------------------------------ after the path: loss, metric, optimiser, stitching
+def _label(label):
+    """class-id labels [B, 1, ...] (any of float32 / int32 / int64 / uint8, as the data pipeline delivers them) -> (tensor, MISEG_LABEL_*)"""
+    kinds = {torch.float32: L.LABEL_F32, torch.int32: L.LABEL_I32, torch.int64: L.LABEL_I64, torch.uint8: L.LABEL_U8}
+    if label.dtype not in kinds:
+        label = label.to(torch.int32)
+    return label.contiguous(), kinds[label.dtype]
+
+
+class SegLossCfg:
+    """DiceFocalLoss / DiceCELoss hyper-parameters as LitMonai builds them (reference lightning_monai.py:48-65)"""
+
+    def __init__(self, kind, include_background, squared_pred, smooth_nr, smooth_dr, gamma=2.0, lambda_dice=1.0, lambda_other=1.0):
+        self.kind, self.include_background, self.squared_pred = kind, bool(include_background), bool(squared_pred)
+        self.smooth_nr, self.smooth_dr, self.gamma, self.lambda_dice, self.lambda_other = float(smooth_nr), float(smooth_dr), float(gamma), float(lambda_dice), float(lambda_other)
+
+
+def _seg_loss_params(logits, label, cfg, sums, ws):
+    if not logits.is_cuda:
+        raise L.MisegHipError("miseg ops need CUDA/HIP tensors: the MI355X path has no CPU fallback")
+    if logits.dtype != torch.float32 or not logits.is_contiguous() or logits.dim() < 3:
+        raise ValueError("seg_loss: logits must be contiguous float32 [B, C, ...]")
+    B, Cc = logits.shape[0], logits.shape[1]
+    S = logits.numel() // (B * Cc)
+    if label.numel() != B * S:
+        raise ValueError(f"seg_loss: label {tuple(label.shape)} does not match logits {tuple(logits.shape)} ([B, 1, ...] class ids)")
+    lab, ldt = _label(label)
+    p = L.SegLoss(C.sizeof(L.SegLoss), cfg.kind, _ptr(logits), _ptr(lab), ldt, B, Cc, S, int(cfg.include_background), int(cfg.squared_pred), cfg.smooth_nr,
+                  cfg.smooth_dr, cfg.gamma, cfg.lambda_dice, cfg.lambda_other, _ptr(ws), _ptr(sums), None, None, None)
+    return p, lab, (B, Cc, S)
+
+
+def seg_loss_fwd(logits, label, cfg):
+    """-> (loss: 0-dim fp32 device tensor, sums: fp64 [3 B C + 1] saved for the backward pass)"""
+    B, Cc = logits.shape[0], logits.shape[1]
+    S = logits.numel() // (B * Cc)
+    lib = L.load()
+    ws = torch.empty(lib.miseg_seg_loss_workspace_bytes(B, Cc, S) // 8, dtype=torch.float64, device=logits.device)
+    sums = torch.empty(3 * B * Cc + 1, dtype=torch.float64, device=logits.device)
+    loss = torch.empty((), dtype=torch.float32, device=logits.device)
+    p, lab, _ = _seg_loss_params(logits, label, cfg, sums, ws)
+    p.loss = _ptr(loss)
+    _call("miseg_seg_loss_fwd", p)
+    return loss, sums
+
+
+def seg_loss_bwd(logits, label, cfg, sums, gscale=None):
+    """d(loss)/d(logits) * gscale (a 0-dim fp32 device tensor or None)"""
+    dlogits = torch.empty_like(logits)
+    ws = torch.empty(1, dtype=torch.float64, device=logits.device)      # not used by the backward pass
+    p, lab, _ = _seg_loss_params(logits, label, cfg, sums, ws)
+    if gscale is not None:
+        gscale = gscale.to(torch.float32).contiguous()
+        p.gscale = _ptr(gscale)
+    p.dlogits = _ptr(dlogits)
+    _call("miseg_seg_loss_bwd", p)
+    return dlogits
+
+
+def dice_metric(logits, label):
+    """[B, C] Dice per class after argmax (NaN where the class is absent from the label)"""
+    if logits.dtype != torch.float32 or not logits.is_contiguous():
+        raise ValueError("dice_metric: logits must be contiguous float32 [B, C, ...]")
+    B, Cc = logits.shape[0], logits.shape[1]
+    S = logits.numel() // (B * Cc)
+    if label.numel() != B * S:
+        raise ValueError("dice_metric: label does not match logits")
+    lab, ldt = _label(label)
+    counts = torch.empty(B * Cc * 3, dtype=torch.int64, device=logits.device)
+    dice = torch.empty(B, Cc, dtype=torch.float32, device=logits.device)
+    _call("miseg_dice_metric", L.DiceMetric(C.sizeof(L.DiceMetric), _ptr(logits), _ptr(lab), ldt, B, Cc, S, _ptr(counts), _ptr(dice)))
+    return dice
+
+
+def stitch_windows(win, out, starts, roi, count=None):
+    """win fp32 [nd*nh*nw, C, rd, rh, rw] (all windows resident), out fp32 [C, D, H, W]; starts = (list_d, list_h, list_w)"""
+    nd, nh, nw = (len(s) for s in starts)
+    Cc, D, H, W = out.shape
+    assert win.dtype == torch.float32 and out.dtype == torch.float32 and win.is_contiguous() and out.is_contiguous()
+    if tuple(win.shape) != (nd * nh * nw, Cc) + tuple(roi):
+        raise ValueError(f"stitch_windows: window buffer {tuple(win.shape)} does not match {nd}x{nh}x{nw} windows of {tuple(roi)} x {Cc} channels")
+    arr = [(C.c_int32 * len(s))(*s) for s in starts]
+    if count is not None:
+        assert count.dtype == torch.int16 and count.is_contiguous() and tuple(count.shape) == (D, H, W)
+    _call("miseg_stitch_windows", L.Stitch(C.sizeof(L.Stitch), _ptr(win), _ptr(out), _ptr(count), Cc, D, H, W, roi[0], roi[1], roi[2], nd, nh, nw,
+                                           C.cast(arr[0], C.c_void_p), C.cast(arr[1], C.c_void_p), C.cast(arr[2], C.c_void_p)))
+    return out

@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from ..training.inferer import sliding_window_inference
 from ..training.losses import DiceCELoss, DiceFocalLoss
-from ..training.metrics import as_discrete_argmax_onehot, as_discrete_onehot, dice_metric
+from ..training.metrics import dice_from_logits
 from ..training.schedulers import WarmupCosineSchedule
 from .utils.utils import model_from_argparse_args
 
@@ -106,7 +106,7 @@ class LitMonai(_Base):
         if self.infer_cpu:
             label = label.cpu()
         loss = self.criterion(logits, label.to(logits.device))
-        accuracy = dice_metric(as_discrete_argmax_onehot(logits, self.out_channels), as_discrete_onehot(label.to(logits.device), self.out_channels))
+        accuracy = dice_from_logits(logits, label.to(logits.device), self.out_channels)
         avg = torch.nanmean(accuracy)
         per_class = torch.nanmean(accuracy, dim=0)
         self.log_dict({f"{prefix}/accuracy/class_{i}": a for i, a in enumerate(per_class)}, on_epoch=True, logger=True, sync_dist=True, batch_size=1)
@@ -121,6 +121,14 @@ class LitMonai(_Base):
         mod = np.array([int(torch.as_tensor(o["modality"]).reshape(-1)[0]) for o in outputs])
         self.log_dict({f"{prefix}/accuracy/modality_{int(m)}": float(np.nanmean(acc[mod == m])) for m in np.unique(mod)}, logger=True, sync_dist=True)
         self.log_dict({f"{prefix}/loss/modality_{int(m)}": float(np.nanmean(los[mod == m])) for m in np.unique(mod)}, logger=True, sync_dist=True)
+
+    def configure_fused_optimizer(self, arena):
+        """the optimiser of configure_optimizers() as ONE kernel launch per step over the model's gradient arena
+        (training/optim.py::ArenaOptimizer, SURVEY 8(f) row f3); same hyper-parameters, same "no gradient => untouched" rule"""
+        from ..training.optim import ArenaOptimizer
+        if self.optim_name not in ("adam", "adamw", "sgd"):
+            raise ValueError("Optimization {} not implemented, please chose another optimizer.".format(self.optim_name))
+        return ArenaOptimizer(arena, kind=self.optim_name, lr=self.learning_rate, weight_decay=self.reg_weight, momentum=self.momentum)
 
     def configure_optimizers(self):
         if self.optim_name == "adam":

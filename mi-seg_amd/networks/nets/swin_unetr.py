@@ -7,10 +7,11 @@ import torch
 import torch.nn as nn
 
 from ...hip import functional as HF
+from ...hip import ops
 from ..blocks.dynunet_block import UnetOutBlock
 from ..blocks.patch_merging import PatchMerging, PatchMergingV2
 from ..blocks.unetr_block import UnetrBasicBlock, UnetrUpBlock
-from ..norms.conditional_instance_norm import styles_to_device
+from ..norms.conditional_instance_norm import styles_limit, styles_to_device
 from ..norms.utils import parse_normalization
 from .swin_transformer import SwinTransformer, look_up_option
 
@@ -159,7 +160,8 @@ class SwinUNETR(nn.Module):
         needs = "instance_cond" in (self.vit_norm_name, self.encoder_norm_name, self.decoder_norm_name)
         if needs and modalities is None:
             raise ValueError("Modalities must be passed to the forward step when encoder_norm_type is 'instance_cond'.")
-        styles = styles_to_device(modalities, x_in.device, x_in.shape[0]) if modalities is not None else None
+        styles = styles_to_device(modalities, x_in.device, x_in.shape[0], styles_limit(self)) if modalities is not None else None
+        ops.begin_forward(self.parameters())      # statistics-pool lifetime: hip/ops.py::_ZeroPool
         x_in = x_in.float().contiguous()
         dt = self.compute_dtype
         # encoder1 (three 96^3 convolutions) depends on the image only: on a side stream it runs next to the Swin transformer, whose

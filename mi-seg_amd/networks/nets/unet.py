@@ -18,8 +18,9 @@ import torch
 import torch.nn as nn
 
 from ...hip import functional as HF
+from ...hip import ops
 from ..layers.utils import apply_norm, get_norm_layer
-from ..norms.conditional_instance_norm import _ConditionalInstanceNorm, styles_to_device
+from ..norms.conditional_instance_norm import _ConditionalInstanceNorm, styles_limit, styles_to_device
 from ..norms.utils import parse_normalization
 
 __all__ = ["UNet", "Unet"]
@@ -176,7 +177,8 @@ class UNet(nn.Module):
         cond = any(isinstance(m, _ConditionalInstanceNorm) for m in self.modules())
         if cond and modalities is None:
             raise ValueError("Modalities must be passed to the forward step when a norm type is 'instance_cond'.")
-        styles = styles_to_device(modalities, x.device, x.shape[0]) if modalities is not None else None
+        styles = styles_to_device(modalities, x.device, x.shape[0], styles_limit(self)) if modalities is not None else None
+        ops.begin_forward(self.parameters())      # statistics-pool lifetime: hip/ops.py::_ZeroPool
         x = x.float().contiguous()
         if self.in_channels > 4:
             raise NotImplementedError("more than 4 image channels")

@@ -4,9 +4,10 @@ from typing import Sequence, Tuple, Union
 import torch
 import torch.nn as nn
 
+from ...hip import ops
 from ..blocks.dynunet_block import UnetOutBlock
 from ..blocks.unetr_block import UnetrBasicBlock, UnetrPrUpBlock, UnetrUpBlock
-from ..norms.conditional_instance_norm import styles_to_device
+from ..norms.conditional_instance_norm import styles_limit, styles_to_device
 from ..norms.utils import parse_normalization
 from .swin_unetr import ensure_tuple_rep
 from .vit import ViT
@@ -87,7 +88,8 @@ class UNETR(nn.Module):
             raise RuntimeError("UNETR (MI355X path) needs a HIP device tensor; there is no CPU fallback")
         if "instance_cond" in (self.vit_norm_name, self.encoder_norm_name, self.decoder_norm_name) and modalities is None:
             raise ValueError("Modalities must be passed to the forward step when encoder_norm_type is 'instance_cond'.")
-        styles = styles_to_device(modalities, x_in.device, x_in.shape[0]) if modalities is not None else None
+        styles = styles_to_device(modalities, x_in.device, x_in.shape[0], styles_limit(self)) if modalities is not None else None
+        ops.begin_forward(self.parameters())      # statistics-pool lifetime: hip/ops.py::_ZeroPool
         x_in = x_in.float().contiguous()
         dt = self.compute_dtype
         x, hidden = self.vit(x_in, styles, dt)

@@ -13,6 +13,62 @@ import torch
 from ..hip import ops
 
 
+def _check_styles(model, modalities, batch):
+    """host tuple of style ids, range-checked BEFORE it reaches the static device tensor a captured graph reads (the kernels index
+    by-value argument arrays with it: an id outside [0, num_styles) would be a wild pointer)"""
+    from ..networks.norms.conditional_instance_norm import _check_range, styles_limit
+    host = tuple(int(m) for m in modalities)
+    if len(host) != batch:
+        raise ValueError("Expected number of styles as batch size.")
+    return _check_range(host, styles_limit(model))
+
+
+class GraphedForward:
+    """hipGraph of the inference forward pass (no autograd tape) for a fixed batch shape: sliding-window validation runs 700 windows per
+    volume through the same ~270 launches, so the host launch path is the cost to remove.  One graph per set of modalities present;
+    use as the `predictor` of training/inferer.py::sliding_window_inference (returns a static logits buffer: consume it before the
+    next call)."""
+
+    def __init__(self, model: torch.nn.Module, batch_shape: Sequence[int], warmup: int = 1):
+        self.model = model
+        dev = next(model.parameters()).device
+        self.x = torch.zeros(*batch_shape, dtype=torch.float32, device=dev)
+        self.styles = torch.zeros(batch_shape[0], dtype=torch.int32, device=dev)
+        self.warmup = warmup
+        self.graphs = {}
+
+    def _run(self, host):
+        with torch.no_grad():
+            ops.begin_step()
+            return self.model(self.x, (self.styles, host))
+
+    def __call__(self, x, modalities=None):
+        if tuple(x.shape) != tuple(self.x.shape):
+            with torch.no_grad():                       # a tail batch of another size: plain launches
+                return self.model(x, modalities)
+        host = _check_styles(self.model, modalities, self.x.shape[0]) if modalities is not None else None
+        self.x.copy_(x, non_blocking=True)
+        if host is not None:
+            self.styles.copy_(torch.tensor(host, dtype=torch.int32), non_blocking=True)
+        key = None if host is None else tuple(sorted(set(host)))
+        if key not in self.graphs:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(self.warmup):
+                    self._run(host)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                y = self._run(host)
+            ops.STAT_POOL.pin()
+            self.graphs[key] = (g, y)
+        g, y = self.graphs[key]
+        g.replay()
+        return y
+
+
 class GraphedStep:
     def __init__(self, model: torch.nn.Module, batch_shape: Sequence[int], out_shape: Sequence[int], warmup: int = 2, arena=None, split=False):
         """arena: optional runtime.arena.ParamArena of the model (gradients accumulate in its flat buffer, parameter
@@ -85,6 +141,7 @@ class GraphedStep:
         else:
             with torch.cuda.graph(g):
                 y = self._run(host)
+        ops.STAT_POOL.pin()        # the graph holds raw pointers into the statistics chunk it was captured on
         if self.arena is not None:
             grads = [bool(p._miseg_used) for p in self.arena.params]       # which slots this graph writes
         else:
@@ -95,7 +152,7 @@ class GraphedStep:
         """x [B,C,D,H,W] fp32, cotangent d(loss)/d(logits); returns logits (static buffer) with p.grad populated.
         between: called between the two replays of a split step; publish=False leaves `p.grad` to the caller
         (arena.allreduce_end does it after the exchange)."""
-        host = tuple(int(m) for m in modalities)
+        host = _check_styles(self.model, modalities, self.x.shape[0])
         self.x.copy_(x, non_blocking=True)
         self.cot.copy_(cot, non_blocking=True)
         self.styles.copy_(torch.tensor(host, dtype=torch.int32), non_blocking=True)

@@ -2,9 +2,24 @@
 utils/training_utils.py:6-33).  Restated from MONAI's public API (MONAI is a pinned third-party dependency of the reference,
 monai~=1.1.0, not present here): PARITY UNPINNED by any reference test -- SURVEY.md Appendix B.
 
-These run after the hot path (on the fp32 logits); they are plain torch ops today (SURVEY 8(f) ranks fused loss kernels next)."""
+On a HIP device ``DiceFocalLoss`` / ``DiceCELoss`` with ``to_onehot_y=True, softmax=True`` (the only way LitMonai builds them) are ONE
+fused pass for the loss and one for d(loss)/d(logits) (csrc/training.hip) instead of ~6 torch passes over the
+[B, C, 96^3] logits plus their autograd tape.  The torch arithmetic below is what runs for CPU tensors (the reference's ``--infer_cpu``
+validation computes its loss on CPU logits, lightning_monai.py:187-189) and is the plain-PyTorch reference the GPU tests compare the
+kernels with.
+
+Channel handling, MONAI 1.1.0:
+  * DiceFocalLoss one-hots the target, then -- when ``include_background`` is False -- strips channel 0 from BOTH logits and target
+    before calling its sub-losses, which it builds WITHOUT include_background / to_onehot_y: the Dice softmax therefore runs over the
+    C-1 foreground logits only, and the focal term sees the same C-1 channels.
+  * DiceCELoss delegates include_background / to_onehot_y to its DiceLoss (softmax over all C channels, channel 0 dropped afterwards)
+    and applies nn.CrossEntropyLoss over all channels."""
 import torch
 import torch.nn.functional as F
+from torch.autograd import Function
+
+from ..hip import lib as L
+from ..hip import ops
 
 
 def _one_hot(label, num_classes):
@@ -55,16 +70,51 @@ class FocalLoss(torch.nn.Module):
         return loss.mean(-1).mean()
 
 
+class _FusedSegLoss(Function):
+    """loss = fused kernel pass 1 (+ fixed-order finalize); d(loss)/d(logits) = pass 2 from the saved per-(b, c) sums."""
+
+    @staticmethod
+    def forward(ctx, logits, label, cfg):
+        logits = logits.contiguous()
+        loss, sums = ops.seg_loss_fwd(logits, label, cfg)
+        ctx.save_for_backward(logits, label, sums)
+        ctx.cfg = cfg
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, label, sums = ctx.saved_tensors
+        return ops.seg_loss_bwd(logits, label, ctx.cfg, sums, g), None, None
+
+
+def _fusable(logits, target, to_onehot_y, softmax):
+    return (logits.is_cuda and logits.dtype == torch.float32 and to_onehot_y and softmax and target.shape[1] == 1 and 2 <= logits.shape[1] <= 16
+            and logits.shape[0] <= 64)
+
+
 class DiceFocalLoss(torch.nn.Module):
     def __init__(self, include_background=True, to_onehot_y=False, softmax=False, squared_pred=False, smooth_nr=1e-5, smooth_dr=1e-5, gamma=2.0,
                  lambda_dice=1.0, lambda_focal=1.0):
         super().__init__()
-        self.dice = DiceLoss(include_background, to_onehot_y, softmax, squared_pred, smooth_nr, smooth_dr)
-        self.focal = FocalLoss(include_background, to_onehot_y, gamma)
+        # MONAI 1.1.0 builds the sub-losses without include_background / to_onehot_y; forward() strips channel 0 itself
+        self.dice = DiceLoss(True, False, softmax, squared_pred, smooth_nr, smooth_dr)
+        self.focal = FocalLoss(True, False, gamma)
+        self.include_background, self.to_onehot_y, self.softmax = include_background, to_onehot_y, softmax
         self.lambda_dice, self.lambda_focal = lambda_dice, lambda_focal
+        self.cfg = ops.SegLossCfg(L.LOSS_DICE_FOCAL, include_background, squared_pred, smooth_nr, smooth_dr, gamma, lambda_dice, lambda_focal)
 
     def forward(self, logits, target):
-        return self.lambda_dice * self.dice(logits, target) + self.lambda_focal * self.focal(logits, target)
+        if _fusable(logits, target, self.to_onehot_y, self.softmax):
+            return _FusedSegLoss.apply(logits, target, self.cfg)
+        return self.forward_torch(logits, target)
+
+    def forward_torch(self, logits, target):
+        n_ch = logits.shape[1]
+        t = _one_hot(target, n_ch) if (self.to_onehot_y and n_ch > 1) else target
+        x = logits
+        if not self.include_background and n_ch > 1:
+            x, t = x[:, 1:], t[:, 1:]
+        return self.lambda_dice * self.dice(x, t) + self.lambda_focal * self.focal(x, t)
 
 
 class DiceCELoss(torch.nn.Module):
@@ -72,8 +122,15 @@ class DiceCELoss(torch.nn.Module):
                  lambda_dice=1.0, lambda_ce=1.0):
         super().__init__()
         self.dice = DiceLoss(include_background, to_onehot_y, softmax, squared_pred, smooth_nr, smooth_dr)
+        self.to_onehot_y, self.softmax = to_onehot_y, softmax
         self.lambda_dice, self.lambda_ce = lambda_dice, lambda_ce
+        self.cfg = ops.SegLossCfg(L.LOSS_DICE_CE, include_background, squared_pred, smooth_nr, smooth_dr, 0.0, lambda_dice, lambda_ce)
 
     def forward(self, logits, target):
+        if _fusable(logits, target, self.to_onehot_y, self.softmax):
+            return _FusedSegLoss.apply(logits, target, self.cfg)
+        return self.forward_torch(logits, target)
+
+    def forward_torch(self, logits, target):
         ce = F.cross_entropy(logits.float(), target[:, 0].long())
         return self.lambda_dice * self.dice(logits, target) + self.lambda_ce * ce

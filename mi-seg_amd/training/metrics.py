@@ -22,3 +22,13 @@ def dice_metric(y_pred_onehot, y_onehot):
     out = 2.0 * inter / den.clamp(min=1e-30)
     out = torch.where(den > 0, out, torch.ones_like(out))
     return torch.where(y_o > 0, out, torch.full_like(out, float("nan")))
+
+
+def dice_from_logits(logits, label, num_classes):
+    """AsDiscrete(argmax, to_onehot) on the logits + AsDiscrete(to_onehot) on the label + DiceMetric, as LitMonai._shared_eval chains them
+    (reference lightning_monai.py:190-195).  On a HIP device: one pass over logits + labels with integer counters (csrc/training.hip,
+    bit-reproducible); on CPU tensors (--infer_cpu) the torch arithmetic above."""
+    if logits.is_cuda and logits.dtype == torch.float32 and logits.shape[1] == num_classes and num_classes <= 64:
+        from ..hip import ops
+        return ops.dice_metric(logits.contiguous(), label.to(logits.device))
+    return dice_metric(as_discrete_argmax_onehot(logits, num_classes), as_discrete_onehot(label, num_classes))

@@ -1,0 +1,73 @@
+"""Optimiser step of the whole model as ONE kernel launch over the gradient arena.
+
+The reference builds torch.optim.AdamW / Adam / SGD(nesterov) over `self.parameters()` (networks/lightning_monai.py:255-278); torch
+skips a parameter whose `grad is None` completely -- no update, no weight decay, no step count -- which is what happens every step to the
+conditional-norm rows of the modality that is absent from the batch.  `ArenaOptimizer` keeps that rule: the "used" flags of
+runtime/arena.py::ParamArena (set by the weight-gradient kernels' autograd nodes, max-reduced over ranks under DDP) travel to the
+device and the kernel leaves unused tensors alone, with a per-parameter step count for Adam's bias correction.  The moments live in two
+flat fp32 buffers laid out like the arena."""
+import ctypes as C
+
+import torch
+
+from ..hip import lib as L
+from ..hip import ops
+
+KINDS = {"adamw": L.OPT_ADAMW, "adam": L.OPT_ADAM, "sgd": L.OPT_SGD_NESTEROV}
+
+
+class ArenaOptimizer:
+    def __init__(self, arena, kind="adamw", lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, momentum=0.99):
+        if kind not in KINDS:
+            raise ValueError("Optimization {} not implemented, please chose another optimizer.".format(kind))
+        self.arena, self.kind = arena, kind
+        self.lr, self.betas, self.eps, self.weight_decay, self.momentum = float(lr), betas, float(eps), float(weight_decay), float(momentum)
+        dev = arena.flat.device
+        self.state1 = torch.zeros_like(arena.flat)
+        self.state2 = torch.zeros_like(arena.flat) if kind != "sgd" else None
+        n = len(arena.params)
+        self.steps = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.used = torch.ones(n, dtype=torch.int32, device=dev)
+        self._used_host = torch.ones(n, dtype=torch.int32).pin_memory() if dev.type == "cuda" else torch.ones(n, dtype=torch.int32)
+        descs = (L.OptDesc * n)()
+        block0 = 0
+        for i, (p, off) in enumerate(zip(arena.params, arena._offs)):
+            if not p.is_contiguous():
+                raise ValueError("parameters must be contiguous float32")
+            descs[i] = L.OptDesc(p.data_ptr(), off, p.numel(), block0)
+            block0 += (p.numel() + L.OPT_BLOCK - 1) // L.OPT_BLOCK
+        self._ptrs = [p.data_ptr() for p in arena.params]
+        self._table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
+        self._blocks = block0
+        self.lr_dev = None
+
+    def set_used_from_arena(self):
+        """copy the host "used" flags of this step (arena.publish / allreduce have settled them) to the device; under hipGraph replay call
+        this BEFORE the replay that contains the step"""
+        flags = self._used_host
+        for i, p in enumerate(self.arena.params):
+            flags[i] = 1 if p._miseg_used else 0
+        self.used.copy_(flags, non_blocking=True)
+
+    def step(self, lr=None, update_flags=True):
+        if [p.data_ptr() for p in self.arena.params] != self._ptrs:
+            raise RuntimeError("a parameter was re-allocated after the optimiser was built (e.g. model.to(...)): rebuild the ArenaOptimizer")
+        if update_flags:
+            self.set_used_from_arena()
+        p = L.OptStep(C.sizeof(L.OptStep), KINDS[self.kind], self._table.data_ptr(), len(self.arena.params), self._blocks, self.arena.flat.data_ptr(),
+                      self.state1.data_ptr(), self.state2.data_ptr() if self.state2 is not None else None, self.used.data_ptr(), self.steps.data_ptr(),
+                      self.lr if lr is None else float(lr), self.betas[0], self.betas[1], self.eps, self.weight_decay, self.momentum,
+                      self.lr_dev.data_ptr() if self.lr_dev is not None else None)
+        ops._call("miseg_opt_step", p)
+
+    def state_dict(self):
+        return {"kind": self.kind, "state1": self.state1.clone(), "state2": None if self.state2 is None else self.state2.clone(), "steps": self.steps.clone(),
+                "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay, "momentum": self.momentum}
+
+    def load_state_dict(self, sd):
+        if sd["kind"] != self.kind or sd["state1"].numel() != self.state1.numel():
+            raise ValueError("optimizer state does not match this model / optimiser kind")
+        self.state1.copy_(sd["state1"])
+        if self.state2 is not None:
+            self.state2.copy_(sd["state2"])
+        self.steps.copy_(sd["steps"])

@@ -338,6 +338,54 @@ def gen_swin_unetr_c2():
     save("swin_unetr_c2", arrays, meta)
 
 
+def gen_swin_unetr_c2_truth():
+    """The conditioning of the C2 gradient comparison, measured on the REFERENCE itself: the same modules, weights, input and cotangents
+    as `swin_unetr_c2` case c2_m0, run (a) in float64 = the "truth" both fp32 implementations approximate, and (b) under
+    torch.autocast(cpu, bfloat16) = the reference's own mixed-precision mode (its default: utils/trainer.py:34 autocast(enabled=amp),
+    tune.py:267 amp = not no_amp; fp16 on CUDA there, bf16 is what this CPU offers).  The parameter gradients of this net are a
+    discontinuous function of the forward pass (LeakyReLU(0.01) sign flips of instance-normalised pre-activations), so a forward
+    deviation eps moves them by ~sqrt(eps): tests bound the HIP path's distance from the float64 run by the reference's OWN distance
+    from it at the same precision (tests/test_hip_modules.py::test_swin_unetr_c2_vs_truth)."""
+    import copy
+    arrays, meta = {}, {"cases": {}}
+    m = SwinUNETR((96, 96, 96), 1, 6, feature_size=48, num_heads=(3, 6, 12, 24), vit_norm_name=copy.deepcopy(COND),
+                  encoder_norm_name=copy.deepcopy(COND), decoder_norm_name=copy.deepcopy(INST))
+    fill_module_(m)
+    x = det_input(1234, (1, 1, 96, 96, 96))
+    g = det_input(4321, (1, 6, 96, 96, 96))
+    tag = "c2_m0"
+
+    def grab(model, key):
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                arrays[f"{tag}/{key}:{k}"] = sample(p.grad)
+        model.zero_grad(set_to_none=True)
+
+    t0 = time.time()
+    md = copy.deepcopy(m).double()
+    yd = md(x.double(), [0])
+    yd.backward(g.double(), retain_graph=True)
+    grab(md, "grad64")
+    yd.backward(ce_cotangent(yd).double())
+    grab(md, "grad64_2")
+    arrays[f"{tag}/logits64_samples"] = sample(yd)
+    t1 = time.time()
+    del md
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ya = m(x, [0])
+    ya.backward(g.to(ya.dtype), retain_graph=True)
+    grab(m, "gradamp")
+    ya.backward(ce_cotangent(ya.float()).to(ya.dtype))
+    grab(m, "gradamp_2")
+    arrays[f"{tag}/logitsamp_samples"] = sample(ya.float())
+    t2 = time.time()
+    meta["cases"][tag] = {"x": [1, 1, 96, 96, 96], "modalities": [0], "fp64_s": round(t1 - t0, 1), "autocast_bf16_s": round(t2 - t1, 1),
+                          "autocast_logits_dtype": str(ya.dtype)}
+    meta["unpinned"] = ["swinViT.*.mlp (MONAI MLPBlock stand-in)"]
+    print(f"    fp64 {t1 - t0:.0f}s autocast {t2 - t1:.0f}s")
+    save("swin_unetr_c2_truth", arrays, meta)
+
+
 def gen_unetr():
     import copy
     arrays, meta = {}, {"cases": {}}
@@ -383,9 +431,9 @@ GENS = {
     "cond_instnorm": gen_cond_instnorm, "window_attention": gen_window_attention, "swin_block": gen_swin_block,
     "patch_merging": gen_patch_merging, "unetr_blocks": gen_unetr_blocks, "transformer_block": gen_transformer_block,
     "swin_unetr_small": gen_swin_unetr_small, "unetr_small": gen_unetr, "unet": gen_unet,
-    "swin_unetr_c2": gen_swin_unetr_c2, "unetr_c3": gen_unetr_c3,
+    "swin_unetr_c2": gen_swin_unetr_c2, "unetr_c3": gen_unetr_c3, "swin_unetr_c2_truth": gen_swin_unetr_c2_truth,
 }
-FULL = ("swin_unetr_c2", "unetr_c3")
+FULL = ("swin_unetr_c2", "unetr_c3", "swin_unetr_c2_truth")
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -1,0 +1,73 @@
+"""The C ABI cannot drift silently: a C translation unit compiled with gcc against include/miseg_hip.h reports sizeof / offsetof of every
+params struct and every field; they must equal the ctypes mirror in mi-seg_amd/hip/lib.py (which names the same fields, so a renamed or
+missing field fails the compile), and the library's own miseg_abi_struct_size / miseg_abi_version must agree with both.  CPU only."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "miseg_hip.h")
+
+
+def _lib():
+    from mi_seg_amd.hip import lib
+    return lib
+
+
+def test_every_header_struct_has_a_ctypes_mirror():
+    lib = _lib()
+    declared = set(re.findall(r"\}\s*(miseg_\w+);", open(HEADER).read()))
+    mirrored = {v for v in lib.C_NAMES.values() if v}
+    assert declared == mirrored, (sorted(declared - mirrored), sorted(mirrored - declared))
+
+
+def test_struct_layouts_match_a_c_compile_of_the_header(tmp_path):
+    lib = _lib()
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
+    for t, cname in lib.C_NAMES.items():
+        lines.append(f'  printf("S {cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in t._fields_:
+            lines.append(f'  printf("F {cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  printf("V %d\\n", MISEG_ABI_VERSION);', "  return 0;", "}"]
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-o", str(exe), str(src)], check=True, capture_output=True, text=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    by_name = {v: k for k, v in lib.C_NAMES.items()}
+    seen = 0
+    for ln in out:
+        w = ln.split()
+        if not w:
+            continue
+        if w[0] == "S":
+            assert C.sizeof(by_name[w[1]]) == int(w[2]), f"sizeof({w[1]}): C {w[2]}, ctypes {C.sizeof(by_name[w[1]])}"
+        elif w[0] == "F":
+            assert getattr(by_name[w[1]], w[2]).offset == int(w[3]), f"offsetof({w[1]}, {w[2]}): C {w[3]}, ctypes {getattr(by_name[w[1]], w[2]).offset}"
+            seen += 1
+        elif w[0] == "V":
+            assert int(w[1]) == lib.ABI_VERSION
+    assert seen > 300
+
+
+def test_library_reports_the_same_sizes_and_version():
+    lib = _lib()
+    so = lib.load()                       # load() itself refuses a version / size mismatch
+    assert so.miseg_abi_version() == lib.ABI_VERSION
+    for t, cname in lib.C_NAMES.items():
+        assert so.miseg_abi_struct_size(cname.encode()) == C.sizeof(t), cname
+    assert so.miseg_abi_struct_size(b"no_such_struct") == 0
+    buf = C.create_string_buffer(16)
+    assert so.miseg_device_arch(buf, 16) == 0 and buf.value == b"gfx950"
+
+
+def test_struct_size_field_is_checked():
+    """the structs added in ABI version 2 carry their own size: a caller built against another header gets BADARG, not a wild read"""
+    lib = _lib()
+    so = lib.load()
+    p = lib.Stitch()
+    p.struct_size = C.sizeof(lib.Stitch) - 8
+    assert so.miseg_stitch_windows(C.byref(p), None) == -1
+    assert b"struct_size" in so.miseg_last_error()

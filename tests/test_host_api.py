@@ -94,7 +94,7 @@ def test_c_abi_exports_every_declared_symbol():
         assert name in lib.PROTOS, f"{name} has no ctypes prototype in hip/lib.py"
     assert set(lib.PROTOS) <= declared
     so.miseg_abi_version.restype = ctypes.c_int
-    assert so.miseg_abi_version() == 1
+    assert so.miseg_abi_version() == lib.ABI_VERSION
 
 
 def test_rank_sharding_matches_distributed_sampler():
@@ -151,6 +151,50 @@ def test_losses_and_metric_semantics():
     lab2 = torch.zeros(1, 1, 4, 4, 4, dtype=torch.long)
     d2 = dice_metric(as_discrete_onehot(lab2, 3), as_discrete_onehot(lab2, 3))
     assert float(d2[0, 0]) == 1.0 and torch.isnan(d2[0, 1])   # NaN when the class is absent from the label
+
+
+def test_dice_focal_strips_background_before_the_softmax():
+    """MONAI 1.1.0 DiceFocalLoss(include_background=False): channel 0 is removed from logits AND one-hot target first and the sub-losses
+    (built without include_background) see C-1 channels -- so the Dice softmax runs over the foreground logits only.  Independent float64
+    numpy restatement on a tiny case (the reference's documented launches use --no_include_background: lightning_monai.py:44,49-55)."""
+    import numpy as np
+    from mi_seg_amd.training.losses import DiceFocalLoss
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(1, 4, 3, 2, 2)) * 2
+    lab = rng.integers(0, 4, size=(1, 1, 3, 2, 2))
+    xs = x[:, 1:]
+    t = np.stack([(lab[:, 0] == c) for c in range(1, 4)], 1).astype(np.float64)
+    e = np.exp(xs - xs.max(1, keepdims=True))
+    p = e / e.sum(1, keepdims=True)
+    ax = (2, 3, 4)
+    dice = (1 - (2 * (p * t).sum(ax)) / ((t * t).sum(ax) + (p * p).sum(ax) + 1e-6)).mean()
+    ce = xs - xs * t + np.log1p(np.exp(-np.abs(xs))) + np.maximum(-xs, 0)
+    z = -xs * (2 * t - 1)
+    logsig = -(np.log1p(np.exp(-np.abs(z))) + np.maximum(-z, 0))
+    focal = (np.exp(2.0 * logsig) * ce).reshape(1, 3, -1).mean(-1).mean()
+    crit = DiceFocalLoss(include_background=False, to_onehot_y=True, softmax=True, squared_pred=True, smooth_nr=0.0, smooth_dr=1e-6)
+    got = float(crit(torch.from_numpy(x), torch.from_numpy(lab)))
+    assert abs(got - (dice + focal)) < 1e-6          # (the focal term of the torch restatement runs in fp32, like MONAI's .float())
+    # and it differs from "softmax over all channels, then drop channel 0" (what DiceCELoss's DiceLoss does)
+    e4 = np.exp(x - x.max(1, keepdims=True))
+    p4 = (e4 / e4.sum(1, keepdims=True))[:, 1:]
+    other = (1 - (2 * (p4 * t).sum(ax)) / ((t * t).sum(ax) + (p4 * p4).sum(ax) + 1e-6)).mean() + focal
+    assert abs(got - other) > 1e-3
+
+
+def test_style_ids_are_range_checked_on_the_host():
+    """the reference indexes a ModuleList with the style id (IndexError outside [-n, n)); the kernels index argument arrays on the device,
+    so the host check is what stands between a bad id and a wild pointer"""
+    from mi_seg_amd.networks.norms.conditional_instance_norm import ConditionalInstanceNorm3d, styles_to_device
+    dev, host = styles_to_device([1, -1, 0], "cpu", 3, num_styles=2)
+    assert host == (1, 1, 0) and dev.tolist() == [1, 1, 0]
+    for bad in ([2, 0, 0], [0, -3, 0], torch.tensor([0, 0, 4])):
+        with pytest.raises(IndexError):
+            styles_to_device(bad, "cpu", 3, num_styles=2)
+    with pytest.raises(IndexError):
+        styles_to_device((torch.zeros(2, dtype=torch.int32), (0, 2)), "cpu", 2, num_styles=2)
+    with pytest.raises(NotImplementedError):
+        ConditionalInstanceNorm3d(5, 8)
 
 
 def test_litmonai_surface():
