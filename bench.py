@@ -22,14 +22,31 @@ import torch  # noqa: E402
 import __graft_entry__ as ge  # noqa: E402
 
 
-def build_model(dtype):
-    from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
+WORKLOADS = {
+    "c2": ("96^3 patches/sec fwd+bwd, C-Swin-UNETR fs=48 6-class", "patches/s",
+           "configs[1]: C-Swin-UNETR feature_size=48 heads=(3,6,12,24) instance_cond, 96^3 patch, 6 classes, batch 1 per GPU, fwd+bwd "
+           "(+ gradient all-reduce at N>1)"),
+    "c3": ("96^3 patches/sec fwd+bwd, C-UNETR (ViT-B/16 encoder, instance_cond) 6-class", "patches/s",
+           "configs[2]: C-UNETR hidden 768 mlp 3072 heads 12 layers 12 feature_size=16 perceptron, 96^3 patch, 6 classes, batch 1 per GPU, fwd+bwd"),
+    "c5": ("96^3 windows/sec, sliding-window inference of a 512x512x363 volume (overlap 0.5, 700 windows), C-Swin-UNETR fs=48 6-class", "windows/s",
+           "configs[4]: whole 512x512x363 CT volume resident in HBM, roi 96^3, overlap 0.5 -> 700 windows in batches of 4 (modality broadcast), "
+           "hipGraph forward, all window logits resident (14.9 GB), one gather-stitch pass; a step = one volume"),
+}
+
+
+def build_model(dtype, workload="c2"):
     from mi_seg_amd.networks.norms.utils import parse_normalization
     from mi_seg_amd.utils.detfill import fill_module_
     cond = parse_normalization("instance_cond", True, 4, 2)
     inst = parse_normalization("instance", True, 4, 2)
-    m = SwinUNETR((96, 96, 96), 1, 6, feature_size=48, num_heads=(3, 6, 12, 24), vit_norm_name=cond, encoder_norm_name=cond,
-                  decoder_norm_name=inst)
+    if workload == "c3":
+        from mi_seg_amd.networks.nets.unetr import UNETR
+        m = UNETR(1, 6, (96, 96, 96), feature_size=16, hidden_size=768, mlp_dim=3072, num_heads=12, pos_embed="perceptron", vit_norm_name=cond,
+                  encoder_norm_name=cond, decoder_norm_name=inst)
+    else:
+        from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
+        m = SwinUNETR((96, 96, 96), 1, 6, feature_size=48, num_heads=(3, 6, 12, 24), vit_norm_name=cond, encoder_norm_name=cond,
+                      decoder_norm_name=inst)
     fill_module_(m)
     return m.cuda().set_compute_dtype(dtype)
 
@@ -60,6 +77,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--workload", default="c2", choices=list(WORKLOADS), help="c2 = BASELINE configs[1] (the metric); c3 / c5 = configs[2] / configs[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
@@ -86,11 +104,20 @@ def main():
         dist.init_process_group(os.environ.get("MISEG_DIST_BACKEND", "nccl"), rank=rank, world_size=world)    # "nccl" is RCCL on ROCm
 
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    model = build_model(dtype)
+    model = build_model(dtype, a.workload)
     from mi_seg_amd.data.sampler import rank_indices
+    from mi_seg_amd.hip import lib as hiplib
     from mi_seg_amd.hip import ops
-    pool, mods = synthetic_pool(16, 1000 + rank, dev)
-    order = rank_indices(len(mods), world_size=1, rank=0, epoch=rank, seed=0)   # per-rank pool, interleaved CT/MR stream
+    hiplib.check_device(local)
+    if a.workload == "c5":
+        return bench_sliding_window(a, model, dtype, dev, rank, world, dist)
+    # ONE global dataset = ConcatDataset([8 CT, 8 MR]) (identical on every rank), sharded like the reference's DistributedSampler
+    # (data/multi_modal.py:282-292, tune.py:164): epoch-seeded permutation, rank r takes perm[r::world]; epochs follow one another
+    pool, mods = synthetic_pool(16, 1000, dev)
+    order, epoch = [], 0
+    while len(order) < a.warmup + a.steps + 4:
+        order += rank_indices(len(mods), world_size=world, rank=rank, epoch=epoch, seed=0)
+        epoch += 1
     cot = torch.randn(1, 6, 96, 96, 96, generator=torch.Generator().manual_seed(4321)).to(dev)
     params = [p for p in model.parameters() if p.requires_grad]
 
@@ -100,7 +127,7 @@ def main():
         arena = ParamArena(params, dtype)
     # N > 1: the backward pass is split behind the decoder side (autograd runs it first), whose gradients - 87 % of the bytes - are
     # all-reduced by RCCL while the encoder / Swin half still runs
-    overlap = dist is not None and arena is not None and not a.no_overlap
+    overlap = dist is not None and arena is not None and not a.no_overlap and hasattr(model, "late_backward_parameters")
     tail = arena.tail_offset(model.late_backward_parameters()) if overlap else None
     graphed = None
     if not a.no_graph:
@@ -214,11 +241,10 @@ def main():
         return {"grad_rel_err_vs_mean_of_ranks": float((arena.flat - want).norm() / want.norm())}
 
     out = {
-        "metric": "96^3 patches/sec fwd+bwd, C-Swin-UNETR fs=48 6-class", "value": world * a.steps / dt, "unit": "patches/s",
+        "metric": WORKLOADS[a.workload][0], "value": world * a.steps / dt, "unit": WORKLOADS[a.workload][1],
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1000 * dt / a.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic", "launch": "eager" if graphed is None else "hipGraph", "allreduce": "overlapped with the encoder half of backward" if overlap else ("after backward" if dist is not None else "none"),
-        "config": {"workload": "configs[1]: C-Swin-UNETR feature_size=48 heads=(3,6,12,24) instance_cond, 96^3 patch, 6 classes, "
-                               "batch 1 per GPU, fwd+bwd (+ gradient all-reduce at N>1)", "global_batch": world},
+        "config": {"workload": WORKLOADS[a.workload][2], "global_batch": world, "sharding": "one 16-volume CT+MR dataset, rank r takes perm[r::world] per epoch"},
     }
     if graphed is not None:
         check = replay_check()
@@ -227,13 +253,59 @@ def main():
         out["replay_check"] = check
     if dist is not None and arena is not None:
         out["exchange_check"] = exchange_check()
+        out["collective"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "payload_bytes_per_step": int(arena.flat.numel() * 4)}
     if rank == 0:
         if not a.no_roofline:
             from mi_seg_amd.testing.roofline import profile_step, summarize
             out["roofline"] = summarize(profile_step(lambda: step(a.warmup + a.steps, eager=True, comm=False)), dtype)      # rank 0 alone: no collectives
         if world == 1 and not a.no_cpu_baseline:
             from mi_seg_amd.testing.cpu_baseline import cpu_baseline
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(a.workload)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_sliding_window(a, model, dtype, dev, rank, world, dist):
+    """BASELINE configs[4]: one step = the sliding-window inference of one whole 512 x 512 x 363 volume resident in HBM (700 windows)."""
+    from mi_seg_amd.runtime.graph import GraphedForward
+    from mi_seg_amd.training.inferer import sliding_window_inference, window_grid
+    size, sw = (512, 512, 363), 4
+    vol = torch.rand(1, 1, *size, generator=torch.Generator().manual_seed(2000 + rank)).to(dev)
+    nwin = len(window_grid(size, (96, 96, 96), 0.5))
+    pred = GraphedForward(model, (sw, 1, 96, 96, 96))
+    run = lambda: sliding_window_inference(vol, 96, sw, pred, overlap=0.5, modalities=[0])
+    for _ in range(max(1, a.warmup)):
+        y = run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        y = run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    out = {"metric": WORKLOADS["c5"][0], "value": world * a.steps * nwin / dt, "unit": "windows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": 1000 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+           "launch": "hipGraph", "config": {"workload": WORKLOADS["c5"][2], "windows_per_volume": nwin, "sw_batch_size": sw,
+                                            "replicas": "one volume per GPU, no collective (windows are independent)"},
+           "finite": bool(torch.isfinite(y).all()), "volumes_per_s": world * a.steps / dt}
+    if rank == 0:
+        if not a.no_roofline:
+            from mi_seg_amd.testing.roofline import profile_step, summarize
+            xw = vol[:, :, :96, :96, :96].expand(sw, -1, -1, -1, -1).contiguous()
+
+            def one_batch():
+                with torch.no_grad():
+                    model(xw, [0] * sw)
+            out["roofline"] = summarize(profile_step(one_batch), dtype)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -500,6 +500,24 @@ typedef struct {
 } miseg_stitch_params;
 int miseg_stitch_windows(const miseg_stitch_params* p, miseg_stream_t stream);
 
+/* GPU-resident training augmentation (the random part of the MONAI chain at data/multi_modal.py:50-65, after the cached deterministic
+ * part): for each of n <= MISEG_AUG_MAX_SAMPLES samples ONE gather pass produces a roi-sized image + label patch from the resident volume:
+ *   RandCropByPosNegLabeld (crop origin, chosen by the host from cached foreground / background voxel lists), RandFlipd x3 (flip[a] on
+ *   the PATCH axis a), RandRotate90d (rot_k quarter turns in the (0, 1) plane, roi_d == roi_h when rot_k is odd), RandScaleIntensityd
+ *   (image * (1 + scale)), RandShiftIntensityd (image + shift) - applied in that order, intensity ops on the image only.
+ * image: fp32 [C][D][H][W]; label: [D][H][W] elements of label_bytes (1, 4 or 8) bytes, copied verbatim; out_image fp32 [n][C][rd][rh][rw];
+ * out_label [n][rd][rh][rw].  Sample descriptors are a HOST array (copied into the kernel arguments). */
+#define MISEG_AUG_MAX_SAMPLES 16
+typedef struct { int32_t origin[3]; int32_t flip[3]; int32_t rot_k; float scale, shift; } miseg_aug_sample;
+typedef struct {
+  uint32_t struct_size;
+  const float* image; const void* label; int label_bytes;
+  int C, D, H, W, rd, rh, rw, n;
+  float* out_image; void* out_label;
+  const miseg_aug_sample* samples_host;
+} miseg_augment_params;
+int miseg_augment_crop(const miseg_augment_params* p, miseg_stream_t stream);
+
 /* sizeof() of a params struct as this library was compiled ("miseg_gemm_params", ...), 0 for an unknown name: bindings compare it with
  * their own mirror at load time (together with miseg_abi_version) so that header and binding cannot drift silently. */
 size_t miseg_abi_struct_size(const char* struct_name);

@@ -414,6 +414,43 @@ static __global__ void __launch_bounds__(256) stitch_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------ augmentation
+struct AugArgs {
+  int C, D, H, W, rd, rh, rw, n, lb;
+  miseg_aug_sample s[MISEG_AUG_MAX_SAMPLES];
+};
+
+// patch coordinate (after rot90 + flips) -> coordinate inside the un-augmented crop.  The forward chain is crop -> flip0 -> flip1 -> flip2 ->
+// rot90^k in the (0, 1) plane; the gather inverts it back to front.
+__device__ __forceinline__ void aug_source(const miseg_aug_sample& a, int rd, int rh, int rw, int i, int j, int k, int& si, int& sj, int& sk) {
+  // torch.rot90(x, k, (0, 1)): k = 1: out[i][j] = in[j][n1 - 1 - i] (n1 = in.size(1) = out.size(0))
+  int pi = i, pj = j;
+  const int kk = a.rot_k & 3;
+  if (kk == 1) { pi = j; pj = rd - 1 - i; }
+  else if (kk == 2) { pi = rd - 1 - i; pj = rh - 1 - j; }
+  else if (kk == 3) { pi = rh - 1 - j; pj = i; }
+  // (rd == rh whenever kk is odd: checked on the host, so the pre-rotation patch has the same extents)
+  si = a.flip[0] ? rd - 1 - pi : pi;
+  sj = a.flip[1] ? rh - 1 - pj : pj;
+  sk = a.flip[2] ? rw - 1 - k : k;
+}
+
+template <class LB>
+__global__ void __launch_bounds__(256) augment_kernel(const float* __restrict__ image, const LB* __restrict__ label, float* __restrict__ oimg, LB* __restrict__ olab, AugArgs a) {
+  const int n = blockIdx.z;
+  const miseg_aug_sample& sm = a.s[n];
+  const int64_t pvol = (int64_t)a.rd * a.rh * a.rw, vvol = (int64_t)a.D * a.H * a.W;
+  const float mul = 1.f + sm.scale;
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < pvol; o += (int64_t)gridDim.x * 256) {
+    const int k = (int)(o % a.rw), j = (int)((o / a.rw) % a.rh), i = (int)(o / ((int64_t)a.rw * a.rh));
+    int si, sj, sk;
+    aug_source(sm, a.rd, a.rh, a.rw, i, j, k, si, sj, sk);
+    const int64_t src = ((int64_t)(sm.origin[0] + si) * a.H + (sm.origin[1] + sj)) * a.W + (sm.origin[2] + sk);
+    for (int c = 0; c < a.C; ++c) oimg[((int64_t)n * a.C + c) * pvol + o] = image[(int64_t)c * vvol + src] * mul + sm.shift;
+    if (label) olab[(int64_t)n * pvol + o] = label[src];
+  }
+}
+
 template <class F> static int dispatch_label(int dt, F&& f) {
   switch (dt) {
     case MISEG_LABEL_F32: return f((const float*)nullptr);
@@ -551,5 +588,33 @@ extern "C" int miseg_stitch_windows(const miseg_stitch_params* p, miseg_stream_t
   }
   stitch_kernel<<<dim3(cdiv(p->W, 256), p->H, p->D), 256, 0, s>>>(p->win, p->out, p->count, a);
   MISEG_LAUNCH_CHECK("stitch_windows");
+  return MISEG_OK;
+}
+
+extern "C" int miseg_augment_crop(const miseg_augment_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->struct_size == sizeof(miseg_augment_params), MISEG_E_BADARG, "augment_crop: struct_size %u != %zu", p ? p->struct_size : 0u,
+                sizeof(miseg_augment_params));
+  MISEG_REQUIRE(p->image && p->out_image && p->samples_host && (!p->label || p->out_label), MISEG_E_BADARG, "augment_crop: null pointer");
+  MISEG_REQUIRE(p->n > 0 && p->n <= MISEG_AUG_MAX_SAMPLES && p->C > 0, MISEG_E_UNSUPPORTED, "augment_crop: %d samples (max %d)", p->n, MISEG_AUG_MAX_SAMPLES);
+  MISEG_REQUIRE(p->label_bytes == 1 || p->label_bytes == 4 || p->label_bytes == 8 || !p->label, MISEG_E_UNSUPPORTED, "augment_crop: label element of %d bytes", p->label_bytes);
+  AugArgs a;
+  a.C = p->C; a.D = p->D; a.H = p->H; a.W = p->W; a.rd = p->rd; a.rh = p->rh; a.rw = p->rw; a.n = p->n; a.lb = p->label_bytes;
+  for (int i = 0; i < p->n; ++i) {
+    const miseg_aug_sample& q = p->samples_host[i];
+    // every gathered coordinate stays inside the volume: checked here, on the host, before the launch
+    MISEG_REQUIRE(q.origin[0] >= 0 && q.origin[1] >= 0 && q.origin[2] >= 0 && q.origin[0] + p->rd <= p->D && q.origin[1] + p->rh <= p->H && q.origin[2] + p->rw <= p->W,
+                  MISEG_E_BADARG, "augment_crop: sample %d crop (%d,%d,%d)+(%d,%d,%d) leaves the %dx%dx%d volume", i, q.origin[0], q.origin[1], q.origin[2], p->rd, p->rh,
+                  p->rw, p->D, p->H, p->W);
+    MISEG_REQUIRE(!(q.rot_k & 1) || p->rd == p->rh, MISEG_E_BADARG, "augment_crop: an odd number of quarter turns needs roi_d == roi_h");
+    a.s[i] = q;
+  }
+  int gx = cdiv((int64_t)p->rd * p->rh * p->rw, 256 * 4);
+  if (gx > 1024) gx = 1024;
+  const dim3 grid(gx, 1, p->n);
+  if (!p->label || p->label_bytes == 1) augment_kernel<uint8_t><<<grid, 256, 0, s>>>(p->image, (const uint8_t*)p->label, p->out_image, (uint8_t*)p->out_label, a);
+  else if (p->label_bytes == 4) augment_kernel<uint32_t><<<grid, 256, 0, s>>>(p->image, (const uint32_t*)p->label, p->out_image, (uint32_t*)p->out_label, a);
+  else augment_kernel<uint64_t><<<grid, 256, 0, s>>>(p->image, (const uint64_t*)p->label, p->out_image, (uint64_t*)p->out_label, a);
+  MISEG_LAUNCH_CHECK("augment_crop");
   return MISEG_OK;
 }

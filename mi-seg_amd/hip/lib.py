@@ -117,6 +117,11 @@ OptStep = _struct("OptStep", cname="miseg_opt_step_params", fields=[
 Stitch = _struct("Stitch", cname="miseg_stitch_params", fields=[
     ("struct_size", u32), ("win", vp), ("out", vp), ("count", vp), ("C", i32), ("D", i32), ("H", i32), ("W", i32), ("rd", i32), ("rh", i32), ("rw", i32),
     ("nd", i32), ("nh", i32), ("nw", i32), ("start_d", vp), ("start_h", vp), ("start_w", vp)])
+AugSample = _struct("AugSample", cname="miseg_aug_sample", fields=[("origin", i32 * 3), ("flip", i32 * 3), ("rot_k", i32), ("scale", f32), ("shift", f32)])
+Augment = _struct("Augment", cname="miseg_augment_params", fields=[
+    ("struct_size", u32), ("image", vp), ("label", vp), ("label_bytes", i32), ("C", i32), ("D", i32), ("H", i32), ("W", i32), ("rd", i32), ("rh", i32),
+    ("rw", i32), ("n", i32), ("out_image", vp), ("out_label", vp), ("samples_host", vp)])
+AUG_MAX_SAMPLES = 16
 LABEL_F32, LABEL_I32, LABEL_I64, LABEL_U8 = 0, 1, 2, 3
 LOSS_DICE_FOCAL, LOSS_DICE_CE = 0, 1
 OPT_ADAMW, OPT_ADAM, OPT_SGD_NESTEROV = 0, 1, 2
@@ -189,6 +194,7 @@ PROTOS = {
     "miseg_dice_metric": (i32, [C.POINTER(DiceMetric), vp]),
     "miseg_opt_step": (i32, [C.POINTER(OptStep), vp]),
     "miseg_stitch_windows": (i32, [C.POINTER(Stitch), vp]),
+    "miseg_augment_crop": (i32, [C.POINTER(Augment), vp]),
     "miseg_abi_struct_size": (C.c_size_t, [C.c_char_p]),
     "miseg_device_check": (i32, [i32]),
 }

@@ -124,7 +124,14 @@ class SwinUNETR(nn.Module):
     def load_from(self, weights):
         """MONAI self-supervised Swin-ViT weights (reference swin_unetr.py:303-351); plain-norm checkpoints only."""
         sd = {k.replace("module.", "").replace("fc1", "linear1").replace("fc2", "linear2"): v for k, v in weights["state_dict"].items()}
-        return self.swinViT.load_state_dict(sd, strict=False)
+        # the reference copies an explicit list (patch_embed, every block of layers1-4, the downsample reduction / norm) and raises KeyError
+        # when a checkpoint lacks one of them; extra keys of the checkpoint are ignored there as here
+        want = [k for k in self.swinViT.state_dict() if k.startswith(("patch_embed.", "layers1.", "layers2.", "layers3.", "layers4."))
+                and not k.endswith("relative_position_index")]
+        missing = [k for k in want if k not in sd]
+        if missing:
+            raise KeyError(f"checkpoint lacks {len(missing)} Swin-ViT entries, e.g. '{missing[0]}'")
+        return self.swinViT.load_state_dict({k: sd[k] for k in want}, strict=False)
 
     # parameters whose gradients are complete once the decoder side has been back-propagated (autograd runs it first): what a
     # data-parallel step can start all-reducing while the encoder / Swin half of the backward pass is still running

@@ -1,6 +1,9 @@
 """cpu_baseline leg of bench.py: the CPU oracle (oracle/, a PyTorch fp32 restatement of the reference's path, pinned
 against the reference's golden vectors) timed on the GPU box's host cores.  This is the checker being timed as a
-baseline -- it is never part of the product path."""
+baseline -- it is never part of the product path.
+
+Protocol: all physical cores available to the process, fp32, the parity input (seed 1234, modality 0, cotangent
+seed 4321), 1 warm-up + 3 timed forward+backward iterations, median; CPU model and core count reported."""
 import os
 import sys
 import time
@@ -8,32 +11,72 @@ import time
 import torch
 
 
-def cpu_baseline():
+def host_cpu():
+    """(model name, physical cores usable by this process, logical CPUs usable)"""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    model, cores, cur = "unknown", set(), {}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if ":" not in line:
+                if cur and int(cur.get("processor", -1)) in allowed:
+                    cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                cur = {}
+                continue
+            k, v = (t.strip() for t in line.split(":", 1))
+            cur[k] = v
+            if k == "model name":
+                model = v
+        if cur and int(cur.get("processor", -1)) in allowed:
+            cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+    except OSError:
+        pass
+    return model, (len(cores) or len(allowed)), len(allowed)
+
+
+def cpu_baseline(workload="c2"):
     root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     if root not in sys.path:
         sys.path.insert(0, root)
     from oracle import nets as ON                     # noqa: E402  (bench.py cpu_baseline leg only)
     from oracle.functional import relative_position_index
-    from ..networks.nets.swin_unetr import SwinUNETR
     from ..networks.norms.utils import parse_normalization
     from ..utils.detfill import det_input, det_values
-    cores = min(16, os.cpu_count() or 1)     # the GPU box's CPU share for one GPU
-    torch.set_num_threads(cores)
+    model_name, phys, logical = host_cpu()
+    torch.set_num_threads(phys)
     cond, inst = parse_normalization("instance_cond", True, 4, 2), parse_normalization("instance", True, 4, 2)
     with torch.device("meta"):
-        m = SwinUNETR((96, 96, 96), 1, 6, feature_size=48, num_heads=(3, 6, 12, 24), vit_norm_name=cond, encoder_norm_name=cond,
-                      decoder_norm_name=inst)
+        if workload == "c3":
+            from ..networks.nets.unetr import UNETR
+            m = UNETR(1, 6, (96, 96, 96), feature_size=16, hidden_size=768, mlp_dim=3072, num_heads=12, pos_embed="perceptron", vit_norm_name=cond,
+                      encoder_norm_name=cond, decoder_norm_name=inst)
+        else:
+            from ..networks.nets.swin_unetr import SwinUNETR
+            m = SwinUNETR((96, 96, 96), 1, 6, feature_size=48, num_heads=(3, 6, 12, 24), vit_norm_name=cond, encoder_norm_name=cond,
+                          decoder_norm_name=inst)
     sd = {}
     for k, v in m.state_dict().items():
         sd[k] = relative_position_index() if k.endswith("relative_position_index") else \
             torch.from_numpy(det_values(k, v.shape)).requires_grad_(True)
-    cfg = ON.swin_unetr_cfg(feature_size=48)
+    if workload == "c3":
+        cfg, fwd = ON.unetr_cfg(), ON.unetr_forward
+    else:
+        cfg, fwd = ON.swin_unetr_cfg(feature_size=48), ON.swin_unetr_forward
     x = det_input(1234, (1, 1, 96, 96, 96))
     g = det_input(4321, (1, 6, 96, 96, 96))
-    t0 = time.perf_counter()
-    y = ON.swin_unetr_forward(sd, x, [0], cfg)
-    y.backward(g)
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 x 96^3 patch forward+backward (first call, no warm-up), oracle/nets.py swin_unetr_forward fp32, "
-                      f"{dt:.1f} s"}
+    times = []
+    for it in range(4):                                # 1 warm-up + 3 timed
+        for v in sd.values():
+            if v.is_floating_point():
+                v.grad = None
+        t0 = time.perf_counter()
+        y = fwd(sd, x, [0], cfg)
+        y.backward(g)
+        times.append(time.perf_counter() - t0)
+    med = sorted(times[1:])[1]
+    return {"value": 1.0 / med, "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port", "cpu_model": model_name,
+            "logical_cpus": logical, "seconds_per_patch_median": med, "seconds_each": [round(t, 2) for t in times],
+            "sample": f"1 warm-up + 3 timed 96^3 forward+backward patches (median), oracle/nets.py fp32 restatement of the reference path, "
+                      f"{phys} physical cores of {model_name}"}

@@ -12,6 +12,7 @@ import torch
 from ..hip import ops
 
 PEAK_TFLOPS = {torch.bfloat16: 2500.0, torch.float32: 157.3}
+PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def profile_step(step_fn):
@@ -52,7 +53,13 @@ def summarize(prof, dtype):
     achieved = flops / (tot_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[dtype]
     traffic, src = _pmc_traffic(name)
+    alg_bytes = sum(t[2] for t in lst) / len(lst)
+    avg_s = tot_ms * 1e-3 / len(lst)
+    # the 3x3x3 conv is reported against BOTH roofs - the matrix-core roof that bounds it (frac) and the HBM roof north_star
+    # names (hbm_frac = algorithmic bytes per launch / launch time / 8 TB/s; hbm_frac_counter = the same with the PMC-counted bytes)
     return {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "hbm_achieved_GBs": alg_bytes / avg_s / 1e9, "hbm_peak_GBs": PEAK_HBM_GBS, "hbm_frac": alg_bytes / avg_s / 1e9 / PEAK_HBM_GBS,
+            "hbm_frac_counter": (traffic / avg_s / 1e9 / PEAK_HBM_GBS) if traffic else None,
             "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": src,
             "algorithmic_bytes_per_launch": sum(t[2] for t in lst) / len(lst), "launches_per_step": len(lst), "avg_launch_ms": tot_ms / len(lst),
             "flops_per_step": flops, "all_kernels_ms": {k: sum(t[0] for t in v) for k, v in prof.items()}}

@@ -92,12 +92,15 @@ def state_from_meta(case, requires_grad=True):
     return sd
 
 
-def compare_grads(got_named, want, tol, sampled=False, vanish_tol=1e-2, skip=(), pool_small=False):
+def compare_grads(got_named, want, tol, sampled=False, vanish_tol=1e-2, skip=(), pool_small=False, allow_small=False):
     """Per-parameter relative L2 check of gradients against golden vectors.
 
     Parameters whose TRUE gradient vanishes (a bias / 1-channel conv in front of an instance norm: the norm removes
     any per-channel constant or scale) hold pure rounding noise in the golden vectors; they are recognised by a
     per-element RMS below 1e-3 of the median over all parameters and only required to be (numerically) zero too.
+    allow_small / pool_small: only for bf16 comparisons against an fp32 fixture where no float64 truth fixture exists (UNETR, UNet) --
+    errors that are small against the typical gradient element pass, per-channel vectors are judged together.  The benchmarked
+    configuration is judged per parameter without either (test_swin_unetr_c2_vs_truth).
     Returns the worst (name, error)."""
     rms = {k: float(g.double().norm()) / max(1, g.numel()) ** 0.5 for k, g in want.items()}
     med = sorted(rms.values())[len(rms) // 2]
@@ -121,7 +124,7 @@ def compare_grads(got_named, want, tol, sampled=False, vanish_tol=1e-2, skip=(),
             continue
         e = rel_err(got, g)
         abs_rms = float((got.double() - g.double()).norm()) / max(1, g.numel()) ** 0.5
-        if e >= tol and abs_rms < 2 * tol * med:
+        if allow_small and e >= tol and abs_rms < 2 * tol * med:
             continue   # error is tiny against the typical gradient element: a (near-)vanishing gradient
         if e > worst[1]:
             worst = (k, e)

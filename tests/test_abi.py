@@ -71,3 +71,28 @@ def test_struct_size_field_is_checked():
     p.struct_size = C.sizeof(lib.Stitch) - 8
     assert so.miseg_stitch_windows(C.byref(p), None) == -1
     assert b"struct_size" in so.miseg_last_error()
+
+
+def _integration_stub():
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"```python\n(import ctypes as C, torch\n.*?)```", md, flags=re.S)
+    assert m, "INTEGRATION.md lost its per-op binding stub"
+    return m.group(1)
+
+
+def test_integration_md_stub_matches_the_binding():
+    """the stub a reference maintainer would copy out of INTEGRATION.md is executed as written (its own asserts compare its structs with
+    the library's sizeof) and its field lists must equal the ones of hip/lib.py, which the gcc test above ties to the header"""
+    lib = _lib()
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(ROOT)                      # the stub opens the library by its in-tree relative path
+    try:
+        exec(compile(_integration_stub(), "INTEGRATION.md", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    for mine, theirs in ((ns["Stats"], lib.InstnormStats), (ns["Apply"], lib.InstnormApply)):
+        assert [f[0] for f in mine._fields_] == [f[0] for f in theirs._fields_]
+        assert C.sizeof(mine) == C.sizeof(theirs)
+        for f in mine._fields_:
+            assert getattr(mine, f[0]).offset == getattr(theirs, f[0]).offset, f[0]

@@ -31,9 +31,37 @@ def test_library_loads_and_reports_arch():
     import ctypes
     L = _L()
     lib = L.load()
-    assert lib.miseg_abi_version() == 1
+    assert lib.miseg_abi_version() == L.ABI_VERSION
     buf = ctypes.create_string_buffer(16)
     assert lib.miseg_device_arch(buf, 16) == 0 and buf.value == b"gfx950"
+    L.check_device(0)          # the card really is what the embedded code objects were built for
+
+
+def test_integration_md_stub_runs():
+    """the per-op binding shown in INTEGRATION.md, executed verbatim, against the reference's per-sample loop
+    (networks/norms/conditional_instance_norm.py:59-60) restated with F.instance_norm"""
+    import os
+    import re
+    from conftest import ROOT
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(import ctypes as C, torch\n.*?)```", md, flags=re.S).group(1)
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    norms = torch.nn.ModuleList([torch.nn.InstanceNorm3d(24, affine=True) for _ in range(2)]).to(DEV)
+    for i, n in enumerate(norms):
+        torch.nn.init.normal_(n.weight, 1.0, 0.3)
+        torch.nn.init.normal_(n.bias, 0.0, 0.3)
+    x = rnd(3, 5, 6, 7, 24)
+    styles = [1, 0, 1]
+    y = ns["cond_instance_norm_ndhwc"](x, torch.tensor(styles, dtype=torch.int32, device=DEV), norms)
+    xc = x.permute(0, 4, 1, 2, 3)
+    want = torch.stack([F.instance_norm(xc[i:i + 1], weight=norms[s].weight, bias=norms[s].bias)[0] for i, s in enumerate(styles)]).permute(0, 2, 3, 4, 1)
+    assert rel_err(y, want) < 2e-5
 
 
 def test_bad_args_raise_value_error():

@@ -172,8 +172,9 @@ def _whole(G, tag, model, tol, dtype=torch.float32, ce=False):
     assert e < tol, ("logits", e)
     y.backward(ce_cotangent(y) if ce else det_input(4321, tuple(y.shape)).to(DEV))
     named = dict(model.named_parameters())
+    # 10 x tol: the reference's own fp32 run sits 1e-3 .. 5e-3 from its float64 run on these gradients (test_swin_unetr_c2_vs_truth)
     worst = compare_grads({k: p.grad for k, p in named.items()}, G.grads2(tag) if ce else G.grads(tag), 10 * tol, sampled=True,
-                          vanish_tol=1e-2 if dtype == torch.float32 else 0.5, pool_small=dtype != torch.float32,
+                          vanish_tol=1e-2 if dtype == torch.float32 else 0.5, pool_small=dtype != torch.float32, allow_small=dtype != torch.float32,
                           # 1-channel 1x1x1 conv in front of an instance norm: d/dw == 0 analytically (the norm removes the
                           # per-channel scale), so in bf16 the value is rounding noise of either implementation
                           skip=() if dtype == torch.float32 else ("encoder1.layer.conv3.conv.weight",))
@@ -193,17 +194,87 @@ def test_swin_unetr_small(golden, tag):
 
 
 @pytest.mark.parametrize("tag,dtype,tol,ce", [("c2_m0", torch.float32, TOL, False), ("c2_m1", torch.float32, TOL, False),
-                                              ("c2_m0", torch.float32, TOL, True), ("c2_m0", torch.bfloat16, TOL_BF16, True)])
+                                              ("c2_m0", torch.float32, TOL, True)])
 def test_swin_unetr_c2_headline(golden, tag, dtype, tol, ce):
     """BASELINE configs[1]: C-Swin-UNETR fs=48, 96^3, 6 classes -- fwd + bwd on the same seeded patch as the reference.
     ce=False: white-noise cotangent on the logits (every parameter gradient is then a sqrt(N)-cancelling random sum: the
-    fp32 path still agrees to ~3e-3); ce=True: gradient of the mean voxel cross-entropy against block labels, the
-    cotangent the bf16 path is judged on."""
+    fp32 path still agrees to ~3e-3); ce=True: gradient of the mean voxel cross-entropy against block labels.  Logits at 1e-3, every
+    parameter gradient at 1e-2 against the reference's fp32 run with no escape for small errors; the bf16 mode and the sharper per-parameter
+    bar against the reference's float64 run are in test_swin_unetr_c2_vs_truth."""
     from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
     G = golden("swin_unetr_c2")
     m = SwinUNETR((96, 96, 96), 1, 6, feature_size=48, num_heads=(3, 6, 12, 24), vit_norm_name=_norm("instance_cond"),
                   encoder_norm_name=_norm("instance_cond"), decoder_norm_name=_norm("instance"))
     _whole(G, tag, m, tol, dtype, ce)
+
+
+@pytest.mark.parametrize("dtype,cot", [(torch.float32, "noise"), (torch.float32, "ce"), (torch.bfloat16, "noise"), (torch.bfloat16, "ce")])
+def test_swin_unetr_c2_vs_truth(golden, dtype, cot):
+    """The gradient bar of the benchmarked configuration, per parameter, no pooling, no escape hatch.
+
+    The parameter gradients of this net are a DISCONTINUOUS function of the forward pass (LeakyReLU(0.01) on instance-normalised
+    pre-activations: a forward deviation eps flips ~0.4 eps of the signs), so they move by ~sqrt(eps): the reference's OWN fp32 run is
+    1.2e-3 (white-noise cotangent) / 3.4e-3 (cross-entropy cotangent) median away from its float64 run, its own autocast-bf16 run 24 %
+    (tests/golden/swin_unetr_c2_truth.npz, made by oracle/tools/make_golden.py from the reference's modules).  "Within 1e-3 of the fp32
+    reference" is therefore below the reference's own rounding noise at this test point; what CAN be asked of an implementation is that it
+    is no further from the float64 run than the reference itself is at the same precision:
+        fp32 mode:  |hip - f64| <= 3.0 x |ref_fp32 - f64|      + 1e-5   (measured worst ratio 2.7)
+        bf16 mode:  |hip - f64| <= 1.75 x |ref_autocast - f64|          (measured worst ratio 1.5; median 0.9)
+    per parameter, relative L2 over the 4096-element sample of each tensor.  Parameters whose true gradient is zero (a bias in front of an
+    instance norm) are listed by the float64 run itself and must be ~0."""
+    from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
+    from mi_seg_amd.utils.detfill import ce_cotangent, det_input
+    T, R = golden("swin_unetr_c2_truth"), golden("swin_unetr_c2")
+    m = _fill(SwinUNETR((96, 96, 96), 1, 6, feature_size=48, num_heads=(3, 6, 12, 24), vit_norm_name=_norm("instance_cond"),
+                        encoder_norm_name=_norm("instance_cond"), decoder_norm_name=_norm("instance")))
+    m.set_compute_dtype(dtype)
+    y = m(det_input(1234, (1, 1, 96, 96, 96)).to(DEV), [0])
+    k64, kref = ("grad64:", "grad:" if dtype == torch.float32 else "gradamp:") if cot == "noise" else ("grad64_2:", "grad2:" if dtype == torch.float32 else "gradamp_2:")
+    src = R if dtype == torch.float32 else T
+    e_logits = rel_err(sample(y), T.t("c2_m0/logits64_samples"))
+    e_ref = rel_err(R.t("c2_m0/logits_samples") if dtype == torch.float32 else T.t("c2_m0/logitsamp_samples"), T.t("c2_m0/logits64_samples"))
+    assert e_logits <= 3.0 * e_ref, ("logits", e_logits, e_ref)
+    y.backward(ce_cotangent(y) if cot == "ce" else det_input(4321, tuple(y.shape)).to(DEV))
+    truth = {k[len("c2_m0/" + k64):]: T.t(k) for k in T.z.files if k.startswith("c2_m0/" + k64)}
+    rms = {k: float(g.double().norm()) / g.numel() ** 0.5 for k, g in truth.items()}
+    med = sorted(rms.values())[len(rms) // 2]
+    named = dict(m.named_parameters())
+    factor, slack = (3.0, 1e-5) if dtype == torch.float32 else (1.75, 0.0)
+    worst = (0.0, "")
+    for k, t in truth.items():
+        got = sample(named[k].grad)
+        if rms[k] < 1e-3 * med:                                   # analytically zero gradient
+            assert float(got.double().norm()) / got.numel() ** 0.5 < (1e-4 if dtype == torch.float32 else 0.1) * med, (k, "should vanish")
+            continue
+        e_hip, e_r = rel_err(got, t), rel_err(src.t(f"c2_m0/{kref}{k}"), t)
+        worst = max(worst, (e_hip / (e_r + 1e-12), k))
+        assert e_hip <= factor * e_r + slack, (k, e_hip, e_r)
+    print(f"c2 vs truth {dtype} {cot}: logits {e_logits:.2e} (reference at this precision {e_ref:.2e}); worst gradient ratio {worst}")
+    assert sorted(k for k, p in named.items() if p.grad is None) == sorted(R.meta["cases"]["c2_m0"]["grad_none"])
+
+
+def test_forward_and_data_gradients_are_bitwise_reproducible():
+    """two identical eager steps: logits, the gradient w.r.t. every activation on the dX chain and hence every dX-derived quantity are
+    bit-identical (no atomics on that path: statistics are fp64 sums whose rounding to fp32 is order-independent in practice, split
+    reductions are summed in a fixed order).  The weight-gradient reductions (split-K partial tiles / fp32 atomics of small outputs) are
+    reproducible to rounding only: checked at 1e-5."""
+    from mi_seg_amd.hip import ops
+    from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
+    from mi_seg_amd.utils.detfill import det_input
+    m = _fill(SwinUNETR((64, 64, 64), 1, 6, feature_size=12, num_heads=(3, 6, 12, 24), vit_norm_name=_norm("instance_cond"),
+                        encoder_norm_name=_norm("instance_cond"), decoder_norm_name=_norm("instance")))
+    x = det_input(1, (2, 1, 64, 64, 64)).to(DEV)
+    cot = det_input(2, (2, 6, 64, 64, 64)).to(DEV)
+    runs = []
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        ops.begin_step()
+        y = m(x, [1, 0])
+        y.backward(cot)
+        runs.append((y.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    assert torch.equal(runs[0][0], runs[1][0]), "logits differ between two identical runs"
+    for k in runs[0][1]:
+        assert rel_err(runs[1][1][k], runs[0][1][k]) < 1e-5, k
 
 
 @pytest.mark.parametrize("tag,dtype", [("c1_64", torch.float32), ("cond_32", torch.float32), ("c1_64", torch.bfloat16)])
@@ -285,15 +356,12 @@ def test_param_arena_matches_plain_autograd(dtype):
             y = net(x, mods)
             y.backward(cot)
             arena.publish()
-            # fp64-atomic statistics and split-K partial sums are order dependent in the last bits: not bitwise run to run
-            assert rel_err(y.detach(), yr) < (1e-5 if dtype == torch.float32 else 2e-2), f"logits differ in arena mode (step {it})"
+            assert torch.equal(y.detach(), yr), f"logits differ in arena mode (step {it})"      # the forward is bit-reproducible
             names = [k for k, _ in net.named_parameters()]
             assert [k for k, g in zip(names, gr) if g is None] == [k for k, p in zip(names, params) if p.grad is None]
             want = {k: g.float().cpu() for k, g in zip(names, gr) if g is not None}
             got = {k: p.grad for k, p in zip(names, params) if p.grad is not None}
-            # two runs of the SAME path already differ by up to ~8e-3 on some parameters (fp64-atomic statistics move the
-            # forward by ~4e-7, which flips a few LeakyReLU masks; scripts/debug_uninit.py): this is a plumbing check
-            compare_grads(got, want, 3e-2 if dtype == torch.float32 else 8e-2, pool_small=dtype != torch.float32)
+            compare_grads(got, want, 1e-4)      # same kernels, same forward bits: only the order of the weight-gradient reductions differs
         assert arena._table is not None and arena._table[1] > 0
     finally:
         arena.detach()
@@ -349,11 +417,11 @@ def test_graphed_step_replays_match_eager(use_arena):
             torch.cuda.synchronize()
             y_ref, g_ref = ref[m]
             # the inline host-side check is part of the regression: it allocates and launches between two replays
-            assert float((y.detach().float() - y_ref.float()).norm() / y_ref.float().norm()) < 1e-5, f"replay {it} (modality {m}): logits differ from eager"
+            assert torch.equal(y.detach(), y_ref), f"replay {it} (modality {m}): logits differ from eager"
             got = {k: p.grad for k, p in zip(names, params) if p.grad is not None}
             assert set(got) == set(g_ref), f"replay {it}: set of parameters with a gradient differs"
             assert all(bool(torch.isfinite(g).all()) for g in got.values()), f"replay {it}: non-finite gradient"
-            compare_grads(got, g_ref, 8e-2, pool_small=True)
+            compare_grads(got, g_ref, 1e-4)
     finally:
         if arena is not None:
             arena.detach()
