@@ -781,6 +781,10 @@ static size_t attn_mfma_fwd_smem(int tsize) {
   return (size_t)(2 * ATT_NP * 16 + 16 * ATT_VT_LD) * 2 + (size_t)3 * ATT_NP * 4 + (size_t)tsize * 4;
 }
 
+// csrc/attention_global.hip: head_dim 64 global attention on the matrix cores; return 1 when they took the call (status in *rc)
+int global_attn_fwd(const miseg_winattn_params* p, hipStream_t s, int* rc);
+int global_attn_bwd(const miseg_winattn_bwd_params* p, hipStream_t s, int* rc);
+
 }  // namespace miseg
 
 using namespace miseg;
@@ -821,6 +825,7 @@ extern "C" int miseg_winattn_fwd(const miseg_winattn_params* p, miseg_stream_t s
   WinGeom g;
   int rc = make_geom(p, &g);
   if (rc) return rc;
+  if (global_attn_fwd(p, s, &rc)) return rc;       // one window = the whole token grid, head_dim 64, bf16 (the ViT of C-UNETR)
   const int tb = 2 * g.tw - 1, tsize = p->bias_table ? tb * tb * tb : 0;
   const size_t sh = attn_smem_bytes(g.n, g.hd, tsize, false);
   MISEG_REQUIRE(sh <= 160 * 1024, MISEG_E_UNSUPPORTED, "winattn_fwd: %zu bytes of LDS needed", sh);
@@ -857,6 +862,7 @@ extern "C" int miseg_winattn_bwd(const miseg_winattn_bwd_params* p, miseg_stream
   WinGeom g;
   int rc = make_geom(&p->f, &g);
   if (rc) return rc;
+  if (global_attn_bwd(p, s, &rc)) return rc;       // must take exactly the calls global_attn_fwd took: its log-sum-exp is in the log2 domain
   const int tb = 2 * g.tw - 1, tsize = p->f.bias_table ? tb * tb * tb : 0;
   const size_t sh = attn_smem_bytes(g.n, g.hd, tsize, true);
   MISEG_REQUIRE(sh <= 160 * 1024, MISEG_E_UNSUPPORTED, "winattn_bwd: %zu bytes of LDS needed", sh);

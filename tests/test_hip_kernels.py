@@ -670,6 +670,31 @@ def test_window_attention_core(dtype, dims, ws, ss, heads, C):
         assert float(dqb.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dims,heads", [((6, 6, 6), 12), ((5, 5, 5), 2), ((3, 3, 3), 3), ((4, 8, 8), 1), ((2, 3, 5), 2)])
+def test_global_attention_head_dim_64_on_the_matrix_cores(dims, heads):
+    """the ViT attention of C-UNETR (BASELINE configs[2]): one window = the whole token grid, no bias table, head_dim 64, bf16 -> the MFMA
+    kernels of csrc/attention_global.hip; against softmax((q k^T) scale) v in fp32 on the same bf16-rounded qkv (MONAI SABlock semantics,
+    reference transformer_block.py:59), and bit-reproducible run to run (no atomics)."""
+    ops = _ops()
+    B, C = 2, 64 * heads
+    n = dims[0] * dims[1] * dims[2]
+    qkv = rnd(B, *dims, 3 * C, dtype=torch.bfloat16, seed=91)
+    scale = 64 ** -0.5
+    out, lse = ops.winattn_fwd(qkv, None, None, heads, dims, (0, 0, 0), 1, scale)
+    qr = qkv.float().clone().requires_grad_(True)
+    q, k, v = qr.reshape(B, n, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = (((q @ k.transpose(-2, -1)) * scale).softmax(-1) @ v).transpose(1, 2).reshape(B, *dims, C)
+    assert rel_err(out, ref) < TOL[torch.bfloat16]
+    g = rnd(*out.shape, dtype=torch.bfloat16, seed=92)
+    ref.backward(g.float())
+    dqkv = ops.winattn_bwd(qkv, out, lse, g, None, None, heads, dims, (0, 0, 0), 1, scale, None, None)
+    for i, name in enumerate("qkv"):
+        assert rel_err(dqkv[..., i * C:(i + 1) * C], qr.grad[..., i * C:(i + 1) * C]) < 2 * TOL[torch.bfloat16], f"d{name}"
+    out2, lse2 = ops.winattn_fwd(qkv, None, None, heads, dims, (0, 0, 0), 1, scale)
+    assert torch.equal(out, out2) and torch.equal(lse, lse2)
+    assert torch.equal(dqkv, ops.winattn_bwd(qkv, out, lse, g, None, None, heads, dims, (0, 0, 0), 1, scale, None, None))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,S,C", [(2, 216, 768), (1, 27, 768), (2, 1728, 384), (2, 210, 6), (1, 512, 48), (2, 513, 48)])

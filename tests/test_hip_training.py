@@ -218,7 +218,7 @@ def test_full_size_volume_stitching_properties():
             c[a:a + 96] += 1
         cov.append(c.to(DEV))
     want_count = cov[0][:, None, None] * cov[1][None, :, None] * cov[2][None, None, :]
-    assert torch.equal(count, want_count) and int(count.min()) >= 1 and int(count.max()) == 8
+    assert torch.equal(count, want_count) and int(count.min()) >= 1 and int(count.max()) == 27     # 3 per axis where the clamped last window overlaps two
     zz = torch.arange(512, device=DEV, dtype=torch.float32)[:, None, None] * 3.0 + torch.arange(512, device=DEV, dtype=torch.float32)[None, :, None] * 0.5 \
         - torch.arange(363, device=DEV, dtype=torch.float32)[None, None, :] * 0.25
     assert bool(torch.isfinite(out).all())
