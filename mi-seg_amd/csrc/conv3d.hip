@@ -161,14 +161,25 @@ __global__ void __launch_bounds__(256) conv3_fwd_kernel(const T* __restrict__ x,
 //   112-byte rows).  Weights come from the planar pack [tap][group][CoutP16][16 B], staged per phase of 2 taps with a
 //   linear copy, next phase prefetched into registers during the MFMAs.
 // ---------------------------------------------------------------------------------------------------------
+// K walk of the fast path.  A chunk (6 channel groups x 27 taps) is covered by 14 phases; a phase gives each of the four MFMA k-slots q
+// one (kd, kw, channel group) "combo" and walks the three kh with it (12 weight groups = 3 MFMA k-steps):
+//   phases 0..8  : kdw = kd * 3 + kw = phase, channel group q               (groups 0..3 of all nine (kd, kw))
+//   phases 9..13 : kdw = 2 (phase - 9) + (q >> 1), channel group 4 + (q & 1)   (groups 4, 5; kdw == 9 in the last phase is a zero dummy)
+// so a lane's halo address is (lane constant) + (compile-time displacement of the phase) - the first version decoded
+// combo = 4 phase + q -> (kdw, cg) with per-lane divisions every phase, ~100 VALU cycles of address arithmetic per phase beside 576 of
+// MFMA - and the weight pack is stored in exactly this order, [chunk][phase][kh * 4 + q][CoutP16][16 B], so a phase's 12 groups are one
+// linear run: uniform base + lane constant (the [tap][group] pack cost three 64-bit multiply-add chains per thread and phase).
+__host__ __device__ constexpr int fwd96_phase_of(int kdw, int cg) { return cg < 4 ? kdw : 9 + (kdw >> 1); }
+__host__ __device__ constexpr int fwd96_slot_of(int kdw, int cg) { return cg < 4 ? cg : ((kdw & 1) << 1) + (cg - 4); }
+static constexpr int FWD96_PHASES = 14, FWD96_GROUPS = 12;
+
 static constexpr int FBD = 4, FBH = 4, FBW = 16;
 static constexpr int FHH = FBH + 2, FHW = FBW + 2;
 static constexpr int FHROWS = (FBD + 2) * FHH * FHW;      // 648
 static constexpr int FPS = 656;                            // plane stride in rows (multiple of 16)
 
-// WD = how many phases ahead the weights are requested: 1 for the large grids (the other workgroup of the CU hides the round
-// trip), 3 for the small ones (NT == 1: a 3^3 .. 12^3 layer is a chain of 14 phases per workgroup, each waiting ~1 us for weights
-// that only 12 MFMAs per wave cover)
+// WD = how many phases ahead the weights are requested (3: a phase's 36 MFMAs per wave last ~0.3 us, an L2 round trip under load ~1 us;
+// measured on 48->48 @ 96^3, same box: WD 1 / 2 / 3 = 135 / 128 / 123 us once the loads were branch-free - see wload below)
 // EPI: the optional epilogue pieces (residual add, norm statistics) are compiled in; the plain instantiation carries none of it
 template <class T, int NT, int WD = 1, bool EPI = false>
 __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, const T* __restrict__ wpk,
@@ -193,8 +204,6 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
   const int d0 = bd * FBD, h0 = bh * FBH, w0 = bw * FBW;
   const int n0 = blockIdx.y * NROWS;
   const int fi = lane & 15, fq = lane >> 4;
-  const int NCG = CinP / KPC;
-
   f32x4 acc[4][NT];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -207,43 +216,43 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
   // plane: 6 LDS reads serve the 12 (mt, kh) pairs (the tap-major walk needed 12) -- the kernel is LDS-bandwidth bound
   // (21 ds_read_b128 per 36 MFMAs per wave = 85 % of the LDS peak at the MFMA-bound rate).  Phase 13 holds combos 52, 53 only.
   VT wreg[WD][WLOADS];
-  int wq[WLOADS], wkh[WLOADS], wrow[WLOADS];
+  // element offset of this thread's items inside a phase of the pack.  The LOADS are unconditional straight-line code (surplus lanes
+  // re-read item 0, rows beyond CoutP16 are clamped to a valid row - their output columns are never stored) and the LDS stores are
+  // guarded by a wave-uniform condition (WITEMS is a multiple of 64): behind any branch around a load the compiler can no longer count
+  // the loads in flight and waits with vmcnt(0) - draining the prefetch of the LATER phases too, which is why requesting weights two or
+  // three phases ahead never paid while the guards were per-lane.
+  int wl[WLOADS];
+  bool wok[WLOADS];
 #pragma unroll
   for (int i = 0; i < WLOADS; ++i) {
     const int idx = tid + 256 * i;
-    const int gk = idx / NROWS, row = idx - gk * NROWS;
-    wkh[i] = gk >> 2;
-    wq[i] = gk & 3;
-    wrow[i] = (idx < WITEMS && n0 + row < CoP) ? n0 + row : -1;
+    wok[i] = (wave * 64 + 256 * i) < WITEMS;
+    const int cidx = idx < WITEMS ? idx : 0;
+    const int gk = cidx / NROWS, row = cidx - gk * NROWS;
+    wl[i] = (gk * CoP + min(n0 + row, CoP - 1)) * KPC;
   }
-  auto wload = [&](int phase, int cg0, int slot) {
+  const int64_t wphase_stride = (int64_t)FWD96_GROUPS * CoP * KPC;
+  auto wload = [&](int phase, int chunk, int slot) {
+    const T* wph = wpk + ((int64_t)chunk * FWD96_PHASES + phase) * wphase_stride;      // uniform
 #pragma unroll
-    for (int i = 0; i < WLOADS; ++i) {
-      VT v;
-#pragma unroll
-      for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(0.f);
-      const int combo = 4 * phase + wq[i];
-      if (wrow[i] >= 0 && combo < 54) {
-        const int kdw = combo / 6, cg = combo - kdw * 6;
-        const int kd = kdw / 3, kw = kdw - kd * 3;
-        const int tap = kd * 9 + wkh[i] * 3 + kw;
-        v = *reinterpret_cast<const VT*>(wpk + (((int64_t)tap * NCG + cg0 + cg) * CoP + wrow[i]) * KPC);
-      }
-      wreg[slot][i] = v;
-    }
+    for (int i = 0; i < WLOADS; ++i) wreg[slot][i] = *reinterpret_cast<const VT*>(wph + wl[i]);     // unconditional (surplus lanes re-read item 0)
   };
   auto wstore = [&](int buf, int slot) {
 #pragma unroll
     for (int i = 0; i < WLOADS; ++i)
-      if (tid + 256 * i < WITEMS) *reinterpret_cast<VT*>(lw + (buf * WITEMS + tid + 256 * i) * 16) = wreg[slot][i];
+      if (wok[i]) *reinterpret_cast<VT*>(lw + (buf * WITEMS + tid + 256 * i) * 16) = wreg[slot][i];
   };
+  // halo addresses of this lane: plane = channel group of its k-slot (see the phase table above), row of (d = wave, h = 0, w = fi)
+  const int laneA = (fq * FPS + (wave * FHH) * FHW + fi) * 16;
+  const int laneB = ((4 + (fq & 1)) * FPS + (wave * FHH) * FHW + fi) * 16;
+  const bool hiB = (fq >> 1) != 0;
   const int wfrag = fi * 16;
 
   int* rowoff = reinterpret_cast<int*>(lw + WITEMS * 16);   // aliases weight buffer 1 (rewritten by phase 1 => rebuilt per chunk)
   const int cbeg = blockIdx.z * chunks_per_split * CHUNK, cend = min(CinP, cbeg + chunks_per_split * CHUNK);
   for (int c0 = cbeg; c0 < cend; c0 += CHUNK) {
 #pragma unroll
-    for (int q = 0; q < WD; ++q) wload(q, c0 / KPC, q);
+    for (int q = 0; q < WD; ++q) wload(q, c0 / CHUNK, q);
     // halo row -> voxel index (or -1 outside the volume = zero padding)
     for (int row = tid; row < FHROWS; row += 256) {
       const int hd = row / (FHH * FHW), rem = row - hd * (FHH * FHW);
@@ -306,14 +315,16 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
     }
     wstore(0, 0);
     __syncthreads();
-    auto run_phase = [&](int phase, int slot_load, int slot_store) {
-      if (phase + WD < 14) wload(phase + WD, c0 / KPC, slot_load);
-      // this lane's combo -> plane and (kd, kw) displacement of its halo rows
-      int combo = 4 * phase + fq;
-      if (combo > 53) combo = 53;                      // the weights of the two missing groups of phase 13 are zero
-      const int kdw = combo / 6, cg = combo - kdw * 6;
-      const int kd = kdw / 3, kw = kdw - kd * 3;
-      const char* abase = lh + (cg * FPS + ((wave + kd) * FHH) * FHW + fi + kw) * 16;
+    auto run_phase = [&](int phase, int slot_load, int slot_store) {      // `phase` is a compile-time constant after unrolling
+      if (phase + WD < FWD96_PHASES) wload(phase + WD, c0 / CHUNK, slot_load);
+      const char* abase;
+      if (phase < 9) {
+        abase = lh + laneA + (((phase / 3) * FHH) * FHW + phase % 3) * 16;
+      } else {
+        const int k0 = 2 * (phase - 9), k1 = k0 + 1 > 8 ? 8 : k0 + 1;       // (kdw == 9: the dummy slots read a valid row against zero weights)
+        const int d0 = (((k0 / 3) * FHH) * FHW + k0 % 3) * 16, d1 = (((k1 / 3) * FHH) * FHW + k1 % 3) * 16;
+        abase = lh + laneB + (hiB ? d1 : d0);
+      }
       const char* wb = lw + ((phase & 1) * WITEMS + fq * NROWS) * 16 + wfrag;
       VT af[6], bfr[2][NT];
 #pragma unroll
@@ -331,18 +342,13 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) MmaC<T>::run(acc[mt][nt], bfr[kh & 1][nt], af[mt + kh]);
       }
-      if (phase + 1 < 14) {
+      if (phase + 1 < FWD96_PHASES) {
         wstore((phase + 1) & 1, slot_store);     // buffer last read in phase - 1: every wave is past that phase's barrier
         __syncthreads();
       }
     };
-    if constexpr (WD == 1) {
-#pragma unroll 1
-      for (int phase = 0; phase < 14; ++phase) run_phase(phase, 0, 0);
-    } else {
 #pragma unroll
-      for (int phase = 0; phase < 14; ++phase) run_phase(phase, phase % WD, (phase + 1) % WD);   // ring slots are compile-time
-    }
+    for (int phase = 0; phase < FWD96_PHASES; ++phase) run_phase(phase, phase % WD, (phase + 1) % WD);   // phase, ring slots: compile-time
     __syncthreads();                 // halo + weight buffers are free for the next chunk
   }
   // epilogue: lane holds channels n0 + 16nt + 4fq .. +3 of voxel (d0 + wave, h0 + mt, w0 + fi)
@@ -461,6 +467,30 @@ __global__ void __launch_bounds__(256) conv3_scratch_to_out_kernel(const float* 
 static constexpr int PK_T = 16;
 static constexpr int PK_LD = PK_T * 27 + 1;      // floats per co row of the LDS tile
 
+// element offset of the 16-byte group (tap, K-side channel group kg, N-side row) in the phase-ordered pack of the fast path
+// [chunk = kg / 6][phase][kh * 4 + slot][N16][KPC]
+__device__ __forceinline__ int64_t fwd96_pack_offset(int tap, int kg, int row, int N16, int KPC) {
+  const int chunk = kg / 6, cg = kg - chunk * 6;
+  const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3, kdw = kd * 3 + kw;
+  const int phase = fwd96_phase_of(kdw, cg), slot = fwd96_slot_of(kdw, cg);
+  return ((((int64_t)chunk * FWD96_PHASES + phase) * FWD96_GROUPS + kh * 4 + slot) * N16 + row) * KPC;
+}
+
+// the two k-slots of phase 13 that no (tap, group) maps to must read as zero: written by the tile that opens a chunk, for its 16 rows
+template <class T>
+__device__ __forceinline__ void fwd96_pack_dummies(T* pack, int chunk, int row0, int N16) {
+  typedef typename Vec16<T>::type VT;
+  constexpr int KPC = Vec16<T>::N;
+  VT z;
+#pragma unroll
+  for (int e = 0; e < KPC; ++e) z[e] = from_f32<T>(0.f);
+  for (int i = threadIdx.x; i < 3 * 2 * PK_T; i += 256) {
+    const int r = i % PK_T, sl = 2 + (i / PK_T) % 2, kh = i / (2 * PK_T);
+    if (row0 + r < N16)
+      *reinterpret_cast<VT*>(pack + ((((int64_t)chunk * FWD96_PHASES + 13) * FWD96_GROUPS + kh * 4 + sl) * N16 + row0 + r) * KPC) = z;
+  }
+}
+
 template <class T>
 __device__ __forceinline__ void pack_conv3_tile(const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ bwd, int Cin, int Cout, int CinP, int CoutP,
                                                 int Cin16, int Cout16, bool fwd_planar, bool bwd_planar, int bx, int by) {
@@ -484,9 +514,11 @@ __device__ __forceinline__ void pack_conv3_tile(const float* __restrict__ w, T* 
       VT v;
 #pragma unroll
       for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(tile[co * PK_LD + (cg * KPC + e) * 27 + tap]);
-      const int64_t off = fwd_planar ? (((int64_t)tap * (CinP / KPC) + cib / KPC) * Cout16 + co0 + co) * KPC : ((int64_t)(co0 + co) * 27 + tap) * CinP + cib;
+      const int64_t off = fwd_planar ? fwd96_pack_offset(tap, cib / KPC, co0 + co, Cout16, KPC) : ((int64_t)(co0 + co) * 27 + tap) * CinP + cib;
       *reinterpret_cast<VT*>(fwd + off) = v;
     }
+    if (fwd_planar)      // every chunk that starts inside this tile's K range
+      for (int ch = (ci0 + 6 * KPC - 1) / (6 * KPC); ch * 6 * KPC < ci0 + PK_T && ch * 6 * KPC < CinP; ++ch) fwd96_pack_dummies<T>(fwd, ch, co0, Cout16);
   }
   if (bwd) {   // K side = co, taps mirrored: vector = KPC consecutive co of (ci, tap)
     for (int i = threadIdx.x; i < PK_T * 27 * NG; i += 256) {
@@ -498,9 +530,11 @@ __device__ __forceinline__ void pack_conv3_tile(const float* __restrict__ w, T* 
       VT v;
 #pragma unroll
       for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(tile[(cg * KPC + e) * PK_LD + ci * 27 + (26 - tap)]);
-      const int64_t off = bwd_planar ? (((int64_t)tap * (CoutP / KPC) + cob / KPC) * Cin16 + ci0 + ci) * KPC : ((int64_t)(ci0 + ci) * 27 + tap) * CoutP + cob;
+      const int64_t off = bwd_planar ? fwd96_pack_offset(tap, cob / KPC, ci0 + ci, Cin16, KPC) : ((int64_t)(ci0 + ci) * 27 + tap) * CoutP + cob;
       *reinterpret_cast<VT*>(bwd + off) = v;
     }
+    if (bwd_planar)
+      for (int ch = (co0 + 6 * KPC - 1) / (6 * KPC); ch * 6 * KPC < co0 + PK_T && ch * 6 * KPC < CoutP; ++ch) fwd96_pack_dummies<T>(bwd, ch, ci0, Cin16);
   }
 }
 
@@ -1169,7 +1203,7 @@ static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
   case n:                                                                                                                                   \
     if (!scratch && (p->res || p->stat)) { F96_LAUNCH(n, wd, true); } else { F96_LAUNCH(n, wd, false); }                                    \
     break;
-    switch (nt) { F96_CASE(1, 3) F96_CASE(2, 1) F96_CASE(3, 1) }
+    switch (nt) { F96_CASE(1, 3) F96_CASE(2, 2) F96_CASE(3, 3) }
 #undef F96_CASE
 #undef F96_LAUNCH
     if (scratch) {
@@ -1214,8 +1248,8 @@ extern "C" int miseg_conv3_fwd(const miseg_conv3_params* p, miseg_stream_t s_) {
 extern "C" size_t miseg_pack_conv3_elems(int Cin, int Cout, int dtype, int which) {
   const int kpc = dtype == MISEG_F32 ? 4 : 8;
   const int CinP = round_up(Cin, kpc), CoutP = round_up(Cout, kpc);
-  // large enough for either layout
-  return which == 0 ? (size_t)27 * CinP * round_up(Cout, 16) : (size_t)27 * CoutP * round_up(Cin, 16);
+  // large enough for either layout (the phase-ordered pack of the fast path holds 14 x 12 = 168 group slots per chunk for 27 x 6 = 162 groups)
+  return which == 0 ? (size_t)28 * CinP * round_up(Cout, 16) : (size_t)28 * CoutP * round_up(Cin, 16);
 }
 
 extern "C" int miseg_pack_conv3_weight(const miseg_pack_conv3_params* p, miseg_stream_t s_) {

@@ -18,8 +18,11 @@ def run(S, Cin, Cout, dtype, iters=10, what=("fwd", "wgrad")):
         with torch.cuda.graph(g):
             for _ in range(iters): fn()
         g.replay(); torch.cuda.synchronize()
-        t0 = time.perf_counter(); g.replay(); torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / iters
+        ts = []
+        for _ in range(7):      # median of 7 replays: single replays scatter by +-5 %
+            t0 = time.perf_counter(); g.replay(); torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / iters)
+        return sorted(ts)[3]
     msg = f"{S}^3 {Cin}->{Cout} {str(dtype)[6:]}:"
     if "fwd" in what:
         d = t(lambda: ops.conv3_fwd(x, fwdp, Cout)); msg += f" fwd {d*1e6:7.1f} us {fl/d/1e12:6.1f} TF"
