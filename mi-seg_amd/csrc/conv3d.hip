@@ -196,11 +196,21 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
   char* lh = lds;                                          // [6][FPS][16]
   char* lw = lds + GPT * FPS * 16;                         // 2 x [12][NROWS][16] (double buffer)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int bid = blockIdx.x;
-  const int bw = bid % g.nbw; bid /= g.nbw;
+  // workgroup -> brick.  The hardware deals consecutive workgroups to the 8 XCDs round-robin, each with its own L2: with bid = blockIdx.x
+  // the spatial neighbours of a brick, which share a third of its halo, run on seven OTHER XCDs and every halo plane is fetched from HBM
+  // by each of them (measured 2.2 x the algorithmic bytes).  XCD k takes the k-th contiguous eighth of the bricks instead.
+  int bid;
+  {
+    const int nb = gridDim.x, xcd = blockIdx.x & 7, q = nb >> 3, r = nb & 7;
+    bid = xcd * q + (xcd < r ? xcd : r) + (blockIdx.x >> 3);
+  }
+  // inside an XCD's range the bricks advance d-fastest, then h, then w: a brick shares 2 of its 6 halo planes with its d- and with its
+  // h-neighbour and only 2 of 18 columns with its w-neighbour, and the L2 (4 MB) has to hold the bricks between two neighbours for the
+  // overlap to hit: one brick for d, one column of nbd bricks (1.5 MB at 96^3) for h; w-fastest needed nbh * nbw bricks (9 MB) for d
+  const int bd = bid % g.nbd; bid /= g.nbd;
   const int bh = bid % g.nbh; bid /= g.nbh;
-  const int bd = bid % g.nbd;
-  const int b = bid / g.nbd;
+  const int bw = bid % g.nbw;
+  const int b = bid / g.nbw;
   const int d0 = bd * FBD, h0 = bh * FBH, w0 = bw * FBW;
   const int n0 = blockIdx.y * NROWS;
   const int fi = lane & 15, fq = lane >> 4;
