@@ -836,7 +836,7 @@ extern "C" int miseg_winattn_fwd(const miseg_winattn_params* p, miseg_stream_t s
     const bool vec = p->ldq % 8 == 0 && (uintptr_t)p->qkv % 16 == 0;
     const bool wide = (int64_t)grid.x * grid.y < 256;       // fewer workgroups than CUs: one query tile per wave
 #define FWD_MFMA(M, NWV)                                                                                                                       \
-  hipFuncSetAttribute((const void*)winattn_fwd_mfma_kernel<M, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                    \
+  MISEG_SET_SMEM((winattn_fwd_mfma_kernel<M, NWV>), shm);                    \
   winattn_fwd_mfma_kernel<M, NWV><<<grid, NWV * 64, shm, s>>>((const bf16*)p->qkv, p->ldq, (bf16*)p->out, p->ldo, p->qkv_bias, p->bias_table, \
                                                               p->lse, g, tsize, vec)
     if ((g.sd | g.sh | g.sw) != 0) { if (wide) { FWD_MFMA(true, 11); } else { FWD_MFMA(true, 8); } }
@@ -848,7 +848,7 @@ extern "C" int miseg_winattn_fwd(const miseg_winattn_params* p, miseg_stream_t s
   return dispatch_dtype(p->dtype, [&](auto* tag) -> int {
     typedef typename std::remove_pointer<decltype(tag)>::type T;
     HD_SWITCH(g.hd / 4, {
-      hipFuncSetAttribute((const void*)winattn_fwd_kernel<T, HD4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      MISEG_SET_SMEM((winattn_fwd_kernel<T, HD4>), sh);
       winattn_fwd_kernel<T, HD4><<<grid, threads, sh, s>>>((const T*)p->qkv, p->ldq, (T*)p->out, p->ldo, p->qkv_bias, p->bias_table, p->lse, g, tsize);
     });
     MISEG_LAUNCH_CHECK("winattn_fwd");
@@ -876,7 +876,7 @@ extern "C" int miseg_winattn_bwd(const miseg_winattn_bwd_params* p, miseg_stream
     const bool wide = true;       // 8 waves everywhere: two such workgroups still fit a CU (2 x 81 KB LDS, 118 VGPRs) and every stage gains
     const size_t shm = attn_mfma_bwd_smem(tsize, wide ? 8 : 4);
 #define BWD_MFMA(M, D, NWV)                                                                                                                                 \
-  hipFuncSetAttribute((const void*)winattn_bwd_mfma_kernel<M, D, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                              \
+  MISEG_SET_SMEM((winattn_bwd_mfma_kernel<M, D, NWV>), shm);                              \
   winattn_bwd_mfma_kernel<M, D, NWV><<<grid, NWV * 64, shm, s>>>((const bf16*)p->f.qkv, p->f.ldq, (const bf16*)p->f.out, p->f.ldo, (const bf16*)p->dout,    \
                                                                  p->lddo, (bf16*)p->dqkv, p->lddq, p->f.qkv_bias, p->f.bias_table, p->f.lse, p->dqkv_bias, \
                                                                  p->dbias_table, g, tsize, vec)
@@ -892,7 +892,7 @@ extern "C" int miseg_winattn_bwd(const miseg_winattn_bwd_params* p, miseg_stream
   return dispatch_dtype(p->f.dtype, [&](auto* tag) -> int {
     typedef typename std::remove_pointer<decltype(tag)>::type T;
     HD_SWITCH(g.hd / 4, {
-      hipFuncSetAttribute((const void*)winattn_bwd_kernel<T, HD4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      MISEG_SET_SMEM((winattn_bwd_kernel<T, HD4>), sh);
       winattn_bwd_kernel<T, HD4><<<grid, threads, sh, s>>>((const T*)p->f.qkv, p->f.ldq, (const T*)p->f.out, p->f.ldo, (const T*)p->dout, p->lddo, (T*)p->dqkv, p->lddq,
                                                            p->f.qkv_bias, p->f.bias_table, p->f.lse, p->dqkv_bias, p->dbias_table ? p->dbias_table : nullptr, g,
                                                            tsize);

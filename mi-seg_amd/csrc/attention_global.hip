@@ -329,7 +329,7 @@ int global_attn_fwd(const miseg_winattn_params* p, hipStream_t s, int* rc) {
   if (!ga_geom(p, &g)) return 0;
   const size_t sh = (size_t)(g.NP * GA_RS + GA_HD * (g.NP + 8)) * 2;
   const dim3 grid(cdiv(g.n, 64), g.heads, g.B);
-#define GA_FWD(NT) do { hipFuncSetAttribute((const void*)gattn_fwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+#define GA_FWD(NT) do { MISEG_SET_SMEM((gattn_fwd_kernel<NT>), sh); \
     gattn_fwd_kernel<NT><<<grid, 256, sh, s>>>((const bf16*)p->qkv, (bf16*)p->out, p->lse, g); } while (0)
   switch (g.NP / 16) {
     case 2: GA_FWD(2); break; case 4: GA_FWD(4); break; case 6: GA_FWD(6); break; case 8: GA_FWD(8); break;
@@ -352,7 +352,7 @@ int global_attn_bwd(const miseg_winattn_bwd_params* p, hipStream_t s, int* rc) {
   const size_t sh_k = (size_t)(2 * g.NP * GA_RS + 2 * GA_HD * (g.NP + 8)) * 2 + (size_t)2 * g.NP * 4;
   const size_t sh = sh_q > sh_k ? sh_q : sh_k;
   const dim3 grid(2 * nqt, g.heads, g.B);
-#define GA_BWD(NT) do { hipFuncSetAttribute((const void*)gattn_bwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+#define GA_BWD(NT) do { MISEG_SET_SMEM((gattn_bwd_kernel<NT>), sh); \
     gattn_bwd_kernel<NT><<<grid, 256, sh, s>>>((const bf16*)p->f.qkv, (const bf16*)p->f.out, (const bf16*)p->dout, p->f.lse, (bf16*)p->dqkv, g, nqt); } while (0)
   switch (g.NP / 16) {
     case 2: GA_BWD(2); break; case 4: GA_BWD(4); break; case 6: GA_BWD(6); break; case 8: GA_BWD(8); break;

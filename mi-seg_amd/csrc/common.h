@@ -90,6 +90,17 @@ static inline hipError_t fill_words_2d_async(void* dst, size_t pitch, uint32_t v
   return hipGetLastError();
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, size) instead of on every launch: the attribute is sticky, the call is a
+// driver round trip on the launch path.  Keyed by the function pointer; raising the size re-applies it.
+#define MISEG_SET_SMEM(fn, bytes)                                                                                  \
+  do {                                                                                                             \
+    static int miseg_smem_set_ = -1;                                                                               \
+    if ((int)(bytes) > miseg_smem_set_) {                                                                          \
+      (void)hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes));      \
+      miseg_smem_set_ = (int)(bytes);                                                                              \
+    }                                                                                                              \
+  } while (0)
+
 template <class F> static inline int dispatch_dtype(int dtype, F&& f) {
   if (dtype == MISEG_F32) return f((float*)nullptr);
   if (dtype == MISEG_BF16) return f((bf16*)nullptr);

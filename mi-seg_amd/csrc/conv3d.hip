@@ -729,11 +729,7 @@ __device__ __forceinline__ void conv3_wgrad_body(const T* __restrict__ x, int64_
     vmask = 0;
   };
   auto pitem = [&](int j) {
-#if defined(MISEG_WG_EXP) && MISEG_WG_EXP == 3
-    const bool ok = ((iface[j >> 2] >> ((j & 3) * 8)) & bfaces) == 0x55;      // timing experiment: every item reads the same bytes
-#else
     const bool ok = ((iface[j >> 2] >> ((j & 3) * 8)) & bfaces) == 0;
-#endif
     if (j < NXI) rx[j] = *reinterpret_cast<const VT*>(xorg + (ok ? ioff[j] : ctr));
     else rd[j - NXI] = *reinterpret_cast<const VT*>(dorg + (ok ? ioff[j] : 0u));
     vmask |= (ok ? 1u : 0u) << j;
@@ -898,15 +894,11 @@ __device__ __forceinline__ void conv3_wgrad_body(const T* __restrict__ x, int64_
               // the accumulators are pinned to AGPRs ("a"): left to the allocator, tiles shuttled between the two register
               // files (600 v_accvgpr moves per brick) and the staged items spilled
               asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[t][mt][nt]) : "v"(bfr[slot % 3][nt]), "v"(afr[ks & 1][mt]));
-#if !defined(MISEG_WG_EXP) || MISEG_WG_EXP != 2
               if (nx < NSLOT) {
                 if (i < 3) frag_b(nx, i);
                 else if (i < 6 && nx % WG_TPW == 0) frag_a(nx / WG_TPW, i - 3);
               }
-#endif
-#if !defined(MISEG_WG_EXP) || MISEG_WG_EXP != 1
               if (i == 6 && slot < NXI + NDI) pitem(slot);          // one per slot from the start: the last item gets 35 slots (~3.7 us) of lead
-#endif
               __builtin_amdgcn_sched_barrier(0);
             }
           }

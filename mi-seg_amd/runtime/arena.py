@@ -52,6 +52,23 @@ class ParamArena:
         self._bm = None         # (stream, pinned source, pinned result, event) of the bitmap exchange on a card
         self._offs, self._size = offs, off
 
+    # ---------------------------------------------------------------------------------------------- gradient accumulation
+    def no_sync(self):
+        """context manager for the micro-batches of a gradient-accumulation window that do NOT end in an optimiser step (reference
+        utils/trainer.py:55-68 wraps them in DDP's `model.no_sync()`): inside it `allreduce()` only publishes the local sums, and the next
+        `begin_step()` keeps the arena (`zero=False` is implied) - the collective runs once, on the last micro-batch, over the accumulated sums."""
+        arena = self
+
+        class _NoSync:
+            def __enter__(self_):
+                arena._sync = False
+                return arena
+
+            def __exit__(self_, *exc):
+                arena._sync = True
+                return False
+        return _NoSync()
+
     # ---------------------------------------------------------------------------------------------- per step
     def begin_step(self, zero=True):
         """once per optimisation step, before the forward: recycles the statistics pool, zeroes the gradient arena and
@@ -64,6 +81,8 @@ class ParamArena:
         ops.WGRAD_STREAM = self.wgrad_stream      # None unless overlap_wgrad: measured SLOWER on one MI355X (93.3 -> 90 patches/s: the
                                                   # cross-stream edges of the hipGraph cost more than the idle CUs they fill)
         self.epoch += 1
+        if getattr(self, "_accumulating", False):     # the previous micro-batch ran under no_sync(): keep summing into the arena
+            zero = False
         if zero:
             ops.fill32(self.flat)
             for p in self.params:
@@ -175,6 +194,7 @@ class ParamArena:
 
     def publish(self):
         self.end_backward()
+        self._accumulating = not getattr(self, "_sync", True)
         for p, v in zip(self.params, self.views):
             p.grad = v if p._miseg_used else None
 
@@ -182,6 +202,9 @@ class ParamArena:
         """mean all-reduce of the arena over RCCL in n_buckets pieces; parameters unused on EVERY rank keep grad None."""
         import torch.distributed as dist
         self.end_backward()
+        if not getattr(self, "_sync", True):          # inside no_sync(): local accumulation only
+            self.publish()
+            return
         ub = self.used_begin(group)
         works = []
         avg = self._avg(group)

@@ -84,6 +84,23 @@ def _worker(rank, world, port, q):
         ok &= torch.allclose(shared.grad, torch.full((5, 3), 1.5 + it))
         ok &= torch.allclose(s0.grad, torch.full((4,), 1.0)) and torch.allclose(s1.grad, torch.full((4,), 3.0))
         ok &= unused.grad is None
+    # gradient accumulation (reference utils/trainer.py:55-68: DDP no_sync() on the micro-batches that do not step): two local micro-batches,
+    # ONE collective over their sum; the window after it starts from zero again
+    import mi_seg_amd.hip.ops as _ops
+    _ops.fill32 = lambda t, word=0: t.zero_()                  # CPU stand-ins for the two device fills begin_step issues
+    _ops.begin_step = lambda: None
+    for window in range(2):
+        with arena.no_sync():
+            arena.begin_step()
+            shared._miseg_grad.add_(float(rank + 1))
+            shared._miseg_used = True
+            before = shared._miseg_grad.clone()
+            arena.allreduce(world)
+            ok &= torch.equal(shared.grad, before)            # no exchange happened
+        arena.begin_step()                                     # keeps the arena: still accumulating
+        shared._miseg_grad.add_(10.0 * (rank + 1))
+        arena.allreduce(world)
+        ok &= torch.allclose(shared.grad, torch.full((5, 3), 1.5 + 15.0))
     arena.detach()
     # rank sharding: disjoint cover of the concatenated CT+MR index range
     mine = rank_indices(32, world, rank, epoch=1, seed=0)

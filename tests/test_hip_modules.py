@@ -11,6 +11,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 TOL = 1e-3          # north_star: within 1e-3 relative fp32
 TOL_BF16 = 4e-2
+ZERO_GRAD = ("encoder1.layer.conv3.conv.weight",)      # d/dw == 0 analytically (a per-channel scale in front of an instance norm): both sides hold rounding noise
 
 
 def _fill(m):
@@ -280,7 +281,9 @@ def test_forward_and_data_gradients_are_bitwise_reproducible():
         y.backward(cot)
         runs.append((y.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
     assert torch.equal(runs[0][0], runs[1][0]), "logits differ between two identical runs"
-    compare_grads(runs[1][1], {k: v.float().cpu() for k, v in runs[0][1].items()}, 1e-5)      # (analytically zero gradients hold rounding noise: judged absolutely)
+    # (analytically zero gradients hold rounding noise: judged absolutely; the stem's 1x1x1 shortcut weight - one input channel in front of
+    # an instance norm, d/dw == 0 - is noise of ordinary magnitude and is left out)
+    compare_grads(runs[1][1], {k: v.float().cpu() for k, v in runs[0][1].items()}, 1e-5, skip=ZERO_GRAD)
 
 
 @pytest.mark.parametrize("tag,dtype", [("c1_64", torch.float32), ("cond_32", torch.float32), ("c1_64", torch.bfloat16)])
@@ -368,7 +371,7 @@ def test_param_arena_matches_plain_autograd(dtype):
             assert [k for k, g in zip(names, gr) if g is None] == [k for k, p in zip(names, params) if p.grad is None]
             want = {k: g.float().cpu() for k, g in zip(names, gr) if g is not None}
             got = {k: p.grad for k, p in zip(names, params) if p.grad is not None}
-            compare_grads(got, want, 1e-3)      # same kernels, same forward bits: only the order of the weight-gradient reductions differs
+            compare_grads(got, want, 1e-3, skip=ZERO_GRAD)      # same kernels, same forward bits: only the order of the weight-gradient reductions differs
         assert arena._table is not None and arena._table[1] > 0
     finally:
         arena.detach()
@@ -428,7 +431,7 @@ def test_graphed_step_replays_match_eager(use_arena):
             got = {k: p.grad for k, p in zip(names, params) if p.grad is not None}
             assert set(got) == set(g_ref), f"replay {it}: set of parameters with a gradient differs"
             assert all(bool(torch.isfinite(g).all()) for g in got.values()), f"replay {it}: non-finite gradient"
-            compare_grads(got, g_ref, 1e-3)
+            compare_grads(got, g_ref, 1e-3, skip=ZERO_GRAD)
     finally:
         if arena is not None:
             arena.detach()

@@ -238,6 +238,8 @@ def oracle_trained():
     from oracle import functional as OF
     from oracle import nets as ON
     m = _small_model(96)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 16))       # torch's CPU kernels lose time beyond ~16 threads on this net (13.8 s vs 6 s per C2 patch at 128)
     sd = {k: (OF.relative_position_index() if k.endswith("relative_position_index") else torch.from_numpy(det_values(k, v.shape)).requires_grad_(True))
           for k, v in m.state_dict().items()}
     cfg = ON.swin_unetr_cfg(feature_size=12)
@@ -258,6 +260,7 @@ def oracle_trained():
     with torch.no_grad():
         logits = sliding_window_inference(img, 96, 1, lambda xx, mm: ON.swin_unetr_forward(sd, xx, mm, cfg), overlap=0.5, modalities=[0])
     dice = dice_from_logits(logits, lab, 6)
+    torch.set_num_threads(threads)
     return {"sd": {k: v.detach() for k, v in sd.items()}, "img": img, "lab": lab, "logits": logits, "dice": dice, "crops": crops, "losses": losses}
 
 
