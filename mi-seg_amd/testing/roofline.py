@@ -60,6 +60,6 @@ def summarize(prof, dtype):
     return {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "hbm_achieved_GBs": alg_bytes / avg_s / 1e9, "hbm_peak_GBs": PEAK_HBM_GBS, "hbm_frac": alg_bytes / avg_s / 1e9 / PEAK_HBM_GBS,
             "hbm_frac_counter": (traffic / avg_s / 1e9 / PEAK_HBM_GBS) if traffic else None,
-            "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": src,
+            "traffic": traffic, "traffic_unit": "bytes per launch on the L2's memory side (PMC FETCH_SIZE x 2 + WRITE_SIZE; Infinity-Cache hits are counted)", "traffic_source": src,
             "algorithmic_bytes_per_launch": sum(t[2] for t in lst) / len(lst), "launches_per_step": len(lst), "avg_launch_ms": tot_ms / len(lst),
             "flops_per_step": flops, "all_kernels_ms": {k: sum(t[0] for t in v) for k, v in prof.items()}}

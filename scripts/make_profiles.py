@@ -57,4 +57,13 @@ json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate pa
                      "dispatches of each kernel averaged; FETCH_SIZE (KB) doubled per the gfx950 correction of MI355X_MICROARCH.md (HBM "
                      "section), WRITE_SIZE (KB) as reported", "kernels": kernels},
           open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+for name, log in (("bench_line", "bench_official.log"), ("bench_f32_line", "bench_f32.log"), ("bench_c3_line", "bench_c3.log"), ("bench_c5_line", "bench_c5.log")):
+    path = os.path.join(root, "gpurun_out", log)
+    if os.path.exists(path):
+        lines = [l for l in open(path) if l.startswith("{")]
+        if lines:
+            open(os.path.join(out, f"{tag}_{name}.json"), "w").write(lines[-1])
+c3 = glob.glob(os.path.join(root, "gpurun_out", "prof_c3/**/*kernel_stats.csv"), recursive=True)
+if c3:
+    shutil.copy(max(c3, key=os.path.getmtime), os.path.join(out, f"{tag}_bench_c3_bf16_kernel_stats.csv"))
 print("wrote", tag, "kernels:", len(kernels))
