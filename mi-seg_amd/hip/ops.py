@@ -342,8 +342,9 @@ def gemm_tn(a, b, out=None, accumulate=False, split_k=0):
         out = torch.empty(M, N, dtype=torch.float32, device=a.device)
         accumulate = False
     assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == M * N
-    if GEMM_TN_QUEUE is not None and accumulate and split_k <= 0 and not (M % 48 == 0 and N % 48 == 0 and K >= 2048 and a.dtype == torch.bfloat16):
-        GEMM_TN_QUEUE.append((a, b, out))      # small problem: grouped launch at the end of the backward pass
+    q = _queues(out) if accumulate else None
+    if q is not None and split_k <= 0 and not (M % 48 == 0 and N % 48 == 0 and K >= 2048 and a.dtype == torch.bfloat16):
+        q.gemm_tn.append((a, b, out))      # small problem: grouped launch at the end of the backward pass
         return out
     split_k = max(0, split_k)          # 0: the library picks the kernel and the split over the reduction rows
     p = L.Gemm(_ptr(a), lda, _ptr(b), ldb, _ptr(out), N, M, N, K, 1, 1, _dt(a), L.F32, None, L.ACT_NONE, int(accumulate), split_k, None, None, 0, None, 0, 0, 0)
@@ -352,9 +353,9 @@ def gemm_tn(a, b, out=None, accumulate=False, split_k=0):
     if wsb:
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=a.device)
         p.workspace = ws.data_ptr()
-        if TN_REDUCE_QUEUE is not None and accumulate:      # the per-split partial tiles are summed by one batched launch later
+        if q is not None:      # the per-split partial tiles are summed by one batched launch later
             p.defer_reduce = 1
-            TN_REDUCE_QUEUE.append((ws, out, N, M, N, lib.miseg_gemm_tn_splits(C.byref(p))))
+            q.tn_reduce.append((ws, out, N, M, N, lib.miseg_gemm_tn_splits(C.byref(p))))
     _call("miseg_gemm", p)
     return out
 
@@ -404,15 +405,37 @@ def join_wgrad():
     _WGRAD_KEEP.clear()
 
 
-COLSUM_QUEUE = None   # list while a training arena defers the bias-gradient reductions of a backward pass (runtime/arena.py)
+class StepQueues:
+    """launch-bound tails of ONE model's backward pass, queued by the host and issued as grouped launches at the end of it
+    (runtime/arena.py::end_backward): bias-gradient column sums, the small weight-gradient GEMMs, the partial-tile sums of the
+    streaming ones, the conv weight gradients of the 48^3-and-smaller layers.  One instance per training arena, found through the
+    storage of the gradient slot a kernel accumulates into - two models (two arenas) in one process do not share anything."""
+
+    def __init__(self):
+        self.colsum, self.gemm_tn, self.tn_reduce, self.conv_wgrad = [], [], [], []
+
+    def flush(self):
+        _flush_conv_wgrads(self.conv_wgrad)
+        _flush_gemm_tn(self.gemm_tn)
+        _flush_tn_reduces(self.tn_reduce)
+        _flush_colsums(self.colsum)
 
 
-GEMM_TN_QUEUE = None   # likewise for the small weight-gradient GEMMs (one grouped launch per 24)
-TN_REDUCE_QUEUE = None   # and for the partial-tile sums of the streaming weight-gradient GEMMs
+QUEUES = {}             # data_ptr of an arena's flat gradient storage -> its StepQueues while a step of that arena is open
+DEFAULT_QUEUES = None   # tests / micro-benchmarks: queue accumulate-mode launches whose destination belongs to no arena
 
 
-def flush_tn_reduces():
-    q = TN_REDUCE_QUEUE
+def _queues(out):
+    if out is None:
+        return None
+    if QUEUES:
+        q = QUEUES.get(out.untyped_storage().data_ptr())
+        if q is not None:
+            return q
+    return DEFAULT_QUEUES
+
+
+def _flush_tn_reduces(q):
     if not q:
         return
     lib = L.load()
@@ -425,8 +448,7 @@ def flush_tn_reduces():
     q.clear()
 
 
-def flush_gemm_tn():
-    q = GEMM_TN_QUEUE
+def _flush_gemm_tn(q):
     if not q:
         return
     lib = L.load()
@@ -443,9 +465,8 @@ def flush_gemm_tn():
     q.clear()
 
 
-def flush_colsums():
+def _flush_colsums(q):
     """issue the queued accumulate-mode column sums in batches of lib.MISEG_COLSUM_BATCH (one launch each)."""
-    q = COLSUM_QUEUE
     if not q:
         return
     lib = L.load()
@@ -463,8 +484,9 @@ def flush_colsums():
 
 def colsum(x, out=None, accumulate=False):
     ld, n, Cc = rows(x)
-    if COLSUM_QUEUE is not None and out is not None and accumulate:
-        COLSUM_QUEUE.append((x, out))          # keeps x alive until the flush
+    q = _queues(out) if (out is not None and accumulate) else None
+    if q is not None:
+        q.colsum.append((x, out))          # keeps x alive until the flush
         return out
     if out is None:
         out = torch.empty(Cc, dtype=torch.float32, device=x.device)
@@ -560,12 +582,10 @@ def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False):
     return (out, stat) if want_stat else out
 
 
-CONV_WGRAD_QUEUE = None   # list while a training arena defers the small-grid conv weight gradients (one grouped launch at the end)
 CONV_WGRAD_GROUP_VOXELS = 48 ** 3   # layers up to this many voxels are queued: alone they fill a fraction of the chip for 40-85 us each
 
 
-def flush_conv_wgrads():
-    q = CONV_WGRAD_QUEUE
+def _flush_conv_wgrads(q):
     if not q:
         return
     lib = L.load()
@@ -595,8 +615,9 @@ def conv3_wgrad(x, dy, dw=None, accumulate=False):
     if dw is None:
         dw = torch.empty(Cout, Cin, 3, 3, 3, dtype=torch.float32, device=x.device)
         accumulate = False
-    if CONV_WGRAD_QUEUE is not None and accumulate and PROFILE_HOOK is None and B * D * H * W <= CONV_WGRAD_GROUP_VOXELS:
-        CONV_WGRAD_QUEUE.append((x, dy, dw, int(accumulate)))      # keeps x and dy alive until the flush
+    q = _queues(dw) if accumulate else None
+    if q is not None and PROFILE_HOOK is None and B * D * H * W <= CONV_WGRAD_GROUP_VOXELS:
+        q.conv_wgrad.append((x, dy, dw, int(accumulate)))      # keeps x and dy alive until the flush
         return dw
     lib = L.load()
     ws = torch.empty(lib.miseg_conv3_wgrad_workspace_bytes(B, D, H, W, Cin, Cout) // 4, dtype=torch.float32, device=x.device)

@@ -51,6 +51,8 @@ class ParamArena:
         self.used_dev = torch.zeros(len(self.params), dtype=torch.int32, device=dev)
         self._bm = None         # (stream, pinned source, pinned result, event) of the bitmap exchange on a card
         self._offs, self._size = offs, off
+        self._qkey = self.flat.untyped_storage().data_ptr()
+        self.queues = None
 
     # ---------------------------------------------------------------------------------------------- gradient accumulation
     def no_sync(self):
@@ -74,10 +76,9 @@ class ParamArena:
         """once per optimisation step, before the forward: recycles the statistics pool, zeroes the gradient arena and
         refreshes every registered parameter re-layout (safe inside hipGraph capture once the table exists)."""
         ops.begin_step()
-        ops.COLSUM_QUEUE = []           # bias-gradient reductions of this step are queued and issued by end_backward()
-        ops.GEMM_TN_QUEUE = []          # so are the small weight-gradient GEMMs
-        ops.TN_REDUCE_QUEUE = []        # and the partial-tile sums of the streaming ones
-        ops.CONV_WGRAD_QUEUE = []       # and the conv weight gradients of the 48^3-and-smaller layers (one grouped launch)
+        # the launch-bound tails of this step's backward pass (bias-gradient reductions, small weight-gradient GEMMs, partial-tile sums,
+        # the conv weight gradients of the 48^3-and-smaller layers) are queued per arena and issued by end_backward()
+        self.queues = ops.QUEUES[self._qkey] = ops.StepQueues()
         ops.WGRAD_STREAM = self.wgrad_stream      # None unless overlap_wgrad: measured SLOWER on one MI355X (93.3 -> 90 patches/s: the
                                                   # cross-stream edges of the hipGraph cost more than the idle CUs they fill)
         self.epoch += 1
@@ -174,23 +175,17 @@ class ParamArena:
     def end_backward(self):
         """issue the queued bias-gradient column sums (one launch per 32); call after loss.backward(), inside the captured
         region when the step is a hipGraph.  publish() / allreduce() call it too."""
-        ops.flush_conv_wgrads()
-        ops.CONV_WGRAD_QUEUE = None
-        ops.flush_gemm_tn()
-        ops.GEMM_TN_QUEUE = None
-        ops.flush_tn_reduces()
-        ops.TN_REDUCE_QUEUE = None
-        ops.flush_colsums()
-        ops.COLSUM_QUEUE = None
+        if self.queues is not None:
+            self.queues.flush()
+            self.queues = None
+            ops.QUEUES.pop(self._qkey, None)
         ops.join_wgrad()
         ops.WGRAD_STREAM = None
 
     def flush(self):
         """issue everything queued so far and keep queueing (between the two halves of a split backward pass)."""
-        ops.flush_conv_wgrads()
-        ops.flush_gemm_tn()
-        ops.flush_tn_reduces()
-        ops.flush_colsums()
+        if self.queues is not None:
+            self.queues.flush()
 
     def publish(self):
         self.end_backward()
@@ -304,10 +299,8 @@ class ParamArena:
         return dist.get_backend(group) == "nccl"
 
     def detach(self):
-        ops.COLSUM_QUEUE = None
-        ops.CONV_WGRAD_QUEUE = None
-        ops.GEMM_TN_QUEUE = None
-        ops.TN_REDUCE_QUEUE = None
+        self.queues = None
+        ops.QUEUES.pop(self._qkey, None)
         ops.join_wgrad()
         ops.WGRAD_STREAM = None
         for p in self.params:

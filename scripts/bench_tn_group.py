@@ -15,11 +15,11 @@ fam["all"] = fam["K=27"] + fam["K=216"] + fam["K=1728"]
 for name, probs in fam.items():
     items = [(torch.randn(K, M, device="cuda").to(dt), torch.randn(K, N, device="cuda").to(dt), torch.zeros(M, N, device="cuda")) for M, N, K in probs]
     def run():
-        ops.GEMM_TN_QUEUE = []
+        ops.DEFAULT_QUEUES = ops.StepQueues()
         for a, b, o in items:
             ops.gemm_tn(a, b, out=o, accumulate=True)
-        ops.flush_gemm_tn()
-        ops.GEMM_TN_QUEUE = None
+        ops.DEFAULT_QUEUES.flush()
+        ops.DEFAULT_QUEUES = None
     run(); torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):

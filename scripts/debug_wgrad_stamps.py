@@ -31,13 +31,13 @@ for name, ls in sets.items():
     for S, Cin, Cout in ls:
         items.append((torch.randn(1, S, S, S, Cin, device="cuda").to(dt), torch.randn(1, S, S, S, Cout, device="cuda").to(dt), torch.zeros(Cout, Cin, 3, 3, 3, device="cuda")))
     for rep in range(2):
-        ops.CONV_WGRAD_QUEUE = []
+        ops.DEFAULT_QUEUES = ops.StepQueues()
         for x, dy, dw in items:
             ops.conv3_wgrad(x, dy, dw=dw, accumulate=True)
         torch.cuda.synchronize(); lib.miseg_debug_wgrad_stamps(buf)
         t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
-        t0.record(); ops.flush_conv_wgrads(); t1.record(); torch.cuda.synchronize()
-        ops.CONV_WGRAD_QUEUE = None
+        t0.record(); ops.DEFAULT_QUEUES.flush(); t1.record(); torch.cuda.synchronize()
+        ops.DEFAULT_QUEUES = None
     lib.miseg_debug_wgrad_stamps(buf)
     stage, kloop, epi, bricks, gwait, lst, vmw = [buf[i] for i in range(7)]
     tot = stage + kloop + epi

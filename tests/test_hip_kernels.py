@@ -464,33 +464,33 @@ def test_conv3_wgrad_grouped(dtype):
         dy = rnd(B, D, H, W, Cout, dtype=dtype, seed=90 + i)
         base = rnd(Cout, Cin, 3, 3, 3, seed=110 + i)
         cases.append((x, dy, base))
-    ops.CONV_WGRAD_QUEUE = []
+    ops.DEFAULT_QUEUES = ops.StepQueues()
     try:
         outs = []
         for x, dy, base in cases:
             dw = base.clone()
             assert ops.conv3_wgrad(x, dy, dw=dw, accumulate=True) is dw
             outs.append(dw)
-        assert len(ops.CONV_WGRAD_QUEUE) == len(cases)
+        assert len(ops.DEFAULT_QUEUES.conv_wgrad) == len(cases)
         assert all(torch.equal(o, c[2]) for o, c in zip(outs, cases)), "queued launches must not have run yet"
-        ops.flush_conv_wgrads()
-        assert not ops.CONV_WGRAD_QUEUE
+        ops.DEFAULT_QUEUES.flush()
+        assert not ops.DEFAULT_QUEUES.conv_wgrad
     finally:
-        ops.CONV_WGRAD_QUEUE = None
+        ops.DEFAULT_QUEUES = None
     for (x, dy, base), dw in zip(cases, outs):
         ref = torch.nn.grad.conv3d_weight(x.float().permute(0, 4, 1, 2, 3), base.shape, dy.float().permute(0, 4, 1, 2, 3), padding=1)
         assert rel_err(dw - base, ref) < TOL[dtype], tuple(x.shape)
         single = ops.conv3_wgrad(x, dy)
         assert rel_err(dw - base, single) < 1e-5 if dtype == torch.float32 else 1e-3
     # accumulate mode 2: "dw holds zeros" (a fresh arena slot) - stores instead of read-modify-write, no fill for the slab layers
-    ops.CONV_WGRAD_QUEUE = []
+    ops.DEFAULT_QUEUES = ops.StepQueues()
     try:
         zs = [torch.zeros_like(c[2]) for c in cases]
         for (x, dy, _), z in zip(cases, zs):
             ops.conv3_wgrad(x, dy, dw=z, accumulate=2)
-        ops.flush_conv_wgrads()
+        ops.DEFAULT_QUEUES.flush()
     finally:
-        ops.CONV_WGRAD_QUEUE = None
+        ops.DEFAULT_QUEUES = None
     for (x, dy, base), dw, z in zip(cases, outs, zs):
         assert rel_err(z, dw - base) < 1e-5 if dtype == torch.float32 else 1e-3, tuple(x.shape)
         z2 = torch.zeros_like(z)

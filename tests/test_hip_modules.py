@@ -261,6 +261,33 @@ def test_swin_unetr_c2_vs_truth(golden, dtype, cot):
     assert sorted(k for k, p in named.items() if p.grad is None) == sorted(R.meta["cases"]["c2_m0"]["grad_none"])
 
 
+def test_swin_unetr_c2_full_tensors_vs_oracle():
+    """the fixtures hold 4096 strided samples per tensor; a localized error (one brick, one window) could hide between them.  Here the CPU
+    oracle runs the C2 patch once (fp32, ~6 s on 16 threads) and EVERY element of the logits and of every parameter gradient is compared:
+    logits relative L2 < 1e-5 and max |diff| < 1e-4 of the largest logit; gradients relative L2 < 1e-2 over the full tensors."""
+    from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
+    from mi_seg_amd.utils.detfill import det_input
+    from oracle import nets as ON
+    m = _fill(SwinUNETR((96, 96, 96), 1, 6, feature_size=48, num_heads=(3, 6, 12, 24), vit_norm_name=_norm("instance_cond"),
+                        encoder_norm_name=_norm("instance_cond"), decoder_norm_name=_norm("instance")))
+    sd = {k: (v.detach().cpu().clone().requires_grad_(True) if v.is_floating_point() else v.detach().cpu().clone()) for k, v in m.state_dict().items()}
+    x, g = det_input(1234, (1, 1, 96, 96, 96)), det_input(4321, (1, 6, 96, 96, 96))
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 16))
+    yo = ON.swin_unetr_forward(sd, x, [1], ON.swin_unetr_cfg(feature_size=48))
+    yo.backward(g)
+    torch.set_num_threads(threads)
+    y = m(x.to(DEV), [1])
+    y.backward(g.to(DEV))
+    d = (y.detach().cpu() - yo.detach())
+    assert rel_err(y, yo) < 1e-5
+    assert float(d.abs().max()) < 1e-4 * float(yo.detach().abs().max())
+    want = {k: v.grad for k, v in sd.items() if v.is_floating_point() and v.grad is not None}
+    got = {k: p.grad for k, p in m.named_parameters()}
+    assert sorted(k for k, p in m.named_parameters() if p.grad is None) == sorted(k for k, v in sd.items() if v.is_floating_point() and v.grad is None)
+    compare_grads(got, want, 1e-2, skip=ZERO_GRAD)
+
+
 def test_forward_and_data_gradients_are_bitwise_reproducible():
     """two identical eager steps: logits, the gradient w.r.t. every activation on the dX chain and hence every dX-derived quantity are
     bit-identical (no atomics on that path: statistics are fp64 sums whose rounding to fp32 is order-independent in practice, split
