@@ -274,7 +274,9 @@ def bench_sliding_window(a, model, dtype, dev, rank, world, dist):
     size, sw = (512, 512, 363), 4
     vol = torch.rand(1, 1, *size, generator=torch.Generator().manual_seed(2000 + rank)).to(dev)
     nwin = len(window_grid(size, (96, 96, 96), 0.5))
-    pred = GraphedForward(model, (sw, 1, 96, 96, 96))
+    from mi_seg_amd.runtime.arena import ParamArena
+    arena = ParamArena(list(model.parameters()), dtype)        # inference: the weights' compute-dtype copies / conv packs are made once
+    pred = GraphedForward(model, (sw, 1, 96, 96, 96), arena=arena)
     run = lambda: sliding_window_inference(vol, 96, sw, pred, overlap=0.5, modalities=[0])
     for _ in range(max(1, a.warmup)):
         y = run()

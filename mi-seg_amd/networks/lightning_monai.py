@@ -102,6 +102,9 @@ class LitMonai(_Base):
     def _shared_eval(self, batch, batch_idx, prefix):
         image, label = batch["image"], batch["label"]
         modality = batch["modality"] if "modality" in batch.keys() else None
+        arena = next((getattr(p, "_miseg_arena", None) for p in self.model.parameters()), None)
+        if arena is not None:              # validation between optimiser steps: the arena's weight copies must be current
+            arena.refresh_weights()
         logits = self.model_inferer(image, modalities=modality)
         if self.infer_cpu:
             label = label.cpu()

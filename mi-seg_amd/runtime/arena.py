@@ -88,6 +88,10 @@ class ParamArena:
             ops.fill32(self.flat)
             for p in self.params:
                 p._miseg_used = False
+        self._refresh()
+
+    def _refresh(self):
+        """one launch each: every registered parameter re-layout (casts / transposes / regroupings) and every 3x3x3 weight pack"""
         if self._dirty:
             self._build_table()
         if self._table is not None:
@@ -108,6 +112,20 @@ class ParamArena:
             for ent in self._packs.values():
                 if ent[4]:
                     ent[3] = self.epoch
+
+    def refresh_weights(self):
+        """inference / validation: bring the compute-dtype copies of the parameters up to date WITHOUT opening a training step (no arena
+        fill, no queues).  They stay valid - for any number of forward passes - until `invalidate()`; buffers keep their addresses, so
+        hipGraphs captured on them (runtime/graph.py::GraphedForward) stay valid across refreshes.  The first forward after a model was
+        built registers its re-layouts lazily (and casts per call); call this again after it."""
+        self.epoch += 1
+        self._refresh()
+
+    def invalidate(self):
+        """the parameters changed (an optimiser step): the copies of this epoch must not be used again; forwards cast per call until the
+        next `begin_step()` / `refresh_weights()`.  training/optim.py::ArenaOptimizer.step calls this; a loop that steps a torch optimiser
+        itself must call it too (or simply begin every step with `begin_step()`, as every loop in this repo does)."""
+        self.epoch += 1
 
     def shadow(self, p, transpose, inner, outer):
         """the re-layout of parameter p refreshed this step, or None (first request: registered for the next step)."""

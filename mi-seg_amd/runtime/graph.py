@@ -29,8 +29,12 @@ class GraphedForward:
     use as the `predictor` of training/inferer.py::sliding_window_inference (returns a static logits buffer: consume it before the
     next call)."""
 
-    def __init__(self, model: torch.nn.Module, batch_shape: Sequence[int], warmup: int = 1):
+    def __init__(self, model: torch.nn.Module, batch_shape: Sequence[int], warmup: int = 1, arena=None):
+        """arena: optional runtime.arena.ParamArena of the model.  Without one every forward re-casts and re-packs every weight (66 of
+        the ~240 launches of a C-Swin-UNETR forward); with one the copies are refreshed ONCE (`arena.refresh_weights()`, here after the
+        warm-up that registers them) and the graph reads them - call `arena.refresh_weights()` again whenever the parameters changed."""
         self.model = model
+        self.arena = arena
         dev = next(model.parameters()).device
         self.x = torch.zeros(*batch_shape, dtype=torch.float32, device=dev)
         self.styles = torch.zeros(batch_shape[0], dtype=torch.int32, device=dev)
@@ -55,8 +59,10 @@ class GraphedForward:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                for _ in range(self.warmup):
+                for _ in range(max(self.warmup, 1 if self.arena is not None else 0)):
                     self._run(host)
+                if self.arena is not None:
+                    self.arena.refresh_weights()
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()

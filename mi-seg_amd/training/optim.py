@@ -59,6 +59,7 @@ class ArenaOptimizer:
                       self.lr if lr is None else float(lr), self.betas[0], self.betas[1], self.eps, self.weight_decay, self.momentum,
                       self.lr_dev.data_ptr() if self.lr_dev is not None else None)
         ops._call("miseg_opt_step", p)
+        self.arena.invalidate()       # the compute-dtype copies of the parameters are stale now
 
     def state_dict(self):
         return {"kind": self.kind, "state1": self.state1.clone(), "state2": None if self.state2 is None else self.state2.clone(), "steps": self.steps.clone(),

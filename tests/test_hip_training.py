@@ -187,6 +187,24 @@ def test_sliding_window_on_the_hip_path_matches_the_oracle():
     assert eager.shape == want.shape and eager.is_cuda
     assert rel_err(eager, want) < 1e-3
     assert torch.equal(eager, graphed)
+    # with an arena the weights are cast / packed once (arena.refresh_weights) instead of in every forward: same bits; and after the
+    # parameters change, a refresh brings the captured graph up to date
+    from mi_seg_amd.runtime.arena import ParamArena
+    arena = ParamArena(list(m.parameters()), torch.float32)
+    try:
+        gf = GraphedForward(m, (4, 1, 64, 64, 64), arena=arena)
+        cached = sliding_window_inference(vol.to(DEV), 64, 4, gf, overlap=0.5, modalities=[1])
+        assert torch.equal(eager, cached)
+        with torch.no_grad():
+            m.out.conv.conv.bias.add_(1.0)
+            m.decoder1.conv_block.conv1.conv.weight.mul_(1.5)
+        arena.refresh_weights()
+        moved = sliding_window_inference(vol.to(DEV), 64, 4, gf, overlap=0.5, modalities=[1])
+        arena.invalidate()
+        again = sliding_window_inference(vol.to(DEV), 64, 4, m, overlap=0.5, modalities=[1])     # eager, casts per call
+        assert not torch.equal(moved, eager) and torch.equal(moved, again)
+    finally:
+        arena.detach()
     with pytest.raises(IndexError):
         m(vol[..., :64, :64, :64].to(DEV), [2])                     # style id outside [0, num_styles): refused on the host, no launch
 
