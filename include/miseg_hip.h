@@ -518,6 +518,17 @@ typedef struct {
 } miseg_augment_params;
 int miseg_augment_crop(const miseg_augment_params* p, miseg_stream_t stream);
 
+/* The resampling step of the cached, deterministic head of the data chain (Spacingd at data/multi_modal.py:41-44: image "bilinear", label
+ * "nearest"): in [C][Di][Hi][Wi] -> out [C][Do][Ho][Wo], voxel centres aligned (src = (dst + 0.5) * in / out - 0.5), coordinates clamped to
+ * the border.  mode 0: trilinear (fp32), mode 1: nearest (round half up).  elem_bytes 4: fp32 for mode 0; 1 / 4 / 8 for mode 1 (labels are
+ * copied verbatim).  MONAI's own grid construction is not restated (parity unpinned). */
+typedef struct {
+  uint32_t struct_size;
+  const void* in; void* out;
+  int C, Di, Hi, Wi, Do, Ho, Wo, mode, elem_bytes;
+} miseg_resample3d_params;
+int miseg_resample3d(const miseg_resample3d_params* p, miseg_stream_t stream);
+
 /* sizeof() of a params struct as this library was compiled ("miseg_gemm_params", ...), 0 for an unknown name: bindings compare it with
  * their own mirror at load time (together with miseg_abi_version) so that header and binding cannot drift silently. */
 size_t miseg_abi_struct_size(const char* struct_name);

@@ -451,6 +451,43 @@ __global__ void __launch_bounds__(256) augment_kernel(const float* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ resampling
+struct ResampleArgs { int C, Di, Hi, Wi, Do, Ho, Wo; };
+
+__device__ __forceinline__ float rs_src(int dst, int in, int out) { return ((float)dst + 0.5f) * ((float)in / (float)out) - 0.5f; }
+
+static __global__ void __launch_bounds__(256) resample_linear_kernel(const float* __restrict__ in, float* __restrict__ out, ResampleArgs a) {
+  const int64_t ovol = (int64_t)a.Do * a.Ho * a.Wo, ivol = (int64_t)a.Di * a.Hi * a.Wi;
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < ovol; o += (int64_t)gridDim.x * 256) {
+    const int w = (int)(o % a.Wo), h = (int)((o / a.Wo) % a.Ho), d = (int)(o / ((int64_t)a.Wo * a.Ho));
+    const float fd = fminf(fmaxf(rs_src(d, a.Di, a.Do), 0.f), (float)(a.Di - 1));
+    const float fh = fminf(fmaxf(rs_src(h, a.Hi, a.Ho), 0.f), (float)(a.Hi - 1));
+    const float fw = fminf(fmaxf(rs_src(w, a.Wi, a.Wo), 0.f), (float)(a.Wi - 1));
+    const int d0 = (int)fd, h0 = (int)fh, w0 = (int)fw;
+    const int d1 = min(d0 + 1, a.Di - 1), h1 = min(h0 + 1, a.Hi - 1), w1 = min(w0 + 1, a.Wi - 1);
+    const float td = fd - d0, th = fh - h0, tw = fw - w0;
+    for (int c = 0; c < a.C; ++c) {
+      const float* p = in + (int64_t)c * ivol;
+      auto at = [&](int z, int y, int x) { return p[((int64_t)z * a.Hi + y) * a.Wi + x]; };
+      const float c00 = at(d0, h0, w0) * (1.f - tw) + at(d0, h0, w1) * tw, c01 = at(d0, h1, w0) * (1.f - tw) + at(d0, h1, w1) * tw;
+      const float c10 = at(d1, h0, w0) * (1.f - tw) + at(d1, h0, w1) * tw, c11 = at(d1, h1, w0) * (1.f - tw) + at(d1, h1, w1) * tw;
+      out[(int64_t)c * ovol + o] = (c00 * (1.f - th) + c01 * th) * (1.f - td) + (c10 * (1.f - th) + c11 * th) * td;
+    }
+  }
+}
+
+template <class E>
+__global__ void __launch_bounds__(256) resample_nearest_kernel(const E* __restrict__ in, E* __restrict__ out, ResampleArgs a) {
+  const int64_t ovol = (int64_t)a.Do * a.Ho * a.Wo, ivol = (int64_t)a.Di * a.Hi * a.Wi;
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < ovol; o += (int64_t)gridDim.x * 256) {
+    const int w = (int)(o % a.Wo), h = (int)((o / a.Wo) % a.Ho), d = (int)(o / ((int64_t)a.Wo * a.Ho));
+    const int sd = min(max((int)floorf(rs_src(d, a.Di, a.Do) + 0.5f), 0), a.Di - 1);
+    const int sh = min(max((int)floorf(rs_src(h, a.Hi, a.Ho) + 0.5f), 0), a.Hi - 1);
+    const int sw = min(max((int)floorf(rs_src(w, a.Wi, a.Wo) + 0.5f), 0), a.Wi - 1);
+    for (int c = 0; c < a.C; ++c) out[(int64_t)c * ovol + o] = in[(int64_t)c * ivol + ((int64_t)sd * a.Hi + sh) * a.Wi + sw];
+  }
+}
+
 template <class F> static int dispatch_label(int dt, F&& f) {
   switch (dt) {
     case MISEG_LABEL_F32: return f((const float*)nullptr);
@@ -616,5 +653,26 @@ extern "C" int miseg_augment_crop(const miseg_augment_params* p, miseg_stream_t 
   else if (p->label_bytes == 4) augment_kernel<uint32_t><<<grid, 256, 0, s>>>(p->image, (const uint32_t*)p->label, p->out_image, (uint32_t*)p->out_label, a);
   else augment_kernel<uint64_t><<<grid, 256, 0, s>>>(p->image, (const uint64_t*)p->label, p->out_image, (uint64_t*)p->out_label, a);
   MISEG_LAUNCH_CHECK("augment_crop");
+  return MISEG_OK;
+}
+
+extern "C" int miseg_resample3d(const miseg_resample3d_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->struct_size == sizeof(miseg_resample3d_params), MISEG_E_BADARG, "resample3d: struct_size %u != %zu", p ? p->struct_size : 0u,
+                sizeof(miseg_resample3d_params));
+  MISEG_REQUIRE(p->in && p->out && p->C > 0 && p->Di > 0 && p->Hi > 0 && p->Wi > 0 && p->Do > 0 && p->Ho > 0 && p->Wo > 0, MISEG_E_BADARG, "resample3d: bad arguments");
+  ResampleArgs a{p->C, p->Di, p->Hi, p->Wi, p->Do, p->Ho, p->Wo};
+  int grid = cdiv((int64_t)p->Do * p->Ho * p->Wo, 256 * 4);
+  if (grid > 4096) grid = 4096;
+  if (p->mode == 0) {
+    MISEG_REQUIRE(p->elem_bytes == 4, MISEG_E_UNSUPPORTED, "resample3d: trilinear needs fp32");
+    resample_linear_kernel<<<grid, 256, 0, s>>>((const float*)p->in, (float*)p->out, a);
+  } else if (p->mode == 1) {
+    if (p->elem_bytes == 1) resample_nearest_kernel<uint8_t><<<grid, 256, 0, s>>>((const uint8_t*)p->in, (uint8_t*)p->out, a);
+    else if (p->elem_bytes == 4) resample_nearest_kernel<uint32_t><<<grid, 256, 0, s>>>((const uint32_t*)p->in, (uint32_t*)p->out, a);
+    else if (p->elem_bytes == 8) resample_nearest_kernel<uint64_t><<<grid, 256, 0, s>>>((const uint64_t*)p->in, (uint64_t*)p->out, a);
+    else return set_error(MISEG_E_UNSUPPORTED, "resample3d: element of %d bytes", p->elem_bytes);
+  } else return set_error(MISEG_E_BADARG, "resample3d: mode %d", p->mode);
+  MISEG_LAUNCH_CHECK("resample3d");
   return MISEG_OK;
 }

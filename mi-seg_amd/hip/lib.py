@@ -121,6 +121,9 @@ AugSample = _struct("AugSample", cname="miseg_aug_sample", fields=[("origin", i3
 Augment = _struct("Augment", cname="miseg_augment_params", fields=[
     ("struct_size", u32), ("image", vp), ("label", vp), ("label_bytes", i32), ("C", i32), ("D", i32), ("H", i32), ("W", i32), ("rd", i32), ("rh", i32),
     ("rw", i32), ("n", i32), ("out_image", vp), ("out_label", vp), ("samples_host", vp)])
+Resample3d = _struct("Resample3d", cname="miseg_resample3d_params", fields=[
+    ("struct_size", u32), ("in", vp), ("out", vp), ("C", i32), ("Di", i32), ("Hi", i32), ("Wi", i32), ("Do", i32), ("Ho", i32), ("Wo", i32),
+    ("mode", i32), ("elem_bytes", i32)])
 AUG_MAX_SAMPLES = 16
 LABEL_F32, LABEL_I32, LABEL_I64, LABEL_U8 = 0, 1, 2, 3
 LOSS_DICE_FOCAL, LOSS_DICE_CE = 0, 1
@@ -195,6 +198,7 @@ PROTOS = {
     "miseg_opt_step": (i32, [C.POINTER(OptStep), vp]),
     "miseg_stitch_windows": (i32, [C.POINTER(Stitch), vp]),
     "miseg_augment_crop": (i32, [C.POINTER(Augment), vp]),
+    "miseg_resample3d": (i32, [C.POINTER(Resample3d), vp]),
     "miseg_abi_struct_size": (C.c_size_t, [C.c_char_p]),
     "miseg_device_check": (i32, [i32]),
 }

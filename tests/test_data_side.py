@@ -116,3 +116,38 @@ def test_gpu_augmentation_matches_torch_ops():
     vol = ResidentVolume(img[0].cuda(), lab[0, 0].cuda())
     with pytest.raises(ValueError):
         GpuAugmenter((96, 96, 96))(vol)                       # volume smaller than the roi
+
+
+@pytest.mark.gpu
+def test_resample_and_the_cached_head_of_the_chain(tmp_path):
+    """Spacingd-style resampling kernel against torch's interpolate (voxel centres aligned), then the whole deterministic head from two
+    NIfTI files to a ResidentVolume that the augmenter and the sliding-window inferer consume."""
+    import torch.nn.functional as F
+    from mi_seg_amd.data.nifti import write_nifti
+    from mi_seg_amd.data.preprocess import load_resident_volume, resample, scale_intensity, spatial_pad
+    from mi_seg_amd.data.synthetic import synthetic_volume
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(2, 20, 24, 18, generator=g).cuda()
+    for size in ((33, 24, 40), (10, 30, 18), (20, 24, 18)):
+        got = resample(x, size, "trilinear")
+        want = F.interpolate(x[None], size=size, mode="trilinear", align_corners=False)[0]
+        assert torch.allclose(got, want, atol=2e-6, rtol=0), size
+        lab = torch.randint(0, 6, (1, 20, 24, 18), generator=g).cuda()
+        got_l = resample(lab, size, "nearest")
+        want_l = F.interpolate(lab[None].float(), size=size, mode="nearest-exact")[0].long()
+        assert torch.equal(got_l, want_l), size
+    assert float(scale_intensity(x).amin()) == 0.0 and float(scale_intensity(x).amax()) == 1.0
+    assert spatial_pad(x, (24, 24, 24)).shape == (2, 24, 24, 24) and torch.equal(spatial_pad(x, (24, 24, 24))[:, 2:22, :, 3:21], x)
+    # files -> resident volume: a 2 mm scan of 40 x 44 x 36 voxels with permuted / flipped axes becomes a RAS 1 mm volume of 80 x 88 x 72
+    img, lab = synthetic_volume((40, 44, 36), 4, 1)
+    A = np.array([[0, -2.0, 0, 10], [2.0, 0, 0, -5], [0, 0, 2.0, 3], [0, 0, 0, 1.0]])
+    write_nifti(str(tmp_path / "mr_1.nii.gz"), img[0, 0].numpy(), A)
+    write_nifti(str(tmp_path / "mr_1_label.nii.gz"), lab[0, 0].numpy().astype(np.uint8), A)
+    vol = load_resident_volume({"image": str(tmp_path / "mr_1.nii.gz"), "label": str(tmp_path / "mr_1_label.nii.gz"), "modality": "MR"}, roi=(96, 96, 64))
+    assert vol.modality == 1 and vol.image.shape == (1, 96, 96, 72) and vol.label.shape == (96, 96, 72)
+    assert 0.0 <= float(vol.image.amin()) and float(vol.image.amax()) <= 1.0 and set(vol.label.unique().tolist()) <= set(range(6))
+    frac_fg = float((lab > 0).float().mean())
+    assert abs(float((vol.label[8:88, 4:92] > 0).float().mean()) - frac_fg) < 0.02      # the label map survived reorientation + resampling
+    from mi_seg_amd.data.augment import GpuAugmenter
+    batch = GpuAugmenter((64, 64, 64), patches_training_sample=2, seed=1)(vol)
+    assert batch["image"].shape == (2, 1, 64, 64, 64) and batch["modality"].tolist() == [1, 1]
