@@ -518,6 +518,28 @@ typedef struct {
 } miseg_augment_params;
 int miseg_augment_crop(const miseg_augment_params* p, miseg_stream_t stream);
 
+/* Dropout / stochastic depth on channels-last rows (the `drop` / `dropout_path_rate` arguments of the reference's Swin stack:
+ * networks/blocks/swin_transformer_block.py:90-97,205,247; MONAI Dropout / DropPath semantics): y = x * keep / (1 - p).
+ *   rows_per_sample == 0: one Bernoulli(1 - p) draw per ELEMENT (nn.Dropout); > 0: one draw per SAMPLE (DropPath: rows r belong to
+ *   sample r / rows_per_sample).  The mask is a pure function of (seed, stream_id, *step_dev, element / sample index) - a counter-based
+ *   hash, nothing is stored: the backward pass is the same call on the gradient.  stream_id tells call sites apart within a step; step_dev
+ *   (device uint64, may be NULL) tells steps apart under hipGraph replay, where seed and stream_id are baked into the graph
+ *   (advance it once per step with miseg_counter_add). */
+typedef struct {
+  uint32_t struct_size;
+  const void* x; int64_t ldx; void* y; int64_t ldy;
+  int64_t rows; int C, dtype;
+  int64_t rows_per_sample;
+  float p;
+  uint64_t seed, stream_id;
+  const uint64_t* step_dev;
+} miseg_dropout_params;
+int miseg_dropout(const miseg_dropout_params* p, miseg_stream_t stream);
+int miseg_counter_add(uint64_t* counter_dev, uint64_t value, miseg_stream_t stream);
+/* *dst = *src on the device (a plain kernel: device-to-device copies recorded as memcpy nodes crashed hipStreamEndCapture on ROCm 7.2).
+ * A dropout call snapshots the step counter so that its backward pass re-creates the same mask after the counter moved on. */
+int miseg_counter_copy(uint64_t* dst_dev, const uint64_t* src_dev, miseg_stream_t stream);
+
 /* The resampling step of the cached, deterministic head of the data chain (Spacingd at data/multi_modal.py:41-44: image "bilinear", label
  * "nearest"): in [C][Di][Hi][Wi] -> out [C][Do][Ho][Wo], voxel centres aligned (src = (dst + 0.5) * in / out - 0.5), coordinates clamped to
  * the border.  mode 0: trilinear (fp32), mode 1: nearest (round half up).  elem_bytes 4: fp32 for mode 0; 1 / 4 / 8 for mode 1 (labels are

@@ -451,6 +451,38 @@ __global__ void __launch_bounds__(256) augment_kernel(const float* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ dropout / drop-path
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {     // splitmix64 finaliser: a counter-based generator, nothing to store
+  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+  z ^= z >> 27; z *= 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// one 64-bit hash per group of 4 consecutive channels: four 16-bit draws against a 16-bit threshold (p is quantised to 1 / 65536)
+template <class T>
+__global__ void __launch_bounds__(256) dropout_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, int64_t rows, int C, int64_t rps,
+                                                      unsigned thresh, float scale, uint64_t key, const uint64_t* __restrict__ step_dev) {
+  const uint64_t k = mix64(key ^ (step_dev ? (*step_dev) * 0x9E3779B97F4A7C15ull : 0ull));
+  const int cg = (C + 3) / 4;
+  const int64_t total = rows * cg;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cg;
+    const int c0 = (int)(i - r * cg) * 4;
+    const uint64_t h = rps > 0 ? mix64(k + (uint64_t)(r / rps) * 0xD1342543DE82EF95ull) : mix64(k + (uint64_t)i * 0xD1342543DE82EF95ull);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (c0 + e < C) {
+        const unsigned draw = rps > 0 ? (unsigned)(h & 0xffff) : (unsigned)((h >> (16 * e)) & 0xffff);
+        const float v = to_f32(x[r * ldx + c0 + e]);
+        y[r * ldy + c0 + e] = from_f32<T>(draw >= thresh ? v * scale : 0.f);
+      }
+    }
+  }
+}
+
+static __global__ void counter_add_kernel(uint64_t* c, uint64_t v) { *c += v; }
+static __global__ void counter_copy_kernel(uint64_t* d, const uint64_t* s) { *d = *s; }
+
 // ------------------------------------------------------------------------------------------------ resampling
 struct ResampleArgs { int C, Di, Hi, Wi, Do, Ho, Wo; };
 
@@ -674,5 +706,38 @@ extern "C" int miseg_resample3d(const miseg_resample3d_params* p, miseg_stream_t
     else return set_error(MISEG_E_UNSUPPORTED, "resample3d: element of %d bytes", p->elem_bytes);
   } else return set_error(MISEG_E_BADARG, "resample3d: mode %d", p->mode);
   MISEG_LAUNCH_CHECK("resample3d");
+  return MISEG_OK;
+}
+
+extern "C" int miseg_dropout(const miseg_dropout_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->struct_size == sizeof(miseg_dropout_params), MISEG_E_BADARG, "dropout: struct_size %u != %zu", p ? p->struct_size : 0u,
+                sizeof(miseg_dropout_params));
+  MISEG_REQUIRE(p->x && p->y && p->rows > 0 && p->C > 0 && p->rows_per_sample >= 0, MISEG_E_BADARG, "dropout: bad arguments");
+  MISEG_REQUIRE(p->p >= 0.f && p->p < 1.f, MISEG_E_BADARG, "dropout: p = %f must lie in [0, 1)", (double)p->p);
+  const unsigned thresh = (unsigned)lrintf(p->p * 65536.f);
+  const float scale = 1.f / (1.f - (float)thresh / 65536.f);
+  const uint64_t key = p->seed * 0x9E3779B97F4A7C15ull + p->stream_id * 0xC2B2AE3D27D4EB4Full + 0x165667B19E3779F9ull;
+  int grid = cdiv(p->rows * ((p->C + 3) / 4), 256 * 4);
+  if (grid > 4096) grid = 4096;
+  return dispatch_dtype(p->dtype, [&](auto* tag) -> int {
+    typedef typename std::remove_pointer<decltype(tag)>::type T;
+    dropout_kernel<T><<<grid, 256, 0, s>>>((const T*)p->x, p->ldx, (T*)p->y, p->ldy, p->rows, p->C, p->rows_per_sample, thresh, scale, key, p->step_dev);
+    MISEG_LAUNCH_CHECK("dropout");
+    return MISEG_OK;
+  });
+}
+
+extern "C" int miseg_counter_add(uint64_t* c, uint64_t v, miseg_stream_t s_) {
+  MISEG_REQUIRE(c, MISEG_E_BADARG, "counter_add: null pointer");
+  counter_add_kernel<<<1, 1, 0, (hipStream_t)s_>>>(c, v);
+  MISEG_LAUNCH_CHECK("counter_add");
+  return MISEG_OK;
+}
+
+extern "C" int miseg_counter_copy(uint64_t* d, const uint64_t* src, miseg_stream_t s_) {
+  MISEG_REQUIRE(d && src, MISEG_E_BADARG, "counter_copy: null pointer");
+  counter_copy_kernel<<<1, 1, 0, (hipStream_t)s_>>>(d, src);
+  MISEG_LAUNCH_CHECK("counter_copy");
   return MISEG_OK;
 }

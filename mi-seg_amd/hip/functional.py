@@ -81,6 +81,32 @@ def add(a, b):
     return _Add.apply(a, b)
 
 
+class _Dropout(Function):
+    """nn.Dropout / DropPath on channels-last rows: the mask is a counter-based hash of (seed, call site, step, index) - nothing is stored,
+    the backward pass is the same kernel call on the gradient (swin_transformer_block.py:90-97,205,247)."""
+
+    @staticmethod
+    def forward(ctx, x, p, per_sample):
+        ctx.key = ops.DROP.next_key(x.device)
+        ctx.p = p
+        ctx.rps = (ops.rows(x)[1] // x.shape[0]) if per_sample else 0
+        return ops.dropout_apply(x, p, ctx.key, ctx.rps)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.dropout_apply(_rv(g), ctx.p, ctx.key, ctx.rps), None, None
+
+
+def dropout(x, p, training=True):
+    """elementwise dropout (identity in eval mode or at p == 0)"""
+    return _Dropout.apply(x, float(p), False) if (training and p > 0.0) else x
+
+
+def drop_path(x, p, training=True):
+    """stochastic depth: the whole residual branch of a sample is dropped with probability p (MONAI DropPath, scale_by_keep)"""
+    return _Dropout.apply(x, float(p), True) if (training and p > 0.0) else x
+
+
 # ----------------------------------------------------------------------------------------------------------------
 _PENDING_OUT = None      # see _InstNorm.forward
 

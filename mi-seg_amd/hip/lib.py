@@ -124,6 +124,9 @@ Augment = _struct("Augment", cname="miseg_augment_params", fields=[
 Resample3d = _struct("Resample3d", cname="miseg_resample3d_params", fields=[
     ("struct_size", u32), ("in", vp), ("out", vp), ("C", i32), ("Di", i32), ("Hi", i32), ("Wi", i32), ("Do", i32), ("Ho", i32), ("Wo", i32),
     ("mode", i32), ("elem_bytes", i32)])
+Dropout = _struct("Dropout", cname="miseg_dropout_params", fields=[
+    ("struct_size", u32), ("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32), ("dtype", i32), ("rows_per_sample", i64),
+    ("p", f32), ("seed", C.c_uint64), ("stream_id", C.c_uint64), ("step_dev", vp)])
 AUG_MAX_SAMPLES = 16
 LABEL_F32, LABEL_I32, LABEL_I64, LABEL_U8 = 0, 1, 2, 3
 LOSS_DICE_FOCAL, LOSS_DICE_CE = 0, 1
@@ -199,6 +202,9 @@ PROTOS = {
     "miseg_stitch_windows": (i32, [C.POINTER(Stitch), vp]),
     "miseg_augment_crop": (i32, [C.POINTER(Augment), vp]),
     "miseg_resample3d": (i32, [C.POINTER(Resample3d), vp]),
+    "miseg_dropout": (i32, [C.POINTER(Dropout), vp]),
+    "miseg_counter_add": (i32, [vp, C.c_uint64, vp]),
+    "miseg_counter_copy": (i32, [vp, vp, vp]),
     "miseg_abi_struct_size": (C.c_size_t, [C.c_char_p]),
     "miseg_device_check": (i32, [i32]),
 }

@@ -139,6 +139,7 @@ def begin_step():
         STAT_POOL.begin_step()
     else:
         STAT_POOL.fresh()
+    DROP.advance()
 
 
 def begin_forward(params=()):
@@ -153,6 +154,7 @@ def begin_forward(params=()):
                 return
             break
     STAT_POOL.fresh()
+    DROP.advance()
 
 
 def instnorm_stats(x, B, S):
@@ -949,3 +951,42 @@ def stitch_windows(win, out, starts, roi, count=None):
     _call("miseg_stitch_windows", L.Stitch(C.sizeof(L.Stitch), _ptr(win), _ptr(out), _ptr(count), Cc, D, H, W, roi[0], roi[1], roi[2], nd, nh, nw,
                                            C.cast(arr[0], C.c_void_p), C.cast(arr[1], C.c_void_p), C.cast(arr[2], C.c_void_p)))
     return out
+
+
+# ------------------------------------------------------------------------------------------ dropout / stochastic depth
+class _DropState:
+    """keys of the counter-based dropout masks: `seed` (host, torch.initial_seed() unless set), a call counter that tells the call sites
+    of one step apart (reset by begin_step / begin_forward) and a DEVICE step counter advanced once per step - under hipGraph replay the
+    first two are baked into the graph, the third is what makes every replay draw new masks."""
+
+    def __init__(self):
+        self.seed, self.calls, self.step_dev = None, 0, None
+
+    def next_key(self, device):
+        if self.seed is None:
+            self.seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+        if self.step_dev is None or self.step_dev.device != device:
+            self.step_dev = torch.zeros(1, dtype=torch.int64, device=device)
+        self.calls += 1
+        # the step counter is SNAPSHOT per call: the backward pass of this forward may run after a later forward advanced the counter
+        snap = torch.empty(1, dtype=torch.int64, device=device)
+        L.check(L.load().miseg_counter_copy(_ptr(snap), _ptr(self.step_dev), _stream()), "counter_copy")
+        return self.seed, self.calls, snap
+
+    def advance(self):
+        """once per training step (arena.begin_step / GraphedStep._run / the nets' forward when nobody manages the step)"""
+        self.calls = 0
+        if self.step_dev is not None:
+            L.check(L.load().miseg_counter_add(_ptr(self.step_dev), 1, _stream()), "counter_add")
+
+
+DROP = _DropState()
+
+
+def dropout_apply(x, p, key, rows_per_sample=0):
+    """y = x * mask(key) / (1 - p); key = (seed, stream_id, step_dev) from DROP.next_key: the same key reproduces the same mask (backward)"""
+    ld, n, Cc = rows(x)
+    y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    seed, sid, step = key
+    _call("miseg_dropout", L.Dropout(C.sizeof(L.Dropout), _ptr(x), ld, _ptr(y), rows(y)[0], n, Cc, _dt(x), rows_per_sample, float(p), seed, sid, _ptr(step)))
+    return y

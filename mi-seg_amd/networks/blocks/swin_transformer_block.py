@@ -27,8 +27,6 @@ class SwinTransformerBlock(nn.Module):
                  qkv_bias: bool = True, drop: float = 0.0, attn_drop: float = 0.0, drop_path: float = 0.0, act_layer: str = "GELU",
                  use_checkpoint: bool = False, norm_type: Union[Tuple, str] = "layer") -> None:
         super().__init__()
-        if drop_path != 0.0 or drop != 0.0:
-            raise NotImplementedError("drop / drop_path > 0 is not implemented by the MI355X path")
         self.dim = dim
         self.num_heads = num_heads
         self.window_size = tuple(window_size)
@@ -41,7 +39,8 @@ class SwinTransformerBlock(nn.Module):
         self.norm2 = get_norm_layer(name=spec, spatial_dims=len(self.window_size), channels=dim)
         self.attn = WindowAttention(dim, window_size=self.window_size, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop,
                                     proj_drop=drop)
-        self.drop_path = nn.Identity()
+        self.drop_path_rate = float(drop_path)
+        self.drop_path = nn.Identity()           # (a parameter-free placeholder with the reference's attribute name; the rate is applied below)
         self.mlp = Mlp(hidden_size=dim, mlp_dim=int(dim * mlp_ratio), act=act_layer, dropout_rate=drop, dropout_mode="swin")
 
     def forward(self, x, styles=None):
@@ -50,6 +49,10 @@ class SwinTransformerBlock(nn.Module):
         window, shift = get_window_size((d, h, w), self.window_size, self.shift_size)
         inst = self.norm_type.startswith("instance")    # the GEMM that feeds an instance norm also produces its statistics
         xn, xs = apply_norm_fork(self.norm1, x, styles)
+        if self.drop_path_rate > 0.0 and self.training:                 # stochastic depth (:247,:251): x + drop_path(branch)
+            x = HF.add(xs, HF.drop_path(self.attn(xn, window, shift), self.drop_path_rate))
+            xn, xs = apply_norm_fork(self.norm2, x, styles)
+            return HF.add(xs, HF.drop_path(self.mlp(xn), self.drop_path_rate))
         x = self.attn(xn, window, shift, res=xs, want_stat=inst)        # x + attn(norm1(x)): add in the proj epilogue
         xn, xs = apply_norm_fork(self.norm2, x, styles)
         return self.mlp(xn, res=xs, want_stat=inst)                     # x + mlp(norm2(x)): add in the fc2 epilogue

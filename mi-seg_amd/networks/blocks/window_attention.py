@@ -14,8 +14,10 @@ class WindowAttention(nn.Module):
     def __init__(self, dim: int, num_heads: int, window_size: Sequence[int], qkv_bias: bool = False, attn_drop: float = 0.0,
                  proj_drop: float = 0.0) -> None:
         super().__init__()
-        if attn_drop != 0.0 or proj_drop != 0.0:
-            raise NotImplementedError("attention dropout > 0 is not implemented by the MI355X path")
+        if attn_drop != 0.0:
+            raise NotImplementedError("dropout on the attention probabilities (attn_drop > 0) is not implemented by the MI355X path: the "
+                                      "scores never leave the fused attention kernel")
+        self.proj_drop = float(proj_drop)
         if len(window_size) != 3:
             raise NotImplementedError("only 3D windows are implemented by the MI355X path")
         self.dim = dim
@@ -46,4 +48,7 @@ class WindowAttention(nn.Module):
         qkv = HF.linear(x, self.qkv.weight, self.qkv.bias)
         o = HF.window_attention(qkv, self.qkv.bias, self.relative_position_bias_table, self.num_heads, window, shift,
                                 self.window_size[0], self.scale)
+        if self.proj_drop > 0.0 and self.training:        # window_attention.py:120-121: proj_drop(proj(x)); the residual is then added separately
+            y = HF.dropout(HF.linear(o, self.proj.weight, self.proj.bias), self.proj_drop)
+            return HF.add(res, y) if res is not None else y
         return HF.linear(o, self.proj.weight, self.proj.bias, res, want_stat)     # res: the block's residual, added in the GEMM epilogue

@@ -57,8 +57,6 @@ class SwinTransformer(nn.Module):
                  attn_drop_rate: float = 0.0, drop_path_rate: float = 0.0, patch_norm: bool = False, use_checkpoint: bool = False,
                  spatial_dims: int = 3, downsample="merging", norm_type: Union[Tuple, str] = "layer") -> None:
         super().__init__()
-        if drop_rate != 0.0 or drop_path_rate != 0.0:
-            raise NotImplementedError("dropout / drop-path > 0 is not implemented by the MI355X path")
         self.num_layers = len(depths)
         self.embed_dim = embed_dim
         self.patch_norm = patch_norm
@@ -68,11 +66,15 @@ class SwinTransformer(nn.Module):
         self.patch_embed = PatchEmbed(patch_size=self.patch_size, in_chans=in_chans, embed_dim=embed_dim,
                                       norm_type=norm_type if self.patch_norm else None, spatial_dims=spatial_dims)
         self.pos_drop = nn.Dropout(p=drop_rate)
+        self.drop_rate = float(drop_rate)
+        # stochastic depth decay rule of the reference (swin_transformer.py:88): linspace(0, drop_path_rate, sum(depths))
+        dpr = [float(v) for v in torch.linspace(0, drop_path_rate, sum(depths))]
         self.layers1, self.layers2, self.layers3, self.layers4 = nn.ModuleList(), nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
         down = look_up_option(downsample, MERGING_MODE) if isinstance(downsample, str) else downsample
         for i_layer in range(self.num_layers):
             layer = BasicLayer(dim=int(embed_dim * 2 ** i_layer), depth=depths[i_layer], num_heads=num_heads[i_layer],
-                               window_size=self.window_size, drop_path=[0.0] * depths[i_layer], mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                               window_size=self.window_size, drop_path=dpr[sum(depths[:i_layer]):sum(depths[:i_layer + 1])], mlp_ratio=mlp_ratio,
+                               qkv_bias=qkv_bias,
                                drop=drop_rate, attn_drop=attn_drop_rate, downsample=down, use_checkpoint=use_checkpoint,
                                norm_type=norm_type)
             (self.layers1, self.layers2, self.layers3, self.layers4)[i_layer].append(layer)
@@ -91,6 +93,7 @@ class SwinTransformer(nn.Module):
     def forward(self, x, normalize=True, styles=None, dtype=torch.float32):
         """x: NCDHW fp32 network input.  Returns 5 channels-last feature maps."""
         x0 = self.patch_embed(x, styles, dtype)
+        x0 = HF.dropout(x0, self.drop_rate, self.training)        # pos_drop (swin_transformer.py:149)
         outs = []
         cur = x0
         inst = normalize and self.norm_type in ("instance", "instance_cond")

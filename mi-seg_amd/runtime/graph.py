@@ -79,6 +79,8 @@ class GraphedStep:
     def __init__(self, model: torch.nn.Module, batch_shape: Sequence[int], out_shape: Sequence[int], warmup: int = 2, arena=None, split=False):
         """arena: optional runtime.arena.ParamArena of the model (gradients accumulate in its flat buffer, parameter
         re-layouts are refreshed by one kernel per step); without it every gradient is a tensor of the graph's pool.
+        Capture needs a quiescent model: drop every reference to outputs of earlier eager steps first - a live autograd graph keeps its
+        AccumulateGrad nodes on the eager stream, torch then inserts a cross-stream wait into the capture and hipStreamEndCapture crashes.
         split (needs an arena and a model with `forward(..., cut=)`): the step is recorded as TWO graphs - forward + the decoder
         side of the backward pass, then the encoder side - and `__call__(..., between=fn)` runs `fn()` between the two replays:
         the data-parallel step starts the all-reduce of the decoder-side gradients there, so RCCL overlaps the second graph."""

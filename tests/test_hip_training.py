@@ -342,3 +342,76 @@ def test_training_loop_on_the_hip_path_tracks_the_oracle(oracle_trained, dtype, 
                 assert torch.equal(v, sd0[k]), k
     finally:
         arena.detach()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dropout_and_drop_path_kernels(dtype):
+    """nn.Dropout / DropPath semantics (the Swin stack's `drop` and `dropout_path_rate`, swin_transformer_block.py:90-97,247): Bernoulli keep
+    with rescaling by 1 / (1 - p), the backward pass re-creates the forward's mask from its key, per-sample mode drops whole samples."""
+    from mi_seg_amd.hip import functional as HF
+    from mi_seg_amd.hip import ops
+    p = 0.25
+    x = (torch.randn(4, 12, 10, 8, 48, generator=torch.Generator().manual_seed(0)) + 3.0).to(DEV).to(dtype).requires_grad_(True)
+    ops.begin_step()
+    y = HF.dropout(x, p)
+    kept = y != 0
+    frac = float(kept.float().mean())
+    n = x.numel()
+    assert abs(frac - (1 - p)) < 5 * math.sqrt(p * (1 - p) / n) + 1e-4          # p is quantised to 1 / 65536
+    assert torch.allclose(y[kept].float(), (x.detach()[kept].float() / (1 - p)), rtol=1e-2 if dtype == torch.bfloat16 else 1e-6)
+    y.backward(torch.ones_like(y))
+    assert torch.equal(x.grad != 0, kept)                                        # the same mask, re-created from the key
+    assert torch.allclose(x.grad[kept].float(), torch.full_like(x.grad[kept].float(), 1 / (1 - p)), rtol=1e-2)
+    y2 = HF.dropout(x.detach(), p)                                               # another call site: another mask
+    assert not torch.equal(y2 != 0, kept)
+    ops.begin_step()                                                             # next step: new masks even for the same call site
+    y3 = HF.dropout(x.detach(), p)
+    assert not torch.equal(y3 != 0, kept)
+    # stochastic depth: whole samples are kept (and rescaled) or dropped; over many draws the keep rate is 1 - p
+    keep_counts = 0
+    for it in range(40):
+        ops.begin_step()
+        z = HF.drop_path(x.detach(), 0.5)
+        per_sample = (z != 0).flatten(1).float().mean(1)
+        assert bool(((per_sample == 0) | (per_sample == 1)).all())
+        keep_counts += int(per_sample.sum())
+    assert 50 <= keep_counts <= 110                                              # 160 Bernoulli(0.5) draws
+    assert HF.dropout(x, 0.0) is x and HF.dropout(x, 0.3, training=False) is x
+
+
+def test_swin_unetr_trains_with_dropout_and_stochastic_depth():
+    """--dropout_rate / --dropout_path_rate > 0 (utils/parser.py:23,38) on the headline model: eval mode is the dropout-free network,
+    train mode draws new masks every step - also when the step is a replayed hipGraph - and back-propagates through them."""
+    from mi_seg_amd.hip import ops
+    from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
+    from mi_seg_amd.runtime.graph import GraphedStep
+    from mi_seg_amd.utils.detfill import det_input, fill_module_
+    mk = lambda **kw: SwinUNETR((64, 64, 64), 1, 3, feature_size=12, num_heads=(3, 6, 12, 24), vit_norm_name=_norm("instance_cond"),
+                                encoder_norm_name=_norm("instance_cond"), decoder_norm_name=_norm("instance"), **kw)
+    plain, drop = mk(), mk(drop_rate=0.1, dropout_path_rate=0.3)
+    for m in (plain, drop):
+        fill_module_(m)
+        m.to(DEV)
+    assert [b.drop_path_rate for l in (drop.swinViT.layers1, drop.swinViT.layers4) for b in l[0].blocks] == pytest.approx([0.0, 0.3 / 7, 0.3 * 6 / 7, 0.3])
+    x = det_input(3, (2, 1, 64, 64, 64)).to(DEV)
+    cot = det_input(4, (2, 3, 64, 64, 64)).to(DEV)
+    drop.eval()
+    with torch.no_grad():
+        assert torch.equal(drop(x, [0, 1]), plain(x, [0, 1]))
+    drop.train()
+    outs = []
+    for _ in range(2):
+        drop.zero_grad(set_to_none=True)
+        ops.begin_step()
+        y = drop(x, [0, 1])
+        y.backward(cot)
+        assert bool(torch.isfinite(y).all()) and all(bool(torch.isfinite(p.grad).all()) for p in drop.parameters() if p.grad is not None)
+        outs.append(y.detach().clone())
+    assert not torch.equal(outs[0], outs[1])
+    del y          # no autograd graph of the model may be alive at capture time (its AccumulateGrad nodes live on the eager stream)
+    step = GraphedStep(drop, x.shape, cot.shape)
+    r1 = step(x, [0, 1], cot).detach().clone()
+    r2 = step(x, [0, 1], cot).detach().clone()
+    assert not torch.equal(r1, r2) and bool(torch.isfinite(r2).all())
+    with pytest.raises(NotImplementedError):
+        mk(attn_drop_rate=0.1)
