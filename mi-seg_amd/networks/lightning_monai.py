@@ -56,7 +56,7 @@ class LitMonai(_Base):
     # ---- logging hooks (Lightning provides them; the stand-alone variant records the last values)
     if not _HAS_PL:
         def log(self, name, value, **_kw):
-            self.logged[name] = float(value) if not isinstance(value, float) else value
+            self.logged[name] = float(value.detach()) if isinstance(value, torch.Tensor) else float(value)
 
         def log_dict(self, d, **_kw):
             for k, v in d.items():

@@ -415,3 +415,58 @@ def test_swin_unetr_trains_with_dropout_and_stochastic_depth():
     assert not torch.equal(r1, r2) and bool(torch.isfinite(r2).all())
     with pytest.raises(NotImplementedError):
         mk(attn_drop_rate=0.1)
+
+
+def test_litmonai_training_and_validation_steps_on_the_hip_path():
+    """SURVEY 8(a) rows a14 / a15 end to end on the device: `LitMonai.from_argparse_args` (reference networks/lightning_monai.py:113-144) ->
+    `training_step` (batch keys image / label / modality, fused DiceFocal with --no_include_background, :149-166) and `validation_step`
+    (sliding window + Dice, :181-219), against the same computation on the CPU: oracle forward + the torch restatement of the loss / metric."""
+    import argparse
+    from mi_seg_amd.data.synthetic import synthetic_volume
+    from mi_seg_amd.networks.lightning_monai import LitMonai
+    from mi_seg_amd.training.inferer import sliding_window_inference
+    from mi_seg_amd.training.metrics import dice_from_logits
+    from mi_seg_amd.utils.detfill import fill_module_
+    from mi_seg_amd.utils.parser import add_data_argparse_args, add_model_argparse_args, add_tune_argparse_args
+    from oracle import nets as ON
+    p = argparse.ArgumentParser()
+    add_tune_argparse_args(add_data_argparse_args(add_model_argparse_args(p)))
+    a = p.parse_args(["--model_name=swin_unetr", "--out_channels=6", "--feature_size=12", "--num_heads=3", "--roi_x=64", "--roi_y=64", "--roi_z=64",
+                      "--encoder_norm_name=instance_cond", "--vit_norm_name=instance_cond", "--no_include_background", "--sw_batch_size=4"])
+    lit = LitMonai.from_argparse_args(a)
+    fill_module_(lit.model)
+    lit = lit.to(DEV)
+    sd = {k: v.detach().cpu().clone() for k, v in lit.model.state_dict().items()}
+    cfg = ON.swin_unetr_cfg(feature_size=12)
+    img, lab = synthetic_volume((96, 80, 64), 11, 1)
+    crop = (slice(None), slice(None), slice(16, 80), slice(8, 72), slice(0, 64))
+    batch = {"image": img[crop].to(DEV), "label": lab[crop].float().to(DEV), "modality": torch.tensor([1], device=DEV)}
+    out = lit.training_step(batch, 0)
+    assert set(out) == {"loss"} and out["loss"].is_cuda
+    out["loss"].backward()
+    assert all(bool(torch.isfinite(q.grad).all()) for q in lit.model.parameters() if q.grad is not None)
+    with torch.no_grad():
+        want = lit.criterion.forward_torch(ON.swin_unetr_forward(sd, img[crop], [1], cfg).double(), lab[crop])
+    assert abs(float(out["loss"]) - float(want)) < 1e-4 * abs(float(want))
+    assert abs(lit.logged["train/loss"] - float(want)) < 1e-4 * abs(float(want))
+    # a batch without the modality key must be refused by the conditional norms, like the reference (dynunet_block.py:102-103)
+    with pytest.raises(ValueError):
+        lit.training_step({"image": batch["image"], "label": batch["label"]}, 0)
+    # validation: whole volume through the sliding window (12 windows of 64^3, batches of 4), loss + Dice
+    val = lit.validation_step({"image": img.to(DEV), "label": lab.float().to(DEV), "modality": torch.tensor([1], device=DEV)}, 0)
+    with torch.no_grad():
+        logits = sliding_window_inference(img, 64, 1, lambda xx, mm: ON.swin_unetr_forward(sd, xx, mm, cfg), overlap=0.5, modalities=[1])
+        want_dice = float(torch.nanmean(dice_from_logits(logits, lab, 6)))
+        want_loss = float(lit.criterion.forward_torch(logits.double(), lab))
+    assert abs(float(val["accuracy"]) - want_dice) < 1e-4 and abs(float(val["loss"]) - want_loss) < 1e-4 * abs(want_loss)
+    assert abs(lit.logged["val/accuracy/avg"] - want_dice) < 1e-4
+    lit._shared_eval_end([val], "val")
+    assert "val/accuracy/modality_1" in lit.logged
+    # the fused optimiser built from the module's hyper-parameters
+    from mi_seg_amd.runtime.arena import ParamArena
+    arena = ParamArena([q for q in lit.model.parameters() if q.requires_grad], torch.float32)
+    try:
+        opt = lit.configure_fused_optimizer(arena)
+        assert opt.kind == "adamw" and opt.lr == a.lr and opt.weight_decay == a.reg_weight
+    finally:
+        arena.detach()
