@@ -32,7 +32,7 @@ def run(S, Cin, Cout, dtype, iters=10, what=("fwd", "wgrad")):
 
 if __name__ == "__main__":
     what = tuple(sys.argv[1].split(",")) if len(sys.argv) > 1 else ("fwd", "wgrad")
-    shapes = [(96, 48, 48), (96, 96, 48), (48, 48, 48), (24, 96, 96), (12, 192, 192), (6, 384, 384), (3, 768, 768)]
+    shapes = [(96, 48, 48), (96, 96, 48), (96, 48, 96), (48, 48, 48), (24, 96, 96), (12, 192, 192), (6, 384, 384), (3, 768, 768)]
     if len(sys.argv) > 2:
         shapes = shapes[:int(sys.argv[2])]
     for s in shapes:

@@ -1,5 +1,6 @@
 """GPU parity tests, kernel level: every C-ABI entry point against a plain PyTorch fp32 reference of the same op
 (run on the device) -- tolerances: fp32 path 2e-4 relative L2 (north_star asks 1e-3), bf16 path 2e-2."""
+import os
 import pytest
 import torch
 import torch.nn.functional as F
