@@ -185,7 +185,7 @@ template <class T, int NT, int WD = 1, bool EPI = false>
 __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, const T* __restrict__ wpk,
                                                              ConvGeom g, int Cin, int CinP, int Cout, int CoP, bool vec_x, bool vec_y,
                                                              float* __restrict__ scratch, int chunks_per_split, const T* __restrict__ res, int64_t ldres,
-                                                             double* __restrict__ stat) {
+                                                             double* __restrict__ stat, int ny) {
   typedef typename Vec16<T>::type VT;
   constexpr int KPC = MmaC<T>::KPC;
   constexpr int GPT = 6, CHUNK = GPT * KPC;
@@ -199,10 +199,16 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
   // workgroup -> brick.  The hardware deals consecutive workgroups to the 8 XCDs round-robin, each with its own L2: with bid = blockIdx.x
   // the spatial neighbours of a brick, which share a third of its halo, run on seven OTHER XCDs and every halo plane is fetched from HBM
   // by each of them (measured 2.2 x the algorithmic bytes).  XCD k takes the k-th contiguous eighth of the bricks instead.
-  int bid;
+  // The output-channel groups of a brick (ny of them: 2 for the data gradient 48 -> 96 at 96^3) are consecutive units of one XCD, so they
+  // run side by side and share the halo, the residual rows and the output rows' cache lines in that L2: as grid.y they were dispatched a
+  // whole grid.x apart, each group fetched the halo from HBM again and read / wrote its 96-byte halves of the 192-byte rows as partial
+  // lines long after the other half had left the cache (48 -> 96 with the fused residual: 317 us against 215 without it).
+  int bid, ygrp;
   {
     const int nb = gridDim.x, xcd = blockIdx.x & 7, q = nb >> 3, r = nb & 7;
-    bid = xcd * q + (xcd < r ? xcd : r) + (blockIdx.x >> 3);
+    const int unit = xcd * q + (xcd < r ? xcd : r) + (blockIdx.x >> 3);
+    bid = unit / ny;
+    ygrp = unit - bid * ny;
   }
   // inside an XCD's range the bricks advance d-fastest, then h, then w: a brick shares 2 of its 6 halo planes with its d- and with its
   // h-neighbour and only 2 of 18 columns with its w-neighbour, and the L2 (4 MB) has to hold the bricks between two neighbours for the
@@ -212,7 +218,7 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
   const int bw = bid % g.nbw;
   const int b = bid / g.nbw;
   const int d0 = bd * FBD, h0 = bh * FBH, w0 = bw * FBW;
-  const int n0 = blockIdx.y * NROWS;
+  const int n0 = ygrp * NROWS;
   const int fi = lane & 15, fq = lane >> 4;
   f32x4 acc[4][NT];
 #pragma unroll
@@ -1195,12 +1201,13 @@ static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
     const int CoP = round_up(p->Cout, 16);
     const size_t lds = (size_t)6 * FPS * 16 + (size_t)2 * 12 * 16 * nt * 16;
     MISEG_REQUIRE((int64_t)p->B * p->D * p->H * p->W < (1LL << 31), MISEG_E_UNSUPPORTED, "conv3_fwd: more than 2^31 voxels");
-    dim3 grid(nbr, cdiv(p->Cout, 16 * nt), ksplit);
+    const int ny = cdiv(p->Cout, 16 * nt);
+    dim3 grid(nbr * ny, 1, ksplit);
 #define F96_LAUNCH(n, wd, epi)                                                                                                               \
     (void)hipFuncSetAttribute((const void*)conv3_fwd96_kernel<T, n, wd, epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
     conv3_fwd96_kernel<T, n, wd, epi><<<grid, 256, lds, s>>>((const T*)p->x, p->ldx, (T*)p->y, p->ldy, (const T*)p->wpk, gf, p->Cin, CinP,    \
                                                              p->Cout, CoP, vec_x, vec_y, scratch, cps, scratch ? nullptr : (const T*)p->res,   \
-                                                             p->ldres, (double*)p->stat)
+                                                             p->ldres, (double*)p->stat, ny)
 #define F96_CASE(n, wd)                                                                                                                      \
   case n:                                                                                                                                   \
     if (!scratch && (p->res || p->stat)) { F96_LAUNCH(n, wd, true); } else { F96_LAUNCH(n, wd, false); }                                    \

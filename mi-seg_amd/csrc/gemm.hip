@@ -281,7 +281,16 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_g;
 template <int K16, bool GELU, int NCH = 12 /* n-tiles per accumulator chunk: fewer for the long rows (K >= 288), whose A fragments fill the registers */,
           bool STAT = false, bool SCAT = false>
 __global__ void __launch_bounds__(256, 2) gemm_nt_stream_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ W, int64_t ldw,
-                                                                bf16* __restrict__ C, int64_t ldc, int M, int N, Epi epi) {
+                                                                bf16* __restrict__ C, int64_t ldc, int M, int Nfull, Epi epi, int N) {
+  // blockIdx.y = column group of N columns (the mid-size token counts: 13,824 rows are 108 workgroups of 128 rows - with the whole weight
+  // staged by each of them, 73 KB for fc1 at stage 1, the staging loop was most of the 33 us; column groups give 4x the workgroups, each
+  // staging a quarter).  Everything below works on the group's slice: pointers advanced by n_off columns / weight rows.
+  const int n_off = blockIdx.y * N;
+  W += (int64_t)n_off * ldw;
+  C += n_off;
+  if (epi.bias) epi.bias += n_off;
+  if (epi.res) epi.res = reinterpret_cast<const bf16*>(epi.res) + n_off;
+  if (epi.aux) epi.aux = reinterpret_cast<bf16*>(epi.aux) + n_off;
   const float* bias = epi.bias;
   constexpr int K = K16 * 16, KS32 = K / 32, TAIL = K16 & 1;
   constexpr int ROWB = K * 2 + 16;   // weight row stride in LDS: conflict-free 16-byte fragment reads
@@ -357,9 +366,9 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_stream_kernel(const bf16* __re
               const f32x4 v = epi_vec4_bf16(acc[mt][j] + b4, row, n, epi, GELU);
               const bf16x4 o4 = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
               if constexpr (SCAT) {
-                const int jj = n / epi.sco, co = n - jj * epi.sco;
+                const int jj = (n + n_off) / epi.sco, co = (n + n_off) - jj * epi.sco;
                 const int64_t drow = srow + ((int64_t)(jj >> 2) * (2 * epi.sh) + ((jj >> 1) & 1)) * (2 * epi.sw) + (jj & 1);
-                *reinterpret_cast<bf16x4*>(C + drow * ldc + co) = o4;
+                *reinterpret_cast<bf16x4*>(C - n_off + drow * ldc + co) = o4;
               } else {
                 *reinterpret_cast<bf16x4*>(crow + n) = o4;
               }
@@ -403,7 +412,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_stream_kernel(const bf16* __re
       float tot = 0.f;
 #pragma unroll 16
       for (int i = 0; i < 64; ++i) tot += rp[i];
-      atomicAdd(epi.stat + ((int64_t)(blockIdx.x & 15) * N + col) * 2 + k, (double)tot);      // [16 replicas][B = 1][N][2]
+      atomicAdd(epi.stat + ((int64_t)(blockIdx.x & 15) * Nfull + n_off + col) * 2 + k, (double)tot);      // [16 replicas][B = 1][N][2]
     }
   }
 }
@@ -819,6 +828,14 @@ extern "C" size_t miseg_gemm_workspace_bytes(const miseg_gemm_params* p) {
 extern "C" int miseg_gemm_fuses_stat(const miseg_gemm_params* p);
 extern "C" int miseg_gemm_fuses_scatter(const miseg_gemm_params* p);
 
+// column groups of the streaming NT kernel: the smallest divisor d of the N / 16 column tiles that brings the grid to >= 300 workgroups
+static int nt_stream_groups(int blocks, int N) {
+  const int tiles = N / 16;
+  for (int d = 1; d <= tiles; ++d)
+    if (tiles % d == 0 && blocks * d >= 300) return d;
+  return tiles;
+}
+
 template <class T, class TO>
 static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
   constexpr int N16 = Vec16<T>::N;
@@ -892,7 +909,7 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
         if (blocks > cap) blocks = cap;
 #define SC_CASE(k16)                                                                                                                         \
   (void)hipFuncSetAttribute((const void*)gemm_nt_stream_kernel<k16, false, 12, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-  gemm_nt_stream_kernel<k16, false, 12, false, true><<<blocks, 256, lds, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, epi)
+  gemm_nt_stream_kernel<k16, false, 12, false, true><<<blocks, 256, lds, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, epi, p->N)
         if (p->K == 48) { SC_CASE(3); } else { SC_CASE(6); }
 #undef SC_CASE
         MISEG_LAUNCH_CHECK("gemm_nt_stream(scatter)");
@@ -902,11 +919,13 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
         const int mtiles = cdiv(p->M, 32);
         int blocks = cdiv(mtiles, 4);
         if (blocks > 512) blocks = 512;
-        size_t lds2 = (size_t)2 * p->N * 65 * sizeof(float);
-        if (lds2 < lds) lds2 = lds;
+        const int ns = nt_stream_groups(blocks, p->N), nper = p->N / ns;
+        size_t lds2 = (size_t)2 * nper * 65 * sizeof(float);
+        const size_t ldsg = (size_t)nper * (p->K * 2 + 16) + (size_t)nper * 4;
+        if (lds2 < ldsg) lds2 = ldsg;
 #define STS_CASE(k16)                                                                                                                        \
   (void)hipFuncSetAttribute((const void*)gemm_nt_stream_kernel<k16, false, 6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
-  gemm_nt_stream_kernel<k16, false, 6, true><<<blocks, 256, lds2, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, epi)
+  gemm_nt_stream_kernel<k16, false, 6, true><<<dim3(blocks, ns), 256, lds2, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, epi, nper)
         if (p->K == 48) { STS_CASE(3); } else if (p->K == 96) { STS_CASE(6); } else { STS_CASE(12); }
 #undef STS_CASE
         MISEG_LAUNCH_CHECK("gemm_nt_stream(stat)");
@@ -917,9 +936,11 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
         int blocks = cdiv(mtiles, 4);
         const int cap = lds > 80 * 1024 ? 256 : 512;
         if (blocks > cap) blocks = cap;
+        const int ns = nt_stream_groups(blocks, p->N), nper = p->N / ns;
+        const size_t ldsg = (size_t)nper * (p->K * 2 + 16) + (size_t)nper * 4;
 #define ST_CASE(k16, g, nch)                                                                                                                  \
-  (void)hipFuncSetAttribute((const void*)gemm_nt_stream_kernel<k16, g, nch>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
-  gemm_nt_stream_kernel<k16, g, nch><<<blocks, 256, lds, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, epi)
+  (void)hipFuncSetAttribute((const void*)gemm_nt_stream_kernel<k16, g, nch>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg);         \
+  gemm_nt_stream_kernel<k16, g, nch><<<dim3(blocks, ns), 256, ldsg, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, epi, nper)
         const bool ge = p->act == MISEG_ACT_GELU;
         if (p->K == 48) { if (ge) { ST_CASE(3, true, 12); } else { ST_CASE(3, false, 12); } }
         else if (p->K == 96) { if (ge) { ST_CASE(6, true, 12); } else { ST_CASE(6, false, 12); } }
