@@ -133,6 +133,8 @@ def main():
     if not a.no_graph:
         from mi_seg_amd.runtime.graph import GraphedStep
         graphed = GraphedStep(model, (1, 1, 96, 96, 96), (1, 6, 96, 96, 96), arena=arena, split=overlap)
+        graphed.cot.copy_(cot)
+        cot = graphed.cot          # the cotangent is constant here: it lives in the graph's static buffer (a loss kernel would write it there)
 
     def step(i, eager=False, sample=None, comm=True):
         k = order[i % len(order)] if sample is None else sample

@@ -38,6 +38,7 @@ class GraphedForward:
         dev = next(model.parameters()).device
         self.x = torch.zeros(*batch_shape, dtype=torch.float32, device=dev)
         self.styles = torch.zeros(batch_shape[0], dtype=torch.int32, device=dev)
+        self._styles_host = None
         self.warmup = warmup
         self.graphs = {}
 
@@ -94,6 +95,7 @@ class GraphedStep:
         self.x = torch.zeros(*batch_shape, dtype=torch.float32, device=dev)
         self.cot = torch.zeros(*out_shape, dtype=torch.float32, device=dev)
         self.styles = torch.zeros(batch_shape[0], dtype=torch.int32, device=dev)
+        self._styles_host = None
         self.warmup = warmup
         self.graphs: Dict[Tuple[int, ...], Tuple[torch.cuda.CUDAGraph, List, torch.Tensor]] = {}
 
@@ -162,8 +164,11 @@ class GraphedStep:
         (arena.allreduce_end does it after the exchange)."""
         host = _check_styles(self.model, modalities, self.x.shape[0])
         self.x.copy_(x, non_blocking=True)
-        self.cot.copy_(cot, non_blocking=True)
-        self.styles.copy_(torch.tensor(host, dtype=torch.int32), non_blocking=True)
+        if cot.data_ptr() != self.cot.data_ptr():      # a caller that writes d(loss)/d(logits) into `self.cot` itself (the fused loss) skips the copy
+            self.cot.copy_(cot, non_blocking=True)
+        if host != self._styles_host:                  # (a pageable host tensor per step was a synchronous staging copy)
+            self.styles.copy_(torch.tensor(host, dtype=torch.int32), non_blocking=True)
+            self._styles_host = list(host)
         key = tuple(sorted(set(host))) + (len(host),)
         if key not in self.graphs:
             self.graphs[key] = self._capture(host)
