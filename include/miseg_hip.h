@@ -233,7 +233,7 @@ typedef struct {
    * res (ldres): added to the result before rounding (the other gradient of a forked input when this is the data-gradient pass);
    * stat: fp64 [16][B][Cout][2] (miseg_instnorm_stat_bytes, zero on entry) - per-channel sum / sum of squares of the ROUNDED
    *       output, i.e. what miseg_instnorm_stats would compute from y (dynunet_block.py:105-107: every conv feeds a norm);
-   *       not with a workspace (split reduction). */
+   *       with a workspace (split reduction) the second launch, which sums the partial slabs into y, computes them. */
   const void* res; int64_t ldres;
   void* stat;
 } miseg_conv3_params;

@@ -107,4 +107,9 @@ template <class F> static inline int dispatch_dtype(int dtype, F&& f) {
   return set_error(MISEG_E_BADARG, "unknown dtype %d", dtype);
 }
 
+// norm.hip: second launch of a split convolution - y = round(sum of nslabs fp32 slabs [B * S][C] (+ res)), and the instance-norm statistics
+// of y into `stat` (replicated fp64 layout of miseg_instnorm_stats; may be null)
+int slabs_to_out_stats(const float* slabs, int nslabs, void* y, int64_t ldy, const void* res, int64_t ldres, int B, int S, int C, int dtype, double* stat,
+                       hipStream_t stream);
+
 }  // namespace miseg

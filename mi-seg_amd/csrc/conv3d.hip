@@ -461,18 +461,6 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
   }
 }
 
-template <class T>
-__global__ void __launch_bounds__(256) conv3_scratch_to_out_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t ldd, int64_t rows, int C, int nslabs,
-                                                                   const T* __restrict__ res, int64_t ldres) {
-  const int64_t total = rows * C;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    float a = src[i];
-    for (int z = 1; z < nslabs; ++z) a += src[(int64_t)z * total + i];
-    if (res) a += to_f32(res[(i / C) * ldres + i % C]);
-    dst[(i / C) * ldd + i % C] = from_f32<T>(a);
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // weight packing.  Row-major packs (generic kernel):   fwd[co][tap][ciP] = w[co][ci][tap] ; bwd[ci][tap][coP] = w[co][ci][26-tap]
 // Planar packs (fast path, chosen when the K-side channel row is a multiple of 96 bytes):
@@ -1192,7 +1180,6 @@ static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
     ksplit = cdiv(nchunks, cps);
     float* scratch = nullptr;
     const int64_t nvox = (int64_t)p->B * p->D * p->H * p->W;
-    MISEG_REQUIRE(!(p->stat && ksplit > 1), MISEG_E_UNSUPPORTED, "conv3_fwd: fused statistics with a split reduction");
     if (ksplit > 1) {
       MISEG_REQUIRE(p->workspace, MISEG_E_BADARG, "conv3_fwd: workspace required (miseg_conv3_fwd_workspace_bytes)");
       scratch = (float*)p->workspace;
@@ -1215,12 +1202,9 @@ static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
     switch (nt) { F96_CASE(1, 3) F96_CASE(2, 2) F96_CASE(3, 3) }
 #undef F96_CASE
 #undef F96_LAUNCH
-    if (scratch) {
-      int cg = (int)((nvox * p->Cout + 255) / 256);
-      if (cg > 4096) cg = 4096;
-      conv3_scratch_to_out_kernel<T><<<cg, 256, 0, s>>>(scratch, (T*)p->y, p->ldy, nvox, p->Cout, ksplit, (const T*)p->res, p->ldres);
-    }
     MISEG_LAUNCH_CHECK("conv3_fwd96");
+    if (scratch)      // sum of the slabs + residual -> y, with the statistics of y when asked for (one launch)
+      return slabs_to_out_stats(scratch, ksplit, p->y, p->ldy, p->res, p->ldres, p->B, p->D * p->H * p->W, p->Cout, p->dtype, (double*)p->stat, s);
     return MISEG_OK;
   }
   MISEG_REQUIRE(!p->res && !p->stat, MISEG_E_UNSUPPORTED, "conv3_fwd: fused residual / statistics need 96-byte channel chunks");

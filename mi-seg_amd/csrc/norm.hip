@@ -147,6 +147,71 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_stats_kernel(const T* _
   block_reduce_to_stat<VEC>(red, s, q, tx, ty, tx_n, ty_n, c0, C, stat + ((int64_t)(chunk % NORM_R) * gridDim.y + b) * C * 2);
 }
 
+// The second launch of a convolution split over its input chunks (conv3d.hip: the small grids of the deep stages): y = round(sum of the
+// fp32 slabs [+ res]) and, in the same pass, the instance-norm statistics of y - the split path used to leave them to a separate
+// miseg_instnorm_stats launch over the tensor it had just written (one launch-and-drain latency per convolution of stages >= 3).
+// Same thread geometry and replicated fp64 reduction as instnorm_stats_kernel; vector lanes read VEC floats of every slab.
+template <class T, int VEC>
+__global__ void __launch_bounds__(NORM_THREADS) slabs_to_out_stats_kernel(const float* __restrict__ slabs, int nslabs, int64_t slab_stride, T* __restrict__ y,
+                                                                          int64_t ldy, const T* __restrict__ res, int64_t ldres, int S, int C, int cv, int tx_n,
+                                                                          int ty_n, int rpb, double* __restrict__ stat) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int b = blockIdx.y, chunk = blockIdx.x, c0 = blockIdx.z * tx_n;
+  const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
+  const int r0 = chunk * rpb, r1 = min(S, r0 + rpb);
+  const int c = c0 + tx;
+  float s[VEC], q[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s[i] = q[i] = 0.f;
+  if (ty < ty_n && c < cv) {
+    for (int r = r0 + ty; r < r1; r += ty_n) {
+      const int64_t row = (int64_t)b * S + r;
+      float a[VEC];
+      const float* p = slabs + row * C + c * VEC;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) a[i] = 0.f;
+      if constexpr (VEC % 4 == 0) {
+        for (int z0 = 0; z0 < nslabs; z0 += 4) {      // four slabs' loads in flight together (clamped: a repeated slab is not added)
+          f32x4 v[4][VEC / 4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int z = min(z0 + u, nslabs - 1);
+#pragma unroll
+            for (int k = 0; k < VEC / 4; ++k) v[u][k] = *reinterpret_cast<const f32x4*>(p + z * slab_stride + 4 * k);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (z0 + u < nslabs) {
+#pragma unroll
+              for (int k = 0; k < VEC / 4; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[4 * k + e] += v[u][k][e];
+            }
+          }
+        }
+      } else {
+        for (int z = 0; z < nslabs; ++z)
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) a[i] += p[z * slab_stride + i];
+      }
+      RowVec<T, VEC> o;
+      if (res) {
+        o.load(res + row * ldres + c * VEC);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) a[i] += o.v[i];
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        o.v[i] = to_f32(from_f32<T>(a[i]));      // statistics of the stored (rounded) values, as miseg_instnorm_stats would read them
+        s[i] += o.v[i];
+        q[i] = fmaf(o.v[i], o.v[i], q[i]);
+      }
+      o.store(y + row * ldy + c * VEC);
+    }
+  }
+  if (stat) block_reduce_to_stat<VEC>(red, s, q, tx, ty, tx_n, ty_n, c0, C, stat + ((int64_t)(chunk % NORM_R) * gridDim.y + b) * C * 2);
+}
+
 struct StylePtrs {
   const float* gamma[MISEG_MAX_STYLES];
   const float* beta[MISEG_MAX_STYLES];
@@ -843,6 +908,38 @@ __global__ void __launch_bounds__(256) layernorm_bwd_param_kernel(const T* __res
 using namespace miseg;
 
 static bool aligned16(const void* p) { return ((uintptr_t)p % 16) == 0; }
+
+namespace miseg {
+// internal (conv3d.hip): enqueue the kernel above; stat may be null (plain sum + convert)
+int slabs_to_out_stats(const float* slabs, int nslabs, void* y, int64_t ldy, const void* res, int64_t ldres, int B, int S, int C, int dtype, double* stat,
+                       hipStream_t stream) {
+  return dispatch_dtype(dtype, [&](auto* tag) -> int {
+    typedef typename std::remove_pointer<decltype(tag)>::type T;
+    constexpr int V = Vec16<T>::N;
+    const bool al = aligned16(y) && ldy % V == 0 && (!res || (aligned16(res) && ldres % V == 0)) && C % 4 == 0 && aligned16(slabs);
+    // the tensors of a split convolution are tiny (27 .. 1728 rows): 8 vector columns x 32 rows per workgroup pass, so that even the 3^3
+    // volume is a dozen workgroups (norm_geom's >= 4 rows per lane made it three, 15 us for 16 slabs of 83 KB)
+    NormGeom g;
+    g.vec = (al && C % V == 0) ? V : 1;
+    g.cv = C / g.vec;
+    g.tx = g.cv < 8 ? g.cv : 8;
+    g.ty = NORM_THREADS / g.tx;
+    g.ctiles = cdiv(g.cv, g.tx);
+    int per = cdiv(S, g.ty * 64);
+    g.rpb = g.ty * (per < 1 ? 1 : per > 8 ? 8 : per);
+    g.chunks = cdiv(S, g.rpb);
+    dim3 grid(g.chunks, B, g.ctiles);
+    const size_t sh = (size_t)g.ty * 2 * g.tx * g.vec * sizeof(float);
+    const int64_t stride = (int64_t)B * S * C;
+    if (g.vec == 1)
+      slabs_to_out_stats_kernel<T, 1><<<grid, NORM_THREADS, sh, stream>>>(slabs, nslabs, stride, (T*)y, ldy, (const T*)res, ldres, S, C, g.cv, g.tx, g.ty, g.rpb, stat);
+    else
+      slabs_to_out_stats_kernel<T, V><<<grid, NORM_THREADS, sh, stream>>>(slabs, nslabs, stride, (T*)y, ldy, (const T*)res, ldres, S, C, g.cv, g.tx, g.ty, g.rpb, stat);
+    MISEG_LAUNCH_CHECK("slabs_to_out_stats");
+    return MISEG_OK;
+  });
+}
+}  // namespace miseg
 
 extern "C" size_t miseg_instnorm_stat_bytes(int B, int C) { return (size_t)NORM_R * B * C * 2 * sizeof(double); }
 

@@ -573,7 +573,7 @@ def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False):
     # algorithmic bytes: x read once, y written once, the weight pack, the fused residual read once
     nbytes = float(x.element_size()) * (B * D * H * W * (Cin + Cout + (Cout if fuse_res else 0)) + wpk.numel())
     stat = None
-    if want_stat and fast and not wsb:
+    if want_stat and fast:      # (a split reduction computes them in its second launch)
         stat = STAT_POOL.take(lib.miseg_instnorm_stat_bytes(B, Cout) // 8, x.device).view(-1, B, Cout, 2)
     mk = lambda st: L.Conv3(_ptr(x), ld, _ptr(out), rows(out)[0], _ptr(wpk), B, D, H, W, Cin, Cout, _dt(x), _ptr(ws),
                             _ptr(res) if fuse_res else None, rows(res)[0] if fuse_res else 0, _ptr(st))
