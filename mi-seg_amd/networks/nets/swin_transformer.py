@@ -68,7 +68,7 @@ class SwinTransformer(nn.Module):
         self.pos_drop = nn.Dropout(p=drop_rate)
         self.drop_rate = float(drop_rate)
         # stochastic depth decay rule of the reference (swin_transformer.py:88): linspace(0, drop_path_rate, sum(depths))
-        dpr = [float(v) for v in torch.linspace(0, drop_path_rate, sum(depths))]
+        dpr = [float(v) for v in torch.linspace(0, drop_path_rate, sum(depths), device="cpu")]      # (a model may be built under torch.device("meta"))
         self.layers1, self.layers2, self.layers3, self.layers4 = nn.ModuleList(), nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
         down = look_up_option(downsample, MERGING_MODE) if isinstance(downsample, str) else downsample
         for i_layer in range(self.num_layers):

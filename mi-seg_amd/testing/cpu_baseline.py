@@ -36,7 +36,9 @@ def host_cpu():
     return model, (len(cores) or len(allowed)), len(allowed)
 
 
-def cpu_baseline(workload="c2"):
+def baseline_case(workload="c2"):
+    """(state dict of deterministic fp32 weights, oracle config, oracle forward, input, cotangent) of the timed workload; the key list
+    and shapes come from the product model built on the meta device (tests/test_host_api.py builds both cases)"""
     root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     if root not in sys.path:
         sys.path.insert(0, root)
@@ -44,8 +46,6 @@ def cpu_baseline(workload="c2"):
     from oracle.functional import relative_position_index
     from ..networks.norms.utils import parse_normalization
     from ..utils.detfill import det_input, det_values
-    model_name, phys, logical = host_cpu()
-    torch.set_num_threads(phys)
     cond, inst = parse_normalization("instance_cond", True, 4, 2), parse_normalization("instance", True, 4, 2)
     with torch.device("meta"):
         if workload == "c3":
@@ -66,6 +66,14 @@ def cpu_baseline(workload="c2"):
         cfg, fwd = ON.swin_unetr_cfg(feature_size=48), ON.swin_unetr_forward
     x = det_input(1234, (1, 1, 96, 96, 96))
     g = det_input(4321, (1, 6, 96, 96, 96))
+    return sd, cfg, fwd, x, g
+
+
+def cpu_baseline(workload="c2"):
+    sd, cfg, fwd, x, g = baseline_case(workload)
+    model_name, phys, logical = host_cpu()
+    torch.set_num_threads(phys)
+
     def one():
         for v in sd.values():
             if v.is_floating_point():

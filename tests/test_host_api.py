@@ -205,3 +205,16 @@ def test_litmonai_surface():
     assert isinstance(conf["optimizer"], torch.optim.AdamW) and conf["lr_scheduler"]["monitor"] == "val/loss/avg"
     with pytest.raises(ValueError):
         LitMonai(lit.model, 6, criterion="nope")
+
+
+@pytest.mark.parametrize("workload", ["c2", "c3"])
+def test_cpu_baseline_case_builds(workload):
+    """bench.py's cpu_baseline leg builds the product model on the meta device for its key list (a `torch.linspace(...).item()` in a
+    constructor broke exactly that once): both timed workloads must construct, with every oracle weight present and finite"""
+    from mi_seg_amd.testing.cpu_baseline import baseline_case, host_cpu
+    sd, cfg, fwd, x, g = baseline_case(workload)
+    assert len(sd) == (273 if workload == "c2" else 280)
+    assert all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())
+    assert tuple(x.shape) == (1, 1, 96, 96, 96) and tuple(g.shape) == (1, 6, 96, 96, 96) and callable(fwd)
+    name, phys, logical = host_cpu()
+    assert phys >= 1 and logical >= phys and isinstance(name, str)
