@@ -376,7 +376,8 @@ class _Mlp(Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, res, want_stat=False):
-        h = torch.empty(x.shape[:-1] + (w1.shape[0],), dtype=x.dtype, device=x.device)
+        # the pre-activation is only the backward pass's input (gelu'): an inference forward (no_grad) does not write it
+        h = torch.empty(x.shape[:-1] + (w1.shape[0],), dtype=x.dtype, device=x.device) if any(ctx.needs_input_grad) else None
         a = ops.gemm_nt(x, ops.cast_matrix(w1, x.dtype), b1, act=L.ACT_GELU, preact_out=h)
         y = ops.gemm_nt(a, ops.cast_matrix(w2, x.dtype), b2, res=res, want_stat=want_stat)
         ctx.save_for_backward(x, h, a, w1, w2)
