@@ -931,6 +931,50 @@ __global__ void __launch_bounds__(256) head_bwd_dx_team_kernel(const float* __re
   }
 }
 
+// The same for up to 8 classes and whole 256-voxel tiles: the lane-per-item kernel above reads the six dy planes with 43-byte runs (six
+// lanes share a voxel) and re-reads its weights from LDS for every item - 57 us for 106 MB on the 96^3 head.  Here a workgroup stages the
+// dy tile with one coalesced 1 KB run per class, a lane keeps the weights of ITS channel vector in registers for all its tiles, and the
+// 3 KB of a pass (32 voxels x 96 bytes at Cin 48) leave as one contiguous run.
+template <class T, int VEC>
+__global__ void __launch_bounds__(256) head_bwd_dx_tile_kernel(const float* __restrict__ dy, T* __restrict__ dx, int64_t lddx, const float* __restrict__ w, int S,
+                                                               int Cin, int Cout, int64_t ntiles) {
+  __shared__ __attribute__((aligned(16))) float gl[256 * 8];      // [voxel][class, padded to 8]
+  const int cv = Cin / VEC, vpp = 256 / cv, tid = threadIdx.x;
+  const int vl = tid / cv, cvec = tid - vl * cv;
+  const bool worker = vl < vpp;
+  float wr[8][VEC];
+#pragma unroll
+  for (int co = 0; co < 8; ++co)
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) wr[co][k] = (worker && co < Cout) ? w[co * Cin + cvec * VEC + k] : 0.f;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int64_t v0 = t * 256;
+    const int b = (int)(v0 / S);
+    const int64_t s0 = v0 - (int64_t)b * S;
+    float g8[8];
+#pragma unroll
+    for (int co = 0; co < 8; ++co) g8[co] = co < Cout ? dy[((int64_t)b * Cout + co) * S + s0 + tid] : 0.f;
+    __syncthreads();      // the previous tile's readers are done
+    *reinterpret_cast<f32x4*>(gl + tid * 8) = f32x4{g8[0], g8[1], g8[2], g8[3]};
+    *reinterpret_cast<f32x4*>(gl + tid * 8 + 4) = f32x4{g8[4], g8[5], g8[6], g8[7]};
+    __syncthreads();
+    if (worker) {
+      for (int vox = vl; vox < 256; vox += vpp) {
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gl + vox * 8), gb = *reinterpret_cast<const f32x4*>(gl + vox * 8 + 4);
+        const float g[8] = {ga[0], ga[1], ga[2], ga[3], gb[0], gb[1], gb[2], gb[3]};
+        V<T, VEC> o;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) o.v[k] = 0.f;
+#pragma unroll
+        for (int co = 0; co < 8; ++co)
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) o.v[k] = fmaf(g[co], wr[co][k], o.v[k]);
+        o.store(dx + (v0 + vox) * lddx + cvec * VEC);
+      }
+    }
+  }
+}
+
 // dw[co][ci] += sum_v dy[b][co][s] x[v][ci], dbias[co] += sum_v dy: lane = (row ty, channel vector tx), CO <= 8 per pass
 template <class T, int VEC>
 __global__ void __launch_bounds__(256) head_bwd_dw_team_kernel(const T* __restrict__ x, int64_t ldx, const float* __restrict__ dy, float* __restrict__ dw,
@@ -1542,7 +1586,10 @@ extern "C" int miseg_head_bwd(const miseg_head_bwd_params* p, miseg_stream_t s_)
     constexpr int N = Vec16<T>::N;
     if (p->dx) {
       size_t sh = (size_t)p->Cin * p->Cout * sizeof(float);
-      if (p->Cin % N == 0 && p->lddx % N == 0 && al16(p->dx))
+      if (p->Cin % N == 0 && p->lddx % N == 0 && al16(p->dx) && p->Cout <= 8 && p->S % 256 == 0 && p->Cin / N <= 32 && N == 8) {
+        const int64_t ntiles = nv / 256;
+        head_bwd_dx_tile_kernel<T, N><<<(int)(ntiles < 2048 ? ntiles : 2048), 256, 0, s>>>(p->dy, (T*)p->dx, p->lddx, p->w, p->S, p->Cin, p->Cout, ntiles);
+      } else if (p->Cin % N == 0 && p->lddx % N == 0 && al16(p->dx))
         if (nv * (p->Cin / N) < (1LL << 29))      // 32-bit item arithmetic (see s2c_kernel)
           head_bwd_dx_team_kernel<T, N, unsigned><<<ew_grid(nv * (p->Cin / N)), 256, sh, s>>>(p->dy, (T*)p->dx, p->lddx, p->w, p->B, p->S, p->Cin, p->Cout);
         else

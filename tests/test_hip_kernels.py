@@ -542,7 +542,8 @@ def test_conv3_thin_and_head_and_patch_embed(dtype):
     # 512 voxels per sample (whole 256-row tiles): the bf16 weight gradient runs on the matrix cores; accumulates on top of dw / dbias
     xh2, g2 = rnd(2, 8, 8, 8, 48, dtype=dtype, seed=64), rnd(2, 6, 8, 8, 8, seed=65)
     dw2, db2 = wh.clone(), bh.clone()
-    ops.head_bwd(xh2, g2, wh, dw2, db2)
+    dx2 = ops.head_bwd(xh2, g2, wh, dw2, db2)      # (bf16 data gradient: the tile kernel - dy staged per 256 voxels, weights in registers)
+    assert rel_err(dx2.permute(0, 4, 1, 2, 3), torch.nn.grad.conv3d_input((2, 48, 8, 8, 8), wh, g2)) < TOL[dtype]
     assert rel_err(dw2 - wh, torch.nn.grad.conv3d_weight(xh2.float().permute(0, 4, 1, 2, 3), wh.shape, g2)) < TOL[dtype]
     assert rel_err(db2 - bh, g2.sum((0, 2, 3, 4))) < 1e-4
     # patch embed
