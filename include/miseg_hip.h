@@ -31,7 +31,7 @@ enum { MISEG_ACT_NONE = 0, MISEG_ACT_LEAKY = 1, MISEG_ACT_GELU = 2, MISEG_ACT_PR
 #define MISEG_MAX_STYLES 4
 
 /* bumped on EVERY change of a struct layout or prototype; bindings must refuse a library whose version differs from the header they mirror */
-#define MISEG_ABI_VERSION 2
+#define MISEG_ABI_VERSION 3
 int miseg_abi_version(void);
 const char* miseg_last_error(void);
 /* writes e.g. "gfx950" for the code objects embedded in the library */
@@ -188,6 +188,27 @@ int miseg_gemm_fuses_stat(const miseg_gemm_params* p);  /* 1: miseg_gemm(p) with
  * round(x[m] * w[n]) WITHOUT storing it: the stem block's shortcut convolution (dynunet_block.py:87-97), consumed through the r1x / r1w
  * fields of miseg_instnorm_apply / miseg_instnorm_pair_bwd.  x: [M] rows of one element (stride ldx), w: [N] (stride ldw), N <= 128 */
 int miseg_rank1_stats(const void* x, int64_t ldx, const void* w, int64_t ldw, int M, int N, int dtype, void* stat, miseg_stream_t stream);
+
+/* Fused MLP of the high-resolution Swin blocks (ABI 3): y = W2 gelu(W1 x + b1) + b2 (+ res)  (MONAI MLPBlock as used at
+ * networks/blocks/swin_transformer_block.py:97,176-205), one launch, the hidden activations never reach memory: the accumulator tile of the
+ * first product is the operand of the second (v_mfma_f32_16x16x16_bf16).  Backward (miseg_mlp_bwd): recomputes the hidden pre-activation
+ * from x, writes dz = (dy W2) * gelu'(z) and h = gelu(z) for the two weight-gradient products (miseg_gemm TN) and dx = dz W1.
+ * bf16, C = 48, HID = 192, M >= 4096 (miseg_mlp_fused tells); weights in the compute dtype: w1 [HID][C], w2 [C][HID], w2t [HID][C] = w2
+ * transposed, w1t [C][HID]; biases fp32 (may be NULL); stat: as miseg_gemm_params::stat (one sample, statistics of the rounded y). */
+typedef struct {
+  uint32_t struct_size;
+  int32_t M, C, HID, dtype;
+  const void* x; int64_t ldx;
+  const void* w1; const float* b1; const void* w2; const float* b2;
+  const void* res; int64_t ldres;          /* forward, optional */
+  void* y; int64_t ldy; void* stat;        /* forward */
+  const void* dy; int64_t lddy;            /* backward */
+  const void* w2t; const void* w1t;
+  void* dz; int64_t lddz; void* h; int64_t ldh; void* dx; int64_t lddx;
+} miseg_mlp_params;
+int miseg_mlp_fused(int M, int C, int HID, int dtype);      /* 1: the two calls below support this problem */
+int miseg_mlp_fwd(const miseg_mlp_params* p, miseg_stream_t stream);
+int miseg_mlp_bwd(const miseg_mlp_params* p, miseg_stream_t stream);
 int miseg_gemm_fuses_scatter(const miseg_gemm_params* p);  /* 1: miseg_gemm(p) with the scat_* fields set is supported for this problem */
 int miseg_gemm_tn_splits(const miseg_gemm_params* p);   /* > 1: partial tiles [splits][M][N] fp32 in the workspace */
 size_t miseg_gemm_workspace_bytes(const miseg_gemm_params* p);

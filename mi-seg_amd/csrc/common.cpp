@@ -27,7 +27,7 @@ extern "C" size_t miseg_abi_struct_size(const char* name) {
 #define MISEG_SZ(T) if (strcmp(name, #T) == 0) return sizeof(T);
   MISEG_SZ(miseg_instnorm_stats_params) MISEG_SZ(miseg_instnorm_apply_params) MISEG_SZ(miseg_instnorm_bwd_params) MISEG_SZ(miseg_instnorm_pair_bwd_params)
   MISEG_SZ(miseg_layernorm_fwd_params) MISEG_SZ(miseg_layernorm_bwd_params) MISEG_SZ(miseg_gemm_params) MISEG_SZ(miseg_tn_reduce_desc) MISEG_SZ(miseg_gemm_tn_desc)
-  MISEG_SZ(miseg_colsum_params) MISEG_SZ(miseg_colsum_desc) MISEG_SZ(miseg_conv3_params) MISEG_SZ(miseg_pack_conv3_params) MISEG_SZ(miseg_pack_conv3_desc)
+  MISEG_SZ(miseg_mlp_params) MISEG_SZ(miseg_colsum_params) MISEG_SZ(miseg_colsum_desc) MISEG_SZ(miseg_conv3_params) MISEG_SZ(miseg_pack_conv3_params) MISEG_SZ(miseg_pack_conv3_desc)
   MISEG_SZ(miseg_conv3_wgrad_params) MISEG_SZ(miseg_winattn_params) MISEG_SZ(miseg_winattn_bwd_params) MISEG_SZ(miseg_add_params) MISEG_SZ(miseg_copy2d_params)
   MISEG_SZ(miseg_cast_params) MISEG_SZ(miseg_cast_desc) MISEG_SZ(miseg_gelu_fwd_params) MISEG_SZ(miseg_gelu_bwd_params) MISEG_SZ(miseg_s2c_params)
   MISEG_SZ(miseg_patch_embed_params) MISEG_SZ(miseg_patch_embed_bwd_params) MISEG_SZ(miseg_conv3_thin_params) MISEG_SZ(miseg_conv3_thin_wgrad_params)

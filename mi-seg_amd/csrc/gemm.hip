@@ -29,7 +29,7 @@ template <> struct Mma<float> {
 // the density term of the derivative.
 __device__ __forceinline__ float gelu_cdf(float t, float& e) {
   const float a = fabsf(t) * 0.70710678118654752f;
-  const float k = __frcp_rn(fmaf(0.3275911f, a, 1.f));
+  const float k = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.f));      // v_rcp_f32 (1 ulp); __frcp_rn is the ten-instruction IEEE division
   float p = fmaf(1.061405429f, k, -1.453152027f);
   p = fmaf(p, k, 1.421413741f);
   p = fmaf(p, k, -0.284496736f);

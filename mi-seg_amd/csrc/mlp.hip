@@ -1,0 +1,269 @@
+// Fused MLP of the high-resolution Swin blocks: y = W2 gelu(W1 x + b1) + b2 (+ res), tokens x 48 -> 192 -> 48
+// (MONAI MLPBlock as wired at networks/blocks/swin_transformer_block.py:97,176-205; exact-erf GELU).
+//
+// Unfused, a stage-0 block moves 411 MB through HBM for its MLP, 300 MB of it the hidden pre-activation z and activation h
+// (110,592 tokens x 192): fc1 writes both, fc2 reads h, the backward reads z and h again.  Here the hidden tile never leaves the wave:
+// with v_mfma_f32_16x16x16_bf16 the accumulator layout of  z^T[hid][tok] = W1 x^T  (lane = token column fi, rows = 4 hidden channels
+// 4kg..4kg+3 of tile j) is exactly the B-operand layout of  y^T[c][tok] = W2 h^T  (lane = token column fi, k = 4 hidden channels), so
+// gelu(z_j) rounded to bf16 goes straight back into the matrix pipe, one 16-channel slice of the hidden layer at a time (no 192-wide
+// accumulator either).  The backward kernel recomputes z_j the same way (same instructions, same order: the same h as the forward),
+// forms dz_j = (W2^T dy^T)_j * gelu'(z_j), feeds it into dx^T += W1^T dz_j, and writes dz and h once for the two weight-gradient products,
+// which stay miseg_gemm TN launches (their 27 x 9 accumulator tiles per wave do not fit beside this).
+// A operands (weights) come from LDS images with 16-byte padded rows (conflict-free 8-byte fragment reads), B operands (tokens)
+// straight from global memory: a lane's operand is 8 contiguous bytes of its token's row.
+#include "common.h"
+
+namespace miseg {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_m;
+
+__device__ __forceinline__ f32x4 mma16(const s16x4_m& a, const s16x4_m& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+
+// cdf(t) = 0.5 (1 + erf(t / sqrt 2)) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7), e = exp(-t^2 / 2): the expressions of gemm.hip
+__device__ __forceinline__ float mlp_gelu_cdf(float t, float& e) {
+  const float a = fabsf(t) * 0.70710678118654752f;
+  const float k = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.f));      // v_rcp_f32 (1 ulp); __frcp_rn is the ten-instruction IEEE division
+  float p = fmaf(1.061405429f, k, -1.453152027f);
+  p = fmaf(p, k, 1.421413741f);
+  p = fmaf(p, k, -0.284496736f);
+  p = fmaf(p, k, 0.254829592f);
+  e = __expf(-a * a);
+  const float half_tail = 0.5f * p * k * e;
+  return t >= 0.f ? 1.f - half_tail : half_tail;
+}
+
+static constexpr int MLP_C = 48, MLP_H = 192, MLP_CS = MLP_C / 16, MLP_HS = MLP_H / 16;
+static constexpr int MLP_ROW_C = MLP_C * 2 + 16;      // byte stride of an LDS row of C channels  ([HID][C] images)
+static constexpr int MLP_ROW_H = MLP_H * 2 + 16;      // ... of HID channels ([C][HID] images)
+
+// image of a [R][K] bf16 matrix with padded rows; K * 2 bytes per row are copied as 16-byte pieces
+__device__ __forceinline__ void mlp_stage(char* img, int rowb, const bf16* __restrict__ w, int R, int K) {
+  const int per = K / 8;
+  for (int c = threadIdx.x; c < R * per; c += blockDim.x) {
+    const int r = c / per, ch = c - r * per;
+    *reinterpret_cast<bf16x8*>(img + r * rowb + ch * 16) = *reinterpret_cast<const bf16x8*>(w + (int64_t)r * K + ch * 8);
+  }
+}
+__device__ __forceinline__ s16x4_m mlp_frag(const char* img, int rowb, int row, int k) { return *reinterpret_cast<const s16x4_m*>(img + row * rowb + k * 2); }
+
+// STAT: instance-norm statistics of the rounded output (one sample), layout / reduction of gemm_nt_stream_kernel
+static constexpr int MLP_FWD_WAVES = 8;
+template <bool STAT>
+__global__ void __launch_bounds__(MLP_FWD_WAVES * 64, 2) mlp_fwd_kernel(const bf16* __restrict__ x, int64_t ldx, const bf16* __restrict__ w1, const float* __restrict__ b1,
+                                                         const bf16* __restrict__ w2, const float* __restrict__ b2, const bf16* __restrict__ res, int64_t ldres,
+                                                         bf16* __restrict__ y, int64_t ldy, int M, double* __restrict__ stat) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* w1i = lds;                                  // [HID][C]
+  char* w2i = w1i + MLP_H * MLP_ROW_C;              // [C][HID]
+  float* lb1 = reinterpret_cast<float*>(w2i + MLP_C * MLP_ROW_H);
+  float* lb2 = lb1 + MLP_H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fi = lane & 15, kg = lane >> 4;
+  const int mtiles = (M + 15) / 16, nwaves = gridDim.x * MLP_FWD_WAVES;
+  s16x4_m xc[MLP_CS], xn[MLP_CS];
+  auto loadx = [&](int tile, s16x4_m (&f)[MLP_CS]) {
+    const bf16* p = x + (int64_t)min(tile * 16 + fi, M - 1) * ldx + 4 * kg;
+#pragma unroll
+    for (int s = 0; s < MLP_CS; ++s) f[s] = *reinterpret_cast<const s16x4_m*>(p + 16 * s);
+  };
+  int tile = blockIdx.x * MLP_FWD_WAVES + wave;
+  if (tile < mtiles) loadx(tile, xc);
+  mlp_stage(w1i, MLP_ROW_C, w1, MLP_H, MLP_C);
+  mlp_stage(w2i, MLP_ROW_H, w2, MLP_C, MLP_H);
+  for (int i = tid; i < MLP_H; i += MLP_FWD_WAVES * 64) lb1[i] = b1 ? b1[i] : 0.f;
+  for (int i = tid; i < MLP_C; i += MLP_FWD_WAVES * 64) lb2[i] = b2 ? b2[i] : 0.f;
+  __syncthreads();
+  float ssum[MLP_CS][4], ssq[MLP_CS][4];
+#pragma unroll
+  for (int i = 0; i < MLP_CS; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ssum[i][r] = 0.f; ssq[i][r] = 0.f; }
+  for (; tile < mtiles; tile += nwaves) {
+    if (tile + nwaves < mtiles) loadx(tile + nwaves, xn);
+    const int row = tile * 16 + fi;
+    f32x4 yacc[MLP_CS];
+#pragma unroll
+    for (int i = 0; i < MLP_CS; ++i) yacc[i] = *reinterpret_cast<const f32x4*>(lb2 + 16 * i + 4 * kg);
+    // (not unrolled further: fully unrolled the compiler hoists all 72 weight fragments of a tile into registers - 251 VGPRs, two waves
+    // per SIMD - and the GELU's vector work of one slice has nothing to overlap with)
+#pragma unroll 2
+    for (int j = 0; j < MLP_HS; ++j) {
+      f32x4 z = *reinterpret_cast<const f32x4*>(lb1 + 16 * j + 4 * kg);
+#pragma unroll
+      for (int s = 0; s < MLP_CS; ++s) z = mma16(mlp_frag(w1i, MLP_ROW_C, 16 * j + fi, 16 * s + 4 * kg), xc[s], z);
+      float e;
+      const bf16x4 h = bf16x4{(bf16)(z[0] * mlp_gelu_cdf(z[0], e)), (bf16)(z[1] * mlp_gelu_cdf(z[1], e)), (bf16)(z[2] * mlp_gelu_cdf(z[2], e)),
+                              (bf16)(z[3] * mlp_gelu_cdf(z[3], e))};
+      const s16x4_m hb = __builtin_bit_cast(s16x4_m, h);
+#pragma unroll
+      for (int i = 0; i < MLP_CS; ++i) yacc[i] = mma16(mlp_frag(w2i, MLP_ROW_H, 16 * i + fi, 16 * j + 4 * kg), hb, yacc[i]);
+    }
+    if (row < M) {
+#pragma unroll
+      for (int i = 0; i < MLP_CS; ++i) {
+        f32x4 v = yacc[i];
+        if (res) {
+          const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(res + (int64_t)row * ldres + 16 * i + 4 * kg);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)r4[r];
+        }
+        const bf16x4 o4 = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        *reinterpret_cast<bf16x4*>(y + (int64_t)row * ldy + 16 * i + 4 * kg) = o4;
+        if constexpr (STAT) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float q = (float)o4[r]; ssum[i][r] += q; ssq[i][r] = fmaf(q, q, ssq[i][r]); }
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < MLP_CS; ++s) xc[s] = xn[s];
+  }
+  if constexpr (STAT) {
+    __syncthreads();      // the weight images are dead once every wave is past its last tile
+    float* red = reinterpret_cast<float*>(lds);
+    constexpr int RS = MLP_FWD_WAVES * 16 + 1, N = MLP_C;
+#pragma unroll
+    for (int i = 0; i < MLP_CS; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = 16 * i + 4 * kg + r;
+        red[(0 * N + col) * RS + wave * 16 + fi] = ssum[i][r];
+        red[(1 * N + col) * RS + wave * 16 + fi] = ssq[i][r];
+      }
+    __syncthreads();
+    for (int o = tid; o < 2 * N; o += MLP_FWD_WAVES * 64) {
+      const int k = o / N, col = o - k * N;
+      const float* rp = red + (k * N + col) * RS;
+      float tot = 0.f;
+#pragma unroll 16
+      for (int i = 0; i < MLP_FWD_WAVES * 16; ++i) tot += rp[i];
+      atomicAdd(stat + ((int64_t)(blockIdx.x & 15) * N + col) * 2 + k, (double)tot);      // [16 replicas][B = 1][N][2]
+    }
+  }
+}
+
+// 8 waves per workgroup: the three weight images (63 KB) allow two workgroups per CU, and 16 resident waves hide the GELU's vector work
+static constexpr int MLP_BWD_WAVES = 8;
+__global__ void __launch_bounds__(MLP_BWD_WAVES * 64, 2) mlp_bwd_kernel(const bf16* __restrict__ x, int64_t ldx, const bf16* __restrict__ dy, int64_t lddy,
+                                                         const bf16* __restrict__ w1, const float* __restrict__ b1, const bf16* __restrict__ w2t,
+                                                         const bf16* __restrict__ w1t, bf16* __restrict__ dz, int64_t lddz, bf16* __restrict__ h, int64_t ldh,
+                                                         bf16* __restrict__ dx, int64_t lddx, int M) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* w1i = lds;                                  // [HID][C]   z = W1 x
+  char* w2ti = w1i + MLP_H * MLP_ROW_C;             // [HID][C]   dh = W2^T dy
+  char* w1ti = w2ti + MLP_H * MLP_ROW_C;            // [C][HID]   dx = W1^T dz
+  float* lb1 = reinterpret_cast<float*>(w1ti + MLP_C * MLP_ROW_H);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fi = lane & 15, kg = lane >> 4;
+  const int mtiles = (M + 15) / 16, nwaves = gridDim.x * MLP_BWD_WAVES;
+  s16x4_m xc[MLP_CS], gc[MLP_CS], xn[MLP_CS], gn[MLP_CS];
+  auto load2 = [&](int tile, s16x4_m (&fx)[MLP_CS], s16x4_m (&fg)[MLP_CS]) {
+    const int r = min(tile * 16 + fi, M - 1);
+    const bf16* px = x + (int64_t)r * ldx + 4 * kg;
+    const bf16* pg = dy + (int64_t)r * lddy + 4 * kg;
+#pragma unroll
+    for (int s = 0; s < MLP_CS; ++s) { fx[s] = *reinterpret_cast<const s16x4_m*>(px + 16 * s); fg[s] = *reinterpret_cast<const s16x4_m*>(pg + 16 * s); }
+  };
+  int tile = blockIdx.x * MLP_BWD_WAVES + wave;
+  if (tile < mtiles) load2(tile, xc, gc);
+  mlp_stage(w1i, MLP_ROW_C, w1, MLP_H, MLP_C);
+  mlp_stage(w2ti, MLP_ROW_C, w2t, MLP_H, MLP_C);
+  mlp_stage(w1ti, MLP_ROW_H, w1t, MLP_C, MLP_H);
+  for (int i = tid; i < MLP_H; i += MLP_BWD_WAVES * 64) lb1[i] = b1 ? b1[i] : 0.f;
+  __syncthreads();
+  for (; tile < mtiles; tile += nwaves) {
+    if (tile + nwaves < mtiles) load2(tile + nwaves, xn, gn);
+    const int row = tile * 16 + fi;
+    const bool live = row < M;
+    f32x4 dxacc[MLP_CS];
+#pragma unroll
+    for (int i = 0; i < MLP_CS; ++i) dxacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int j = 0; j < MLP_HS; ++j) {
+      f32x4 z = *reinterpret_cast<const f32x4*>(lb1 + 16 * j + 4 * kg);
+      f32x4 dh = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < MLP_CS; ++s) {
+        z = mma16(mlp_frag(w1i, MLP_ROW_C, 16 * j + fi, 16 * s + 4 * kg), xc[s], z);
+        dh = mma16(mlp_frag(w2ti, MLP_ROW_C, 16 * j + fi, 16 * s + 4 * kg), gc[s], dh);
+      }
+      float hv[4], dzv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float e;
+        const float c = mlp_gelu_cdf(z[r], e);
+        hv[r] = z[r] * c;
+        dzv[r] = dh[r] * fmaf(z[r] * 0.39894228040143268f, e, c);
+      }
+      const bf16x4 h4 = bf16x4{(bf16)hv[0], (bf16)hv[1], (bf16)hv[2], (bf16)hv[3]};
+      const bf16x4 d4 = bf16x4{(bf16)dzv[0], (bf16)dzv[1], (bf16)dzv[2], (bf16)dzv[3]};
+      if (live) {
+        *reinterpret_cast<bf16x4*>(h + (int64_t)row * ldh + 16 * j + 4 * kg) = h4;
+        *reinterpret_cast<bf16x4*>(dz + (int64_t)row * lddz + 16 * j + 4 * kg) = d4;
+      }
+      const s16x4_m db = __builtin_bit_cast(s16x4_m, d4);
+#pragma unroll
+      for (int i = 0; i < MLP_CS; ++i) dxacc[i] = mma16(mlp_frag(w1ti, MLP_ROW_H, 16 * i + fi, 16 * j + 4 * kg), db, dxacc[i]);
+    }
+    if (live && dx) {
+#pragma unroll
+      for (int i = 0; i < MLP_CS; ++i)
+        *reinterpret_cast<bf16x4*>(dx + (int64_t)row * lddx + 16 * i + 4 * kg) = bf16x4{(bf16)dxacc[i][0], (bf16)dxacc[i][1], (bf16)dxacc[i][2], (bf16)dxacc[i][3]};
+    }
+#pragma unroll
+    for (int s = 0; s < MLP_CS; ++s) { xc[s] = xn[s]; gc[s] = gn[s]; }
+  }
+}
+
+}  // namespace miseg
+
+using namespace miseg;
+
+extern "C" int miseg_mlp_fused(int M, int C, int HID, int dtype) { return dtype == MISEG_BF16 && C == MLP_C && HID == MLP_H && M >= 4096; }
+
+static int mlp_check(const miseg_mlp_params* p, const char* what) {
+  MISEG_REQUIRE(p && p->struct_size == sizeof(miseg_mlp_params), MISEG_E_BADARG, "%s: struct_size %u != %zu (header / binding drift)", what, p ? p->struct_size : 0u,
+                sizeof(miseg_mlp_params));
+  MISEG_REQUIRE(miseg_mlp_fused(p->M, p->C, p->HID, p->dtype), MISEG_E_UNSUPPORTED, "%s: M %d C %d HID %d dtype %d (ask miseg_mlp_fused)", what, p->M, p->C, p->HID,
+                p->dtype);
+  MISEG_REQUIRE(p->x && p->w1 && p->ldx >= p->C && p->ldx % 4 == 0 && ((uintptr_t)p->x % 8) == 0 && ((uintptr_t)p->w1 % 16) == 0, MISEG_E_BADARG,
+                "%s: x / w1 (8-byte aligned rows, 16-byte aligned weights)", what);
+  return MISEG_OK;
+}
+
+extern "C" int miseg_mlp_fwd(const miseg_mlp_params* p, miseg_stream_t s_) {
+  if (int rc = mlp_check(p, "mlp_fwd")) return rc;
+  MISEG_REQUIRE(p->w2 && p->y && ((uintptr_t)p->w2 % 16) == 0 && ((uintptr_t)p->y % 8) == 0 && p->ldy % 4 == 0 && p->ldy >= p->C, MISEG_E_BADARG, "mlp_fwd: w2 / y");
+  MISEG_REQUIRE(!p->res || (((uintptr_t)p->res % 8) == 0 && p->ldres % 4 == 0), MISEG_E_BADARG, "mlp_fwd: res alignment");
+  size_t lds = (size_t)MLP_H * MLP_ROW_C + (size_t)MLP_C * MLP_ROW_H + (size_t)(MLP_H + MLP_C) * 4;
+  const size_t red = (size_t)2 * MLP_C * (MLP_FWD_WAVES * 16 + 1) * sizeof(float);      // the statistics reduction re-uses the images
+  if (p->stat && lds < red) lds = red;
+  int blocks = cdiv(cdiv(p->M, 16), MLP_FWD_WAVES);
+  if (blocks > 512) blocks = 512;
+  hipStream_t s = (hipStream_t)s_;
+  if (p->stat) {
+    MISEG_SET_SMEM((mlp_fwd_kernel<true>), lds);
+    mlp_fwd_kernel<true><<<blocks, MLP_FWD_WAVES * 64, lds, s>>>((const bf16*)p->x, p->ldx, (const bf16*)p->w1, p->b1, (const bf16*)p->w2, p->b2, (const bf16*)p->res, p->ldres,
+                                                  (bf16*)p->y, p->ldy, p->M, (double*)p->stat);
+  } else {
+    MISEG_SET_SMEM((mlp_fwd_kernel<false>), lds);
+    mlp_fwd_kernel<false><<<blocks, MLP_FWD_WAVES * 64, lds, s>>>((const bf16*)p->x, p->ldx, (const bf16*)p->w1, p->b1, (const bf16*)p->w2, p->b2, (const bf16*)p->res, p->ldres,
+                                                   (bf16*)p->y, p->ldy, p->M, nullptr);
+  }
+  MISEG_LAUNCH_CHECK("mlp_fwd");
+  return MISEG_OK;
+}
+
+extern "C" int miseg_mlp_bwd(const miseg_mlp_params* p, miseg_stream_t s_) {
+  if (int rc = mlp_check(p, "mlp_bwd")) return rc;
+  MISEG_REQUIRE(p->dy && p->w2t && p->w1t && p->dz && p->h, MISEG_E_BADARG, "mlp_bwd: null pointer");
+  MISEG_REQUIRE(((uintptr_t)p->dy % 8) == 0 && p->lddy % 4 == 0 && ((uintptr_t)p->dz % 8) == 0 && p->lddz % 4 == 0 && ((uintptr_t)p->h % 8) == 0 && p->ldh % 4 == 0 &&
+                    (!p->dx || (((uintptr_t)p->dx % 8) == 0 && p->lddx % 4 == 0)) && ((uintptr_t)p->w2t % 16) == 0 && ((uintptr_t)p->w1t % 16) == 0,
+                MISEG_E_BADARG, "mlp_bwd: alignment");
+  const size_t lds = (size_t)2 * MLP_H * MLP_ROW_C + (size_t)MLP_C * MLP_ROW_H + (size_t)MLP_H * 4;
+  int blocks = cdiv(cdiv(p->M, 16), MLP_BWD_WAVES);
+  if (blocks > 512) blocks = 512;
+  MISEG_SET_SMEM(mlp_bwd_kernel, lds);
+  mlp_bwd_kernel<<<blocks, MLP_BWD_WAVES * 64, lds, (hipStream_t)s_>>>((const bf16*)p->x, p->ldx, (const bf16*)p->dy, p->lddy, (const bf16*)p->w1, p->b1, (const bf16*)p->w2t,
+                                                        (const bf16*)p->w1t, (bf16*)p->dz, p->lddz, (bf16*)p->h, p->ldh, (bf16*)p->dx, p->lddx, p->M);
+  MISEG_LAUNCH_CHECK("mlp_bwd");
+  return MISEG_OK;
+}

@@ -376,6 +376,12 @@ class _Mlp(Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, res, want_stat=False):
+        ctx.fused = ops.mlp_fused(x, w1.shape[0])
+        if ctx.fused:      # 48 -> 192 -> 48 on >= 4096 tokens (stage 1 of the headline net): one launch, hidden activations never stored
+            y = ops.mlp_fwd(x, ops.cast_matrix(w1, x.dtype), b1, ops.cast_matrix(w2, x.dtype), b2, res=res, want_stat=want_stat)
+            ctx.save_for_backward(x, None, None, w1, w2)
+            ctx.params = (w1, b1, w2, b2)
+            return y
         # the pre-activation is only the backward pass's input (gelu'): an inference forward (no_grad) does not write it
         h = torch.empty(x.shape[:-1] + (w1.shape[0],), dtype=x.dtype, device=x.device) if any(ctx.needs_input_grad) else None
         a = ops.gemm_nt(x, ops.cast_matrix(w1, x.dtype), b1, act=L.ACT_GELU, preact_out=h)
@@ -389,8 +395,12 @@ class _Mlp(Function):
         x, h, a, w1, w2 = ctx.saved_tensors
         pw1, pb1, pw2, pb2 = ctx.params
         dy = _rv(dy)
-        dh = ops.gemm_nt(dy, ops.cast_matrix(w2, dy.dtype, transpose=True), gelu_grad_of=h)
-        dx = ops.gemm_nt(dh, ops.cast_matrix(w1, dy.dtype, transpose=True)) if ctx.needs_input_grad[0] else None
+        if ctx.fused:      # z recomputed from x; dz and h are written once, for the two weight-gradient products below
+            dh, a, dx = ops.mlp_bwd(x, dy, ops.cast_matrix(w1, dy.dtype), pb1, ops.cast_matrix(w2, dy.dtype, transpose=True),
+                                    ops.cast_matrix(w1, dy.dtype, transpose=True), need_dx=ctx.needs_input_grad[0])
+        else:
+            dh = ops.gemm_nt(dy, ops.cast_matrix(w2, dy.dtype, transpose=True), gelu_grad_of=h)
+            dx = ops.gemm_nt(dh, ops.cast_matrix(w1, dy.dtype, transpose=True)) if ctx.needs_input_grad[0] else None
         out = [dx, None, None, None, None, dy if ctx.needs_input_grad[5] else None, None]
         for i, (p, act, g) in enumerate(((pw1, x, dh), (pw2, a, dy))):
             if ctx.needs_input_grad[1 + 2 * i]:

@@ -20,7 +20,7 @@ class _S(C.Structure):
     pass
 
 
-ABI_VERSION = 2          # == MISEG_ABI_VERSION of include/miseg_hip.h; load() refuses a library that reports another
+ABI_VERSION = 3          # == MISEG_ABI_VERSION of include/miseg_hip.h; load() refuses a library that reports another
 C_NAMES = {}             # ctypes mirror -> name of the C struct it mirrors (tests/test_abi.py checks sizeof / offsetof of every field)
 
 
@@ -104,6 +104,9 @@ Im2col3 = _struct("Im2col3", cname="miseg_im2col3_params", fields=[("src", vp), 
                               ("C", i32), ("dtype", i32)])
 
 u32, u64p = C.c_uint32, C.POINTER(C.c_uint64)
+Mlp = _struct("Mlp", cname="miseg_mlp_params", fields=[("struct_size", u32), ("M", i32), ("C", i32), ("HID", i32), ("dtype", i32), ("x", vp), ("ldx", i64),
+                      ("w1", vp), ("b1", vp), ("w2", vp), ("b2", vp), ("res", vp), ("ldres", i64), ("y", vp), ("ldy", i64), ("stat", vp),
+                      ("dy", vp), ("lddy", i64), ("w2t", vp), ("w1t", vp), ("dz", vp), ("lddz", i64), ("h", vp), ("ldh", i64), ("dx", vp), ("lddx", i64)])
 SegLoss = _struct("SegLoss", cname="miseg_seg_loss_params", fields=[
     ("struct_size", u32), ("kind", i32), ("logits", vp), ("label", vp), ("label_dtype", i32), ("B", i32), ("C", i32), ("S", i64),
     ("include_background", i32), ("squared_pred", i32), ("smooth_nr", f32), ("smooth_dr", f32), ("gamma", f32), ("lambda_dice", f32),
@@ -150,6 +153,9 @@ PROTOS = {
     "miseg_gemm_fuses_stat": (i32, [C.POINTER(Gemm)]),
     "miseg_gemm_fuses_scatter": (i32, [C.POINTER(Gemm)]),
     "miseg_rank1_stats": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, vp]),
+    "miseg_mlp_fused": (i32, [i32, i32, i32, i32]),
+    "miseg_mlp_fwd": (i32, [C.POINTER(Mlp), vp]),
+    "miseg_mlp_bwd": (i32, [C.POINTER(Mlp), vp]),
     "miseg_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(Gemm)]),
     "miseg_gemm": (i32, [C.POINTER(Gemm), vp]),
     "miseg_permute3": (i32, [vp, vp, i32, i32, i32, i64, i64, i64, i32, vp]),

@@ -317,6 +317,45 @@ def gemm_nt(a, w, bias=None, act=L.ACT_NONE, out=None, out_dtype=None, split_k=1
     return out
 
 
+def mlp_fused(x, hid):
+    """the fused MLP kernels take this problem (bf16, 48 -> 192 -> 48 channels, >= 4096 tokens)"""
+    if PROFILE_HOOK is not None or os.environ.get("MISEG_NO_FUSED_MLP"):
+        return False
+    _, M, Cc = rows(x)
+    return x.dtype == torch.bfloat16 and bool(L.load().miseg_mlp_fused(M, Cc, hid, _dt(x)))
+
+
+def mlp_fwd(x, w1, b1, w2, b2, res=None, want_stat=False):
+    """y = w2 gelu(w1 x + b1) + b2 (+ res) in one launch, hidden activations never stored; w1 [HID, C], w2 [C, HID] contiguous in x.dtype.
+    want_stat (all rows one sample): the instance-norm statistics of y are left for pop_gemm_stat(y)."""
+    ldx, M, Cc = rows(x)
+    y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    p = L.Mlp(C.sizeof(L.Mlp), M, Cc, w1.shape[0], _dt(x), _ptr(x), ldx, _ptr(w1), _ptr(_fp32(b1)), _ptr(w2), _ptr(_fp32(b2)),
+              _ptr(res), rows(res)[0] if res is not None else 0, _ptr(y), rows(y)[0], None)
+    global LAST_GEMM_STAT
+    LAST_GEMM_STAT = None
+    if want_stat:
+        stat = STAT_POOL.take(L.load().miseg_instnorm_stat_bytes(1, Cc) // 8, x.device).view(-1, 1, Cc, 2)
+        p.stat = stat.data_ptr()
+        LAST_GEMM_STAT = (y.data_ptr(), stat)
+    _call("miseg_mlp_fwd", p)
+    return y
+
+
+def mlp_bwd(x, dy, w1, b1, w2t, w1t, need_dx=True):
+    """(dz, h, dx) of the fused MLP: dz = (dy w2) * gelu'(z), h = gelu(z) with z = w1 x + b1 recomputed, dx = dz w1.
+    w2t [HID, C] = w2 transposed, w1t [C, HID] = w1 transposed (cast_matrix(..., transpose=True))."""
+    ldx, M, Cc = rows(x)
+    hid = w1.shape[0]
+    dz = torch.empty(x.shape[:-1] + (hid,), dtype=x.dtype, device=x.device)
+    h = torch.empty_like(dz)
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device) if need_dx else None
+    p = L.Mlp(C.sizeof(L.Mlp), M, Cc, hid, _dt(x), _ptr(x), ldx, _ptr(w1), _ptr(_fp32(b1)), None, None, None, 0, None, 0, None,
+              _ptr(dy), rows(dy)[0], _ptr(w2t), _ptr(w1t), _ptr(dz), rows(dz)[0], _ptr(h), rows(h)[0], _ptr(dx), rows(dx)[0] if dx is not None else 0)
+    _call("miseg_mlp_bwd", p)
+    return dz, h, dx
+
+
 def gemm_nt_scatter(a, w, dst, grid):
     """The GEMM of a ConvTranspose3d(k2, s2) with its 2x2x2 scatter as the store: a = the voxels of `grid` = (B, d, h, w) as rows [.., Cin],
     w = [(j, co)][ci] (j = 4 jd + 2 jh + jw), dst = rows view [B, 2d, 2h, 2w, co] (e.g. the left half of a concat buffer).

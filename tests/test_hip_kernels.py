@@ -352,6 +352,40 @@ def test_gemm_nt_epilogues(dtype, M, N, K):
     assert rel_err(ops.gemm_nt(a, w, None, gelu_grad_of=h), (z - bias) * hf.grad) < 2 * TOL[dtype]
 
 
+@pytest.mark.parametrize("M", [4096, 13829])
+def test_fused_mlp_forward_and_backward(M):
+    """the one-launch MLP of the 48-channel Swin stage (hidden tile fed from the first product's accumulator into the second) and its
+    backward (pre-activation recomputed; dz, h written for the weight-gradient products) against fp32 torch on the bf16-rounded operands,
+    the fused statistics against a statistics pass over y, and the two-GEMM path it replaces (MISEG_NO_FUSED_MLP, read per call)."""
+    ops = _ops()
+    dt = torch.bfloat16
+    x, res, dy = rnd(1, M, 48, dtype=dt, seed=81), rnd(1, M, 48, dtype=dt, seed=82), rnd(1, M, 48, dtype=dt, seed=83)
+    w1, b1 = rnd(192, 48, seed=84) / 48 ** 0.5, rnd(192, seed=85) / 4
+    w2, b2 = rnd(48, 192, seed=86) / 192 ** 0.5, rnd(48, seed=87) / 4
+    w1b, w2b = w1.to(dt), w2.to(dt)
+    assert ops.mlp_fused(x, 192)
+    ops.begin_step()
+    y = ops.mlp_fwd(x, w1b, b1, w2b, b2, res=res, want_stat=True)
+    stat = ops.pop_gemm_stat(y)
+    z = x.float() @ w1b.float().t() + b1
+    hr = F.gelu(z)
+    yr = hr.to(dt).float() @ w2b.float().t() + b2 + res.float()
+    assert rel_err(y, yr) < 5e-3
+    assert stat is not None and torch.allclose(stat.sum(0), ops.instnorm_stats(y, 1, M).sum(0), rtol=1e-6, atol=1e-3)
+    zf = z.clone().requires_grad_(True)
+    F.gelu(zf).backward(torch.ones_like(zf))
+    dzr = (dy.float() @ w2b.float()) * zf.grad
+    dz, h, dx = ops.mlp_bwd(x, dy, w1b, b1, w2b.t().contiguous(), w1b.t().contiguous())
+    assert rel_err(h, hr) < 5e-3 and rel_err(dz, dzr) < 5e-3
+    assert rel_err(dx, dz.float() @ w1b.float()) < 5e-3
+    # the path it replaces (pre-activation rounded to bf16 before gelu'): same results within bf16 rounding
+    pre = torch.empty(1, M, 192, dtype=dt, device=DEV)
+    a0 = ops.gemm_nt(x, w1b, b1, act=_L().ACT_GELU, preact_out=pre)
+    y0 = ops.gemm_nt(a0, w2b, b2, res=res)
+    assert rel_err(y, y0) < 5e-3 and rel_err(h, a0) < 5e-3
+    assert rel_err(dz, ops.gemm_nt(dy, w2b.t().contiguous(), gelu_grad_of=pre)) < 1e-2
+
+
 def test_gemm_nt_exact_integers():
     """asymmetric small-integer operands: catches transposed / permuted MFMA fragment maps exactly."""
     ops = _ops()
