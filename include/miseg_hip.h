@@ -308,6 +308,12 @@ typedef struct {
   int B, D, H, W, C, heads, dtype;
   int wd, wh, ww, sd, sh, sw, tw;
   float scale;
+  /* ABI 3: dropout on the attention probabilities (attn_drop of WindowAttention, swin_transformer_block.py:56-58,91; the SABlock of the
+   * ViT): drop_p in [0, 1), 0 = off.  The mask is the counter-based one of miseg_dropout over the matrix [B*nW*heads*n rows][n columns]
+   * (row = ((window * heads + head) * n + query), column = key) with the same (seed, stream_id, step_dev) key, so the backward call
+   * re-creates it from the same three values; nothing is stored.  With drop_p > 0 the one-lane-per-query kernels run (any head_dim, both
+   * dtypes): the matrix-core kernels take no mask. */
+  float drop_p; uint64_t drop_seed, drop_stream; const uint64_t* drop_step_dev;
 } miseg_winattn_params;
 int miseg_winattn_fwd(const miseg_winattn_params* p, miseg_stream_t stream);
 

@@ -87,9 +87,12 @@ static size_t attn_smem_bytes(int n, int hd, int tsize, bool bwd) {
   return ((size_t)2 * n * hd + (size_t)tsize * (bwd ? 2 : 1) + (size_t)5 * n + (size_t)3 * hd) * sizeof(float);
 }
 
+// dropout on the attention probabilities (attn_drop): thresh == 0 = off.  Mask = miseg_dropout's over the [windows * heads * n][n] matrix
+struct AttnDrop { unsigned thresh; float scale; uint64_t key; const uint64_t* step_dev; };
+
 template <class T, int HD4>
 __global__ void __launch_bounds__(384) winattn_fwd_kernel(const T* __restrict__ qkv, int64_t ldq, T* __restrict__ out, int64_t ldo, const float* __restrict__ qkv_bias,
-                                                          const float* __restrict__ bias_table, float* __restrict__ lse_out, WinGeom g, int tsize) {
+                                                          const float* __restrict__ bias_table, float* __restrict__ lse_out, WinGeom g, int tsize, AttnDrop dr) {
   constexpr int HD = HD4 * 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   AttnSmem s = carve<HD4>(smem, g.n, tsize, false);
@@ -117,6 +120,11 @@ __global__ void __launch_bounds__(384) winattn_fwd_kernel(const T* __restrict__ 
   float m = -INFINITY, l = 0.f, o[HD];
 #pragma unroll
   for (int d = 0; d < HD; ++d) o[d] = 0.f;
+  // attn_drop: out = (P * mask / (1 - p)) V with P the full softmax (the denominator l sums every key, dropped or not)
+  const uint64_t dk0 = dr.thresh ? dropout_step_key(dr.key, dr.step_dev) : 0ull;
+  const int64_t drow = ((int64_t)win * g.heads + head) * n + t;
+  const int dcg = (n + 3) / 4;
+  uint64_t dh = 0;
   for (int j = 0; j < n; ++j) {
     const f32x4* kr = reinterpret_cast<const f32x4*>(s.A + j * HD);
     float sc = 0.f;
@@ -131,8 +139,13 @@ __global__ void __launch_bounds__(384) winattn_fwd_kernel(const T* __restrict__ 
     if (bias_table) sc += s.table[code - s.code[j] + centre];
     if (use_mask && s.label[j] != label) sc -= 100.f;
     const float mn = fmaxf(m, sc);
-    const float alpha = __expf(m - mn), p = __expf(sc - mn);
+    const float alpha = __expf(m - mn);
+    float p = __expf(sc - mn);
     l = l * alpha + p;
+    if (dr.thresh) {
+      if ((j & 3) == 0) dh = dropout_group_hash(dk0, drow, dcg, j);
+      p = dropout_keeps(dh, j, dr.thresh) ? p * dr.scale : 0.f;
+    }
     const f32x4* vr = reinterpret_cast<const f32x4*>(s.Bm + j * HD);
 #pragma unroll
     for (int d4 = 0; d4 < HD4; ++d4) {
@@ -157,7 +170,7 @@ template <class T, int HD4>
 __global__ void __launch_bounds__(384) winattn_bwd_kernel(const T* __restrict__ qkv, int64_t ldq, const T* __restrict__ out, int64_t ldo, const T* __restrict__ dout,
                                                           int64_t lddo, T* __restrict__ dqkv, int64_t lddq, const float* __restrict__ qkv_bias,
                                                           const float* __restrict__ bias_table, const float* __restrict__ lse_in, float* __restrict__ dqkv_bias,
-                                                          float* __restrict__ dbias_table, WinGeom g, int tsize) {
+                                                          float* __restrict__ dbias_table, WinGeom g, int tsize, AttnDrop dr) {
   constexpr int HD = HD4 * 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   AttnSmem s = carve<HD4>(smem, g.n, tsize, true);
@@ -206,6 +219,11 @@ __global__ void __launch_bounds__(384) winattn_bwd_kernel(const T* __restrict__ 
     float dq[HD];
 #pragma unroll
     for (int d = 0; d < HD; ++d) dq[d] = 0.f;
+    // attn_drop: O = (P * M) V with M = mask / (1 - p), so dP = (dO V^T) * M and delta = rowsum(dO * O) as without dropout
+    const uint64_t dk0 = dr.thresh ? dropout_step_key(dr.key, dr.step_dev) : 0ull;
+    const int64_t drow = ((int64_t)win * g.heads + head) * n + t;
+    const int dcg = (n + 3) / 4;
+    uint64_t dh = 0;
     for (int j = 0; j < n; ++j) {
       const f32x4* kr = reinterpret_cast<const f32x4*>(s.A + j * HD);
       const f32x4* vr = reinterpret_cast<const f32x4*>(s.Bm + j * HD);
@@ -225,6 +243,10 @@ __global__ void __launch_bounds__(384) winattn_bwd_kernel(const T* __restrict__ 
       if (bias_table) sc += s.table[bidx];
       if (use_mask && s.label[j] != label) sc -= 100.f;
       const float p = __expf(sc - lse);
+      if (dr.thresh) {
+        if ((j & 3) == 0) dh = dropout_group_hash(dk0, drow, dcg, j);
+        dp = dropout_keeps(dh, j, dr.thresh) ? dp * dr.scale : 0.f;
+      }
       const float ds = p * (dp - delta);
       if (dbias_table) atomicAdd(&s.dtable[bidx], ds);
 #pragma unroll
@@ -258,6 +280,8 @@ __global__ void __launch_bounds__(384) winattn_bwd_kernel(const T* __restrict__ 
     float dk[HD], dv[HD];
 #pragma unroll
     for (int d = 0; d < HD; ++d) dk[d] = dv[d] = 0.f;
+    const uint64_t dk0 = dr.thresh ? dropout_step_key(dr.key, dr.step_dev) : 0ull;
+    const int dcg = (n + 3) / 4;
     for (int i = 0; i < n; ++i) {
       const f32x4* qr = reinterpret_cast<const f32x4*>(s.A + i * HD);
       const f32x4* gr = reinterpret_cast<const f32x4*>(s.Bm + i * HD);
@@ -276,13 +300,19 @@ __global__ void __launch_bounds__(384) winattn_bwd_kernel(const T* __restrict__ 
       if (bias_table) sc += s.table[s.code[i] - code + centre];
       if (use_mask && s.label[i] != label) sc -= 100.f;
       const float p = __expf(sc - s.lse[i]);
+      float pm = p;      // the probability that multiplied V: masked and rescaled under attn_drop
+      if (dr.thresh) {
+        const float keep = dropout_keeps(dropout_group_hash(dk0, ((int64_t)win * g.heads + head) * n + i, dcg, t), t, dr.thresh) ? dr.scale : 0.f;
+        dp *= keep;
+        pm = p * keep;
+      }
       const float ds = p * (dp - s.delta[i]);
 #pragma unroll
       for (int d4 = 0; d4 < HD4; ++d4)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           dk[4 * d4 + e] = fmaf(ds, qq[d4][e], dk[4 * d4 + e]);   // q already carries the scale
-          dv[4 * d4 + e] = fmaf(p, gg[d4][e], dv[4 * d4 + e]);
+          dv[4 * d4 + e] = fmaf(pm, gg[d4][e], dv[4 * d4 + e]);
         }
     }
     if (row >= 0) {
@@ -819,19 +849,30 @@ static int make_geom(const miseg_winattn_params* p, WinGeom* g) {
     default: return set_error(MISEG_E_UNSUPPORTED, "winattn: head_dim %d not instantiated (4,8,12,16,32,64)", 4 * (hd4)); \
   }
 
+static AttnDrop attn_drop_args(const miseg_winattn_params* p) {
+  AttnDrop dr;
+  dr.thresh = (unsigned)lrintf(p->drop_p * 65536.f);      // p quantised to 1 / 65536 like miseg_dropout
+  dr.scale = 1.f / (1.f - (float)dr.thresh / 65536.f);
+  dr.key = dropout_host_key(p->drop_seed, p->drop_stream);
+  dr.step_dev = p->drop_step_dev;
+  return dr;
+}
+
 extern "C" int miseg_winattn_fwd(const miseg_winattn_params* p, miseg_stream_t s_) {
   hipStream_t s = (hipStream_t)s_;
   MISEG_REQUIRE(p, MISEG_E_BADARG, "winattn_fwd: null params");
   WinGeom g;
   int rc = make_geom(p, &g);
   if (rc) return rc;
-  if (global_attn_fwd(p, s, &rc)) return rc;       // one window = the whole token grid, head_dim 64, bf16 (the ViT of C-UNETR)
+  MISEG_REQUIRE(p->drop_p >= 0.f && p->drop_p < 1.f, MISEG_E_BADARG, "winattn_fwd: drop_p = %f must lie in [0, 1)", (double)p->drop_p);
+  const AttnDrop dr = attn_drop_args(p);
+  if (!dr.thresh && global_attn_fwd(p, s, &rc)) return rc;       // one window = the whole token grid, head_dim 64, bf16 (the ViT of C-UNETR)
   const int tb = 2 * g.tw - 1, tsize = p->bias_table ? tb * tb * tb : 0;
   const size_t sh = attn_smem_bytes(g.n, g.hd, tsize, false);
   MISEG_REQUIRE(sh <= 160 * 1024, MISEG_E_UNSUPPORTED, "winattn_fwd: %zu bytes of LDS needed", sh);
   dim3 grid(g.B * g.nwd * g.nwh * g.nww, g.heads);
   const int threads = cdiv(g.n, 64) * 64;
-  if (p->dtype == MISEG_BF16 && g.hd == 16 && g.n <= ATT_NP && p->bias_table && ((uintptr_t)p->out % 8 == 0) && p->ldo % 4 == 0) {
+  if (!dr.thresh && p->dtype == MISEG_BF16 && g.hd == 16 && g.n <= ATT_NP && p->bias_table && ((uintptr_t)p->out % 8 == 0) && p->ldo % 4 == 0) {
     const size_t shm = attn_mfma_fwd_smem(tsize);
     const bool vec = p->ldq % 8 == 0 && (uintptr_t)p->qkv % 16 == 0;
     const bool wide = (int64_t)grid.x * grid.y < 256;       // fewer workgroups than CUs: one query tile per wave
@@ -849,7 +890,7 @@ extern "C" int miseg_winattn_fwd(const miseg_winattn_params* p, miseg_stream_t s
     typedef typename std::remove_pointer<decltype(tag)>::type T;
     HD_SWITCH(g.hd / 4, {
       MISEG_SET_SMEM((winattn_fwd_kernel<T, HD4>), sh);
-      winattn_fwd_kernel<T, HD4><<<grid, threads, sh, s>>>((const T*)p->qkv, p->ldq, (T*)p->out, p->ldo, p->qkv_bias, p->bias_table, p->lse, g, tsize);
+      winattn_fwd_kernel<T, HD4><<<grid, threads, sh, s>>>((const T*)p->qkv, p->ldq, (T*)p->out, p->ldo, p->qkv_bias, p->bias_table, p->lse, g, tsize, dr);
     });
     MISEG_LAUNCH_CHECK("winattn_fwd");
     return MISEG_OK;
@@ -862,13 +903,15 @@ extern "C" int miseg_winattn_bwd(const miseg_winattn_bwd_params* p, miseg_stream
   WinGeom g;
   int rc = make_geom(&p->f, &g);
   if (rc) return rc;
-  if (global_attn_bwd(p, s, &rc)) return rc;       // must take exactly the calls global_attn_fwd took: its log-sum-exp is in the log2 domain
+  MISEG_REQUIRE(p->f.drop_p >= 0.f && p->f.drop_p < 1.f, MISEG_E_BADARG, "winattn_bwd: drop_p = %f must lie in [0, 1)", (double)p->f.drop_p);
+  const AttnDrop dr = attn_drop_args(&p->f);
+  if (!dr.thresh && global_attn_bwd(p, s, &rc)) return rc;       // must take exactly the calls global_attn_fwd took: its log-sum-exp is in the log2 domain
   const int tb = 2 * g.tw - 1, tsize = p->f.bias_table ? tb * tb * tb : 0;
   const size_t sh = attn_smem_bytes(g.n, g.hd, tsize, true);
   MISEG_REQUIRE(sh <= 160 * 1024, MISEG_E_UNSUPPORTED, "winattn_bwd: %zu bytes of LDS needed", sh);
   dim3 grid(g.B * g.nwd * g.nwh * g.nww, g.heads);
   const int threads = cdiv(g.n, 64) * 64;
-  if (p->f.dtype == MISEG_BF16 && g.hd == 16 && g.n <= ATT_NP && p->f.bias_table && ((uintptr_t)p->dqkv % 8 == 0) && p->lddq % 4 == 0 &&
+  if (!dr.thresh && p->f.dtype == MISEG_BF16 && g.hd == 16 && g.n <= ATT_NP && p->f.bias_table && ((uintptr_t)p->dqkv % 8 == 0) && p->lddq % 4 == 0 &&
       ((uintptr_t)p->f.qkv % 8 == 0) && p->f.ldq % 4 == 0) {
     const bool vec = p->f.ldq % 8 == 0 && p->f.ldo % 8 == 0 && p->lddo % 8 == 0 && (uintptr_t)p->f.qkv % 16 == 0 && (uintptr_t)p->f.out % 16 == 0 &&
                      (uintptr_t)p->dout % 16 == 0;
@@ -895,7 +938,7 @@ extern "C" int miseg_winattn_bwd(const miseg_winattn_bwd_params* p, miseg_stream
       MISEG_SET_SMEM((winattn_bwd_kernel<T, HD4>), sh);
       winattn_bwd_kernel<T, HD4><<<grid, threads, sh, s>>>((const T*)p->f.qkv, p->f.ldq, (const T*)p->f.out, p->f.ldo, (const T*)p->dout, p->lddo, (T*)p->dqkv, p->lddq,
                                                            p->f.qkv_bias, p->f.bias_table, p->f.lse, p->dqkv_bias, p->dbias_table ? p->dbias_table : nullptr, g,
-                                                           tsize);
+                                                           tsize, dr);
     });
     MISEG_LAUNCH_CHECK("winattn_bwd");
     return MISEG_OK;

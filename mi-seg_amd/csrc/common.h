@@ -107,6 +107,18 @@ template <class F> static inline int dispatch_dtype(int dtype, F&& f) {
   return set_error(MISEG_E_BADARG, "unknown dtype %d", dtype);
 }
 
+// counter-based dropout (training.hip: miseg_dropout; attention.hip: attention-probability dropout): splitmix64 finaliser, nothing stored
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+  z ^= z >> 27; z *= 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+static inline uint64_t dropout_host_key(uint64_t seed, uint64_t stream_id) { return seed * 0x9E3779B97F4A7C15ull + stream_id * 0xC2B2AE3D27D4EB4Full + 0x165667B19E3779F9ull; }
+__device__ __forceinline__ uint64_t dropout_step_key(uint64_t key, const uint64_t* step_dev) { return mix64(key ^ (step_dev ? (*step_dev) * 0x9E3779B97F4A7C15ull : 0ull)); }
+// element (row, c) of a [rows][C] matrix: one hash per group of 4 consecutive columns, four 16-bit draws against the 16-bit threshold
+__device__ __forceinline__ uint64_t dropout_group_hash(uint64_t k, int64_t row, int cg, int c) { return mix64(k + (uint64_t)(row * cg + (c >> 2)) * 0xD1342543DE82EF95ull); }
+__device__ __forceinline__ bool dropout_keeps(uint64_t h, int c, unsigned thresh) { return (unsigned)((h >> (16 * (c & 3))) & 0xffff) >= thresh; }
+
 // norm.hip: second launch of a split convolution - y = round(sum of nslabs fp32 slabs [B * S][C] (+ res)), and the instance-norm statistics
 // of y into `stat` (replicated fp64 layout of miseg_instnorm_stats; may be null)
 int slabs_to_out_stats(const float* slabs, int nslabs, void* y, int64_t ldy, const void* res, int64_t ldres, int B, int S, int C, int dtype, double* stat,

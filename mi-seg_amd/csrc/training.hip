@@ -452,17 +452,13 @@ __global__ void __launch_bounds__(256) augment_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ dropout / drop-path
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {     // splitmix64 finaliser: a counter-based generator, nothing to store
-  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
-  z ^= z >> 27; z *= 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
+// (mix64 and the key / group-hash helpers live in common.h: the attention kernels draw the same masks)
 
 // one 64-bit hash per group of 4 consecutive channels: four 16-bit draws against a 16-bit threshold (p is quantised to 1 / 65536)
 template <class T>
 __global__ void __launch_bounds__(256) dropout_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, int64_t rows, int C, int64_t rps,
                                                       unsigned thresh, float scale, uint64_t key, const uint64_t* __restrict__ step_dev) {
-  const uint64_t k = mix64(key ^ (step_dev ? (*step_dev) * 0x9E3779B97F4A7C15ull : 0ull));
+  const uint64_t k = dropout_step_key(key, step_dev);
   const int cg = (C + 3) / 4;
   const int64_t total = rows * cg;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -717,7 +713,7 @@ extern "C" int miseg_dropout(const miseg_dropout_params* p, miseg_stream_t s_) {
   MISEG_REQUIRE(p->p >= 0.f && p->p < 1.f, MISEG_E_BADARG, "dropout: p = %f must lie in [0, 1)", (double)p->p);
   const unsigned thresh = (unsigned)lrintf(p->p * 65536.f);
   const float scale = 1.f / (1.f - (float)thresh / 65536.f);
-  const uint64_t key = p->seed * 0x9E3779B97F4A7C15ull + p->stream_id * 0xC2B2AE3D27D4EB4Full + 0x165667B19E3779F9ull;
+  const uint64_t key = dropout_host_key(p->seed, p->stream_id);
   int grid = cdiv(p->rows * ((p->C + 3) / 4), 256 * 4);
   if (grid > 4096) grid = 4096;
   return dispatch_dtype(p->dtype, [&](auto* tag) -> int {

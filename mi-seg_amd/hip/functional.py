@@ -788,8 +788,10 @@ class _WinAttn(Function):
     (window_attention.py:99-119, swin_transformer_block.py:116-169)."""
 
     @staticmethod
-    def forward(ctx, qkv, qkv_bias, table, heads, window, shift, tw, scale):
-        out, lse = ops.winattn_fwd(qkv, qkv_bias, table, heads, window, shift, tw, scale)
+    def forward(ctx, qkv, qkv_bias, table, heads, window, shift, tw, scale, drop_p):
+        # attn_drop (swin_transformer_block.py:56-58,91): the mask is drawn inside the kernels from a key, the backward re-creates it
+        ctx.drop = (drop_p, ops.DROP.next_key(qkv.device)) if drop_p > 0.0 else None
+        out, lse = ops.winattn_fwd(qkv, qkv_bias, table, heads, window, shift, tw, scale, ctx.drop)
         ctx.save_for_backward(qkv, out, lse, qkv_bias, table)
         ctx.meta = (heads, window, shift, tw, scale)
         ctx.params = (qkv_bias, table)
@@ -803,12 +805,12 @@ class _WinAttn(Function):
         st = _slot(ctx.params[1]) if ctx.needs_input_grad[2] else None
         dqb = sq if sq is not None else (ops.zeros_f32(qkv_bias.shape, qkv.device) if qkv_bias is not None and ctx.needs_input_grad[1] else None)
         dtab = st if st is not None else (ops.zeros_f32(table.shape, qkv.device) if table is not None and ctx.needs_input_grad[2] else None)
-        dqkv = ops.winattn_bwd(qkv, out, lse, _rv(dout), qkv_bias, table, heads, window, shift, tw, scale, dqb, dtab)
-        return dqkv, None if sq is not None else dqb, None if st is not None else dtab, None, None, None, None, None
+        dqkv = ops.winattn_bwd(qkv, out, lse, _rv(dout), qkv_bias, table, heads, window, shift, tw, scale, dqb, dtab, ctx.drop)
+        return dqkv, None if sq is not None else dqb, None if st is not None else dtab, None, None, None, None, None, None
 
 
-def window_attention(qkv, qkv_bias, table, heads, window, shift, tw, scale):
-    return _WinAttn.apply(qkv, qkv_bias, table, heads, tuple(window), tuple(shift), tw, scale)
+def window_attention(qkv, qkv_bias, table, heads, window, shift, tw, scale, drop_p=0.0, training=True):
+    return _WinAttn.apply(qkv, qkv_bias, table, heads, tuple(window), tuple(shift), tw, scale, float(drop_p) if training else 0.0)
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -71,7 +71,7 @@ Conv3Wgrad = _struct("Conv3Wgrad", cname="miseg_conv3_wgrad_params", fields=[("x
 Winattn = _struct("Winattn", cname="miseg_winattn_params", fields=[("qkv", vp), ("ldq", i64), ("out", vp), ("ldo", i64), ("qkv_bias", vp), ("bias_table", vp),
                               ("lse", vp), ("B", i32), ("D", i32), ("H", i32), ("W", i32), ("C", i32), ("heads", i32),
                               ("dtype", i32), ("wd", i32), ("wh", i32), ("ww", i32), ("sd", i32), ("sh", i32), ("sw", i32),
-                              ("tw", i32), ("scale", f32)])
+                              ("tw", i32), ("scale", f32), ("drop_p", f32), ("drop_seed", C.c_uint64), ("drop_stream", C.c_uint64), ("drop_step_dev", vp)])
 WinattnBwd = _struct("WinattnBwd", cname="miseg_winattn_bwd_params", fields=[("f", Winattn), ("dout", vp), ("lddo", i64), ("dqkv", vp), ("lddq", i64),
                                     ("dqkv_bias", vp), ("dbias_table", vp)])
 Add = _struct("Add", cname="miseg_add_params", fields=[("a", vp), ("lda", i64), ("b", vp), ("ldb", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32), ("dtype", i32)])

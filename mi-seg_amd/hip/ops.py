@@ -770,27 +770,29 @@ def im2col3(x, adjoint=False, C_out=None):
 
 
 # ------------------------------------------------------------------------------------------ attention
-def winattn_params(qkv, out, qkv_bias, table, lse, heads, window, shift, tw, scale):
+def winattn_params(qkv, out, qkv_bias, table, lse, heads, window, shift, tw, scale, drop=None):
+    """drop = (p, (seed, stream_id, step_dev)) puts dropout on the attention probabilities; the key is DROP.next_key's"""
     B, D, H, W = _vol(qkv)
     ldq, n, C3 = rows(qkv)
     Cc = C3 // 3
+    dp, (seed, sid, step) = drop if drop else (0.0, (0, 0, None))
     return L.Winattn(_ptr(qkv), ldq, _ptr(out), rows(out)[0], _ptr(qkv_bias), _ptr(table), _ptr(lse), B, D, H, W, Cc, heads, _dt(qkv),
-                     window[0], window[1], window[2], shift[0], shift[1], shift[2], tw, scale)
+                     window[0], window[1], window[2], shift[0], shift[1], shift[2], tw, scale, float(dp), seed, sid, _ptr(step))
 
 
-def winattn_fwd(qkv, qkv_bias, table, heads, window, shift, tw, scale):
+def winattn_fwd(qkv, qkv_bias, table, heads, window, shift, tw, scale, drop=None):
     B, D, H, W = _vol(qkv)
     Cc = qkv.shape[-1] // 3
     out = torch.empty(B, D, H, W, Cc, dtype=qkv.dtype, device=qkv.device)
     nw = B * -(-D // window[0]) * -(-H // window[1]) * -(-W // window[2])
     lse = torch.empty(nw, heads, window[0] * window[1] * window[2], dtype=torch.float32, device=qkv.device)
-    _call("miseg_winattn_fwd", winattn_params(qkv, out, qkv_bias, table, lse, heads, window, shift, tw, scale))
+    _call("miseg_winattn_fwd", winattn_params(qkv, out, qkv_bias, table, lse, heads, window, shift, tw, scale, drop))
     return out, lse
 
 
-def winattn_bwd(qkv, out, lse, dout, qkv_bias, table, heads, window, shift, tw, scale, dqkv_bias, dtable):
+def winattn_bwd(qkv, out, lse, dout, qkv_bias, table, heads, window, shift, tw, scale, dqkv_bias, dtable, drop=None):
     dqkv = torch.empty(qkv.shape, dtype=qkv.dtype, device=qkv.device)
-    f = winattn_params(qkv, out, qkv_bias, table, lse, heads, window, shift, tw, scale)
+    f = winattn_params(qkv, out, qkv_bias, table, lse, heads, window, shift, tw, scale, drop)
     p = L.WinattnBwd(f, _ptr(dout), rows(dout)[0], _ptr(dqkv), rows(dqkv)[0], _ptr(dqkv_bias), _ptr(dtable))
     _call("miseg_winattn_bwd", p)
     return dqkv

@@ -54,8 +54,9 @@ class PatchEmbeddingBlock(nn.Module):
             raise ValueError("hidden size should be divisible by num_heads.")
         if pos_embed not in ("conv", "perceptron"):
             raise ValueError(f"Unsupported option '{pos_embed}'")
-        if spatial_dims != 3 or dropout_rate != 0.0:
-            raise NotImplementedError("only spatial_dims=3, dropout 0 are implemented by the MI355X path")
+        if spatial_dims != 3:
+            raise NotImplementedError("only spatial_dims=3 is implemented by the MI355X path")
+        self.dropout_rate = float(dropout_rate)
         self.pos_embed = pos_embed
         img_size = (img_size,) * 3 if isinstance(img_size, int) else tuple(img_size)
         patch_size = (patch_size,) * 3 if isinstance(patch_size, int) else tuple(patch_size)
@@ -99,4 +100,4 @@ class PatchEmbeddingBlock(nn.Module):
         pos = self.position_embeddings.to(dtype)
         if b > 1:   # [1, L, C] learned table broadcast over the batch (L*C elements: negligible next to the GEMM above)
             pos = pos.expand(b, -1, -1).contiguous()
-        return HF.add(e, pos)
+        return HF.dropout(HF.add(e, pos), self.dropout_rate, self.training)      # patch_embedding.py:121-122

@@ -13,8 +13,7 @@ class SABlock(nn.Module):
             raise ValueError("dropout_rate should be between 0 and 1.")
         if hidden_size % num_heads != 0:
             raise ValueError("hidden size should be divisible by num_heads.")
-        if dropout_rate != 0.0:
-            raise NotImplementedError("dropout > 0 is not implemented by the MI355X path")
+        self.dropout_rate = float(dropout_rate)     # MONAI SABlock: drop_weights on the probabilities, drop_output after out_proj
         self.num_heads = num_heads
         self.out_proj = nn.Linear(hidden_size, hidden_size)
         self.qkv = nn.Linear(hidden_size, hidden_size * 3, bias=qkv_bias)
@@ -26,5 +25,5 @@ class SABlock(nn.Module):
         b, l, c = x.shape
         qkv = HF.linear(x, self.qkv.weight, self.qkv.bias)          # "b h (qkv l d)": q | k | v blocks, head-major inside
         qkv5 = qkv.view(b, grid[0], grid[1], grid[2], 3 * c)
-        o = HF.window_attention(qkv5, self.qkv.bias, None, self.num_heads, grid, (0, 0, 0), 1, self.scale)
-        return HF.linear(o.view(b, l, c), self.out_proj.weight, self.out_proj.bias)
+        o = HF.window_attention(qkv5, self.qkv.bias, None, self.num_heads, grid, (0, 0, 0), 1, self.scale, self.dropout_rate, self.training)
+        return HF.dropout(HF.linear(o.view(b, l, c), self.out_proj.weight, self.out_proj.bias), self.dropout_rate, self.training)

@@ -14,9 +14,7 @@ class WindowAttention(nn.Module):
     def __init__(self, dim: int, num_heads: int, window_size: Sequence[int], qkv_bias: bool = False, attn_drop: float = 0.0,
                  proj_drop: float = 0.0) -> None:
         super().__init__()
-        if attn_drop != 0.0:
-            raise NotImplementedError("dropout on the attention probabilities (attn_drop > 0) is not implemented by the MI355X path: the "
-                                      "scores never leave the fused attention kernel")
+        self.attn_drop = float(attn_drop)       # window_attention.py:93,114: drawn inside the fused attention kernels, the scores never leave them
         self.proj_drop = float(proj_drop)
         if len(window_size) != 3:
             raise NotImplementedError("only 3D windows are implemented by the MI355X path")
@@ -47,7 +45,7 @@ class WindowAttention(nn.Module):
         """x: normalised tokens on the unpadded grid [B, D, H, W, C]; window/shift already clamped."""
         qkv = HF.linear(x, self.qkv.weight, self.qkv.bias)
         o = HF.window_attention(qkv, self.qkv.bias, self.relative_position_bias_table, self.num_heads, window, shift,
-                                self.window_size[0], self.scale)
+                                self.window_size[0], self.scale, self.attn_drop, self.training)
         if self.proj_drop > 0.0 and self.training:        # window_attention.py:120-121: proj_drop(proj(x)); the residual is then added separately
             y = HF.dropout(HF.linear(o, self.proj.weight, self.proj.bias), self.proj_drop)
             return HF.add(res, y) if res is not None else y

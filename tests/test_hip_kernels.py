@@ -1,5 +1,6 @@
 """GPU parity tests, kernel level: every C-ABI entry point against a plain PyTorch fp32 reference of the same op
 (run on the device) -- tolerances: fp32 path 2e-4 relative L2 (north_star asks 1e-3), bf16 path 2e-2."""
+import math
 import os
 import pytest
 import torch
@@ -641,7 +642,7 @@ def test_space_channel_im2col_misc(dtype):
     assert torch.equal(ops.cast_matrix(w, dtype, transpose=True), w.t().contiguous().to(dtype))
 
 
-def _ref_window_attention(qkv, qkv_bias, table, heads, ws, ss, tw, scale):
+def _ref_window_attention(qkv, qkv_bias, table, heads, ws, ss, tw, scale, drop_mask=None):
     """plain PyTorch fp32 reference of the fused attention core (pad with the bias row, roll, partition, softmax(QK^T+bias+mask)V,
     reverse, roll back, crop) built from the oracle's helpers."""
     from oracle.functional import compute_mask, relative_position_index, window_partition, window_reverse
@@ -668,7 +669,10 @@ def _ref_window_attention(qkv, qkv_bias, table, heads, ws, ss, tw, scale):
     if mask is not None:
         nw = mask.shape[0]
         attn = (attn.view(b // nw, nw, heads, n, n) + mask.unsqueeze(1).unsqueeze(0)).view(-1, heads, n, n)
-    o = (attn.softmax(-1) @ v).transpose(1, 2).reshape(b, n, C)
+    prob = attn.softmax(-1)
+    if drop_mask is not None:         # attn_drop: [windows, heads, n, n] of 0 or 1 / (1 - p), window_attention.py:114
+        prob = prob * drop_mask
+    o = (prob @ v).transpose(1, 2).reshape(b, n, C)
     o = window_reverse(o.view(-1, *ws, C), ws, (B, Dp, Hp, Wp))
     if any(ss):
         o = torch.roll(o, shifts=ss, dims=(1, 2, 3))
@@ -704,6 +708,66 @@ def test_window_attention_core(dtype, dims, ws, ss, heads, C):
         assert rel_err(dqb, qbr.grad) < 2 * tol
     else:
         assert float(dqb.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dims,ws,ss,heads,C", [((14, 14, 14), (7, 7, 7), (3, 3, 3), 3, 48), ((10, 9, 8), (7, 7, 7), (3, 3, 3), 2, 32),
+                                                ((6, 6, 6), (6, 6, 6), (0, 0, 0), 3, 48)])
+def test_window_attention_dropout_on_the_probabilities(dtype, dims, ws, ss, heads, C):
+    """attn_drop > 0 (swin_transformer_block.py:56-58 -> window_attention.py:93,114): out = (softmax(.) * mask / (1 - p)) v.  The mask the
+    kernels draw is miseg_dropout's over the matrix [windows * heads * n][n], so the reference takes it from ops.dropout_apply on ones with the
+    same key; forward, every gradient, and the backward pass re-creating the mask from the key alone."""
+    ops = _ops()
+    B, p = 2, 0.25
+    qkv = rnd(B, *dims, 3 * C, dtype=dtype, seed=85)
+    qb = rnd(3 * C, seed=86) * 0.3
+    table = rnd(2197, heads, seed=87) * 0.5
+    scale = (C // heads) ** -0.5
+    n = ws[0] * ws[1] * ws[2]
+    nwin = B * math.prod(-(-d // w) for d, w in zip(dims, ws))
+    ops.begin_step()
+    key = ops.DROP.next_key(qkv.device)
+    mask = ops.dropout_apply(torch.ones(nwin * heads * n, n, device=DEV), p, key).view(nwin, heads, n, n)
+    kept = float((mask != 0).float().mean())
+    assert abs(kept - (1 - p)) < 0.01 and torch.all((mask == 0) | ((mask - 1 / (1 - p)).abs() < 1e-6))
+    out, lse = ops.winattn_fwd(qkv, qb, table, heads, ws, ss, 7, scale, drop=(p, key))
+    qr = qkv.float().clone().requires_grad_(True)
+    qbr, tr = qb.clone().requires_grad_(True), table.clone().requires_grad_(True)
+    ref = _ref_window_attention(qr, qbr, tr, heads, ws, ss, 7, scale, drop_mask=mask)
+    assert rel_err(out, ref) < TOL[dtype]
+    plain, _ = ops.winattn_fwd(qkv, qb, table, heads, ws, ss, 7, scale)
+    assert rel_err(plain, ref) > 0.1                      # the mask really was applied
+    g = rnd(*out.shape, dtype=dtype, seed=88)
+    ref.backward(g.float())
+    dqb, dtab = torch.zeros_like(qb), torch.zeros_like(table)
+    dqkv = ops.winattn_bwd(qkv, out, lse, g, qb, table, heads, ws, ss, 7, scale, dqb, dtab, drop=(p, key))
+    tol = TOL[dtype] * (2 if dtype == torch.bfloat16 else 1)
+    for i, name in enumerate("qkv"):
+        assert rel_err(dqkv[..., i * C:(i + 1) * C], qr.grad[..., i * C:(i + 1) * C]) < tol, f"d{name}"
+    assert rel_err(dtab, tr.grad) < tol
+    if any((-d) % w for d, w in zip(dims, ws)):
+        assert rel_err(dqb, qbr.grad) < 2 * tol
+
+
+def test_global_attention_dropout_takes_the_query_lane_kernels():
+    """the SABlock of the ViT with dropout_rate > 0 (MONAI SABlock.drop_weights): head_dim 64, no bias table, one window"""
+    ops = _ops()
+    B, heads, dims, p = 2, 2, (4, 4, 4), 0.1
+    C, n = 64 * heads, 64
+    qkv = rnd(B, *dims, 3 * C, dtype=torch.bfloat16, seed=93)
+    scale = 64 ** -0.5
+    ops.begin_step()
+    key = ops.DROP.next_key(qkv.device)
+    mask = ops.dropout_apply(torch.ones(B * heads * n, n, device=DEV), p, key).view(B, heads, n, n)
+    out, lse = ops.winattn_fwd(qkv, None, None, heads, dims, (0, 0, 0), 1, scale, drop=(p, key))
+    qr = qkv.float().clone().requires_grad_(True)
+    q, k, v = qr.reshape(B, n, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = ((((q @ k.transpose(-2, -1)) * scale).softmax(-1) * mask) @ v).transpose(1, 2).reshape(B, *dims, C)
+    assert rel_err(out, ref) < TOL[torch.bfloat16]
+    g = rnd(*out.shape, dtype=torch.bfloat16, seed=94)
+    ref.backward(g.float())
+    dqkv = ops.winattn_bwd(qkv, out, lse, g, None, None, heads, dims, (0, 0, 0), 1, scale, None, None, drop=(p, key))
+    assert rel_err(dqkv, qr.grad) < 2 * TOL[torch.bfloat16]
 
 
 @pytest.mark.parametrize("dims,heads", [((6, 6, 6), 12), ((5, 5, 5), 2), ((3, 3, 3), 3), ((4, 8, 8), 1), ((2, 3, 5), 2)])

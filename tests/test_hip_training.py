@@ -380,7 +380,7 @@ def test_dropout_and_drop_path_kernels(dtype):
 
 
 def test_swin_unetr_trains_with_dropout_and_stochastic_depth():
-    """--dropout_rate / --dropout_path_rate > 0 (utils/parser.py:23,38) on the headline model: eval mode is the dropout-free network,
+    """--dropout_rate / --attn_drop_rate / --dropout_path_rate > 0 (utils/parser.py:23,26,38) on the headline model: eval mode is the dropout-free network,
     train mode draws new masks every step - also when the step is a replayed hipGraph - and back-propagates through them."""
     from mi_seg_amd.hip import ops
     from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
@@ -388,7 +388,7 @@ def test_swin_unetr_trains_with_dropout_and_stochastic_depth():
     from mi_seg_amd.utils.detfill import det_input, fill_module_
     mk = lambda **kw: SwinUNETR((64, 64, 64), 1, 3, feature_size=12, num_heads=(3, 6, 12, 24), vit_norm_name=_norm("instance_cond"),
                                 encoder_norm_name=_norm("instance_cond"), decoder_norm_name=_norm("instance"), **kw)
-    plain, drop = mk(), mk(drop_rate=0.1, dropout_path_rate=0.3)
+    plain, drop = mk(), mk(drop_rate=0.1, attn_drop_rate=0.1, dropout_path_rate=0.3)
     for m in (plain, drop):
         fill_module_(m)
         m.to(DEV)
@@ -413,8 +413,38 @@ def test_swin_unetr_trains_with_dropout_and_stochastic_depth():
     r1 = step(x, [0, 1], cot).detach().clone()
     r2 = step(x, [0, 1], cot).detach().clone()
     assert not torch.equal(r1, r2) and bool(torch.isfinite(r2).all())
-    with pytest.raises(NotImplementedError):
-        mk(attn_drop_rate=0.1)
+
+
+def test_unetr_trains_with_dropout():
+    """--dropout_rate > 0 on UNETR (networks/nets/unetr.py -> MONAI ViT: patch-embedding dropout, SABlock drop_weights / drop_output,
+    MLPBlock drop1 / drop2): eval mode is the dropout-free network, train mode draws new masks per step and back-propagates through them."""
+    from mi_seg_amd.hip import ops
+    from mi_seg_amd.networks.nets.unetr import UNETR
+    from mi_seg_amd.utils.detfill import det_input, fill_module_
+    mk = lambda **kw: UNETR(1, 3, (32, 32, 32), feature_size=8, hidden_size=48, mlp_dim=96, num_heads=4, pos_embed="perceptron",
+                            vit_norm_name=_norm("instance_cond"), encoder_norm_name=_norm("instance_cond"), decoder_norm_name=_norm("instance"), **kw)
+    plain, drop = mk(), mk(dropout_rate=0.2)
+    for m in (plain, drop):
+        fill_module_(m)
+        m.to(DEV)
+    x = det_input(5, (2, 1, 32, 32, 32)).to(DEV)
+    cot = det_input(6, (2, 3, 32, 32, 32)).to(DEV)
+    drop.eval()
+    with torch.no_grad():
+        assert torch.equal(drop(x, [0, 1]), plain(x, [0, 1]))
+    drop.train()
+    outs = []
+    for _ in range(2):
+        drop.zero_grad(set_to_none=True)
+        ops.begin_step()
+        y = drop(x, [0, 1])
+        y.backward(cot)
+        assert bool(torch.isfinite(y).all()) and all(bool(torch.isfinite(p.grad).all()) for p in drop.parameters() if p.grad is not None)
+        outs.append(y.detach().clone())
+    assert not torch.equal(outs[0], outs[1])
+    with torch.no_grad():
+        ref = plain(x, [0, 1])
+    assert 0.0 < rel_err(outs[0], ref) < 1.0      # a perturbation of the dropout-free network, not noise
 
 
 def test_litmonai_training_and_validation_steps_on_the_hip_path():
