@@ -1142,11 +1142,18 @@ static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 static void fwd96_plan(int nbricks, int Cout, int nchunks, int* nt, int* ksplit) {
   *nt = Cout <= 16 ? 1 : Cout <= 32 ? 2 : 3;
   int blocks = nbricks * cdiv(Cout, 16 * (*nt));
-  if (blocks < 256 && *nt > 1) { *nt = 1; blocks = nbricks * cdiv(Cout, 16); }
   int ks = 1;
-  if (blocks < 256 && nchunks > 1) {
-    ks = cdiv(1024, blocks);      // tiny grids: one 96-byte chunk per workgroup (each chunk is a serial staging + 14-phase chain)
-    if (ks > nchunks) ks = nchunks;
+  if (nbricks <= 4 && nchunks > 1) {
+    // a volume of a few bricks (6^3, 3^3: 384 - 768 channels): the launch is one serial chain of staging + 14 phases per chunk however it is
+    // cut, so every chunk gets its own workgroup and the 48-channel tile keeps the halo staging shared by three times the MFMAs
+    // (scripts/micro/f96_plan_sweep.py: 768 -> 384 at 6^3 33.8 -> 28.2 us, 768 -> 768 at 3^3 22.7 -> 19.7 us)
+    ks = nchunks;
+  } else {
+    if (blocks < 256 && *nt > 1) { *nt = 1; blocks = nbricks * cdiv(Cout, 16); }
+    if (blocks < 256 && nchunks > 1) {
+      ks = cdiv(512, blocks);       // small grids: about two workgroups per CU (384 -> 192 at 12^3: split 8 / 4 / 2 = 30.1 / 25.7 / 31.5 us)
+      if (ks > nchunks) ks = nchunks;
+    }
   }
   *ksplit = ks;
 }
