@@ -223,9 +223,8 @@ def _run_convolution(m: "Convolution", x, styles, image=None, dtype=None):
                 y = apply_norm(child, y, styles)
             elif name == "A":
                 y = HF.prelu(y, child.weight)
-            # "D": Dropout(p=0) is the identity (constructors reject p > 0 elsewhere; here p is honoured as 0 only)
-            elif name == "D" and child.p != 0.0:
-                raise NotImplementedError("dropout > 0 is not implemented by the MI355X path")
+            elif name == "D":       # MONAI ADN, dropout_dim 1: nn.Dropout (the counter-based mask of miseg_dropout, identity in eval mode)
+                y = HF.dropout(y, child.p, child.training)
     return y
 
 

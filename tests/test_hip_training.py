@@ -447,6 +447,35 @@ def test_unetr_trains_with_dropout():
     assert 0.0 < rel_err(outs[0], ref) < 1.0      # a perturbation of the dropout-free network, not noise
 
 
+def test_unet_trains_with_dropout():
+    """--dropout_rate > 0 on the UNet (reference networks/nets/unet.py:232 -> every ADN's nn.Dropout between norm and PReLU)"""
+    from mi_seg_amd.hip import ops
+    from mi_seg_amd.networks.nets.unet import UNet
+    from mi_seg_amd.utils.detfill import det_input, fill_module_
+    mk = lambda **kw: UNet(3, 1, 3, channels=(8, 16, 32), strides=(2, 2), num_res_units=2, norm_down=_norm("instance_cond"), norm_up=_norm("instance"), **kw)
+    plain, drop = mk(), mk(dropout=0.2)
+    for m in (plain, drop):
+        fill_module_(m)
+        m.to(DEV)
+    x = det_input(7, (2, 1, 32, 32, 32)).to(DEV)
+    cot = det_input(8, (2, 3, 32, 32, 32)).to(DEV)
+    drop.eval()
+    with torch.no_grad():
+        ref = plain(x, [0, 1])
+        assert torch.equal(drop(x, [0, 1]), ref)
+    drop.train()
+    outs = []
+    for _ in range(2):
+        drop.zero_grad(set_to_none=True)
+        ops.begin_step()
+        y = drop(x, [0, 1])
+        y.backward(cot)
+        assert bool(torch.isfinite(y).all()) and all(bool(torch.isfinite(p.grad).all()) for p in drop.parameters() if p.grad is not None)
+        outs.append(y.detach().clone())
+    assert not torch.equal(outs[0], outs[1])
+    assert 0.0 < rel_err(outs[0], ref) < 1.0
+
+
 def test_litmonai_training_and_validation_steps_on_the_hip_path():
     """SURVEY 8(a) rows a14 / a15 end to end on the device: `LitMonai.from_argparse_args` (reference networks/lightning_monai.py:113-144) ->
     `training_step` (batch keys image / label / modality, fused DiceFocal with --no_include_background, :149-166) and `validation_step`
