@@ -37,5 +37,8 @@ def run(S, C, dtype=torch.bfloat16, act=L.ACT_LEAKY):
     print(f"S {S:7d} C {C:4d}: fwd {t_f:6.1f} us | stats {t_s:7.1f} us ({nb/t_s/1e6:5.2f} TB/s)  apply {t_a:7.1f} us ({2*nb/t_a/1e6:5.2f} TB/s)  "
           f"bwd {t_b:7.1f} us ({7*nb/t_b/1e6:5.2f} TB/s of 7N)", flush=True)
 
-for S, C in [(96**3, 48), (48**3, 96), (48**3, 48), (24**3, 192), (24**3, 96), (12**3, 384), (6**3, 768), (27, 768)]:
+shapes = [(96**3, 48), (48**3, 96), (48**3, 48), (24**3, 192), (24**3, 96), (12**3, 384), (6**3, 768), (27, 768)]
+if len(sys.argv) > 1 and sys.argv[1] == "mid":
+    shapes = [(24**3, 96), (24**3, 192), (12**3, 192), (12**3, 384), (6**3, 384), (6**3, 768)]
+for S, C in shapes:
     run(S, C)
