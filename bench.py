@@ -225,7 +225,16 @@ def main():
             ye.backward(cot)
         ge_ = flat()
         rel = lambda u, v: float((u - v).norm() / v.norm())
-        return {"logits_rel_err": rel(y, ye.detach().float()), "grad_rel_err": rel(g, ge_), "finite": bool(torch.isfinite(g).all())}
+        res = {"logits_rel_err": rel(y, ye.detach().float()), "grad_rel_err": rel(g, ge_), "finite": bool(torch.isfinite(g).all())}
+        # no work skipped: every parameter received a gradient except the conditional-norm rows of the modality absent from this batch
+        # (reference: grad is None for them), and none of the received ones is identically zero
+        got = [(n, p.grad) for n, p in model.named_parameters() if p.requires_grad]
+        missing = [n for n, g_ in got if g_ is None]
+        other = 1 - int(mods[k])
+        unexpected = [n for n in missing if f".norms.{other}." not in n]
+        zero = [n for n, g_ in got if g_ is not None and float(g_.float().abs().max()) == 0.0]
+        res.update({"params": len(got), "params_without_grad": len(missing), "params_without_grad_unexpected": unexpected[:5], "params_with_zero_grad": zero[:5]})
+        return res
 
     def exchange_check():
         """untimed, N > 1: the arena after one (overlapped) data-parallel step against the plain mean of the ranks' local gradients"""
@@ -252,6 +261,8 @@ def main():
         check = replay_check()
         if not check["finite"] or check["logits_rel_err"] > 1e-2 or check["grad_rel_err"] > 5e-2:
             raise SystemExit(f"hipGraph replay does not reproduce the eager step: {check}")
+        if check["params_without_grad_unexpected"] or check["params_with_zero_grad"]:
+            raise SystemExit(f"the timed step left parameters without a gradient: {check}")
         out["replay_check"] = check
     if dist is not None and arena is not None:
         out["exchange_check"] = exchange_check()

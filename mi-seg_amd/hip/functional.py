@@ -567,6 +567,36 @@ def rowbias(x, bias):
     return x if bias is None else _RowBias.apply(x, bias)
 
 
+class _AddPosition(Function):
+    """x [B, L, C] + the learned position table [1, L, C] (MONAI PatchEmbeddingBlock, reference patch_embedding.py:121): the fp32 parameter
+    is added to the activations directly (one rounding), its gradient - the sum of dy over the batch - goes to the parameter's arena slot
+    like every other weight gradient (a `.to(dtype)` copy made autograd write `p.grad` itself, which arena.publish() then dropped)."""
+
+    @staticmethod
+    def forward(ctx, x, pos):
+        ctx.params = (pos,)
+        B = x.shape[0]
+        return ops.rowbias_add(x.reshape(B, -1), pos.reshape(-1)).view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _rv(g)
+        pos = ctx.params[0]
+        dpos = None
+        if ctx.needs_input_grad[1]:
+            g2 = g.reshape(g.shape[0], -1)
+            slot = _slot(pos)
+            if slot is not None:
+                ops.colsum(g2, out=slot.view(-1), accumulate=True)
+            else:
+                dpos = ops.colsum(g2).view(pos.shape)
+        return g, dpos
+
+
+def add_position(x, pos):
+    return _AddPosition.apply(x, pos)
+
+
 class _PReLU(Function):
     @staticmethod
     def forward(ctx, x, slope):

@@ -97,7 +97,4 @@ class PatchEmbeddingBlock(nn.Module):
             bias = self.patch_embeddings.bias
         t = t.reshape(b, self.n_patches, self.patch_dim).to(dtype)
         e = HF.linear(t, w2, bias)
-        pos = self.position_embeddings.to(dtype)
-        if b > 1:   # [1, L, C] learned table broadcast over the batch (L*C elements: negligible next to the GEMM above)
-            pos = pos.expand(b, -1, -1).contiguous()
-        return HF.dropout(HF.add(e, pos), self.dropout_rate, self.training)      # patch_embedding.py:121-122
+        return HF.dropout(HF.add_position(e, self.position_embeddings), self.dropout_rate, self.training)      # patch_embedding.py:121-122

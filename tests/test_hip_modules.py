@@ -359,21 +359,33 @@ def test_unetr_c3(golden, dtype, tol):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["swin_unetr", "unetr", "unet"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_param_arena_matches_plain_autograd(dtype):
+def test_param_arena_matches_plain_autograd(dtype, kind):
     """arena mode (flat gradient buffer the kernels accumulate into, batched per-step weight re-layouts) must give the
-    gradients of the plain path: same kernels, different destination; also across two steps and a skipped style."""
+    gradients of the plain path: same kernels, different destination; also across two steps and a skipped style.  All three nets:
+    a parameter whose gradient autograd writes itself (round 2: UNETR's position table went through a `.to(dtype)` copy) is dropped by
+    arena.publish() - the None pattern and every gradient are compared."""
     from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
+    from mi_seg_amd.networks.nets.unetr import UNETR
+    from mi_seg_amd.networks.nets.unet import UNet
     from mi_seg_amd.runtime.arena import ParamArena
     from mi_seg_amd.utils.detfill import fill_module_, det_input
     from mi_seg_amd.hip import ops
     torch.manual_seed(0)
-    net = SwinUNETR((64, 64, 64), 1, 3, feature_size=12, num_heads=(3, 6, 12, 24), vit_norm_name=_norm("instance_cond"),
+    S = 64 if kind == "swin_unetr" else 32
+    if kind == "swin_unetr":
+        net = SwinUNETR((64, 64, 64), 1, 3, feature_size=12, num_heads=(3, 6, 12, 24), vit_norm_name=_norm("instance_cond"),
+                        encoder_norm_name=_norm("instance_cond"), decoder_norm_name=_norm("instance")).cuda()
+    elif kind == "unetr":
+        net = UNETR(1, 3, (32, 32, 32), feature_size=8, hidden_size=48, mlp_dim=96, num_heads=4, pos_embed="perceptron", vit_norm_name=_norm("instance_cond"),
                     encoder_norm_name=_norm("instance_cond"), decoder_norm_name=_norm("instance")).cuda()
+    else:
+        net = UNet(3, 1, 3, channels=(8, 16, 32), strides=(2, 2), num_res_units=2, norm_down=_norm("instance_cond"), norm_up=_norm("instance")).cuda()
     fill_module_(net)
     net.set_compute_dtype(dtype)
-    x = det_input(3, (2, 1, 64, 64, 64)).cuda()
-    cot = det_input(4, (2, 3, 64, 64, 64)).cuda()
+    x = det_input(3, (2, 1, S, S, S)).cuda()
+    cot = det_input(4, (2, 3, S, S, S)).cuda()
     params = [p for p in net.parameters() if p.requires_grad]
 
     def plain(mods):
