@@ -93,7 +93,8 @@ class PatchEmbeddingBlock(nn.Module):
         else:
             # conv k=s=p == linear over (c p1 p2 p3)
             t = x.view(b, c, H // p0, p0, W // p1, p1, D // p2, p2).permute(0, 2, 4, 6, 1, 3, 5, 7)
-            w2 = self.patch_embeddings.weight.view(self.patch_embeddings.weight.shape[0], -1)
+            w2 = self.patch_embeddings.weight       # [hidden, c, p1, p2, p3] used as the [hidden, c*p1*p2*p3] matrix: the PARAMETER itself goes to
+                                                    # HF.linear (a view of it would carry neither its arena slot nor its cached cast)
             bias = self.patch_embeddings.bias
         t = t.reshape(b, self.n_patches, self.patch_dim).to(dtype)
         e = HF.linear(t, w2, bias)
