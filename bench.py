@@ -212,6 +212,7 @@ def main():
         flat = lambda: arena.flat.clone() if arena is not None else torch.cat([p.grad.reshape(-1).float() for p in params if p.grad is not None])
         y = graphed(pool[k:k + 1], [mods[k]], cot).detach().float().clone()
         g = flat()
+        bg0 = ops.BACKGROUND_LAUNCHES
         if arena is not None:
             arena.begin_step()
             ye = model(pool[k:k + 1], [mods[k]])
@@ -234,6 +235,9 @@ def main():
         unexpected = [n for n in missing if f".norms.{other}." not in n]
         zero = [n for n, g_ in got if g_ is not None and float(g_.float().abs().max()) == 0.0]
         res.update({"params": len(got), "params_without_grad": len(missing), "params_without_grad_unexpected": unexpected[:5], "params_with_zero_grad": zero[:5]})
+        # launches per step that the model's side branch issues throttled (hip/ops.py::_background): conv3_fwd96 at one workgroup per CU,
+        # conv3_wgrad on few CUs.  They run beside the main stream's launches in the step; the roofline leg times the kernels alone
+        res["side_branch_background_launches_per_step"] = ops.BACKGROUND_LAUNCHES - bg0
         return res
 
     def exchange_check():

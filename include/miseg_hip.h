@@ -31,7 +31,7 @@ enum { MISEG_ACT_NONE = 0, MISEG_ACT_LEAKY = 1, MISEG_ACT_GELU = 2, MISEG_ACT_PR
 #define MISEG_MAX_STYLES 4
 
 /* bumped on EVERY change of a struct layout or prototype; bindings must refuse a library whose version differs from the header they mirror */
-#define MISEG_ABI_VERSION 3
+#define MISEG_ABI_VERSION 4
 int miseg_abi_version(void);
 const char* miseg_last_error(void);
 /* writes e.g. "gfx950" for the code objects embedded in the library */
@@ -257,6 +257,9 @@ typedef struct {
    *       with a workspace (split reduction) the second launch, which sums the partial slabs into y, computes them. */
   const void* res; int64_t ldres;
   void* stat;
+  /* ABI 4: 1 = background launch (96-byte-chunk path): one workgroup per CU instead of two, so that the kernels of another stream find
+   * registers, LDS and wave slots on every CU while this one runs (a branch of the step running beside its latency-bound chain) */
+  int32_t background;
 } miseg_conv3_params;
 /* small grids split the reduction over workgroups and need an fp32 staging buffer of the output */
 size_t miseg_conv3_fwd_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int dtype);
@@ -279,6 +282,8 @@ typedef struct {
   int B, D, H, W, Cin, Cout, dtype;
   int accumulate;                  /* 0: dw = result; 1: dw += result; 2: dw is known to be zero on entry (no fill, no read-back) */
   void* workspace;                 /* miseg_conv3_wgrad_workspace_bytes */
+  int32_t max_workgroups;          /* ABI 4: 0 = fill the chip (256); else a cap on the workgroups of the launch (a workgroup owns its CU's registers:
+                                    * a background launch leaves the other CUs to the kernels of another stream).  miseg_conv3_wgrad only */
 } miseg_conv3_wgrad_params;
 size_t miseg_conv3_wgrad_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int miseg_conv3_wgrad(const miseg_conv3_wgrad_params* p, miseg_stream_t stream);

@@ -1193,7 +1193,8 @@ static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
     }
     const bool vec_y = ((uintptr_t)p->y % 16 == 0) && (p->ldy % KPC == 0);
     const int CoP = round_up(p->Cout, 16);
-    const size_t lds = (size_t)6 * FPS * 16 + (size_t)2 * 12 * 16 * nt * 16;
+    size_t lds = (size_t)6 * FPS * 16 + (size_t)2 * 12 * 16 * nt * 16;
+    if (p->background && lds < 83 * 1024) lds = 83 * 1024;      // more than half of the 160 KB: one workgroup per CU
     MISEG_REQUIRE((int64_t)p->B * p->D * p->H * p->W < (1LL << 31), MISEG_E_UNSUPPORTED, "conv3_fwd: more than 2^31 voxels");
     const int ny = cdiv(p->Cout, 16 * nt);
     dim3 grid(nbr * ny, 1, ksplit);
@@ -1280,12 +1281,13 @@ extern "C" int miseg_pack_conv3_batch(const miseg_pack_conv3_desc* descs, int n,
   });
 }
 
-static void wgrad_plan(int B, int D, int H, int W, int Cin, int Cout, int wbd, int* ncob, int* ncib, int* nsplit) {
+static void wgrad_plan(int B, int D, int H, int W, int Cin, int Cout, int wbd, int* ncob, int* ncib, int* nsplit, int max_wg = 0) {
   *ncob = cdiv(Cout, WG_CB);
   *ncib = cdiv(Cin, WG_CB);
   const int nbricks = B * cdiv(D, wbd) * cdiv(H, BH) * cdiv(W, BW);
   int pairs = (*ncob) * (*ncib);
   int ns = 256 / pairs;
+  if (max_wg > 0 && max_wg < 256) ns = max_wg / pairs;
   if (ns < 1) ns = 1;
   if (ns > nbricks) ns = nbricks;
   *nsplit = ns;
@@ -1310,7 +1312,7 @@ template <class T, int WBD>
 static int conv3_wgrad_launch(const miseg_conv3_wgrad_params* p, hipStream_t s) {
   constexpr int KPC = Vec16<T>::N;
   int ncob, ncib, nsplit;
-  wgrad_plan(p->B, p->D, p->H, p->W, p->Cin, p->Cout, WBD, &ncob, &ncib, &nsplit);
+  wgrad_plan(p->B, p->D, p->H, p->W, p->Cin, p->Cout, WBD, &ncob, &ncib, &nsplit, p->max_workgroups);
   ConvGeom g{p->B, p->D, p->H, p->W, cdiv(p->D, WBD), cdiv(p->H, BH), cdiv(p->W, BW)};
   const int rowb = WG_CB * (int)sizeof(T) + 16;
   const size_t lds = (size_t)((WBD + 2) * HH * HW + WBD * BH * BW) * rowb;

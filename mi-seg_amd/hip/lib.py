@@ -20,7 +20,7 @@ class _S(C.Structure):
     pass
 
 
-ABI_VERSION = 3          # == MISEG_ABI_VERSION of include/miseg_hip.h; load() refuses a library that reports another
+ABI_VERSION = 4          # == MISEG_ABI_VERSION of include/miseg_hip.h; load() refuses a library that reports another
 C_NAMES = {}             # ctypes mirror -> name of the C struct it mirrors (tests/test_abi.py checks sizeof / offsetof of every field)
 
 
@@ -62,12 +62,12 @@ ColsumDesc = _struct("ColsumDesc", cname="miseg_colsum_desc", fields=[("x", vp),
 GemmTnDesc = _struct("GemmTnDesc", cname="miseg_gemm_tn_desc", fields=[("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32), ("K", i32), ("pad_", i32)])
 Colsum = _struct("Colsum", cname="miseg_colsum_params", fields=[("x", vp), ("ldx", i64), ("rows", i64), ("C", i32), ("dtype", i32), ("out", vp), ("accumulate", i32)])
 Conv3 = _struct("Conv3", cname="miseg_conv3_params", fields=[("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("wpk", vp), ("B", i32), ("D", i32), ("H", i32),
-                          ("W", i32), ("Cin", i32), ("Cout", i32), ("dtype", i32), ("workspace", vp), ("res", vp), ("ldres", i64), ("stat", vp)])
+                          ("W", i32), ("Cin", i32), ("Cout", i32), ("dtype", i32), ("workspace", vp), ("res", vp), ("ldres", i64), ("stat", vp), ("background", i32)])
 PackConv3Desc = _struct("PackConv3Desc", cname="miseg_pack_conv3_desc", fields=[("w", vp), ("fwd_pack", vp), ("bwd_pack", vp), ("Cin", i32), ("Cout", i32), ("tile0", i32), ("pad_", i32)])
 PackConv3 = _struct("PackConv3", cname="miseg_pack_conv3_params", fields=[("w", vp), ("fwd_pack", vp), ("bwd_pack", vp), ("Cin", i32), ("Cout", i32), ("dtype", i32)])
 Conv3Wgrad = _struct("Conv3Wgrad", cname="miseg_conv3_wgrad_params", fields=[("x", vp), ("ldx", i64), ("dy", vp), ("lddy", i64), ("dw", vp), ("B", i32), ("D", i32),
                                     ("H", i32), ("W", i32), ("Cin", i32), ("Cout", i32), ("dtype", i32), ("accumulate", i32),
-                                    ("workspace", vp)])
+                                    ("workspace", vp), ("max_workgroups", i32)])
 Winattn = _struct("Winattn", cname="miseg_winattn_params", fields=[("qkv", vp), ("ldq", i64), ("out", vp), ("ldo", i64), ("qkv_bias", vp), ("bias_table", vp),
                               ("lse", vp), ("B", i32), ("D", i32), ("H", i32), ("W", i32), ("C", i32), ("heads", i32),
                               ("dtype", i32), ("wd", i32), ("wh", i32), ("ww", i32), ("sd", i32), ("sh", i32), ("sw", i32),

@@ -439,8 +439,42 @@ def wgrad_side(*keep, kind="gemm"):
     return _Side(keep, kind)
 
 
+_BRANCH_STREAM = None
+BACKGROUND_LAUNCHES = 0        # running count of launches issued in background form (bench.py reports the per-step figure)
+BACKGROUND_WORKGROUPS = 24     # cap of a background weight-gradient launch (each workgroup owns a CU).  Step against no branch, two boxes:
+                               # 256 (no cap) -0.4 %, 128 +1.0, 64 +1.4, 32 +2.0 / +2.4, 16 +2.0, 8 -3.8 (the launch becomes the critical path)
+
+
+def branch_stream(device):
+    """the stream of a model's side branch (SwinUNETR: the two image-resolution encoder blocks).  Autograd replays the branch's backward
+    pass on it - beside the latency-bound launches of the deep stages - and `join_branch` joins it."""
+    global _BRANCH_STREAM
+    if _BRANCH_STREAM is None or _BRANCH_STREAM.device != device:
+        _BRANCH_STREAM = torch.cuda.Stream(device=device)
+    return _BRANCH_STREAM
+
+
+def join_branch():
+    """the current stream waits for the branch stream: before anything that consumes what the branch's backward produced (the queued
+    weight-gradient launches of arena.end_backward, the optimiser, the end of a hipGraph capture)"""
+    if _BRANCH_STREAM is not None:
+        torch.cuda.current_stream().wait_stream(_BRANCH_STREAM)
+
+
+def _background():
+    """> 0 (the workgroup cap) when this launch belongs to the branch's BACKWARD pass: the 3x3x3 convolution kernels then run in their
+    background form (miseg_conv3_params.background, miseg_conv3_wgrad_params.max_workgroups) so that the main stream's small-grid
+    launches keep finding free CUs.  The branch's forward runs right in front of its join, beside nothing: normal form."""
+    if _BRANCH_STREAM is None or torch._C._current_graph_task_id() < 0 or torch.cuda.current_stream() != _BRANCH_STREAM:
+        return 0
+    global BACKGROUND_LAUNCHES
+    BACKGROUND_LAUNCHES += 1
+    return BACKGROUND_WORKGROUPS
+
+
 def join_wgrad():
-    """the current stream waits for the side stream; call once after the backward pass (arena.end_backward)."""
+    """the current stream waits for the side streams; call once after the backward pass (arena.end_backward)."""
+    join_branch()
     if WGRAD_STREAM is not None:
         torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
     _WGRAD_KEEP.clear()
@@ -607,7 +641,8 @@ def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False):
     flops = 2.0 * B * D * H * W * 27 * Cin * Cout
     kpc = 16 // x.element_size()
     fast = (_round_up(Cin, kpc) * x.element_size()) % 96 == 0
-    name = f"conv3_fwd{'96' if fast else ''}_kernel<{'bf16' if x.dtype == torch.bfloat16 else 'f32'}>"
+    bg = 1 if (fast and _background()) else 0
+    name = f"conv3_fwd{'96' if fast else ''}_kernel<{'bf16' if x.dtype == torch.bfloat16 else 'f32'}>" + (" (background)" if bg else "")
     fuse_res = res is not None and fast and res.dtype == x.dtype       # (the roofline leg times the launches exactly as the step issues them)
     # algorithmic bytes: x read once, y written once, the weight pack, the fused residual read once
     nbytes = float(x.element_size()) * (B * D * H * W * (Cin + Cout + (Cout if fuse_res else 0)) + wpk.numel())
@@ -615,7 +650,7 @@ def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False):
     if want_stat and fast:      # (a split reduction computes them in its second launch)
         stat = STAT_POOL.take(lib.miseg_instnorm_stat_bytes(B, Cout) // 8, x.device).view(-1, B, Cout, 2)
     mk = lambda st: L.Conv3(_ptr(x), ld, _ptr(out), rows(out)[0], _ptr(wpk), B, D, H, W, Cin, Cout, _dt(x), _ptr(ws),
-                            _ptr(res) if fuse_res else None, rows(res)[0] if fuse_res else 0, _ptr(st))
+                            _ptr(res) if fuse_res else None, rows(res)[0] if fuse_res else 0, _ptr(st), bg)
     scratch = torch.zeros_like(stat) if (stat is not None and PROFILE_HOOK is not None) else None
     _call("miseg_conv3_fwd", mk(stat), prof=(name, flops, nbytes), prof_params=mk(scratch) if scratch is not None else None)
     if res is not None and not fuse_res:
@@ -662,8 +697,9 @@ def conv3_wgrad(x, dy, dw=None, accumulate=False):
         return dw
     lib = L.load()
     ws = torch.empty(lib.miseg_conv3_wgrad_workspace_bytes(B, D, H, W, Cin, Cout) // 4, dtype=torch.float32, device=x.device)
-    _call("miseg_conv3_wgrad", L.Conv3Wgrad(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), B, D, H, W, Cin, Cout, _dt(x), int(accumulate), _ptr(ws)),
-          prof=(f"conv3_wgrad_kernel<{'bf16' if x.dtype == torch.bfloat16 else 'f32'}>", 2.0 * B * D * H * W * 27 * Cin * Cout))
+    bg = _background()
+    _call("miseg_conv3_wgrad", L.Conv3Wgrad(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), B, D, H, W, Cin, Cout, _dt(x), int(accumulate), _ptr(ws), bg),
+          prof=(f"conv3_wgrad_kernel<{'bf16' if x.dtype == torch.bfloat16 else 'f32'}>" + (" (background)" if bg else ""), 2.0 * B * D * H * W * 27 * Cin * Cout))
     return dw
 
 

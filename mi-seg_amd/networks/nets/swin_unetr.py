@@ -2,6 +2,8 @@
 forward(x_in, modalities) and state_dict keys); all device arithmetic runs in csrc/libmiseg_hip.so."""
 from typing import Sequence, Tuple, Union
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -137,14 +139,13 @@ class SwinUNETR(nn.Module):
     # data-parallel step can start all-reducing while the encoder / Swin half of the backward pass is still running
     late_backward_prefixes = ("encoder10.", "decoder5.", "decoder4.", "decoder3.", "decoder2.", "decoder1.", "out.")
 
-    overlap_encoder1 = False     # measured on one MI355X (hipGraph): 12 % of the kernel time ran concurrently, the step time did not move (the
-                                 # graph already keeps the chip 98.7 % busy; co-resident kernels just stretch each other) - off
-
-    def _side_stream(self, device):
-        st = getattr(self, "_side", None)
-        if st is None or st.device != device:
-            st = self._side = torch.cuda.Stream(device=device)
-        return st
+    # The two image-resolution encoder blocks read the image / the first Swin feature map and feed the last two decoders only.  With
+    # `side_branch` they are taped right in front of decoder2 on a branch stream: autograd, which walks the tape backwards and runs every
+    # node on the stream of its forward, then reaches their backward pass - 0.7 ms of full-size kernels - right after decoder2's and runs
+    # it BESIDE the ~2 ms of small-grid launches of the deeper blocks' backward (the convolution kernels in their background form, see
+    # hip/ops.py::_background).  The forward runs right in front of its join, i.e. where it always ran.  Measured A/B on one box (DESIGN.md
+    # section 5); `MISEG_NO_BRANCH=1` switches it off.
+    side_branch = os.environ.get("MISEG_NO_BRANCH") is None
 
     @staticmethod
     def _skip_block(block, inp, styles, shape, channels, dt, **kw):
@@ -171,22 +172,14 @@ class SwinUNETR(nn.Module):
         ops.begin_forward(self.parameters())      # statistics-pool lifetime: hip/ops.py::_ZeroPool
         x_in = x_in.float().contiguous()
         dt = self.compute_dtype
-        # encoder1 (three 96^3 convolutions) depends on the image only: on a side stream it runs next to the Swin transformer, whose
-        # ~300 short launches per direction leave the chip idle between dependent kernels.  One fork / one join per direction; autograd
-        # replays each backward on the stream of its forward.
-        side = self._side_stream(x_in.device) if self.overlap_encoder1 else None
-        if side is not None:
-            cur = torch.cuda.current_stream()
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                enc0 = self.encoder1(None, styles, image=x_in, dtype=dt)
+        # (bf16 only: in the fp32 parity mode the branch's convolutions are long enough to become the critical path when throttled - 31.2 -> 29.5)
+        # (not under bench.py's per-launch profiling hook either: that leg times every launch alone, in its normal form)
+        branch = self.side_branch and dt == torch.bfloat16 and torch.is_grad_enabled() and not x_in.requires_grad and ops.PROFILE_HOOK is None
         hs = self.swinViT(x_in, self.normalize, styles, dt)
-        if side is not None:
-            cur.wait_stream(side)
-            enc0.record_stream(cur)
-        else:
+        enc0 = enc1 = None
+        if not branch:
             enc0 = self._skip_block(self.encoder1, None, styles, x_in.shape, self.encoder1.layer.conv2.conv.weight.shape[0], dt, image=x_in, dtype=dt)
-        enc1 = self._skip_block(self.encoder2, hs[0], styles, hs[0].shape, hs[0].shape[-1], dt)
+            enc1 = self._skip_block(self.encoder2, hs[0], styles, hs[0].shape, hs[0].shape[-1], dt)
         enc2 = self._skip_block(self.encoder3, hs[1], styles, hs[1].shape, hs[1].shape[-1], dt)
         enc3 = self._skip_block(self.encoder4, hs[2], styles, hs[2].shape, hs[2].shape[-1], dt)
         h4, h3 = hs[4], hs[3]
@@ -197,11 +190,28 @@ class SwinUNETR(nn.Module):
                     l._miseg_cat = t._miseg_cat
                 cut.append((t, l))
                 return l
-            h4, h3, enc3, enc2, enc1, enc0 = (leaf(t) for t in (h4, h3, enc3, enc2, enc1, enc0))
+            h4, h3, enc3, enc2 = (leaf(t) for t in (h4, h3, enc3, enc2))
+            if not branch:
+                enc1, enc0 = leaf(enc1), leaf(enc0)
         dec4 = self.encoder10(h4, styles)
         dec3 = self.decoder5(dec4, h3, styles)
         dec2 = self.decoder4(dec3, enc3, styles)
         dec1 = self.decoder3(dec2, enc2, styles)
+        if branch:
+            side, cur = ops.branch_stream(x_in.device), torch.cuda.current_stream()
+            side.wait_stream(cur)
+            for t in (hs[0], x_in, styles[0] if styles is not None else None):      # allocated on this stream, read by the branch's kernels
+                if t is not None:
+                    t.record_stream(side)
+            with torch.cuda.stream(side):
+                enc0 = self._skip_block(self.encoder1, None, styles, x_in.shape, self.encoder1.layer.conv2.conv.weight.shape[0], dt, image=x_in, dtype=dt)
+                enc1 = self._skip_block(self.encoder2, hs[0], styles, hs[0].shape, hs[0].shape[-1], dt)
+            cur.wait_stream(side)
+            for t in (enc0, enc1):
+                t.record_stream(cur)
+                t._miseg_cat.record_stream(cur)
+            if cut is not None:
+                enc1, enc0 = leaf(enc1), leaf(enc0)
         dec0 = self.decoder2(dec1, enc1, styles)
         out = self.decoder1(dec0, enc0, styles)
         return self.out(out)

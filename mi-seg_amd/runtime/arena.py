@@ -193,6 +193,7 @@ class ParamArena:
     def end_backward(self):
         """issue the queued bias-gradient column sums (one launch per 32); call after loss.backward(), inside the captured
         region when the step is a hipGraph.  publish() / allreduce() call it too."""
+        ops.join_branch()          # the queued launches below read what a model's side branch produced
         if self.queues is not None:
             self.queues.flush()
             self.queues = None
@@ -202,6 +203,7 @@ class ParamArena:
 
     def flush(self):
         """issue everything queued so far and keep queueing (between the two halves of a split backward pass)."""
+        ops.join_branch()
         if self.queues is not None:
             self.queues.flush()
 

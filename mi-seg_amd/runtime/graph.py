@@ -110,6 +110,8 @@ class GraphedStep:
         y.backward(self.cot)
         if self.arena is not None:
             self.arena.end_backward()
+        else:
+            ops.join_branch()          # a capture must not end with a model's side branch unjoined
         return y
 
     def _run_first(self, host):

@@ -62,4 +62,8 @@ def summarize(prof, dtype):
             "hbm_frac_counter": (traffic / avg_s / 1e9 / PEAK_HBM_GBS) if traffic else None,
             "traffic": traffic, "traffic_unit": "bytes per launch on the L2's memory side (PMC FETCH_SIZE x 2 + WRITE_SIZE; Infinity-Cache hits are counted)", "traffic_source": src,
             "algorithmic_bytes_per_launch": sum(t[2] for t in lst) / len(lst), "launches_per_step": len(lst), "avg_launch_ms": tot_ms / len(lst),
-            "flops_per_step": flops, "all_kernels_ms": {k: sum(t[0] for t in v) for k, v in prof.items()}}
+            "flops_per_step": flops, "all_kernels_ms": {k: sum(t[0] for t in v) for k, v in prof.items()}
+            # (the profiled step runs WITHOUT the model's side branch - networks/nets/swin_unetr.py: one stream, every launch in its normal
+            # form, nothing beside anything - so that the figure covers the same 38 launches round after round; what the real step
+            # throttles is reported by bench.py as `side_branch`)
+            }

@@ -443,6 +443,58 @@ def test_param_arena_matches_plain_autograd(dtype, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["eager", "arena", "graph"])
+def test_side_branch_matches_the_single_stream_step(mode):
+    """SwinUNETR.side_branch (encoder1 + encoder2 taped in front of decoder2 on a branch stream, their backward beside the deeper blocks'
+    with the convolution kernels in background form) against the same step on one stream: bit-identical logits, the same None pattern,
+    gradients equal up to the order of the weight-gradient sums (the throttled weight gradient splits its rows differently)."""
+    from mi_seg_amd.hip import ops
+    from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
+    from mi_seg_amd.runtime.arena import ParamArena
+    from mi_seg_amd.runtime.graph import GraphedStep
+    from mi_seg_amd.utils.detfill import fill_module_, det_input
+    net = SwinUNETR((96, 96, 96), 1, 3, feature_size=48, num_heads=(3, 6, 12, 24), vit_norm_name=_norm("instance_cond"),
+                    encoder_norm_name=_norm("instance_cond"), decoder_norm_name=_norm("instance")).cuda()
+    fill_module_(net)
+    net.set_compute_dtype(torch.bfloat16)
+    x = det_input(3, (1, 1, 96, 96, 96)).cuda()
+    cot = det_input(4, (1, 3, 96, 96, 96)).cuda()
+    params = [p for p in net.parameters() if p.requires_grad]
+    names = [k for k, _ in net.named_parameters()]
+
+    def run(branch):
+        net.side_branch = branch
+        for p in params:
+            p.grad = None
+        arena = ParamArena(params, torch.bfloat16) if mode != "eager" else None
+        bg0 = ops.BACKGROUND_LAUNCHES
+        try:
+            if mode == "graph":
+                step = GraphedStep(net, x.shape, cot.shape, arena=arena)
+                y = step(x, [1], cot)
+                y = step(x, [1], cot).detach().clone()
+            else:
+                (arena.begin_step if arena is not None else ops.begin_step)()
+                y = net(x, [1])
+                y.backward(cot)
+                if arena is not None:
+                    arena.publish()
+                y = y.detach().clone()
+            torch.cuda.synchronize()
+            return y, {k: (None if p.grad is None else p.grad.detach().float().cpu().clone()) for k, p in zip(names, params)}, ops.BACKGROUND_LAUNCHES - bg0
+        finally:
+            if arena is not None:
+                arena.detach()
+
+    y0, g0, n0 = run(False)
+    y1, g1, n1 = run(True)
+    assert n0 == 0 and n1 >= 4, (n0, n1)            # 3 data-gradient convolutions + the 96^3 weight gradient (per eager step / capture)
+    assert torch.equal(y0, y1)
+    assert [k for k in names if g0[k] is None] == [k for k in names if g1[k] is None]
+    compare_grads({k: v for k, v in g1.items() if v is not None}, {k: v for k, v in g0.items() if v is not None}, 2e-3, skip=ZERO_GRAD)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("use_arena", [False, True, "split"])
 def test_graphed_step_replays_match_eager(use_arena):
     """every replay of the captured step - not only the first - must reproduce the eager step, for both modalities and with
