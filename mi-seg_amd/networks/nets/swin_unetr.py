@@ -174,7 +174,9 @@ class SwinUNETR(nn.Module):
         dt = self.compute_dtype
         # (bf16 only: in the fp32 parity mode the branch's convolutions are long enough to become the critical path when throttled - 31.2 -> 29.5)
         # (not under bench.py's per-launch profiling hook either: that leg times every launch alone, in its normal form)
-        branch = self.side_branch and dt == torch.bfloat16 and torch.is_grad_enabled() and not x_in.requires_grad and ops.PROFILE_HOOK is None
+        # (not in the split step of the data-parallel path either, `cut`: beside the RCCL kernels the branch costs 2 % - 122.9 -> 120.2)
+        branch = (self.side_branch and cut is None and dt == torch.bfloat16 and torch.is_grad_enabled() and not x_in.requires_grad
+                  and ops.PROFILE_HOOK is None)
         hs = self.swinViT(x_in, self.normalize, styles, dt)
         enc0 = enc1 = None
         if not branch:
@@ -190,9 +192,7 @@ class SwinUNETR(nn.Module):
                     l._miseg_cat = t._miseg_cat
                 cut.append((t, l))
                 return l
-            h4, h3, enc3, enc2 = (leaf(t) for t in (h4, h3, enc3, enc2))
-            if not branch:
-                enc1, enc0 = leaf(enc1), leaf(enc0)
+            h4, h3, enc3, enc2, enc1, enc0 = (leaf(t) for t in (h4, h3, enc3, enc2, enc1, enc0))
         dec4 = self.encoder10(h4, styles)
         dec3 = self.decoder5(dec4, h3, styles)
         dec2 = self.decoder4(dec3, enc3, styles)
@@ -210,8 +210,6 @@ class SwinUNETR(nn.Module):
             for t in (enc0, enc1):
                 t.record_stream(cur)
                 t._miseg_cat.record_stream(cur)
-            if cut is not None:
-                enc1, enc0 = leaf(enc1), leaf(enc0)
         dec0 = self.decoder2(dec1, enc1, styles)
         out = self.decoder1(dec0, enc0, styles)
         return self.out(out)
