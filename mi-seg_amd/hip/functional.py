@@ -480,7 +480,11 @@ class _Conv3(Function):
         dw = None
         if ctx.needs_input_grad[1]:
             slot, mode = _slot_first(ctx.params[0])
-            if slot is not None:
+            if slot is not None and ops.defer_to_branch(x, dy, slot, mode):
+                pass
+            elif slot is not None:
+                if ops.BRANCH_DEFERRED and ops.in_branch_backward():
+                    ops.flush_branch_deferred()
                 with ops.wgrad_side(x, dy, kind="conv"):
                     ops.conv3_wgrad(x, dy, dw=slot, accumulate=mode)
             else:

@@ -441,8 +441,13 @@ def wgrad_side(*keep, kind="gemm"):
 
 _BRANCH_STREAM = None
 BACKGROUND_LAUNCHES = 0        # running count of launches issued in background form (bench.py reports the per-step figure)
-BACKGROUND_WORKGROUPS = 24     # cap of a background weight-gradient launch (each workgroup owns a CU).  Step against no branch, two boxes:
-                               # 256 (no cap) -0.4 %, 128 +1.0, 64 +1.4, 32 +2.0 / +2.4, 16 +2.0, 8 -3.8 (the launch becomes the critical path)
+BACKGROUND_WORKGROUPS = 32     # cap of the branch's own background weight-gradient launch (each workgroup owns a CU).  Step against no branch,
+                               # two boxes, before the deferral below: 256 (no cap) -0.4 %, 128 +1.0, 64 +1.4, 32 +2.0 / +2.4, 16 +2.0, 8 -3.8
+DEFERRED_WORKGROUPS = 64       # cap of the main stream's deferred weight gradients (defer_to_branch).  (own cap, this cap) on one box, no branch =
+                               # 132.6, branch alone 134.5: (24, 48) 136.9, (24, 64) 140.8, (24, 96) 139.8, (48, 64) 140.6, (64, 64) 140.7, (32, 32) 128.9
+DEFER_MIN_ROWS = 400000        # 96^3 layers only (the smaller ones are grouped into one launch at the end of the backward pass)
+BRANCH_DEFERRED = None         # while a model's side branch is open: [(x, dy, slot, mode)] - full-size conv weight gradients of the MAIN stream
+                               # (SwinUNETR: decoder1's two 96^3 layers) that wait for the branch's backward pass and run at its head, in background form
 
 
 def branch_stream(device):
@@ -454,18 +459,48 @@ def branch_stream(device):
     return _BRANCH_STREAM
 
 
+def defer_to_branch(x, dy, slot, mode):
+    """True when the conv weight gradient (x, dy) -> slot was queued for the head of the side branch's backward pass: leaf work of the main
+    stream's full-size kernels (0.3 ms per step on the critical path) that then runs beside the small-grid launches instead"""
+    if BRANCH_DEFERRED is None or in_branch_backward() or rows(x)[1] < DEFER_MIN_ROWS:
+        return False
+    BRANCH_DEFERRED.append((x, dy, slot, mode))
+    return True
+
+
+def flush_branch_deferred():
+    """launch what `defer_to_branch` queued on the current stream (the branch's, in background form; join_branch's as a fallback)"""
+    global BRANCH_DEFERRED, BACKGROUND_WORKGROUPS
+    items, BRANCH_DEFERRED = BRANCH_DEFERRED, None
+    if not items:
+        return
+    keep, BACKGROUND_WORKGROUPS = BACKGROUND_WORKGROUPS, DEFERRED_WORKGROUPS
+    try:
+        for x, dy, slot, mode in items:
+            conv3_wgrad(x, dy, dw=slot, accumulate=mode)
+    finally:
+        BACKGROUND_WORKGROUPS = keep
+    _WGRAD_KEEP.extend(t for it in items for t in it[:2])      # alive until join_wgrad
+
+
 def join_branch():
     """the current stream waits for the branch stream: before anything that consumes what the branch's backward produced (the queued
     weight-gradient launches of arena.end_backward, the optimiser, the end of a hipGraph capture)"""
+    if BRANCH_DEFERRED:                # the branch's backward never ran (nothing in it needed a gradient): here and now
+        flush_branch_deferred()
     if _BRANCH_STREAM is not None:
         torch.cuda.current_stream().wait_stream(_BRANCH_STREAM)
+
+
+def in_branch_backward():
+    return _BRANCH_STREAM is not None and torch._C._current_graph_task_id() >= 0 and torch.cuda.current_stream() == _BRANCH_STREAM
 
 
 def _background():
     """> 0 (the workgroup cap) when this launch belongs to the branch's BACKWARD pass: the 3x3x3 convolution kernels then run in their
     background form (miseg_conv3_params.background, miseg_conv3_wgrad_params.max_workgroups) so that the main stream's small-grid
     launches keep finding free CUs.  The branch's forward runs right in front of its join, beside nothing: normal form."""
-    if _BRANCH_STREAM is None or torch._C._current_graph_task_id() < 0 or torch.cuda.current_stream() != _BRANCH_STREAM:
+    if not in_branch_backward():
         return 0
     global BACKGROUND_LAUNCHES
     BACKGROUND_LAUNCHES += 1

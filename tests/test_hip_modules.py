@@ -488,7 +488,8 @@ def test_side_branch_matches_the_single_stream_step(mode):
 
     y0, g0, n0 = run(False)
     y1, g1, n1 = run(True)
-    assert n0 == 0 and n1 >= 4, (n0, n1)            # 3 data-gradient convolutions + the 96^3 weight gradient (per eager step / capture)
+    # per eager step / capture: 3 data-gradient convolutions + the branch's 96^3 weight gradient; with an arena also decoder1's two deferred ones
+    assert n0 == 0 and n1 >= (4 if mode == "eager" else 6), (n0, n1)
     assert torch.equal(y0, y1)
     assert [k for k in names if g0[k] is None] == [k for k in names if g1[k] is None]
     compare_grads({k: v for k, v in g1.items() if v is not None}, {k: v for k, v in g0.items() if v is not None}, 2e-3, skip=ZERO_GRAD)
