@@ -211,6 +211,7 @@ class SwinUNETR(nn.Module):
                 t.record_stream(cur)
                 t._miseg_cat.record_stream(cur)
         if branch and os.environ.get("MISEG_NO_DEFER") is None:
+            ops.DEFERRED_WORKGROUPS = 64
             ops.BRANCH_DEFERRED = []       # decoder1's two 96^3 weight gradients wait for the branch's backward pass (hip/ops.py::defer_to_branch)
         dec0 = self.decoder2(dec1, enc1, styles)
         out = self.decoder1(dec0, enc0, styles)

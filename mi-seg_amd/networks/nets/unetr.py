@@ -1,6 +1,8 @@
 """UNETR -- drop-in for reference networks/nets/unetr.py (ViT-B/16 encoder + UNETR CNN decoder)."""
 from typing import Sequence, Tuple, Union
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -83,6 +85,8 @@ class UNETR(nn.Module):
         """[B, L, hidden] tokens -> channels-last feature map [B, d, h, w, hidden] (reference unetr.py:248-252: a pure view here)."""
         return x.view(x.shape[0], *self.feat_size, self.hidden_size)
 
+    side_branch = os.environ.get("MISEG_NO_BRANCH") is None       # A/B switch (DESIGN.md section 5): configs[2] 129.6 -> 133.2 patches/s
+
     def forward(self, x_in, modalities=None):
         if not x_in.is_cuda:
             raise RuntimeError("UNETR (MI355X path) needs a HIP device tensor; there is no CPU fallback")
@@ -93,12 +97,30 @@ class UNETR(nn.Module):
         x_in = x_in.float().contiguous()
         dt = self.compute_dtype
         x, hidden = self.vit(x_in, styles, dt)
-        enc1 = self.encoder1(None, styles, image=x_in, dtype=dt)
+        # side branch (see SwinUNETR.side_branch): encoder1 reads the image only and feeds the last decoder only, and autograd reaches its
+        # backward pass right in front of the ViT's - 12 blocks of 216-token launches that leave the chip idle.  On the branch stream it runs
+        # BESIDE them, in background form.
+        branch = (self.side_branch and dt == torch.bfloat16 and torch.is_grad_enabled() and not x_in.requires_grad and ops.PROFILE_HOOK is None)
+        if branch:
+            side, cur = ops.branch_stream(x_in.device), torch.cuda.current_stream()
+            side.wait_stream(cur)
+            for t in (x_in, styles[0] if styles is not None else None):      # allocated on this stream, read by the branch's kernels
+                if t is not None:
+                    t.record_stream(side)
+            with torch.cuda.stream(side):
+                enc1 = self.encoder1(None, styles, image=x_in, dtype=dt)
+            ops.BRANCH_DEFERRED = None       # decoder2's 96^3 weight gradients stay where they are: at 16 channels they are long launches (0.29 ms)
+                                             # that become the critical path when throttled and gain nothing un-throttled (133.2 -> 123 .. 132.9)
+        else:
+            enc1 = self.encoder1(None, styles, image=x_in, dtype=dt)
         enc2 = self.encoder2(self.proj_feat(hidden[3]), styles)
         enc3 = self.encoder3(self.proj_feat(hidden[6]), styles)
         enc4 = self.encoder4(self.proj_feat(hidden[9]), styles)
         dec3 = self.decoder5(self.proj_feat(x), enc4, styles)
         dec2 = self.decoder4(dec3, enc3, styles)
         dec1 = self.decoder3(dec2, enc2, styles)
+        if branch:
+            cur.wait_stream(side)
+            enc1.record_stream(cur)
         out = self.decoder2(dec1, enc1, styles)
         return self.out(out)
