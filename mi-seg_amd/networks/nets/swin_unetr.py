@@ -140,11 +140,11 @@ class SwinUNETR(nn.Module):
     late_backward_prefixes = ("encoder10.", "decoder5.", "decoder4.", "decoder3.", "decoder2.", "decoder1.", "out.")
 
     # The two image-resolution encoder blocks read the image / the first Swin feature map and feed the last two decoders only.  With
-    # `side_branch` they are taped right in front of decoder2 on a branch stream: autograd, which walks the tape backwards and runs every
-    # node on the stream of its forward, then reaches their backward pass - 0.7 ms of full-size kernels - right after decoder2's and runs
-    # it BESIDE the ~2 ms of small-grid launches of the deeper blocks' backward (the convolution kernels in their background form, see
-    # hip/ops.py::_background).  The forward runs right in front of its join, i.e. where it always ran.  Measured A/B on one box (DESIGN.md
-    # section 5); `MISEG_NO_BRANCH=1` switches it off.
+    # `side_branch` they run on a branch stream, taped in front of encoder10: autograd, which walks the tape backwards and runs every
+    # node on the stream of its forward, reaches their backward pass - 0.7 ms of full-size kernels - behind encoder10's and runs it
+    # BESIDE the small-grid launches of the deeper blocks' backward (the convolution kernels in their background form, see
+    # hip/ops.py::_background), and their forward runs beside encoder10 / decoder5..3.  Measured A/B;
+    # `MISEG_NO_BRANCH=1` switches it off.
     side_branch = os.environ.get("MISEG_NO_BRANCH") is None
 
     @staticmethod
@@ -193,11 +193,11 @@ class SwinUNETR(nn.Module):
                 cut.append((t, l))
                 return l
             h4, h3, enc3, enc2, enc1, enc0 = (leaf(t) for t in (h4, h3, enc3, enc2, enc1, enc0))
-        dec4 = self.encoder10(h4, styles)
-        dec3 = self.decoder5(dec4, h3, styles)
-        dec2 = self.decoder4(dec3, enc3, styles)
-        dec1 = self.decoder3(dec2, enc2, styles)
         if branch:
+            # taped HERE, in front of encoder10 and decoder5..3: forward, the branch's 0.36 ms of full-size kernels run beside those blocks' small
+            # launches; backward, autograd reaches the branch behind encoder10's backward and runs it beside encoder4 / encoder3 / the deep
+            # Swin stages (in front of decoder2, i.e. no forward overlap but a longer backward window, measured 138.7; here 143.4; right
+            # behind the Swin transformer 143.3)
             side, cur = ops.branch_stream(x_in.device), torch.cuda.current_stream()
             side.wait_stream(cur)
             for t in (hs[0], x_in, styles[0] if styles is not None else None):      # allocated on this stream, read by the branch's kernels
@@ -206,6 +206,11 @@ class SwinUNETR(nn.Module):
             with torch.cuda.stream(side):
                 enc0 = self._skip_block(self.encoder1, None, styles, x_in.shape, self.encoder1.layer.conv2.conv.weight.shape[0], dt, image=x_in, dtype=dt)
                 enc1 = self._skip_block(self.encoder2, hs[0], styles, hs[0].shape, hs[0].shape[-1], dt)
+        dec4 = self.encoder10(h4, styles)
+        dec3 = self.decoder5(dec4, h3, styles)
+        dec2 = self.decoder4(dec3, enc3, styles)
+        dec1 = self.decoder3(dec2, enc2, styles)
+        if branch:       # join: decoder2 is the first consumer of the branch
             cur.wait_stream(side)
             for t in (enc0, enc1):
                 t.record_stream(cur)
