@@ -237,7 +237,7 @@ def main():
         res.update({"params": len(got), "params_without_grad": len(missing), "params_without_grad_unexpected": unexpected[:5], "params_with_zero_grad": zero[:5]})
         # launches per step that the model's side branch issues throttled (hip/ops.py::_background): conv3_fwd96 at one workgroup per CU,
         # conv3_wgrad on few CUs.  They run beside the main stream's launches in the step; the roofline leg times the kernels alone
-        res["side_branch_background_launches_per_step"] = 0 if overlap else ops.BACKGROUND_LAUNCHES - bg0      # (the split step of N > 1 runs without the branch)
+        res["side_branch_background_launches_per_step"] = ops.BACKGROUND_LAUNCHES - bg0      # (the split step of N > 1 defers nothing: 2 fewer)
         return res
 
     def exchange_check():

@@ -174,8 +174,7 @@ class SwinUNETR(nn.Module):
         dt = self.compute_dtype
         # (bf16 only: in the fp32 parity mode the branch's convolutions are long enough to become the critical path when throttled - 31.2 -> 29.5)
         # (not under bench.py's per-launch profiling hook either: that leg times every launch alone, in its normal form)
-        # (not in the split step of the data-parallel path either, `cut`: beside the RCCL kernels the branch costs 2 % - 122.9 -> 120.2)
-        branch = (self.side_branch and cut is None and dt == torch.bfloat16 and torch.is_grad_enabled() and not x_in.requires_grad
+        branch = (self.side_branch and dt == torch.bfloat16 and torch.is_grad_enabled() and not x_in.requires_grad
                   and ops.PROFILE_HOOK is None)
         hs = self.swinViT(x_in, self.normalize, styles, dt)
         enc0 = enc1 = None
@@ -192,7 +191,10 @@ class SwinUNETR(nn.Module):
                     l._miseg_cat = t._miseg_cat
                 cut.append((t, l))
                 return l
-            h4, h3, enc3, enc2, enc1, enc0 = (leaf(t) for t in (h4, h3, enc3, enc2, enc1, enc0))
+            if branch:
+                h4, h3, enc3, enc2 = (leaf(t) for t in (h4, h3, enc3, enc2))
+            else:
+                h4, h3, enc3, enc2, enc1, enc0 = (leaf(t) for t in (h4, h3, enc3, enc2, enc1, enc0))
         if branch:
             # taped HERE, in front of encoder10 and decoder5..3: forward, the branch's 0.36 ms of full-size kernels run beside those blocks' small
             # launches; backward, autograd reaches the branch behind encoder10's backward and runs it beside encoder4 / encoder3 / the deep
@@ -215,7 +217,11 @@ class SwinUNETR(nn.Module):
             for t in (enc0, enc1):
                 t.record_stream(cur)
                 t._miseg_cat.record_stream(cur)
-        if branch and os.environ.get("MISEG_NO_DEFER") is None:
+            if cut is not None:
+                enc1, enc0 = leaf(enc1), leaf(enc0)
+        if branch and cut is not None:
+            ops.BRANCH_DEFERRED = None     # split step: the decoder side's gradients are all-reduced right after the first half - nothing of it may wait
+        if branch and cut is None and os.environ.get("MISEG_NO_DEFER") is None:
             ops.DEFERRED_WORKGROUPS = 64
             ops.BRANCH_DEFERRED = []       # decoder1's two 96^3 weight gradients wait for the branch's backward pass (hip/ops.py::defer_to_branch)
         dec0 = self.decoder2(dec1, enc1, styles)
