@@ -129,6 +129,15 @@ def main():
     # all-reduced by RCCL while the encoder / Swin half still runs
     overlap = dist is not None and arena is not None and not a.no_overlap and hasattr(model, "late_backward_parameters")
     tail = arena.tail_offset(model.late_backward_parameters()) if overlap else None
+    # the side branch defers decoder1's two 96^3 weight gradients into the second half of the backward pass: their slots are a hole in the
+    # tail that goes out after the first half, and join the ranges reduced at the end
+    hole = None
+    if overlap and hasattr(model, "deferred_backward_parameters") and getattr(model, "side_branch", False) and dtype == torch.bfloat16 and not os.environ.get("MISEG_NO_DEFER"):
+        hole = arena.param_range(model.deferred_backward_parameters())
+        assert tail <= hole[0] < hole[1] <= arena.flat.numel()
+        model.split_defers = True
+    early_ranges = [(tail, arena.flat.numel())] if (overlap and hole is None) else ([(hole[1], arena.flat.numel()), (tail, hole[0])] if overlap else [])
+    late_ranges = [(0, tail)] + ([hole] if hole is not None else []) if overlap else []
     graphed = None
     if not a.no_graph:
         from mi_seg_amd.runtime.graph import GraphedStep
@@ -143,16 +152,20 @@ def main():
             if graphed is not None and not eager:
                 def between():          # the flags of a replayed graph are known up front: the bitmap exchange starts here as well
                     ub.append(arena.used_begin())
-                    works.extend(arena.allreduce_begin(tail, arena.flat.numel()))
+                    for lo, hi in early_ranges:
+                        if hi > lo:
+                            works.extend(arena.allreduce_begin(lo, hi))
                 graphed(pool[k:k + 1], [mods[k]], cot, between=between, publish=False)
             else:
                 arena.begin_step()
                 cut = []
                 model(pool[k:k + 1], [mods[k]], cut=cut).backward(cot)
                 arena.flush()
-                works.extend(arena.allreduce_begin(tail, arena.flat.numel()))
+                for lo, hi in early_ranges:
+                    if hi > lo:
+                        works.extend(arena.allreduce_begin(lo, hi))
                 torch.autograd.backward([o for o, _ in cut], [l.grad for _, l in cut])
-            arena.allreduce_end(works, world, rest=(0, tail), used_work=ub[0] if ub else None)
+            arena.allreduce_end(works, world, rest=late_ranges, used_work=ub[0] if ub else None)
             return
         if graphed is not None and not eager:
             graphed(pool[k:k + 1], [mods[k]], cot)

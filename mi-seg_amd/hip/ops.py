@@ -483,10 +483,10 @@ def flush_branch_deferred():
     _WGRAD_KEEP.extend(t for it in items for t in it[:2])      # alive until join_wgrad
 
 
-def join_branch():
+def join_branch(flush_deferred=True):
     """the current stream waits for the branch stream: before anything that consumes what the branch's backward produced (the queued
     weight-gradient launches of arena.end_backward, the optimiser, the end of a hipGraph capture)"""
-    if BRANCH_DEFERRED:                # the branch's backward never ran (nothing in it needed a gradient): here and now
+    if BRANCH_DEFERRED and flush_deferred:                # the branch's backward never ran (nothing in it needed a gradient): here and now
         flush_branch_deferred()
     if _BRANCH_STREAM is not None:
         torch.cuda.current_stream().wait_stream(_BRANCH_STREAM)

@@ -155,6 +155,15 @@ class SwinUNETR(nn.Module):
         cat, view = HF.concat_buffer((shape[0],) + dims, channels, dt, (inp if inp is not None else kw["image"]).device)
         return HF.tag_concat(block(inp, styles, out_view=view, **kw), cat)
 
+    # split (data-parallel) step: True when the caller leaves `deferred_backward_parameters()` out of the range it all-reduces after the first
+    # half (bench.py does): decoder1's two 96^3 weight gradients are then deferred to the branch's backward pass there as well
+    split_defers = False
+
+    def deferred_backward_parameters(self):
+        """the parameters whose gradients the side branch defers into the second half of the backward pass (adjacent in registration order)"""
+        blk = self.decoder1.conv_block
+        return [blk.conv1.conv.weight, blk.conv2.conv.weight]
+
     def late_backward_parameters(self):
         return [p for k, p in self.named_parameters() if k.startswith(self.late_backward_prefixes)]
 
@@ -219,9 +228,9 @@ class SwinUNETR(nn.Module):
                 t._miseg_cat.record_stream(cur)
             if cut is not None:
                 enc1, enc0 = leaf(enc1), leaf(enc0)
-        if branch and cut is not None:
+        if branch and cut is not None and not self.split_defers:
             ops.BRANCH_DEFERRED = None     # split step: the decoder side's gradients are all-reduced right after the first half - nothing of it may wait
-        if branch and cut is None and os.environ.get("MISEG_NO_DEFER") is None:
+        if branch and (cut is None or self.split_defers) and os.environ.get("MISEG_NO_DEFER") is None:
             ops.DEFERRED_WORKGROUPS = 64
             ops.BRANCH_DEFERRED = []       # decoder1's two 96^3 weight gradients wait for the branch's backward pass (hip/ops.py::defer_to_branch)
         dec0 = self.decoder2(dec1, enc1, styles)

@@ -203,7 +203,7 @@ class ParamArena:
 
     def flush(self):
         """issue everything queued so far and keep queueing (between the two halves of a split backward pass)."""
-        ops.join_branch()
+        ops.join_branch(flush_deferred=False)      # (weight gradients deferred to the branch's backward pass wait for the second half)
         if self.queues is not None:
             self.queues.flush()
 
@@ -245,6 +245,15 @@ class ParamArena:
         if not all(flags[first:]) or any(flags[:first]):
             raise ValueError("the late parameters are not a contiguous tail of the arena (parameter registration order changed?)")
         return self._offs[first] if first < len(flags) else self._size
+
+    def param_range(self, params):
+        """(lo, hi) element range of `params` in the flat arena; they must be adjacent (registration order)"""
+        ids = {id(p) for p in params}
+        idx = [i for i, p in enumerate(self.params) if id(p) in ids]
+        if not idx or idx != list(range(idx[0], idx[-1] + 1)) or len(idx) != len(ids):
+            raise ValueError("the parameters are not adjacent in the arena")
+        hi = self._offs[idx[-1] + 1] if idx[-1] + 1 < len(self._offs) else self._size
+        return self._offs[idx[0]], hi
 
     def allreduce_begin(self, lo, hi, group=None, piece=None):
         """start the sum all-reduce of flat[lo:hi] (pieces of `piece` elements, last first) behind everything already queued on the
@@ -302,7 +311,9 @@ class ParamArena:
         ub = used_work if used_work is not None else self.used_begin(group)
         works = list(works)
         if rest is not None:
-            works += self.allreduce_begin(rest[0], rest[1], group)
+            for lo, hi in ([rest] if isinstance(rest[0], int) else rest):      # one range or several (a hole left in the tail, see bench.py)
+                if hi > lo:
+                    works += self.allreduce_begin(lo, hi, group)
         used = ub()
         for w in works:
             w.wait()
