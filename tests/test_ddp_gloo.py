@@ -84,6 +84,30 @@ def _worker(rank, world, port, q):
         ok &= torch.allclose(shared.grad, torch.full((5, 3), 1.5 + it))
         ok &= torch.allclose(s0.grad, torch.full((4,), 1.0)) and torch.allclose(s1.grad, torch.full((4,), 3.0))
         ok &= unused.grad is None
+    # a hole in the early range (the side branch defers some decoder-side weight gradients into the second half: bench.py): the tail goes out
+    # as the ranges around it, the hole joins the ranges reduced at the end
+    hole = arena.param_range([s1])
+    ok &= hole == (arena._offs[2], arena._offs[3]) and tail <= hole[0]
+    try:
+        arena.param_range([shared, s1])       # not adjacent
+        ok = False
+    except ValueError:
+        pass
+    for it in range(2):
+        arena.flat.zero_()
+        for p in params:
+            p._miseg_used = False
+        works = []
+        for lo, hi in ((hole[1], arena.flat.numel()), (tail, hole[0])):
+            if hi > lo:
+                works += arena.allreduce_begin(lo, hi)
+        shared._miseg_grad.fill_(float(rank + 1) + it)                             # second half: the early part of the arena ...
+        shared._miseg_used = True
+        s1._miseg_grad.fill_(6.0 if rank == 1 else 0.0)                            # ... and the deferred slot
+        s1._miseg_used = rank == 1
+        arena.allreduce_end(works, world, rest=[(0, tail), hole])
+        ok &= torch.allclose(shared.grad, torch.full((5, 3), 1.5 + it)) and torch.allclose(s1.grad, torch.full((4,), 3.0))
+        ok &= s0.grad is None and unused.grad is None
     # gradient accumulation (reference utils/trainer.py:55-68: DDP no_sync() on the micro-batches that do not step): two local micro-batches,
     # ONE collective over their sum; the window after it starts from zero again
     import mi_seg_amd.hip.ops as _ops
