@@ -90,8 +90,10 @@ class SwinTransformer(nn.Module):
             return HF.instance_norm(x, None)
         return x
 
-    def forward(self, x, normalize=True, styles=None, dtype=torch.float32):
-        """x: NCDHW fp32 network input.  Returns 5 channels-last feature maps."""
+    def forward(self, x, normalize=True, styles=None, dtype=torch.float32, after_stage1=None):
+        """x: NCDHW fp32 network input.  Returns 5 channels-last feature maps.
+        after_stage1: optional callable(first feature map), called once the launches of `layers1` are queued (SwinUNETR's inference
+        forward forks its image-resolution encoder blocks there)."""
         x0 = self.patch_embed(x, styles, dtype)
         x0 = HF.dropout(x0, self.drop_rate, self.training)        # pos_drop (swin_transformer.py:149)
         outs = []
@@ -105,5 +107,7 @@ class SwinTransformer(nn.Module):
                 a, cur = HF.fork(cur)
                 outs.append(self.proj_out(a, normalize))
             cur = layers[0](cur, styles)
+            if after_stage1 is not None and layers is self.layers1:
+                after_stage1(outs[0])
         outs.append(self.proj_out(cur, normalize))
         return outs

@@ -185,9 +185,25 @@ class SwinUNETR(nn.Module):
         # (not under bench.py's per-launch profiling hook either: that leg times every launch alone, in its normal form)
         branch = (self.side_branch and dt == torch.bfloat16 and torch.is_grad_enabled() and not x_in.requires_grad
                   and ops.PROFILE_HOOK is None)
-        hs = self.swinViT(x_in, self.normalize, styles, dt)
+        # inference (no tape, so no ordering constraint from the backward pass): the two blocks are forked right behind `layers1` and run
+        # beside the deep Swin stages, encoder3 / 4 / 10 and decoder5..3
+        infer_branch = (self.side_branch and dt == torch.bfloat16 and not torch.is_grad_enabled() and ops.PROFILE_HOOK is None
+                        and os.environ.get("MISEG_NO_INFER_BRANCH") is None)
         enc0 = enc1 = None
-        if not branch:
+
+        def fork_inference(hs0):
+            nonlocal enc0, enc1
+            side, cur = ops.branch_stream(x_in.device), torch.cuda.current_stream()
+            side.wait_stream(cur)
+            for t in (hs0, x_in, styles[0] if styles is not None else None):
+                if t is not None:
+                    t.record_stream(side)
+            with torch.cuda.stream(side):
+                enc0 = self._skip_block(self.encoder1, None, styles, x_in.shape, self.encoder1.layer.conv2.conv.weight.shape[0], dt, image=x_in, dtype=dt)
+                enc1 = self._skip_block(self.encoder2, hs0, styles, hs0.shape, hs0.shape[-1], dt)
+
+        hs = self.swinViT(x_in, self.normalize, styles, dt, after_stage1=fork_inference if infer_branch else None)
+        if not branch and not infer_branch:
             enc0 = self._skip_block(self.encoder1, None, styles, x_in.shape, self.encoder1.layer.conv2.conv.weight.shape[0], dt, image=x_in, dtype=dt)
             enc1 = self._skip_block(self.encoder2, hs[0], styles, hs[0].shape, hs[0].shape[-1], dt)
         enc2 = self._skip_block(self.encoder3, hs[1], styles, hs[1].shape, hs[1].shape[-1], dt)
@@ -221,7 +237,9 @@ class SwinUNETR(nn.Module):
         dec3 = self.decoder5(dec4, h3, styles)
         dec2 = self.decoder4(dec3, enc3, styles)
         dec1 = self.decoder3(dec2, enc2, styles)
-        if branch:       # join: decoder2 is the first consumer of the branch
+        if infer_branch:
+            side, cur = ops.branch_stream(x_in.device), torch.cuda.current_stream()
+        if branch or infer_branch:       # join: decoder2 is the first consumer of the branch
             cur.wait_stream(side)
             for t in (enc0, enc1):
                 t.record_stream(cur)
