@@ -2,7 +2,10 @@
 """bench.py -- 96^3 patches/s, forward+backward, C-Swin-UNETR fs=48 / 6 classes (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-For N > 1 launch one rank per GPU:  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+N > 1 runs one rank per GPU.  Under an external launcher (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+every rank reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment; invoked bare, this process starts the N ranks itself as
+child processes through torch.distributed.run - before it has made any GPU call - and exits with the launcher's code (non-zero unless all
+N ranks came up and finished).
 
 One step = forward + backward of one 96^3 patch per rank (batch 1/rank, synthetic CT/MR volume already resident in
 HBM, cotangent = d(sum of logits * fixed noise)); at N > 1 the fp32 gradient arena is mean-all-reduced over RCCL
@@ -71,6 +74,26 @@ def synthetic_pool(n, seed, device):
     return torch.stack(vols).unsqueeze(1).to(device), mods
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (this process has not touched the GPU and never
+    will: counting devices does not initialise HIP), one per GPU over RCCL, rendezvous on 127.0.0.1; returns the launcher's exit code -
+    torch.distributed.run fails the whole job when any rank fails to start or exits non-zero, so fewer than N ranks never print a line"""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and not os.environ.get("MISEG_REHEARSE_ONE_GPU"):
+        print(f"bench.py: --gpus {n} but this node shows {have} GPU(s)", file=sys.stderr)
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL's intra-node transport on this driver
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,8 +112,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a.gpus))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: start one rank per GPU (or run `python bench.py --gpus {a.gpus}` bare)")
     if os.environ.get("MISEG_REHEARSE_ONE_GPU"):      # rehearsal of the N > 1 code path with every rank on the one card of a 1-GPU box
         local = 0
     torch.cuda.set_device(local)
@@ -102,6 +129,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(os.environ.get("MISEG_DIST_BACKEND", "nccl"), rank=rank, world_size=world)    # "nccl" is RCCL on ROCm
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit(f"--gpus {a.gpus} but the process group has {dist.get_world_size()} ranks")
 
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     model = build_model(dtype, a.workload)

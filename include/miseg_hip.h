@@ -31,7 +31,7 @@ enum { MISEG_ACT_NONE = 0, MISEG_ACT_LEAKY = 1, MISEG_ACT_GELU = 2, MISEG_ACT_PR
 #define MISEG_MAX_STYLES 4
 
 /* bumped on EVERY change of a struct layout or prototype; bindings must refuse a library whose version differs from the header they mirror */
-#define MISEG_ABI_VERSION 4
+#define MISEG_ABI_VERSION 5
 int miseg_abi_version(void);
 const char* miseg_last_error(void);
 /* writes e.g. "gfx950" for the code objects embedded in the library */
@@ -522,13 +522,18 @@ int miseg_opt_step(const miseg_opt_step_params* p, miseg_stream_t stream);
  * stay resident (win: fp32 [nd*nh*nw][C][rd][rh][rw], window (id, ih, iw) at index (id*nh + ih)*nw + iw, origin (start_d[id], start_h[ih],
  * start_w[iw]); 700 windows x 6 x 96^3 = 14.9 GB of the 288), and ONE gather pass writes out[c][d][h][w] = (sum over the windows covering the
  * voxel, in window-index order = the order MONAI accumulates them) / count.  No atomics, no read-modify-write of the 2.3 GB accumulator.
- * starts: HOST int32 arrays (copied into the kernel arguments; at most MISEG_STITCH_MAX_WINDOWS per axis); count (optional): uint16 [D][H][W]. */
-#define MISEG_STITCH_MAX_WINDOWS 32
+ * starts: HOST int32 arrays (copied into the kernel arguments; at most MISEG_STITCH_MAX_WINDOWS per axis); count (optional): uint16 [D][H][W].
+ * Slab form (ABI 5; volumes whose window logits do not fit in memory at once): d_count > 0 writes only the depths [d_begin, d_begin + d_count)
+ * of `out` / `count` (which still address the whole [C][D][H][W] volume) from the nd RESIDENT depth layers whose starts are start_d[0..nd):
+ * every depth of the slab must be covered by resident layers only, i.e. start_d[0] <= d_begin, no gaps, and the layer after the last
+ * resident one starts at or behind d_begin + d_count (the caller's promise; MONAI's accumulation order is kept inside the slab). */
+#define MISEG_STITCH_MAX_WINDOWS 64
 typedef struct {
   uint32_t struct_size;
   const float* win; float* out; uint16_t* count;
   int C, D, H, W, rd, rh, rw, nd, nh, nw;
   const int32_t* start_d; const int32_t* start_h; const int32_t* start_w;
+  int d_begin, d_count;            /* d_count == 0: the whole volume */
 } miseg_stitch_params;
 int miseg_stitch_windows(const miseg_stitch_params* p, miseg_stream_t stream);
 

@@ -90,6 +90,16 @@ static size_t attn_smem_bytes(int n, int hd, int tsize, bool bwd) {
 // dropout on the attention probabilities (attn_drop): thresh == 0 = off.  Mask = miseg_dropout's over the [windows * heads * n][n] matrix
 struct AttnDrop { unsigned thresh; float scale; uint64_t key; const uint64_t* step_dev; };
 
+// fp32 parity mode: the library expf / logf (torch's CPU softmax evaluates these); bf16 keeps the single-instruction forms
+template <class T> __device__ __forceinline__ float exp_t(float x) {
+  if constexpr (sizeof(T) == 4) return expf(x);
+  else return __expf(x);
+}
+template <class T> __device__ __forceinline__ float log_t(float x) {
+  if constexpr (sizeof(T) == 4) return logf(x);
+  else return __logf(x);
+}
+
 template <class T, int HD4>
 __global__ void __launch_bounds__(384) winattn_fwd_kernel(const T* __restrict__ qkv, int64_t ldq, T* __restrict__ out, int64_t ldo, const float* __restrict__ qkv_bias,
                                                           const float* __restrict__ bias_table, float* __restrict__ lse_out, WinGeom g, int tsize, AttnDrop dr) {
@@ -139,8 +149,8 @@ __global__ void __launch_bounds__(384) winattn_fwd_kernel(const T* __restrict__ 
     if (bias_table) sc += s.table[code - s.code[j] + centre];
     if (use_mask && s.label[j] != label) sc -= 100.f;
     const float mn = fmaxf(m, sc);
-    const float alpha = __expf(m - mn);
-    float p = __expf(sc - mn);
+    const float alpha = exp_t<T>(m - mn);
+    float p = exp_t<T>(sc - mn);
     l = l * alpha + p;
     if (dr.thresh) {
       if ((j & 3) == 0) dh = dropout_group_hash(dk0, drow, dcg, j);
@@ -158,7 +168,7 @@ __global__ void __launch_bounds__(384) winattn_fwd_kernel(const T* __restrict__ 
     m = mn;
   }
   const float inv = 1.f / l;
-  lse_out[((int64_t)win * g.heads + head) * n + t] = m + __logf(l);
+  lse_out[((int64_t)win * g.heads + head) * n + t] = m + log_t<T>(l);
   if (row >= 0) {
     T* op = out + (int64_t)row * ldo + head * HD;
 #pragma unroll
@@ -242,7 +252,7 @@ __global__ void __launch_bounds__(384) winattn_bwd_kernel(const T* __restrict__ 
       const int bidx = code - s.code[j] + centre;
       if (bias_table) sc += s.table[bidx];
       if (use_mask && s.label[j] != label) sc -= 100.f;
-      const float p = __expf(sc - lse);
+      const float p = exp_t<T>(sc - lse);
       if (dr.thresh) {
         if ((j & 3) == 0) dh = dropout_group_hash(dk0, drow, dcg, j);
         dp = dropout_keeps(dh, j, dr.thresh) ? dp * dr.scale : 0.f;
@@ -299,7 +309,7 @@ __global__ void __launch_bounds__(384) winattn_bwd_kernel(const T* __restrict__ 
       }
       if (bias_table) sc += s.table[s.code[i] - code + centre];
       if (use_mask && s.label[i] != label) sc -= 100.f;
-      const float p = __expf(sc - s.lse[i]);
+      const float p = exp_t<T>(sc - s.lse[i]);
       float pm = p;      // the probability that multiplied V: masked and rescaled under attn_drop
       if (dr.thresh) {
         const float keep = dropout_keeps(dropout_group_hash(dk0, ((int64_t)win * g.heads + head) * n + i, dcg, t), t, dr.thresh) ? dr.scale : 0.f;
@@ -905,7 +915,7 @@ extern "C" int miseg_winattn_bwd(const miseg_winattn_bwd_params* p, miseg_stream
   if (rc) return rc;
   MISEG_REQUIRE(p->f.drop_p >= 0.f && p->f.drop_p < 1.f, MISEG_E_BADARG, "winattn_bwd: drop_p = %f must lie in [0, 1)", (double)p->f.drop_p);
   const AttnDrop dr = attn_drop_args(&p->f);
-  if (!dr.thresh && global_attn_bwd(p, s, &rc)) return rc;       // must take exactly the calls global_attn_fwd took: its log-sum-exp is in the log2 domain
+  if (!dr.thresh && global_attn_bwd(p, s, &rc)) return rc;       // a call it declines (stricter alignment than the forward's) falls through: every forward kernel stores the log-sum-exp in natural-log units
   const int tb = 2 * g.tw - 1, tsize = p->f.bias_table ? tb * tb * tb : 0;
   const size_t sh = attn_smem_bytes(g.n, g.hd, tsize, true);
   MISEG_REQUIRE(sh <= 160 * 1024, MISEG_E_UNSUPPORTED, "winattn_bwd: %zu bytes of LDS needed", sh);

@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) gattn_fwd_kernel(const bf16* __restrict__
       for (int r = 0; r < 4; ++r) v[r] = (bf16)(o[mt][r] * inv);
       *reinterpret_cast<bf16x4*>(orow + 16 * mt + 4 * kg) = v;
     }
-    if (kg == 0) lse[((int64_t)b * g.heads + h) * g.n + q] = m + log2f(l);     // log2 domain, consumed by gattn_bwd_kernel only
+    if (kg == 0) lse[((int64_t)b * g.heads + h) * g.n + q] = (m + log2f(l)) * 0.6931471805599453f;   // natural-log units, like every forward kernel: any backward kernel may consume it
   }
 }
 
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256) gattn_bwd_kernel(const bf16* __restrict__
       for (int e = 0; e < 8; ++e) delta += (float)dob[ks][e] * (float)ov[e];
     }
     delta = ga_colreduce_sum(delta);
-    const float lq = qv ? lrow[q] : INFINITY;
+    const float lq = qv ? lrow[q] * GA_LOG2E : INFINITY;
     __syncthreads();
     if (blockIdx.x * 64 + wave * 16 >= g.n) return;
     f32x4 dq[4];
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(256) gattn_bwd_kernel(const bf16* __restrict__
     d += __shfl_xor(d, 4, 64);
     if (g8 == 0) {
       dsh[r] = d;
-      lsh[r] = r < g.n ? lrow[r] : INFINITY;      // a padded query row: p = exp2(-inf) = 0
+      lsh[r] = r < g.n ? lrow[r] * GA_LOG2E : INFINITY;      // a padded query row: p = exp2(-inf) = 0
     }
   }
   const int k0 = ((int)blockIdx.x - nqt) * 64 + wave * 16;

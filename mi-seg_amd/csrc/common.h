@@ -4,9 +4,12 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 #include "../../include/miseg_hip.h"
 
 namespace miseg {
+
+static constexpr int MAX_DEVICES = 64;   // device ordinals with a cached kernel attribute (MISEG_SET_SMEM); others set it on every launch
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -90,14 +93,18 @@ static inline hipError_t fill_words_2d_async(void* dst, size_t pitch, uint32_t v
   return hipGetLastError();
 }
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, size) instead of on every launch: the attribute is sticky, the call is a
-// driver round trip on the launch path.  Keyed by the function pointer; raising the size re-applies it.
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device, size) instead of on every launch: the attribute is sticky per
+// device, the call is a driver round trip on the launch path.  One cache per call site (= per kernel instantiation), one slot per device
+// ordinal; raising the size re-applies it.  Relaxed atomics: two threads racing on a slot both set the attribute, which is idempotent.
 #define MISEG_SET_SMEM(fn, bytes)                                                                                  \
   do {                                                                                                             \
-    static int miseg_smem_set_ = -1;                                                                               \
-    if ((int)(bytes) > miseg_smem_set_) {                                                                          \
+    static std::atomic<int> miseg_smem_set_[miseg::MAX_DEVICES];                                                   \
+    int dev__ = 0;                                                                                                 \
+    (void)hipGetDevice(&dev__);                                                                                    \
+    const int slot__ = (dev__ >= 0 && dev__ < miseg::MAX_DEVICES) ? dev__ : -1;                                    \
+    if (slot__ < 0 || (int)(bytes) + 1 > miseg_smem_set_[slot__].load(std::memory_order_relaxed)) {                \
       (void)hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes));      \
-      miseg_smem_set_ = (int)(bytes);                                                                              \
+      if (slot__ >= 0) miseg_smem_set_[slot__].store((int)(bytes) + 1, std::memory_order_relaxed);                 \
     }                                                                                                              \
   } while (0)
 

@@ -11,6 +11,7 @@
 //   one workgroup = (48 out-ch) x (48 in-ch) x 27 taps, accumulated in registers over a strided set of bricks
 //   (k = voxels; operands are "transposed": ds_read_b64_tr_b16 for bf16, 4-byte reads for fp32), written as one
 //   fp32 slab per workgroup and reduced by a second kernel (deterministic, no atomics).
+#include <type_traits>
 #include "common.h"
 
 namespace miseg {
@@ -108,6 +109,15 @@ __global__ void __launch_bounds__(256) conv3_fwd_kernel(const T* __restrict__ x,
     __syncthreads();
     // ---- K loop over (tap, group) in steps of 4 groups
     const int nsteps = (G + 3) / 4;
+    // fp32 parity mode: blocked summation (every 4 k-steps = 64 products per output element join the running sum once), see conv3_fwd96_kernel
+    constexpr bool BLOCKED = std::is_same<T, float>::value;
+    f32x4 pacc[BLOCKED ? 4 : 1][BLOCKED ? NT : 1];
+    if constexpr (BLOCKED) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) pacc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     for (int s = 0; s < nsteps; ++s) {
       int gi = 4 * s + fq;
       const bool gv = gi < G;
@@ -130,7 +140,18 @@ __global__ void __launch_bounds__(256) conv3_fwd_kernel(const T* __restrict__ x,
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) MmaC<T>::run(acc[mt][nt], bfr[nt], af[mt]);
+        for (int nt = 0; nt < NT; ++nt) {
+          if constexpr (BLOCKED) MmaC<T>::run(pacc[mt][nt], bfr[nt], af[mt]);
+          else MmaC<T>::run(acc[mt][nt], bfr[nt], af[mt]);
+        }
+      if constexpr (BLOCKED) {
+        if ((s & 3) == 3 || s + 1 == nsteps) {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { acc[mt][nt] += pacc[mt][nt]; pacc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        }
+      }
     }
   }
   // ---- epilogue: lane holds channels n0 + 16nt + 4fq .. +3 of voxel (d0+wave, h0+2mt+(fi>>3), w0+(fi&7))
@@ -347,16 +368,50 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
       for (int nt = 0; nt < NT; ++nt) bfr[0][nt] = *reinterpret_cast<const VT*>(wb + nt * 256);
 #pragma unroll
       for (int hh = 0; hh < 6; ++hh) af[hh] = *reinterpret_cast<const VT*>(abase + hh * FHW * 16);
+      // fp32 parity mode: a phase's 48 products per output element are summed in an accumulator of their own and join the running sum
+      // once - two-level (blocked) summation.  One fp32 accumulator walked all K = 27 Cin terms (1296 .. 20736) and its rounding random
+      // walk (~0.3 ulp sqrt(K)) was THE forward error of the parity mode: C2 logits 1.30e-6 from the float64 run, 3.5e-7 with this
+      // convolution alone evaluated in float64 (scripts/debug/f32_error_sources.py); the reference's own fp32 run sits at 7.6e-7.
+      // The bf16 mode keeps one accumulator (its error is the operands' rounding, 2^-9).
+      constexpr bool BLOCKED = std::is_same<T, float>::value;
+      if constexpr (BLOCKED) {
+        // output row by output row: its three kh steps (48 products per element) go to a 4 x NT-register block accumulator, then one add
+        VT bf3[3][NT];
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        if (kh + 1 < 3) {   // next step's weight fragments in flight during the MFMAs
+        for (int nt = 0; nt < NT; ++nt) bf3[0][nt] = bfr[0][nt];
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) bfr[(kh + 1) & 1][nt] = *reinterpret_cast<const VT*>(wb + ((kh + 1) * 4 * NROWS) * 16 + nt * 256);
+        for (int kh = 1; kh < 3; ++kh)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bf3[kh][nt] = *reinterpret_cast<const VT*>(wb + (kh * 4 * NROWS) * 16 + nt * 256);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          f32x4 pacc[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) pacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) MmaC<T>::run(pacc[nt], bf3[kh][nt], af[mt + kh]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[mt][nt] += pacc[nt];
+            // the sum is pinned HERE: left alone, the optimiser sank all adds behind the last phase (the running sum has no user before
+            // the epilogue), every phase's block accumulators stayed live and the kernel spilled 2.3 KB per lane
+            asm volatile("" : "+v"(acc[mt][nt]));
+          }
         }
+      } else {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int kh = 0; kh < 3; ++kh) {
+          if (kh + 1 < 3) {   // next step's weight fragments in flight during the MFMAs
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) MmaC<T>::run(acc[mt][nt], bfr[kh & 1][nt], af[mt + kh]);
+            for (int nt = 0; nt < NT; ++nt) bfr[(kh + 1) & 1][nt] = *reinterpret_cast<const VT*>(wb + ((kh + 1) * 4 * NROWS) * 16 + nt * 256);
+          }
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) MmaC<T>::run(acc[mt][nt], bfr[kh & 1][nt], af[mt + kh]);
+        }
       }
       if (phase + 1 < FWD96_PHASES) {
         wstore((phase + 1) & 1, slot_store);     // buffer last read in phase - 1: every wave is past that phase's barrier

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) gelu_bwd_kernel(const T* dy, int64_t lddy
     for (int k = 0; k < VEC; ++k) {
       const float t = xv.v[k];
       const float cdf = 0.5f * (1.f + erff(t * 0.70710678118654752f));
-      const float pdf = 0.39894228040143268f * __expf(-0.5f * t * t);
+      const float pdf = 0.39894228040143268f * (sizeof(T) == 4 ? expf(-0.5f * t * t) : __expf(-0.5f * t * t));
       g.v[k] *= cdf + t * pdf;
     }
     g.store(dx + r * lddx + c);

@@ -40,6 +40,16 @@ __device__ __forceinline__ float gelu_cdf(float t, float& e) {
 }
 __device__ __forceinline__ float gelu_erf(float t) { float e; return t * gelu_cdf(t, e); }
 __device__ __forceinline__ float gelu_erf_grad(float t) { float e; const float c = gelu_cdf(t, e); return fmaf(t * 0.39894228040143268f, e, c); }
+// fp32 parity mode (output type float): the library erff / expf, i.e. what torch's CPU kernels evaluate - the short forms above put the
+// parity mode's logits 1.7x further from the float64 run than the reference's own fp32 run; bf16 keeps the short forms
+template <class TO> __device__ __forceinline__ float gelu_fwd_t(float t) {
+  if constexpr (sizeof(TO) == 4) return 0.5f * t * (1.f + erff(t * 0.70710678118654752f));
+  else return gelu_erf(t);
+}
+template <class TO> __device__ __forceinline__ float gelu_grad_t(float t) {
+  if constexpr (sizeof(TO) == 4) return fmaf(t * 0.39894228040143268f, expf(-0.5f * t * t), 0.5f * (1.f + erff(t * 0.70710678118654752f)));
+  else return gelu_erf_grad(t);
+}
 
 // epilogue of the NT kernels: z = acc + bias ; mode 2: z *= gelu'(aux) ; mode 1: aux = z (the pre-activation, for the backward) ;
 // act ; + res.  aux / res are [M][N] row views in the output dtype.
@@ -56,9 +66,9 @@ struct Epi {
 template <class TO>
 __device__ __forceinline__ float epi_one(float x, int m, int n, const Epi& e) {
   if (e.bias) x += e.bias[n];
-  if (e.mode == 2) x *= gelu_erf_grad(to_f32(reinterpret_cast<const TO*>(e.aux)[(int64_t)m * e.ldaux + n]));
+  if (e.mode == 2) x *= gelu_grad_t<TO>(to_f32(reinterpret_cast<const TO*>(e.aux)[(int64_t)m * e.ldaux + n]));
   if (e.mode == 1) reinterpret_cast<TO*>(e.aux)[(int64_t)m * e.ldaux + n] = from_f32<TO>(x);
-  if (e.act == MISEG_ACT_GELU) x = gelu_erf(x);
+  if (e.act == MISEG_ACT_GELU) x = gelu_fwd_t<TO>(x);
   if (e.res) x += to_f32(reinterpret_cast<const TO*>(e.res)[(int64_t)m * e.ldres + n]);
   return x;
 }

@@ -845,7 +845,7 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const T* __restrict_
   float q = 0.f;
   for (int c = lane; c < C; c += 64) { const float d = to_f32(xr[c]) - m; q = fmaf(d, d, q); }
   q = wave_sum(q);
-  const float rs = rsqrtf(q / C + eps);
+  const float rs = 1.0f / sqrtf(q / C + eps);      // correctly rounded (v_rsq_f32 is 1 ulp: the fp32 parity mode wants torch's value)
   if (lane == 0) { mean[row] = m; rstd[row] = rs; }
   T* yr = y + row * ldy;
   for (int c = lane; c < C; c += 64) {

@@ -15,9 +15,9 @@ constexpr int LOSS_VPB = 2048;         // voxels per workgroup (256 threads x 2 
 template <class L> __device__ __forceinline__ int label_at(const L* lab, int64_t i) { return (int)lab[i]; }
 
 __device__ __forceinline__ float softplus_neg(float x) {      // log(1 + exp(-x)), stable
-  return fmaxf(-x, 0.f) + log1pf(__expf(-fabsf(x)));
+  return fmaxf(-x, 0.f) + log1pf(expf(-fabsf(x)));
 }
-__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 
 struct LossGeom {
   int B, C, kind, c0, sq;
@@ -31,7 +31,7 @@ __device__ __forceinline__ void focal_term(float x, float t, float gamma, float&
   const float z = 2.f * t - 1.f;
   const float ce = x - x * t + softplus_neg(x);
   const float ls = -softplus_neg(-x * z);            // logsigmoid(-x z) = -softplus(x z) = -log(1 + exp(x z))
-  const float w = __expf(gamma * ls);
+  const float w = expf(gamma * ls);
   f = w * ce;
   df = w * (-gamma * z * sigmoidf(x * z) * ce + sigmoidf(x) - t);
 }
@@ -44,13 +44,13 @@ template <int MAXC> __device__ __forceinline__ float softmax_from(const float (&
   float sum = 0.f;
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) {
-    p[c] = (c >= c0s && c < C) ? __expf(x[c] - mx) : 0.f;
+    p[c] = (c >= c0s && c < C) ? expf(x[c] - mx) : 0.f;
     sum += p[c];
   }
   const float inv = 1.f / sum;
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) p[c] *= inv;
-  return mx + __logf(sum);
+  return mx + logf(sum);
 }
 
 // grid (blocks per sample, B).  part: double [B][nblk][3 C + 1]
@@ -379,7 +379,7 @@ static __global__ void opt_count_kernel(const int32_t* __restrict__ used, int32_
 
 // ------------------------------------------------------------------------------------------------ stitching
 struct StitchArgs {
-  int C, D, H, W, rd, rh, rw, nd, nh, nw;
+  int C, D, H, W, rd, rh, rw, nd, nh, nw, d0;
   int sd[MISEG_STITCH_MAX_WINDOWS], sh[MISEG_STITCH_MAX_WINDOWS], sw[MISEG_STITCH_MAX_WINDOWS];
 };
 
@@ -392,7 +392,7 @@ __device__ __forceinline__ void cover(const int* st, int n, int r, int x, int& l
 
 // grid (ceil(W/64 / 4)..., H, D): thread = one voxel; channels looped (C small).  Reads of a window row are contiguous along w.
 static __global__ void __launch_bounds__(256) stitch_kernel(const float* __restrict__ win, float* __restrict__ out, uint16_t* __restrict__ count, StitchArgs a) {
-  const int w = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y, d = blockIdx.z;
+  const int w = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y, d = a.d0 + blockIdx.z;
   if (w >= a.W) return;
   int dl, dh_, hl, hh, wl, wh;
   cover(a.sd, a.nd, a.rd, d, dl, dh_);
@@ -640,18 +640,32 @@ extern "C" int miseg_stitch_windows(const miseg_stitch_params* p, miseg_stream_t
   const int* src[3] = {p->start_d, p->start_h, p->start_w};
   int* dst[3] = {a.sd, a.sh, a.sw};
   const int n[3] = {p->nd, p->nh, p->nw}, r[3] = {p->rd, p->rh, p->rw}, size[3] = {p->D, p->H, p->W};
+  const bool slab = p->d_count > 0;
+  MISEG_REQUIRE(p->d_count >= 0 && (!slab || (p->d_begin >= 0 && p->d_begin + p->d_count <= p->D)), MISEG_E_BADARG, "stitch_windows: slab [%d, %d + %d) of depth %d",
+                p->d_begin, p->d_begin, p->d_count, p->D);
+  a.d0 = slab ? p->d_begin : 0;
   for (int ax = 0; ax < 3; ++ax) {
     for (int i = 0; i < MISEG_STITCH_MAX_WINDOWS; ++i) dst[ax][i] = i < n[ax] ? src[ax][i] : 0;
     // every coordinate must be covered, windows inside the volume, starts non-decreasing: checked here, on the host, before any launch
     int reach = 0;
     for (int i = 0; i < n[ax]; ++i) {
+      if (ax == 0 && slab && i == 0) {      // resident layers of a slab: the first one only has to reach back to the slab's first depth
+        MISEG_REQUIRE(src[0][0] >= 0 && src[0][0] <= p->d_begin, MISEG_E_BADARG, "stitch_windows: the first resident layer starts at %d, behind the slab's first depth %d",
+                      src[0][0], p->d_begin);
+        reach = src[0][0];
+      }
       MISEG_REQUIRE(src[ax][i] >= 0 && src[ax][i] + r[ax] <= size[ax] && (i == 0 || src[ax][i] >= src[ax][i - 1]) && src[ax][i] <= reach, MISEG_E_BADARG,
                     "stitch_windows: axis %d window %d start %d (roi %d, size %d) leaves a gap or leaves the volume", ax, i, src[ax][i], r[ax], size[ax]);
       reach = src[ax][i] + r[ax];
     }
+    if (ax == 0 && slab) {
+      MISEG_REQUIRE(reach >= p->d_begin + p->d_count, MISEG_E_BADARG, "stitch_windows: the resident layers cover depths up to %d, the slab ends at %d", reach,
+                    p->d_begin + p->d_count);
+      continue;
+    }
     MISEG_REQUIRE(reach == size[ax], MISEG_E_BADARG, "stitch_windows: axis %d is covered up to %d of %d", ax, reach, size[ax]);
   }
-  stitch_kernel<<<dim3(cdiv(p->W, 256), p->H, p->D), 256, 0, s>>>(p->win, p->out, p->count, a);
+  stitch_kernel<<<dim3(cdiv(p->W, 256), p->H, slab ? p->d_count : p->D), 256, 0, s>>>(p->win, p->out, p->count, a);
   MISEG_LAUNCH_CHECK("stitch_windows");
   return MISEG_OK;
 }

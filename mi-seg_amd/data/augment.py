@@ -47,7 +47,8 @@ class GpuAugmenter:
         return float(torch.rand((), generator=self.gen))
 
     def draw(self, vol: ResidentVolume):
-        """per-patch parameters (host side): list of dicts origin / flip / rot_k / scale / shift"""
+        """per-patch parameters (host side): list of dicts origin / flip / rot_k / scale / shift (+ centre: the voxel the crop was drawn around,
+        before the crop was moved inside the volume - what the pos / neg balance is about)"""
         D, H, W = vol.label.shape
         out = []
         for _ in range(self.n):
@@ -64,7 +65,7 @@ class GpuAugmenter:
             rot_k = int(torch.randint(1, 4, (), generator=self.gen)) if self._u() < self.p_rot else 0
             scale = (self._u() * 0.2 - 0.1) if self._u() < self.p_scale else 0.0
             shift = (self._u() * 0.2 - 0.1) if self._u() < self.p_shift else 0.0
-            out.append(dict(origin=origin, flip=flip, rot_k=rot_k, scale=scale, shift=shift))
+            out.append(dict(origin=origin, flip=flip, rot_k=rot_k, scale=scale, shift=shift, centre=centre))
         return out
 
     def __call__(self, vol: ResidentVolume, params=None):

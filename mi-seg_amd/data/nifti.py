@@ -49,8 +49,12 @@ def read_nifti(path):
     dt = np.dtype(DTYPES[datatype]).newbyteorder(end)
     n = int(np.prod(shape))
     arr = np.frombuffer(raw, dtype=dt, count=n, offset=int(vox_offset)).reshape(shape, order="F")
-    if slope not in (0.0, 1.0) or inter != 0.0:
-        if slope != 0.0:
+    # scl_slope / scl_inter as nibabel reads them: scaling applies only with a finite non-zero slope, a non-finite intercept counts as 0,
+    # and (1, 0) is the identity (writers leave NaN in these fields to say "no scaling")
+    if np.isfinite(slope) and slope != 0.0:
+        if not np.isfinite(inter):
+            inter = 0.0
+        if (slope, inter) != (1.0, 0.0):
             arr = arr.astype(np.float32) * np.float32(slope) + np.float32(inter)
     if sform_code > 0:
         A = np.vstack([srow, [0, 0, 0, 1]])

@@ -20,7 +20,7 @@ class _S(C.Structure):
     pass
 
 
-ABI_VERSION = 4          # == MISEG_ABI_VERSION of include/miseg_hip.h; load() refuses a library that reports another
+ABI_VERSION = 5          # == MISEG_ABI_VERSION of include/miseg_hip.h; load() refuses a library that reports another
 C_NAMES = {}             # ctypes mirror -> name of the C struct it mirrors (tests/test_abi.py checks sizeof / offsetof of every field)
 
 
@@ -119,7 +119,7 @@ OptStep = _struct("OptStep", cname="miseg_opt_step_params", fields=[
     ("used", vp), ("steps", vp), ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("momentum", f32), ("lr_dev", vp)])
 Stitch = _struct("Stitch", cname="miseg_stitch_params", fields=[
     ("struct_size", u32), ("win", vp), ("out", vp), ("count", vp), ("C", i32), ("D", i32), ("H", i32), ("W", i32), ("rd", i32), ("rh", i32), ("rw", i32),
-    ("nd", i32), ("nh", i32), ("nw", i32), ("start_d", vp), ("start_h", vp), ("start_w", vp)])
+    ("nd", i32), ("nh", i32), ("nw", i32), ("start_d", vp), ("start_h", vp), ("start_w", vp), ("d_begin", i32), ("d_count", i32)])
 AugSample = _struct("AugSample", cname="miseg_aug_sample", fields=[("origin", i32 * 3), ("flip", i32 * 3), ("rot_k", i32), ("scale", f32), ("shift", f32)])
 Augment = _struct("Augment", cname="miseg_augment_params", fields=[
     ("struct_size", u32), ("image", vp), ("label", vp), ("label_bytes", i32), ("C", i32), ("D", i32), ("H", i32), ("W", i32), ("rd", i32), ("rh", i32),
@@ -135,7 +135,7 @@ LABEL_F32, LABEL_I32, LABEL_I64, LABEL_U8 = 0, 1, 2, 3
 LOSS_DICE_FOCAL, LOSS_DICE_CE = 0, 1
 OPT_ADAMW, OPT_ADAM, OPT_SGD_NESTEROV = 0, 1, 2
 OPT_BLOCK = 4096
-STITCH_MAX_WINDOWS = 32
+STITCH_MAX_WINDOWS = 64
 
 # symbol -> (restype, argtypes); every prototype of include/miseg_hip.h appears here (checked by tests/test_abi.py)
 PROTOS = {

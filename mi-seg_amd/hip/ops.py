@@ -1050,8 +1050,10 @@ def dice_metric(logits, label):
     return dice
 
 
-def stitch_windows(win, out, starts, roi, count=None):
-    """win fp32 [nd*nh*nw, C, rd, rh, rw] (all windows resident), out fp32 [C, D, H, W]; starts = (list_d, list_h, list_w)"""
+def stitch_windows(win, out, starts, roi, count=None, slab=None):
+    """win fp32 [nd*nh*nw, C, rd, rh, rw] (the windows of the nd depth layers `starts[0]`, all resident), out fp32 [C, D, H, W];
+    starts = (list_d, list_h, list_w).  slab = (d_begin, d_count): write only these depths of `out` from the resident layers (which then
+    need not cover the whole depth axis, miseg_stitch_params)."""
     nd, nh, nw = (len(s) for s in starts)
     Cc, D, H, W = out.shape
     assert win.dtype == torch.float32 and out.dtype == torch.float32 and win.is_contiguous() and out.is_contiguous()
@@ -1060,8 +1062,9 @@ def stitch_windows(win, out, starts, roi, count=None):
     arr = [(C.c_int32 * len(s))(*s) for s in starts]
     if count is not None:
         assert count.dtype == torch.int16 and count.is_contiguous() and tuple(count.shape) == (D, H, W)
+    d0, dn = slab if slab is not None else (0, 0)
     _call("miseg_stitch_windows", L.Stitch(C.sizeof(L.Stitch), _ptr(win), _ptr(out), _ptr(count), Cc, D, H, W, roi[0], roi[1], roi[2], nd, nh, nw,
-                                           C.cast(arr[0], C.c_void_p), C.cast(arr[1], C.c_void_p), C.cast(arr[2], C.c_void_p)))
+                                           C.cast(arr[0], C.c_void_p), C.cast(arr[1], C.c_void_p), C.cast(arr[2], C.c_void_p), int(d0), int(dn)))
     return out
 
 

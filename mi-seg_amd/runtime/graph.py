@@ -170,7 +170,7 @@ class GraphedStep:
             self.cot.copy_(cot, non_blocking=True)
         if host != self._styles_host:                  # (a pageable host tensor per step was a synchronous staging copy)
             self.styles.copy_(torch.tensor(host, dtype=torch.int32), non_blocking=True)
-            self._styles_host = list(host)
+            self._styles_host = tuple(host)
         key = tuple(sorted(set(host))) + (len(host),)
         if key not in self.graphs:
             self.graphs[key] = self._capture(host)

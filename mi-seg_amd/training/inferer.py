@@ -9,6 +9,10 @@ On a HIP device the stitching is sized for 288 GB of HBM: every window's logits 
 14.9 GB for the 512 x 512 x 363 volume of BASELINE configs[4]) and ONE gather kernel (csrc/training.hip::stitch_kernel) writes
 out = sum / count with the windows summed in window-index order -- MONAI's accumulation order, so the result is bit-identical to the
 sequential `out[window] += pred` loop, without its 700 read-modify-write passes over the 2.3 GB accumulator and without atomics.
+A volume whose window logits exceed the resident budget (a share of the card's FREE memory, `resident_budget`) is stitched in slabs of
+depth layers: whenever the buffer is full, the depths that no later layer can touch are written (slab form of the same kernel, same
+accumulation order) and the layers that still overlap the next depths move to the front of the buffer - MONAI's loop has no size limit
+and neither has this one.
 With `device=cpu` (the reference's --infer_cpu: logits stitched in host memory) or CPU inputs the plain loop below runs."""
 import math
 
@@ -30,7 +34,69 @@ def window_grid(image_size, roi_size, overlap):
     return [(d, h, w) for d in sd for h in sh for w in sw]
 
 
-RESIDENT_LIMIT_BYTES = 200e9     # window logits kept in HBM for the gather (288 GB card)
+RESIDENT_LIMIT_BYTES = None      # None: RESIDENT_FRACTION of the device's free memory at the first window; a number overrides it (tests)
+RESIDENT_FRACTION = 0.7
+
+
+def resident_budget(device):
+    """bytes of window logits kept in HBM at a time for the gather"""
+    if RESIDENT_LIMIT_BYTES is not None:
+        return int(RESIDENT_LIMIT_BYTES)
+    free, _ = torch.cuda.mem_get_info(device)
+    return int(free * RESIDENT_FRACTION)
+
+
+class _SlabStitcher:
+    """resident window logits of the depth layers [lo, ...) of one volume + the slab-wise gather (see the module docstring)"""
+
+    def __init__(self, starts, roi, channels, size, device, sw_batch_size):
+        self.starts, self.roi, self.size = starts, roi, size
+        self.layer = len(starts[1]) * len(starts[2])                       # windows per depth layer
+        nd = len(starts[0])
+        per_window = channels * roi[0] * roi[1] * roi[2] * 4
+        # layers that can overlap one depth (+ the one being filled); the buffer never holds fewer
+        span = 1 + max(sum(1 for j in range(i) if starts[0][j] + roi[0] > starts[0][i]) for i in range(nd))
+        budget = resident_budget(device)
+        self.cap = min(nd, max(budget // (per_window * self.layer), span + 1))       # whole layers kept resident
+        need = (self.cap * self.layer + (sw_batch_size if self.cap < nd else 0)) * per_window
+        if need > torch.cuda.mem_get_info(device)[0]:
+            raise MemoryError(f"sliding-window stitching needs {need / 1e9:.1f} GB for {self.cap} resident depth layers of {self.layer} windows")
+        self.win = torch.empty((self.cap * self.layer + (sw_batch_size if self.cap < nd else 0), channels) + tuple(roi), dtype=torch.float32, device=device)
+        self.lo = self.computed = self.done = 0                            # first resident layer, windows computed, depths written
+
+    def reset(self):
+        self.lo = self.computed = self.done = 0
+
+    def add(self, pred, out):
+        """append the next windows' logits (window-index order); stitches a slab first when they would not fit"""
+        n = pred.shape[0]
+        if self.computed - self.lo * self.layer + n > self.win.shape[0]:
+            self._flush(out, self.computed // self.layer)
+        at = self.computed - self.lo * self.layer
+        self.win[at:at + n].copy_(pred)
+        self.computed += n
+
+    def finish(self, out):
+        self._flush(out, len(self.starts[0]))
+
+    def _flush(self, out, upto):
+        """write the depths that only the complete layers [lo, upto) cover; keep the layers that reach beyond them"""
+        from ..hip import ops
+        sd, rd = self.starts[0], self.roi[0]
+        nxt = sd[upto] if upto < len(sd) else self.size[0]
+        if nxt <= self.done or upto <= self.lo:
+            if self.computed - self.lo * self.layer >= self.win.shape[0]:
+                raise RuntimeError("sliding-window stitching: the resident buffer holds no complete depth layer to write")
+            return
+        whole = self.lo == 0 and upto == len(sd)
+        ops.stitch_windows(self.win[:(upto - self.lo) * self.layer], out, (sd[self.lo:upto], self.starts[1], self.starts[2]), self.roi,
+                           slab=None if whole else (self.done, nxt - self.done))
+        self.done = nxt
+        keep = next((j for j in range(self.lo, upto) if sd[j] + rd > nxt), upto)
+        a, b = (keep - self.lo) * self.layer, self.computed - self.lo * self.layer
+        if a and b > a:
+            self.win[:b - a].copy_(self.win[a:b].clone())
+        self.lo = keep
 
 
 @torch.no_grad()
@@ -53,6 +119,7 @@ def sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, overlap
         mods = [int(m) for m in (modalities.reshape(-1).tolist() if isinstance(modalities, torch.Tensor) else modalities)]
     on_hip = inputs.is_cuda and (device is None or torch.device(device).type == "cuda")
     out = cnt = win = None
+    stitcher = None
     for b in range(B):
         for i in range(0, len(grid), sw_batch_size):
             chunk = grid[i:i + sw_batch_size]
@@ -63,22 +130,19 @@ def sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, overlap
                 out = torch.empty((B, pred.shape[1]) + size, dtype=torch.float32, device=dev) if on_hip else \
                     torch.zeros((B, pred.shape[1]) + size, dtype=torch.float32, device=dev)
                 if on_hip:
-                    need = len(grid) * pred.shape[1] * roi[0] * roi[1] * roi[2] * 4
-                    if need > RESIDENT_LIMIT_BYTES:
-                        raise NotImplementedError(f"{need / 1e9:.0f} GB of window logits exceed the resident budget; stitch the volume in slabs")
-                    win = torch.empty((len(grid), pred.shape[1]) + roi, dtype=torch.float32, device=dev)
+                    stitcher = _SlabStitcher(starts, roi, pred.shape[1], size, dev, sw_batch_size)
                 else:
                     cnt = torch.zeros((1, 1) + size, dtype=torch.float32, device=dev)
             if on_hip:
-                win[i:i + len(chunk)].copy_(pred)
+                stitcher.add(pred, out[b])
                 continue
             for j, (d, h, w) in enumerate(chunk):
                 out[b, :, d:d + roi[0], h:h + roi[1], w:w + roi[2]] += pred[j].to(out.device, torch.float32)
                 if b == 0:
                     cnt[0, 0, d:d + roi[0], h:h + roi[1], w:w + roi[2]] += 1.0
         if on_hip:
-            from ..hip import ops
-            ops.stitch_windows(win, out[b], starts, roi)
+            stitcher.finish(out[b])
+            stitcher.reset()
     if not on_hip:
         out = out / cnt
     if any(pads):

@@ -28,7 +28,7 @@ class ArenaOptimizer:
         n = len(arena.params)
         self.steps = torch.zeros(n, dtype=torch.int32, device=dev)
         self.used = torch.ones(n, dtype=torch.int32, device=dev)
-        self._used_host = torch.ones(n, dtype=torch.int32).pin_memory() if dev.type == "cuda" else torch.ones(n, dtype=torch.int32)
+        self._used_cache = {}      # bytes of a step's "used" flags -> the same flags on the device (one entry per present-modality set)
         descs = (L.OptDesc * n)()
         block0 = 0
         for i, (p, off) in enumerate(zip(arena.params, arena._offs)):
@@ -44,10 +44,16 @@ class ArenaOptimizer:
     def set_used_from_arena(self):
         """copy the host "used" flags of this step (arena.publish / allreduce have settled them) to the device; under hipGraph replay call
         this BEFORE the replay that contains the step"""
-        flags = self._used_host
-        for i, p in enumerate(self.arena.params):
-            flags[i] = 1 if p._miseg_used else 0
-        self.used.copy_(flags, non_blocking=True)
+        # The flags of a step are one of a handful of patterns (which modalities were in the batch).  Each pattern is uploaded ONCE from a
+        # host buffer of its own and then copied device-to-device on the stream: a single pinned staging buffer rewritten every step raced
+        # with its own asynchronous upload once the host ran ahead of the device (sync-free loops), and a step then saw the next step's flags.
+        key = bytes(1 if p._miseg_used else 0 for p in self.arena.params)
+        dev = self._used_cache.get(key)
+        if dev is None:
+            if len(self._used_cache) >= 64:
+                self._used_cache.clear()
+            dev = self._used_cache[key] = torch.tensor(list(key), dtype=torch.int32, device=self.used.device)
+        self.used.copy_(dev, non_blocking=True)
 
     def step(self, lr=None, update_flags=True):
         if [p.data_ptr() for p in self.arena.params] != self._ptrs:

@@ -34,7 +34,8 @@ def main():
     if "--period" in sys.argv:                                      # back-to-back replays: cut one period out of the longest segment
         lo, hi = max(segs, key=lambda ab: ab[1] - ab[0])
         reg = names[lo:hi]
-        per = next(p for p in range(50, len(reg) // 2) if sum(reg[i] == reg[i + p] for i in range(len(reg) - p)) > 0.98 * (len(reg) - p))
+        # (launches of the side-branch stream interleave a little differently from replay to replay: take the best-matching period)
+        per = max(range(50, min(len(reg) // 2, 2000)), key=lambda p: sum(reg[i] == reg[i + p] for i in range(len(reg) - p)) / (len(reg) - p))
         first = next(i for i in range(lo, hi) if names[i] == "fill_words_kernel" or "fill" in names[i])
         lo = first + per * ((hi - first) // per - 1)
         hi = lo + per

@@ -52,6 +52,22 @@ def test_nifti_round_trip_and_ras(tmp_path, dtype):
         read_nifti(str(tmp_path / "bad.nii"))
 
 
+def test_nifti_scl_slope_inter_follow_nibabel(tmp_path):
+    """scl_slope / scl_inter: NaN (or slope 0) means "no scaling", a NaN intercept counts as 0 - never a NaN volume"""
+    import struct
+    from mi_seg_amd.data.nifti import read_nifti, write_nifti
+    vol = np.arange(24, dtype=np.int16).reshape(2, 3, 4)
+    write_nifti(str(tmp_path / "v.nii"), vol)
+    raw = bytearray((tmp_path / "v.nii").read_bytes())
+    nan = float("nan")
+    for slope, inter, want in ((nan, nan, vol), (nan, 0.0, vol), (0.0, 5.0, vol), (1.0, nan, vol), (1.0, 0.0, vol),
+                               (2.0, nan, vol.astype(np.float32) * 2), (2.0, -1.0, vol.astype(np.float32) * 2 - 1), (1.0, 3.0, vol.astype(np.float32) + 3)):
+        struct.pack_into("<2f", raw, 112, slope, inter)
+        (tmp_path / "s.nii").write_bytes(bytes(raw))
+        got, _ = read_nifti(str(tmp_path / "s.nii"))
+        assert np.all(np.isfinite(got)) and np.array_equal(got, want), (slope, inter)
+
+
 def test_checkpoint_import_export(tmp_path):
     from mi_seg_amd.data.checkpoint import export_state, load_model_state
     from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
@@ -111,9 +127,18 @@ def test_gpu_augmentation_matches_torch_ops():
             want = ci * (1.0 + torch.tensor(p["scale"], dtype=torch.float32)) + torch.tensor(p["shift"], dtype=torch.float32)
             assert torch.equal(out["label"][i], cl)
             assert torch.allclose(out["image"][i], want, rtol=0, atol=1e-6)
-    # pos / neg balance: about half of the crop centres are foreground voxels
-    aug = GpuAugmenter((32, 32, 32), patches_training_sample=16, seed=5)
+    # pos / neg balance (RandCropByPosNegLabeld pos=1, neg=1, data/multi_modal.py:50-59): the share of crop centres that are foreground
+    # voxels follows pos / (pos + neg) although the foreground is a small part of the volume; every centre comes from the right voxel list
     vol = ResidentVolume(img[0].cuda(), lab[0, 0].cuda())
+    lab_host = lab[0, 0]
+    fg_share = float((lab_host > 0).float().mean())
+    assert fg_share < 0.35
+    for pos, neg, want in ((1.0, 1.0, 0.5), (3.0, 1.0, 0.75)):
+        aug = GpuAugmenter((32, 32, 32), patches_training_sample=16, pos=pos, neg=neg, seed=5)
+        centres = [p["centre"] for _ in range(40) for p in aug.draw(vol)]
+        hits = sum(int(lab_host[c] > 0) for c in centres)
+        assert abs(hits / len(centres) - want) < 0.07, (pos, neg, hits / len(centres))            # 640 draws: sigma 0.02
+        assert all(0 <= o and o + 32 <= s for p in aug.draw(vol) for o, s in zip(p["origin"], lab_host.shape))
     with pytest.raises(ValueError):
         GpuAugmenter((96, 96, 96))(vol)                       # volume smaller than the roi
 

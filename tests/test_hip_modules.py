@@ -553,3 +553,70 @@ def test_graphed_step_replays_match_eager(use_arena):
     finally:
         if arena is not None:
             arena.detach()
+
+
+@pytest.mark.gpu
+def test_split_step_as_bench_times_it_at_n_gt_1():
+    """The step `bench.py --gpus N` (N > 1) times on the headline net (fs=48, 96^3, bf16): two hipGraphs, the side branch in the second one,
+    decoder1's two deferred weight gradients a HOLE in the decoder-side tail (`split_defers`).  At the hook between the graphs - where
+    bench.py starts RCCL on the early ranges - those ranges must be final and the hole must not be; after the second graph the whole arena
+    must equal the single-graph step's (reference: tune.py:103-109, one DDP exchange per step over the same gradients)."""
+    from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
+    from mi_seg_amd.runtime.arena import ParamArena
+    from mi_seg_amd.runtime.graph import GraphedStep
+    from mi_seg_amd.utils.detfill import fill_module_, det_input
+    net = SwinUNETR((96, 96, 96), 1, 6, feature_size=48, num_heads=(3, 6, 12, 24), vit_norm_name=_norm("instance_cond"),
+                    encoder_norm_name=_norm("instance_cond"), decoder_norm_name=_norm("instance")).cuda()
+    fill_module_(net)
+    net.set_compute_dtype(torch.bfloat16)
+    assert net.side_branch
+    x = det_input(3, (1, 1, 96, 96, 96)).cuda()
+    cot = det_input(4, (1, 6, 96, 96, 96)).cuda()
+    params = [p for p in net.parameters() if p.requires_grad]
+    arena = ParamArena(params, torch.bfloat16)
+    try:
+        single = GraphedStep(net, x.shape, cot.shape, arena=arena)
+        ref = {}
+        for m in (0, 1):
+            y = single(x, [m], cot)
+            torch.cuda.synchronize()
+            ref[m] = (y.detach().clone(), arena.flat.clone(), [p.grad is None for p in params])
+        # bench.py's ranges: the decoder-side tail minus the hole goes out at the hook, the head and the hole after the second graph
+        n = arena.flat.numel()
+        tail = arena.tail_offset(net.late_backward_parameters())
+        hole = arena.param_range(net.deferred_backward_parameters())
+        assert 0 < tail <= hole[0] < hole[1] <= n
+        early = [(hole[1], n), (tail, hole[0])]
+        net.split_defers = True
+        split = GraphedStep(net, x.shape, cot.shape, arena=arena, split=True)
+        seen = []
+        hook = lambda: seen.append(([arena.flat[lo:hi].clone() for lo, hi in early], arena.flat[hole[0]:hole[1]].clone(), arena.flat[:tail].clone()))
+        for it, m in enumerate([1, 0, 0, 1]):
+            y = split(x, [m], cot, between=hook)
+            torch.cuda.synchronize()
+            at_hook, hole_at_hook, head_at_hook = seen[-1]
+            for (lo, hi), t in zip(early, at_hook):
+                assert torch.equal(t, arena.flat[lo:hi]), f"replay {it}: arena[{lo}:{hi}] changed after the hook - it is not final there"
+                assert float(t.abs().max()) > 0
+            # the deferred weight gradients and the encoder / Swin side are produced by the second graph
+            assert float(hole_at_hook.abs().max()) == 0.0 and float(arena.flat[hole[0]:hole[1]].abs().max()) > 0, "the hole must be written by the second graph"
+            assert float(head_at_hook.abs().max()) == 0.0 and float(arena.flat[:tail].abs().max()) > 0
+            y_ref, g_ref, none_ref = ref[m]
+            assert torch.equal(y.detach(), y_ref), f"replay {it}: logits differ from the single-graph step"
+            assert [p.grad is None for p in params] == none_ref
+            assert bool(torch.isfinite(arena.flat).all())
+            # decoder side (everything bench.py sends at the hook + the hole): the same kernels on the same inputs - equal up to the order
+            # of the weight-gradient sums (<= 1e-5, DESIGN section 3).  Encoder / Swin side: the cut tensors' gradients reach it as ONE
+            # bf16 tensor instead of joining the fan-out sums one by one, i.e. a different bf16 rounding of the same sum - the tolerance of
+            # the other graph-vs-eager tests
+            names = [k for k, _ in net.named_parameters()]
+            for k, p, v in zip(names, params, arena.views):
+                if p.grad is not None and k not in ZERO_GRAD:
+                    lo = v.storage_offset()
+                    a, b = arena.flat[lo:lo + p.numel()], g_ref[lo:lo + p.numel()]
+                    tol = 2e-5 if lo >= tail else 2e-3
+                    err = float((a - b).norm()) / (float(b.norm()) + 1e-30)
+                    assert err <= tol, f"replay {it}: gradient of {k} differs from the single graph by {err:.2e} (arena offset {lo}, tail starts at {tail})"
+    finally:
+        net.split_defers = False
+        arena.detach()

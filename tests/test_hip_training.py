@@ -160,6 +160,32 @@ def test_stitch_kernel_is_bit_identical_to_the_sequential_loop(size, roi, overla
         ops.stitch_windows(win, out, (starts[0][:-1] + [starts[0][-1] - 1],) + starts[1:], roi)     # leaves a gap at the end of an axis
 
 
+@pytest.mark.parametrize("size,roi,overlap,layers", [((200, 40, 33), (32, 24, 16), 0.5, 3), ((70, 41, 33), (32, 24, 16), 0.25, 2), ((96, 24, 16), (16, 24, 16), 0.75, 5)])
+def test_slab_wise_stitching_equals_the_resident_gather(size, roi, overlap, layers, monkeypatch):
+    """window logits beyond the resident budget (lightning_monai.py:86-93 has no such limit): the volume is stitched in slabs of depth
+    layers, bit-identical to the one-pass gather and to MONAI's sequential loop"""
+    from mi_seg_amd.training import inferer
+    starts = tuple(inferer._starts(s, r, overlap) for s, r in zip(size, roi))
+    grid = [(d, h, w) for d in starts[0] for h in starts[1] for w in starts[2]]
+    table = torch.randn(len(grid), 3, *roi, generator=torch.Generator().manual_seed(5)).to(DEV)
+    vol = torch.zeros((1, 1) + size, device=DEV)
+    state = {"i": 0}           # the inferer asks for the windows in window-index order: the predictor hands out the table in that order
+
+    def predictor(x):
+        n = x.shape[0]
+        out = table[state["i"]:state["i"] + n]
+        state["i"] += n
+        return out
+
+    want, _ = _loop_stitch(table, starts, roi, size)
+    per_layer = len(starts[1]) * len(starts[2]) * 3 * roi[0] * roi[1] * roi[2] * 4
+    for budget, batch in ((None, 4), (layers * per_layer, 4), (layers * per_layer, 1), (1, 3)):
+        monkeypatch.setattr(inferer, "RESIDENT_LIMIT_BYTES", budget)
+        state["i"] = 0
+        got = inferer.sliding_window_inference(vol, roi, batch, predictor, overlap=overlap)
+        assert torch.equal(got[0], want), (budget, batch)
+
+
 def _small_model(roi, dtype=torch.float32, out=6):
     from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
     from mi_seg_amd.utils.detfill import fill_module_
