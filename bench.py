@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-arena", action="store_true", help="torch-style per-parameter gradient tensors and per-call weight casts")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: all-reduce after the whole backward pass instead of overlapping the encoder half")
+    ap.add_argument("--host-flags", dest="device_flags", action="store_false",
+                    help="N > 1: read the exchanged 'used on any rank' bitmap back to the host every step (what a torch optimiser needs); default: it stays "
+                         "on the device for the fused optimiser and the step has no host synchronisation")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group (and take the N > 1 code path) even with one rank")
     a = ap.parse_args()
 
@@ -180,7 +183,7 @@ def main():
             works, ub = [], []
             if graphed is not None and not eager:
                 def between():          # the flags of a replayed graph are known up front: the bitmap exchange starts here as well
-                    ub.append(arena.used_begin())
+                    ub.append(arena.used_begin(host=not a.device_flags))
                     for lo, hi in early_ranges:
                         if hi > lo:
                             works.extend(arena.allreduce_begin(lo, hi))
@@ -194,7 +197,7 @@ def main():
                     if hi > lo:
                         works.extend(arena.allreduce_begin(lo, hi))
                 torch.autograd.backward([o for o, _ in cut], [l.grad for _, l in cut])
-            arena.allreduce_end(works, world, rest=late_ranges, used_work=ub[0] if ub else None)
+            arena.allreduce_end(works, world, rest=late_ranges, used_work=ub[0] if ub else None, host_flags=not a.device_flags)
             return
         if graphed is not None and not eager:
             graphed(pool[k:k + 1], [mods[k]], cot)

@@ -49,7 +49,8 @@ class ParamArena:
                 self.buckets.append((start, e))
                 start = e
         self.used_dev = torch.zeros(len(self.params), dtype=torch.int32, device=dev)
-        self._bm = None         # (stream, pinned source, pinned result, event) of the bitmap exchange on a card
+        self._bm = None         # (stream, pinned result, event) of the bitmap exchange on a card
+        self.used_on_device = False     # True after an exchange that left the global "used" flags in `used_dev` only (allreduce_end(host_flags=False))
         self._offs, self._size = offs, off
         self._qkey = self.flat.untyped_storage().data_ptr()
         self.queues = None
@@ -223,8 +224,10 @@ class ParamArena:
         ub = self.used_begin(group)
         works = []
         avg = self._avg(group)
-        for lo, hi in reversed(self.buckets):
-            works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=group, async_op=True))
+        if dist.get_world_size(group) > 1:
+            for lo, hi in reversed(self.buckets):
+                works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=group, async_op=True))
+        self.used_on_device = False
         used = ub()
         for w in works:
             w.wait()
@@ -259,6 +262,8 @@ class ParamArena:
         """start the sum all-reduce of flat[lo:hi] (pieces of `piece` elements, last first) behind everything already queued on the
         current stream; returns the work handles.  RCCL runs them on its own stream: kernels launched afterwards overlap."""
         import torch.distributed as dist
+        if dist.get_world_size(group) == 1:
+            return []                   # a one-rank group: the local sums ARE the mean (RCCL would run a 249 MB copy kernel per step)
         piece = piece or (hi - lo)      # the whole range is final when this is called: one collective (each costs a ring latency)
         works, e = [], hi
         while e > lo:
@@ -267,34 +272,61 @@ class ParamArena:
             e = b
         return works
 
-    def used_begin(self, group=None):
+    def _flags_to_device(self):
+        """this rank's "used" flags of the step in `used_dev`, without a host staging buffer that a later step could overwrite while the copy
+        is still queued: each distinct pattern (which modalities were in the batch) is uploaded once and then copied device-to-device"""
+        key = bytes(1 if p._miseg_used else 0 for p in self.params)
+        cache = self.__dict__.setdefault("_flag_cache", {})
+        dev = cache.get(key)
+        if dev is None:
+            if len(cache) >= 64:
+                cache.clear()
+            dev = cache[key] = torch.tensor(list(key), dtype=torch.int32, device=self.used_dev.device)
+        self.used_dev.copy_(dev, non_blocking=True)
+
+    def used_begin(self, group=None, host=True):
         """start the max all-reduce of the "used on this rank" bitmap (call once the flags of this step are known: for a replayed
         hipGraph that is before the replay); hand the result - a callable that waits for the exchange and returns the flags -
-        to allreduce_end."""
+        to allreduce_end.
+        host=False: the exchanged flags stay on the device (`used_dev`, what training/optim.py::ArenaOptimizer consumes: "unused on every
+        rank => no update, no decay, no step count") and the callable returns None after making the current STREAM wait for the exchange -
+        the step has no host synchronisation at all, so the host keeps launching the next step's graphs while this one runs (with the
+        host read every step ended in a stream drain and the next graph launch started on an idle card)."""
         import torch.distributed as dist
-        flags = torch.tensor([int(p._miseg_used) for p in self.params], dtype=torch.int32)
         if not self.used_dev.is_cuda:
-            self.used_dev.copy_(flags)
+            self.used_dev.copy_(torch.tensor([int(p._miseg_used) for p in self.params], dtype=torch.int32))
             work = dist.all_reduce(self.used_dev, op=dist.ReduceOp.MAX, group=group, async_op=True)
 
             def finish():
                 work.wait()
-                return self.used_dev.tolist()
+                return self.used_dev.tolist() if host else None
             return finish
+        single = dist.get_world_size(group) == 1          # nothing to exchange: the local flags are the global ones
+        if not host:
+            self._flags_to_device()
+            work = None if single else dist.all_reduce(self.used_dev, op=dist.ReduceOp.MAX, group=group, async_op=True)
+
+            def finish_dev():
+                if work is not None:
+                    work.wait()                          # the current stream waits for RCCL's; the host does not
+                return None
+            return finish_dev
+        if single:
+            flags = [int(p._miseg_used) for p in self.params]
+            return lambda: flags
         # On the card the exchange and the read-back run on a stream of their own, through pinned host buffers: a `.tolist()` on the
         # compute stream would queue behind the whole step and stall the host until the step has drained - the launch of the next
         # step's graphs would then start on an idle card (+0.75 ms per step measured with one rank)
         if self._bm is None:
             n = len(self.params)
-            self._bm = (torch.cuda.Stream(device=self.used_dev.device), torch.empty(n, dtype=torch.int32).pin_memory(),
-                        torch.empty(n, dtype=torch.int32).pin_memory(), torch.cuda.Event())
-        side, src, dst, done = self._bm
-        src.copy_(flags)
+            self._bm = (torch.cuda.Stream(device=self.used_dev.device), torch.empty(n, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+        side, dst, done = self._bm
+        self._flags_to_device()
+        side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            self.used_dev.copy_(src, non_blocking=True)
             work = dist.all_reduce(self.used_dev, op=dist.ReduceOp.MAX, group=group, async_op=True)
             work.wait()                                  # the side stream waits for RCCL's
-            dst.copy_(self.used_dev, non_blocking=True)
+            dst.copy_(self.used_dev, non_blocking=True)  # (the host reads `dst` in finish(), before any later step can queue another copy)
             done.record()
 
         def finish():
@@ -302,13 +334,15 @@ class ParamArena:
             return dst.tolist()
         return finish
 
-    def allreduce_end(self, works, world_size, group=None, rest=None, used_work=None):
+    def allreduce_end(self, works, world_size, group=None, rest=None, used_work=None, host_flags=True):
         """finish a split exchange: the "used on any rank" bitmap (unless used_begin already started it), then the all-reduce of
         flat[rest[0]:rest[1]] (the part the second half of the backward pass produced), wait for everything, mean, publish.  The
         bitmap goes first so that the host read of it (the one host sync of a step, like torch DDP's find_unused_parameters)
-        completes while the rest is still in flight."""
+        completes while the rest is still in flight.
+        host_flags=False (with used_begin(host=False)): no host read - the global flags are in `used_dev` for the fused optimiser, `p.grad`
+        follows this rank's own flags (a parameter unused here but used elsewhere still holds the averaged gradient in its arena slot)."""
         self.end_backward()
-        ub = used_work if used_work is not None else self.used_begin(group)
+        ub = used_work if used_work is not None else self.used_begin(group, host=host_flags)
         works = list(works)
         if rest is not None:
             for lo, hi in ([rest] if isinstance(rest[0], int) else rest):      # one range or several (a hole left in the tail, see bench.py)
@@ -319,8 +353,10 @@ class ParamArena:
             w.wait()
         if not self._avg(group):
             self.flat.mul_(1.0 / world_size)
-        for p, u in zip(self.params, used):
-            p._miseg_used = bool(u)
+        if used is not None:
+            for p, u in zip(self.params, used):
+                p._miseg_used = bool(u)
+        self.used_on_device = used is None
         self.publish()
 
     @staticmethod

@@ -59,7 +59,10 @@ class ArenaOptimizer:
         if [p.data_ptr() for p in self.arena.params] != self._ptrs:
             raise RuntimeError("a parameter was re-allocated after the optimiser was built (e.g. model.to(...)): rebuild the ArenaOptimizer")
         if update_flags:
-            self.set_used_from_arena()
+            if getattr(self.arena, "used_on_device", False):      # a data-parallel exchange left the GLOBAL flags on the device (no host read)
+                self.used.copy_(self.arena.used_dev, non_blocking=True)
+            else:
+                self.set_used_from_arena()
         p = L.OptStep(C.sizeof(L.OptStep), KINDS[self.kind], self._table.data_ptr(), len(self.arena.params), self._blocks, self.arena.flat.data_ptr(),
                       self.state1.data_ptr(), self.state2.data_ptr() if self.state2 is not None else None, self.used.data_ptr(), self.steps.data_ptr(),
                       self.lr if lr is None else float(lr), self.betas[0], self.betas[1], self.eps, self.weight_decay, self.momentum,

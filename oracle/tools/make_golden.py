@@ -386,6 +386,66 @@ def gen_swin_unetr_c2_truth():
     save("swin_unetr_c2_truth", arrays, meta)
 
 
+def truth_case(arrays, meta, tag, build, xshape, modalities, unpinned):
+    """float64 and autocast-bf16 runs of the reference modules `build()` yields (same weights / input / white-noise cotangent as the
+    fp32 case `tag` of the companion fixture): the conditioning baseline of tests/test_hip_modules.py::_vs_truth"""
+    m = build()
+    fill_module_(m)
+    x = det_input(1234, xshape)
+    t0 = time.time()
+    md = build()
+    fill_module_(md)
+    md = md.double()
+    yd = md(x.double(), modalities)
+    g = det_input(4321, tuple(yd.shape))
+    yd.backward(g.double())
+    for k, p in md.named_parameters():
+        if p.grad is not None:
+            arrays[f"{tag}/grad64:{k}"] = sample(p.grad)
+    arrays[f"{tag}/logits64_samples"] = sample(yd)
+    t1 = time.time()
+    del md
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ya = m(x, modalities)
+    ya.backward(g.to(ya.dtype))
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            arrays[f"{tag}/gradamp:{k}"] = sample(p.grad)
+    arrays[f"{tag}/logitsamp_samples"] = sample(ya.float())
+    t2 = time.time()
+    meta["cases"][tag] = {"x": list(xshape), "modalities": None if modalities is None else [int(v) for v in modalities], "fp64_s": round(t1 - t0, 1),
+                          "autocast_bf16_s": round(t2 - t1, 1), "autocast_logits_dtype": str(ya.dtype)}
+    meta["unpinned"] = unpinned
+    print(f"    {tag}: fp64 {t1 - t0:.0f}s autocast {t2 - t1:.0f}s")
+
+
+def gen_unetr_c3_truth():
+    """C3 (and the small UNETR) in float64 and under autocast-bf16: see gen_swin_unetr_c2_truth"""
+    import copy
+    arrays, meta = {}, {"cases": {}}
+    up = ["vit.blocks.*.attn (MONAI SABlock stand-in)", "vit.blocks.*.mlp (MONAI MLPBlock stand-in)"]
+    truth_case(arrays, meta, "small_32", lambda: UNETR(1, 6, (32, 32, 32), feature_size=8, hidden_size=48, mlp_dim=96, num_heads=4, pos_embed="perceptron",
+                                                        vit_norm_name=copy.deepcopy(COND), encoder_norm_name=copy.deepcopy(COND),
+                                                        decoder_norm_name=copy.deepcopy(INST)), (2, 1, 32, 32, 32), [0, 1], up)
+    truth_case(arrays, meta, "c3_m1", lambda: UNETR(1, 6, (96, 96, 96), feature_size=16, hidden_size=768, mlp_dim=3072, num_heads=12, pos_embed="perceptron",
+                                                     vit_norm_name=copy.deepcopy(COND), encoder_norm_name=copy.deepcopy(COND),
+                                                     decoder_norm_name=copy.deepcopy(INST)), (1, 1, 96, 96, 96), [1], up)
+    save("unetr_c3_truth", arrays, meta)
+
+
+def gen_unet_truth():
+    """C1 (the plain UNet, BASELINE configs[0]) and its conditional variant in float64 and under autocast-bf16"""
+    import copy
+    arrays, meta = {}, {"cases": {}}
+    truth_case(arrays, meta, "c1_64", lambda: UNet(3, 1, 6, channels=[32, 64, 128, 256], strides=[2, 2, 2], num_res_units=2, act="prelu",
+                                                   norm_down=copy.deepcopy(INST), norm_up=copy.deepcopy(INST), dropout=0.0, bias=True, adn_ordering="NDA"),
+               (1, 1, 64, 64, 64), None, [])
+    truth_case(arrays, meta, "cond_32", lambda: UNet(3, 1, 6, channels=[8, 16, 32], strides=[2, 2], num_res_units=2, act="prelu",
+                                                     norm_down=copy.deepcopy(COND), norm_up=copy.deepcopy(INST), dropout=0.0, bias=True, adn_ordering="NDA"),
+               (2, 1, 32, 32, 32), [1, 0], [])
+    save("unet_truth", arrays, meta)
+
+
 def gen_unetr():
     import copy
     arrays, meta = {}, {"cases": {}}
@@ -432,8 +492,9 @@ GENS = {
     "patch_merging": gen_patch_merging, "unetr_blocks": gen_unetr_blocks, "transformer_block": gen_transformer_block,
     "swin_unetr_small": gen_swin_unetr_small, "unetr_small": gen_unetr, "unet": gen_unet,
     "swin_unetr_c2": gen_swin_unetr_c2, "unetr_c3": gen_unetr_c3, "swin_unetr_c2_truth": gen_swin_unetr_c2_truth,
+    "unetr_c3_truth": gen_unetr_c3_truth, "unet_truth": gen_unet_truth,
 }
-FULL = ("swin_unetr_c2", "unetr_c3", "swin_unetr_c2_truth")
+FULL = ("swin_unetr_c2", "unetr_c3", "swin_unetr_c2_truth", "unetr_c3_truth")
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -160,7 +160,7 @@ def test_unetr_blocks(golden, tag):
     _check_param_grads(m, G.grads(tag), case["grad_none"], TOL)
 
 
-def _whole(G, tag, model, tol, dtype=torch.float32, ce=False, allow_small=False):
+def _whole(G, tag, model, tol, dtype=torch.float32, ce=False):
     from mi_seg_amd.utils.detfill import ce_cotangent, det_input
     case = G.meta["cases"][tag]
     model = _fill(model)
@@ -173,12 +173,11 @@ def _whole(G, tag, model, tol, dtype=torch.float32, ce=False, allow_small=False)
     assert e < tol, ("logits", e)
     y.backward(ce_cotangent(y) if ce else det_input(4321, tuple(y.shape)).to(DEV))
     named = dict(model.named_parameters())
-    # 10 x tol: the reference's own fp32 run sits 1e-3 .. 5e-3 from its float64 run on these gradients (test_swin_unetr_c2_vs_truth)
-    worst = compare_grads({k: p.grad for k, p in named.items()}, G.grads2(tag) if ce else G.grads(tag), 10 * tol, sampled=True,
-                          vanish_tol=1e-2 if dtype == torch.float32 else 0.5, pool_small=dtype != torch.float32, allow_small=allow_small or dtype != torch.float32,
-                          # 1-channel 1x1x1 conv in front of an instance norm: d/dw == 0 analytically (the norm removes the
-                          # per-channel scale), so in bf16 the value is rounding noise of either implementation
-                          skip=() if dtype == torch.float32 else ("encoder1.layer.conv3.conv.weight",))
+    # 10 x tol: the reference's own fp32 run sits 1e-3 .. 5e-3 from its float64 run on these gradients (test_swin_unetr_c2_vs_truth).
+    # bf16: the gradients are judged per parameter against the float64 fixtures (test_*_vs_truth) - the fp32 fixture is no bar for them
+    worst = None
+    if dtype == torch.float32:
+        worst = compare_grads({k: p.grad for k, p in named.items()}, G.grads2(tag) if ce else G.grads(tag), 10 * tol, sampled=True, vanish_tol=1e-2)
     none = [k for k, p in named.items() if p.grad is None]
     assert sorted(none) == sorted(case["grad_none"])
     return worst
@@ -219,11 +218,13 @@ def test_swin_unetr_c2_vs_truth(golden, dtype, cot):
     (tests/golden/swin_unetr_c2_truth.npz, made by oracle/tools/make_golden.py from the reference's modules).  "Within 1e-3 of the fp32
     reference" is therefore below the reference's own rounding noise at this test point; what CAN be asked of an implementation is that it
     is no further from the float64 run than the reference itself is at the same precision:
-        fp32 mode:  |hip - f64| <= 5 x |ref_fp32 - f64| + 1e-5 per parameter,  median over parameters <= 2.5 x the reference's median
+        fp32 mode:  |hip - f64| <= 3 x |ref_fp32 - f64| + 1e-5 per parameter,  median over parameters <= 1.5 x the reference's median,
+                    logits within 8e-7 of the float64 run (the reference's fp32 run: 7.6e-7)
         bf16 mode:  |hip - f64| <= 2 x |ref_autocast - f64| per parameter,      median over parameters <= 1.25 x the reference's median
     relative L2 over the 4096-element sample of each tensor.  Both sides of each inequality are single draws of rounding noise (any change
-    of a summation order re-rolls them): measured worst per-parameter ratios 2.7 - 3.5 (fp32) and 1.2 - 1.5 (bf16) over three builds,
-    medians 0.45 - 1.7 (fp32) and 0.90 - 0.93 (bf16).  Parameters whose true gradient is zero (a bias in front of an
+    of a summation order re-rolls them).  Round 3: the parity mode's 3x3x3 convolution sums in blocks (csrc/conv3d.hip) - logits 1.3e-6 ->
+    4.6e-7 from the float64 run, gradient medians 0.79 x (white noise) / 1.01 x (cross-entropy) the reference's, worst per-parameter ratio
+    1.5 (rounds 1-2, one running fp32 sum over K = 27 Cin: medians 1.65 x, worst ratios 2.7 - 3.9); bf16: worst 1.2 - 1.5, medians 0.90 - 0.93.  Parameters whose true gradient is zero (a bias in front of an
     instance norm) are listed by the float64 run itself and must be ~0."""
     from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
     from mi_seg_amd.utils.detfill import ce_cotangent, det_input
@@ -236,13 +237,13 @@ def test_swin_unetr_c2_vs_truth(golden, dtype, cot):
     src = R if dtype == torch.float32 else T
     e_logits = rel_err(sample(y), T.t("c2_m0/logits64_samples"))
     e_ref = rel_err(R.t("c2_m0/logits_samples") if dtype == torch.float32 else T.t("c2_m0/logitsamp_samples"), T.t("c2_m0/logits64_samples"))
-    assert e_logits <= 3.0 * e_ref, ("logits", e_logits, e_ref)
+    assert e_logits <= (8e-7 if dtype == torch.float32 else 3.0 * e_ref), ("logits", e_logits, e_ref)
     y.backward(ce_cotangent(y) if cot == "ce" else det_input(4321, tuple(y.shape)).to(DEV))
     truth = {k[len("c2_m0/" + k64):]: T.t(k) for k in T.z.files if k.startswith("c2_m0/" + k64)}
     rms = {k: float(g.double().norm()) / g.numel() ** 0.5 for k, g in truth.items()}
     med = sorted(rms.values())[len(rms) // 2]
     named = dict(m.named_parameters())
-    factor, slack, med_factor = (5.0, 1e-5, 2.5) if dtype == torch.float32 else (2.0, 0.0, 1.25)
+    factor, slack, med_factor = (3.0, 1e-5, 1.5) if dtype == torch.float32 else (2.0, 0.0, 1.25)
     worst = (0.0, "")
     all_hip, all_ref = [], []
     for k, t in truth.items():
@@ -322,8 +323,7 @@ def test_unet(golden, tag, dtype):
     c = G.meta["cases"][tag]
     m = UNet(3, 1, 6, channels=c["channels"], strides=c["strides"], num_res_units=c["num_res_units"], act="prelu",
              norm_down=_norm(c.get("norm_down", "instance")), norm_up=_norm("instance"), dropout=0.0, bias=True, adn_ordering="NDA")
-    _whole(G, tag, m, TOL if dtype == torch.float32 else TOL_BF16, dtype, allow_small=True)      # (the one-element PReLU slope gradients are
-    # cancelling sums over ~2 M voxels: 1.8e-2 on one of them in fp32; no float64 fixture exists for this net)
+    _whole(G, tag, m, TOL if dtype == torch.float32 else TOL_BF16, dtype)
 
 
 @pytest.mark.parametrize("tag", ["cond", "layer_bias"])
@@ -356,6 +356,80 @@ def test_unetr_c3(golden, dtype, tol):
     m = UNETR(1, 6, (96, 96, 96), feature_size=16, hidden_size=768, mlp_dim=3072, num_heads=12, pos_embed="perceptron",
               vit_norm_name=_norm("instance_cond"), encoder_norm_name=_norm("instance_cond"), decoder_norm_name=_norm("instance"))
     _whole(G, "c3_m1", m, tol, dtype)
+
+
+SMALL_NET_BAR = dict(fp32=(3.0, 1e-2, 1.5), bf16=(3.0, 6e-2, 1.5))
+"""(factor, slack, median factor) of _vs_truth for the 32^3 / 64^3 nets.  Their gradients jump with every single activation-sign flip
+(LeakyReLU / PReLU on normalised pre-activations): with ~1e6 pre-activations and a forward error of 3e-7 the expected number of flips is
+below one, so the reference's fp32 run happens to sit 8e-7 from its float64 run while ONE flip near the output puts every upstream
+gradient 1e-4 .. 7e-3 away (measured: UNETR 32^3, 205 of 276 parameters at 3.6e-3 .. 6.6e-3 together; UNet 64^3, the six parameters in front of
+the first PReLU at 1.1e-4) - the slack is that jump, the 1e-2 the fp32 fixtures are compared at (`_whole`).  bf16: torch.autocast keeps norm outputs / activations in fp32 and only runs convolutions
+and linears in bf16, this path STORES every activation in bf16 - sums with heavy cancellation (the one-element PReLU slope gradients: a
+sum over ~2 M voxels) carry that storage rounding: 1.05e-1 against autocast's 1.8e-2 at worst.  The full-size nets (C2, C3) need neither."""
+
+
+def _vs_truth(T, R, tag, model, dtype, fp32=(3.0, 1e-5, 1.5), bf16=(2.0, 0.0, 1.25)):
+    """the bar of test_swin_unetr_c2_vs_truth for any net: per parameter no further from the reference's float64 run (fixture T) than the
+    reference's own run at the same precision (fp32: fixture R, autocast-bf16: T) times `factor` (+ slack), medians within `med_factor` (+ slack)"""
+    from mi_seg_amd.utils.detfill import det_input
+    case = T.meta["cases"][tag]
+    m = _fill(model)
+    m.set_compute_dtype(dtype)
+    y = m(det_input(1234, case["x"]).to(DEV), case["modalities"])
+    is32 = dtype == torch.float32
+    e_logits = rel_err(sample(y), T.t(f"{tag}/logits64_samples"))
+    e_ref = rel_err(R.t(f"{tag}/logits_samples") if is32 else T.t(f"{tag}/logitsamp_samples"), T.t(f"{tag}/logits64_samples"))
+    assert e_logits <= 2.0 * e_ref + (1e-6 if is32 else 0.0), ("logits", e_logits, e_ref)
+    y.backward(det_input(4321, tuple(y.shape)).to(DEV))
+    k64 = f"{tag}/grad64:"
+    truth = {k[len(k64):]: T.t(k) for k in T.z.files if k.startswith(k64)}
+    rms = {k: float(g.double().norm()) / g.numel() ** 0.5 for k, g in truth.items()}
+    med = sorted(rms.values())[len(rms) // 2]
+    named = dict(m.named_parameters())
+    factor, slack, med_factor = fp32 if is32 else bf16
+    all_hip, all_ref, worst, bad = [], [], (0.0, ""), []
+    for k, t in truth.items():
+        got = sample(named[k].grad)
+        if rms[k] < 1e-3 * med:                                   # analytically zero gradient
+            assert float(got.double().norm()) / got.numel() ** 0.5 < (1e-4 if is32 else 0.1) * med, (k, "should vanish")
+            continue
+        e_hip = rel_err(got, t)
+        e_r = rel_err(R.t(f"{tag}/grad:{k}") if is32 else T.t(f"{tag}/gradamp:{k}"), t)
+        worst = max(worst, (e_hip / (e_r + 1e-12), k))
+        all_hip.append(e_hip)
+        all_ref.append(e_r)
+        if e_hip > factor * e_r + slack:
+            bad.append((round(e_hip / (e_r + 1e-12), 2), k, f"{e_hip:.2e}", f"{e_r:.2e}"))
+    assert not bad, (f"{len(bad)} of {len(all_hip)} parameters further from the float64 run than {factor} x the reference at this precision", sorted(bad)[-12:])
+    m_hip, m_ref = sorted(all_hip)[len(all_hip) // 2], sorted(all_ref)[len(all_ref) // 2]
+    assert m_hip <= med_factor * m_ref + slack, ("median over parameters", m_hip, m_ref)
+    print(f"{tag} vs truth {dtype}: logits {e_logits:.2e} (reference at this precision {e_ref:.2e}); gradient medians {m_hip:.2e} vs {m_ref:.2e}; worst ratio {worst}")
+    assert sorted(k for k, p in named.items() if p.grad is None) == sorted(R.meta["cases"][tag]["grad_none"])
+
+
+@pytest.mark.parametrize("tag", ["small_32", "c3_m1"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_unetr_vs_truth(golden, tag, dtype):
+    """BASELINE configs[2] (C-UNETR, networks/nets/unetr.py:254-276) and the small UNETR against the reference's float64 run: the per-parameter
+    bar of test_swin_unetr_c2_vs_truth, no pooling of small parameters, no escape for small errors"""
+    from mi_seg_amd.networks.nets.unetr import UNETR
+    T, R = golden("unetr_c3_truth"), golden("unetr_small" if tag == "small_32" else "unetr_c3")
+    kw = dict(feature_size=8, hidden_size=48, mlp_dim=96, num_heads=4) if tag == "small_32" else dict(feature_size=16, hidden_size=768, mlp_dim=3072, num_heads=12)
+    m = UNETR(1, 6, tuple(T.meta["cases"][tag]["x"][2:]), pos_embed="perceptron", vit_norm_name=_norm("instance_cond"), encoder_norm_name=_norm("instance_cond"),
+              decoder_norm_name=_norm("instance"), **kw)
+    _vs_truth(T, R, tag, m, dtype, **(SMALL_NET_BAR if tag == "small_32" else {}))
+
+
+@pytest.mark.parametrize("tag", ["c1_64", "cond_32"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_unet_vs_truth(golden, tag, dtype):
+    """BASELINE configs[0] (the plain UNet, networks/nets/unet.py:351-353) and its conditional variant against the reference's float64 run"""
+    from mi_seg_amd.networks.nets.unet import UNet
+    T, R = golden("unet_truth"), golden("unet")
+    c = R.meta["cases"][tag]
+    m = UNet(3, 1, 6, channels=c["channels"], strides=c["strides"], num_res_units=c["num_res_units"], act="prelu",
+             norm_down=_norm(c.get("norm_down", "instance")), norm_up=_norm("instance"), dropout=0.0, bias=True, adn_ordering="NDA")
+    _vs_truth(T, R, tag, m, dtype, **SMALL_NET_BAR)
 
 
 @pytest.mark.gpu
