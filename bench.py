@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-arena", action="store_true", help="torch-style per-parameter gradient tensors and per-call weight casts")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: all-reduce after the whole backward pass instead of overlapping the encoder half")
+    ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"],
+                    help="N > 1: dtype of the gradient buckets on the wire (bf16 halves the xGMI bytes; the reference's DDP averages fp32: default)")
     ap.add_argument("--host-flags", dest="device_flags", action="store_false",
                     help="N > 1: read the exchanged 'used on any rank' bitmap back to the host every step (what a torch optimiser needs); default: it stays "
                          "on the device for the fused optimiser and the step has no host synchronisation")
@@ -156,7 +158,7 @@ def main():
     arena = None
     if not a.no_arena:
         from mi_seg_amd.runtime.arena import ParamArena
-        arena = ParamArena(params, dtype)
+        arena = ParamArena(params, dtype, grad_dtype=torch.bfloat16 if a.grad_dtype == "bf16" else torch.float32)
     # N > 1: the backward pass is split behind the decoder side (autograd runs it first), whose gradients - 87 % of the bytes - are
     # all-reduced by RCCL while the encoder / Swin half still runs
     overlap = dist is not None and arena is not None and not a.no_overlap and hasattr(model, "late_backward_parameters")
@@ -283,6 +285,26 @@ def main():
         # launches per step that the model's side branch issues throttled (hip/ops.py::_background): conv3_fwd96 at one workgroup per CU,
         # conv3_wgrad on few CUs.  They run beside the main stream's launches in the step; the roofline leg times the kernels alone
         res["side_branch_background_launches_per_step"] = ops.BACKGROUND_LAUNCHES - bg0      # (the split step of N > 1 defers nothing: 2 fewer)
+        # The timed steps have no optimiser step, so the versioned refresh of the weights' compute-dtype copies / conv packs (runtime/arena.py)
+        # found them current and re-laid-out nothing.  Proof that a replay DOES pick up changed weights: scale every parameter a little
+        # (in place), replay, and compare with the eager step on the changed weights - and with the replay before the change
+        if arena is not None:
+            with torch.no_grad():
+                for p in params:
+                    p.mul_(1.0 + 2.0 ** -7)
+            y2 = graphed(pool[k:k + 1], [mods[k]], cot).detach().float().clone()
+            g2 = flat()
+            arena.begin_step()
+            ye2 = model(pool[k:k + 1], [mods[k]])
+            ye2.backward(cot)
+            arena.publish()
+            ge2 = flat()
+            with torch.no_grad():
+                for p in params:
+                    p.div_(1.0 + 2.0 ** -7)
+            res["after_weight_change"] = {"logits_rel_err_vs_eager": rel(y2, ye2.detach().float()), "grad_rel_err_vs_eager": rel(g2, ge2),
+                                          "logits_moved_by": rel(y2, y), "grads_moved_by": rel(g2, g)}
+            graphed(pool[k:k + 1], [mods[k]], cot)      # (and back: the restored weights are re-laid-out by this replay)
         return res
 
     def exchange_check():
@@ -312,10 +334,15 @@ def main():
             raise SystemExit(f"hipGraph replay does not reproduce the eager step: {check}")
         if check["params_without_grad_unexpected"] or check["params_with_zero_grad"]:
             raise SystemExit(f"the timed step left parameters without a gradient: {check}")
+        awc = check.get("after_weight_change")
+        if awc and (awc["logits_rel_err_vs_eager"] > 1e-2 or awc["grad_rel_err_vs_eager"] > 5e-2 or awc["logits_moved_by"] < 1e-4):
+            raise SystemExit(f"a replay after a weight change does not use the changed weights: {check}")
         out["replay_check"] = check
     if dist is not None and arena is not None:
         out["exchange_check"] = exchange_check()
-        out["collective"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "payload_bytes_per_step": int(arena.flat.numel() * 4)}
+        out["collective"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "grad_dtype": a.grad_dtype,
+                             "payload_bytes_per_step": int(arena.flat.numel() * (4 if a.grad_dtype == "f32" else 2)),
+                             "used_flags": "device" if (a.device_flags and overlap) else "host read per step"}
     if rank == 0:
         if not a.no_roofline:
             from mi_seg_amd.testing.roofline import profile_step, summarize

@@ -274,7 +274,15 @@ int miseg_pack_conv3_weight(const miseg_pack_conv3_params* p, miseg_stream_t str
 /* every 3x3x3 weight of a model in ONE launch: `descs` is a DEVICE array of n descriptors sorted by tile0 = number of 16x16
  * (co, ci) tiles before the descriptor; total_tiles = the sum over descriptors of ceil(Cin/16) * ceil(Cout/16). */
 typedef struct { const float* w; void* fwd_pack; void* bwd_pack; int32_t Cin, Cout, tile0, pad_; } miseg_pack_conv3_desc;
-int miseg_pack_conv3_batch(const miseg_pack_conv3_desc* descs_dev, int n, int total_tiles, int dtype, miseg_stream_t stream);
+/* Versioned refresh (ABI 5; also miseg_param_cast_batch): `params_version` is a DEVICE int64 that counts the changes of the fp32 parameters
+ * (miseg_opt_step bumps it through its `params_version` field; after any other change of a parameter the host adds to it with
+ * miseg_counter_add), `state` a DEVICE int64[2] owned by this table of copies: state[0] = the version the copies were last made from,
+ * state[1] = an arrival counter (zero between launches).  With both non-NULL the launch re-lays-out NOTHING when state[0] equals
+ * *params_version (every workgroup reads the two words and exits) and otherwise records the new version when its last workgroup retires -
+ * a replayed hipGraph thus refreshes the copies exactly in the steps that follow an optimiser step, with no host involvement.  NULL, NULL:
+ * unconditional.  Set state[0] = -1 (miseg_fill32) after the table changed. */
+int miseg_pack_conv3_batch(const miseg_pack_conv3_desc* descs_dev, int n, int total_tiles, int dtype, const int64_t* params_version, int64_t* state,
+                           miseg_stream_t stream);
 
 /* weight gradient: dw[Cout][Cin][27] (fp32, torch layout) (+)= sum_v dy[v][co] * x[v + tap][ci] */
 typedef struct {
@@ -355,7 +363,8 @@ typedef struct {
   const float* src; void* dst;
   int32_t R, C, transpose, inner, outer, tile0;
 } miseg_cast_desc;
-int miseg_param_cast_batch(const miseg_cast_desc* descs_dev, int ndesc, int total_tiles, int dtype, miseg_stream_t stream);
+int miseg_param_cast_batch(const miseg_cast_desc* descs_dev, int ndesc, int total_tiles, int dtype, const int64_t* params_version, int64_t* state,
+                           miseg_stream_t stream);      /* params_version / state: see miseg_pack_conv3_batch */
 
 /* GELU (exact, erf): y = gelu(x); backward: dx = dy * gelu'(x)  (MONAI MLPBlock act, swin_transformer_block.py:97) */
 typedef struct { const void* x; int64_t ldx; void* y; int64_t ldy; int64_t rows; int C, dtype; } miseg_gelu_fwd_params;
@@ -515,6 +524,7 @@ typedef struct {
   const int32_t* used; int32_t* steps;
   float lr, beta1, beta2, eps, weight_decay, momentum;
   const float* lr_dev;             /* optional device scalar overriding lr (schedulers under hipGraph replay) */
+  int64_t* params_version;         /* optional DEVICE int64, incremented once per launch: the parameters changed (miseg_pack_conv3_batch) */
 } miseg_opt_step_params;
 int miseg_opt_step(const miseg_opt_step_params* p, miseg_stream_t stream);
 

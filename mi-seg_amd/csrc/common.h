@@ -108,6 +108,23 @@ static inline hipError_t fill_words_2d_async(void* dst, size_t pitch, uint32_t v
     }                                                                                                              \
   } while (0)
 
+// Versioned refresh of parameter copies (miseg_hip.h, miseg_pack_conv3_batch): grid cap of the refresh kernels - a launch that finds its copies
+// current costs the dispatch of this many empty workgroups - and the epilogue every workgroup of a working launch runs: the last one to arrive
+// records the version the copies now hold (all of them read state[0] before their first tile, so nobody can see the new value in this launch).
+static constexpr int REFRESH_MAX_WG = 2048;
+__device__ __forceinline__ void refresh_done(const int64_t* params_version, int64_t* state, int64_t pv) {
+  if (!params_version) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned long long prev = atomicAdd(reinterpret_cast<unsigned long long*>(state + 1), 1ull);
+    if (prev == (unsigned long long)gridDim.x - 1) {
+      state[0] = pv;
+      state[1] = 0;
+    }
+  }
+}
+
 template <class F> static inline int dispatch_dtype(int dtype, F&& f) {
   if (dtype == MISEG_F32) return f((float*)nullptr);
   if (dtype == MISEG_BF16) return f((bf16*)nullptr);

@@ -604,18 +604,25 @@ __global__ void __launch_bounds__(256) pack_conv3_kernel(const float* __restrict
 }
 
 template <class T>
-__global__ void __launch_bounds__(256) pack_conv3_batch_kernel(const miseg_pack_conv3_desc* __restrict__ descs, int n) {
+__global__ void __launch_bounds__(256) pack_conv3_batch_kernel(const miseg_pack_conv3_desc* __restrict__ descs, int n, int total_tiles,
+                                                               const int64_t* __restrict__ params_version, int64_t* __restrict__ state) {
   constexpr int KPC = Vec16<T>::N;
-  int lo = 0, hi = n - 1;
-  while (lo < hi) {   // last descriptor with tile0 <= blockIdx.x
-    const int mid = (lo + hi + 1) >> 1;
-    if (descs[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  const int64_t pv = params_version ? *params_version : 0;
+  if (params_version && state[0] == pv) return;      // versioned refresh (miseg_hip.h): the packs were made from the current parameters
+  for (int tl = blockIdx.x; tl < total_tiles; tl += gridDim.x) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {   // last descriptor with tile0 <= tl
+      const int mid = (lo + hi + 1) >> 1;
+      if (descs[mid].tile0 <= tl) lo = mid; else hi = mid - 1;
+    }
+    const miseg_pack_conv3_desc d = descs[lo];
+    const int t = tl - d.tile0, tci = (d.Cin + PK_T - 1) / PK_T;
+    const int CinP = (d.Cin + KPC - 1) / KPC * KPC, CoutP = (d.Cout + KPC - 1) / KPC * KPC;
+    __syncthreads();      // pack_conv3_tile's LDS tile of the previous iteration has been read
+    pack_conv3_tile<T>(d.w, (T*)d.fwd_pack, (T*)d.bwd_pack, d.Cin, d.Cout, CinP, CoutP, (d.Cin + 15) / 16 * 16, (d.Cout + 15) / 16 * 16,
+                       (CinP * (int)sizeof(T)) % 96 == 0, (CoutP * (int)sizeof(T)) % 96 == 0, t % tci, t / tci);
   }
-  const miseg_pack_conv3_desc d = descs[lo];
-  const int t = blockIdx.x - d.tile0, tci = (d.Cin + PK_T - 1) / PK_T;
-  const int CinP = (d.Cin + KPC - 1) / KPC * KPC, CoutP = (d.Cout + KPC - 1) / KPC * KPC;
-  pack_conv3_tile<T>(d.w, (T*)d.fwd_pack, (T*)d.bwd_pack, d.Cin, d.Cout, CinP, CoutP, (d.Cin + 15) / 16 * 16, (d.Cout + 15) / 16 * 16,
-                     (CinP * (int)sizeof(T)) % 96 == 0, (CoutP * (int)sizeof(T)) % 96 == 0, t % tci, t / tci);
+  refresh_done(params_version, state, pv);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1326,11 +1333,13 @@ extern "C" int miseg_pack_conv3_weight(const miseg_pack_conv3_params* p, miseg_s
   });
 }
 
-extern "C" int miseg_pack_conv3_batch(const miseg_pack_conv3_desc* descs, int n, int total_tiles, int dtype, miseg_stream_t s_) {
+extern "C" int miseg_pack_conv3_batch(const miseg_pack_conv3_desc* descs, int n, int total_tiles, int dtype, const int64_t* params_version, int64_t* state,
+                                      miseg_stream_t s_) {
   MISEG_REQUIRE(descs && n > 0 && total_tiles > 0, MISEG_E_BADARG, "pack_conv3_batch: bad args");
+  MISEG_REQUIRE((params_version == nullptr) == (state == nullptr), MISEG_E_BADARG, "pack_conv3_batch: params_version and state go together");
   return dispatch_dtype(dtype, [&](auto* tag) -> int {
     typedef typename std::remove_pointer<decltype(tag)>::type T;
-    pack_conv3_batch_kernel<T><<<total_tiles, 256, 0, (hipStream_t)s_>>>(descs, n);
+    pack_conv3_batch_kernel<T><<<total_tiles < REFRESH_MAX_WG ? total_tiles : REFRESH_MAX_WG, 256, 0, (hipStream_t)s_>>>(descs, n, total_tiles, params_version, state);
     MISEG_LAUNCH_CHECK("pack_conv3_batch");
     return MISEG_OK;
   });

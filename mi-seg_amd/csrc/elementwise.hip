@@ -1697,41 +1697,52 @@ extern "C" int miseg_ncdhw_to_rows(const float* x, void* y, int B, int Cin, int6
 
 namespace miseg {
 template <class T>
-__global__ void __launch_bounds__(256) param_cast_batch_kernel(const miseg_cast_desc* __restrict__ descs, int ndesc) {
+__global__ void __launch_bounds__(256) param_cast_batch_kernel(const miseg_cast_desc* __restrict__ descs, int ndesc, int total_tiles,
+                                                               const int64_t* __restrict__ params_version, int64_t* __restrict__ state) {
   __shared__ float tile[32][33];
-  // binary search: last descriptor with tile0 <= blockIdx.x
-  int lo = 0, hi = ndesc - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (descs[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-  }
-  const miseg_cast_desc d = descs[lo];
-  const int t = blockIdx.x - d.tile0, tc = (d.C + 31) / 32;
-  const int by = (t / tc) * 32, bx = (t % tc) * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  for (int j = ty; j < 32; j += 8)
-    if (by + j < d.R && bx + tx < d.C) tile[j][tx] = d.src[(int64_t)(by + j) * d.C + bx + tx];
-  __syncthreads();
-  T* dst = (T*)d.dst;
-  if (d.transpose) {
-    for (int j = ty; j < 32; j += 8) {
-      const int c = bx + j;
-      if (c < d.C && by + tx < d.R) dst[(int64_t)((c % d.inner) * d.outer + c / d.inner) * d.R + by + tx] = from_f32<T>(tile[tx][j]);
+  // versioned refresh (miseg_hip.h): nothing to do when the copies were made from the current parameters
+  const int64_t pv = params_version ? *params_version : 0;
+  if (params_version && state[0] == pv) return;
+  for (int tl = blockIdx.x; tl < total_tiles; tl += gridDim.x) {
+    // binary search: last descriptor with tile0 <= tl
+    int lo = 0, hi = ndesc - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (descs[mid].tile0 <= tl) lo = mid; else hi = mid - 1;
     }
-  } else {
-    for (int j = ty; j < 32; j += 8) {
-      const int c = bx + tx;
-      if (by + j < d.R && c < d.C) dst[(int64_t)(by + j) * d.C + (c % d.inner) * d.outer + c / d.inner] = from_f32<T>(tile[j][tx]);
+    const miseg_cast_desc d = descs[lo];
+    const int t = tl - d.tile0, tc = (d.C + 31) / 32;
+    const int by = (t / tc) * 32, bx = (t % tc) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    __syncthreads();                                         // the tile buffer of the previous iteration has been read
+    for (int j = ty; j < 32; j += 8)
+      if (by + j < d.R && bx + tx < d.C) tile[j][tx] = d.src[(int64_t)(by + j) * d.C + bx + tx];
+    __syncthreads();
+    T* dst = (T*)d.dst;
+    if (d.transpose) {
+      for (int j = ty; j < 32; j += 8) {
+        const int c = bx + j;
+        if (c < d.C && by + tx < d.R) dst[(int64_t)((c % d.inner) * d.outer + c / d.inner) * d.R + by + tx] = from_f32<T>(tile[tx][j]);
+      }
+    } else {
+      for (int j = ty; j < 32; j += 8) {
+        const int c = bx + tx;
+        if (by + j < d.R && c < d.C) dst[(int64_t)(by + j) * d.C + (c % d.inner) * d.outer + c / d.inner] = from_f32<T>(tile[j][tx]);
+      }
     }
   }
+  refresh_done(params_version, state, pv);
 }
 }  // namespace miseg
 
-extern "C" int miseg_param_cast_batch(const miseg_cast_desc* descs, int ndesc, int total_tiles, int dtype, miseg_stream_t s_) {
+extern "C" int miseg_param_cast_batch(const miseg_cast_desc* descs, int ndesc, int total_tiles, int dtype, const int64_t* params_version, int64_t* state,
+                                      miseg_stream_t s_) {
   MISEG_REQUIRE(descs && ndesc > 0 && total_tiles > 0, MISEG_E_BADARG, "param_cast_batch: bad arguments");
+  MISEG_REQUIRE((params_version == nullptr) == (state == nullptr), MISEG_E_BADARG, "param_cast_batch: params_version and state go together");
   return dispatch_dtype(dtype, [&](auto* tag) -> int {
     typedef typename std::remove_pointer<decltype(tag)>::type T;
-    miseg::param_cast_batch_kernel<T><<<total_tiles, 256, 0, (hipStream_t)s_>>>(descs, ndesc);
+    miseg::param_cast_batch_kernel<T><<<total_tiles < miseg::REFRESH_MAX_WG ? total_tiles : miseg::REFRESH_MAX_WG, 256, 0, (hipStream_t)s_>>>(descs, ndesc, total_tiles,
+                                                                                                                                         params_version, state);
     MISEG_LAUNCH_CHECK("param_cast_batch");
     return MISEG_OK;
   });

@@ -372,9 +372,10 @@ static __global__ void __launch_bounds__(256) opt_step_kernel(const miseg_opt_de
   }
 }
 
-static __global__ void opt_count_kernel(const int32_t* __restrict__ used, int32_t* __restrict__ steps, int n) {
+static __global__ void opt_count_kernel(const int32_t* __restrict__ used, int32_t* __restrict__ steps, int n, int64_t* __restrict__ params_version) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && (!used || used[i])) steps[i] += 1;
+  if (i == 0 && params_version) *params_version += 1;      // the parameters changed: the versioned refresh kernels re-lay-out their copies
 }
 
 // ------------------------------------------------------------------------------------------------ stitching
@@ -622,7 +623,7 @@ extern "C" int miseg_opt_step(const miseg_opt_step_params* p, miseg_stream_t s_)
   opt_step_kernel<<<p->total_blocks, 256, 0, s>>>(p->descs_dev, p->ndesc, p->kind, p->grad, p->state1, p->kind == MISEG_OPT_SGD_NESTEROV ? nullptr : p->state2, p->used,
                                                  p->steps, p->lr, p->beta1, p->beta2, p->eps, p->weight_decay, p->momentum, p->lr_dev);
   MISEG_LAUNCH_CHECK("opt_step");
-  opt_count_kernel<<<cdiv(p->ndesc, 256), 256, 0, s>>>(p->used, p->steps, p->ndesc);
+  opt_count_kernel<<<cdiv(p->ndesc, 256), 256, 0, s>>>(p->used, p->steps, p->ndesc, p->params_version);
   MISEG_LAUNCH_CHECK("opt_count");
   return MISEG_OK;
 }

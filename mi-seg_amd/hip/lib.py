@@ -116,7 +116,7 @@ DiceMetric = _struct("DiceMetric", cname="miseg_dice_metric_params", fields=[
 OptDesc = _struct("OptDesc", cname="miseg_opt_desc", fields=[("param", vp), ("off", i64), ("n", i32), ("block0", i32)])
 OptStep = _struct("OptStep", cname="miseg_opt_step_params", fields=[
     ("struct_size", u32), ("kind", i32), ("descs_dev", vp), ("ndesc", i32), ("total_blocks", i32), ("grad", vp), ("state1", vp), ("state2", vp),
-    ("used", vp), ("steps", vp), ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("momentum", f32), ("lr_dev", vp)])
+    ("used", vp), ("steps", vp), ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("momentum", f32), ("lr_dev", vp), ("params_version", vp)])
 Stitch = _struct("Stitch", cname="miseg_stitch_params", fields=[
     ("struct_size", u32), ("win", vp), ("out", vp), ("count", vp), ("C", i32), ("D", i32), ("H", i32), ("W", i32), ("rd", i32), ("rh", i32), ("rw", i32),
     ("nd", i32), ("nh", i32), ("nw", i32), ("start_d", vp), ("start_h", vp), ("start_w", vp), ("d_begin", i32), ("d_count", i32)])
@@ -168,7 +168,7 @@ PROTOS = {
     "miseg_conv3_fwd": (i32, [C.POINTER(Conv3), vp]),
     "miseg_pack_conv3_elems": (C.c_size_t, [i32, i32, i32, i32]),
     "miseg_pack_conv3_weight": (i32, [C.POINTER(PackConv3), vp]),
-    "miseg_pack_conv3_batch": (i32, [vp, i32, i32, i32, vp]),
+    "miseg_pack_conv3_batch": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "miseg_conv3_wgrad_workspace_bytes": (C.c_size_t, [i32, i32, i32, i32, i32, i32]),
     "miseg_conv3_wgrad": (i32, [C.POINTER(Conv3Wgrad), vp]),
     "miseg_conv3_wgrad_group_workspace_bytes": (C.c_size_t, [C.POINTER(Conv3Wgrad), i32]),
@@ -193,7 +193,7 @@ PROTOS = {
     "miseg_im2col3": (i32, [C.POINTER(Im2col3), vp]),
     "miseg_col2im3": (i32, [C.POINTER(Im2col3), vp]),
     "miseg_fill32": (i32, [vp, C.c_uint32, C.c_size_t, vp]),
-    "miseg_param_cast_batch": (i32, [vp, C.c_int, C.c_int, C.c_int, vp]),
+    "miseg_param_cast_batch": (i32, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "miseg_resample2": (i32, [C.POINTER(Resample2), vp]),
     "miseg_rowbias_add": (i32, [C.POINTER(Rowbias), vp]),
     "miseg_prelu_fwd": (i32, [C.POINTER(PreluFwd), vp]),

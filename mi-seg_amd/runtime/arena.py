@@ -17,7 +17,11 @@ from ..hip import ops
 
 
 class ParamArena:
-    def __init__(self, params, dtype=torch.bfloat16, n_buckets=4, overlap_wgrad=False):
+    def __init__(self, params, dtype=torch.bfloat16, n_buckets=4, overlap_wgrad=False, grad_dtype=torch.float32):
+        """grad_dtype: the dtype the gradient buckets travel in.  float32 (default) averages the fp32 sums themselves, like the reference's DDP
+        (tune.py:103-109); bfloat16 halves the bytes on xGMI (248.9 -> 124.5 MB per step for C-Swin-UNETR fs=48): every range is rounded into a
+        bf16 staging buffer, averaged there, and written back to the fp32 arena when the exchange is waited for - the local sums stay fp32,
+        the exchanged mean carries one bf16 rounding per rank."""
         self.params = [p for p in params if p.requires_grad]
         assert self.params, "no trainable parameters"
         dev = self.params[0].device
@@ -41,6 +45,13 @@ class ParamArena:
         self._ptable = None
         self._pdirty = False
         self._dirty = False
+        # versioned refresh (include/miseg_hip.h, miseg_pack_conv3_batch): [0] = version of the fp32 parameters (bumped on the device by the
+        # fused optimiser, by invalidate() otherwise), [1..2] / [3..4] = (version held, arrival counter) of the cast copies / the conv packs.
+        # The refresh launches of a step re-lay-out nothing while the parameters have not changed - decided on the DEVICE, so a replayed
+        # hipGraph does the right thing after an optimiser step without the host knowing
+        self.versions = torch.zeros(5, dtype=torch.int64, device=dev)
+        self.versions[1] = -1
+        self.versions[3] = -1
         # all-reduce buckets on slot edges, roughly equal bytes, reduced last-to-first (reverse autograd order)
         ends = offs[1:] + [off]
         self.buckets, start, target = [], 0, off / n_buckets
@@ -48,6 +59,11 @@ class ParamArena:
             if e - start >= target or i == len(ends) - 1:
                 self.buckets.append((start, e))
                 start = e
+        if grad_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("grad_dtype must be torch.float32 or torch.bfloat16")
+        self.grad_dtype = grad_dtype
+        self._stage = None      # bf16 staging copy of the arena (grad_dtype bfloat16)
+        self._staged = []       # ranges whose exchanged values still sit in the staging buffer
         self.used_dev = torch.zeros(len(self.params), dtype=torch.int32, device=dev)
         self._bm = None         # (stream, pinned result, event) of the bitmap exchange on a card
         self.used_on_device = False     # True after an exchange that left the global "used" flags in `used_dev` only (allreduce_end(host_flags=False))
@@ -77,6 +93,8 @@ class ParamArena:
         """once per optimisation step, before the forward: recycles the statistics pool, zeroes the gradient arena and
         refreshes every registered parameter re-layout (safe inside hipGraph capture once the table exists)."""
         ops.begin_step()
+        if not (self.flat.is_cuda and torch.cuda.is_current_stream_capturing()):
+            self.params_changed()
         # the launch-bound tails of this step's backward pass (bias-gradient reductions, small weight-gradient GEMMs, partial-tile sums,
         # the conv weight gradients of the 48^3-and-smaller layers) are queued per arena and issued by end_backward()
         self.queues = ops.QUEUES[self._qkey] = ops.StepQueues()
@@ -98,7 +116,7 @@ class ParamArena:
         if self._table is not None:
             buf, n, tiles = self._table
             lib = L.load()
-            L.check(lib.miseg_param_cast_batch(buf.data_ptr(), n, tiles, L.F32 if self.dtype == torch.float32 else L.BF16, ops._stream()),
+            L.check(lib.miseg_param_cast_batch(buf.data_ptr(), n, tiles, L.F32 if self.dtype == torch.float32 else L.BF16, *self._ver(1), ops._stream()),
                     "param_cast_batch")
             for ent in self._req.values():
                 if ent[3]:
@@ -108,17 +126,45 @@ class ParamArena:
         if self._ptable is not None:
             buf, n, tiles = self._ptable
             lib = L.load()
-            L.check(lib.miseg_pack_conv3_batch(buf.data_ptr(), n, tiles, L.F32 if self.dtype == torch.float32 else L.BF16, ops._stream()),
+            L.check(lib.miseg_pack_conv3_batch(buf.data_ptr(), n, tiles, L.F32 if self.dtype == torch.float32 else L.BF16, *self._ver(3), ops._stream()),
                     "pack_conv3_batch")
             for ent in self._packs.values():
                 if ent[4]:
                     ent[3] = self.epoch
+
+    def _ver(self, slot):
+        """(params_version, state) device pointers of the versioned refresh launches; (None, None) = unconditional (MISEG_REFRESH_ALWAYS=1)"""
+        import os
+        if os.environ.get("MISEG_REFRESH_ALWAYS"):
+            return None, None
+        base = self.versions.data_ptr()
+        return C.c_void_p(base), C.c_void_p(base + 8 * slot)
+
+    def params_version_ptr(self):
+        """device int64 that counts parameter changes: hand it to miseg_opt_step (training/optim.py does)"""
+        return self.versions.data_ptr()
+
+    def params_changed(self):
+        """True when a parameter was modified through torch since the last call (in-place ops bump `Tensor._version`: a torch optimiser's
+        step, load_state_dict, .copy_()); the device-side parameter version is bumped then, so the next refresh launch - eager or inside a
+        replayed hipGraph - re-lays-out the copies.  The fused optimiser writes through raw pointers and bumps the device version itself."""
+        v = 0
+        for p in self.params:
+            v += p._version
+        if v != self.__dict__.get("_pver"):
+            first = "_pver" not in self.__dict__
+            self._pver = v
+            if not first:
+                self.invalidate()
+            return True
+        return False
 
     def refresh_weights(self):
         """inference / validation: bring the compute-dtype copies of the parameters up to date WITHOUT opening a training step (no arena
         fill, no queues).  They stay valid - for any number of forward passes - until `invalidate()`; buffers keep their addresses, so
         hipGraphs captured on them (runtime/graph.py::GraphedForward) stay valid across refreshes.  The first forward after a model was
         built registers its re-layouts lazily (and casts per call); call this again after it."""
+        self.params_changed()
         self.epoch += 1
         self._refresh()
 
@@ -127,6 +173,8 @@ class ParamArena:
         next `begin_step()` / `refresh_weights()`.  training/optim.py::ArenaOptimizer.step calls this; a loop that steps a torch optimiser
         itself must call it too (or simply begin every step with `begin_step()`, as every loop in this repo does)."""
         self.epoch += 1
+        if self.versions.is_cuda:
+            L.check(L.load().miseg_counter_add(C.c_void_p(self.versions.data_ptr()), 1, ops._stream()), "counter_add")
 
     def shadow(self, p, transpose, inner, outer):
         """the re-layout of parameter p refreshed this step, or None (first request: registered for the next step)."""
@@ -171,6 +219,7 @@ class ParamArena:
         raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.flat.device)
         self._ptable = (raw, len(self._packs), tile0)
         self._pdirty = False
+        self.versions[3] = -1          # new packs in the table: the next refresh launch fills all of them
 
     def _build_table(self):
         if torch.cuda.is_current_stream_capturing():
@@ -189,6 +238,7 @@ class ParamArena:
         raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.flat.device)
         self._table = (raw, len(self._req), tile0)
         self._dirty = False
+        self.versions[1] = -1          # new copies in the table: the next refresh launch fills all of them
 
     # ---------------------------------------------------------------------------------------------- after backward
     def end_backward(self):
@@ -226,16 +276,42 @@ class ParamArena:
         avg = self._avg(group)
         if dist.get_world_size(group) > 1:
             for lo, hi in reversed(self.buckets):
-                works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=group, async_op=True))
+                works.append(self._reduce_range(lo, hi, group))
         self.used_on_device = False
         used = ub()
         for w in works:
             w.wait()
+        self._unstage()
         if not avg:
             self.flat.mul_(1.0 / world_size)
         for p, u in zip(self.params, used):
             p._miseg_used = bool(u)
         self.publish()
+
+    def _convert(self, src, dst):
+        """dtype-converting copy of a 16-byte-aligned range (our strided-copy kernel on the card, torch on the CPU of the gloo tests)"""
+        if src.is_cuda:
+            ops.copy2d(src.view(-1, 4), dst.view(-1, 4))
+        else:
+            dst.copy_(src)
+
+    def _reduce_range(self, lo, hi, group):
+        """start the mean (RCCL) / sum (gloo) all-reduce of flat[lo:hi] in `grad_dtype`; returns the work handle"""
+        import torch.distributed as dist
+        op = dist.ReduceOp.AVG if self._avg(group) else dist.ReduceOp.SUM
+        if self.grad_dtype == torch.float32:
+            return dist.all_reduce(self.flat[lo:hi], op=op, group=group, async_op=True)
+        if self._stage is None:
+            self._stage = torch.empty(self._size, dtype=self.grad_dtype, device=self.flat.device)
+        self._convert(self.flat[lo:hi], self._stage[lo:hi])
+        self._staged.append((lo, hi))
+        return dist.all_reduce(self._stage[lo:hi], op=op, group=group, async_op=True)
+
+    def _unstage(self):
+        """after the exchanges have been waited for: the averaged bf16 ranges go back into the fp32 arena"""
+        for lo, hi in self._staged:
+            self._convert(self._stage[lo:hi], self.flat[lo:hi])
+        self._staged = []
 
     # ------------------------------------------------------------------ all-reduce overlapped with the rest of the backward pass
     def tail_offset(self, late_params):
@@ -268,7 +344,7 @@ class ParamArena:
         works, e = [], hi
         while e > lo:
             b = max(lo, e - piece)
-            works.append(dist.all_reduce(self.flat[b:e], op=dist.ReduceOp.AVG if self._avg(group) else dist.ReduceOp.SUM, group=group, async_op=True))
+            works.append(self._reduce_range(b, e, group))
             e = b
         return works
 
@@ -351,6 +427,7 @@ class ParamArena:
         used = ub()
         for w in works:
             w.wait()
+        self._unstage()
         if not self._avg(group):
             self.flat.mul_(1.0 / world_size)
         if used is not None:

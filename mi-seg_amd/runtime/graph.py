@@ -53,8 +53,11 @@ class GraphedForward:
                 return self.model(x, modalities)
         host = _check_styles(self.model, modalities, self.x.shape[0]) if modalities is not None else None
         self.x.copy_(x, non_blocking=True)
-        if host is not None:
+        if host is not None and host != self._styles_host:
             self.styles.copy_(torch.tensor(host, dtype=torch.int32), non_blocking=True)
+            self._styles_host = host
+        if self.arena is not None and self.graphs and self.arena.params_changed():
+            self.arena.refresh_weights()          # the graphs read the arena's copies: bring them up to date (a no-op on the device otherwise)
         key = None if host is None else tuple(sorted(set(host)))
         if key not in self.graphs:
             s = torch.cuda.Stream()
@@ -171,6 +174,8 @@ class GraphedStep:
         if host != self._styles_host:                  # (a pageable host tensor per step was a synchronous staging copy)
             self.styles.copy_(torch.tensor(host, dtype=torch.int32), non_blocking=True)
             self._styles_host = tuple(host)
+        if self.arena is not None:
+            self.arena.params_changed()           # torch-level parameter updates since the last step bump the device-side version the graph reads
         key = tuple(sorted(set(host))) + (len(host),)
         if key not in self.graphs:
             self.graphs[key] = self._capture(host)

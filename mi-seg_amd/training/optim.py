@@ -66,9 +66,11 @@ class ArenaOptimizer:
         p = L.OptStep(C.sizeof(L.OptStep), KINDS[self.kind], self._table.data_ptr(), len(self.arena.params), self._blocks, self.arena.flat.data_ptr(),
                       self.state1.data_ptr(), self.state2.data_ptr() if self.state2 is not None else None, self.used.data_ptr(), self.steps.data_ptr(),
                       self.lr if lr is None else float(lr), self.betas[0], self.betas[1], self.eps, self.weight_decay, self.momentum,
-                      self.lr_dev.data_ptr() if self.lr_dev is not None else None)
+                      self.lr_dev.data_ptr() if self.lr_dev is not None else None, self.arena.params_version_ptr())
         ops._call("miseg_opt_step", p)
-        self.arena.invalidate()       # the compute-dtype copies of the parameters are stale now
+        # the compute-dtype copies of the parameters are stale now: the kernel bumped the arena's device-side parameter version (the refresh
+        # launches of the next step re-lay-out everything); the host-side epoch moves on too, so that eager forwards cast per call until then
+        self.arena.epoch += 1
 
     def state_dict(self):
         return {"kind": self.kind, "state1": self.state1.clone(), "state2": None if self.state2 is None else self.state2.clone(), "steps": self.steps.clone(),

@@ -108,6 +108,29 @@ def _worker(rank, world, port, q):
         arena.allreduce_end(works, world, rest=[(0, tail), hole])
         ok &= torch.allclose(shared.grad, torch.full((5, 3), 1.5 + it)) and torch.allclose(s1.grad, torch.full((4,), 3.0))
         ok &= s0.grad is None and unused.grad is None
+    # the same exchange with the "used on any rank" flags left on the device side (bench.py's default at N > 1: no host read per step) and with
+    # bf16 gradient buckets (bench.py --grad-dtype bf16): the local sums are rounded to bf16 for the wire, the mean returns into the fp32 arena
+    arena16 = ParamArena(params, torch.float32, grad_dtype=torch.bfloat16)
+    for it in range(2):
+        arena16.flat.zero_()
+        for p in params:
+            p._miseg_used = False
+        mine_p = s0 if rank == 0 else s1
+        mine_p._miseg_grad.fill_(2.0 if rank == 0 else 6.0)
+        mine_p._miseg_used = True
+        shared._miseg_used = True                                                  # (a replayed hipGraph knows all its flags before it starts)
+        ub = arena16.used_begin(host=False)
+        works = arena16.allreduce_begin(tail, arena16.flat.numel())
+        shared._miseg_grad.fill_((1.0 + 2.0 ** -10) * (rank + 1))                 # rounds to (rank + 1) in bf16
+        arena16.allreduce_end(works, world, rest=(0, tail), used_work=ub, host_flags=False)
+        ok &= torch.equal(shared.grad, torch.full((5, 3), 1.5))                    # the bf16-rounded values were averaged
+        ok &= arena16.used_on_device and arena16.used_dev.tolist() == [1, 1, 1, 0]  # the GLOBAL flags, for the fused optimiser
+        ok &= (s0.grad is not None) == (rank == 0) and (s1.grad is not None) == (rank == 1)      # p.grad follows the LOCAL flags
+        ok &= torch.allclose(s0._miseg_grad, torch.full((4,), 1.0)) and torch.allclose(s1._miseg_grad, torch.full((4,), 3.0))
+        ok &= unused.grad is None
+    arena16.detach()
+    for p, v in zip(params, arena.views):                                           # back to the fp32 arena for the rest of the test
+        p._miseg_grad, p._miseg_arena, p._miseg_used = v, arena, False
     # gradient accumulation (reference utils/trainer.py:55-68: DDP no_sync() on the micro-batches that do not step): two local micro-batches,
     # ONE collective over their sum; the window after it starts from zero again
     import mi_seg_amd.hip.ops as _ops
