@@ -437,7 +437,11 @@ int miseg_rowbias_add(const miseg_rowbias_params* p, miseg_stream_t stream);
  * backward: dx = dy (x > 0 ? 1 : a), dslope += sum dy x [x <= 0]  (dslope accumulated, may be NULL) */
 typedef struct { const void* x; int64_t ldx; const float* slope; void* y; int64_t ldy; int64_t rows; int C, dtype; } miseg_prelu_fwd_params;
 int miseg_prelu_fwd(const miseg_prelu_fwd_params* p, miseg_stream_t stream);
-typedef struct { const void* dy; int64_t lddy; const void* x; int64_t ldx; const float* slope; void* dx; int64_t lddx; float* dslope; int64_t rows; int C, dtype; } miseg_prelu_bwd_params;
+typedef struct {
+  const void* dy; int64_t lddy; const void* x; int64_t ldx; const float* slope; void* dx; int64_t lddx; float* dslope; int64_t rows; int C, dtype;
+  double* scratch;   /* DEVICE double[2], zero on entry (with dslope): the one-element slope gradient is a cancelling sum over every voxel - workgroup
+                        partials meet here in float64 and the last workgroup adds the total to dslope (fp32 atomics were off by up to 60 %) */
+} miseg_prelu_bwd_params;
 int miseg_prelu_bwd(const miseg_prelu_bwd_params* p, miseg_stream_t stream);
 /* channels-last rows [B][S][C] (ld) in `dtype`  <->  NCDHW fp32 [B][C][S]: dir 0 rows -> NCDHW (network output), dir 1 NCDHW -> rows */
 int miseg_layout_ncdhw(const void* rows_, int64_t ld, float* ncdhw, int B, int C, int64_t S, int dtype, int dir, miseg_stream_t stream);

@@ -1806,7 +1806,8 @@ __global__ void __launch_bounds__(256) prelu_fwd_kernel(const T* __restrict__ x,
 
 template <class T, int VEC>
 __global__ void __launch_bounds__(256) prelu_bwd_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ x, int64_t ldx, const float* __restrict__ slope,
-                                                        T* __restrict__ dx, int64_t lddx, float* __restrict__ dslope, int64_t rows, int cv) {
+                                                        T* __restrict__ dx, int64_t lddx, float* __restrict__ dslope, int64_t rows, int cv,
+                                                        double* __restrict__ scratch) {
   __shared__ float red[4];
   const float a = slope[0];
   const int64_t total = rows * cv;
@@ -1828,7 +1829,18 @@ __global__ void __launch_bounds__(256) prelu_bwd_kernel(const T* __restrict__ dy
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(dslope, (red[0] + red[1]) + (red[2] + red[3]));
+    if (threadIdx.x == 0) {
+      // the slope gradient is ONE number, a sum over every voxel with heavy cancellation: the workgroup partials meet in float64 (fp32 atomics
+      // in arrival order were off by up to 60 % on the 64^3 UNet and not reproducible), the last workgroup to arrive hands the total over.
+      // The add returns its old value and the wave waits for it (s_waitcnt: the add has been performed) before it takes its arrival
+      // ticket - a dependency written in C++ ("cond ? 1 : 1") is folded away and the ticket could overtake the add.
+      const double part = ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]);
+      const double before = atomicAdd(scratch, part);
+      asm volatile("s_waitcnt vmcnt(0)" : : "v"(before) : "memory");
+      unsigned long long* ticket = reinterpret_cast<unsigned long long*>(scratch + 1);
+      const unsigned long long arrived = atomicAdd(ticket, 1ull);
+      if (arrived == (unsigned long long)gridDim.x - 1) atomicAdd(dslope, (float)atomicAdd(scratch, 0.0));
+    }
   }
 }
 
@@ -1897,14 +1909,15 @@ extern "C" int miseg_prelu_fwd(const miseg_prelu_fwd_params* p, miseg_stream_t s
 extern "C" int miseg_prelu_bwd(const miseg_prelu_bwd_params* p, miseg_stream_t s_) {
   hipStream_t s = (hipStream_t)s_;
   MISEG_REQUIRE(p && p->dy && p->x && p->dx && p->slope && p->rows > 0 && p->C > 0, MISEG_E_BADARG, "prelu_bwd: bad args");
+  MISEG_REQUIRE(!p->dslope || p->scratch, MISEG_E_BADARG, "prelu_bwd: dslope needs the zeroed double[2] scratch");
   DT(p, {
     constexpr int N = Vec16<T>::N;
     const bool vec = p->C % N == 0 && p->lddy % N == 0 && p->ldx % N == 0 && p->lddx % N == 0 && al16(p->dy) && al16(p->x) && al16(p->dx);
     int64_t n = vec ? p->rows * (p->C / N) : p->rows * p->C;
     int grid = (int)((n + 255) / 256);
     if (grid > 1024) grid = 1024;       // one atomic per workgroup on the single slope gradient
-    if (vec) miseg::prelu_bwd_kernel<T, N><<<grid, 256, 0, s>>>((const T*)p->dy, p->lddy, (const T*)p->x, p->ldx, p->slope, (T*)p->dx, p->lddx, p->dslope, p->rows, p->C / N);
-    else miseg::prelu_bwd_kernel<T, 1><<<grid, 256, 0, s>>>((const T*)p->dy, p->lddy, (const T*)p->x, p->ldx, p->slope, (T*)p->dx, p->lddx, p->dslope, p->rows, p->C);
+    if (vec) miseg::prelu_bwd_kernel<T, N><<<grid, 256, 0, s>>>((const T*)p->dy, p->lddy, (const T*)p->x, p->ldx, p->slope, (T*)p->dx, p->lddx, p->dslope, p->rows, p->C / N, p->scratch);
+    else miseg::prelu_bwd_kernel<T, 1><<<grid, 256, 0, s>>>((const T*)p->dy, p->lddy, (const T*)p->x, p->ldx, p->slope, (T*)p->dx, p->lddx, p->dslope, p->rows, p->C, p->scratch);
     MISEG_LAUNCH_CHECK("prelu_bwd");
   });
 }

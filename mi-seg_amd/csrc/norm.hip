@@ -3,9 +3,23 @@
 // backward = reduce (dy, y, x reads) + apply (dy, y, x reads, dx [+dres] writes).
 // Thread layout: tx owns one 16-byte channel vector for the whole block (its affine/statistics live in
 // registers), ty walks rows, so every wave-instruction reads contiguous row segments.
+#include <cstdlib>
 #include "common.h"
 
 namespace miseg {
+
+#ifdef MISEG_NORM_STAMPS      // debug build (scripts/debug/norm_stamps.py): where a small norm launch spends its time, seen by thread 0 of workgroup 0
+__device__ unsigned long long g_norm_stamps[16];
+#define NSTAMP(i)                                                                                   \
+  do {                                                                                              \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {                \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                   \
+      g_norm_stamps[i] = __builtin_readcyclecounter();                                              \
+    }                                                                                               \
+  } while (0)
+#else
+#define NSTAMP(i)
+#endif
 
 static constexpr int NORM_THREADS = 256;
 static constexpr int NORM_TX_MAX = 32;   // channel vectors per block (wider rows are tiled over blockIdx.z)
@@ -660,67 +674,166 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_pair_bwd_apply_kernel(c
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Register-resident fused kernels (round 3): tensors of up to NORM_FUSED_MAX_ROWS = 2048 rows per sample (the 12^3, 6^3 and 3^3 stages).
+// One workgroup per (sample, tile of tx_n channel vectors); thread (tx, ty) owns rows ty, ty + ty_n, ... - at most FUSED_MAXR of them - of
+// its channel vector and keeps them IN REGISTERS (packed, 4 registers per 16-byte row): every tensor is read exactly once, all its loads are
+// in flight together and are issued BEFORE the statistics are gathered, the reduction over the rows is a cross-lane step + one LDS round
+// across the four waves, and the second pass (normalise / the input gradient) runs from the registers.  The round-2 kernels walked the rows
+// twice with four loads in flight behind the statistics gather (6.5 - 11 us for 166 KB); the chunked pairs they replace at 12^3 were
+// two launches with an fp64-atomic hand-off between them (8 + 8 us).
+// ---------------------------------------------------------------------------------------------------
+static constexpr int FUSED_MAXR = 8;
+static constexpr int NORM_FUSED_MAX_ROWS_HW = FUSED_MAXR * NORM_THREADS;
+// (debug / A-B switch: MISEG_NORM_FUSED_MAX=<rows> lowers the limit, 0 sends every tensor through the chunked kernels)
+static int norm_fused_max_rows() {
+  static const int v = [] { const char* e = getenv("MISEG_NORM_FUSED_MAX"); const int n = e ? atoi(e) : NORM_FUSED_MAX_ROWS_HW; return n < NORM_FUSED_MAX_ROWS_HW ? n : NORM_FUSED_MAX_ROWS_HW; }();
+  return v;
+}
+#define NORM_FUSED_MAX_ROWS norm_fused_max_rows()
+
+template <class T, int VEC> struct PRow {       // one row's VEC channels of a lane as loaded (packed: VEC * sizeof(T) bytes, one load)
+  typedef T raw_t __attribute__((ext_vector_type(VEC)));
+  raw_t raw;
+  __device__ __forceinline__ void load(const T* p) { raw = *reinterpret_cast<const raw_t*>(p); }
+  __device__ __forceinline__ void store(T* p) const { *reinterpret_cast<raw_t*>(p) = raw; }
+  __device__ __forceinline__ float get(int i) const { return to_f32(raw[i]); }
+  __device__ __forceinline__ void set(int i, float v) { raw[i] = from_f32<T>(v); }
+};
+template <class T> struct PRow<T, 1> {
+  T raw;
+  __device__ __forceinline__ void load(const T* p) { raw = p[0]; }
+  __device__ __forceinline__ void store(T* p) const { p[0] = raw; }
+  __device__ __forceinline__ float get(int) const { return to_f32(raw); }
+  __device__ __forceinline__ void set(int, float v) { raw = from_f32<T>(v); }
+};
+
+// totals over the ty rows of the workgroup of NVV per-thread floats.  thread = ty * tx_n + tx with tx_n a power of two <= 16, so the lanes of
+// a 16-lane DPP row that share tx are those congruent modulo tx_n: rotations of the row by 8, 4, .. tx_n (plain VALU instructions with a DPP
+// operand - the xor shuffles of the first version went through the LDS crossbar, 1.3 - 2.1 us of a 10 us launch) leave every lane with
+// its class's row total; the 16 rows of the workgroup then meet in LDS.  tot[k * tx_n + tx] (double) is valid for every thread afterwards.
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int NVV>
+__device__ __forceinline__ void fused_totals(float (&v)[NVV], float* red, double* tot, int tx_n) {
+  const int lane = threadIdx.x & 63, row = threadIdx.x >> 4;
+  if (tx_n <= 8) {
+#pragma unroll
+    for (int k = 0; k < NVV; ++k) v[k] = dpp_add<0x128>(v[k]);      // row_ror:8
+  }
+  if (tx_n <= 4) {
+#pragma unroll
+    for (int k = 0; k < NVV; ++k) v[k] = dpp_add<0x124>(v[k]);      // row_ror:4
+  }
+  if (tx_n <= 2) {
+#pragma unroll
+    for (int k = 0; k < NVV; ++k) v[k] = dpp_add<0x122>(v[k]);      // row_ror:2
+  }
+  if (tx_n <= 1) {
+#pragma unroll
+    for (int k = 0; k < NVV; ++k) v[k] = dpp_add<0x121>(v[k]);      // row_ror:1
+  }
+  if ((lane & 15) < tx_n) {
+#pragma unroll
+    for (int k = 0; k < NVV; ++k) red[(row * NVV + k) * tx_n + (lane & 15)] = v[k];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < NVV * tx_n; e += NORM_THREADS) {
+    double acc = 0.0;
+#pragma unroll
+    for (int w = 0; w < NORM_THREADS / 16; ++w) acc += (double)red[w * NVV * tx_n + e];
+    tot[e] = acc;
+  }
+  __syncthreads();
+}
+
 template <class T, int VEC>
 __global__ void __launch_bounds__(NORM_THREADS) instnorm_fused_fwd_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ res, int64_t ldres,
                                                                           T* __restrict__ y, int64_t ldy, int S, int C, int cv, int tx_n, int ty_n,
                                                                           double* __restrict__ stat, float eps, const int32_t* __restrict__ styles, StylePtrs sp,
                                                                           int act, float slope) {
   extern __shared__ __attribute__((aligned(16))) float red[];
-  double* tot = reinterpret_cast<double*>(red + ty_n * 2 * tx_n * VEC);
+  double* tot = reinterpret_cast<double*>(red + (NORM_THREADS / 16) * 2 * VEC * tx_n);
   const int b = blockIdx.y;
   const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
   const int c = blockIdx.x * tx_n + tx;
-  const bool live = ty < ty_n && c < cv;
+  const bool live = c < cv;
   const int64_t boff = (int64_t)b * S;
-  float s[VEC], q[VEC];
+  // (style id and affine rows are requested first: they are in flight with the rows)
+  const int st = styles ? styles[b] : 0;
+  float gam[VEC], bet[VEC];
+  {
+    const float* g = sp.gamma[st];
+    const float* be = sp.beta[st];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) s[i] = q[i] = 0.f;
-  if (live) {
-#pragma unroll 4
-    for (int r = ty; r < S; r += ty_n) {
-      RowVec<T, VEC> v;
-      v.load(x + (boff + r) * ldx + c * VEC);
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) { s[i] += v.v[i]; q[i] = fmaf(v.v[i], v.v[i], q[i]); }
+    for (int i = 0; i < VEC; ++i) {
+      const int ch = min(c * VEC + i, C - 1);
+      gam[i] = g ? g[ch] : 1.f;
+      bet[i] = be ? be[ch] : 0.f;
     }
   }
-  team_totals<VEC>(red, tot, s, q, tx, ty, tx_n, ty_n);
-  // replica 0 of the statistics buffer (the others stay zero): the backward reads it like any other
-  for (int e = threadIdx.x; e < 2 * tx_n * VEC; e += NORM_THREADS) {
-    const int ch = blockIdx.x * tx_n * VEC + (e >> 1);
-    if (ch < C) stat[((int64_t)b * C + ch) * 2 + (e & 1)] = tot[e];
+  PRow<T, VEC> xr[FUSED_MAXR], rr[FUSED_MAXR];
+#pragma unroll
+  for (int u = 0; u < FUSED_MAXR; ++u) {
+    const int r = ty + u * ty_n;
+    if (live && r < S) xr[u].load(x + (boff + r) * ldx + c * VEC);
+  }
+  if (res) {
+#pragma unroll
+    for (int u = 0; u < FUSED_MAXR; ++u) {
+      const int r = ty + u * ty_n;
+      if (live && r < S) rr[u].load(res + (boff + r) * ldres + c * VEC);
+    }
+  }
+  float sq[2 * VEC];
+#pragma unroll
+  for (int i = 0; i < 2 * VEC; ++i) sq[i] = 0.f;
+#pragma unroll
+  for (int u = 0; u < FUSED_MAXR; ++u) {
+    if (live && ty + u * ty_n < S) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { const float v = xr[u].get(i); sq[i] += v; sq[VEC + i] = fmaf(v, v, sq[VEC + i]); }
+    }
+  }
+  fused_totals<2 * VEC>(sq, red, tot, tx_n);      // tot[(which * VEC + i) * tx_n + tx]
+  // replica 0 of the statistics buffer (the others stay zero): the backward pass reads it like any other
+  for (int e = threadIdx.x; e < 2 * VEC * tx_n; e += NORM_THREADS) {
+    const int k = e / tx_n, t = e - k * tx_n, which = k / VEC, i = k - which * VEC;
+    const int ch = (blockIdx.x * tx_n + t) * VEC + i;
+    if (ch < C) stat[((int64_t)b * C + ch) * 2 + which] = tot[e];
   }
   if (!live) return;
-  const int st = styles ? styles[b] : 0;
-  const float* g = sp.gamma[st];
-  const float* be = sp.beta[st];
   const double invS = 1.0 / S;
   float sc[VEC], sh[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
-    const int ch = c * VEC + i;
+    const double two[2] = {tot[i * tx_n + tx], tot[(VEC + i) * tx_n + tx]};
     float m, rs;
-    mean_rstd(tot + (tx * VEC + i) * 2, invS, eps, m, rs);
-    sc[i] = rs * (g ? g[ch] : 1.f);
-    sh[i] = (be ? be[ch] : 0.f) - m * sc[i];
+    mean_rstd(two, invS, eps, m, rs);
+    sc[i] = rs * gam[i];
+    sh[i] = bet[i] - m * sc[i];
   }
-#pragma unroll 4
-  for (int r = ty; r < S; r += ty_n) {
-    RowVec<T, VEC> v, o;
-    v.load(x + (boff + r) * ldx + c * VEC);
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) o.v[i] = fmaf(v.v[i], sc[i], sh[i]);
-    if (res) {
-      RowVec<T, VEC> rr;
-      rr.load(res + (boff + r) * ldres + c * VEC);
+  for (int u = 0; u < FUSED_MAXR; ++u) {
+    const int r = ty + u * ty_n;
+    if (r < S) {
+      float v[VEC];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) o.v[i] += rr.v[i];
+      for (int i = 0; i < VEC; ++i) v[i] = fmaf(xr[u].get(i), sc[i], sh[i]);
+      if (res) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] += rr[u].get(i);
+      }
+      if (act == MISEG_ACT_LEAKY) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * slope;
+      }
+      PRow<T, VEC> o;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o.set(i, v[i]);
+      o.store(y + (boff + r) * ldy + c * VEC);
     }
-    if (act == MISEG_ACT_LEAKY) {
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) o.v[i] = o.v[i] > 0.f ? o.v[i] : o.v[i] * slope;
-    }
-    o.store(y + (boff + r) * ldy + c * VEC);
   }
 }
 
@@ -732,99 +845,285 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_fused_bwd_kernel(const 
                                                                           StylePtrs sp, StyleGradPtrs gp, int act, float slope, const T* __restrict__ gadd,
                                                                           int64_t ldgadd) {
   extern __shared__ __attribute__((aligned(16))) float red[];
-  double* tot = reinterpret_cast<double*>(red + ty_n * 2 * tx_n * VEC);   // dstat totals
-  double* sums = tot + 2 * tx_n * VEC;                                   // forward statistics
+  double* tot = reinterpret_cast<double*>(red + (NORM_THREADS / 16) * 2 * VEC * tx_n);   // totals of (g, g * xhat)
+  double* sums = tot + 2 * VEC * tx_n;                                                  // forward statistics [col][2]
   const int b = blockIdx.y;
   const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
   const int c = blockIdx.x * tx_n + tx;
-  const bool live = ty < ty_n && c < cv;
+  const bool live = c < cv;
   const int64_t boff = (int64_t)b * S;
-  gather_stat(sums, stat, (int64_t)gridDim.y * C * 2, b, C, blockIdx.x * tx_n * VEC, tx_n * VEC);
-  const double invS = 1.0 / S;
-  float s[VEC], q[VEC], m[VEC], rs[VEC];
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) { s[i] = q[i] = 0.f; mean_rstd(sums + (tx * VEC + i) * 2, invS, eps, m[i], rs[i]); }
-  float zsc[VEC], zsh[VEC];     // the forward's scale / shift: only to recompute the activation's sign when y was not kept
+  const bool masked = act == MISEG_ACT_LEAKY;
+  NSTAMP(0);
+  // style id, affine rows and all row loads first: nothing below depends on them until the statistics have arrived as well
+  const int st = styles ? styles[b] : 0;
+  float gam[VEC], bet[VEC];
   {
-    const int stz = styles ? styles[b] : 0;
-    const float* gz = sp.gamma[stz];
-    const float* bz = sp.beta[stz];
+    const float* gz = sp.gamma[st];
+    const float* bz = sp.beta[st];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      const int ch = c * VEC + i;
-      zsc[i] = rs[i] * ((gz && c < cv) ? gz[ch] : 1.f);
-      zsh[i] = ((bz && c < cv) ? bz[ch] : 0.f) - m[i] * zsc[i];
+      const int ch = min(c * VEC + i, C - 1);
+      gam[i] = gz ? gz[ch] : 1.f;
+      bet[i] = (bz && masked && !yact) ? bz[ch] : 0.f;
     }
   }
-  if (live) {
-#pragma unroll 4
-    for (int r = ty; r < S; r += ty_n) {
-      RowVec<T, VEC> g, xv;
-      g.load(dy + (boff + r) * lddy + c * VEC);
-      xv.load(x + (boff + r) * ldx + c * VEC);
-      if (act == MISEG_ACT_LEAKY) {
-        if (yact) {
-          RowVec<T, VEC> yv;
-          yv.load(yact + (boff + r) * ldy + c * VEC);
+  PRow<T, VEC> gr[FUSED_MAXR], xr[FUSED_MAXR], yr[FUSED_MAXR];
+  const bool from_y = masked && yact;      // a residual entered the activation: its sign comes from the stored output
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) g.v[i] = yv.v[i] > 0.f ? g.v[i] : g.v[i] * slope;
-        } else {   // no residual went into the activation: its sign is the sign of the forward's fma(x, sc, sh), recomputed from x
+  for (int u = 0; u < FUSED_MAXR; ++u) {
+    const int r = ty + u * ty_n;
+    if (live && r < S) {
+      gr[u].load(dy + (boff + r) * lddy + c * VEC);
+      xr[u].load(x + (boff + r) * ldx + c * VEC);
+      if (from_y) yr[u].load(yact + (boff + r) * ldy + c * VEC);
+    }
+  }
+  NSTAMP(1);
+  gather_stat(sums, stat, (int64_t)gridDim.y * C * 2, b, C, blockIdx.x * tx_n * VEC, tx_n * VEC);
+  NSTAMP(2);
+  const double invS = 1.0 / S;
+  float m[VEC], rs[VEC], sc[VEC], zsh[VEC];
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) g.v[i] = fmaf(xv.v[i], zsc[i], zsh[i]) > 0.f ? g.v[i] : g.v[i] * slope;
-        }
+  for (int i = 0; i < VEC; ++i) {
+    mean_rstd(sums + (tx * VEC + i) * 2, invS, eps, m[i], rs[i]);
+    sc[i] = rs[i] * gam[i];
+    zsh[i] = bet[i] - m[i] * sc[i];      // the forward's shift: without a residual the activation's sign is the sign of fma(x, sc, zsh)
+  }
+  // the activation-masked gradient of row u; evaluated in both passes (three instructions per element) rather than stored.  The mode
+  // tests are per ROW: inside the element loop they were a scalar branch per element - 40 instructions per element, 3.8 us for 7 rows
+  auto gmask = [&](int u, float (&gm)[VEC]) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) gm[i] = gr[u].get(i);
+    if (from_y) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) gm[i] = yr[u].get(i) > 0.f ? gm[i] : gm[i] * slope;
+    } else if (masked) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) gm[i] = fmaf(xr[u].get(i), sc[i], zsh[i]) > 0.f ? gm[i] : gm[i] * slope;
+    }
+  };
+  float sq[2 * VEC];
+#pragma unroll
+  for (int i = 0; i < 2 * VEC; ++i) sq[i] = 0.f;
+#pragma unroll
+  for (int u = 0; u < FUSED_MAXR; ++u) {
+    if (live && ty + u * ty_n < S) {
+      float gm[VEC];
+      gmask(u, gm);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        sq[i] += gm[i];
+        sq[VEC + i] = fmaf(gm[i], (xr[u].get(i) - m[i]) * rs[i], sq[VEC + i]);
+      }
+    }
+  }
+  NSTAMP(3);
+  fused_totals<2 * VEC>(sq, red, tot, tx_n);
+  NSTAMP(4);
+  for (int e = threadIdx.x; e < VEC * tx_n; e += NORM_THREADS) {      // the affine gradients of this (sample, channel tile)
+    const int i = e / tx_n, t = e - i * tx_n;
+    const int ch = (blockIdx.x * tx_n + t) * VEC + i;
+    if (ch < C) {
+      if (gp.dgamma[st]) atomicAdd(gp.dgamma[st] + ch, (float)tot[(VEC + i) * tx_n + t]);
+      if (gp.dbeta[st]) atomicAdd(gp.dbeta[st] + ch, (float)tot[i * tx_n + t]);
+    }
+  }
+  NSTAMP(5);
+  if (!live) return;
+  float a[VEC], bq[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    a[i] = (float)(tot[i * tx_n + tx] * invS);
+    bq[i] = (float)(tot[(VEC + i) * tx_n + tx] * invS);
+  }
+#pragma unroll
+  for (int u = 0; u < FUSED_MAXR; ++u) {
+    const int r = ty + u * ty_n;
+    if (r < S) {
+      float gm[VEC], v[VEC];
+      gmask(u, gm);
+      if (dres) {
+        PRow<T, VEC> dr;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) dr.set(i, gm[i]);
+        dr.store(dres + (boff + r) * lddres + c * VEC);
       }
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) { s[i] += g.v[i]; q[i] = fmaf(g.v[i], (xv.v[i] - m[i]) * rs[i], q[i]); }
+      for (int i = 0; i < VEC; ++i) v[i] = sc[i] * (gm[i] - a[i] - (xr[u].get(i) - m[i]) * rs[i] * bq[i]);
+      if (gadd) {
+        PRow<T, VEC> ga;
+        ga.load(gadd + (boff + r) * ldgadd + c * VEC);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] += ga.get(i);
+      }
+      PRow<T, VEC> o;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o.set(i, v[i]);
+      o.store(dx + (boff + r) * lddx + c * VEC);
     }
   }
-  team_totals<VEC>(red, tot, s, q, tx, ty, tx_n, ty_n);
+  NSTAMP(6);
+}
+
+// backward of y = LeakyReLU(norm_a(xa) + norm_b(xb)) in ONE launch (see instnorm_pair_bwd_{reduce,apply}_kernel for the arithmetic):
+// dy, xa, xb stay in registers, the three sums (g, g * xhat_a, g * xhat_b) meet inside the workgroup.
+template <class T, int VEC>
+__global__ void __launch_bounds__(NORM_THREADS) instnorm_pair_fused_bwd_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ yact, int64_t ldy,
+                                                                               const T* __restrict__ xa, int64_t ldxa, const T* __restrict__ xb, int64_t ldxb,
+                                                                               T* __restrict__ dxa, int64_t lddxa, T* __restrict__ dxb, int64_t lddxb, int S, int C,
+                                                                               int cv, int tx_n, int ty_n, const double* __restrict__ stat_a,
+                                                                               const double* __restrict__ stat_b, float eps, const int32_t* __restrict__ styles,
+                                                                               StylePtrs spa, StylePtrs spb, float slope, StyleGradPtrs gpa, StyleGradPtrs gpb) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  double* tot = reinterpret_cast<double*>(red + (NORM_THREADS / 16) * 3 * VEC * tx_n);   // totals of (g, g * xhat_a, g * xhat_b)
+  double* sums_a = tot + 3 * VEC * tx_n;
+  double* sums_b = sums_a + 2 * VEC * tx_n;
+  const int b = blockIdx.y;
+  const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
+  const int c = blockIdx.x * tx_n + tx;
+  const bool live = c < cv;
+  const int64_t boff = (int64_t)b * S;
+  // style id + affine rows first (in flight with the rows)
   const int st = styles ? styles[b] : 0;
-  for (int e = threadIdx.x; e < tx_n * VEC; e += NORM_THREADS) {
-    const int ch = blockIdx.x * tx_n * VEC + e;
+  float gma[VEC], bta[VEC], gmb[VEC], btb[VEC];
+  {
+    const float* ga = spa.gamma[st];
+    const float* ba = spa.beta[st];
+    const float* gb = spb.gamma[st];
+    const float* bb = spb.beta[st];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const int ch = min(c * VEC + i, C - 1);
+      gma[i] = ga ? ga[ch] : 1.f;
+      bta[i] = ba ? ba[ch] : 0.f;
+      gmb[i] = gb ? gb[ch] : 1.f;
+      btb[i] = bb ? bb[ch] : 0.f;
+    }
+  }
+  PRow<T, VEC> gr[FUSED_MAXR], ar[FUSED_MAXR], br[FUSED_MAXR], yr[FUSED_MAXR];
+#pragma unroll
+  for (int u = 0; u < FUSED_MAXR; ++u) {
+    const int r = ty + u * ty_n;
+    if (live && r < S) {
+      gr[u].load(dy + (boff + r) * lddy + c * VEC);
+      ar[u].load(xa + (boff + r) * ldxa + c * VEC);
+      br[u].load(xb + (boff + r) * ldxb + c * VEC);
+      if (yact) yr[u].load(yact + (boff + r) * ldy + c * VEC);
+    }
+  }
+  gather_stat(sums_a, stat_a, (int64_t)gridDim.y * C * 2, b, C, blockIdx.x * tx_n * VEC, tx_n * VEC);
+  gather_stat(sums_b, stat_b, (int64_t)gridDim.y * C * 2, b, C, blockIdx.x * tx_n * VEC, tx_n * VEC);
+  const double invS = 1.0 / S;
+  float ma[VEC], rsa[VEC], mb[VEC], rsb[VEC], sca[VEC], scb[VEC], zha[VEC], zhb[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    mean_rstd(sums_a + (tx * VEC + i) * 2, invS, eps, ma[i], rsa[i]);
+    mean_rstd(sums_b + (tx * VEC + i) * 2, invS, eps, mb[i], rsb[i]);
+    sca[i] = rsa[i] * gma[i];      // the expressions of pair_preact_coeffs (instnorm_apply_kernel's scale / shift): the recomputed sign
+    zha[i] = bta[i] - ma[i] * sca[i];      // must be the sign the forward pass saw
+    scb[i] = rsb[i] * gmb[i];
+    zhb[i] = btb[i] - mb[i] * scb[i];
+  }
+  auto gmask = [&](int u, float (&gm)[VEC]) {      // (mode test per row, not per element: see instnorm_fused_bwd_kernel)
+    if (yact) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { const float g = gr[u].get(i); gm[i] = yr[u].get(i) > 0.f ? g : g * slope; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float g = gr[u].get(i);
+        gm[i] = pair_preact(ar[u].get(i), sca[i], zha[i], br[u].get(i), scb[i], zhb[i]) > 0.f ? g : g * slope;
+      }
+    }
+  };
+  float sq[3 * VEC];
+#pragma unroll
+  for (int i = 0; i < 3 * VEC; ++i) sq[i] = 0.f;
+#pragma unroll
+  for (int u = 0; u < FUSED_MAXR; ++u) {
+    if (live && ty + u * ty_n < S) {
+      float gm[VEC];
+      gmask(u, gm);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        sq[i] += gm[i];
+        sq[VEC + i] = fmaf(gm[i], (ar[u].get(i) - ma[i]) * rsa[i], sq[VEC + i]);
+        sq[2 * VEC + i] = fmaf(gm[i], (br[u].get(i) - mb[i]) * rsb[i], sq[2 * VEC + i]);
+      }
+    }
+  }
+  fused_totals<3 * VEC>(sq, red, tot, tx_n);
+  for (int e = threadIdx.x; e < VEC * tx_n; e += NORM_THREADS) {
+    const int i = e / tx_n, t = e - i * tx_n;
+    const int ch = (blockIdx.x * tx_n + t) * VEC + i;
     if (ch < C) {
-      if (gp.dgamma[st]) atomicAdd(gp.dgamma[st] + ch, (float)tot[2 * e + 1]);
-      if (gp.dbeta[st]) atomicAdd(gp.dbeta[st] + ch, (float)tot[2 * e]);
+      if (gpa.dgamma[st]) atomicAdd(gpa.dgamma[st] + ch, (float)tot[(VEC + i) * tx_n + t]);
+      if (gpa.dbeta[st]) atomicAdd(gpa.dbeta[st] + ch, (float)tot[i * tx_n + t]);
+      if (gpb.dgamma[st]) atomicAdd(gpb.dgamma[st] + ch, (float)tot[(2 * VEC + i) * tx_n + t]);
+      if (gpb.dbeta[st]) atomicAdd(gpb.dbeta[st] + ch, (float)tot[i * tx_n + t]);
     }
   }
   if (!live) return;
-  const float* g = sp.gamma[st];
-  float sc[VEC], a[VEC], bq[VEC];
+  float aa[VEC], bqa[VEC], bqb[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
-    sc[i] = rs[i] * (g ? g[c * VEC + i] : 1.f);
-    a[i] = (float)(tot[(tx * VEC + i) * 2] * invS);
-    bq[i] = (float)(tot[(tx * VEC + i) * 2 + 1] * invS);
+    aa[i] = (float)(tot[i * tx_n + tx] * invS);
+    bqa[i] = (float)(tot[(VEC + i) * tx_n + tx] * invS);
+    bqb[i] = (float)(tot[(2 * VEC + i) * tx_n + tx] * invS);
   }
-#pragma unroll 4
-  for (int r = ty; r < S; r += ty_n) {
-    RowVec<T, VEC> gv, xv, o;
-    gv.load(dy + (boff + r) * lddy + c * VEC);
-    xv.load(x + (boff + r) * ldx + c * VEC);
-    if (act == MISEG_ACT_LEAKY) {
-      if (yact) {
-        RowVec<T, VEC> yv;
-        yv.load(yact + (boff + r) * ldy + c * VEC);
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) gv.v[i] = yv.v[i] > 0.f ? gv.v[i] : gv.v[i] * slope;
-      } else {
+  for (int u = 0; u < FUSED_MAXR; ++u) {
+    const int r = ty + u * ty_n;
+    if (r < S) {
+      PRow<T, VEC> oa, ob;
+      float gm[VEC];
+      gmask(u, gm);
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) gv.v[i] = fmaf(xv.v[i], zsc[i], zsh[i]) > 0.f ? gv.v[i] : gv.v[i] * slope;
+      for (int i = 0; i < VEC; ++i) {
+        oa.set(i, sca[i] * (gm[i] - aa[i] - (ar[u].get(i) - ma[i]) * rsa[i] * bqa[i]));
+        ob.set(i, scb[i] * (gm[i] - aa[i] - (br[u].get(i) - mb[i]) * rsb[i] * bqb[i]));
       }
+      oa.store(dxa + (boff + r) * lddxa + c * VEC);
+      ob.store(dxb + (boff + r) * lddxb + c * VEC);
     }
-    if (dres) gv.store(dres + (boff + r) * lddres + c * VEC);
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      const float xh = (xv.v[i] - m[i]) * rs[i];
-      o.v[i] = sc[i] * (gv.v[i] - a[i] - xh * bq[i]);
-    }
-    if (gadd) {
-      RowVec<T, VEC> ga;
-      ga.load(gadd + (boff + r) * ldgadd + c * VEC);
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) o.v[i] += ga.v[i];
-    }
-    o.store(dx + (boff + r) * lddx + c * VEC);
   }
+}
+
+// thread geometry of the register-resident kernels: ty_n = the power of two >= S, between 16 and 256 - as FEW rows per lane as the tensor
+// allows, i.e. as many workgroups as it has channel vectors: these launches are bound by the instructions one wave issues (in-kernel stamps:
+// 8 rows x 8 channels per lane cost 3.2 us of arithmetic alone), not by bytes - and tx_n = 256 / ty_n <= 16 channel vectors
+struct FusedGeom { int vec, cv, tx, ty; };
+static FusedGeom fused_geom(int S, int C, bool vec_ok, int vecN) {
+  FusedGeom g;
+  int ty = 16;
+  while (ty < S && ty < NORM_THREADS) ty <<= 1;
+  g.ty = ty;
+  g.tx = NORM_THREADS / ty;
+  const int rows_per_lane = cdiv(S, ty);
+  // channels per lane: 16 bytes where a lane has few rows; narrower (8- / 4-byte loads) where it has many, so that a lane handles <= 16
+  // elements and the tensor spreads over 2 - 4 x the workgroups - at 1728 rows x 192 channels the 16-byte form was 24 workgroups of 56
+  // elements per lane: 17 us of issue-bound arithmetic (one wave per SIMD) for 0.66 MB
+  int vec = 1;
+  if (vec_ok) {
+    vec = vecN;
+    while (vec > 1 && C % vec != 0) vec >>= 1;
+    while (vec > 2 && rows_per_lane * vec > 16) vec >>= 1;
+  }
+  g.vec = vec;
+  g.cv = C / g.vec;
+  return g;
+}
+// launch `KERNEL<T, vec>` for the lane width the geometry chose (bf16: 8 / 4 / 2 / 1 channels, fp32: 4 / 2 / 1)
+#define FUSED_DISPATCH(GEOM, LAUNCH)                          \
+  do {                                                        \
+    if ((GEOM).vec == 8) { if constexpr (V >= 8) { LAUNCH(8); } } \
+    else if ((GEOM).vec == 4) { if constexpr (V >= 4) { LAUNCH(4); } } \
+    else if ((GEOM).vec == 2) { LAUNCH(2); }                  \
+    else { LAUNCH(1); }                                       \
+  } while (0)
+static size_t fused_smem(const FusedGeom& g, int nsum, int nstat) {      // red + tot + gathered statistics
+  return (size_t)(NORM_THREADS / 16) * nsum * g.vec * g.tx * sizeof(float) + (size_t)nsum * g.vec * g.tx * sizeof(double) +
+         (size_t)nstat * 2 * g.vec * g.tx * sizeof(double);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -941,6 +1240,10 @@ int slabs_to_out_stats(const float* slabs, int nslabs, void* y, int64_t ldy, con
 }
 }  // namespace miseg
 
+#ifdef MISEG_NORM_STAMPS
+extern "C" int miseg_debug_norm_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(miseg::g_norm_stamps), sizeof(miseg::g_norm_stamps)); }
+#endif
+
 extern "C" size_t miseg_instnorm_stat_bytes(int B, int C) { return (size_t)NORM_R * B * C * 2 * sizeof(double); }
 
 extern "C" int miseg_instnorm_stats(const miseg_instnorm_stats_params* p, miseg_stream_t stream_) {
@@ -996,8 +1299,6 @@ extern "C" int miseg_instnorm_apply(const miseg_instnorm_apply_params* p, miseg_
   });
 }
 
-static constexpr int NORM_FUSED_MAX_ROWS = 512;    // 1728 rows x 384 channels: 12 workgroups walking 110 KB twice lose to the chunked pair
-
 // statistics + normalisation: the two kernels above, or one fused launch for the small tensors of the deep stages
 extern "C" int miseg_instnorm_fwd(const miseg_instnorm_apply_params* p, miseg_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -1014,19 +1315,17 @@ extern "C" int miseg_instnorm_fwd(const miseg_instnorm_apply_params* p, miseg_st
     typedef typename std::remove_pointer<decltype(tag)>::type T;
     constexpr int V = Vec16<T>::N;
     const int64_t ldor = p->ldx | p->ldy | (p->res ? p->ldres : 0);
-    const bool al = aligned16(p->x) && aligned16(p->y) && (!p->res || aligned16(p->res)) && ldor % V == 0 && p->C % V == 0;
-    const int vec = al ? V : 1, cv = p->C / vec;
-    const int tx = cv < 4 ? cv : 4, ty = NORM_THREADS / tx;
+    const bool al = aligned16(p->x) && aligned16(p->y) && (!p->res || aligned16(p->res)) && ldor % V == 0;
+    const FusedGeom g = fused_geom(p->S, p->C, al, V);
     StylePtrs sp;
     for (int s = 0; s < MISEG_MAX_STYLES; ++s) { sp.gamma[s] = s < p->num_styles ? p->gamma[s] : nullptr; sp.beta[s] = s < p->num_styles ? p->beta[s] : nullptr; }
-    dim3 grid(cdiv(cv, tx), p->B);
-    const size_t sh = (size_t)ty * 2 * tx * vec * sizeof(float) + (size_t)2 * tx * vec * sizeof(double);
-    if (vec == 1)
-      instnorm_fused_fwd_kernel<T, 1><<<grid, NORM_THREADS, sh, stream>>>((const T*)p->x, p->ldx, (const T*)p->res, p->ldres, (T*)p->y, p->ldy, p->S, p->C, cv, tx, ty,
-                                                                          (double*)p->stat, p->eps, p->styles, sp, p->act, p->slope);
-    else
-      instnorm_fused_fwd_kernel<T, V><<<grid, NORM_THREADS, sh, stream>>>((const T*)p->x, p->ldx, (const T*)p->res, p->ldres, (T*)p->y, p->ldy, p->S, p->C, cv, tx, ty,
-                                                                          (double*)p->stat, p->eps, p->styles, sp, p->act, p->slope);
+    dim3 grid(cdiv(g.cv, g.tx), p->B);
+    const size_t sh = fused_smem(g, 2, 0);
+#define FWD_LAUNCH(VV)                                                                                                                                       \
+    instnorm_fused_fwd_kernel<T, VV><<<grid, NORM_THREADS, sh, stream>>>((const T*)p->x, p->ldx, (const T*)p->res, p->ldres, (T*)p->y, p->ldy, p->S, p->C, g.cv, g.tx, \
+                                                                         g.ty, (double*)p->stat, p->eps, p->styles, sp, p->act, p->slope)
+    FUSED_DISPATCH(g, FWD_LAUNCH);
+#undef FWD_LAUNCH
     MISEG_LAUNCH_CHECK("instnorm_fwd");
     return MISEG_OK;
   });
@@ -1053,18 +1352,15 @@ extern "C" int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stre
       gp.dbeta[s] = s < p->num_styles ? p->dbeta[s] : nullptr;
     }
     if (p->S <= NORM_FUSED_MAX_ROWS) {
-      const int vec = g.vec, cv = p->C / vec;
-      const int tx = cv < 4 ? cv : 4, ty = NORM_THREADS / tx;
-      dim3 fgrid(cdiv(cv, tx), p->B);
-      const size_t fsh = (size_t)ty * 2 * tx * vec * sizeof(float) + (size_t)4 * tx * vec * sizeof(double);
-      if (vec == 1)
-        instnorm_fused_bwd_kernel<T, 1><<<fgrid, NORM_THREADS, fsh, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, (T*)p->dx,
-                                                                              p->lddx, (T*)p->dres, p->lddres, p->S, p->C, cv, tx, ty, (const double*)p->stat, p->eps,
-                                                                              p->styles, sp, gp, p->act, p->slope, (const T*)p->gadd, p->ldgadd);
-      else
-        instnorm_fused_bwd_kernel<T, V><<<fgrid, NORM_THREADS, fsh, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, (T*)p->dx,
-                                                                              p->lddx, (T*)p->dres, p->lddres, p->S, p->C, cv, tx, ty, (const double*)p->stat, p->eps,
-                                                                              p->styles, sp, gp, p->act, p->slope, (const T*)p->gadd, p->ldgadd);
+      const FusedGeom f = fused_geom(p->S, p->C, al, V);
+      dim3 fgrid(cdiv(f.cv, f.tx), p->B);
+      const size_t fsh = fused_smem(f, 2, 1);
+#define FBWD_LAUNCH(VV)                                                                                                                                      \
+      instnorm_fused_bwd_kernel<T, VV><<<fgrid, NORM_THREADS, fsh, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, (T*)p->dx,      \
+                                                                             p->lddx, (T*)p->dres, p->lddres, p->S, p->C, f.cv, f.tx, f.ty, (const double*)p->stat, \
+                                                                             p->eps, p->styles, sp, gp, p->act, p->slope, (const T*)p->gadd, p->ldgadd)
+      FUSED_DISPATCH(f, FBWD_LAUNCH);
+#undef FBWD_LAUNCH
       MISEG_LAUNCH_CHECK("instnorm_bwd");
       return MISEG_OK;
     }
@@ -1108,6 +1404,20 @@ extern "C" int miseg_instnorm_pair_bwd(const miseg_instnorm_pair_bwd_params* p, 
       spb.gamma[s] = on ? p->gamma_b[s] : nullptr; spb.beta[s] = on ? p->beta_b[s] : nullptr;
       gpa.dgamma[s] = on ? p->dgamma_a[s] : nullptr; gpa.dbeta[s] = on ? p->dbeta_a[s] : nullptr;
       gpb.dgamma[s] = on ? p->dgamma_b[s] : nullptr; gpb.dbeta[s] = on ? p->dbeta_b[s] : nullptr;
+    }
+    if (!p->r1x && p->S <= NORM_FUSED_MAX_ROWS) {      // small tensors: one register-resident launch
+      const FusedGeom f = fused_geom(p->S, p->C, al, V);
+      dim3 fgrid(cdiv(f.cv, f.tx), p->B);
+      const size_t fsh = fused_smem(f, 3, 2);
+#define PFBWD_LAUNCH(VV)                                                                                                                                     \
+      instnorm_pair_fused_bwd_kernel<T, VV><<<fgrid, NORM_THREADS, fsh, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->xa, p->ldxa,         \
+                                                                                  (const T*)p->xb, p->ldxb, (T*)p->dxa, p->lddxa, (T*)p->dxb, p->lddxb, p->S, p->C,  \
+                                                                                  f.cv, f.tx, f.ty, (const double*)p->stat_a, (const double*)p->stat_b, p->eps,   \
+                                                                                  p->styles, spa, spb, p->slope, gpa, gpb)
+      FUSED_DISPATCH(f, PFBWD_LAUNCH);
+#undef PFBWD_LAUNCH
+      MISEG_LAUNCH_CHECK("instnorm_pair_bwd");
+      return MISEG_OK;
     }
     dim3 grid(g.chunks, p->B, g.ctiles);
     size_t sh = (size_t)g.ty * 2 * g.tx * g.vec * sizeof(float);

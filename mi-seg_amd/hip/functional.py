@@ -127,11 +127,11 @@ class _InstNorm(Function):
         # beside the autograd inputs: to autograd the result is an ordinary fresh output, not an aliased / in-place-modified input
         global _PENDING_OUT
         out, _PENDING_OUT = _PENDING_OUT, None
-        if stat_in is not None or out is not None:      # statistics already produced by the epilogue of the kernel that wrote x
-            stat = stat_in if stat_in is not None else ops.instnorm_stats(x, B, S)
+        if stat_in is not None:      # statistics already produced by the epilogue of the kernel that wrote x
+            stat = stat_in
             y = ops.instnorm_apply(x, B, S, stat, styles_dev, gammas, betas, res=res, act=act, slope=slope, eps=eps, out=out)
         else:
-            y, stat = ops.instnorm_fwd(x, B, S, styles_dev, gammas, betas, res=res, act=act, slope=slope, eps=eps)
+            y, stat = ops.instnorm_fwd(x, B, S, styles_dev, gammas, betas, res=res, act=act, slope=slope, eps=eps, out=out)
         ctx.meta = (B, S, styles_host, num_styles, affine, act, slope, res is not None, eps)
         ctx.params = params
         # y is kept only where a residual entered the activation: otherwise the backward kernels recompute the LeakyReLU's sign from x

@@ -82,7 +82,7 @@ Resample2 = _struct("Resample2", cname="miseg_resample2_params", fields=[("x", v
 Rowbias = _struct("Rowbias", cname="miseg_rowbias_params", fields=[("x", vp), ("ldx", i64), ("bias", vp), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
 PreluFwd = _struct("PreluFwd", cname="miseg_prelu_fwd_params", fields=[("x", vp), ("ldx", i64), ("slope", vp), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
 PreluBwd = _struct("PreluBwd", cname="miseg_prelu_bwd_params", fields=[("dy", vp), ("lddy", i64), ("x", vp), ("ldx", i64), ("slope", vp), ("dx", vp), ("lddx", i64), ("dslope", vp),
-                                ("rows", i64), ("C", i32), ("dtype", i32)])
+                                ("rows", i64), ("C", i32), ("dtype", i32), ("scratch", vp)])
 Cast = _struct("Cast", cname="miseg_cast_params", fields=[("src", vp), ("dst", vp), ("R", i32), ("C", i32), ("dtype", i32), ("transpose", i32)])
 GeluFwd = _struct("GeluFwd", cname="miseg_gelu_fwd_params", fields=[("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
 GeluBwd = _struct("GeluBwd", cname="miseg_gelu_bwd_params", fields=[("dy", vp), ("lddy", i64), ("x", vp), ("ldx", i64), ("dx", vp), ("lddx", i64), ("rows", i64), ("C", i32), ("dtype", i32)])

@@ -203,12 +203,12 @@ def instnorm_apply(x, B, S, stat, styles, gammas, betas, res=None, act=L.ACT_NON
     return y
 
 
-def instnorm_fwd(x, B, S, styles, gammas, betas, res=None, act=L.ACT_NONE, slope=0.01, eps=1e-5):
-    """statistics + normalisation (one fused launch for tensors of <= 512 rows per sample); returns (y, stat)."""
+def instnorm_fwd(x, B, S, styles, gammas, betas, res=None, act=L.ACT_NONE, slope=0.01, eps=1e-5, out=None):
+    """statistics + normalisation (one register-resident launch for tensors of <= 2048 rows per sample); returns (y, stat)."""
     ld, n, Cc = rows(x)
     assert n == B * S, (n, B, S)
     stat = STAT_POOL.take(L.load().miseg_instnorm_stat_bytes(B, Cc) // 8, x.device).view(-1, B, Cc, 2)
-    y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    y = out if out is not None else torch.empty(x.shape, dtype=x.dtype, device=x.device)
     ldr = rows(res)[0] if res is not None else 0
     ns = len(gammas) if gammas is not None else 1
     p = L.InstnormApply(_ptr(x), ld, _ptr(res), ldr, _ptr(y), rows(y)[0], B, S, Cc, _dt(x), _ptr(stat), eps, _ptr(styles), ns,
@@ -802,7 +802,8 @@ def prelu_fwd(x, slope):
 def prelu_bwd(dy, x, slope, dslope):
     ld, n, Cc = rows(x)
     dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
-    _call("miseg_prelu_bwd", L.PreluBwd(_ptr(dy), rows(dy)[0], _ptr(x), ld, _ptr(_fp32(slope)), _ptr(dx), rows(dx)[0], _ptr(dslope), n, Cc, _dt(x)))
+    scratch = STAT_POOL.take(2, x.device) if dslope is not None else None      # zeroed fp64 (sum, arrival ticket) of the slope-gradient reduction
+    _call("miseg_prelu_bwd", L.PreluBwd(_ptr(dy), rows(dy)[0], _ptr(x), ld, _ptr(_fp32(slope)), _ptr(dx), rows(dx)[0], _ptr(dslope), n, Cc, _dt(x), _ptr(scratch)))
     return dx
 
 

@@ -58,12 +58,11 @@ def apply_norm_fork(norm: nn.Module, x, styles=None):
 
 
 def apply_res_norm_pair(norm_a: nn.Module, xa, norm_b: nn.Module, xb, styles=None, slope=0.01, stat_a=None, out=None, w1=None):
-    """LeakyReLU(norm_a(xa) + norm_b(xb)) in one apply pass (HF.res_norm_pair) where both norms are instance norms of the same kind and
-    the tensors have more than 512 rows per sample (below that the single-launch fused norms win); None where that does not apply.
+    """LeakyReLU(norm_a(xa) + norm_b(xb)) in one apply pass (HF.res_norm_pair) where both norms are instance norms of the same kind (any
+    size: the joint backward is ONE register-resident launch up to 2048 rows per sample, two chunked ones above); None where that does not apply.
     w1: xb is a one-channel image and norm_b sees conv1x1x1(xb; w1), which is then never materialised (one sample, bf16 / fp32 rows)."""
-    rows_per_sample = xa.numel() // (xa.shape[0] * xa.shape[-1])
-    if rows_per_sample <= 512 or (xa.shape != xb.shape if w1 is None else (xa.shape[:-1] != xb.shape[:-1] or xb.shape[-1] != 1 or xa.shape[0] != 1
-                                                                          or xb.requires_grad or xa.shape[-1] % 8 != 0)):
+    if (xa.shape != xb.shape if w1 is None else (xa.shape[:-1] != xb.shape[:-1] or xb.shape[-1] != 1 or xa.shape[0] != 1
+                                                   or xb.requires_grad or xa.shape[-1] % 8 != 0)):
         return None
     if isinstance(norm_a, _ConditionalInstanceNorm) and isinstance(norm_b, _ConditionalInstanceNorm):
         if styles is None:

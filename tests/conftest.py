@@ -102,6 +102,7 @@ def compare_grads(got_named, want, tol, sampled=False, vanish_tol=1e-2, skip=())
     rms = {k: float(g.double().norm()) / max(1, g.numel()) ** 0.5 for k, g in want.items()}
     med = sorted(rms.values())[len(rms) // 2]
     worst = ("", 0.0)
+    scal = scalar_scale(want)
     for k, g in want.items():
         if k in skip:
             continue
@@ -113,7 +114,19 @@ def compare_grads(got_named, want, tol, sampled=False, vanish_tol=1e-2, skip=())
             assert got_rms < vanish_tol * med, (k, "should vanish", got_rms, med)
             continue
         e = rel_err(got, g)
+        if g.numel() == 1:
+            e = min(e, float((got.double() - g.double()).abs().max()) / scal)
         if e > worst[1]:
             worst = (k, e)
     assert worst[1] < tol, worst
     return worst
+
+
+def scalar_scale(want):
+    """One-element parameters (the UNet's PReLU slopes) are sums over every voxel of a layer with heavy cancellation: d slope = sum dy * min(x, 0)
+    has terms adding up to ~600 in absolute value where the result is -1.49 (C1, level 3), so a 1.5e-3 relative change of dy - ONE
+    activation-sign flip somewhere behind it, see SMALL_NET_BAR in test_hip_modules.py - moves it by 60 % while the other slope gradients of
+    the same net (|g| ~ 100 - 1000) move by 1e-3.  Such a parameter is judged on the scale of its peers: error / max(|g|, median |g| over the
+    one-element parameters).  Returns that median (1.0 if the net has none)."""
+    vals = sorted(float(g.double().abs().max()) for g in want.values() if g.numel() == 1)
+    return max(vals[len(vals) // 2], 1e-30) if vals else 1.0
