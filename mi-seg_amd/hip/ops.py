@@ -79,6 +79,16 @@ def _call(fn_name, params, prof=None, prof_params=None):
     L.check(getattr(lib, fn_name)(C.byref(params), _stream()), fn_name)
 
 
+def _nb(*tensors):
+    """bytes of the given tensors (None skipped): the algorithmic traffic of a launch that touches each of them once"""
+    return float(sum(t.numel() * t.element_size() for t in tensors if t is not None))
+
+
+def _prof_scratch(t):
+    """roofline leg only: a throw-away zero buffer shaped like `t` for the accumulating outputs of the repeated launches"""
+    return torch.zeros_like(t) if (t is not None and PROFILE_HOOK is not None) else None
+
+
 # ------------------------------------------------------------------------------------------ instance norm
 class _ZeroPool:
     """fp64 statistics buffers of a step come from one pre-zeroed pool (one fill instead of ~100 small memsets).
@@ -162,7 +172,9 @@ def instnorm_stats(x, B, S):
     ld, n, Cc = rows(x)
     assert n == B * S, (n, B, S)
     stat = STAT_POOL.take(L.load().miseg_instnorm_stat_bytes(B, Cc) // 8, x.device).view(-1, B, Cc, 2)
-    _call("miseg_instnorm_stats", L.InstnormStats(_ptr(x), ld, B, S, Cc, _dt(x), _ptr(stat)))
+    sc = _prof_scratch(stat)
+    _call("miseg_instnorm_stats", L.InstnormStats(_ptr(x), ld, B, S, Cc, _dt(x), _ptr(stat)), prof=("instnorm", 0.0, _nb(x)),
+          prof_params=L.InstnormStats(_ptr(x), ld, B, S, Cc, _dt(x), _ptr(sc)) if sc is not None else None)
     return stat
 
 
@@ -199,7 +211,7 @@ def instnorm_apply(x, B, S, stat, styles, gammas, betas, res=None, act=L.ACT_NON
     if r1 is not None:
         assert res is None and rows(r1[0])[1] == n and r1[1].numel() == Cc and r1[1].dtype == x.dtype
         p.r1x, p.ldr1x, p.r1w = _ptr(r1[0]), rows(r1[0])[0], _ptr(r1[1])
-    _call("miseg_instnorm_apply", p)
+    _call("miseg_instnorm_apply", p, prof=("instnorm", 0.0, _nb(x, res, y, r1[0] if r1 is not None else None)))
     return y
 
 
@@ -213,7 +225,7 @@ def instnorm_fwd(x, B, S, styles, gammas, betas, res=None, act=L.ACT_NONE, slope
     ns = len(gammas) if gammas is not None else 1
     p = L.InstnormApply(_ptr(x), ld, _ptr(res), ldr, _ptr(y), rows(y)[0], B, S, Cc, _dt(x), _ptr(stat), eps, _ptr(styles), ns,
                         _style_arrays(gammas, ns), _style_arrays(betas, ns), act, slope)
-    _call("miseg_instnorm_fwd", p)
+    _call("miseg_instnorm_fwd", p, prof=("instnorm", 0.0, _nb(x, res, y)))      # (statistics are stored, not accumulated: repeatable)
     return y, stat
 
 
@@ -224,11 +236,14 @@ def instnorm_bwd(dy, y, x, B, S, stat, styles, gammas, dgammas, dbetas, act=L.AC
     dres = torch.empty(x.shape, dtype=x.dtype, device=x.device) if want_dres else None
     dstat = STAT_POOL.take(L.load().miseg_instnorm_stat_bytes(B, Cc) // 8, x.device)
     ns = len(gammas) if gammas is not None else 1
-    p = L.InstnormBwd(_ptr(dy), rows(dy)[0], _ptr(y), rows(y)[0] if y is not None else 0, _ptr(x), ld, _ptr(dx), rows(dx)[0],
-                      _ptr(dres), rows(dres)[0] if dres is not None else 0, B, S, Cc, _dt(x), _ptr(stat), eps, _ptr(dstat), _ptr(styles), ns,
-                      _style_arrays(gammas, ns), _style_arrays(dgammas, ns), _style_arrays(dbetas, ns), act, slope,
-                      _ptr(gadd), rows(gadd)[0] if gadd is not None else 0, _style_arrays(betas, ns))
-    _call("miseg_instnorm_bwd", p)
+    mk = lambda ds, dg, db: L.InstnormBwd(_ptr(dy), rows(dy)[0], _ptr(y), rows(y)[0] if y is not None else 0, _ptr(x), ld, _ptr(dx), rows(dx)[0],
+                                          _ptr(dres), rows(dres)[0] if dres is not None else 0, B, S, Cc, _dt(x), _ptr(stat), eps, _ptr(ds), _ptr(styles), ns,
+                                          _style_arrays(gammas, ns), _style_arrays(dg, ns), _style_arrays(db, ns), act, slope,
+                                          _ptr(gadd), rows(gadd)[0] if gadd is not None else 0, _style_arrays(betas, ns))
+    # (roofline leg: the repeated launches accumulate their reduction into scratch and leave the affine gradients alone)
+    sc = _prof_scratch(dstat)
+    _call("miseg_instnorm_bwd", mk(dstat, dgammas, dbetas), prof=("instnorm", 0.0, _nb(dy, y, x, dx, dres, gadd)),
+          prof_params=mk(sc, None, None) if sc is not None else None)
     return dx, dres
 
 
@@ -243,15 +258,22 @@ def instnorm_pair_bwd(dy, y, xa, xb, B, S, stat_a, stat_b, styles, gammas_a, gam
     nb = L.load().miseg_instnorm_stat_bytes(B, Cc) // 8
     dsa, dsb = STAT_POOL.take(nb, xa.device), STAT_POOL.take(nb, xa.device)
     ns = len(gammas_a) if gammas_a is not None else 1
-    p = L.InstnormPairBwd(_ptr(dy), rows(dy)[0], _ptr(y), rows(y)[0] if y is not None else 0, _ptr(xa), ld, _ptr(xb), rows(xb)[0] if xb is not None else 0,
-                          _ptr(dxa), rows(dxa)[0], _ptr(dxb), rows(dxb)[0] if dxb is not None else 0,
-                          B, S, Cc, _dt(xa), _ptr(stat_a), _ptr(stat_b), eps, _ptr(dsa), _ptr(dsb), _ptr(styles), ns,
-                          _style_arrays(gammas_a, ns), _style_arrays(gammas_b, ns), _style_arrays(dgammas_a, ns), _style_arrays(dbetas_a, ns),
-                          _style_arrays(dgammas_b, ns), _style_arrays(dbetas_b, ns), slope, _style_arrays(betas_a, ns), _style_arrays(betas_b, ns))
     if r1 is not None:
         assert xb is None and y is None and rows(r1[0])[1] == n and r1[1].numel() == Cc and r1[2].numel() == Cc and r1[2].dtype == torch.float32
-        p.r1x, p.ldr1x, p.r1w, p.r1dw = _ptr(r1[0]), rows(r1[0])[0], _ptr(r1[1]), _ptr(r1[2])
-    _call("miseg_instnorm_pair_bwd", p)
+
+    def mk(da, db_, ga, ba, gb, bb, dw):
+        p = L.InstnormPairBwd(_ptr(dy), rows(dy)[0], _ptr(y), rows(y)[0] if y is not None else 0, _ptr(xa), ld, _ptr(xb), rows(xb)[0] if xb is not None else 0,
+                              _ptr(dxa), rows(dxa)[0], _ptr(dxb), rows(dxb)[0] if dxb is not None else 0,
+                              B, S, Cc, _dt(xa), _ptr(stat_a), _ptr(stat_b), eps, _ptr(da), _ptr(db_), _ptr(styles), ns,
+                              _style_arrays(gammas_a, ns), _style_arrays(gammas_b, ns), _style_arrays(ga, ns), _style_arrays(ba, ns),
+                              _style_arrays(gb, ns), _style_arrays(bb, ns), slope, _style_arrays(betas_a, ns), _style_arrays(betas_b, ns))
+        if r1 is not None:
+            p.r1x, p.ldr1x, p.r1w, p.r1dw = _ptr(r1[0]), rows(r1[0])[0], _ptr(r1[1]), _ptr(dw)
+        return p
+    sa, sb = _prof_scratch(dsa), _prof_scratch(dsb)
+    _call("miseg_instnorm_pair_bwd", mk(dsa, dsb, dgammas_a, dbetas_a, dgammas_b, dbetas_b, r1[2] if r1 is not None else None),
+          prof=("instnorm", 0.0, _nb(dy, y, xa, xb, dxa, dxb, r1[0] if r1 is not None else None)),
+          prof_params=mk(sa, sb, None, None, None, None, _prof_scratch(r1[2]) if r1 is not None else None) if sa is not None else None)
     return dxa, dxb
 
 
@@ -313,7 +335,7 @@ def gemm_nt(a, w, bias=None, act=L.ACT_NONE, out=None, out_dtype=None, split_k=1
         stat = STAT_POOL.take(L.load().miseg_instnorm_stat_bytes(1, N) // 8, a.device).view(-1, 1, N, 2)
         p.stat = stat.data_ptr()
         LAST_GEMM_STAT = (out.data_ptr(), stat)
-    _call("miseg_gemm", p)
+    _call("miseg_gemm", p, prof=("gemm_nt", 2.0 * M * N * K, _nb(a, w, out, res, aux)))      # (no accumulating output on the NT side: repeatable)
     return out
 
 
@@ -858,15 +880,22 @@ def winattn_fwd(qkv, qkv_bias, table, heads, window, shift, tw, scale, drop=None
     out = torch.empty(B, D, H, W, Cc, dtype=qkv.dtype, device=qkv.device)
     nw = B * -(-D // window[0]) * -(-H // window[1]) * -(-W // window[2])
     lse = torch.empty(nw, heads, window[0] * window[1] * window[2], dtype=torch.float32, device=qkv.device)
-    _call("miseg_winattn_fwd", winattn_params(qkv, out, qkv_bias, table, lse, heads, window, shift, tw, scale, drop))
+    n = window[0] * window[1] * window[2]
+    _call("miseg_winattn_fwd", winattn_params(qkv, out, qkv_bias, table, lse, heads, window, shift, tw, scale, drop),
+          prof=("winattn", 4.0 * nw * heads * n * n * (Cc // heads), _nb(qkv, out, lse)))
     return out, lse
 
 
 def winattn_bwd(qkv, out, lse, dout, qkv_bias, table, heads, window, shift, tw, scale, dqkv_bias, dtable, drop=None):
     dqkv = torch.empty(qkv.shape, dtype=qkv.dtype, device=qkv.device)
     f = winattn_params(qkv, out, qkv_bias, table, lse, heads, window, shift, tw, scale, drop)
-    p = L.WinattnBwd(f, _ptr(dout), rows(dout)[0], _ptr(dqkv), rows(dqkv)[0], _ptr(dqkv_bias), _ptr(dtable))
-    _call("miseg_winattn_bwd", p)
+    mk = lambda dqb, dtb: L.WinattnBwd(f, _ptr(dout), rows(dout)[0], _ptr(dqkv), rows(dqkv)[0], _ptr(dqb), _ptr(dtb))
+    B, D, H, W = _vol(qkv)
+    n = window[0] * window[1] * window[2]
+    nw = B * -(-D // window[0]) * -(-H // window[1]) * -(-W // window[2])
+    sq, st_ = _prof_scratch(dqkv_bias), _prof_scratch(dtable)      # (roofline leg: the repeats accumulate the bias / table gradients into scratch)
+    _call("miseg_winattn_bwd", mk(dqkv_bias, dtable), prof=("winattn", 10.0 * nw * heads * n * n * (qkv.shape[-1] // 3 // heads), _nb(qkv, out, lse, dout, dqkv)),
+          prof_params=mk(sq, st_) if (sq is not None or st_ is not None) else None)
     return dqkv
 
 
