@@ -104,6 +104,10 @@ typedef struct {
   const float* beta[MISEG_MAX_STYLES];
 } miseg_instnorm_bwd_params;
 int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stream_t stream);
+/* the reduction half alone (ABI 5): dstat[r][b][c] += (sum dy, sum dy * xhat) over the rows of sample b, xhat from `stat` - what the group /
+ * batch norms of the reference's factory (networks/layers/factories.py:219-257) need besides the kernels above (their means run over channel
+ * groups / the whole batch: mi-seg_amd/hip/functional.py::group_norm).  Reads dy, x, stat, eps, styles / gamma / beta only with an activation. */
+int miseg_instnorm_bwd_reduce(const miseg_instnorm_bwd_params* p, miseg_stream_t stream);
 
 /* Backward of y = LeakyReLU(norm_a(xa) + norm_b(xb)) (miseg_instnorm_apply with res_stat; dynunet_block.py:118-126): one reduction and one
  * apply pass for both norms.  dstat_a / dstat_b: scratch like miseg_instnorm_bwd's dstat (zero on entry); dgamma / dbeta accumulate. */
@@ -345,6 +349,10 @@ int miseg_winattn_bwd(const miseg_winattn_bwd_params* p, miseg_stream_t stream);
 /* y = a + b (elementwise over rows x C), any of the three may alias */
 typedef struct { const void* a; int64_t lda; const void* b; int64_t ldb; void* y; int64_t ldy; int64_t rows; int C, dtype; } miseg_add_params;
 int miseg_add(const miseg_add_params* p, miseg_stream_t stream);
+/* y[b][s][c] = coef[b][c][0] * a[b][s][c] + coef[b][c][1] * x[b][s][c] + coef[b][c][2]   (ABI 5; coef: fp32 [B][C][3] on the device) - the input
+ * gradient of a normalisation whose means run over several channels: dx = P dy + R x + Q with per-(sample, channel) coefficients */
+typedef struct { uint32_t struct_size; const void* a; int64_t lda; const void* x; int64_t ldx; void* y; int64_t ldy; const float* coef; int B, S, C, dtype; } miseg_affine2_params;
+int miseg_affine2(const miseg_affine2_params* p, miseg_stream_t stream);
 
 /* strided 2D copy with dtype conversion: dst[r][c] = src[r][c] */
 typedef struct { const void* src; int64_t lds; int sdtype; void* dst; int64_t ldd; int ddtype; int64_t rows; int C; } miseg_copy2d_params;

@@ -1360,6 +1360,43 @@ using namespace miseg;
     return MISEG_OK;                                                        \
   })
 
+namespace miseg {
+template <class T, int VEC>
+__global__ void __launch_bounds__(256) affine2_kernel(const T* __restrict__ a, int64_t lda, const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy,
+                                                      const float* __restrict__ coef, int B, int S, int cv, int C) {
+  const int64_t total = (int64_t)B * S * cv;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cv;
+    const int c = (int)(i % cv) * VEC;
+    const int b = (int)(r / S);
+    V<T, VEC> av, xv;
+    av.load(a + r * lda + c);
+    xv.load(x + r * ldx + c);
+    const float* k = coef + ((int64_t)b * C + c) * 3;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) av.v[e] = fmaf(k[3 * e], av.v[e], fmaf(k[3 * e + 1], xv.v[e], k[3 * e + 2]));
+    av.store(y + r * ldy + c);
+  }
+}
+}  // namespace miseg
+
+extern "C" int miseg_affine2(const miseg_affine2_params* p, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->struct_size == sizeof(miseg_affine2_params), MISEG_E_BADARG, "affine2: struct_size");
+  MISEG_REQUIRE(p->a && p->x && p->y && p->coef && p->B > 0 && p->S > 0 && p->C > 0, MISEG_E_BADARG, "affine2: bad args");
+  DT(p, {
+    constexpr int N = Vec16<T>::N;
+    const bool vec = p->C % N == 0 && p->lda % N == 0 && p->ldx % N == 0 && p->ldy % N == 0 && al16(p->a) && al16(p->x) && al16(p->y);
+    const int cv = vec ? p->C / N : p->C;
+    int64_t n = (int64_t)p->B * p->S * cv;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    if (vec) miseg::affine2_kernel<T, N><<<grid, 256, 0, s>>>((const T*)p->a, p->lda, (const T*)p->x, p->ldx, (T*)p->y, p->ldy, p->coef, p->B, p->S, cv, p->C);
+    else miseg::affine2_kernel<T, 1><<<grid, 256, 0, s>>>((const T*)p->a, p->lda, (const T*)p->x, p->ldx, (T*)p->y, p->ldy, p->coef, p->B, p->S, cv, p->C);
+    MISEG_LAUNCH_CHECK("affine2");
+  });
+}
+
 extern "C" int miseg_add(const miseg_add_params* p, miseg_stream_t s_) {
   hipStream_t s = (hipStream_t)s_;
   MISEG_REQUIRE(p && p->a && p->b && p->y && p->rows > 0 && p->C > 0, MISEG_E_BADARG, "add: bad args");

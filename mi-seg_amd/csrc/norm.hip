@@ -1383,6 +1383,31 @@ extern "C" int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stre
   });
 }
 
+extern "C" int miseg_instnorm_bwd_reduce(const miseg_instnorm_bwd_params* p, miseg_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  MISEG_REQUIRE(p && p->dy && p->x && p->stat && p->dstat, MISEG_E_BADARG, "instnorm_bwd_reduce: null pointer");
+  MISEG_REQUIRE(p->act == MISEG_ACT_NONE, MISEG_E_UNSUPPORTED, "instnorm_bwd_reduce: no activation (compose it outside)");
+  return dispatch_dtype(p->dtype, [&](auto* tag) -> int {
+    typedef typename std::remove_pointer<decltype(tag)>::type T;
+    constexpr int V = Vec16<T>::N;
+    const bool al = aligned16(p->dy) && aligned16(p->x) && (p->lddy | p->ldx) % V == 0;
+    NormGeom g = norm_geom(p->S, p->C, al, V);
+    StylePtrs sp;
+    for (int s = 0; s < MISEG_MAX_STYLES; ++s) { sp.gamma[s] = nullptr; sp.beta[s] = nullptr; }
+    dim3 grid(g.chunks, p->B, g.ctiles);
+    size_t sh = (size_t)g.ty * 2 * g.tx * g.vec * sizeof(float);
+    if (sh < (size_t)2 * g.tx * g.vec * sizeof(double)) sh = (size_t)2 * g.tx * g.vec * sizeof(double);
+    if (g.vec == 1)
+      instnorm_bwd_reduce_kernel<T, 1><<<grid, NORM_THREADS, sh, stream>>>((const T*)p->dy, p->lddy, nullptr, 0, (const T*)p->x, p->ldx, p->S, p->C, g.cv, g.tx, g.ty,
+                                                                           g.rpb, (const double*)p->stat, p->eps, MISEG_ACT_NONE, 0.f, (double*)p->dstat, nullptr, sp);
+    else
+      instnorm_bwd_reduce_kernel<T, V><<<grid, NORM_THREADS, sh, stream>>>((const T*)p->dy, p->lddy, nullptr, 0, (const T*)p->x, p->ldx, p->S, p->C, g.cv, g.tx, g.ty,
+                                                                           g.rpb, (const double*)p->stat, p->eps, MISEG_ACT_NONE, 0.f, (double*)p->dstat, nullptr, sp);
+    MISEG_LAUNCH_CHECK("instnorm_bwd_reduce");
+    return MISEG_OK;
+  });
+}
+
 extern "C" int miseg_instnorm_pair_bwd(const miseg_instnorm_pair_bwd_params* p, miseg_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   MISEG_REQUIRE(p && p->dy && p->xa && p->dxa && p->stat_a && p->stat_b && p->dstat_a && p->dstat_b, MISEG_E_BADARG, "instnorm_pair_bwd: null pointer");

@@ -287,6 +287,102 @@ def instance_norm(x, params=None, styles_dev=None, styles_host=None, res=None, a
     return _InstNorm.apply(x, res, styles_dev, styles_host, n, params is not None, act, slope, eps, fork, stat, *flat)
 
 
+class _GroupStatNorm(Function):
+    """GroupNorm / BatchNorm on channels-last rows out of the instance-norm kernels (reference networks/layers/factories.py:219-257: the
+    `batch` / `group` entries of the norm factory, reachable through --encoder_norm_name / --decoder_norm_name, networks/norms/utils.py:11-14).
+    Statistics are means over (rows of a sample) x (the `cg` channels of a group) - GroupNorm - or over (all rows of the batch) per channel -
+    BatchNorm: the caller passes the batch as ONE sample and cg = 1.  Forward: per-channel sums (miseg_instnorm_stats), the group means as a
+    handful of [B, C] float64 operations, miseg_instnorm_apply with the per-channel affine.  Backward: per-channel (sum dy, sum dy xhat)
+    (miseg_instnorm_bwd_reduce) give d gamma, d beta directly and, weighted by gamma and summed over the group, the two means of
+    dx = rs (gamma dy - mean(gamma dy) - xhat mean(gamma dy xhat)), which one pass evaluates as P dy + R x + Q (miseg_affine2)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cg, eps):
+        B, Cc = x.shape[0], x.shape[-1]
+        S = ops.rows(x)[1] // B
+        G = Cc // cg
+        raw = ops.instnorm_stats(x, B, S)                                   # [R, B, C, 2] float64
+        tot = raw.sum(0).view(B, G, cg, 2).sum(2, keepdim=True) / cg        # group means of the per-channel sums
+        stat = torch.zeros_like(raw)
+        stat[0] = tot.expand(B, G, cg, 2).reshape(B, Cc, 2)
+        y = ops.instnorm_apply(x, B, S, stat, None, [weight] if weight is not None else None, [bias] if bias is not None else None, eps=eps)
+        ctx.save_for_backward(x, stat, weight)
+        ctx.meta = (B, S, Cc, cg, eps)
+        ctx.params = (weight, bias)
+        ctx.mark_non_differentiable(stat)
+        return y, stat
+
+    @staticmethod
+    def backward(ctx, dy, _dstat=None):
+        x, stat, weight = ctx.saved_tensors
+        B, S, Cc, cg, eps = ctx.meta
+        G = Cc // cg
+        dy = _rv(dy)
+        ds = ops.instnorm_bwd_reduce(dy, x, B, S, stat, eps).sum(0)        # [B, C, 2]: (sum dy, sum dy xhat) per (sample, channel), float64
+        gam = weight.double() if weight is not None else torch.ones(Cc, dtype=torch.float64, device=x.device)
+        mu = stat[0, :, :, 0] / S
+        rs = 1.0 / torch.sqrt((stat[0, :, :, 1] / S - mu * mu).clamp_min(0.0).float() + eps).double()
+        n = float(cg * S)
+        A = ((gam * ds[..., 0]).view(B, G, cg).sum(2, keepdim=True) / n).expand(B, G, cg).reshape(B, Cc)
+        Bq = ((gam * ds[..., 1]).view(B, G, cg).sum(2, keepdim=True) / n).expand(B, G, cg).reshape(B, Cc)
+        coef = torch.stack([rs * gam, -rs * rs * Bq, -rs * A + rs * rs * mu * Bq], dim=-1).float().contiguous()
+        dx = ops.affine2(dy, x, coef, B, S) if ctx.needs_input_grad[0] else None
+        dg = db = None
+        pw, pb = ctx.params
+        if pw is not None and ctx.needs_input_grad[1]:
+            v = ds[..., 1].sum(0).float()
+            slot = _slot(pw)
+            if slot is not None:
+                slot.add_(v)
+            else:
+                dg = v
+        if pb is not None and ctx.needs_input_grad[2]:
+            v = ds[..., 0].sum(0).float()
+            slot = _slot(pb)
+            if slot is not None:
+                slot.add_(v)
+            else:
+                db = v
+        return dx, dg, db, None, None
+
+
+def group_norm(x, weight, bias, num_groups, eps=1e-5):
+    """nn.GroupNorm(num_groups, C) on a channels-last tensor [B, ..., C]"""
+    Cc = x.shape[-1]
+    if Cc % num_groups != 0:
+        raise ValueError("num_channels must be divisible by num_groups")
+    return _GroupStatNorm.apply(x, weight, bias, Cc // num_groups, eps)[0]
+
+
+def batch_norm(x, weight, bias, running_mean, running_var, training, momentum=0.1, eps=1e-5, num_batches_tracked=None):
+    """nn.BatchNorm3d on a channels-last tensor [B, ..., C]: batch statistics in training mode (the running estimates are updated like torch:
+    momentum mix, unbiased variance; momentum None = cumulative average), the running estimates in eval mode (forward only)."""
+    B, Cc = x.shape[0], x.shape[-1]
+    if training or running_mean is None:
+        xb = x.reshape((1, -1, Cc))                                           # the whole batch is one "sample": per-channel batch statistics
+        y, stat = _GroupStatNorm.apply(xb, weight, bias, 1, eps)
+        if training and running_mean is not None:
+            with torch.no_grad():
+                n = xb.shape[1]
+                mean = stat[0, 0, :, 0] / n
+                var = (stat[0, 0, :, 1] / n - mean * mean).clamp_min(0.0)
+                if num_batches_tracked is not None:
+                    num_batches_tracked += 1
+                m = momentum if momentum is not None else 1.0 / float(num_batches_tracked)
+                running_mean.mul_(1.0 - m).add_(mean.to(running_mean.dtype), alpha=m)
+                running_var.mul_(1.0 - m).add_((var * (n / max(n - 1, 1))).to(running_var.dtype), alpha=m)
+        return y.view(x.shape)
+    if torch.is_grad_enabled() and x.requires_grad:
+        raise NotImplementedError("BatchNorm in eval mode (running statistics) is forward-only on the MI355X path")
+    n = ops.rows(x)[1]
+    stat = torch.zeros(L.load().miseg_instnorm_stat_bytes(1, Cc) // 8, dtype=torch.float64, device=x.device).view(-1, 1, Cc, 2)
+    rm, rv = running_mean.double(), running_var.double()
+    stat[0, 0, :, 0] = rm * n
+    stat[0, 0, :, 1] = (rv + rm * rm) * n
+    xb = x.reshape((1, -1, Cc))
+    return ops.instnorm_apply(xb, 1, n, stat, None, [weight] if weight is not None else None, [bias] if bias is not None else None, eps=eps).view(x.shape)
+
+
 class _LayerNorm(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
@@ -621,6 +717,18 @@ def prelu(x, slope):
     return _PReLU.apply(x, slope)
 
 
+_CONST_SLOPES = {}
+
+
+def leaky_relu(x, slope=0.01):
+    """LeakyReLU(slope) (slope 0: ReLU) as the PReLU kernels with a constant one-element slope (no gradient for it)"""
+    key = (x.device, float(slope))
+    t = _CONST_SLOPES.get(key)
+    if t is None:
+        t = _CONST_SLOPES[key] = torch.full((1,), float(slope), dtype=torch.float32, device=x.device)
+    return _PReLU.apply(x, t)
+
+
 class _Cat2(Function):
     """cat([a, b], channel) with our strided-copy kernel; the backward hands out the two halves as views."""
 
@@ -641,6 +749,12 @@ class _Cat2(Function):
 
 def cat_channels(a, b):
     return _Cat2.apply(a, b)
+
+
+def image_rows(x_ncdhw, dtype):
+    """the NCDHW fp32 network input as channels-last rows [B, D, H, W, C] in the compute dtype (no gradient: the image is data) - the entry
+    of multi-channel images (--in_channels > 1, utils/parser.py:11) into the ordinary convolution kernels"""
+    return ops.ncdhw_to_rows_exact(x_ncdhw.detach().float().contiguous(), dtype)
 
 
 class _ToNCDHW(Function):

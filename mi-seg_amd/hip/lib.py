@@ -75,6 +75,8 @@ Winattn = _struct("Winattn", cname="miseg_winattn_params", fields=[("qkv", vp), 
 WinattnBwd = _struct("WinattnBwd", cname="miseg_winattn_bwd_params", fields=[("f", Winattn), ("dout", vp), ("lddo", i64), ("dqkv", vp), ("lddq", i64),
                                     ("dqkv_bias", vp), ("dbias_table", vp)])
 Add = _struct("Add", cname="miseg_add_params", fields=[("a", vp), ("lda", i64), ("b", vp), ("ldb", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
+Affine2 = _struct("Affine2", cname="miseg_affine2_params", fields=[("struct_size", C.c_uint32), ("a", vp), ("lda", i64), ("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("coef", vp),
+                                                                  ("B", i32), ("S", i32), ("C", i32), ("dtype", i32)])
 Copy2d = _struct("Copy2d", cname="miseg_copy2d_params", fields=[("src", vp), ("lds", i64), ("sdtype", i32), ("dst", vp), ("ldd", i64), ("ddtype", i32), ("rows", i64), ("C", i32)])
 CastDesc = _struct("CastDesc", cname="miseg_cast_desc", fields=[("src", vp), ("dst", vp), ("R", i32), ("C", i32), ("transpose", i32), ("inner", i32), ("outer", i32), ("tile0", i32)])
 Resample2 = _struct("Resample2", cname="miseg_resample2_params", fields=[("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("B", i32), ("D", i32), ("H", i32), ("W", i32), ("C", i32),
@@ -176,6 +178,8 @@ PROTOS = {
     "miseg_winattn_fwd": (i32, [C.POINTER(Winattn), vp]),
     "miseg_winattn_bwd": (i32, [C.POINTER(WinattnBwd), vp]),
     "miseg_add": (i32, [C.POINTER(Add), vp]),
+    "miseg_affine2": (i32, [C.POINTER(Affine2), vp]),
+    "miseg_instnorm_bwd_reduce": (i32, [C.POINTER(InstnormBwd), vp]),
     "miseg_copy2d": (i32, [C.POINTER(Copy2d), vp]),
     "miseg_cast_matrix": (i32, [C.POINTER(Cast), vp]),
     "miseg_gelu_fwd": (i32, [C.POINTER(GeluFwd), vp]),

@@ -106,6 +106,7 @@ class _ZeroPool:
     def __init__(self, numel=1 << 20):
         self.numel, self.buf, self.off, self.high = numel, None, 0, 0
         self._pinned = []
+        self._filled = None      # (event recorded behind the zero fill of the current chunk, streams already ordered behind it)
 
     def take(self, n, device):
         n = (n + 1) & ~1
@@ -115,6 +116,21 @@ class _ZeroPool:
             lib = L.load()
             L.check(lib.miseg_fill32(_ptr(self.buf), 0, self.buf.numel() * 2, _stream()), "fill32")
             self.off = 0
+            self._filled = None
+            if not torch.cuda.is_current_stream_capturing():
+                ev = torch.cuda.Event()
+                ev.record()
+                self._filled = (ev, {torch.cuda.current_stream().cuda_stream})
+        elif self._filled is not None:
+            # A chunk is zero-filled on the stream that happened to need it first.  A model's side branch (SwinUNETR / UNETR) takes buffers of
+            # the same chunk on ANOTHER stream: ordered behind the fill only if that stream happened to wait for the first one after the
+            # fill was queued - true for the chunk a forward starts with, not for one that an overflow starts in the middle of a branch.
+            # Every other stream waits for the fill once, and the allocator learns that the chunk is in use there.
+            cs = torch.cuda.current_stream()
+            if cs.cuda_stream not in self._filled[1]:
+                cs.wait_event(self._filled[0])
+                self.buf.record_stream(cs)
+                self._filled[1].add(cs.cuda_stream)
         t = self.buf[self.off:self.off + n]
         self.off += n
         self.high = max(self.high, self.off)
@@ -130,7 +146,7 @@ class _ZeroPool:
     def fresh(self):
         """start the next forward on a new chunk (unless the current one is untouched); see the class docstring"""
         if self.buf is not None and self.off > 0 and not torch.cuda.is_current_stream_capturing():
-            self.buf, self.off = None, 0
+            self.buf, self.off, self._filled = None, 0, None
 
     def pin(self):
         """keep the current chunk alive for good: a captured hipGraph holds raw pointers into it"""
@@ -245,6 +261,26 @@ def instnorm_bwd(dy, y, x, B, S, stat, styles, gammas, dgammas, dbetas, act=L.AC
     _call("miseg_instnorm_bwd", mk(dstat, dgammas, dbetas), prof=("instnorm", 0.0, _nb(dy, y, x, dx, dres, gadd)),
           prof_params=mk(sc, None, None) if sc is not None else None)
     return dx, dres
+
+
+def instnorm_bwd_reduce(dy, x, B, S, stat, eps=1e-5):
+    """dstat [R, B, C, 2] fp64 whose replicas sum to (sum dy, sum dy * xhat) per (sample, channel); xhat from `stat` (group / batch norms)"""
+    ld, n, Cc = rows(x)
+    assert n == B * S and rows(dy)[1] == n
+    dstat = STAT_POOL.take(L.load().miseg_instnorm_stat_bytes(B, Cc) // 8, x.device).view(-1, B, Cc, 2)
+    p = L.InstnormBwd(_ptr(dy), rows(dy)[0], None, 0, _ptr(x), ld, None, 0, None, 0, B, S, Cc, _dt(x), _ptr(stat), eps, _ptr(dstat), None, 1,
+                      _style_arrays(None, 1), _style_arrays(None, 1), _style_arrays(None, 1), L.ACT_NONE, 0.0, None, 0, _style_arrays(None, 1))
+    _call("miseg_instnorm_bwd_reduce", p)
+    return dstat
+
+
+def affine2(a, x, coef, B, S):
+    """y[b, s, c] = coef[b, c, 0] * a + coef[b, c, 1] * x + coef[b, c, 2]; a, x rows views of [B * S, C], coef fp32 [B, C, 3]"""
+    lda, n, Cc = rows(a)
+    assert n == B * S and rows(x)[1] == n and coef.dtype == torch.float32 and coef.is_contiguous() and tuple(coef.shape) == (B, Cc, 3)
+    y = torch.empty(a.shape, dtype=a.dtype, device=a.device)
+    _call("miseg_affine2", L.Affine2(C.sizeof(L.Affine2), _ptr(a), lda, _ptr(x), rows(x)[0], _ptr(y), rows(y)[0], _ptr(coef), B, S, Cc, _dt(a)))
+    return y
 
 
 def instnorm_pair_bwd(dy, y, xa, xb, B, S, stat_a, stat_b, styles, gammas_a, gammas_b, dgammas_a, dbetas_a, dgammas_b, dbetas_b, slope=0.01, eps=1e-5,

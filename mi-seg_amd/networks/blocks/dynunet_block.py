@@ -94,6 +94,10 @@ class UnetResBlock(nn.Module):
         """inp: channels-last activation; for a block fed by the raw image pass ``image`` (NCDHW fp32) instead.
         out_view: rows view the result is written into (HF.concat_buffer)."""
         _needs_modalities(self.norm1, styles)
+        if image is not None and image.shape[1] != 1:
+            # multi-channel image (--in_channels > 1, dynunet_block.py:82-98): rows of C channels through the ordinary kernels; the
+            # one-channel shortcuts below (rank-1 1x1x1 convolution, image-as-rows view) are a special case of the headline configuration
+            inp, image = HF.image_rows(image, dtype), None
         if image is not None:
             out = HF.conv3_thin(image, self.conv1.conv.weight, dtype)
             residual = _image_rows(image, dtype)
@@ -136,6 +140,8 @@ class UnetBasicBlock(nn.Module):
 
     def forward(self, inp, styles=None, image=None, dtype=None, out_view=None):
         _needs_modalities(self.norm1, styles)
+        if image is not None and image.shape[1] > 4:
+            inp, image = HF.image_rows(image, dtype), None
         out, st1 = (HF.conv3_thin(image, self.conv1.conv.weight, dtype), None) if image is not None else HF.conv3(inp, self.conv1.conv.weight, want_stat=True)
         out = apply_norm(self.norm1, out, styles, act=L.ACT_LEAKY, slope=LEAKY_SLOPE, stat=st1)
         out, st2 = HF.conv3(out, self.conv2.conv.weight, want_stat=True)

@@ -38,9 +38,15 @@ def get_norm_layer(name: Union[Tuple, str], spatial_dims: Optional[int] = 1, cha
     if key == "layer":
         kw.setdefault("normalized_shape", channels)
         return nn.LayerNorm(**kw)
-    if key in ("batch", "group", "localresponse", "syncbatch", "instance_nvfuser"):
+    if key == "batch":                                   # factories.py:240-243
+        kw.setdefault("num_features", channels)
+        return (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)[spatial_dims - 1](**kw)
+    if key == "group":                                   # factories.py:246-248 (num_groups comes with the spec: norms/utils.py:13-14)
+        kw.setdefault("num_channels", channels)
+        return nn.GroupNorm(**kw)
+    if key in ("localresponse", "syncbatch", "instance_nvfuser"):
         raise NotImplementedError(f"normalisation '{key}' is not implemented by the MI355X path "
-                                  "(supported: instance_cond, instance, layer)")
+                                  "(supported: instance_cond, instance, layer, batch, group)")
     raise ValueError(f"Unsupported option '{norm_name}'")
 
 
@@ -89,6 +95,22 @@ def apply_norm(norm: nn.Module, x, styles=None, res=None, act=L.ACT_NONE, slope=
     if isinstance(norm, _INSTANCE):
         params = [(norm.weight, norm.bias)] if norm.affine else None
         return HF.instance_norm(x, params, None, None, res=res, act=act, slope=slope, eps=norm.eps, stat=stat, out=out)
+    if isinstance(norm, (nn.GroupNorm, nn.modules.batchnorm._BatchNorm)):
+        if isinstance(norm, nn.GroupNorm):
+            y = HF.group_norm(x, norm.weight, norm.bias, norm.num_groups, norm.eps)
+        else:
+            y = HF.batch_norm(x, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.training, norm.momentum, norm.eps,
+                              norm.num_batches_tracked)
+        # (no fused residual / activation for these kinds: composed from the stand-alone kernels)
+        if res is not None:
+            y = HF.add(y, res)
+        if act == L.ACT_LEAKY:
+            y = HF.leaky_relu(y, slope)
+        if out is not None:
+            from ...hip import ops as _ops
+            _ops.copy2d(y, out)
+            y = out
+        return y
     if isinstance(norm, nn.LayerNorm):
         if res is not None or act != L.ACT_NONE:
             raise NotImplementedError("LayerNorm with fused residual / activation")

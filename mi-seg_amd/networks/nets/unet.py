@@ -35,9 +35,16 @@ class ADN(nn.Sequential):
         if norm is not None:
             ops["N"] = get_norm_layer(name=norm, spatial_dims=norm_dim, channels=in_channels)
         if act is not None:
-            if str(act).lower() != "prelu":
-                raise NotImplementedError(f"UNet activation '{act}' (only prelu is reproduced)")
-            ops["A"] = nn.PReLU()
+            # the reference hands --activation to MONAI's Act factory (networks/nets/unet.py:116-134, utils/parser.py:57): the kinds the HIP
+            # path has kernels for - prelu (one learned slope), relu / leakyrelu (the same kernels with a constant slope), gelu (exact erf)
+            kind = str(act[0] if isinstance(act, (tuple, list)) else act).lower()
+            kw = dict(act[1]) if isinstance(act, (tuple, list)) and len(act) > 1 else {}
+            makers = {"prelu": nn.PReLU, "relu": nn.ReLU, "leakyrelu": nn.LeakyReLU, "gelu": nn.GELU}
+            if kind not in makers:
+                raise NotImplementedError(f"UNet activation '{act}' is not implemented by the MI355X path (supported: {sorted(makers)})")
+            ops["A"] = makers[kind](**kw)
+            if kind == "gelu" and getattr(ops["A"], "approximate", "none") != "none":
+                raise NotImplementedError("GELU(approximate='tanh') is not implemented by the MI355X path (exact erf only)")
         if dropout is not None:
             ops["D"] = nn.Dropout(float(dropout))
         for item in ordering.upper():
@@ -180,9 +187,10 @@ class UNet(nn.Module):
         styles = styles_to_device(modalities, x.device, x.shape[0], styles_limit(self)) if modalities is not None else None
         ops.begin_forward(self.parameters())      # statistics-pool lifetime: hip/ops.py::_ZeroPool
         x = x.float().contiguous()
-        if self.in_channels > 4:
-            raise NotImplementedError("more than 4 image channels")
-        y = _run_block(self.model, None, styles, image=x, dtype=self.compute_dtype)
+        if self.in_channels > 4:      # (up to 4 channels the first convolution reads the NCDHW image itself)
+            y = _run_block(self.model, HF.image_rows(x, self.compute_dtype), styles)
+        else:
+            y = _run_block(self.model, None, styles, image=x, dtype=self.compute_dtype)
         return HF.to_ncdhw(y)
 
 
@@ -222,7 +230,14 @@ def _run_convolution(m: "Convolution", x, styles, image=None, dtype=None):
             if name == "N":
                 y = apply_norm(child, y, styles)
             elif name == "A":
-                y = HF.prelu(y, child.weight)
+                if isinstance(child, nn.PReLU):
+                    y = HF.prelu(y, child.weight)
+                elif isinstance(child, nn.GELU):
+                    y = HF.gelu(y)
+                elif isinstance(child, nn.LeakyReLU):
+                    y = HF.leaky_relu(y, child.negative_slope)
+                else:
+                    y = HF.leaky_relu(y, 0.0)                # ReLU
             elif name == "D":       # MONAI ADN, dropout_dim 1: nn.Dropout (the counter-based mask of miseg_dropout, identity in eval mode)
                 y = HF.dropout(y, child.p, child.training)
     return y
