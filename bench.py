@@ -408,11 +408,25 @@ def bench_sliding_window(a, model, dtype, dev, rank, world, dist):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # untimed: replays of the captured forward against the eager forward on window batches from the corners, the centre and the clamped
+    # last windows of the volume - `finite` alone let a replay bug through in round 2 (statistics pool recycled short: every replay after
+    # the first normalised with accumulated sums, logits 43 % off and perfectly finite)
+    grid = window_grid(size, (96, 96, 96), 0.5)
+    worst = 0.0
+    with torch.no_grad():
+        for i0 in (0, 348, 696, 4, 0):
+            xb = torch.cat([vol[:, :, d:d + 96, h:h + 96, w:w + 96] for (d, h, w) in grid[i0:i0 + sw]], 0).contiguous()
+            yg = pred(xb, [0] * sw).float().clone()
+            ye = model(xb, [0] * sw).float()
+            worst = max(worst, float((yg - ye).norm() / ye.norm()))
+    if not worst < 1e-2:
+        raise SystemExit(f"sliding window: the replayed forward is {worst:.3e} from the eager forward of the same window batch")
     out = {"metric": WORKLOADS["c5"][0], "value": world * a.steps * nwin / dt, "unit": "windows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": 1000 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
            "launch": "hipGraph", "config": {"workload": WORKLOADS["c5"][2], "windows_per_volume": nwin, "sw_batch_size": sw,
                                             "replicas": "one volume per GPU, no collective (windows are independent)"},
-           "finite": bool(torch.isfinite(y).all()), "volumes_per_s": world * a.steps / dt}
+           "finite": bool(torch.isfinite(y).all()), "replay_check": {"window_batches": 5, "worst_rel_err_vs_eager": worst},
+           "volumes_per_s": world * a.steps / dt}
     if rank == 0:
         if not a.no_roofline:
             from mi_seg_amd.testing.roofline import profile_step, summarize

@@ -579,8 +579,9 @@ class _Conv3(Function):
             if slot is not None and ops.defer_to_branch(x, dy, slot, mode):
                 pass
             elif slot is not None:
-                if ops.BRANCH_DEFERRED and ops.in_branch_backward():
-                    ops.flush_branch_deferred()
+                q = ops._queues(slot)
+                if q is not None and q.branch_deferred and ops.in_branch_backward():
+                    ops.flush_branch_deferred(q)
                 with ops.wgrad_side(x, dy, kind="conv"):
                     ops.conv3_wgrad(x, dy, dw=slot, accumulate=mode)
             else:

@@ -105,23 +105,36 @@ class _ZeroPool:
 
     def __init__(self, numel=1 << 20):
         self.numel, self.buf, self.off, self.high = numel, None, 0, 0
+        self.spilled = 0         # doubles of this step that live in chunks an overflow has left behind
         self._pinned = []
         self._filled = None      # (event recorded behind the zero fill of the current chunk, streams already ordered behind it)
 
     def take(self, n, device):
         n = (n + 1) & ~1
         if self.buf is None or self.buf.device != device or self.off + n > self.buf.numel():
-            self.high = max(self.high, self.off + n)
+            capturing = torch.cuda.is_current_stream_capturing()
+            if self.buf is not None:
+                self.spilled += self.off
+                if capturing:
+                    # Overflow INSIDE a hipGraph capture: the graph being recorded holds raw pointers into the chunk that is left behind, so it
+                    # must never be freed.  Round 3 found this the hard way: a GraphedForward captured as the first GPU work of a process (the
+                    # 1 M-double first chunk overflows several times in a batch-4 fs=48 forward) kept only its LAST chunk alive; the others
+                    # went back to the allocator, were handed to the window batches of the sliding-window loop, and every replay after the
+                    # first normalised with statistics that other tensors had been written over (logits 43 % off, finite, unnoticed by a
+                    # finiteness check; tests/test_hip_training.py::test_full_volume_sliding_window_of_the_headline_model).
+                    self.pin()
+            # the next chunk holds what the WHOLE step has needed so far, not just the chunk that overflowed: one overflow per step at most
+            self.high = max(self.high, self.spilled + n)
             self.buf = torch.empty(max(self.numel, n, int(self.high * 1.5)), dtype=torch.float64, device=device)
             lib = L.load()
             L.check(lib.miseg_fill32(_ptr(self.buf), 0, self.buf.numel() * 2, _stream()), "fill32")
             self.off = 0
             self._filled = None
-            if not torch.cuda.is_current_stream_capturing():
+            if not capturing:
                 ev = torch.cuda.Event()
                 ev.record()
                 self._filled = (ev, {torch.cuda.current_stream().cuda_stream})
-        elif self._filled is not None:
+        elif self._filled is not None and not torch.cuda.is_current_stream_capturing():
             # A chunk is zero-filled on the stream that happened to need it first.  A model's side branch (SwinUNETR / UNETR) takes buffers of
             # the same chunk on ANOTHER stream: ordered behind the fill only if that stream happened to wait for the first one after the
             # fill was queued - true for the chunk a forward starts with, not for one that an overflow starts in the middle of a branch.
@@ -133,20 +146,27 @@ class _ZeroPool:
                 self._filled[1].add(cs.cuda_stream)
         t = self.buf[self.off:self.off + n]
         self.off += n
-        self.high = max(self.high, self.off)
+        self.high = max(self.high, self.spilled + self.off)
         return t
 
     def begin_step(self):
         """call once per training step, after the previous step's backward has been enqueued: recycles the pool."""
-        if self.buf is not None and self.off > 0:
+        # The WHOLE chunk is zeroed, not the part the previous step used: a chunk an overflow started late in the warm-up step holds only
+        # that step's tail ([0, off)), while the step being captured takes its buffers from the chunk's beginning and walks past `off` into
+        # memory that was zero when the chunk was created - and never again: every replay after the first added its statistics to the
+        # previous replay's (round 3, found with a GraphedForward captured as the first GPU work of a process; see take()).
+        if self.buf is not None:
             lib = L.load()
-            L.check(lib.miseg_fill32(_ptr(self.buf), 0, self.off * 2, _stream()), "fill32")
+            L.check(lib.miseg_fill32(_ptr(self.buf), 0, self.buf.numel() * 2, _stream()), "fill32")
             self.off = 0
+        self.spilled = 0
 
     def fresh(self):
         """start the next forward on a new chunk (unless the current one is untouched); see the class docstring"""
         if self.buf is not None and self.off > 0 and not torch.cuda.is_current_stream_capturing():
             self.buf, self.off, self._filled = None, 0, None
+        if not torch.cuda.is_current_stream_capturing():
+            self.spilled = 0
 
     def pin(self):
         """keep the current chunk alive for good: a captured hipGraph holds raw pointers into it"""
@@ -504,8 +524,8 @@ BACKGROUND_WORKGROUPS = 32     # cap of the branch's own background weight-gradi
 DEFERRED_WORKGROUPS = 64       # cap of the main stream's deferred weight gradients (defer_to_branch).  (own cap, this cap) on one box, no branch =
                                # 132.6, branch alone 134.5: (24, 48) 136.9, (24, 64) 140.8, (24, 96) 139.8, (48, 64) 140.6, (64, 64) 140.7, (32, 32) 128.9
 DEFER_MIN_ROWS = 400000        # 96^3 layers only (the smaller ones are grouped into one launch at the end of the backward pass)
-BRANCH_DEFERRED = None         # while a model's side branch is open: [(x, dy, slot, mode)] - full-size conv weight gradients of the MAIN stream
-                               # (SwinUNETR: decoder1's two 96^3 layers) that wait for the branch's backward pass and run at its head, in background form
+# (round 3: the queue of deferred launches itself lives on the training arena's StepQueues - `branch_deferred` - and is found through the
+# gradient slot a launch accumulates into, like the other per-step queues: two models in one process no longer share it)
 
 
 def branch_stream(device):
@@ -517,21 +537,48 @@ def branch_stream(device):
     return _BRANCH_STREAM
 
 
-def defer_to_branch(x, dy, slot, mode):
-    """True when the conv weight gradient (x, dy) -> slot was queued for the head of the side branch's backward pass: leaf work of the main
-    stream's full-size kernels (0.3 ms per step on the critical path) that then runs beside the small-grid launches instead"""
-    if BRANCH_DEFERRED is None or in_branch_backward() or rows(x)[1] < DEFER_MIN_ROWS:
+def open_branch_deferral(params):
+    """a model's forward opens the deferral for this step: full-size conv weight gradients of the MAIN stream (SwinUNETR: decoder1's two 96^3
+    layers) wait for the side branch's backward pass and run at its head, in background form.  Needs a training arena (the queue lives on
+    its StepQueues); returns False without one."""
+    q = _arena_queues(params)
+    if q is None:
         return False
-    BRANCH_DEFERRED.append((x, dy, slot, mode))
+    q.branch_deferred = []
     return True
 
 
-def flush_branch_deferred():
+def close_branch_deferral(params):
+    q = _arena_queues(params)
+    if q is not None:
+        q.branch_deferred = None
+
+
+def _arena_queues(params):
+    for p in params:
+        arena = getattr(p, "_miseg_arena", None)
+        return QUEUES.get(arena._qkey) if arena is not None else None
+    return None
+
+
+def defer_to_branch(x, dy, slot, mode):
+    """True when the conv weight gradient (x, dy) -> slot was queued for the head of the side branch's backward pass: leaf work of the main
+    stream's full-size kernels (0.3 ms per step on the critical path) that then runs beside the small-grid launches instead"""
+    q = _queues(slot)
+    if q is None or q.branch_deferred is None or in_branch_backward() or rows(x)[1] < DEFER_MIN_ROWS:
+        return False
+    q.branch_deferred.append((x, dy, slot, mode))
+    return True
+
+
+def flush_branch_deferred(q):
     """launch what `defer_to_branch` queued on the current stream (the branch's, in background form; join_branch's as a fallback)"""
-    global BRANCH_DEFERRED, BACKGROUND_WORKGROUPS
-    items, BRANCH_DEFERRED = BRANCH_DEFERRED, None
-    if not items:
+    global BACKGROUND_WORKGROUPS
+    if q is None or not q.branch_deferred:
+        if q is not None:
+            q.branch_deferred = None
         return
+    items, q.branch_deferred = q.branch_deferred, None
     keep, BACKGROUND_WORKGROUPS = BACKGROUND_WORKGROUPS, DEFERRED_WORKGROUPS
     try:
         for x, dy, slot, mode in items:
@@ -541,11 +588,14 @@ def flush_branch_deferred():
     _WGRAD_KEEP.extend(t for it in items for t in it[:2])      # alive until join_wgrad
 
 
-def join_branch(flush_deferred=True):
+def join_branch(flush_deferred=True, queues=None):
     """the current stream waits for the branch stream: before anything that consumes what the branch's backward produced (the queued
-    weight-gradient launches of arena.end_backward, the optimiser, the end of a hipGraph capture)"""
-    if BRANCH_DEFERRED and flush_deferred:                # the branch's backward never ran (nothing in it needed a gradient): here and now
-        flush_branch_deferred()
+    weight-gradient launches of arena.end_backward, the optimiser, the end of a hipGraph capture).  queues: the arena's StepQueues whose
+    deferred launches are issued here when the branch's backward never ran (nothing in it needed a gradient)."""
+    if flush_deferred:
+        for q in ([queues] if queues is not None else list(QUEUES.values())):
+            if q.branch_deferred:
+                flush_branch_deferred(q)
     if _BRANCH_STREAM is not None:
         torch.cuda.current_stream().wait_stream(_BRANCH_STREAM)
 
@@ -581,6 +631,7 @@ class StepQueues:
 
     def __init__(self):
         self.colsum, self.gemm_tn, self.tn_reduce, self.conv_wgrad = [], [], [], []
+        self.branch_deferred = None      # while the model's side branch is open: [(x, dy, slot, mode)], see defer_to_branch
 
     def flush(self):
         _flush_conv_wgrads(self.conv_wgrad)

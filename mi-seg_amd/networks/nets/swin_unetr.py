@@ -247,10 +247,9 @@ class SwinUNETR(nn.Module):
             if cut is not None:
                 enc1, enc0 = leaf(enc1), leaf(enc0)
         if branch and cut is not None and not self.split_defers:
-            ops.BRANCH_DEFERRED = None     # split step: the decoder side's gradients are all-reduced right after the first half - nothing of it may wait
+            ops.close_branch_deferral(self.parameters())     # split step: the decoder side's gradients are all-reduced right after the first half - nothing of it may wait
         if branch and (cut is None or self.split_defers) and os.environ.get("MISEG_NO_DEFER") is None:
-            ops.DEFERRED_WORKGROUPS = 64
-            ops.BRANCH_DEFERRED = []       # decoder1's two 96^3 weight gradients wait for the branch's backward pass (hip/ops.py::defer_to_branch)
+            ops.open_branch_deferral(self.parameters())       # decoder1's two 96^3 weight gradients wait for the branch's backward pass (hip/ops.py::defer_to_branch)
         dec0 = self.decoder2(dec1, enc1, styles)
         out = self.decoder1(dec0, enc0, styles)
         return self.out(out)

@@ -109,7 +109,7 @@ class UNETR(nn.Module):
                     t.record_stream(side)
             with torch.cuda.stream(side):
                 enc1 = self.encoder1(None, styles, image=x_in, dtype=dt)
-            ops.BRANCH_DEFERRED = None       # decoder2's 96^3 weight gradients stay where they are: at 16 channels they are long launches (0.29 ms)
+            ops.close_branch_deferral(self.parameters())       # decoder2's 96^3 weight gradients stay where they are: at 16 channels they are long launches (0.29 ms)
                                              # that become the critical path when throttled and gain nothing un-throttled (133.2 -> 123 .. 132.9)
         else:
             enc1 = self.encoder1(None, styles, image=x_in, dtype=dt)

@@ -244,7 +244,7 @@ class ParamArena:
     def end_backward(self):
         """issue the queued bias-gradient column sums (one launch per 32); call after loss.backward(), inside the captured
         region when the step is a hipGraph.  publish() / allreduce() call it too."""
-        ops.join_branch()          # the queued launches below read what a model's side branch produced
+        ops.join_branch(queues=self.queues)          # the queued launches below read what a model's side branch produced
         if self.queues is not None:
             self.queues.flush()
             self.queues = None
@@ -254,7 +254,7 @@ class ParamArena:
 
     def flush(self):
         """issue everything queued so far and keep queueing (between the two halves of a split backward pass)."""
-        ops.join_branch(flush_deferred=False)      # (weight gradients deferred to the branch's backward pass wait for the second half)
+        ops.join_branch(flush_deferred=False, queues=self.queues)      # (weight gradients deferred to the branch's backward pass wait for the second half)
         if self.queues is not None:
             self.queues.flush()
 

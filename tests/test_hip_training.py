@@ -270,6 +270,55 @@ def test_full_size_volume_stitching_properties():
         assert float((out[c] - (zz + c)).abs().max()) < 1e-3       # sum of <= 8 equal values / count: exact up to one rounding of the sum
 
 
+def test_full_volume_sliding_window_of_the_headline_model():
+    """BASELINE configs[4] end to end (lightning_monai.py:86-93,181-195): the fs=48 C-Swin-UNETR over the whole 512 x 512 x 363 volume, 700
+    windows in batches of 4 through `GraphedForward` (hipGraph replays on the arena's weight copies) and the gather-stitch.  Checked:
+    finiteness, and - on 9 windows sampled over the grid (corners, centre, the clamped last windows) - that the window logits the stitcher
+    received equal an eager per-window forward of the same model, and that voxels covered by exactly one window carry that window's logits."""
+    from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
+    from mi_seg_amd.runtime.arena import ParamArena
+    from mi_seg_amd.runtime.graph import GraphedForward
+    from mi_seg_amd.training import inferer
+    from mi_seg_amd.utils.detfill import fill_module_
+    m = SwinUNETR((96, 96, 96), 1, 6, feature_size=48, num_heads=(3, 6, 12, 24), vit_norm_name=_norm("instance_cond"),
+                  encoder_norm_name=_norm("instance_cond"), decoder_norm_name=_norm("instance"))
+    fill_module_(m)
+    m = m.to(DEV).set_compute_dtype(torch.bfloat16).eval()
+    size, roi, sw = (512, 512, 363), (96, 96, 96), 4
+    vol = torch.rand(1, 1, *size, generator=torch.Generator().manual_seed(77)).to(DEV)
+    grid = inferer.window_grid(size, roi, 0.5)
+    assert len(grid) == 700
+    arena = ParamArena(list(m.parameters()), torch.bfloat16)
+    try:
+        pred = GraphedForward(m, (sw, 1) + roi, arena=arena)
+        seen = {}
+
+        def predictor(x, mods):
+            y = pred(x, mods)
+            i = predictor.n
+            for j in range(x.shape[0]):
+                if i + j in picks:
+                    seen[i + j] = y[j].clone()
+            predictor.n += x.shape[0]
+            return y
+        predictor.n = 0
+        picks = {0, 6, 7 * 7 - 1, 349, 350, 699 - 6, 699, 343, 57}
+        out = inferer.sliding_window_inference(vol, roi, sw, predictor, overlap=0.5, modalities=[1])
+        assert tuple(out.shape) == (1, 6) + size and bool(torch.isfinite(out).all())
+        assert sorted(seen) == sorted(picks)
+        with torch.no_grad():
+            for i in sorted(picks):
+                d, h, w = grid[i]
+                ye = m(vol[:, :, d:d + 96, h:h + 96, w:w + 96].contiguous(), [1])[0]
+                # the graphed forward runs the window in a batch of 4 (the norms are per sample, the kernels the same): bf16 bits may differ in the
+                # order of a reduction, nothing more
+                assert rel_err(seen[i], ye) < 2e-2, (i, rel_err(seen[i], ye))
+        # a voxel covered by ONE window only (the volume's first corner) carries that window's logits
+        assert torch.equal(out[0, :, :48, :48, :48], seen[0][:, :48, :48, :48])
+    finally:
+        arena.detach()
+
+
 @pytest.fixture(scope="module")
 def oracle_trained():
     """fs=12 C-Swin-UNETR trained for 12 AdamW steps by the CPU oracle (DiceFocal, include_background=False, like LitMonai) on random 96^3
