@@ -1112,18 +1112,23 @@ static constexpr int WG_GROUP_MAX = 24;
 struct WgradGroup { WgradLayer l[WG_GROUP_MAX]; int n; };
 
 template <class T, int WBD>
-__global__ void __launch_bounds__(WG_THREADS) conv3_wgrad_group_kernel(const WgradGroup grp, int rowb) {
-  int li = 0;
-  for (int i = 1; i < grp.n; ++i)
-    if ((int)blockIdx.x >= grp.l[i].wg0) li = i;
-  const WgradLayer& L = grp.l[li];
-  const int local = blockIdx.x - L.wg0;
-  if (std::is_same<T, bf16>::value && ((L.flags >> 4) & 1))
-    conv3_wgrad_body<T, WBD, true>((const T*)L.x, L.ldx, (const T*)L.dy, L.lddy, L.slabs, L.dw, L.g, L.Cin, L.Cout, L.ncib, L.nsplit, rowb, true, true,
-                                   local % L.nsplit, local / L.nsplit, (L.flags >> 2) & 3, ((L.nsplit | L.wg0) & 7) == 0);
-  else
-    conv3_wgrad_body<T, WBD, false>((const T*)L.x, L.ldx, (const T*)L.dy, L.lddy, L.slabs, L.dw, L.g, L.Cin, L.Cout, L.ncib, L.nsplit, rowb, L.flags & 1,
-                                    (L.flags >> 1) & 1, local % L.nsplit, local / L.nsplit, (L.flags >> 2) & 3, ((L.nsplit | L.wg0) & 7) == 0);
+__global__ void __launch_bounds__(WG_THREADS) conv3_wgrad_group_kernel(const WgradGroup grp, int rowb, int total_units) {
+  // one unit = one (layer, channel pair, split).  Normal form: one workgroup per unit.  Background form (max_workgroups of the first
+  // descriptor: the launch runs on a side stream beside another stream's kernels): a capped grid walks the units, longest layers first.
+  for (int unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
+    if (unit != (int)blockIdx.x) __syncthreads();      // the LDS images of the previous unit have been read
+    int li = 0;
+    for (int i = 1; i < grp.n; ++i)
+      if (unit >= grp.l[i].wg0) li = i;
+    const WgradLayer& L = grp.l[li];
+    const int local = unit - L.wg0;
+    if (std::is_same<T, bf16>::value && ((L.flags >> 4) & 1))
+      conv3_wgrad_body<T, WBD, true>((const T*)L.x, L.ldx, (const T*)L.dy, L.lddy, L.slabs, L.dw, L.g, L.Cin, L.Cout, L.ncib, L.nsplit, rowb, true, true,
+                                     local % L.nsplit, local / L.nsplit, (L.flags >> 2) & 3, ((L.nsplit | L.wg0) & 7) == 0);
+    else
+      conv3_wgrad_body<T, WBD, false>((const T*)L.x, L.ldx, (const T*)L.dy, L.lddy, L.slabs, L.dw, L.g, L.Cin, L.Cout, L.ncib, L.nsplit, rowb, L.flags & 1,
+                                      (L.flags >> 1) & 1, local % L.nsplit, local / L.nsplit, (L.flags >> 2) & 3, ((L.nsplit | L.wg0) & 7) == 0);
+  }
 }
 
 // dw[co][ci0..+48][tap] += sum over this group's splits of slab[pair][split][co%48][tap][0..48).
@@ -1482,7 +1487,8 @@ static int conv3_wgrad_group_launch(const miseg_conv3_wgrad_params* descs, int n
     }
   }
   hipFuncSetAttribute((const void*)conv3_wgrad_group_kernel<T, WBD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  conv3_wgrad_group_kernel<T, WBD><<<wg, WG_THREADS, lds, s>>>(grp, rowb);
+  const int cap = descs[0].max_workgroups;      // > 0: background form (see the kernel)
+  conv3_wgrad_group_kernel<T, WBD><<<(cap > 0 && cap < wg) ? cap : wg, WG_THREADS, lds, s>>>(grp, rowb, wg);
   if (rb > 0) conv3_wgrad_reduce_group_kernel<<<rb, 256, 0, s>>>(grp);
   MISEG_LAUNCH_CHECK("conv3_wgrad_group");
   return MISEG_OK;

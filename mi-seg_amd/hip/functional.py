@@ -799,6 +799,7 @@ class _Conv3Thin(Function):
             dy = _rv(dy)
             if slot is not None:
                 ops.conv3_thin_wgrad(xr, dy, slot)
+                ops.early_group_flush(ops._queues(slot))      # the stem's weight gradient is the last node of a side branch's backward pass
                 return None, None, None
             return None, ops.conv3_thin_wgrad(xr, dy, ops.zeros_f32(ctx.wshape, dy.device)), None
         if slot is not None:

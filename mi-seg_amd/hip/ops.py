@@ -523,6 +523,7 @@ BACKGROUND_WORKGROUPS = 32     # cap of the branch's own background weight-gradi
                                # two boxes, before the deferral below: 256 (no cap) -0.4 %, 128 +1.0, 64 +1.4, 32 +2.0 / +2.4, 16 +2.0, 8 -3.8
 DEFERRED_WORKGROUPS = 64       # cap of the main stream's deferred weight gradients (defer_to_branch).  (own cap, this cap) on one box, no branch =
                                # 132.6, branch alone 134.5: (24, 48) 136.9, (24, 64) 140.8, (24, 96) 139.8, (48, 64) 140.6, (64, 64) 140.7, (32, 32) 128.9
+GROUP_EARLY_WORKGROUPS = int(os.environ.get("MISEG_EARLY_GROUP_WG", "0"))      # cap of the early (branch-stream) grouped weight-gradient launch; 0 = off
 DEFER_MIN_ROWS = 400000        # 96^3 layers only (the smaller ones are grouped into one launch at the end of the backward pass)
 # (round 3: the queue of deferred launches itself lives on the training arena's StepQueues - `branch_deferred` - and is found through the
 # gradient slot a launch accumulates into, like the other per-step queues: two models in one process no longer share it)
@@ -586,6 +587,17 @@ def flush_branch_deferred(q):
     finally:
         BACKGROUND_WORKGROUPS = keep
     _WGRAD_KEEP.extend(t for it in items for t in it[:2])      # alive until join_wgrad
+
+
+
+def early_group_flush(q):
+    """at the TAIL of the side branch's backward pass (its last node calls this): the small layers' weight gradients queued so far go out on
+    the branch stream as one grouped launch in background form, beside what the main stream has left of its small-grid chain - instead of
+    after it, at the very end of the step.  (At the HEAD of the branch the same launch made the branch the critical path: 145.4 -> 134.7
+    patches/s with 64 workgroups, 141.1 with 128.)  GROUP_EARLY_WORKGROUPS = 0 switches it off."""
+    if q is None or not q.conv_wgrad or not GROUP_EARLY_WORKGROUPS or not in_branch_backward():
+        return
+    _flush_conv_wgrads(q.conv_wgrad, background=GROUP_EARLY_WORKGROUPS)
 
 
 def join_branch(flush_deferred=True, queues=None):
@@ -805,7 +817,10 @@ def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False):
 CONV_WGRAD_GROUP_VOXELS = 48 ** 3   # layers up to this many voxels are queued: alone they fill a fraction of the chip for 40-85 us each
 
 
-def _flush_conv_wgrads(q):
+def _flush_conv_wgrads(q, background=0):
+    """background > 0: the grouped launch walks its units with that many workgroups (miseg_conv3_wgrad_params.max_workgroups of the first
+    descriptor) - issued on the side-branch stream beside the main stream's small-grid launches; operands and workspace stay alive until
+    join_wgrad (the queue that held them is cleared here, and the allocator knows nothing about the branch stream's reads)"""
     if not q:
         return
     lib = L.load()
@@ -818,10 +833,13 @@ def _flush_conv_wgrads(q):
                 B, D, H, W = _vol(x)
                 ldx, _, Cin = rows(x)
                 lddy, _, Cout = rows(dy)
-                descs[j] = L.Conv3Wgrad(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), B, D, H, W, Cin, Cout, _dt(x), acc, None)
+                descs[j] = L.Conv3Wgrad(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), B, D, H, W, Cin, Cout, _dt(x), acc, None, int(background) if j == 0 else 0)
             wsb = lib.miseg_conv3_wgrad_group_workspace_bytes(descs, len(chunk))
             ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32, device=chunk[0][0].device)
             L.check(lib.miseg_conv3_wgrad_group(descs, len(chunk), _ptr(ws), _stream()), "conv3_wgrad_group")
+            if background:
+                _WGRAD_KEEP.append(ws)
+                _WGRAD_KEEP.extend(t for it in chunk for t in it[:2])
     q.clear()
 
 
