@@ -1098,6 +1098,164 @@ __global__ void __launch_bounds__(WG_THREADS) conv3_wgrad_kernel(const T* __rest
                                   (nsplit & 7) == 0);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient of NARROW layers (round 3; bf16, Cin and Cout in {16, 32}: every 3x3x3 convolution of C-UNETR's image- and half-resolution
+// blocks, networks/nets/unetr.py:254-276).  The 48 x 48 channel-pair kernel above spends 9 MFMAs per (tap, k-step) on a tile of which 1/9
+// (16 x 16) is real and walks its non-pipelined loop: 0.9 ms per 96^3 layer, 27 % of the C-UNETR step's kernel time.  Here a workgroup owns
+// whole 16 x NCO by 16 x NCI tiles: per brick (4 x 8 x 8 voxels = 8 k-steps of 32) each of its four waves takes 7 of the 27 taps,
+// 8 x 7 x NCO x NCI MFMAs; bricks are walked persistently, two workgroups per CU (one stages while the other multiplies), the partial
+// sums of a workgroup leave as ONE fp32 slab [tap][co][ci] and a second launch adds the slabs up in a fixed order (no atomics: reproducible).
+// Operands are the transposed LDS reads of the kernel above (k = voxels: 4 h-rows x 8 w of one depth per k-step).
+// ---------------------------------------------------------------------------------------------------------
+template <int NCO, int NCI>
+__global__ void __launch_bounds__(WG_THREADS, 2) conv3_wgrad_narrow_kernel(const bf16* __restrict__ x, int64_t ldx, const bf16* __restrict__ dy, int64_t lddy,
+                                                                           float* __restrict__ slabs, ConvGeom g) {
+  constexpr int WBD = 4, NVOX = WBD * BH * BW, HROWS = (WBD + 2) * HH * HW;
+  constexpr int CI = 16 * NCI, CO = 16 * NCO;
+  constexpr int RBX = CI * 2 + 16, RBD = CO * 2 + 16;      // padded LDS rows (bytes): conflict-free transposed reads
+  constexpr int GX = CI / 8, GD = CO / 8;                  // 16-byte groups per row
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* lx = lds;
+  char* ld = lds + HROWS * RBX;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fi = lane & 15, fq = lane >> 4, qq = fi >> 2, p4 = (fi & 3) * 4;
+  f32x4 acc[WG_TPW][NCO][NCI];
+#pragma unroll
+  for (int t = 0; t < WG_TPW; ++t)
+#pragma unroll
+    for (int i = 0; i < NCO; ++i)
+#pragma unroll
+      for (int j = 0; j < NCI; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int toff[WG_TPW];
+#pragma unroll
+  for (int t = 0; t < WG_TPW; ++t) {
+    const int tap = wave + WG_WAVES * t;
+    toff[t] = tap < 27 ? (((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3) : 0;
+  }
+  const int nbricks = g.B * g.nbd * g.nbh * g.nbw;
+  for (int brick = blockIdx.x; brick < nbricks; brick += gridDim.x) {
+    int bid = brick;
+    const int bw = bid % g.nbw; bid /= g.nbw;
+    const int bh = bid % g.nbh; bid /= g.nbh;
+    const int bd = bid % g.nbd;
+    const int b = bid / g.nbd;
+    const int d0 = bd * WBD, h0 = bh * BH, w0 = bw * BW;
+    __syncthreads();      // every wave is done with the previous brick's images
+    for (int idx = tid; idx < HROWS * GX; idx += WG_THREADS) {
+      const int row = idx / GX, cg = idx - row * GX;
+      const int hd = row / (HH * HW), rem = row - hd * (HH * HW);
+      const int hh = rem / HW, hw = rem - hh * HW;
+      const int d = d0 - 1 + hd, h = h0 - 1 + hh, w = w0 - 1 + hw;
+      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (d >= 0 && d < g.D && h >= 0 && h < g.H && w >= 0 && w < g.W) v = *reinterpret_cast<const bf16x8*>(x + ((((int64_t)b * g.D + d) * g.H + h) * g.W + w) * ldx + cg * 8);
+      *reinterpret_cast<bf16x8*>(lx + row * RBX + cg * 16) = v;
+    }
+    for (int idx = tid; idx < NVOX * GD; idx += WG_THREADS) {
+      const int row = idx / GD, cg = idx - row * GD;
+      const int vd = row / (BH * BW), rem = row - vd * (BH * BW);
+      const int vh = rem / BW, vw = rem - vh * BW;
+      const int d = d0 + vd, h = h0 + vh, w = w0 + vw;
+      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (d < g.D && h < g.H && w < g.W) v = *reinterpret_cast<const bf16x8*>(dy + ((((int64_t)b * g.D + d) * g.H + h) * g.W + w) * lddy + cg * 8);
+      *reinterpret_cast<bf16x8*>(ld + row * RBD + cg * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int ks = 0; ks < NVOX / 32; ++ks) {
+      if (d0 + (ks >> 1) >= g.D || h0 + (ks & 1) * 4 >= g.H) continue;      // k-step entirely outside the volume: all zeros
+      const int vd = ks >> 1, vh = (ks & 1) * 4 + fq;
+      const int vrow = (vd * BH + vh) * BW + qq;       // rows supplied by this lane for the two transposed reads: w = qq and w = 4 + qq
+      const int hrow = (vd * HH + vh) * HW + qq;       // halo row at tap (0, 0, 0)
+      bf16x8 af[NCO];
+#pragma unroll
+      for (int mt = 0; mt < NCO; ++mt) {
+        const char* a1 = ld + vrow * RBD + (mt * 16 + p4) * 2;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1 + 4 * RBD));
+        af[mt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int t = 0; t < WG_TPW; ++t) {       // (the last wave's 7th slot re-computes tap 0 into accumulators nobody stores)
+        bf16x8 bfr[NCI];
+#pragma unroll
+        for (int nt = 0; nt < NCI; ++nt) {
+          const char* a1 = lx + (hrow + toff[t]) * RBX + (nt * 16 + p4) * 2;
+          bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1));
+          bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a1 + 4 * RBX));
+          bfr[nt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int mt = 0; mt < NCO; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NCI; ++nt) acc[t][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[mt], acc[t][mt][nt], 0, 0, 0);
+      }
+    }
+  }
+  // slab[workgroup][tap][co][ci]; swapped operands => lane holds ci = 16 nt + 4 fq + r, co = 16 mt + fi
+  float* slab = slabs + (int64_t)blockIdx.x * 27 * CO * CI;
+#pragma unroll
+  for (int t = 0; t < WG_TPW; ++t) {
+    const int tap = wave + WG_WAVES * t;
+    if (tap < 27) {
+#pragma unroll
+      for (int mt = 0; mt < NCO; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NCI; ++nt) *reinterpret_cast<f32x4*>(slab + ((int64_t)tap * CO + mt * 16 + fi) * CI + nt * 16 + fq * 4) = acc[t][mt][nt];
+    }
+  }
+}
+
+// dw[co][ci][tap] (torch layout) (+)= sum over the workgroups' slabs [tap][co][ci], in slab order
+__global__ void __launch_bounds__(256) conv3_wgrad_narrow_reduce_kernel(const float* __restrict__ slabs, int nslabs, float* __restrict__ dw, int Cin, int Cout, int accumulate) {
+  const int n = 27 * Cout * Cin;
+  const int e = blockIdx.x * 256 + threadIdx.x;      // e = (tap, co, ci), ci fastest: coalesced slab reads
+  if (e >= n) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int k = 0;
+  for (; k + 3 < nslabs; k += 4) {
+    a0 += slabs[(int64_t)k * n + e];
+    a1 += slabs[(int64_t)(k + 1) * n + e];
+    a2 += slabs[(int64_t)(k + 2) * n + e];
+    a3 += slabs[(int64_t)(k + 3) * n + e];
+  }
+  for (; k < nslabs; ++k) a0 += slabs[(int64_t)k * n + e];
+  const float v = (a0 + a1) + (a2 + a3);
+  const int ci = e % Cin, co = (e / Cin) % Cout, tap = e / (Cin * Cout);
+  float* dst = dw + ((int64_t)co * Cin + ci) * 27 + tap;
+  *dst = accumulate == 1 ? *dst + v : v;
+}
+
+static constexpr int WG_NARROW_MAX_WG = 512;      // two workgroups per CU
+static bool wgrad_narrow(const miseg_conv3_wgrad_params* p) {
+  return p->dtype == MISEG_BF16 && (p->Cin == 16 || p->Cin == 32) && (p->Cout == 16 || p->Cout == 32) && ((uintptr_t)p->x % 16 == 0) && ((uintptr_t)p->dy % 16 == 0) &&
+         p->ldx % 8 == 0 && p->lddy % 8 == 0;
+}
+static int wgrad_narrow_workgroups(const miseg_conv3_wgrad_params* p) {
+  const int nbricks = p->B * cdiv(p->D, 4) * cdiv(p->H, BH) * cdiv(p->W, BW);
+  int wg = nbricks < WG_NARROW_MAX_WG ? nbricks : WG_NARROW_MAX_WG;
+  if (p->max_workgroups > 0 && p->max_workgroups < wg) wg = p->max_workgroups;      // background form
+  return wg;
+}
+static int conv3_wgrad_narrow_launch(const miseg_conv3_wgrad_params* p, hipStream_t s) {
+  ConvGeom g{p->B, p->D, p->H, p->W, cdiv(p->D, 4), cdiv(p->H, BH), cdiv(p->W, BW)};
+  const int wg = wgrad_narrow_workgroups(p);
+  const size_t lds = (size_t)6 * HH * HW * (p->Cin * 2 + 16) + (size_t)4 * BH * BW * (p->Cout * 2 + 16);
+#define NARROW_LAUNCH(A, B_)                                                                                                              \
+  do {                                                                                                                                    \
+    MISEG_SET_SMEM((conv3_wgrad_narrow_kernel<A, B_>), lds);                                                                                \
+    conv3_wgrad_narrow_kernel<A, B_><<<wg, WG_THREADS, lds, s>>>((const bf16*)p->x, p->ldx, (const bf16*)p->dy, p->lddy, (float*)p->workspace, g); \
+  } while (0)
+  if (p->Cout == 16 && p->Cin == 16) NARROW_LAUNCH(1, 1);
+  else if (p->Cout == 16) NARROW_LAUNCH(1, 2);
+  else if (p->Cin == 16) NARROW_LAUNCH(2, 1);
+  else NARROW_LAUNCH(2, 2);
+#undef NARROW_LAUNCH
+  const int n = 27 * p->Cout * p->Cin;
+  conv3_wgrad_narrow_reduce_kernel<<<cdiv(n, 256), 256, 0, s>>>((const float*)p->workspace, wg, p->dw, p->Cin, p->Cout, p->accumulate);
+  MISEG_LAUNCH_CHECK("conv3_wgrad (narrow)");
+  return MISEG_OK;
+}
+
 // Several layers in one launch (the small-grid weight gradients of a backward pass, queued by the host): descriptors travel
 // in the kernel arguments, a workgroup finds its layer by its index range.
 struct WgradLayer {
@@ -1367,7 +1525,12 @@ extern "C" size_t miseg_conv3_wgrad_workspace_bytes(int B, int D, int H, int W, 
   wgrad_plan(B, D, H, W, Cin, Cout, 2, &ncob, &ncib, &ns2);
   wgrad_plan(B, D, H, W, Cin, Cout, 4, &ncob, &ncib, &ns4);
   const int ns = ns2 > ns4 ? ns2 : ns4;
-  return (size_t)ncob * ncib * ns * 27 * WG_CB * WG_CB * sizeof(float);
+  size_t need = (size_t)ncob * ncib * ns * 27 * WG_CB * WG_CB * sizeof(float);
+  if ((Cin == 16 || Cin == 32) && (Cout == 16 || Cout == 32)) {      // the narrow-layer kernel: one slab per workgroup
+    const size_t nar = (size_t)WG_NARROW_MAX_WG * 27 * Cin * Cout * sizeof(float);
+    if (nar > need) need = nar;
+  }
+  return need;
 }
 
 template <class T, int WBD>
@@ -1520,6 +1683,7 @@ extern "C" int miseg_conv3_wgrad(const miseg_conv3_wgrad_params* p, miseg_stream
   MISEG_REQUIRE(p && p->x && p->dy && p->dw && p->workspace, MISEG_E_BADARG, "conv3_wgrad: null pointer");
   MISEG_REQUIRE(p->B > 0 && p->D > 0 && p->H > 0 && p->W > 0 && p->Cin > 0 && p->Cout > 0, MISEG_E_BADARG, "conv3_wgrad: bad shape");
   if (p->dtype == MISEG_F32) return conv3_wgrad_launch<float, 2>(p, (hipStream_t)s_);
+  if (p->dtype == MISEG_BF16 && wgrad_narrow(p)) return conv3_wgrad_narrow_launch(p, (hipStream_t)s_);
   if (p->dtype == MISEG_BF16) return conv3_wgrad_launch<bf16, 4>(p, (hipStream_t)s_);
   return set_error(MISEG_E_BADARG, "conv3_wgrad: dtype %d", p->dtype);
 }

@@ -854,7 +854,9 @@ def conv3_wgrad(x, dy, dw=None, accumulate=False):
         dw = torch.empty(Cout, Cin, 3, 3, 3, dtype=torch.float32, device=x.device)
         accumulate = False
     q = _queues(dw) if accumulate else None
-    if q is not None and PROFILE_HOOK is None and B * D * H * W <= CONV_WGRAD_GROUP_VOXELS:
+    # (narrow bf16 layers - 16 / 32 channels on both sides - have a kernel of their own that finishes a 48^3 layer in ~10 us: never queued)
+    narrow = x.dtype == torch.bfloat16 and Cin in (16, 32) and Cout in (16, 32)
+    if q is not None and PROFILE_HOOK is None and B * D * H * W <= CONV_WGRAD_GROUP_VOXELS and not narrow:
         q.conv_wgrad.append((x, dy, dw, int(accumulate)))      # keeps x and dy alive until the flush
         return dw
     lib = L.load()

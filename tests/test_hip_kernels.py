@@ -426,7 +426,8 @@ def _conv_case(dtype, B, D, H, W, Cin, Cout, seed=0):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,D,H,W,Cin,Cout", [(1, 8, 8, 8, 48, 48), (2, 5, 9, 11, 12, 24), (1, 12, 16, 8, 96, 48), (1, 3, 3, 3, 192, 96),
-                                             (1, 6, 6, 6, 8, 12), (1, 4, 8, 16, 48, 96), (1, 7, 7, 7, 16, 16)])
+                                             (1, 6, 6, 6, 8, 12), (1, 4, 8, 16, 48, 96), (1, 7, 7, 7, 16, 16), (2, 9, 10, 13, 32, 16), (1, 24, 24, 24, 16, 32),
+                                             (1, 5, 8, 8, 32, 32)])      # (the 16 / 32-channel bf16 cases take the narrow-layer weight-gradient kernel)
 def test_conv3_fwd_dgrad_wgrad(dtype, B, D, H, W, Cin, Cout):
     ops = _ops()
     x, w = _conv_case(dtype, B, D, H, W, Cin, Cout)
@@ -443,6 +444,13 @@ def test_conv3_fwd_dgrad_wgrad(dtype, B, D, H, W, Cin, Cout):
     assert rel_err(dx.permute(0, 4, 1, 2, 3), xr.grad) < TOL[dtype]
     dw = ops.conv3_wgrad(x, dy)
     assert rel_err(dw, wr.grad) < TOL[dtype]
+    # accumulate into an existing gradient (mode 1) and into a zeroed slot (mode 2), as the training arena asks for
+    acc = torch.full_like(dw, 0.5)
+    ops.conv3_wgrad(x, dy, dw=acc, accumulate=True)
+    assert rel_err(acc - 0.5, wr.grad) < 2 * TOL[dtype]
+    z = torch.zeros_like(dw)
+    ops.conv3_wgrad(x, dy, dw=z, accumulate=2)
+    assert rel_err(z, wr.grad) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
