@@ -273,10 +273,17 @@ int miseg_conv3_fwd(const miseg_conv3_params* p, miseg_stream_t stream);
  * on dy; either may be NULL.  The layout is internal (row-major [Cout][27][CinP] or planar [27][CinP/k][CoutP16][k], by channel count);
  * buffers hold miseg_pack_conv3_elems(Cin, Cout, dtype, which) elements of `dtype` (which: 0 = fwd, 1 = bwd). */
 size_t miseg_pack_conv3_elems(int Cin, int Cout, int dtype, int which);
+/* K extent (elements; a whole number of 96-byte chunks) of the fast path for C channels on the K side of miseg_conv3_fwd, or 0 where the
+ * generic row-major kernel runs.  Rows of >= MISEG_CONV3_PAD_MIN bytes (environment, default 64; 0 = never) that are no multiple of 96
+ * bytes are padded with zero weights to the next chunk (32 -> 48, 64 -> 96, 128 -> 144, 256 -> 288 bf16 channels; C-UNETR: 146.2 / 155.2 / 161.0 / 165.7 / 163.4 patches/s at 0 / 256 / 128 / 64 / 32).  Fused residual / statistics
+ * (miseg_conv3_params.res / .stat) need a non-zero value. */
+int miseg_conv3_k96(int C, int dtype);
+/* 16x16 tiles miseg_pack_conv3_batch walks for one layer (the padded K groups of a fast-path pack get tiles of their own) */
+int miseg_pack_conv3_tiles(int Cin, int Cout, int dtype);
 typedef struct { const float* w; void* fwd_pack; void* bwd_pack; int Cin, Cout, dtype; } miseg_pack_conv3_params;
 int miseg_pack_conv3_weight(const miseg_pack_conv3_params* p, miseg_stream_t stream);
 /* every 3x3x3 weight of a model in ONE launch: `descs` is a DEVICE array of n descriptors sorted by tile0 = number of 16x16
- * (co, ci) tiles before the descriptor; total_tiles = the sum over descriptors of ceil(Cin/16) * ceil(Cout/16). */
+ * (co, ci) tiles before the descriptor; total_tiles = the sum over descriptors of miseg_pack_conv3_tiles(Cin, Cout, dtype). */
 typedef struct { const float* w; void* fwd_pack; void* bwd_pack; int32_t Cin, Cout, tile0, pad_; } miseg_pack_conv3_desc;
 /* Versioned refresh (ABI 5; also miseg_param_cast_batch): `params_version` is a DEVICE int64 that counts the changes of the fp32 parameters
  * (miseg_opt_step bumps it through its `params_version` field; after any other change of a parameter the host adds to it with

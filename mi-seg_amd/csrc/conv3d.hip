@@ -526,6 +526,28 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
 static constexpr int PK_T = 16;
 static constexpr int PK_LD = PK_T * 27 + 1;      // floats per co row of the LDS tile
 
+// K extent (elements, a whole number of 96-byte chunks) the fast path walks for C channels on its K side, or 0 where the generic row-major
+// kernel serves them.  Rows that are not a multiple of 96 bytes but at least `pad_min_bytes` wide are PADDED to the next chunk (zero weights
+// in the pack; the staging reads nothing beyond C): C-UNETR's 128 / 256-channel layers at 12^3 - 24^3 get the split-K plan of the fast path
+// instead of 12 - 54 workgroups of the generic kernel (85 - 160 us -> 20 - 30 us each), its 32 / 64-channel layers the planar LDS images and
+// the fused residual / statistics epilogue although a third to a half of their MFMA work multiplies zeros (C-UNETR patches/s with the
+// threshold at 0 / 256 / 128 / 64 / 32 bytes: 146.2 / 155.2 / 161.0 / 165.7 / 163.4 - 16 channels padded to 48 no longer pay).  ONE predicate for the pack, the launch, the
+// workspace size and the host side (miseg_conv3_k96).
+__host__ __device__ inline int conv3_k96(int C, int esz, int pad_min_bytes) {
+  const int kpc = 16 / esz, cp = (C + kpc - 1) / kpc * kpc, per = 96 / esz;
+  if ((cp * esz) % 96 == 0) return cp;
+  if (pad_min_bytes > 0 && cp * esz >= pad_min_bytes) return (C + per - 1) / per * per;
+  return 0;
+}
+
+static int conv3_pad_min_bytes() {      // MISEG_CONV3_PAD_MIN (bytes of a channel row; 0 = never pad), read once
+  static const int v = [] {
+    const char* e = getenv("MISEG_CONV3_PAD_MIN");
+    return e ? atoi(e) : 64;
+  }();
+  return v;
+}
+
 // element offset of the 16-byte group (tap, K-side channel group kg, N-side row) in the phase-ordered pack of the fast path
 // [chunk = kg / 6][phase][kh * 4 + slot][N16][KPC]
 __device__ __forceinline__ int64_t fwd96_pack_offset(int tap, int kg, int row, int N16, int KPC) {
@@ -569,7 +591,7 @@ __device__ __forceinline__ void pack_conv3_tile(const float* __restrict__ w, T* 
       if (fwd_planar) { co = i % PK_T; cg = (i / PK_T) % NG; tap = i / (PK_T * NG); }
       else { cg = i % NG; tap = (i / NG) % 27; co = i / (NG * 27); }
       const int cib = ci0 + cg * KPC;
-      if (cib >= CinP || (!fwd_planar && co0 + co >= Cout)) continue;
+      if (cib >= CinP || (fwd_planar ? co0 + co >= Cout16 : co0 + co >= Cout)) continue;
       VT v;
 #pragma unroll
       for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(tile[co * PK_LD + (cg * KPC + e) * 27 + tap]);
@@ -585,7 +607,7 @@ __device__ __forceinline__ void pack_conv3_tile(const float* __restrict__ w, T* 
       if (bwd_planar) { ci = i % PK_T; cg = (i / PK_T) % NG; tap = i / (PK_T * NG); }
       else { cg = i % NG; tap = (i / NG) % 27; ci = i / (NG * 27); }
       const int cob = co0 + cg * KPC;
-      if (cob >= CoutP || (!bwd_planar && ci0 + ci >= Cin)) continue;
+      if (cob >= CoutP || (bwd_planar ? ci0 + ci >= Cin16 : ci0 + ci >= Cin)) continue;
       VT v;
 #pragma unroll
       for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(tile[(cg * KPC + e) * PK_LD + ci * 27 + (26 - tap)]);
@@ -605,7 +627,7 @@ __global__ void __launch_bounds__(256) pack_conv3_kernel(const float* __restrict
 
 template <class T>
 __global__ void __launch_bounds__(256) pack_conv3_batch_kernel(const miseg_pack_conv3_desc* __restrict__ descs, int n, int total_tiles,
-                                                               const int64_t* __restrict__ params_version, int64_t* __restrict__ state) {
+                                                               const int64_t* __restrict__ params_version, int64_t* __restrict__ state, int pad_min) {
   constexpr int KPC = Vec16<T>::N;
   const int64_t pv = params_version ? *params_version : 0;
   if (params_version && state[0] == pv) return;      // versioned refresh (miseg_hip.h): the packs were made from the current parameters
@@ -616,11 +638,12 @@ __global__ void __launch_bounds__(256) pack_conv3_batch_kernel(const miseg_pack_
       if (descs[mid].tile0 <= tl) lo = mid; else hi = mid - 1;
     }
     const miseg_pack_conv3_desc d = descs[lo];
-    const int t = tl - d.tile0, tci = (d.Cin + PK_T - 1) / PK_T;
-    const int CinP = (d.Cin + KPC - 1) / KPC * KPC, CoutP = (d.Cout + KPC - 1) / KPC * KPC;
+    const int kf = conv3_k96(d.Cin, (int)sizeof(T), pad_min), kb = conv3_k96(d.Cout, (int)sizeof(T), pad_min);
+    const int t = tl - d.tile0, tci = ((kf > d.Cin ? kf : d.Cin) + PK_T - 1) / PK_T;     // tile grid of a layer: pack_tiles()
+    const int CinP = kf ? kf : (d.Cin + KPC - 1) / KPC * KPC, CoutP = kb ? kb : (d.Cout + KPC - 1) / KPC * KPC;
     __syncthreads();      // pack_conv3_tile's LDS tile of the previous iteration has been read
     pack_conv3_tile<T>(d.w, (T*)d.fwd_pack, (T*)d.bwd_pack, d.Cin, d.Cout, CinP, CoutP, (d.Cin + 15) / 16 * 16, (d.Cout + 15) / 16 * 16,
-                       (CinP * (int)sizeof(T)) % 96 == 0, (CoutP * (int)sizeof(T)) % 96 == 0, t % tci, t / tci);
+                       kf != 0, kb != 0, t % tci, t / tci);
   }
   refresh_done(params_version, state, pv);
 }
@@ -1384,9 +1407,9 @@ static void fwd96_plan(int nbricks, int Cout, int nchunks, int* nt, int* ksplit)
 }
 
 extern "C" size_t miseg_conv3_fwd_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int dtype) {
-  const int esz = dtype == MISEG_F32 ? 4 : 2, kpc = 16 / esz;
-  const int rowbytes = round_up(Cin, kpc) * esz;
-  if (rowbytes % 96 != 0) return 0;
+  const int esz = dtype == MISEG_F32 ? 4 : 2;
+  const int rowbytes = conv3_k96(Cin, esz, conv3_pad_min_bytes()) * esz;
+  if (!rowbytes) return 0;
   int nt, ks;
   fwd96_plan(B * cdiv(D, FBD) * cdiv(H, FBH) * cdiv(W, FBW), Cout, rowbytes / 96, &nt, &ks);
   return ks > 1 ? (size_t)ks * B * D * H * W * Cout * sizeof(float) : 0;
@@ -1395,14 +1418,15 @@ extern "C" size_t miseg_conv3_fwd_workspace_bytes(int B, int D, int H, int W, in
 template <class T>
 static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
   constexpr int KPC = Vec16<T>::N;
-  const int CinP = round_up(p->Cin, KPC);
+  const int k96 = conv3_k96(p->Cin, (int)sizeof(T), conv3_pad_min_bytes());
+  const int CinP = k96 ? k96 : round_up(p->Cin, KPC);
   const int rowbytes = CinP * (int)sizeof(T);
   ConvGeom g{p->B, p->D, p->H, p->W, cdiv(p->D, BD), cdiv(p->H, BH), cdiv(p->W, BW)};
   const int nbricks = g.B * g.nbd * g.nbh * g.nbw;
   const bool vec_x = ((uintptr_t)p->x % 16 == 0) && (p->ldx % KPC == 0);
   // ---- fast path: 96-byte channel chunks, planar LDS images (weights must come from the planar pack: same predicate
-  // in miseg_pack_conv3_weight)
-  if (rowbytes % 96 == 0) {
+  // in miseg_pack_conv3_weight: conv3_k96)
+  if (k96) {
     ConvGeom gf{p->B, p->D, p->H, p->W, cdiv(p->D, FBD), cdiv(p->H, FBH), cdiv(p->W, FBW)};
     const int nbr = gf.B * gf.nbd * gf.nbh * gf.nbw;
     int nt, ksplit;
@@ -1472,10 +1496,17 @@ extern "C" int miseg_conv3_fwd(const miseg_conv3_params* p, miseg_stream_t s_) {
 }
 
 extern "C" size_t miseg_pack_conv3_elems(int Cin, int Cout, int dtype, int which) {
-  const int kpc = dtype == MISEG_F32 ? 4 : 8;
-  const int CinP = round_up(Cin, kpc), CoutP = round_up(Cout, kpc);
+  const int per = dtype == MISEG_F32 ? 24 : 48;
+  const int CinP = round_up(Cin, per), CoutP = round_up(Cout, per);      // a padded K side ends on a whole 96-byte chunk
   // large enough for either layout (the phase-ordered pack of the fast path holds 14 x 12 = 168 group slots per chunk for 27 x 6 = 162 groups)
   return which == 0 ? (size_t)28 * CinP * round_up(Cout, 16) : (size_t)28 * CoutP * round_up(Cin, 16);
+}
+
+extern "C" int miseg_conv3_k96(int C, int dtype) { return conv3_k96(C, dtype == MISEG_F32 ? 4 : 2, conv3_pad_min_bytes()); }
+
+extern "C" int miseg_pack_conv3_tiles(int Cin, int Cout, int dtype) {
+  const int kf = miseg_conv3_k96(Cin, dtype), kb = miseg_conv3_k96(Cout, dtype);
+  return cdiv(kf > Cin ? kf : Cin, PK_T) * cdiv(kb > Cout ? kb : Cout, PK_T);
 }
 
 extern "C" int miseg_pack_conv3_weight(const miseg_pack_conv3_params* p, miseg_stream_t s_) {
@@ -1484,11 +1515,12 @@ extern "C" int miseg_pack_conv3_weight(const miseg_pack_conv3_params* p, miseg_s
   return dispatch_dtype(p->dtype, [&](auto* tag) -> int {
     typedef typename std::remove_pointer<decltype(tag)>::type T;
     constexpr int KPC = Vec16<T>::N;
-    const int CinP = round_up(p->Cin, KPC), CoutP = round_up(p->Cout, KPC);
-    const bool fplanar = (CinP * (int)sizeof(T)) % 96 == 0, bplanar = (CoutP * (int)sizeof(T)) % 96 == 0;
+    const int kf = conv3_k96(p->Cin, (int)sizeof(T), conv3_pad_min_bytes()), kb = conv3_k96(p->Cout, (int)sizeof(T), conv3_pad_min_bytes());
+    const int CinP = kf ? kf : round_up(p->Cin, KPC), CoutP = kb ? kb : round_up(p->Cout, KPC);
+    const bool fplanar = kf != 0, bplanar = kb != 0;
     MISEG_REQUIRE((!p->fwd_pack || (uintptr_t)p->fwd_pack % 16 == 0) && (!p->bwd_pack || (uintptr_t)p->bwd_pack % 16 == 0), MISEG_E_BADARG,
                   "pack_conv3_weight: packs must be 16-byte aligned");
-    dim3 grid(cdiv(p->Cin, PK_T), cdiv(p->Cout, PK_T));
+    dim3 grid(cdiv(kf > p->Cin ? kf : p->Cin, PK_T), cdiv(kb > p->Cout ? kb : p->Cout, PK_T));     // the padded K groups get their (zero) tiles
     pack_conv3_kernel<T><<<grid, 256, 0, s>>>(p->w, (T*)p->fwd_pack, (T*)p->bwd_pack, p->Cin, p->Cout, CinP, CoutP, round_up(p->Cin, 16), round_up(p->Cout, 16),
                                               fplanar, bplanar);
     MISEG_LAUNCH_CHECK("pack_conv3_weight");
@@ -1502,7 +1534,8 @@ extern "C" int miseg_pack_conv3_batch(const miseg_pack_conv3_desc* descs, int n,
   MISEG_REQUIRE((params_version == nullptr) == (state == nullptr), MISEG_E_BADARG, "pack_conv3_batch: params_version and state go together");
   return dispatch_dtype(dtype, [&](auto* tag) -> int {
     typedef typename std::remove_pointer<decltype(tag)>::type T;
-    pack_conv3_batch_kernel<T><<<total_tiles < REFRESH_MAX_WG ? total_tiles : REFRESH_MAX_WG, 256, 0, (hipStream_t)s_>>>(descs, n, total_tiles, params_version, state);
+    pack_conv3_batch_kernel<T><<<total_tiles < REFRESH_MAX_WG ? total_tiles : REFRESH_MAX_WG, 256, 0, (hipStream_t)s_>>>(descs, n, total_tiles, params_version, state,
+                                                                                                                         conv3_pad_min_bytes());
     MISEG_LAUNCH_CHECK("pack_conv3_batch");
     return MISEG_OK;
   });

@@ -169,6 +169,8 @@ PROTOS = {
     "miseg_conv3_fwd_workspace_bytes": (C.c_size_t, [i32, i32, i32, i32, i32, i32, i32]),
     "miseg_conv3_fwd": (i32, [C.POINTER(Conv3), vp]),
     "miseg_pack_conv3_elems": (C.c_size_t, [i32, i32, i32, i32]),
+    "miseg_conv3_k96": (i32, [i32, i32]),
+    "miseg_pack_conv3_tiles": (i32, [i32, i32, i32]),
     "miseg_pack_conv3_weight": (i32, [C.POINTER(PackConv3), vp]),
     "miseg_pack_conv3_batch": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "miseg_conv3_wgrad_workspace_bytes": (C.c_size_t, [i32, i32, i32, i32, i32, i32]),

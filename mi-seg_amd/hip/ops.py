@@ -795,8 +795,7 @@ def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False):
     wsb = lib.miseg_conv3_fwd_workspace_bytes(B, D, H, W, Cin, Cout, _dt(x))
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device) if wsb else None
     flops = 2.0 * B * D * H * W * 27 * Cin * Cout
-    kpc = 16 // x.element_size()
-    fast = (_round_up(Cin, kpc) * x.element_size()) % 96 == 0
+    fast = lib.miseg_conv3_k96(Cin, _dt(x)) != 0      # 96-byte chunks (padded where the rows are wide enough to pay for it)
     bg = 1 if (fast and _background()) else 0
     name = f"conv3_fwd{'96' if fast else ''}_kernel<{'bf16' if x.dtype == torch.bfloat16 else 'f32'}>" + (" (background)" if bg else "")
     fuse_res = res is not None and fast and res.dtype == x.dtype       # (the roofline leg times the launches exactly as the step issues them)

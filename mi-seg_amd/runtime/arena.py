@@ -207,12 +207,14 @@ class ParamArena:
         if torch.cuda.is_current_stream_capturing():
             return
         descs = (L.PackConv3Desc * len(self._packs))()
+        lib = L.load()
+        dt = L.F32 if self.dtype == torch.float32 else L.BF16
         tile0 = 0
         for i, ent in enumerate(self._packs.values()):
             p = ent[0]
             Cout, Cin = p.shape[0], p.shape[1]
             descs[i] = L.PackConv3Desc(p.data_ptr(), ent[1].data_ptr(), ent[2].data_ptr(), Cin, Cout, tile0, 0)
-            tile0 += ((Cin + 15) // 16) * ((Cout + 15) // 16)
+            tile0 += lib.miseg_pack_conv3_tiles(Cin, Cout, dt)
             ent[4] = True
         if self._ptable is not None:
             self._retired.append(self._ptable[0])

@@ -427,7 +427,10 @@ def _conv_case(dtype, B, D, H, W, Cin, Cout, seed=0):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,D,H,W,Cin,Cout", [(1, 8, 8, 8, 48, 48), (2, 5, 9, 11, 12, 24), (1, 12, 16, 8, 96, 48), (1, 3, 3, 3, 192, 96),
                                              (1, 6, 6, 6, 8, 12), (1, 4, 8, 16, 48, 96), (1, 7, 7, 7, 16, 16), (2, 9, 10, 13, 32, 16), (1, 24, 24, 24, 16, 32),
-                                             (1, 5, 8, 8, 32, 32)])      # (the 16 / 32-channel bf16 cases take the narrow-layer weight-gradient kernel)
+                                             (1, 5, 8, 8, 32, 32),       # (the 16 / 32-channel bf16 cases take the narrow-layer weight-gradient kernel)
+                                             # rows >= 256 bytes that are no multiple of 96: K side padded to the next chunk (miseg_conv3_k96),
+                                             # forward on Cin, data gradient on Cout; ragged channel counts and a generic-path partner
+                                             (1, 12, 12, 12, 128, 256), (1, 6, 7, 5, 256, 128), (2, 5, 6, 7, 130, 64), (1, 4, 4, 4, 200, 40)])
 def test_conv3_fwd_dgrad_wgrad(dtype, B, D, H, W, Cin, Cout):
     ops = _ops()
     x, w = _conv_case(dtype, B, D, H, W, Cin, Cout)

@@ -360,17 +360,22 @@ def test_unetr_c3(golden, dtype, tol):
     _whole(G, "c3_m1", m, tol, dtype)
 
 
-SMALL_NET_BAR = dict(fp32=(3.0, 1e-2, 1.5), bf16=(3.0, 1e-1, 1.5))
+SMALL_NET_BAR = dict(fp32=(3.0, 1e-2, 1.5), bf16=(3.0, 1e-1, 1.5), bf16_scalar_family=True)
 """(factor, slack, median factor) of _vs_truth for the 32^3 / 64^3 nets.  Their gradients jump with every single activation-sign flip
 (LeakyReLU / PReLU on normalised pre-activations): with ~1e6 pre-activations and a forward error of 3e-7 the expected number of flips is
 below one, so the reference's fp32 run happens to sit 8e-7 from its float64 run while ONE flip near the output puts every upstream
 gradient 1e-4 .. 7e-3 away (measured: UNETR 32^3, 205 of 276 parameters at 3.6e-3 .. 6.6e-3 together; UNet 64^3, the six parameters in front of
 the first PReLU at 1.1e-4) - the slack is that jump, the 1e-2 the fp32 fixtures are compared at (`_whole`).  bf16: torch.autocast keeps norm outputs / activations in fp32 and only runs convolutions
 and linears in bf16, this path STORES every activation in bf16 - sums with heavy cancellation (the one-element PReLU slope gradients: a
-sum over ~2 M voxels) carry that storage rounding: 1.05e-1 against autocast's 1.8e-2, 2.2e-1 against 4.8e-2 at worst.  The full-size nets (C2, C3) need neither."""
+sum over ~2 M voxels) carry that storage rounding, and so do autocast's: against the float64 run the 13 slopes of the C1 UNet (|g| 1.5 .. 1166,
+median 174) sit 2 .. 86 away under autocast (rms 36 = 0.21 of the median) and 3 .. 103 away here (rms 33 / 41 / 41 with the 96-byte-chunk
+convolution path padded from 0 / 64 / 128 bytes: every change of a summation order in front of them re-draws all 13, the largest error
+moves from slope to slope - scripts/debug/unet_scalar_bf16.py).  One draw against one draw is no bar for them: `bf16_scalar_family` compares
+the FAMILY (rms of error / scale no more than 1.5 x autocast's + 0.05) and holds every single slope within 3 x autocast's rms + 0.1.
+The full-size nets (C2, C3) need none of this."""
 
 
-def _vs_truth(T, R, tag, model, dtype, fp32=(4.0, 1e-5, 2.0), bf16=(2.0, 0.0, 1.25)):
+def _vs_truth(T, R, tag, model, dtype, fp32=(4.0, 1e-5, 2.0), bf16=(2.0, 0.0, 1.25), bf16_scalar_family=False):
     """the bar of test_swin_unetr_c2_vs_truth for any net: per parameter no further from the reference's float64 run (fixture T) than the
     reference's own run at the same precision (fp32: fixture R, autocast-bf16: T) times `factor` (+ slack), medians within `med_factor` (+ slack)"""
     from mi_seg_amd.utils.detfill import det_input
@@ -389,7 +394,7 @@ def _vs_truth(T, R, tag, model, dtype, fp32=(4.0, 1e-5, 2.0), bf16=(2.0, 0.0, 1.
     med = sorted(rms.values())[len(rms) // 2]
     named = dict(m.named_parameters())
     factor, slack, med_factor = fp32 if is32 else bf16
-    all_hip, all_ref, worst, bad = [], [], (0.0, ""), []
+    all_hip, all_ref, worst, bad, fam = [], [], (0.0, ""), [], []
     scal = scalar_scale(truth)
     for k, t in truth.items():
         got = sample(named[k].grad)
@@ -405,8 +410,15 @@ def _vs_truth(T, R, tag, model, dtype, fp32=(4.0, 1e-5, 2.0), bf16=(2.0, 0.0, 1.
         worst = max(worst, (e_hip / (e_r + 1e-12), k))
         all_hip.append(e_hip)
         all_ref.append(e_r)
+        if t.numel() == 1 and not is32 and bf16_scalar_family:      # judged as a family below (SMALL_NET_BAR)
+            fam.append((e_hip, e_r, k))
+            continue
         if e_hip > factor * e_r + slack:
             bad.append((round(e_hip / (e_r + 1e-12), 2), k, f"{e_hip:.2e}", f"{e_r:.2e}"))
+    if fam:
+        rms_hip, rms_ref = (sum(f[0] ** 2 for f in fam) / len(fam)) ** 0.5, (sum(f[1] ** 2 for f in fam) / len(fam)) ** 0.5
+        assert rms_hip <= 1.5 * rms_ref + 0.05, ("one-element parameters as a family", rms_hip, rms_ref)
+        bad += [(round(f[0] / (rms_ref + 1e-12), 2), f[2], f"{f[0]:.2e}", f"family rms {rms_ref:.2e}") for f in fam if f[0] > 3.0 * rms_ref + 0.1]
     assert not bad, (f"{len(bad)} of {len(all_hip)} parameters further from the float64 run than {factor} x the reference at this precision", sorted(bad)[-12:])
     m_hip, m_ref = sorted(all_hip)[len(all_hip) // 2], sorted(all_ref)[len(all_ref) // 2]
     assert m_hip <= med_factor * m_ref + slack, ("median over parameters", m_hip, m_ref)
