@@ -279,6 +279,11 @@ def measure(a, rank, world, dist, dev):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    if ops.STAMPS and rank == 0:          # MISEG_STEP_STAMPS=1: where the streams of the last replayed step were when (device clock, us)
+        st = ops.read_stamps()
+        t0_ = st.get("step_begin", min(st.values()))
+        print("step stamps (us after step_begin): " + ", ".join(f"{k} {v - t0_:.0f}" for k, v in sorted(st.items(), key=lambda kv: kv[1])), file=sys.stderr)
+
     def replay_check():
         """untimed: the last replays of the captured step against the same step launched eagerly (logits and all gradients)"""
         k = order[(a.warmup + a.steps) % len(order)]

@@ -605,6 +605,10 @@ int miseg_counter_add(uint64_t* counter_dev, uint64_t value, miseg_stream_t stre
 /* *dst = *src on the device (a plain kernel: device-to-device copies recorded as memcpy nodes crashed hipStreamEndCapture on ROCm 7.2).
  * A dropout call snapshots the step counter so that its backward pass re-creates the same mask after the counter moved on. */
 int miseg_counter_copy(uint64_t* dst_dev, const uint64_t* src_dev, miseg_stream_t stream);
+/* measurement aid: *slot_dev = the device's constant-rate wall clock (100 MHz on gfx950) when the stream reaches this point.  A one-thread
+ * kernel, so it can be recorded into a hipGraph: the order in which the streams of a replayed step reach their joins is visible without a
+ * tracer (whose per-dispatch cost reorders exactly that; scripts/debug/step_stamps.py). */
+int miseg_debug_stamp(uint64_t* slot_dev, miseg_stream_t stream);
 
 /* The resampling step of the cached, deterministic head of the data chain (Spacingd at data/multi_modal.py:41-44: image "bilinear", label
  * "nearest"): in [C][Di][Hi][Wi] -> out [C][Do][Ho][Wo], voxel centres aligned (src = (dst + 0.5) * in / out - 0.5), coordinates clamped to

@@ -433,51 +433,79 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_stream_kernel(const bf16* __re
 // one 16 x (16*NTW) output tile, its four waves split K, and every lane's operands (16 contiguous bytes of a row each) go
 // straight from global memory (L2) to registers in batches of four k-steps, all loads of a batch in flight together;
 // the four partial tiles meet in LDS.
-template <int NTW, bool GELU>
+// Workgroup -> tile: the hardware deals consecutive workgroups to the 8 XCDs round-robin, each with its own L2.  With (m-tile, n-tile) =
+// (blockIdx.x, blockIdx.y) the 14 row tiles that share a weight tile ran on 8 different XCDs and every XCD fetched the WHOLE weight
+// matrix from HBM: 216 tokens x (768 .. 3072)^2 took 3.5 us + 3 us per MB of weights (0.33 TB/s of weight bytes).  XCD k owns the k-th
+// contiguous eighth of the n-tiles instead (all row tiles of an n-tile side by side): the weights cross HBM once, the few activations
+// (216 x K) are what every XCD reads.
+// MTW x NTW MFMA tiles per workgroup.  The kernel is bound by the operand traffic L2 -> CU, not by a latency chain (a software-pipelined
+// K loop with unconditional, clamped loads was SLOWER: 216 x 768 x 3072 18.8 -> 20.3 us, it over-fetches two batches per wave): 32 x 32
+// outputs read 64 operand rows per k-step for 4 MFMAs where 16 x 32 read 48 for 2 (216 x 768 x 3072: 20.2 -> 14.2 us, 216 x 768 x 768:
+// 8.4 -> 6.4), 32 x 64 read 96 for 8 (216 x 2304 x 768: 12.8 -> 8.9).  scripts/bench_gemm.py small, MISEG_GEMM_SMALL_TILE.
+static constexpr int SM_BS = 4;      // k-steps whose loads are in flight together
+template <int MTW, int NTW, bool GELU>
 __global__ void __launch_bounds__(256) gemm_nt_small_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ W, int64_t ldw, bf16* __restrict__ C,
-                                                            int64_t ldc, int M, int N, int K, Epi epi) {
+                                                            int64_t ldc, int M, int N, int K, Epi epi, int gm) {
   const float* bias = epi.bias;
-  __shared__ __attribute__((aligned(16))) float part[4][NTW][64][4];
+  constexpr int NTILE = MTW * NTW;
+  __shared__ __attribute__((aligned(16))) float part[4][NTILE][64][4];
   // wave index as a SCALAR: the k-range guards below must be real branches -- an MFMA ignores EXEC, so a guard the compiler
   // if-converts (it cannot know tid >> 6 is wave-uniform) would let the skipped k-steps accumulate garbage operands
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fi = lane & 15, kg = lane >> 4;
-  const int m0 = blockIdx.x * 16, n0 = blockIdx.y * 16 * NTW;
+  int m0, n0;
+  {
+    const int nb = gridDim.x, xcd = blockIdx.x & 7, q = nb >> 3, r = nb & 7;
+    const int unit = xcd * q + (xcd < r ? xcd : r) + (blockIdx.x >> 3);
+    const int nt_ = unit / gm;
+    m0 = (unit - nt_ * gm) * 16 * MTW;
+    n0 = nt_ * 16 * NTW;
+  }
   const int ksteps = K / 32, kpw = (ksteps + 3) / 4;
   const int ks0 = wave * kpw, ks1 = min(ksteps, ks0 + kpw);
-  const bf16* arow = A + (int64_t)min(m0 + fi, M - 1) * lda + 8 * kg;
+  const bf16* arow[MTW];
   const bf16* wrow[NTW];
 #pragma unroll
+  for (int mt = 0; mt < MTW; ++mt) arow[mt] = A + (int64_t)min(m0 + mt * 16 + fi, M - 1) * lda + 8 * kg;
+#pragma unroll
   for (int nt = 0; nt < NTW; ++nt) wrow[nt] = W + (int64_t)min(n0 + nt * 16 + fi, N - 1) * ldw + 8 * kg;
-  f32x4 acc[NTW];
+  f32x4 acc[MTW][NTW];
 #pragma unroll
-  for (int nt = 0; nt < NTW; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int ks = ks0; ks < ks1; ks += 4) {
-    bf16x8 af[4], wf[4][NTW];
+  for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int ks = ks0; ks < ks1; ks += SM_BS) {
+    bf16x8 af[SM_BS][MTW], wf[SM_BS][NTW];
+#pragma unroll
+    for (int u = 0; u < SM_BS; ++u) {
       if (ks + u < ks1) {
-        af[u] = *reinterpret_cast<const bf16x8*>(arow + (ks + u) * 32);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) af[u][mt] = *reinterpret_cast<const bf16x8*>(arow[mt] + (ks + u) * 32);
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) wf[u][nt] = *reinterpret_cast<const bf16x8*>(wrow[nt] + (ks + u) * 32);
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < SM_BS; ++u) {
       if (ks + u < ks1) {
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][nt], af[u], acc[nt], 0, 0, 0);
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][nt], af[u][mt], acc[mt][nt], 0, 0, 0);
       }
     }
   }
 #pragma unroll
-  for (int nt = 0; nt < NTW; ++nt) *reinterpret_cast<f32x4*>(&part[wave][nt][lane][0]) = acc[nt];
-  __syncthreads();
-  // wave w finishes n-tiles w, w + 4, ...: lane (fi = row, kg): columns n0 + nt * 16 + 4kg .. +3
-  for (int nt = wave; nt < NTW; nt += 4) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(&part[0][nt][lane][0]);
+  for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-    for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(&part[w][nt][lane][0]);
-    const int m = m0 + fi, n = n0 + nt * 16 + 4 * kg;
+    for (int nt = 0; nt < NTW; ++nt) *reinterpret_cast<f32x4*>(&part[wave][mt * NTW + nt][lane][0]) = acc[mt][nt];
+  __syncthreads();
+  // wave w finishes tiles w, w + 4, ...: lane (fi = row, kg): columns n0 + nt * 16 + 4kg .. +3
+  for (int t = wave; t < NTILE; t += 4) {
+    const int mt = t / NTW, nt = t - mt * NTW;
+    f32x4 v = *reinterpret_cast<const f32x4*>(&part[0][t][lane][0]);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(&part[w][t][lane][0]);
+    const int m = m0 + mt * 16 + fi, n = n0 + nt * 16 + 4 * kg;
     if (m < M && n < N) {
       if (bias) { v[0] += bias[n]; v[1] += bias[n + 1]; v[2] += bias[n + 2]; v[3] += bias[n + 3]; }
       v = epi_vec4_bf16(v, m, n, epi, GELU);
@@ -893,16 +921,33 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
     if constexpr (std::is_same<T, bf16>::value && std::is_same<TO, bf16>::value) {
       // deep-stage linears (see gemm_nt_small_kernel)
       if (split == 1 && !p->accumulate && p->M <= 2048 && p->K % 32 == 0 && p->N % 16 == 0 && al_a && al_b && ((uintptr_t)p->C % 8 == 0) && p->ldc % 4 == 0 && epi_vec_ok) {
-        const int ntw = (p->N % 64 == 0 && (int64_t)cdiv(p->M, 16) * (p->N / 64) >= 256) ? 4 : (p->N % 32 == 0 && (int64_t)cdiv(p->M, 16) * (p->N / 32) >= 256) ? 2 : 1;
-        dim3 grid(cdiv(p->M, 16), p->N / (16 * ntw));
+        // the largest tile that still leaves >= 140 workgroups (sweep over the deep-stage / ViT shapes in the kernel's comment: with fewer
+        // the launch is one workgroup's K loop long; beyond, the smaller tile only adds operand traffic)
+        int mtw = 1, ntw = 1;
+        {
+          static const int cand[5][2] = {{2, 4}, {2, 2}, {2, 1}, {1, 2}, {1, 1}};
+          for (int c = 0; c < 5; ++c) {
+            const int a_ = cand[c][0], b_ = cand[c][1];
+            if (p->N % (16 * b_) != 0 || (a_ == 2 && p->M <= 16)) continue;
+            mtw = a_; ntw = b_;
+            if ((int64_t)cdiv(p->M, 16 * a_) * (p->N / (16 * b_)) >= 140) break;
+          }
+        }
+        if (const char* e = getenv("MISEG_GEMM_SMALL_TILE")) {      // sweeps (scripts/bench_gemm.py small): "mtw,ntw"
+          int a_ = 0, b_ = 0;
+          if (sscanf(e, "%d,%d", &a_, &b_) == 2 && (a_ == 1 || a_ == 2) && (b_ == 1 || b_ == 2 || b_ == 4) && p->N % (16 * b_) == 0) { mtw = a_; ntw = b_; }
+        }
+        const int gm = cdiv(p->M, 16 * mtw);
+        dim3 grid(gm * (p->N / (16 * ntw)));
         const bool ge = p->act == MISEG_ACT_GELU;
-#define SM_CASE(n)                                                                                                                              \
-  case n:                                                                                                                                       \
-    if (ge) gemm_nt_small_kernel<n, true><<<grid, 256, 0, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, p->K, epi); \
-    else gemm_nt_small_kernel<n, false><<<grid, 256, 0, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, p->K, epi); \
-    break;
-        switch (ntw) { SM_CASE(1) SM_CASE(2) SM_CASE(4) }
-#undef SM_CASE
+#define SM_LAUNCH(m_, n_)                                                                                                                       \
+  do {                                                                                                                                          \
+    if (ge) gemm_nt_small_kernel<m_, n_, true><<<grid, 256, 0, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, p->K, epi, gm); \
+    else gemm_nt_small_kernel<m_, n_, false><<<grid, 256, 0, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, p->K, epi, gm); \
+  } while (0)
+        if (mtw == 2) { if (ntw == 4) SM_LAUNCH(2, 4); else if (ntw == 2) SM_LAUNCH(2, 2); else SM_LAUNCH(2, 1); }
+        else { if (ntw == 4) SM_LAUNCH(1, 4); else if (ntw == 2) SM_LAUNCH(1, 2); else SM_LAUNCH(1, 1); }
+#undef SM_LAUNCH
         MISEG_LAUNCH_CHECK("gemm_nt_small");
         return MISEG_OK;
       }

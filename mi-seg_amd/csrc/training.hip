@@ -746,6 +746,15 @@ extern "C" int miseg_counter_add(uint64_t* c, uint64_t v, miseg_stream_t s_) {
   return MISEG_OK;
 }
 
+__global__ void stamp_kernel(uint64_t* slot) { *slot = wall_clock64(); }
+
+extern "C" int miseg_debug_stamp(uint64_t* slot, miseg_stream_t s_) {
+  MISEG_REQUIRE(slot, MISEG_E_BADARG, "debug_stamp: null pointer");
+  stamp_kernel<<<1, 1, 0, (hipStream_t)s_>>>(slot);
+  MISEG_LAUNCH_CHECK("debug_stamp");
+  return MISEG_OK;
+}
+
 extern "C" int miseg_counter_copy(uint64_t* d, const uint64_t* src, miseg_stream_t s_) {
   MISEG_REQUIRE(d && src, MISEG_E_BADARG, "counter_copy: null pointer");
   counter_copy_kernel<<<1, 1, 0, (hipStream_t)s_>>>(d, src);

@@ -216,6 +216,7 @@ PROTOS = {
     "miseg_resample3d": (i32, [C.POINTER(Resample3d), vp]),
     "miseg_dropout": (i32, [C.POINTER(Dropout), vp]),
     "miseg_counter_add": (i32, [vp, C.c_uint64, vp]),
+    "miseg_debug_stamp": (i32, [vp, vp]),
     "miseg_counter_copy": (i32, [vp, vp, vp]),
     "miseg_abi_struct_size": (C.c_size_t, [C.c_char_p]),
     "miseg_device_check": (i32, [i32]),

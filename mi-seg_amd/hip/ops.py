@@ -27,6 +27,28 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+STAMPS = {} if os.environ.get("MISEG_STEP_STAMPS") == "1" else None      # measurement aid (scripts/debug/step_stamps.py): name -> slot of _STAMP_BUF
+_STAMP_BUF = None
+
+
+def stamp(name, stream=None):
+    """record the device wall clock when `stream` (default: the current one) gets here (miseg_debug_stamp; capture-safe); off unless
+    MISEG_STEP_STAMPS=1.  read_stamps() returns {name: microseconds} of the last run / replay."""
+    global _STAMP_BUF
+    if STAMPS is None:
+        return
+    if _STAMP_BUF is None:
+        _STAMP_BUF = torch.zeros(64, dtype=torch.int64, device="cuda")
+    slot = STAMPS.setdefault(name, len(STAMPS))
+    st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+    L.check(L.load().miseg_debug_stamp(C.c_void_p(_STAMP_BUF.data_ptr() + 8 * slot), st), "debug_stamp")
+
+
+def read_stamps():
+    v = _STAMP_BUF.cpu().tolist()
+    return {k: v[i] / 100.0 for k, i in STAMPS.items()}      # 100 MHz
+
+
 def rows(t):
     """(ld, nrows, C) of a channels-last row view; raises if the leading dims are not uniformly strided."""
     if not t.is_cuda:
@@ -463,7 +485,7 @@ def gemm_tn(a, b, out=None, accumulate=False, split_k=0):
     assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == M * N
     q = _queues(out) if accumulate else None
     if q is not None and split_k <= 0 and not (M % 48 == 0 and N % 48 == 0 and K >= 2048 and a.dtype == torch.bfloat16):
-        q.gemm_tn.append((a, b, out))      # small problem: grouped launch at the end of the backward pass
+        q.lists().gemm_tn.append((a, b, out))      # small problem: grouped launch at the end of the backward pass
         return out
     split_k = max(0, split_k)          # 0: the library picks the kernel and the split over the reduction rows
     p = L.Gemm(_ptr(a), lda, _ptr(b), ldb, _ptr(out), N, M, N, K, 1, 1, _dt(a), L.F32, None, L.ACT_NONE, int(accumulate), split_k, None, None, 0, None, 0, 0, 0)
@@ -474,7 +496,7 @@ def gemm_tn(a, b, out=None, accumulate=False, split_k=0):
         p.workspace = ws.data_ptr()
         if q is not None:      # the per-split partial tiles are summed by one batched launch later
             p.defer_reduce = 1
-            q.tn_reduce.append((ws, out, N, M, N, lib.miseg_gemm_tn_splits(C.byref(p))))
+            q.lists().tn_reduce.append((ws, out, N, M, N, lib.miseg_gemm_tn_splits(C.byref(p))))
     _call("miseg_gemm", p)
     return out
 
@@ -524,6 +546,7 @@ BACKGROUND_WORKGROUPS = 32     # cap of the branch's own background weight-gradi
 DEFERRED_WORKGROUPS = 64       # cap of the main stream's deferred weight gradients (defer_to_branch).  (own cap, this cap) on one box, no branch =
                                # 132.6, branch alone 134.5: (24, 48) 136.9, (24, 64) 140.8, (24, 96) 139.8, (48, 64) 140.6, (64, 64) 140.7, (32, 32) 128.9
 GROUP_EARLY_WORKGROUPS = int(os.environ.get("MISEG_EARLY_GROUP_WG", "0"))      # cap of the early (branch-stream) grouped weight-gradient launch; 0 = off
+FLUSH_MAIN_BEFORE_JOIN = os.environ.get("MISEG_FLUSH_AFTER_JOIN", "0") != "1"   # arena.end_backward: the main stream's grouped launches do not wait for the branch
 DEFER_MIN_ROWS = 400000        # 96^3 layers only (the smaller ones are grouped into one launch at the end of the backward pass)
 # (round 3: the queue of deferred launches itself lives on the training arena's StepQueues - `branch_deferred` - and is found through the
 # gradient slot a launch accumulates into, like the other per-step queues: two models in one process no longer share it)
@@ -600,16 +623,24 @@ def early_group_flush(q):
     _flush_conv_wgrads(q.conv_wgrad, background=GROUP_EARLY_WORKGROUPS)
 
 
-def join_branch(flush_deferred=True, queues=None):
-    """the current stream waits for the branch stream: before anything that consumes what the branch's backward produced (the queued
-    weight-gradient launches of arena.end_backward, the optimiser, the end of a hipGraph capture).  queues: the arena's StepQueues whose
-    deferred launches are issued here when the branch's backward never ran (nothing in it needed a gradient)."""
+def join_branch(flush_deferred=True, queues=None, flush_main=False):
+    """the current stream waits for the branch stream: before anything that consumes what the branch's backward produced (the side queue's
+    launches of arena.end_backward, the optimiser, the end of a hipGraph capture).  queues: the arena's StepQueues whose
+    deferred launches are issued here when the branch's backward never ran (nothing in it needed a gradient).
+    flush_main: the main stream's own queued launches go out BEFORE the wait (they read nothing of the branch's)."""
     if flush_deferred:
         for q in ([queues] if queues is not None else list(QUEUES.values())):
             if q.branch_deferred:
                 flush_branch_deferred(q)
+    stamp("main_chain_end")
+    if flush_main and queues is not None:
+        queues.flush(side=False)
+        stamp("main_flushed")
     if _BRANCH_STREAM is not None:
+        if STAMPS is not None and not torch.cuda.current_stream() == _BRANCH_STREAM:
+            stamp("branch_end", _BRANCH_STREAM)
         torch.cuda.current_stream().wait_stream(_BRANCH_STREAM)
+        stamp("joined")
 
 
 def in_branch_backward():
@@ -641,15 +672,25 @@ class StepQueues:
     streaming ones, the conv weight gradients of the 48^3-and-smaller layers.  One instance per training arena, found through the
     storage of the gradient slot a kernel accumulates into - two models (two arenas) in one process do not share anything."""
 
-    def __init__(self):
+    def __init__(self, side=True):
         self.colsum, self.gemm_tn, self.tn_reduce, self.conv_wgrad = [], [], [], []
         self.branch_deferred = None      # while the model's side branch is open: [(x, dy, slot, mode)], see defer_to_branch
+        # what the side branch's backward pass queues (it reads tensors the BRANCH stream produced) is kept apart: the main stream issues
+        # its own grouped launches as soon as its chain ends - beside the branch's last full-size kernels, which run in background form on
+        # a fraction of the CUs - and only the branch's few wait for the join (arena.end_backward)
+        self.side = StepQueues(side=False) if side else None
 
-    def flush(self):
+    def lists(self):
+        """the queue a launch issued NOW belongs to"""
+        return self.side if (self.side is not None and in_branch_backward()) else self
+
+    def flush(self, side=True):
         _flush_conv_wgrads(self.conv_wgrad)
         _flush_gemm_tn(self.gemm_tn)
         _flush_tn_reduces(self.tn_reduce)
         _flush_colsums(self.colsum)
+        if side and self.side is not None:
+            self.side.flush()
 
 
 QUEUES = {}             # data_ptr of an arena's flat gradient storage -> its StepQueues while a step of that arena is open
@@ -717,7 +758,7 @@ def colsum(x, out=None, accumulate=False):
     ld, n, Cc = rows(x)
     q = _queues(out) if (out is not None and accumulate) else None
     if q is not None:
-        q.colsum.append((x, out))          # keeps x alive until the flush
+        q.lists().colsum.append((x, out))          # keeps x alive until the flush
         return out
     if out is None:
         out = torch.empty(Cc, dtype=torch.float32, device=x.device)
@@ -856,7 +897,7 @@ def conv3_wgrad(x, dy, dw=None, accumulate=False):
     # (narrow bf16 layers - 16 / 32 channels on both sides - have a kernel of their own that finishes a 48^3 layer in ~10 us: never queued)
     narrow = x.dtype == torch.bfloat16 and Cin in (16, 32) and Cout in (16, 32)
     if q is not None and PROFILE_HOOK is None and B * D * H * W <= CONV_WGRAD_GROUP_VOXELS and not narrow:
-        q.conv_wgrad.append((x, dy, dw, int(accumulate)))      # keeps x and dy alive until the flush
+        q.lists().conv_wgrad.append((x, dy, dw, int(accumulate)))      # keeps x and dy alive until the flush
         return dw
     lib = L.load()
     ws = torch.empty(lib.miseg_conv3_wgrad_workspace_bytes(B, D, H, W, Cin, Cout) // 4, dtype=torch.float32, device=x.device)

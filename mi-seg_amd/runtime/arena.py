@@ -246,11 +246,13 @@ class ParamArena:
     def end_backward(self):
         """issue the queued bias-gradient column sums (one launch per 32); call after loss.backward(), inside the captured
         region when the step is a hipGraph.  publish() / allreduce() call it too."""
-        ops.join_branch(queues=self.queues)          # the queued launches below read what a model's side branch produced
+        # the main stream's grouped launches first (beside the branch's last kernels), the wait, then what the branch's backward queued
+        ops.join_branch(queues=self.queues, flush_main=ops.FLUSH_MAIN_BEFORE_JOIN)
         if self.queues is not None:
             self.queues.flush()
             self.queues = None
             ops.QUEUES.pop(self._qkey, None)
+        ops.stamp("queues_flushed")
         ops.join_wgrad()
         ops.WGRAD_STREAM = None
 

@@ -109,12 +109,15 @@ class GraphedStep:
             for p in self.params:
                 p.grad = None
             ops.begin_step()
+        ops.stamp("step_begin")
         y = self.model(self.x, (self.styles, host))
+        ops.stamp("forward_end")
         y.backward(self.cot)
         if self.arena is not None:
             self.arena.end_backward()
         else:
             ops.join_branch()          # a capture must not end with a model's side branch unjoined
+        ops.stamp("step_end")
         return y
 
     def _run_first(self, host):

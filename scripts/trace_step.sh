@@ -6,7 +6,7 @@ TAG=${1:-step}
 shift || true
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/trace_$TAG
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/trace_$TAG -o t -- python3 $R/bench.py --no-cpu-baseline --no-roofline --steps 10 --warmup 3 "$@" > $R/gpurun_out/trace_$TAG.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/trace_$TAG -o t -- python3 $R/bench.py --no-cpu-baseline --no-roofline --no-secondary --steps 10 --warmup 3 "$@" > $R/gpurun_out/trace_$TAG.log 2>&1
 cd $R
 T=$(find gpurun_out/trace_$TAG -name '*kernel_trace.csv' | head -1)
 S=$(find gpurun_out/trace_$TAG -name '*kernel_stats.csv' | head -1)
