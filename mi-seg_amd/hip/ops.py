@@ -540,12 +540,15 @@ def wgrad_side(*keep, kind="gemm"):
 
 
 _BRANCH_STREAM = None
+_MAIN_STREAM = None            # the stream a model's forward forked its side branch from (swin_unetr.py sets it)
 BACKGROUND_LAUNCHES = 0        # running count of launches issued in background form (bench.py reports the per-step figure)
 BACKGROUND_WORKGROUPS = 32     # cap of the branch's own background weight-gradient launch (each workgroup owns a CU).  Step against no branch,
                                # two boxes, before the deferral below: 256 (no cap) -0.4 %, 128 +1.0, 64 +1.4, 32 +2.0 / +2.4, 16 +2.0, 8 -3.8
 DEFERRED_WORKGROUPS = 64       # cap of the main stream's deferred weight gradients (defer_to_branch).  (own cap, this cap) on one box, no branch =
                                # 132.6, branch alone 134.5: (24, 48) 136.9, (24, 64) 140.8, (24, 96) 139.8, (48, 64) 140.6, (64, 64) 140.7, (32, 32) 128.9
 GROUP_EARLY_WORKGROUPS = int(os.environ.get("MISEG_EARLY_GROUP_WG", "0"))      # cap of the early (branch-stream) grouped weight-gradient launch; 0 = off
+FLUSH_SMALL_ON_BRANCH = os.environ.get("MISEG_SMALL_FLUSH_ON_MAIN", "0") != "1"
+FLUSH_SIDE_ON_BRANCH = os.environ.get("MISEG_SIDE_FLUSH_AFTER_JOIN", "0") != "1"
 FLUSH_MAIN_BEFORE_JOIN = os.environ.get("MISEG_FLUSH_AFTER_JOIN", "0") != "1"   # arena.end_backward: the main stream's grouped launches do not wait for the branch
 DEFER_MIN_ROWS = 400000        # 96^3 layers only (the smaller ones are grouped into one launch at the end of the backward pass)
 # (round 3: the queue of deferred launches itself lives on the training arena's StepQueues - `branch_deferred` - and is found through the
@@ -617,10 +620,20 @@ def early_group_flush(q):
     """at the TAIL of the side branch's backward pass (its last node calls this): the small layers' weight gradients queued so far go out on
     the branch stream as one grouped launch in background form, beside what the main stream has left of its small-grid chain - instead of
     after it, at the very end of the step.  (At the HEAD of the branch the same launch made the branch the critical path: 145.4 -> 134.7
-    patches/s with 64 workgroups, 141.1 with 128.)  GROUP_EARLY_WORKGROUPS = 0 switches it off."""
-    if q is None or not q.conv_wgrad or not GROUP_EARLY_WORKGROUPS or not in_branch_backward():
+    patches/s with 64 workgroups, 141.1 with 128.)  GROUP_EARLY_WORKGROUPS = 0 switches it off.
+    Round 3, with the wait on the main stream this launch needs for its operands: 146.5 -> 114.0 patches/s uncapped, 111.1 with 128 - the
+    device-clock stamps show the WHOLE branch starting 2.3 ms later (its head at 5.9 ms instead of 3.6): a second edge main -> branch inside
+    the captured step makes the hipGraph executor run the branch's segment behind the main stream's.  The same happened to a third stream
+    forked for this launch at the point where the main stream enters the Swin stages' backward pass (147 -> 118: branch and third stream
+    shared one queue, GPU_MAX_HW_QUEUES=8 changed nothing).  One fork and one join per side stream is what replays concurrently."""
+    if q is None or not q.conv_wgrad or not GROUP_EARLY_WORKGROUPS or not in_branch_backward() or _MAIN_STREAM is None:
         return
-    _flush_conv_wgrads(q.conv_wgrad, background=GROUP_EARLY_WORKGROUPS)
+    # the queued layers' operands were produced on the MAIN stream: everything the host has issued there so far (autograd issues the nodes of
+    # both streams in one order) is what the launch needs.  -1: no cap (the branch's chain is over, the launch is alone on its stream)
+    torch.cuda.current_stream().wait_stream(_MAIN_STREAM)
+    stamp("early_group_begin")
+    _flush_conv_wgrads(q.conv_wgrad, background=max(GROUP_EARLY_WORKGROUPS, 0), keep=True)
+    stamp("early_group_end")
 
 
 def join_branch(flush_deferred=True, queues=None, flush_main=False):
@@ -634,6 +647,22 @@ def join_branch(flush_deferred=True, queues=None, flush_main=False):
                 flush_branch_deferred(q)
     stamp("main_chain_end")
     if flush_main and queues is not None:
+        cur = torch.cuda.current_stream() if _BRANCH_STREAM is not None else None      # (no side stream: the CPU ranks of the gloo tests)
+        if queues.side is not None and _BRANCH_STREAM is not None and FLUSH_SIDE_ON_BRANCH and cur != _BRANCH_STREAM:
+            # what the branch's backward queued goes out on the BRANCH stream, behind its last kernel: the branch ends ~0.3 ms before the main
+            # chain (step stamps), so these launches run beside the main stream's last kernels instead of behind the join.  The main stream's
+            # grouped GEMM weight gradients, partial-tile sums and column sums follow them there (after a wait for the main chain), beside
+            # the main stream's grouped conv weight gradients: that launch holds one 96 KB workgroup per CU and leaves the rest of the CU idle
+            with torch.cuda.stream(_BRANCH_STREAM):
+                queues.side.flush()
+            if FLUSH_SMALL_ON_BRANCH and (queues.gemm_tn or queues.tn_reduce or queues.colsum):
+                for lst in (queues.gemm_tn, queues.tn_reduce, queues.colsum):      # operands of the main stream, read on the branch: alive until join_wgrad
+                    _WGRAD_KEEP.extend(t for it in lst for t in it if isinstance(t, torch.Tensor))
+                _BRANCH_STREAM.wait_stream(cur)
+                with torch.cuda.stream(_BRANCH_STREAM):
+                    _flush_gemm_tn(queues.gemm_tn)
+                    _flush_tn_reduces(queues.tn_reduce)
+                    _flush_colsums(queues.colsum)
         queues.flush(side=False)
         stamp("main_flushed")
     if _BRANCH_STREAM is not None:
@@ -857,7 +886,7 @@ def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False):
 CONV_WGRAD_GROUP_VOXELS = 48 ** 3   # layers up to this many voxels are queued: alone they fill a fraction of the chip for 40-85 us each
 
 
-def _flush_conv_wgrads(q, background=0):
+def _flush_conv_wgrads(q, background=0, keep=False):
     """background > 0: the grouped launch walks its units with that many workgroups (miseg_conv3_wgrad_params.max_workgroups of the first
     descriptor) - issued on the side-branch stream beside the main stream's small-grid launches; operands and workspace stay alive until
     join_wgrad (the queue that held them is cleared here, and the allocator knows nothing about the branch stream's reads)"""
@@ -877,7 +906,7 @@ def _flush_conv_wgrads(q, background=0):
             wsb = lib.miseg_conv3_wgrad_group_workspace_bytes(descs, len(chunk))
             ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32, device=chunk[0][0].device)
             L.check(lib.miseg_conv3_wgrad_group(descs, len(chunk), _ptr(ws), _stream()), "conv3_wgrad_group")
-            if background:
+            if background or keep:
                 _WGRAD_KEEP.append(ws)
                 _WGRAD_KEEP.extend(t for it in chunk for t in it[:2])
     q.clear()

@@ -227,6 +227,7 @@ class SwinUNETR(nn.Module):
             # Swin stages (in front of decoder2, i.e. no forward overlap but a longer backward window, measured 138.7; here 143.4; right
             # behind the Swin transformer 143.3)
             side, cur = ops.branch_stream(x_in.device), torch.cuda.current_stream()
+            ops._MAIN_STREAM = cur
             side.wait_stream(cur)
             for t in (hs[0], x_in, styles[0] if styles is not None else None):      # allocated on this stream, read by the branch's kernels
                 if t is not None:
@@ -235,10 +236,19 @@ class SwinUNETR(nn.Module):
                 enc0 = self._skip_block(self.encoder1, None, styles, x_in.shape, self.encoder1.layer.conv2.conv.weight.shape[0], dt, image=x_in, dtype=dt)
                 enc1 = self._skip_block(self.encoder2, hs[0], styles, hs[0].shape, hs[0].shape[-1], dt)
                 ops.stamp("branch_fwd_end")
-        dec4 = self.encoder10(h4, styles)
-        dec3 = self.decoder5(dec4, h3, styles)
-        dec2 = self.decoder4(dec3, enc3, styles)
-        dec1 = self.decoder3(dec2, enc2, styles)
+        def mark(t, name):      # measurement aid (MISEG_STEP_STAMPS=1): the device clock when the forward / the backward pass gets here
+            if ops.STAMPS is not None:
+                ops.stamp("f:" + name)
+                if t.requires_grad:
+                    t.register_hook(lambda g, n=name: ops.stamp("b:" + n))
+            return t
+        for i_, t_ in enumerate(hs):
+            mark(t_, f"hs{i_}")
+        mark(enc2, "enc2"); mark(enc3, "enc3")
+        dec4 = mark(self.encoder10(h4, styles), "dec4")
+        dec3 = mark(self.decoder5(dec4, h3, styles), "dec3")
+        dec2 = mark(self.decoder4(dec3, enc3, styles), "dec2")
+        dec1 = mark(self.decoder3(dec2, enc2, styles), "dec1")
         if infer_branch:
             side, cur = ops.branch_stream(x_in.device), torch.cuda.current_stream()
         if branch or infer_branch:       # join: decoder2 is the first consumer of the branch
@@ -253,6 +263,6 @@ class SwinUNETR(nn.Module):
             ops.close_branch_deferral(self.parameters())     # split step: the decoder side's gradients are all-reduced right after the first half - nothing of it may wait
         if branch and (cut is None or self.split_defers) and os.environ.get("MISEG_NO_DEFER") is None:
             ops.open_branch_deferral(self.parameters())       # decoder1's two 96^3 weight gradients wait for the branch's backward pass (hip/ops.py::defer_to_branch)
-        dec0 = self.decoder2(dec1, enc1, styles)
-        out = self.decoder1(dec0, enc0, styles)
+        dec0 = mark(self.decoder2(dec1, enc1, styles), "dec0")
+        out = mark(self.decoder1(dec0, enc0, styles), "out")
         return self.out(out)
