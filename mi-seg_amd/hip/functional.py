@@ -581,7 +581,7 @@ class _Conv3(Function):
             elif slot is not None:
                 q = ops._queues(slot)
                 if q is not None and q.branch_deferred and ops.in_branch_backward():
-                    ops.stamp("branch_bwd_head")
+                    ops.stamp("branch_bwd_head", fine=True)
                     ops.flush_branch_deferred(q)
                 with ops.wgrad_side(x, dy, kind="conv"):
                     ops.conv3_wgrad(x, dy, dw=slot, accumulate=mode)

@@ -27,15 +27,17 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-STAMPS = {} if os.environ.get("MISEG_STEP_STAMPS") == "1" else None      # measurement aid (scripts/debug/step_stamps.py): name -> slot of _STAMP_BUF
+STAMPS = {} if os.environ.get("MISEG_STEP_STAMPS") in ("1", "2") else None
+STAMPS_FINE = os.environ.get("MISEG_STEP_STAMPS") == "1"      # "2": only the stamps at the ends of the passes (every stamp is a graph node and
+                                                              # the nodes around a fork change how the executor cuts the graph into chains)      # measurement aid (scripts/debug/step_stamps.py): name -> slot of _STAMP_BUF
 _STAMP_BUF = None
 
 
-def stamp(name, stream=None):
+def stamp(name, stream=None, fine=False):
     """record the device wall clock when `stream` (default: the current one) gets here (miseg_debug_stamp; capture-safe); off unless
     MISEG_STEP_STAMPS=1.  read_stamps() returns {name: microseconds} of the last run / replay."""
     global _STAMP_BUF
-    if STAMPS is None:
+    if STAMPS is None or (fine and not STAMPS_FINE):
         return
     if _STAMP_BUF is None:
         _STAMP_BUF = torch.zeros(64, dtype=torch.int64, device="cuda")

@@ -203,7 +203,7 @@ class SwinUNETR(nn.Module):
                 enc1 = self._skip_block(self.encoder2, hs0, styles, hs0.shape, hs0.shape[-1], dt)
 
         hs = self.swinViT(x_in, self.normalize, styles, dt, after_stage1=fork_inference if infer_branch else None)
-        ops.stamp("swin_end")
+        ops.stamp("swin_end", fine=True)
         if not branch and not infer_branch:
             enc0 = self._skip_block(self.encoder1, None, styles, x_in.shape, self.encoder1.layer.conv2.conv.weight.shape[0], dt, image=x_in, dtype=dt)
             enc1 = self._skip_block(self.encoder2, hs[0], styles, hs[0].shape, hs[0].shape[-1], dt)
@@ -235,9 +235,9 @@ class SwinUNETR(nn.Module):
             with torch.cuda.stream(side):
                 enc0 = self._skip_block(self.encoder1, None, styles, x_in.shape, self.encoder1.layer.conv2.conv.weight.shape[0], dt, image=x_in, dtype=dt)
                 enc1 = self._skip_block(self.encoder2, hs[0], styles, hs[0].shape, hs[0].shape[-1], dt)
-                ops.stamp("branch_fwd_end")
+                ops.stamp("branch_fwd_end", fine=True)
         def mark(t, name):      # measurement aid (MISEG_STEP_STAMPS=1): the device clock when the forward / the backward pass gets here
-            if ops.STAMPS is not None:
+            if ops.STAMPS is not None and ops.STAMPS_FINE:
                 ops.stamp("f:" + name)
                 if t.requires_grad:
                     t.register_hook(lambda g, n=name: ops.stamp("b:" + n))
@@ -252,7 +252,7 @@ class SwinUNETR(nn.Module):
         if infer_branch:
             side, cur = ops.branch_stream(x_in.device), torch.cuda.current_stream()
         if branch or infer_branch:       # join: decoder2 is the first consumer of the branch
-            ops.stamp("main_at_fwd_join")
+            ops.stamp("main_at_fwd_join", fine=True)
             cur.wait_stream(side)
             for t in (enc0, enc1):
                 t.record_stream(cur)

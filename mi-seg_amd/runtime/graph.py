@@ -124,15 +124,21 @@ class GraphedStep:
         """forward + the decoder-side half of the backward pass; everything queued so far is issued, so the late parameters'
         arena slots are final when this returns"""
         self.arena.begin_step()
+        ops.stamp("step_begin")
         cut = []
         y = self.model(self.x, (self.styles, host), cut=cut)
+        ops.stamp("forward_end")
         y.backward(self.cot)
+        ops.stamp("first_half_chain_end")
         self.arena.flush()
+        ops.stamp("first_half_end")
         return y, cut
 
     def _run_second(self, cut):
+        ops.stamp("second_half_begin")
         torch.autograd.backward([o for o, _ in cut], [l.grad for _, l in cut])
         self.arena.end_backward()
+        ops.stamp("step_end")
 
     def _capture(self, host):
         s = torch.cuda.Stream()
