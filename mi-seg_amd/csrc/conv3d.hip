@@ -1078,7 +1078,7 @@ __device__ __forceinline__ void conv3_wgrad_body(const T* __restrict__ x, int64_
             f32x4* dst = reinterpret_cast<f32x4*>(dw + ((int64_t)co * Cin + ci0) * 27 + o);
             f32x4 v = *reinterpret_cast<const f32x4*>(tile + col * (WG_CB * 27) + o);
             if (direct != 2) v += *dst;
-            *dst = v;
+            __builtin_nontemporal_store(v, dst);      // 64 MB per 768 -> 768 layer, written once and read by the optimiser much later
           }
         }
       } else {
