@@ -148,7 +148,7 @@ def main():
             import copy
             out["secondary"] = {}
             for name, over in (("c2_fp32_parity_mode", dict(dtype="f32", steps=5, warmup=2)), ("c3_c_unetr_bf16", dict(workload="c3", steps=10, warmup=3)),
-                               ("c5_sliding_window_bf16", dict(workload="c5", steps=1, warmup=1))):
+                               ("c5_sliding_window_bf16", dict(workload="c5", steps=2, warmup=2))):
                 b = copy.copy(a)
                 b.no_roofline, b.no_cpu_baseline = True, True
                 for k, v in over.items():
