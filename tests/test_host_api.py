@@ -218,3 +218,18 @@ def test_cpu_baseline_case_builds(workload):
     assert tuple(x.shape) == (1, 1, 96, 96, 96) and tuple(g.shape) == (1, 6, 96, 96, 96) and callable(fwd)
     name, phys, logical = host_cpu()
     assert phys >= 1 and logical >= phys and isinstance(name, str)
+
+
+def test_bench_refuses_to_time_fewer_ranks_than_asked_for():
+    """`python bench.py --gpus N` with no launcher starts the N ranks itself (bench.py::self_launch) - and on a node with fewer than N GPUs
+    it exits non-zero with a message instead of silently timing one rank and printing n_gpus = 1.  No GPU is touched."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    have = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MISEG_REHEARSE_ONE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(have + 2), "--steps", "1", "--warmup", "0"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0
+    assert f"--gpus {have + 2} but this node shows {have} GPU(s)" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")], "no JSON line may be printed"
