@@ -340,6 +340,9 @@ typedef struct {
   float drop_p; uint64_t drop_seed, drop_stream; const uint64_t* drop_step_dev;
 } miseg_winattn_params;
 int miseg_winattn_fwd(const miseg_winattn_params* p, miseg_stream_t stream);
+/* 1 when the head_dim-16 bf16 matrix-core kernels take this forward call (window attention with a bias table, <= 352 tokens per window;
+ * since round 3 with or without attention dropout), 0 when the one-lane-per-query kernels do.  No launch. */
+int miseg_winattn_on_matrix_cores(const miseg_winattn_params* p);
 
 typedef struct {
   miseg_winattn_params f;          /* same geometry; f.out is the saved forward output */

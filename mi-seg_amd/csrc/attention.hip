@@ -403,10 +403,13 @@ __device__ __forceinline__ void att_load16v(const bf16* p, bool vec, float* dst)
 // NW = waves per workgroup; a wave owns whole 32-query tiles (11 of them for a 7^3 window).  8 for the large grids (measured: 4 -> 8
 // +0.7 % on the step, 11 no better), 11 - one tile per wave - when the launch has fewer workgroups than CUs (stages 3 and 4) and lasts
 // exactly as long as one workgroup.
-template <bool MASK, int NW = 4>
+// DROP: attn_drop on the probabilities (round 3: on the matrix-core path too).  The mask is miseg_dropout's over [windows * heads * n][n]:
+// one 64-bit hash per (query row, group of 4 consecutive keys) - a lane of the 32x32 accumulator holds exactly such groups (keys 8g + 4h ..
+// + 3 of its query), so the cost is 4 hashes per 16 probabilities, what the query-lane kernels pay.
+template <bool MASK, int NW = 4, bool DROP = false>
 __global__ void __launch_bounds__(NW * 64) winattn_fwd_mfma_kernel(const bf16* __restrict__ qkv, int64_t ldq, bf16* __restrict__ out, int64_t ldo,
                                                                const float* __restrict__ qkv_bias, const float* __restrict__ bias_table,
-                                                               float* __restrict__ lse_out, WinGeom g, int tsize, bool vec) {
+                                                               float* __restrict__ lse_out, WinGeom g, int tsize, bool vec, AttnDrop dr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16* Qs = reinterpret_cast<bf16*>(smem);                 // [NP][16]  (pre-scaled, log2 domain)
   bf16* Ks = Qs + ATT_NP * 16;                              // [NP][16]
@@ -454,8 +457,11 @@ __global__ void __launch_bounds__(NW * 64) winattn_fwd_mfma_kernel(const bf16* _
   const int centre = ((g.tw - 1) * tb + (g.tw - 1)) * tb + (g.tw - 1);
   const bool ragged = (n & 31) != 0;
   constexpr float MASKV = -100.f * ATT_LOG2E;
+  const uint64_t dk0 = DROP ? dropout_step_key(dr.key, dr.step_dev) : 0ull;
+  const int dcg = (n + 3) / 4;
   for (int qt = wave; qt < ntiles; qt += NW) {
     const int qi = qt * 32 + r;
+    const int64_t drow = ((int64_t)win * g.heads + head) * n + qi;
     const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + qi * 16 + 8 * h);
     const char* tq = reinterpret_cast<const char*>(table) + kofs[qi] + 4 * centre;   // table[code_q + centre - code_k]
     const int lq = klab[qi];
@@ -503,6 +509,14 @@ __global__ void __launch_bounds__(NW * 64) winattn_fwd_mfma_kernel(const bf16* _
       m = mn;
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[i] *= alpha;
+      if (DROP) {      // out = (P * mask / (1 - p)) V; the denominator l sums every key, dropped or not
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const uint64_t hh = dropout_group_hash(dk0, drow, dcg, kt * 32 + 8 * gq + 4 * h);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sv[4 * gq + e] = dropout_keeps(hh, e, dr.thresh) ? sv[4 * gq + e] * dr.scale : 0.f;
+        }
+      }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 pf = cvt8(sv + 8 * s2);
@@ -578,12 +592,14 @@ __device__ __forceinline__ void att_load16(const bf16* p, bool vec, float* dst) 
 // NW = waves per workgroup (key tiles are dealt to the waves: 24 / NW each).  8 everywhere: two such workgroups still fit a CU (2 x 81 KB
 // LDS, 118 VGPRs); at the deep stages the launch is ONE round of < 256 workgroups and lasts as long as one workgroup, which the extra
 // waves halve (+1.2 % on the step), the large grids gain another 0.7 %.
-template <bool MASK, bool DT /* rel-pos table gradient wanted: no per-element branch around its atomics */, int NW = 4>
+// DROP: dS = P o (M s o dP - delta) with the forward's mask M (re-created from the key), dV += (P o M s)^T dO.  A lane of the 16x16 accumulator
+// holds ONE key of four queries, i.e. four mask rows: four hashes per tile where the forward needs one per four probabilities.
+template <bool MASK, bool DT /* rel-pos table gradient wanted: no per-element branch around its atomics */, int NW = 4, bool DROP = false>
 __global__ void __launch_bounds__(NW * 64, 2) winattn_bwd_mfma_kernel(const bf16* __restrict__ qkv, int64_t ldq, const bf16* __restrict__ out, int64_t ldo,
                                                                   const bf16* __restrict__ dout, int64_t lddo, bf16* __restrict__ dqkv, int64_t lddq,
                                                                   const float* __restrict__ qkv_bias, const float* __restrict__ bias_table,
                                                                   const float* __restrict__ lse_in, float* __restrict__ dqkv_bias,
-                                                                  float* __restrict__ dbias_table, WinGeom g, int tsize, bool vec) {
+                                                                  float* __restrict__ dbias_table, WinGeom g, int tsize, bool vec, AttnDrop dr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16* Qs = reinterpret_cast<bf16*>(smem);          // [NP][16] q * scale * log2e
   bf16* Gs = Qs + ATT_NP * 16;                       // dO
@@ -698,6 +714,9 @@ __global__ void __launch_bounds__(NW * 64, 2) winattn_bwd_mfma_kernel(const bf16
       if (kt == nt16 - 1 && (n & 15)) { itail = i; kval = ki < n; }
     }
   }
+  const uint64_t dk0 = DROP ? dropout_step_key(dr.key, dr.step_dev) : 0ull;
+  const int dcg = (n + 3) / 4;
+  const int64_t dbase = ((int64_t)win * g.heads + head) * n;
   char* mytile = dstile + wave * 16 * ATT_DS_LD;
   char* const ds_w = mytile + fi * ATT_DS_LD + kg * 8;                         // dS[key fi][queries 4kg..]
   const char* const ds_r = mytile + (4 * kg + (fi >> 2)) * ATT_DS_LD + (fi & 3) * 8;   // transposed read: lane (query fi, keys 4kg..)
@@ -722,7 +741,7 @@ __global__ void __launch_bounds__(NW * 64, 2) winattn_bwd_mfma_kernel(const bf16
     for (int i = 0; i < NI; ++i) {
       if (wave + NW * i < nt16) {
         const f32x4 sacc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qfA, kfB[i], nl4, 0, 0, 0);   // rows = queries 4kg+e, col = key fi
-        const f32x4 pacc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gfA, vfB[i], nd4, 0, 0, 0);   // dP - delta
+        const f32x4 pacc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gfA, vfB[i], DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : nd4, 0, 0, 0);   // dP - delta (DROP: dP)
         float pv[4], dsv[4], tbv[4];
         int bidx[4];
 #pragma unroll
@@ -740,9 +759,20 @@ __global__ void __launch_bounds__(NW * 64, 2) winattn_bwd_mfma_kernel(const bf16
 #pragma unroll
           for (int e = 0; e < 4; ++e) pv[e] = kval ? pv[e] : 0.f;
         }
+        float pm[4];       // the probabilities that multiplied V in the forward pass
+        if (DROP) {
+          const int ki = (wave + NW * i) * 16 + fi;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dsv[e] = pv[e] * pacc[e];
-        const bf16x4 pb4 = bf16x4{(bf16)pv[0], (bf16)pv[1], (bf16)pv[2], (bf16)pv[3]};
+          for (int e = 0; e < 4; ++e) {
+            const uint64_t hh = dropout_group_hash(dk0, dbase + q0 + 4 * kg + e, dcg, ki);
+            pm[e] = dropout_keeps(hh, ki, dr.thresh) ? pv[e] * dr.scale : 0.f;
+            dsv[e] = fmaf(pm[e], pacc[e], pv[e] * nd4[e]);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { pm[e] = pv[e]; dsv[e] = pv[e] * pacc[e]; }
+        }
+        const bf16x4 pb4 = bf16x4{(bf16)pm[0], (bf16)pm[1], (bf16)pm[2], (bf16)pm[3]};
         const bf16x4 db4 = bf16x4{(bf16)dsv[0], (bf16)dsv[1], (bf16)dsv[2], (bf16)dsv[3]};
         const s16x4 pb = __builtin_bit_cast(s16x4, pb4), db = __builtin_bit_cast(s16x4, db4);
         dvt[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gtA, pb, dvt[i], 0, 0, 0);   // dV^T[dim][key] += dO^T P
@@ -868,6 +898,16 @@ static AttnDrop attn_drop_args(const miseg_winattn_params* p) {
   return dr;
 }
 
+static bool fwd_takes_mfma(const miseg_winattn_params* p, const WinGeom& g) {
+  return p->dtype == MISEG_BF16 && g.hd == 16 && g.n <= ATT_NP && p->bias_table && ((uintptr_t)p->out % 8 == 0) && p->ldo % 4 == 0;
+}
+
+extern "C" int miseg_winattn_on_matrix_cores(const miseg_winattn_params* p) {
+  WinGeom g;
+  if (!p || make_geom(p, &g)) return 0;
+  return fwd_takes_mfma(p, g) ? 1 : 0;
+}
+
 extern "C" int miseg_winattn_fwd(const miseg_winattn_params* p, miseg_stream_t s_) {
   hipStream_t s = (hipStream_t)s_;
   MISEG_REQUIRE(p, MISEG_E_BADARG, "winattn_fwd: null params");
@@ -882,17 +922,19 @@ extern "C" int miseg_winattn_fwd(const miseg_winattn_params* p, miseg_stream_t s
   MISEG_REQUIRE(sh <= 160 * 1024, MISEG_E_UNSUPPORTED, "winattn_fwd: %zu bytes of LDS needed", sh);
   dim3 grid(g.B * g.nwd * g.nwh * g.nww, g.heads);
   const int threads = cdiv(g.n, 64) * 64;
-  if (!dr.thresh && p->dtype == MISEG_BF16 && g.hd == 16 && g.n <= ATT_NP && p->bias_table && ((uintptr_t)p->out % 8 == 0) && p->ldo % 4 == 0) {
+  if (fwd_takes_mfma(p, g)) {
     const size_t shm = attn_mfma_fwd_smem(tsize);
     const bool vec = p->ldq % 8 == 0 && (uintptr_t)p->qkv % 16 == 0;
     const bool wide = (int64_t)grid.x * grid.y < 256;       // fewer workgroups than CUs: one query tile per wave
-#define FWD_MFMA(M, NWV)                                                                                                                       \
-  MISEG_SET_SMEM((winattn_fwd_mfma_kernel<M, NWV>), shm);                    \
-  winattn_fwd_mfma_kernel<M, NWV><<<grid, NWV * 64, shm, s>>>((const bf16*)p->qkv, p->ldq, (bf16*)p->out, p->ldo, p->qkv_bias, p->bias_table, \
-                                                              p->lse, g, tsize, vec)
+#define FWD_MFMA_D(M, NWV, D)                                                                                                                  \
+  MISEG_SET_SMEM((winattn_fwd_mfma_kernel<M, NWV, D>), shm);                    \
+  winattn_fwd_mfma_kernel<M, NWV, D><<<grid, NWV * 64, shm, s>>>((const bf16*)p->qkv, p->ldq, (bf16*)p->out, p->ldo, p->qkv_bias, p->bias_table, \
+                                                                 p->lse, g, tsize, vec, dr)
+#define FWD_MFMA(M, NWV) do { if (dr.thresh) { FWD_MFMA_D(M, NWV, true); } else { FWD_MFMA_D(M, NWV, false); } } while (0)
     if ((g.sd | g.sh | g.sw) != 0) { if (wide) { FWD_MFMA(true, 11); } else { FWD_MFMA(true, 8); } }
     else { if (wide) { FWD_MFMA(false, 11); } else { FWD_MFMA(false, 8); } }
 #undef FWD_MFMA
+#undef FWD_MFMA_D
     MISEG_LAUNCH_CHECK("winattn_fwd_mfma");
     return MISEG_OK;
   }
@@ -921,24 +963,26 @@ extern "C" int miseg_winattn_bwd(const miseg_winattn_bwd_params* p, miseg_stream
   MISEG_REQUIRE(sh <= 160 * 1024, MISEG_E_UNSUPPORTED, "winattn_bwd: %zu bytes of LDS needed", sh);
   dim3 grid(g.B * g.nwd * g.nwh * g.nww, g.heads);
   const int threads = cdiv(g.n, 64) * 64;
-  if (!dr.thresh && p->f.dtype == MISEG_BF16 && g.hd == 16 && g.n <= ATT_NP && p->f.bias_table && ((uintptr_t)p->dqkv % 8 == 0) && p->lddq % 4 == 0 &&
+  if (p->f.dtype == MISEG_BF16 && g.hd == 16 && g.n <= ATT_NP && p->f.bias_table && ((uintptr_t)p->dqkv % 8 == 0) && p->lddq % 4 == 0 &&
       ((uintptr_t)p->f.qkv % 8 == 0) && p->f.ldq % 4 == 0) {
     const bool vec = p->f.ldq % 8 == 0 && p->f.ldo % 8 == 0 && p->lddo % 8 == 0 && (uintptr_t)p->f.qkv % 16 == 0 && (uintptr_t)p->f.out % 16 == 0 &&
                      (uintptr_t)p->dout % 16 == 0;
     // fewer workgroups than CUs (stages 3 and 4): the 8-wave form
     const bool wide = true;       // 8 waves everywhere: two such workgroups still fit a CU (2 x 81 KB LDS, 118 VGPRs) and every stage gains
     const size_t shm = attn_mfma_bwd_smem(tsize, wide ? 8 : 4);
-#define BWD_MFMA(M, D, NWV)                                                                                                                                 \
-  MISEG_SET_SMEM((winattn_bwd_mfma_kernel<M, D, NWV>), shm);                              \
-  winattn_bwd_mfma_kernel<M, D, NWV><<<grid, NWV * 64, shm, s>>>((const bf16*)p->f.qkv, p->f.ldq, (const bf16*)p->f.out, p->f.ldo, (const bf16*)p->dout,    \
-                                                                 p->lddo, (bf16*)p->dqkv, p->lddq, p->f.qkv_bias, p->f.bias_table, p->f.lse, p->dqkv_bias, \
-                                                                 p->dbias_table, g, tsize, vec)
+#define BWD_MFMA_X(M, D, NWV, X)                                                                                                                            \
+  MISEG_SET_SMEM((winattn_bwd_mfma_kernel<M, D, NWV, X>), shm);                              \
+  winattn_bwd_mfma_kernel<M, D, NWV, X><<<grid, NWV * 64, shm, s>>>((const bf16*)p->f.qkv, p->f.ldq, (const bf16*)p->f.out, p->f.ldo, (const bf16*)p->dout,    \
+                                                                    p->lddo, (bf16*)p->dqkv, p->lddq, p->f.qkv_bias, p->f.bias_table, p->f.lse, p->dqkv_bias, \
+                                                                    p->dbias_table, g, tsize, vec, dr)
+#define BWD_MFMA(M, D, NWV) do { if (dr.thresh) { BWD_MFMA_X(M, D, NWV, true); } else { BWD_MFMA_X(M, D, NWV, false); } } while (0)
 #define BWD_MFMA_W(M, D) do { if (wide) { BWD_MFMA(M, D, 8); } else { BWD_MFMA(M, D, 4); } } while (0)
     const bool masked = (g.sd | g.sh | g.sw) != 0;
     if (p->dbias_table) { if (masked) BWD_MFMA_W(true, true); else BWD_MFMA_W(false, true); }
     else { if (masked) BWD_MFMA_W(true, false); else BWD_MFMA_W(false, false); }
 #undef BWD_MFMA_W
 #undef BWD_MFMA
+#undef BWD_MFMA_X
     MISEG_LAUNCH_CHECK("winattn_bwd_mfma");
     return MISEG_OK;
   }

@@ -178,6 +178,7 @@ PROTOS = {
     "miseg_conv3_wgrad_group_workspace_bytes": (C.c_size_t, [C.POINTER(Conv3Wgrad), i32]),
     "miseg_conv3_wgrad_group": (i32, [C.POINTER(Conv3Wgrad), i32, vp, vp]),
     "miseg_winattn_fwd": (i32, [C.POINTER(Winattn), vp]),
+    "miseg_winattn_on_matrix_cores": (i32, [vp]),
     "miseg_winattn_bwd": (i32, [C.POINTER(WinattnBwd), vp]),
     "miseg_add": (i32, [C.POINTER(Add), vp]),
     "miseg_affine2": (i32, [C.POINTER(Affine2), vp]),

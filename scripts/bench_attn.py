@@ -27,7 +27,15 @@ def run(dims, heads, C, ws, ss, dtype, iters=10):
         return sorted(ts)[2]
     f = t(lambda: ops.winattn_fwd(qkv, qb, tab, heads, ws, ss, 7, scale))
     b = t(lambda: ops.winattn_bwd(qkv, out, lse, g, qb, tab, heads, ws, ss, 7, scale, dqb, dt))
-    print(f"dims {dims} heads {heads} C {C} shift {ss} {str(dtype)[6:]}: fwd {f:8.1f} us  bwd {b:8.1f} us", flush=True)
+    msg = f"dims {dims} heads {heads} C {C} shift {ss} {str(dtype)[6:]}: fwd {f:8.1f} us  bwd {b:8.1f} us"
+    if "drop" in sys.argv:      # attn_drop = 0.1: the same kernels with the mask drawn inside (round 3; the query-lane kernels before)
+        ops.begin_step()
+        key = ops.DROP.next_key(qkv.device)
+        outd, lsed = ops.winattn_fwd(qkv, qb, tab, heads, ws, ss, 7, scale, drop=(0.1, key))
+        fd = t(lambda: ops.winattn_fwd(qkv, qb, tab, heads, ws, ss, 7, scale, drop=(0.1, key)))
+        bd = t(lambda: ops.winattn_bwd(qkv, outd, lsed, g, qb, tab, heads, ws, ss, 7, scale, dqb, dt, drop=(0.1, key)))
+        msg += f" | attn_drop 0.1: fwd {fd:8.1f} us  bwd {bd:8.1f} us"
+    print(msg, flush=True)
 
 for dt in (torch.bfloat16,):
     run((48, 48, 48), 3, 48, (7, 7, 7), (0, 0, 0), dt)

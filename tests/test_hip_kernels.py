@@ -742,6 +742,11 @@ def test_window_attention_dropout_on_the_probabilities(dtype, dims, ws, ss, head
     kept = float((mask != 0).float().mean())
     assert abs(kept - (1 - p)) < 0.01 and torch.all((mask == 0) | ((mask - 1 / (1 - p)).abs() < 1e-6))
     out, lse = ops.winattn_fwd(qkv, qb, table, heads, ws, ss, 7, scale, drop=(p, key))
+    # round 3: attention dropout no longer leaves the matrix-core kernels (head_dim 16, bf16) - the same mask, drawn in their accumulator layout
+    import ctypes
+    from mi_seg_amd.hip import lib as hiplib
+    prm = ops.winattn_params(qkv, out, qb, table, lse, heads, ws, ss, 7, scale, (p, key))
+    assert hiplib.load().miseg_winattn_on_matrix_cores(ctypes.byref(prm)) == (1 if dtype == torch.bfloat16 else 0)
     qr = qkv.float().clone().requires_grad_(True)
     qbr, tr = qb.clone().requires_grad_(True), table.clone().requires_grad_(True)
     ref = _ref_window_attention(qr, qbr, tr, heads, ws, ss, 7, scale, drop_mask=mask)
