@@ -81,6 +81,12 @@ typedef struct {
 int miseg_instnorm_apply(const miseg_instnorm_apply_params* p, miseg_stream_t stream);
 /* statistics (into the zero-filled p->stat) + apply in one call; tensors of <= 512 rows per sample take ONE fused launch */
 int miseg_instnorm_fwd(const miseg_instnorm_apply_params* p, miseg_stream_t stream);
+/* miseg_instnorm_fwd whose input is still the `nslabs` fp32 partial slabs [B*S][C] (slab_stride elements apart) of a split convolution
+ * (miseg_conv3_params.defer_slabs): x = round(sum of the slabs) is formed in registers and WRITTEN to p->x (the convolution's output, which
+ * the backward pass reads), statistics, normalisation, residual and activation follow in the same launch.  S <= miseg_instnorm_fused_max_rows()
+ * (2048) only: one workgroup owns every row of its channels there (dynunet_block.py:100-126 at the 12^3-and-smaller stages). */
+int miseg_instnorm_fwd_slabs(const miseg_instnorm_apply_params* p, const float* slabs, int nslabs, int64_t slab_stride, miseg_stream_t stream);
+int miseg_instnorm_fused_max_rows(void);
 
 /* backward of the fused op above.  dy is the gradient w.r.t. y; when act != NONE, y (the saved output)
  * supplies the sign for the activation gradient.  Outputs: dx, optionally dres (= gradient flowing to the
@@ -264,9 +270,14 @@ typedef struct {
   /* ABI 4: 1 = background launch (96-byte-chunk path): one workgroup per CU instead of two, so that the kernels of another stream find
    * registers, LDS and wave slots on every CU while this one runs (a branch of the step running beside its latency-bound chain) */
   int32_t background;
+  /* ABI 5: 1 = when the launch splits its reduction (miseg_conv3_fwd_splits > 1) it stops after the partial slabs in `workspace`
+   * ([splits][B*D*H*W][Cout] fp32): the caller's next launch sums them (miseg_instnorm_fwd_slabs) - y and stat are NOT written.  No `res`. */
+  int32_t defer_slabs;
 } miseg_conv3_params;
 /* small grids split the reduction over workgroups and need an fp32 staging buffer of the output */
 size_t miseg_conv3_fwd_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int dtype);
+/* number of partial slabs the launch leaves in `workspace` (1 = no split: y is written directly) */
+int miseg_conv3_fwd_splits(int B, int D, int H, int W, int Cin, int Cout, int dtype);
 int miseg_conv3_fwd(const miseg_conv3_params* p, miseg_stream_t stream);
 
 /* w: fp32 torch layout [Cout][Cin][3][3][3].  fwd_pack feeds miseg_conv3_fwd on x, bwd_pack (taps mirrored, channels swapped) feeds it

@@ -1415,6 +1415,17 @@ extern "C" size_t miseg_conv3_fwd_workspace_bytes(int B, int D, int H, int W, in
   return ks > 1 ? (size_t)ks * B * D * H * W * Cout * sizeof(float) : 0;
 }
 
+extern "C" int miseg_conv3_fwd_splits(int B, int D, int H, int W, int Cin, int Cout, int dtype) {
+  const int esz = dtype == MISEG_F32 ? 4 : 2;
+  const int rowbytes = conv3_k96(Cin, esz, conv3_pad_min_bytes()) * esz;
+  if (!rowbytes) return 1;
+  int nt, ks;
+  const int nchunks = rowbytes / 96;
+  fwd96_plan(B * cdiv(D, FBD) * cdiv(H, FBH) * cdiv(W, FBW), Cout, nchunks, &nt, &ks);
+  const int cps = cdiv(nchunks, ks);
+  return cdiv(nchunks, cps);
+}
+
 template <class T>
 static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
   constexpr int KPC = Vec16<T>::N;
@@ -1460,6 +1471,10 @@ static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
 #undef F96_CASE
 #undef F96_LAUNCH
     MISEG_LAUNCH_CHECK("conv3_fwd96");
+    if (scratch && p->defer_slabs) {      // the caller's next launch sums the slabs itself (miseg_instnorm_fwd_slabs)
+      MISEG_REQUIRE(!p->res, MISEG_E_UNSUPPORTED, "conv3_fwd: defer_slabs with a fused residual");
+      return MISEG_OK;
+    }
     if (scratch)      // sum of the slabs + residual -> y, with the statistics of y when asked for (one launch)
       return slabs_to_out_stats(scratch, ksplit, p->y, p->ldy, p->res, p->ldres, p->B, p->D * p->H * p->W, p->Cout, p->dtype, (double*)p->stat, s);
     return MISEG_OK;

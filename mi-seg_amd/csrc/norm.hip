@@ -748,11 +748,28 @@ __device__ __forceinline__ void fused_totals(float (&v)[NVV], float* red, double
   __syncthreads();
 }
 
-template <class T, int VEC>
-__global__ void __launch_bounds__(NORM_THREADS) instnorm_fused_fwd_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ res, int64_t ldres,
+template <int VEC> __device__ __forceinline__ void add_floats(const float* __restrict__ p, float (&a)[VEC]) {
+  if constexpr (VEC % 4 == 0) {
+#pragma unroll
+    for (int j = 0; j < VEC / 4; ++j) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * j);
+      a[4 * j] += v[0]; a[4 * j + 1] += v[1]; a[4 * j + 2] += v[2]; a[4 * j + 3] += v[3];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) a[j] += p[j];
+  }
+}
+
+// SLABS: the input is still the `nslabs` fp32 partial slabs [B * S][C] of a split convolution (miseg_conv3_params.defer_slabs): a lane sums
+// its elements, rounds them to T - that IS the convolution's output, written to x for the backward pass - and goes on as below.  One launch
+// where the split convolution's reduce launch and the norm's apply launch were two (the <= 2048-row layers of the deep stages).
+template <class T, int VEC, bool SLABS = false>
+__global__ void __launch_bounds__(NORM_THREADS) instnorm_fused_fwd_kernel(T* __restrict__ x, int64_t ldx, const T* __restrict__ res, int64_t ldres,
                                                                           T* __restrict__ y, int64_t ldy, int S, int C, int cv, int tx_n, int ty_n,
                                                                           double* __restrict__ stat, float eps, const int32_t* __restrict__ styles, StylePtrs sp,
-                                                                          int act, float slope) {
+                                                                          int act, float slope, const float* __restrict__ slabs = nullptr, int nslabs = 0,
+                                                                          int64_t slab_stride = 0) {
   extern __shared__ __attribute__((aligned(16))) float red[];
   double* tot = reinterpret_cast<double*>(red + (NORM_THREADS / 16) * 2 * VEC * tx_n);
   const int b = blockIdx.y;
@@ -774,10 +791,27 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_fused_fwd_kernel(const 
     }
   }
   PRow<T, VEC> xr[FUSED_MAXR], rr[FUSED_MAXR];
+  if constexpr (SLABS) {
 #pragma unroll
-  for (int u = 0; u < FUSED_MAXR; ++u) {
-    const int r = ty + u * ty_n;
-    if (live && r < S) xr[u].load(x + (boff + r) * ldx + c * VEC);
+    for (int u = 0; u < FUSED_MAXR; ++u) {
+      const int r = ty + u * ty_n;
+      if (live && r < S) {
+        float a[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) a[i] = 0.f;
+        const float* sp0 = slabs + (boff + r) * (int64_t)C + c * VEC;
+        for (int k = 0; k < nslabs; ++k) add_floats<VEC>(sp0 + k * slab_stride, a);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) xr[u].set(i, a[i]);
+        xr[u].store(x + (boff + r) * ldx + c * VEC);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < FUSED_MAXR; ++u) {
+      const int r = ty + u * ty_n;
+      if (live && r < S) xr[u].load(x + (boff + r) * ldx + c * VEC);
+    }
   }
   if (res) {
 #pragma unroll
@@ -1299,11 +1333,18 @@ extern "C" int miseg_instnorm_apply(const miseg_instnorm_apply_params* p, miseg_
   });
 }
 
+extern "C" int miseg_instnorm_fused_max_rows(void) { return NORM_FUSED_MAX_ROWS; }
+
 // statistics + normalisation: the two kernels above, or one fused launch for the small tensors of the deep stages
-extern "C" int miseg_instnorm_fwd(const miseg_instnorm_apply_params* p, miseg_stream_t stream_) {
+static int instnorm_fwd_impl(const miseg_instnorm_apply_params* p, const float* slabs, int nslabs, int64_t slab_stride, miseg_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   MISEG_REQUIRE(p && p->x && p->y && p->stat, MISEG_E_BADARG, "instnorm_fwd: null pointer");
   MISEG_REQUIRE(!p->res_stat, MISEG_E_UNSUPPORTED, "instnorm_fwd: res_stat (shortcut norm on the fly) is a miseg_instnorm_apply feature");
+  if (slabs) {
+    MISEG_REQUIRE(p->S <= NORM_FUSED_MAX_ROWS, MISEG_E_UNSUPPORTED, "instnorm_fwd_slabs: %d rows per sample (at most %d: miseg_instnorm_fused_max_rows)", p->S,
+                  NORM_FUSED_MAX_ROWS);
+    MISEG_REQUIRE(nslabs >= 1 && slab_stride >= (int64_t)p->B * p->S * p->C, MISEG_E_BADARG, "instnorm_fwd_slabs: nslabs / slab_stride");
+  }
   if (p->S > NORM_FUSED_MAX_ROWS) {
     miseg_instnorm_stats_params sp_{p->x, p->ldx, p->B, p->S, p->C, p->dtype, const_cast<void*>(p->stat)};
     const int rc = miseg_instnorm_stats(&sp_, stream_);
@@ -1314,21 +1355,33 @@ extern "C" int miseg_instnorm_fwd(const miseg_instnorm_apply_params* p, miseg_st
   return dispatch_dtype(p->dtype, [&](auto* tag) -> int {
     typedef typename std::remove_pointer<decltype(tag)>::type T;
     constexpr int V = Vec16<T>::N;
-    const int64_t ldor = p->ldx | p->ldy | (p->res ? p->ldres : 0);
-    const bool al = aligned16(p->x) && aligned16(p->y) && (!p->res || aligned16(p->res)) && ldor % V == 0;
+    const int64_t ldor = p->ldx | p->ldy | (p->res ? p->ldres : 0) | (slabs ? p->C : 0);
+    const bool al = aligned16(p->x) && aligned16(p->y) && (!p->res || aligned16(p->res)) && ldor % V == 0 && (!slabs || (aligned16(slabs) && slab_stride % 4 == 0));
     const FusedGeom g = fused_geom(p->S, p->C, al, V);
     StylePtrs sp;
     for (int s = 0; s < MISEG_MAX_STYLES; ++s) { sp.gamma[s] = s < p->num_styles ? p->gamma[s] : nullptr; sp.beta[s] = s < p->num_styles ? p->beta[s] : nullptr; }
     dim3 grid(cdiv(g.cv, g.tx), p->B);
     const size_t sh = fused_smem(g, 2, 0);
 #define FWD_LAUNCH(VV)                                                                                                                                       \
-    instnorm_fused_fwd_kernel<T, VV><<<grid, NORM_THREADS, sh, stream>>>((const T*)p->x, p->ldx, (const T*)p->res, p->ldres, (T*)p->y, p->ldy, p->S, p->C, g.cv, g.tx, \
-                                                                         g.ty, (double*)p->stat, p->eps, p->styles, sp, p->act, p->slope)
+    if (slabs)                                                                                                                                               \
+      instnorm_fused_fwd_kernel<T, VV, true><<<grid, NORM_THREADS, sh, stream>>>((T*)p->x, p->ldx, (const T*)p->res, p->ldres, (T*)p->y, p->ldy, p->S, p->C, g.cv, \
+                                                                                 g.tx, g.ty, (double*)p->stat, p->eps, p->styles, sp, p->act, p->slope, slabs,       \
+                                                                                 nslabs, slab_stride);                                                               \
+    else                                                                                                                                                     \
+      instnorm_fused_fwd_kernel<T, VV, false><<<grid, NORM_THREADS, sh, stream>>>((T*)p->x, p->ldx, (const T*)p->res, p->ldres, (T*)p->y, p->ldy, p->S, p->C, g.cv, \
+                                                                                  g.tx, g.ty, (double*)p->stat, p->eps, p->styles, sp, p->act, p->slope)
     FUSED_DISPATCH(g, FWD_LAUNCH);
 #undef FWD_LAUNCH
     MISEG_LAUNCH_CHECK("instnorm_fwd");
     return MISEG_OK;
   });
+}
+
+extern "C" int miseg_instnorm_fwd(const miseg_instnorm_apply_params* p, miseg_stream_t stream) { return instnorm_fwd_impl(p, nullptr, 0, 0, stream); }
+
+extern "C" int miseg_instnorm_fwd_slabs(const miseg_instnorm_apply_params* p, const float* slabs, int nslabs, int64_t slab_stride, miseg_stream_t stream) {
+  MISEG_REQUIRE(slabs, MISEG_E_BADARG, "instnorm_fwd_slabs: null slabs");
+  return instnorm_fwd_impl(p, slabs, nslabs, slab_stride, stream);
 }
 
 extern "C" int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stream_t stream_) {

@@ -127,7 +127,9 @@ class _InstNorm(Function):
         # beside the autograd inputs: to autograd the result is an ordinary fresh output, not an aliased / in-place-modified input
         global _PENDING_OUT
         out, _PENDING_OUT = _PENDING_OUT, None
-        if stat_in is not None:      # statistics already produced by the epilogue of the kernel that wrote x
+        if isinstance(stat_in, ops.PendingSlabs):      # x is the not-yet-summed output of a split convolution: one launch finishes both
+            y, stat = ops.instnorm_fwd_slabs(x, stat_in, B, S, styles_dev, gammas, betas, res=res, act=act, slope=slope, eps=eps, out=out)
+        elif stat_in is not None:      # statistics already produced by the epilogue of the kernel that wrote x
             stat = stat_in
             y = ops.instnorm_apply(x, B, S, stat, styles_dev, gammas, betas, res=res, act=act, slope=slope, eps=eps, out=out)
         else:
@@ -549,16 +551,17 @@ class _Conv3(Function):
     def forward(ctx, x, weight, want_stat=False, fork=False):
         need_dx = ctx.needs_input_grad[0]
         fwdp, bwdp = ops.pack_conv3(weight, x.dtype, True, need_dx)
-        y, stat = ops.conv3_fwd(x, fwdp, weight.shape[0], want_stat=True) if want_stat else (ops.conv3_fwd(x, fwdp, weight.shape[0]), None)
+        # want_stat = "defer": the statistics slot may come back as ops.PendingSlabs - y is then written by the instance norm that consumes it
+        y, stat = ops.conv3_fwd(x, fwdp, weight.shape[0], want_stat=want_stat) if want_stat else (ops.conv3_fwd(x, fwdp, weight.shape[0]), None)
         ctx.save_for_backward(x, bwdp)
         ctx.wshape = weight.shape
         ctx.params = (weight,)
-        ctx.layout = (want_stat, fork)
+        ctx.layout = (bool(want_stat), fork)
         # the statistics output never gets a gradient: without this autograd would materialise a zero tensor for it (a fill launch)
         ctx.set_materialize_grads(False)
         outs = [y]
         if want_stat:
-            if stat is not None:
+            if isinstance(stat, torch.Tensor):
                 ctx.mark_non_differentiable(stat)
             outs.append(stat)
         if fork:

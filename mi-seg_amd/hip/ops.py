@@ -82,7 +82,7 @@ PROFILE_HOOK = None   # bench.py roofline leg: list collecting (kernel, start_ev
 PROFILE_REPS = 5      # launches per timed interval in the roofline leg (event packets cost several us each)
 
 
-def _call(fn_name, params, prof=None, prof_params=None):
+def _call(fn_name, params, prof=None, prof_params=None, extra=()):
     lib = L.load()
     if PROFILE_HOOK is not None and prof is not None:
         # roofline leg only: the launch is repeated back to back between two events on the launch stream, so the interval is
@@ -91,16 +91,16 @@ def _call(fn_name, params, prof=None, prof_params=None):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         fn = getattr(lib, fn_name)
         rp = prof_params if prof_params is not None else params
-        L.check(fn(C.byref(rp), _stream()), fn_name)          # warm (weights / L2 state as in a normal step)
+        L.check(fn(C.byref(rp), *extra, _stream()), fn_name)          # warm (weights / L2 state as in a normal step)
         e0.record()
         for _ in range(PROFILE_REPS):
-            L.check(fn(C.byref(rp), _stream()), fn_name)
+            L.check(fn(C.byref(rp), *extra, _stream()), fn_name)
         e1.record()
         PROFILE_HOOK.append((prof[0], e0, e1, prof[1], prof[2] if len(prof) > 2 else 0.0))
         if prof_params is not None:
-            L.check(fn(C.byref(params), _stream()), fn_name)
+            L.check(fn(C.byref(params), *extra, _stream()), fn_name)
         return
-    L.check(getattr(lib, fn_name)(C.byref(params), _stream()), fn_name)
+    L.check(getattr(lib, fn_name)(C.byref(params), *extra, _stream()), fn_name)
 
 
 def _nb(*tensors):
@@ -286,6 +286,21 @@ def instnorm_fwd(x, B, S, styles, gammas, betas, res=None, act=L.ACT_NONE, slope
     p = L.InstnormApply(_ptr(x), ld, _ptr(res), ldr, _ptr(y), rows(y)[0], B, S, Cc, _dt(x), _ptr(stat), eps, _ptr(styles), ns,
                         _style_arrays(gammas, ns), _style_arrays(betas, ns), act, slope)
     _call("miseg_instnorm_fwd", p, prof=("instnorm", 0.0, _nb(x, res, y)))      # (statistics are stored, not accumulated: repeatable)
+    return y, stat
+
+
+def instnorm_fwd_slabs(x, pending, B, S, styles, gammas, betas, res=None, act=L.ACT_NONE, slope=0.01, eps=1e-5, out=None):
+    """instnorm_fwd on the output `x` of a split convolution that is still `pending` (PendingSlabs): ONE launch sums the slabs, writes x,
+    and normalises; returns (y, stat)."""
+    ld, n, Cc = rows(x)
+    assert n == B * S and ld == Cc, (n, B, S, ld, Cc)
+    stat = STAT_POOL.take(L.load().miseg_instnorm_stat_bytes(B, Cc) // 8, x.device).view(-1, B, Cc, 2)
+    y = out if out is not None else torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    ldr = rows(res)[0] if res is not None else 0
+    ns = len(gammas) if gammas is not None else 1
+    p = L.InstnormApply(_ptr(x), ld, _ptr(res), ldr, _ptr(y), rows(y)[0], B, S, Cc, _dt(x), _ptr(stat), eps, _ptr(styles), ns,
+                        _style_arrays(gammas, ns), _style_arrays(betas, ns), act, slope)
+    _call("miseg_instnorm_fwd_slabs", p, prof=("instnorm", 0.0, _nb(x, res, y) + 4.0 * pending.n * pending.stride), extra=(_ptr(pending.ws), pending.n, pending.stride))
     return y, stat
 
 
@@ -544,9 +559,9 @@ def wgrad_side(*keep, kind="gemm"):
 _BRANCH_STREAM = None
 _MAIN_STREAM = None            # the stream a model's forward forked its side branch from (swin_unetr.py sets it)
 BACKGROUND_LAUNCHES = 0        # running count of launches issued in background form (bench.py reports the per-step figure)
-BACKGROUND_WORKGROUPS = 32     # cap of the branch's own background weight-gradient launch (each workgroup owns a CU).  Step against no branch,
+BACKGROUND_WORKGROUPS = int(os.environ.get("MISEG_BG_WG", "32"))     # cap of the branch's own background weight-gradient launch (each workgroup owns a CU).  Step against no branch,
                                # two boxes, before the deferral below: 256 (no cap) -0.4 %, 128 +1.0, 64 +1.4, 32 +2.0 / +2.4, 16 +2.0, 8 -3.8
-DEFERRED_WORKGROUPS = 64       # cap of the main stream's deferred weight gradients (defer_to_branch).  (own cap, this cap) on one box, no branch =
+DEFERRED_WORKGROUPS = int(os.environ.get("MISEG_DEFER_WG", "64"))       # cap of the main stream's deferred weight gradients (defer_to_branch).  (own cap, this cap) on one box, no branch =
                                # 132.6, branch alone 134.5: (24, 48) 136.9, (24, 64) 140.8, (24, 96) 139.8, (48, 64) 140.6, (64, 64) 140.7, (32, 32) 128.9
 GROUP_EARLY_WORKGROUPS = int(os.environ.get("MISEG_EARLY_GROUP_WG", "0"))      # cap of the early (branch-stream) grouped weight-gradient launch; 0 = off
 FLUSH_SMALL_ON_BRANCH = os.environ.get("MISEG_SMALL_FLUSH_ON_MAIN", "0") != "1"
@@ -874,15 +889,30 @@ def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False):
     # algorithmic bytes: x read once, y written once, the weight pack, the fused residual read once
     nbytes = float(x.element_size()) * (B * D * H * W * (Cin + Cout + (Cout if fuse_res else 0)) + wpk.numel())
     stat = None
-    if want_stat and fast:      # (a split reduction computes them in its second launch)
+    # want_stat == "defer" (the caller's next op is an instance norm that can take the partial slabs: instnorm_fwd_slabs): a split launch
+    # over <= 2048 rows per sample stops after its slabs and the norm's ONE launch sums them, writes `out`, and normalises
+    nsplit = lib.miseg_conv3_fwd_splits(B, D, H, W, Cin, Cout, _dt(x)) if (want_stat == "defer" and fast and res is None and ws is not None) else 1
+    defer = nsplit > 1 and D * H * W <= lib.miseg_instnorm_fused_max_rows() and rows(out)[0] == Cout
+    if want_stat and fast and not defer:      # (a split reduction computes them in its second launch)
         stat = STAT_POOL.take(lib.miseg_instnorm_stat_bytes(B, Cout) // 8, x.device).view(-1, B, Cout, 2)
     mk = lambda st: L.Conv3(_ptr(x), ld, _ptr(out), rows(out)[0], _ptr(wpk), B, D, H, W, Cin, Cout, _dt(x), _ptr(ws),
-                            _ptr(res) if fuse_res else None, rows(res)[0] if fuse_res else 0, _ptr(st), bg)
+                            _ptr(res) if fuse_res else None, rows(res)[0] if fuse_res else 0, _ptr(st), bg, 1 if defer else 0)
     scratch = torch.zeros_like(stat) if (stat is not None and PROFILE_HOOK is not None) else None
     _call("miseg_conv3_fwd", mk(stat), prof=(name, flops, nbytes), prof_params=mk(scratch) if scratch is not None else None)
     if res is not None and not fuse_res:
         out = add(out, res)
+    if defer:
+        return out, PendingSlabs(ws, nsplit, B * D * H * W * Cout)
     return (out, stat) if want_stat else out
+
+
+class PendingSlabs:
+    """what conv3_fwd(..., want_stat="defer") returns in place of the statistics: its output tensor is NOT written yet - the fp32 partial
+    slabs of the split launch wait in `ws` for instnorm_fwd_slabs"""
+    __slots__ = ("ws", "n", "stride")
+
+    def __init__(self, ws, n, stride):
+        self.ws, self.n, self.stride = ws, n, stride
 
 
 CONV_WGRAD_GROUP_VOXELS = 48 ** 3   # layers up to this many voxels are queued: alone they fill a fraction of the chip for 40-85 us each

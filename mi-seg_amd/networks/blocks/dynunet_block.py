@@ -13,7 +13,7 @@ import torch.nn as nn
 from ...hip import functional as HF
 from ...hip import lib as L
 from ...hip import ops
-from ..layers.utils import apply_norm, apply_res_norm_pair, get_norm_layer
+from ..layers.utils import apply_norm, apply_res_norm_pair, get_norm_layer, stat_request
 from ..norms.conditional_instance_norm import _ConditionalInstanceNorm
 
 LEAKY_SLOPE = 0.01
@@ -105,11 +105,12 @@ class UnetResBlock(nn.Module):
         elif inp.requires_grad:
             # conv1 hands its input back as the residual branch (its data-gradient epilogue adds that branch's gradient) and the
             # statistics of its output come from its epilogue
-            out, st1, residual = HF.conv3(inp, self.conv1.conv.weight, want_stat=True, fork=True)
+            out, st1, residual = HF.conv3(inp, self.conv1.conv.weight, want_stat=stat_request(self.norm1), fork=True)
         else:
-            (out, st1), residual = HF.conv3(inp, self.conv1.conv.weight, want_stat=True), inp
+            (out, st1), residual = HF.conv3(inp, self.conv1.conv.weight, want_stat=stat_request(self.norm1)), inp
         out = apply_norm(self.norm1, out, styles, act=L.ACT_LEAKY, slope=LEAKY_SLOPE, stat=st1)
-        out, st2 = HF.conv3(out, self.conv2.conv.weight, want_stat=True)
+        # (with a shortcut convolution the pair kernels below read the finished tensor and its statistics)
+        out, st2 = HF.conv3(out, self.conv2.conv.weight, want_stat=True if self.downsample else stat_request(self.norm2))
         if self.downsample:
             if image is not None:       # one-channel image: the shortcut convolution is a rank-1 product, formed inside the norm kernels
                 y = apply_res_norm_pair(self.norm2, out, self.norm3, residual, styles, slope=LEAKY_SLOPE, stat_a=st2, out=out_view,
@@ -142,9 +143,10 @@ class UnetBasicBlock(nn.Module):
         _needs_modalities(self.norm1, styles)
         if image is not None and image.shape[1] > 4:
             inp, image = HF.image_rows(image, dtype), None
-        out, st1 = (HF.conv3_thin(image, self.conv1.conv.weight, dtype), None) if image is not None else HF.conv3(inp, self.conv1.conv.weight, want_stat=True)
+        out, st1 = ((HF.conv3_thin(image, self.conv1.conv.weight, dtype), None) if image is not None
+                    else HF.conv3(inp, self.conv1.conv.weight, want_stat=stat_request(self.norm1)))
         out = apply_norm(self.norm1, out, styles, act=L.ACT_LEAKY, slope=LEAKY_SLOPE, stat=st1)
-        out, st2 = HF.conv3(out, self.conv2.conv.weight, want_stat=True)
+        out, st2 = HF.conv3(out, self.conv2.conv.weight, want_stat=stat_request(self.norm2))
         return apply_norm(self.norm2, out, styles, act=L.ACT_LEAKY, slope=LEAKY_SLOPE, stat=st2, out=out_view)
 
 

@@ -84,6 +84,13 @@ def apply_res_norm_pair(norm_a: nn.Module, xa, norm_b: nn.Module, xb, styles=Non
     return None
 
 
+def stat_request(norm: nn.Module):
+    """what to pass as HF.conv3(..., want_stat=) when `norm` is applied to the convolution's output by apply_norm right away: "defer" lets a
+    split convolution of a small stage leave its partial slabs to the (conditional) instance norm's one launch (HF.ops.PendingSlabs); the
+    other norm kinds read the finished tensor"""
+    return "defer" if isinstance(norm, (_ConditionalInstanceNorm,) + _INSTANCE) else True
+
+
 def apply_norm(norm: nn.Module, x, styles=None, res=None, act=L.ACT_NONE, slope=0.01, stat=None, out=None):
     """Apply a norm *module* (used as a parameter container) to a channels-last tensor through the HIP kernels.
     ``styles`` is the (device int32 tensor, host tuple) pair from styles_to_device; ``stat``: instance-norm statistics of x that the

@@ -482,6 +482,42 @@ def test_conv3_fused_residual_and_statistics(dtype, B, D, H, W, Cin, Cout):
     assert torch.allclose(s, ref, rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,D,H,W,Cin,Cout,with_res", [(1, 12, 12, 12, 192, 192, True), (2, 6, 6, 6, 96, 48, False), (1, 3, 3, 3, 768, 768, True), (2, 5, 7, 6, 96, 96, True)])
+def test_split_conv_leaves_its_slabs_to_the_instance_norm(dtype, B, D, H, W, Cin, Cout, with_res):
+    """conv -> (conditional) instance norm -> + residual -> LeakyReLU at the small stages (dynunet_block.py:100-126): a split convolution
+    asked with want_stat="defer" stops after its fp32 partial slabs and the norm's ONE launch sums them, writes the convolution's output
+    (the backward pass reads it), and normalises (miseg_instnorm_fwd_slabs).  Against the two-step route: bit-identical convolution output,
+    the same statistics and result."""
+    ops = _ops()
+    from mi_seg_amd.hip import lib as hiplib
+    if dtype == torch.float32:
+        Cin = Cin // 2
+    x, w = _conv_case(dtype, B, D, H, W, Cin, Cout, seed=11)
+    fwdp, _ = ops.pack_conv3(w, dtype)
+    S = D * H * W
+    styles = torch.tensor([1, 0][:B], dtype=torch.int32, device=DEV)
+    gam = [rnd(Cout, seed=21 + i) * 0.2 + 1.0 for i in range(2)]
+    bet = [rnd(Cout, seed=31 + i) * 0.2 for i in range(2)]
+    res = rnd(B, D, H, W, Cout, dtype=dtype, seed=41) if with_res else None
+    ops.begin_step()
+    y0, st0 = ops.conv3_fwd(x, fwdp, Cout, want_stat=True)
+    if st0 is None:
+        st0 = ops.instnorm_stats(y0, B, S)
+    out0 = ops.instnorm_apply(y0, B, S, st0, styles, gam, bet, res=res, act=hiplib.ACT_LEAKY, slope=0.01)
+    y1, pend = ops.conv3_fwd(x, fwdp, Cout, want_stat="defer")
+    assert isinstance(pend, ops.PendingSlabs), "these shapes split their reduction and have <= 2048 rows per sample"
+    out1, st1 = ops.instnorm_fwd_slabs(y1, pend, B, S, styles, gam, bet, res=res, act=hiplib.ACT_LEAKY, slope=0.01)
+    assert torch.equal(y1, y0)
+    assert torch.allclose(st1.sum(0), st0.sum(0), rtol=1e-4, atol=1e-3)      # (the one-launch form sums a lane's rows in fp32 before the fp64 totals)
+    assert rel_err(out1.float(), out0.float()) < (1e-6 if dtype == torch.float32 else 4e-3)
+    # a volume above the fused norm's row limit or an unsplit launch keeps the two-step route
+    xb, wb = _conv_case(dtype, 1, 16, 16, 16, 48 if dtype == torch.bfloat16 else 24, 48, seed=12)
+    fb, _ = ops.pack_conv3(wb, dtype)
+    _, stb = ops.conv3_fwd(xb, fb, 48, want_stat="defer")
+    assert not isinstance(stb, ops.PendingSlabs)
+
+
 def test_conv3_exact_integers():
     ops = _ops()
     for dtype in (torch.float32, torch.bfloat16):
