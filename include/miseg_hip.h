@@ -110,6 +110,9 @@ typedef struct {
   const float* beta[MISEG_MAX_STYLES];
 } miseg_instnorm_bwd_params;
 int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stream_t stream);
+/* miseg_instnorm_bwd whose incoming gradient is still the partial slabs of a split data-gradient convolution (as miseg_instnorm_fwd_slabs):
+ * p->dy is ignored (the gradient is summed and rounded in registers and never written).  S <= miseg_instnorm_fused_max_rows() only. */
+int miseg_instnorm_bwd_slabs(const miseg_instnorm_bwd_params* p, const float* slabs, int nslabs, int64_t slab_stride, miseg_stream_t stream);
 /* the reduction half alone (ABI 5): dstat[r][b][c] += (sum dy, sum dy * xhat) over the rows of sample b, xhat from `stat` - what the group /
  * batch norms of the reference's factory (networks/layers/factories.py:219-257) need besides the kernels above (their means run over channel
  * groups / the whole batch: mi-seg_amd/hip/functional.py::group_norm).  Reads dy, x, stat, eps, styles / gamma / beta only with an activation. */

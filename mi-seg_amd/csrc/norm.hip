@@ -871,13 +871,16 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_fused_fwd_kernel(T* __r
   }
 }
 
-template <class T, int VEC>
+// SLABS: dy is still the `nslabs` fp32 partial slabs of the split data-gradient convolution in front of this norm (see the forward kernel):
+// summed and rounded to T in registers - the incoming gradient is never written to memory at all.
+template <class T, int VEC, bool SLABS = false>
 __global__ void __launch_bounds__(NORM_THREADS) instnorm_fused_bwd_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ yact, int64_t ldy,
                                                                           const T* __restrict__ x, int64_t ldx, T* __restrict__ dx, int64_t lddx,
                                                                           T* __restrict__ dres, int64_t lddres, int S, int C, int cv, int tx_n, int ty_n,
                                                                           const double* __restrict__ stat, float eps, const int32_t* __restrict__ styles,
                                                                           StylePtrs sp, StyleGradPtrs gp, int act, float slope, const T* __restrict__ gadd,
-                                                                          int64_t ldgadd) {
+                                                                          int64_t ldgadd, const float* __restrict__ slabs = nullptr, int nslabs = 0,
+                                                                          int64_t slab_stride = 0) {
   extern __shared__ __attribute__((aligned(16))) float red[];
   double* tot = reinterpret_cast<double*>(red + (NORM_THREADS / 16) * 2 * VEC * tx_n);   // totals of (g, g * xhat)
   double* sums = tot + 2 * VEC * tx_n;                                                  // forward statistics [col][2]
@@ -907,7 +910,17 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_fused_bwd_kernel(const 
   for (int u = 0; u < FUSED_MAXR; ++u) {
     const int r = ty + u * ty_n;
     if (live && r < S) {
-      gr[u].load(dy + (boff + r) * lddy + c * VEC);
+      if constexpr (SLABS) {
+        float a[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) a[i] = 0.f;
+        const float* sp0 = slabs + (boff + r) * (int64_t)C + c * VEC;
+        for (int k = 0; k < nslabs; ++k) add_floats<VEC>(sp0 + k * slab_stride, a);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) gr[u].set(i, a[i]);
+      } else {
+        gr[u].load(dy + (boff + r) * lddy + c * VEC);
+      }
       xr[u].load(x + (boff + r) * ldx + c * VEC);
       if (from_y) yr[u].load(yact + (boff + r) * ldy + c * VEC);
     }
@@ -1384,17 +1397,22 @@ extern "C" int miseg_instnorm_fwd_slabs(const miseg_instnorm_apply_params* p, co
   return instnorm_fwd_impl(p, slabs, nslabs, slab_stride, stream);
 }
 
-extern "C" int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stream_t stream_) {
+static int instnorm_bwd_impl(const miseg_instnorm_bwd_params* p, const float* slabs, int nslabs, int64_t slab_stride, miseg_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  MISEG_REQUIRE(p && p->dy && p->x && p->dx && p->stat && p->dstat, MISEG_E_BADARG, "instnorm_bwd: null pointer");
+  MISEG_REQUIRE(p && (p->dy || slabs) && p->x && p->dx && p->stat && p->dstat, MISEG_E_BADARG, "instnorm_bwd: null pointer");
+  if (slabs) {
+    MISEG_REQUIRE(p->S <= NORM_FUSED_MAX_ROWS, MISEG_E_UNSUPPORTED, "instnorm_bwd_slabs: %d rows per sample (at most %d: miseg_instnorm_fused_max_rows)", p->S,
+                  NORM_FUSED_MAX_ROWS);
+    MISEG_REQUIRE(nslabs >= 1 && slab_stride >= (int64_t)p->B * p->S * p->C, MISEG_E_BADARG, "instnorm_bwd_slabs: nslabs / slab_stride");
+  }
   MISEG_REQUIRE(p->act == MISEG_ACT_NONE || p->act == MISEG_ACT_LEAKY, MISEG_E_BADARG, "instnorm_bwd: act %d", p->act);
   MISEG_REQUIRE(p->num_styles >= 1 && p->num_styles <= MISEG_MAX_STYLES, MISEG_E_BADARG, "instnorm_bwd: num_styles %d", p->num_styles);
   return dispatch_dtype(p->dtype, [&](auto* tag) -> int {
     typedef typename std::remove_pointer<decltype(tag)>::type T;
     constexpr int V = Vec16<T>::N;
-    const int64_t ldor = p->lddy | p->ldx | p->lddx | (p->act ? p->ldy : 0) | (p->dres ? p->lddres : 0) | (p->gadd ? p->ldgadd : 0);
-    const bool al = aligned16(p->dy) && aligned16(p->x) && aligned16(p->dx) && (!p->act || aligned16(p->y)) && (!p->dres || aligned16(p->dres)) &&
-                    (!p->gadd || aligned16(p->gadd)) && ldor % V == 0;
+    const int64_t ldor = (slabs ? p->C : p->lddy) | p->ldx | p->lddx | (p->act ? p->ldy : 0) | (p->dres ? p->lddres : 0) | (p->gadd ? p->ldgadd : 0);
+    const bool al = (slabs ? aligned16(slabs) && slab_stride % 4 == 0 : aligned16(p->dy)) && aligned16(p->x) && aligned16(p->dx) && (!p->act || aligned16(p->y)) &&
+                    (!p->dres || aligned16(p->dres)) && (!p->gadd || aligned16(p->gadd)) && ldor % V == 0;
     NormGeom g = norm_geom(p->S, p->C, al, V);
     StylePtrs sp;
     StyleGradPtrs gp;
@@ -1409,9 +1427,16 @@ extern "C" int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stre
       dim3 fgrid(cdiv(f.cv, f.tx), p->B);
       const size_t fsh = fused_smem(f, 2, 1);
 #define FBWD_LAUNCH(VV)                                                                                                                                      \
-      instnorm_fused_bwd_kernel<T, VV><<<fgrid, NORM_THREADS, fsh, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, (T*)p->dx,      \
-                                                                             p->lddx, (T*)p->dres, p->lddres, p->S, p->C, f.cv, f.tx, f.ty, (const double*)p->stat, \
-                                                                             p->eps, p->styles, sp, gp, p->act, p->slope, (const T*)p->gadd, p->ldgadd)
+      if (slabs)                                                                                                                                             \
+        instnorm_fused_bwd_kernel<T, VV, true><<<fgrid, NORM_THREADS, fsh, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx,         \
+                                                                                     (T*)p->dx, p->lddx, (T*)p->dres, p->lddres, p->S, p->C, f.cv, f.tx, f.ty,        \
+                                                                                     (const double*)p->stat, p->eps, p->styles, sp, gp, p->act, p->slope,             \
+                                                                                     (const T*)p->gadd, p->ldgadd, slabs, nslabs, slab_stride);                      \
+      else                                                                                                                                                   \
+        instnorm_fused_bwd_kernel<T, VV, false><<<fgrid, NORM_THREADS, fsh, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx,        \
+                                                                                      (T*)p->dx, p->lddx, (T*)p->dres, p->lddres, p->S, p->C, f.cv, f.tx, f.ty,       \
+                                                                                      (const double*)p->stat, p->eps, p->styles, sp, gp, p->act, p->slope,            \
+                                                                                      (const T*)p->gadd, p->ldgadd)
       FUSED_DISPATCH(f, FBWD_LAUNCH);
 #undef FBWD_LAUNCH
       MISEG_LAUNCH_CHECK("instnorm_bwd");
@@ -1434,6 +1459,13 @@ extern "C" int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stre
     MISEG_LAUNCH_CHECK("instnorm_bwd");
     return MISEG_OK;
   });
+}
+
+extern "C" int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stream_t stream) { return instnorm_bwd_impl(p, nullptr, 0, 0, stream); }
+
+extern "C" int miseg_instnorm_bwd_slabs(const miseg_instnorm_bwd_params* p, const float* slabs, int nslabs, int64_t slab_stride, miseg_stream_t stream) {
+  MISEG_REQUIRE(slabs, MISEG_E_BADARG, "instnorm_bwd_slabs: null slabs");
+  return instnorm_bwd_impl(p, slabs, nslabs, slab_stride, stream);
 }
 
 extern "C" int miseg_instnorm_bwd_reduce(const miseg_instnorm_bwd_params* p, miseg_stream_t stream_) {

@@ -161,7 +161,8 @@ class _InstNorm(Function):
             dgam = [buf[s, 0] if s in present else None for s in range(num_styles)]
             dbet = [buf[s, 1] if s in present else None for s in range(num_styles)]
         dx, dres = ops.instnorm_bwd(dy, y, x, B, S, stat, styles_dev, gammas if affine else None, dgam, dbet, act=act, slope=slope, eps=eps,
-                                    want_dres=has_res and ctx.needs_input_grad[1], gadd=_rv(gskip), betas=betas)
+                                    want_dres=has_res and ctx.needs_input_grad[1], gadd=_rv(gskip), betas=betas,
+                                    pending=ops.PENDING_DX.pop(dy.data_ptr(), None) if ops.PENDING_DX else None)
         pg = []
         if affine:
             for s in range(num_styles):
@@ -548,8 +549,11 @@ class _Conv3(Function):
     data-gradient kernel instead of by a separate pass."""
 
     @staticmethod
-    def forward(ctx, x, weight, want_stat=False, fork=False):
+    def forward(ctx, x, weight, want_stat=False, fork=False, dx_to_norm=False):
+        """dx_to_norm: x is the output of a (conditional) instance norm that nothing else reads, so the data gradient computed here goes
+        straight to that norm's backward pass - a split launch over a small stage may then leave its partial slabs to it (ops.PENDING_DX)"""
         need_dx = ctx.needs_input_grad[0]
+        ctx.dx_to_norm = bool(dx_to_norm)
         fwdp, bwdp = ops.pack_conv3(weight, x.dtype, True, need_dx)
         # want_stat = "defer": the statistics slot may come back as ops.PendingSlabs - y is then written by the instance norm that consumes it
         y, stat = ops.conv3_fwd(x, fwdp, weight.shape[0], want_stat=want_stat) if want_stat else (ops.conv3_fwd(x, fwdp, weight.shape[0]), None)
@@ -575,7 +579,12 @@ class _Conv3(Function):
         gskip = _rv(rest[-1]) if ctx.layout[1] and rest[-1] is not None else None
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.conv3_fwd(dy, bwdp, ctx.wshape[1], res=gskip)
+            if ctx.dx_to_norm and gskip is None:
+                dx, pend = ops.conv3_fwd(dy, bwdp, ctx.wshape[1], defer=True)
+                if pend is not None:
+                    ops.PENDING_DX[dx.data_ptr()] = pend
+            else:
+                dx = ops.conv3_fwd(dy, bwdp, ctx.wshape[1], res=gskip)
         dw = None
         if ctx.needs_input_grad[1]:
             slot, mode = _slot_first(ctx.params[0])
@@ -590,11 +599,11 @@ class _Conv3(Function):
                     ops.conv3_wgrad(x, dy, dw=slot, accumulate=mode)
             else:
                 dw = ops.conv3_wgrad(x, dy)
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
-def conv3(x, weight, want_stat=False, fork=False):
-    return _Conv3.apply(x, weight, want_stat, fork)
+def conv3(x, weight, want_stat=False, fork=False, dx_to_norm=False):
+    return _Conv3.apply(x, weight, want_stat, fork, dx_to_norm)
 
 
 class _Conv3T(Function):

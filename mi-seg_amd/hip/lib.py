@@ -147,6 +147,7 @@ PROTOS = {
     "miseg_instnorm_stat_bytes": (C.c_size_t, [i32, i32]),
     "miseg_instnorm_stats": (i32, [C.POINTER(InstnormStats), vp]),
     "miseg_instnorm_apply": (i32, [C.POINTER(InstnormApply), vp]),
+    "miseg_instnorm_bwd_slabs": (i32, [C.POINTER(InstnormBwd), vp, i32, i64, vp]),
     "miseg_instnorm_fwd_slabs": (i32, [C.POINTER(InstnormApply), vp, i32, i64, vp]),
     "miseg_instnorm_fused_max_rows": (i32, []),
     "miseg_conv3_fwd_splits": (i32, [i32, i32, i32, i32, i32, i32, i32]),

@@ -210,6 +210,7 @@ def begin_step():
     else:
         STAT_POOL.fresh()
     DROP.advance()
+    check_no_pending()
 
 
 def begin_forward(params=()):
@@ -304,8 +305,10 @@ def instnorm_fwd_slabs(x, pending, B, S, styles, gammas, betas, res=None, act=L.
     return y, stat
 
 
-def instnorm_bwd(dy, y, x, B, S, stat, styles, gammas, dgammas, dbetas, act=L.ACT_NONE, slope=0.01, eps=1e-5, want_dres=False, gadd=None, betas=None):
-    """y=None with a LeakyReLU: valid when no residual entered the activation; the kernels recompute its sign from x (needs betas)."""
+def instnorm_bwd(dy, y, x, B, S, stat, styles, gammas, dgammas, dbetas, act=L.ACT_NONE, slope=0.01, eps=1e-5, want_dres=False, gadd=None, betas=None,
+                 pending=None):
+    """y=None with a LeakyReLU: valid when no residual entered the activation; the kernels recompute its sign from x (needs betas).
+    pending (PendingSlabs): dy is the unwritten output of a split data-gradient convolution - the one-launch kernel sums its slabs itself."""
     ld, n, Cc = rows(x)
     dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     dres = torch.empty(x.shape, dtype=x.dtype, device=x.device) if want_dres else None
@@ -317,6 +320,10 @@ def instnorm_bwd(dy, y, x, B, S, stat, styles, gammas, dgammas, dbetas, act=L.AC
                                           _ptr(gadd), rows(gadd)[0] if gadd is not None else 0, _style_arrays(betas, ns))
     # (roofline leg: the repeated launches accumulate their reduction into scratch and leave the affine gradients alone)
     sc = _prof_scratch(dstat)
+    if pending is not None:
+        _call("miseg_instnorm_bwd_slabs", mk(dstat, dgammas, dbetas), prof=("instnorm", 0.0, _nb(y, x, dx, dres, gadd) + 4.0 * pending.n * pending.stride),
+              prof_params=mk(sc, None, None) if sc is not None else None, extra=(_ptr(pending.ws), pending.n, pending.stride))
+        return dx, dres
     _call("miseg_instnorm_bwd", mk(dstat, dgammas, dbetas), prof=("instnorm", 0.0, _nb(dy, y, x, dx, dres, gadd)),
           prof_params=mk(sc, None, None) if sc is not None else None)
     return dx, dres
@@ -870,7 +877,19 @@ def _vol(x):
     return x.shape[0], x.shape[1], x.shape[2], x.shape[3]
 
 
-def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False):
+PENDING_DX = {}      # data_ptr of a data gradient whose split convolution left its slabs to the norm backward that consumes it -> PendingSlabs
+
+
+def check_no_pending():
+    """every deferred slab sum must have been taken by its consumer (the instance-norm backward right behind the data-gradient convolution):
+    a gradient tensor that reached anything else would have been read unwritten"""
+    if PENDING_DX:
+        n = len(PENDING_DX)
+        PENDING_DX.clear()
+        raise RuntimeError(f"{n} deferred data-gradient slab sum(s) were never consumed (conv3(..., dx_to_norm=True) in front of something that is no instance norm)")
+
+
+def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False, defer=False):
     """x [B,D,H,W,Cin] rows view; wpk [Cout][27][CinP].  res: rows view added to the result in the epilogue (falls back to a separate
     add where the kernel path cannot fuse it).  want_stat: returns (out, stat) with stat the instance-norm statistics of `out`
     ([16, B, Cout, 2] fp64, from the kernel's epilogue) or None where that is not available (the caller's norm then computes them)."""
@@ -891,7 +910,8 @@ def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False):
     stat = None
     # want_stat == "defer" (the caller's next op is an instance norm that can take the partial slabs: instnorm_fwd_slabs): a split launch
     # over <= 2048 rows per sample stops after its slabs and the norm's ONE launch sums them, writes `out`, and normalises
-    nsplit = lib.miseg_conv3_fwd_splits(B, D, H, W, Cin, Cout, _dt(x)) if (want_stat == "defer" and fast and res is None and ws is not None) else 1
+    defer_req = bool(defer) or want_stat == "defer"      # (defer without want_stat: the data-gradient direction, returns (out, PendingSlabs | None))
+    nsplit = lib.miseg_conv3_fwd_splits(B, D, H, W, Cin, Cout, _dt(x)) if (defer_req and fast and res is None and ws is not None) else 1
     defer = nsplit > 1 and D * H * W <= lib.miseg_instnorm_fused_max_rows() and rows(out)[0] == Cout
     if want_stat and fast and not defer:      # (a split reduction computes them in its second launch)
         stat = STAT_POOL.take(lib.miseg_instnorm_stat_bytes(B, Cout) // 8, x.device).view(-1, B, Cout, 2)
@@ -903,6 +923,8 @@ def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False):
         out = add(out, res)
     if defer:
         return out, PendingSlabs(ws, nsplit, B * D * H * W * Cout)
+    if defer_req and not want_stat:
+        return out, None
     return (out, stat) if want_stat else out
 
 

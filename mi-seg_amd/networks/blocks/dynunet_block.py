@@ -110,7 +110,8 @@ class UnetResBlock(nn.Module):
             (out, st1), residual = HF.conv3(inp, self.conv1.conv.weight, want_stat=stat_request(self.norm1)), inp
         out = apply_norm(self.norm1, out, styles, act=L.ACT_LEAKY, slope=LEAKY_SLOPE, stat=st1)
         # (with a shortcut convolution the pair kernels below read the finished tensor and its statistics)
-        out, st2 = HF.conv3(out, self.conv2.conv.weight, want_stat=True if self.downsample else stat_request(self.norm2))
+        out, st2 = HF.conv3(out, self.conv2.conv.weight, want_stat=True if self.downsample else stat_request(self.norm2),
+                            dx_to_norm=stat_request(self.norm1) == "defer")      # (norm1's output has no other reader)
         if self.downsample:
             if image is not None:       # one-channel image: the shortcut convolution is a rank-1 product, formed inside the norm kernels
                 y = apply_res_norm_pair(self.norm2, out, self.norm3, residual, styles, slope=LEAKY_SLOPE, stat_a=st2, out=out_view,
@@ -146,7 +147,7 @@ class UnetBasicBlock(nn.Module):
         out, st1 = ((HF.conv3_thin(image, self.conv1.conv.weight, dtype), None) if image is not None
                     else HF.conv3(inp, self.conv1.conv.weight, want_stat=stat_request(self.norm1)))
         out = apply_norm(self.norm1, out, styles, act=L.ACT_LEAKY, slope=LEAKY_SLOPE, stat=st1)
-        out, st2 = HF.conv3(out, self.conv2.conv.weight, want_stat=stat_request(self.norm2))
+        out, st2 = HF.conv3(out, self.conv2.conv.weight, want_stat=stat_request(self.norm2), dx_to_norm=stat_request(self.norm1) == "defer")
         return apply_norm(self.norm2, out, styles, act=L.ACT_LEAKY, slope=LEAKY_SLOPE, stat=st2, out=out_view)
 
 

@@ -253,6 +253,7 @@ class ParamArena:
             self.queues = None
             ops.QUEUES.pop(self._qkey, None)
         ops.stamp("queues_flushed")
+        ops.check_no_pending()
         ops.join_wgrad()
         ops.WGRAD_STREAM = None
 

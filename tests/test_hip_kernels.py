@@ -511,6 +511,28 @@ def test_split_conv_leaves_its_slabs_to_the_instance_norm(dtype, B, D, H, W, Cin
     assert torch.equal(y1, y0)
     assert torch.allclose(st1.sum(0), st0.sum(0), rtol=1e-4, atol=1e-3)      # (the one-launch form sums a lane's rows in fp32 before the fp64 totals)
     assert rel_err(out1.float(), out0.float()) < (1e-6 if dtype == torch.float32 else 4e-3)
+    # the same in the backward direction: the data-gradient convolution (mirrored pack, Cout -> Cin) in front of the norm's backward pass
+    # leaves its slabs to miseg_instnorm_bwd_slabs - the incoming gradient is never written
+    _, bwdp = ops.pack_conv3(w, dtype)
+    g2 = rnd(B, D, H, W, Cout, dtype=dtype, seed=51)
+    xin = rnd(B, D, H, W, Cin, dtype=dtype, seed=52)          # the norm's input (Cin channels), its statistics and affine rows
+    gam_i = [rnd(Cin, seed=61 + i) * 0.2 + 1.0 for i in range(2)]
+    bet_i = [rnd(Cin, seed=71 + i) * 0.2 for i in range(2)]
+    st_in = ops.instnorm_stats(xin, B, S)
+    def grads():
+        return [torch.zeros(Cin, device=DEV) for _ in range(2)], [torch.zeros(Cin, device=DEV) for _ in range(2)]
+    dy0 = ops.conv3_fwd(g2, bwdp, Cin)
+    dg0, db0 = grads()
+    dx0, _ = ops.instnorm_bwd(dy0, None, xin, B, S, st_in, styles, gam_i, dg0, db0, act=hiplib.ACT_LEAKY, slope=0.01, betas=bet_i)
+    dy1, pend = ops.conv3_fwd(g2, bwdp, Cin, defer=True)
+    assert isinstance(pend, ops.PendingSlabs) == (Cout * g2.element_size() > 96), "one 96-byte chunk on the K side: nothing to split"
+    if pend is None:
+        assert torch.equal(dy1, dy0)
+    dg1, db1 = grads()
+    dx1, _ = ops.instnorm_bwd(dy1, None, xin, B, S, st_in, styles, gam_i, dg1, db1, act=hiplib.ACT_LEAKY, slope=0.01, betas=bet_i, pending=pend)
+    assert rel_err(dx1.float(), dx0.float()) < (1e-6 if dtype == torch.float32 else 4e-3)
+    for a_, b_ in zip(dg1 + db1, dg0 + db0):
+        assert rel_err(a_, b_) < 1e-4 or float(b_.abs().max()) == 0.0
     # a volume above the fused norm's row limit or an unsplit launch keeps the two-step route
     xb, wb = _conv_case(dtype, 1, 16, 16, 16, 48 if dtype == torch.bfloat16 else 24, 48, seed=12)
     fb, _ = ops.pack_conv3(wb, dtype)
