@@ -198,7 +198,14 @@ class _ZeroPool:
             self._pinned.append(self.buf)
 
 
-STAT_POOL = _ZeroPool()
+DEFAULT_POOL = _ZeroPool()
+STAT_POOL = DEFAULT_POOL      # the ACTIVE pool: every ParamArena owns one (round 3) and makes it the active one for its step / its model's forward
+                              # (use_pool); models without an arena share DEFAULT_POOL.  Two models in one process no longer recycle each other's chunk.
+
+
+def use_pool(pool=None):
+    global STAT_POOL
+    STAT_POOL = pool if pool is not None else DEFAULT_POOL
 
 
 def begin_step():
@@ -217,13 +224,15 @@ def begin_forward(params=()):
     """called by the nets at the top of `forward`: when no training arena manages the step (its begin_step() recycles the pool), the
     statistics of this forward go to a fresh chunk, so an un-managed loop neither grows the pool nor clobbers statistics that an earlier,
     not yet back-propagated forward still needs."""
+    arena = None
+    for p in params:
+        arena = getattr(p, "_miseg_arena", None)
+        break
+    use_pool(getattr(arena, "pool", None))
     if torch.cuda.is_current_stream_capturing():
         return
-    if torch.is_grad_enabled():
-        for p in params:
-            if getattr(p, "_miseg_arena", None) is not None:
-                return
-            break
+    if torch.is_grad_enabled() and arena is not None:
+        return
     STAT_POOL.fresh()
     DROP.advance()
 

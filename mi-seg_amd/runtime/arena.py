@@ -70,6 +70,7 @@ class ParamArena:
         self._offs, self._size = offs, off
         self._qkey = self.flat.untyped_storage().data_ptr()
         self.queues = None
+        self.pool = ops._ZeroPool() if self.flat.is_cuda else None      # this model's statistics scratch (ops.use_pool); CPU arenas (gloo tests) have none
 
     # ---------------------------------------------------------------------------------------------- gradient accumulation
     def no_sync(self):
@@ -92,6 +93,7 @@ class ParamArena:
     def begin_step(self, zero=True):
         """once per optimisation step, before the forward: recycles the statistics pool, zeroes the gradient arena and
         refreshes every registered parameter re-layout (safe inside hipGraph capture once the table exists)."""
+        ops.use_pool(self.pool)          # this arena's statistics pool is the active one from here on
         ops.begin_step()
         if not (self.flat.is_cuda and torch.cuda.is_current_stream_capturing()):
             self.params_changed()

@@ -452,6 +452,51 @@ def test_unet_vs_truth(golden, tag, dtype):
 
 
 @pytest.mark.gpu
+def test_two_models_in_one_process_keep_their_own_step_state():
+    """VERDICT round 2 (process-global launch state): two models with an arena each - a training net and, say, its EMA / validation twin -
+    whose steps INTERLEAVE (forward A, forward B, backward A, backward B).  Each arena owns its step queues, its branch-deferral queue and
+    (round 3) its statistics pool; both steps must give exactly what each model gives alone."""
+    from mi_seg_amd.networks.nets.unetr import UNETR
+    from mi_seg_amd.networks.nets.unet import UNet
+    from mi_seg_amd.runtime.arena import ParamArena
+    from mi_seg_amd.utils.detfill import fill_module_, det_input
+    from mi_seg_amd.hip import ops
+    a = UNETR(1, 3, (32, 32, 32), feature_size=8, hidden_size=48, mlp_dim=96, num_heads=4, pos_embed="perceptron", vit_norm_name=_norm("instance_cond"),
+              encoder_norm_name=_norm("instance_cond"), decoder_norm_name=_norm("instance")).cuda()
+    b = UNet(3, 1, 3, channels=(8, 16, 32), strides=(2, 2), num_res_units=2, norm_down=_norm("instance_cond"), norm_up=_norm("instance")).cuda()
+    for m in (a, b):
+        fill_module_(m)
+        m.set_compute_dtype(torch.bfloat16)
+    x = det_input(3, (2, 1, 32, 32, 32)).cuda()
+    cot = det_input(4, (2, 3, 32, 32, 32)).cuda()
+    arenas = [ParamArena([p for p in m.parameters() if p.requires_grad], torch.bfloat16) for m in (a, b)]
+    assert arenas[0].pool is not arenas[1].pool and arenas[0].pool is not ops.DEFAULT_POOL
+
+    def alone(m, ar):
+        out = None
+        for _ in range(2):          # (the first step of an arena registers its weight re-layouts)
+            ar.begin_step()
+            y = m(x, [0, 1])
+            y.backward(cot)
+            ar.publish()
+            out = y.detach().clone(), ar.flat.clone()
+        return out
+    ref = [alone(m, ar) for m, ar in zip((a, b), arenas)]
+    arenas[0].begin_step()
+    ya = a(x, [0, 1])
+    arenas[1].begin_step()
+    yb = b(x, [0, 1])
+    ya.backward(cot)
+    yb.backward(cot)
+    arenas[0].publish()
+    arenas[1].publish()
+    for y, ar, (yr, gr) in zip((ya, yb), arenas, ref):
+        assert torch.equal(y.detach(), yr)
+        assert rel_err(ar.flat, gr) < 1e-5
+    ops.use_pool(None)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["swin_unetr", "unetr", "unetr_conv", "unet"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_param_arena_matches_plain_autograd(dtype, kind):
