@@ -360,6 +360,7 @@ __global__ void __launch_bounds__(384) winattn_bwd_kernel(const T* __restrict__ 
 // =====================================================================================================================
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+static constexpr int ATT_TMAX = 2200;               // floats reserved for the bias table of a head ((2 * 7 - 1)^3 = 2197 entries)
 static constexpr int ATT_MAXT = 11;                 // ceil(343 / 32) tiles
 static constexpr int ATT_NP = ATT_MAXT * 32;        // 352 padded tokens
 static constexpr int ATT_VT_LD = ATT_NP + 8;        // row stride (elements) of the dim-major copies
@@ -589,6 +590,13 @@ __device__ __forceinline__ void att_load16(const bf16* p, bool vec, float* dst) 
   }
 }
 
+typedef unsigned pk2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned att_pk_bf16(float a, float b) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_{a, b}, bf16x2_));
+}
+
 // NW = waves per workgroup (key tiles are dealt to the waves: 24 / NW each).  8 everywhere: two such workgroups still fit a CU (2 x 81 KB
 // LDS, 118 VGPRs); at the deep stages the launch is ONE round of < 256 workgroups and lasts as long as one workgroup, which the extra
 // waves halve (+1.2 % on the step), the large grids gain another 0.7 %.
@@ -601,21 +609,23 @@ __global__ void __launch_bounds__(NW * 64, 2) winattn_bwd_mfma_kernel(const bf16
                                                                   const float* __restrict__ lse_in, float* __restrict__ dqkv_bias,
                                                                   float* __restrict__ dbias_table, WinGeom g, int tsize, bool vec, AttnDrop dr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16* Qs = reinterpret_cast<bf16*>(smem);          // [NP][16] q * scale * log2e
-  bf16* Gs = Qs + ATT_NP * 16;                       // dO
-  bf16* Ks = Gs + ATT_NP * 16;
-  int* qcode = reinterpret_cast<int*>(Ks + ATT_NP * 16);
+  // LDS layout: the two tables FIRST - the bias gather and the bin update of a (query, key) pair share one address register (the byte offset
+  // code_q - code_k) and both bases are ds_* immediates (< 64 KB); behind the big tiles the bin update paid an address add per element
+  constexpr int NI = 24 / NW, NTHR = NW * 64;
+  float* table = reinterpret_cast<float*>(smem);            // [ATT_TMAX] bias of this head * log2e
+  int* dtable = reinterpret_cast<int*>(table + ATT_TMAX);   // [ATT_TMAX] fixed point, see `fscale`
+  float* padb = reinterpret_cast<float*>(dtable + ATT_TMAX);   // [48] + 3 bound words (|dO|^2, |V|^2, |delta| maxima), padded to 64 words
+  unsigned* bound = reinterpret_cast<unsigned*>(padb + 48);
+  char* dstile = reinterpret_cast<char*>(padb + 64);        // [NW waves][16 keys][ATT_DS_LD]
+  float* dqpart = reinterpret_cast<float*>(dstile + NW * 16 * ATT_DS_LD);   // [2][NW waves][16 queries][16 dims]
+  int* qcode = reinterpret_cast<int*>(dqpart + 2 * NW * 256);
   int* qlabel = qcode + ATT_NP;
   int* rowq = qlabel + ATT_NP;
   float* nlse = reinterpret_cast<float*>(rowq + ATT_NP);   // -lse * log2e  (-inf beyond the window)
   float* ndelta = nlse + ATT_NP;                            // -rowsum(dO * O)
-  constexpr int NI = 24 / NW, NTHR = NW * 64;
-  float* dqpart = ndelta + ATT_NP;                          // [2][NW waves][16 queries][16 dims]
-  char* dstile = reinterpret_cast<char*>(dqpart + 2 * NW * 256);   // [NW waves][16 keys][ATT_DS_LD]
-  float* padb = reinterpret_cast<float*>(dstile + NW * 16 * ATT_DS_LD);   // [48] + 3 bound words (|dO|^2, |V|^2, |delta| maxima)
-  unsigned* bound = reinterpret_cast<unsigned*>(padb + 48);
-  float* table = padb + 52;                                 // [tsize] * log2e
-  int* dtable = reinterpret_cast<int*>(table + tsize);      // fixed point, see `fscale`
+  bf16* Qs = reinterpret_cast<bf16*>(ndelta + ATT_NP);      // [NP][16] q * scale * log2e
+  bf16* Gs = Qs + ATT_NP * 16;                              // dO
+  bf16* Ks = Gs + ATT_NP * 16;
   const int win = blockIdx.x, head = blockIdx.y, tid = threadIdx.x;
   const int n = g.n, C = g.C, nt16 = (n + 15) / 16;
   if (tid < 52) padb[tid] = 0.f;
@@ -658,7 +668,7 @@ __global__ void __launch_bounds__(NW * 64, 2) winattn_bwd_mfma_kernel(const bf16
     att_store_row(Qs, t, q);
     att_store_row(Ks, t, k);
     att_store_row(Gs, t, go);
-    qcode[t] = code;
+    qcode[t] = code * 4;            // byte offsets into the table
     qlabel[t] = label;
     rowq[t] = row;
     nlse[t] = -ls * ATT_LOG2E;
@@ -674,7 +684,9 @@ __global__ void __launch_bounds__(NW * 64, 2) winattn_bwd_mfma_kernel(const bf16
   // binned in fixed point.  |dS_qk| <= p_qk (|dO_q||V_k| + |delta_q|) and a bin receives at most one key per query, so
   // |bin| <= n * bmax; the scale keeps two bits of headroom for the bf16 rounding of the operands.
   const float bmax = sqrtf(__uint_as_float(bound[0]) * __uint_as_float(bound[1])) + __uint_as_float(bound[2]);
-  const float fscale = bmax > 0.f ? 536870912.f / ((float)n * bmax) : 0.f;
+  // (a contribution stays below 2^21 so that fma(x, fscale, 1.5 * 2^23) rounds it to an integer in the low mantissa bits: one fma + one
+  // integer subtract where mul + rndne + cvt were three instructions)
+  const float fscale = bmax > 0.f ? 536870912.f / ((float)(n > 256 ? n : 256) * bmax) : 0.f;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fi = lane & 15, kg = lane >> 4;   // wave: scalar, so the per-tile guards are scalar branches
   const int tb = 2 * g.tw - 1;
   const int centre = ((g.tw - 1) * tb + (g.tw - 1)) * tb + (g.tw - 1);
@@ -684,6 +696,7 @@ __global__ void __launch_bounds__(NW * 64, 2) winattn_bwd_mfma_kernel(const bf16
   s16x4 kfB[NI], vfB[NI], kA[NI];
   f32x4 dvt[NI], dkt[NI];
   int ck[NI], lk[NI];
+  const char* tkb[NI];        // table - code_k (bytes)
   bool kval = true;
   int itail = -1;
 #pragma unroll
@@ -692,11 +705,13 @@ __global__ void __launch_bounds__(NW * 64, 2) winattn_bwd_mfma_kernel(const bf16
     dvt[i] = dkt[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     kfB[i] = vfB[i] = kA[i] = s16x4{0, 0, 0, 0};
     ck[i] = lk[i] = 0;
+    tkb[i] = reinterpret_cast<const char*>(table);
     if (kt < nt16) {
       const int ki = kt * 16 + fi;
       kfB[i] = att_ld4(Ks, ki, kg);                           // B operand of S:  [k = dim 4kg..][col = key]
       kA[i] = att_tr_rows(Ks, kt * 16, fi, kg);               // A operand of dQ^T: [row = dim][k = key 4kg..]
-      ck[i] = qcode[ki] - centre;
+      ck[i] = qcode[ki] - 4 * centre;
+      tkb[i] = reinterpret_cast<const char*>(table) - ck[i];
       lk[i] = qlabel[ki];
       float v[4] = {0.f, 0.f, 0.f, 0.f};
       if (ki < n) {
@@ -747,7 +762,7 @@ __global__ void __launch_bounds__(NW * 64, 2) winattn_bwd_mfma_kernel(const bf16
 #pragma unroll
         for (int e = 0; e < 4; ++e) {      // all four bias gathers first: an LDS read issued behind one of the bin atomics would wait for it
           bidx[e] = qc[e] - ck[i];
-          tbv[e] = table[bidx[e]];
+          tbv[e] = *reinterpret_cast<const float*>(tkb[i] + qc[e]);      // = table + bidx: the key's share of the address is formed once per wave
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -772,9 +787,12 @@ __global__ void __launch_bounds__(NW * 64, 2) winattn_bwd_mfma_kernel(const bf16
 #pragma unroll
           for (int e = 0; e < 4; ++e) { pm[e] = pv[e]; dsv[e] = pv[e] * pacc[e]; }
         }
-        const bf16x4 pb4 = bf16x4{(bf16)pm[0], (bf16)pm[1], (bf16)pm[2], (bf16)pm[3]};
-        const bf16x4 db4 = bf16x4{(bf16)dsv[0], (bf16)dsv[1], (bf16)dsv[2], (bf16)dsv[3]};
-        const s16x4 pb = __builtin_bit_cast(s16x4, pb4), db = __builtin_bit_cast(s16x4, db4);
+        // pairs through v_cvt_pk_bf16_f32 (two values per instruction, already in operand order): element-wise casts compiled to one
+        // conversion per value plus v_perm packing, and a second set of conversions for the LDS copy - 18 instructions where 4 do
+        const pk2 pbp = pk2{att_pk_bf16(pm[0], pm[1]), att_pk_bf16(pm[2], pm[3])};
+        const pk2 dbp = pk2{att_pk_bf16(dsv[0], dsv[1]), att_pk_bf16(dsv[2], dsv[3])};
+        const s16x4 pb = __builtin_bit_cast(s16x4, pbp), db = __builtin_bit_cast(s16x4, dbp);
+        const bf16x4 db4 = __builtin_bit_cast(bf16x4, dbp);
         dvt[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gtA, pb, dvt[i], 0, 0, 0);   // dV^T[dim][key] += dO^T P
         dkt[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qtA, db, dkt[i], 0, 0, 0);   // dK^T[dim][key] += Q'^T dS
         *reinterpret_cast<bf16x4*>(ds_w) = db4;
@@ -786,7 +804,8 @@ __global__ void __launch_bounds__(NW * 64, 2) winattn_bwd_mfma_kernel(const bf16
         __builtin_amdgcn_wave_barrier();
         if (DT) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) atomicAdd(&dtable[bidx[e]], __float2int_rn(dsv[e] * fscale));
+          for (int e = 0; e < 4; ++e)
+            atomicAdd(reinterpret_cast<int*>(reinterpret_cast<char*>(dtable) + bidx[e]), __float_as_int(fmaf(dsv[e], fscale, 12582912.f)) - 0x4B400000);
         }
       }
     }
@@ -844,7 +863,8 @@ __global__ void __launch_bounds__(NW * 64, 2) winattn_bwd_mfma_kernel(const bf16
 }
 
 static size_t attn_mfma_bwd_smem(int tsize, int nw = 4) {
-  return (size_t)3 * ATT_NP * 32 + (size_t)5 * ATT_NP * 4 + (size_t)2 * nw * 256 * 4 + (size_t)nw * 16 * ATT_DS_LD + 52 * 4 + (size_t)2 * tsize * 4;
+  (void)tsize;
+  return (size_t)3 * ATT_NP * 32 + (size_t)5 * ATT_NP * 4 + (size_t)2 * nw * 256 * 4 + (size_t)nw * 16 * ATT_DS_LD + 64 * 4 + (size_t)2 * ATT_TMAX * 4;
 }
 
 static size_t attn_mfma_fwd_smem(int tsize) {
@@ -963,7 +983,7 @@ extern "C" int miseg_winattn_bwd(const miseg_winattn_bwd_params* p, miseg_stream
   MISEG_REQUIRE(sh <= 160 * 1024, MISEG_E_UNSUPPORTED, "winattn_bwd: %zu bytes of LDS needed", sh);
   dim3 grid(g.B * g.nwd * g.nwh * g.nww, g.heads);
   const int threads = cdiv(g.n, 64) * 64;
-  if (p->f.dtype == MISEG_BF16 && g.hd == 16 && g.n <= ATT_NP && p->f.bias_table && ((uintptr_t)p->dqkv % 8 == 0) && p->lddq % 4 == 0 &&
+  if (p->f.dtype == MISEG_BF16 && g.hd == 16 && g.n <= ATT_NP && p->f.bias_table && tsize <= ATT_TMAX && ((uintptr_t)p->dqkv % 8 == 0) && p->lddq % 4 == 0 &&
       ((uintptr_t)p->f.qkv % 8 == 0) && p->f.ldq % 4 == 0) {
     const bool vec = p->f.ldq % 8 == 0 && p->f.ldo % 8 == 0 && p->lddo % 8 == 0 && (uintptr_t)p->f.qkv % 16 == 0 && (uintptr_t)p->f.out % 16 == 0 &&
                      (uintptr_t)p->dout % 16 == 0;
