@@ -470,7 +470,10 @@ __global__ void __launch_bounds__(NW * 64) winattn_fwd_mfma_kernel(const bf16* _
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    for (int kt = 0; kt < ntiles; ++kt) {
+    // the key tile as a lambda instantiated twice: the test for keys beyond the window belongs to the LAST tile of a ragged window only - as a
+    // condition inside one loop body the compiler turned it into selects executed for every tile (15 compares + 30 v_cndmask of ~175 VALU)
+    auto key_tile = [&](int kt, auto last_tag) {
+      constexpr bool LAST = decltype(last_tag)::value;
       const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + r) * 16 + 8 * h);
       f32x16 sacc;
 #pragma unroll
@@ -491,7 +494,7 @@ __global__ void __launch_bounds__(NW * 64) winattn_fwd_mfma_kernel(const bf16* _
           for (int e = 0; e < 4; ++e) sv[4 * gq + e] += (klv[e] != lq) ? MASKV : 0.f;
         }
       }
-      if (ragged && kt == ntiles - 1) {      // keys beyond the window (only in the last tile)
+      if constexpr (LAST) {      // keys beyond the window (only in the last tile of a ragged window)
 #pragma unroll
         for (int i = 0; i < 16; ++i)
           if (kt * 32 + att_row(i, h) >= n) sv[i] = -INFINITY;
@@ -524,7 +527,10 @@ __global__ void __launch_bounds__(NW * 64) winattn_fwd_mfma_kernel(const bf16* _
         const bf16x8 vf = att_dimmajor_frag(Vt, r, h, kt * 32, s2);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, acc, 0, 0, 0);     // O^T[dim][query] += V^T P^T
       }
-    }
+    };
+    const int nfull = ragged ? ntiles - 1 : ntiles;
+    for (int kt = 0; kt < nfull; ++kt) key_tile(kt, std::false_type{});
+    if (ragged) key_tile(ntiles - 1, std::true_type{});
     const float inv = 1.f / l;
     const int row = rowq[qi];
     if (qi < n) {
