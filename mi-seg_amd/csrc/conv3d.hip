@@ -1156,33 +1156,69 @@ __global__ void __launch_bounds__(WG_THREADS, 2) conv3_wgrad_narrow_kernel(const
     toff[t] = tap < 27 ? (((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3) : 0;
   }
   const int nbricks = g.B * g.nbd * g.nbh * g.nbw;
-  for (int brick = blockIdx.x; brick < nbricks; brick += gridDim.x) {
+  // staging: a thread's 16-byte items (halo rows of x, rows of dy) are the same for every brick - their LDS offsets, their offsets from the
+  // brick's origin and their position inside the halo are worked out ONCE; per brick an item costs three compares and a select, and the
+  // loads of brick i + 1 are in flight while brick i is multiplied (round 3, first form: index arithmetic with four divisions per item and
+  // load -> store -> multiply in sequence: 15 us per brick and workgroup for 0.75 us of MFMAs)
+  constexpr int NXI = (HROWS * GX + WG_THREADS - 1) / WG_THREADS, NDI = (NVOX * GD + WG_THREADS - 1) / WG_THREADS;
+  int xlds[NXI], xrel[NXI], xpos[NXI], dlds[NDI], drel[NDI], dpos[NDI];
+#pragma unroll
+  for (int j = 0; j < NXI; ++j) {
+    const int idx = tid + j * WG_THREADS, row = min(idx, HROWS * GX - 1) / GX, cg = min(idx, HROWS * GX - 1) % GX;
+    const int hd = row / (HH * HW), rem = row - hd * (HH * HW), hh = rem / HW, hw = rem - hh * HW;
+    xlds[j] = row * RBX + cg * 16;
+    xrel[j] = (int)((((int64_t)hd * g.H + hh) * g.W + hw) * ldx + cg * 8);
+    xpos[j] = hd | (hh << 8) | (hw << 16) | (idx < HROWS * GX ? 0 : 1 << 24);
+  }
+#pragma unroll
+  for (int j = 0; j < NDI; ++j) {
+    const int idx = tid + j * WG_THREADS, row = min(idx, NVOX * GD - 1) / GD, cg = min(idx, NVOX * GD - 1) % GD;
+    const int vd = row / (BH * BW), rem = row - vd * (BH * BW), vh = rem / BW, vw = rem - vh * BW;
+    dlds[j] = row * RBD + cg * 16;
+    drel[j] = (int)((((int64_t)vd * g.H + vh) * g.W + vw) * lddy + cg * 8);
+    dpos[j] = vd | (vh << 8) | (vw << 16) | (idx < NVOX * GD ? 0 : 1 << 24);
+  }
+  const int xsafe = (int)((((int64_t)1 * g.H + 1) * g.W + 1) * ldx);      // the brick's first voxel: always inside the volume
+  bf16x8 rx[NXI], rd[NDI];
+  unsigned okx = 0, okd = 0;
+  auto gload = [&](int brick) {
     int bid = brick;
     const int bw = bid % g.nbw; bid /= g.nbw;
     const int bh = bid % g.nbh; bid /= g.nbh;
     const int bd = bid % g.nbd;
     const int b = bid / g.nbd;
     const int d0 = bd * WBD, h0 = bh * BH, w0 = bw * BW;
+    const bf16* xo = x + ((((int64_t)b * g.D + d0 - 1) * g.H + h0 - 1) * g.W + w0 - 1) * ldx;      // halo origin (dereferenced in-bounds only)
+    const bf16* yo = dy + ((((int64_t)b * g.D + d0) * g.H + h0) * g.W + w0) * lddy;
+    okx = okd = 0;
+#pragma unroll
+    for (int j = 0; j < NXI; ++j) {
+      const int d = d0 - 1 + (xpos[j] & 255), h = h0 - 1 + ((xpos[j] >> 8) & 255), w = w0 - 1 + ((xpos[j] >> 16) & 255);
+      const bool ok = !(xpos[j] >> 24) && d >= 0 && d < g.D && h >= 0 && h < g.H && w >= 0 && w < g.W;
+      rx[j] = *reinterpret_cast<const bf16x8*>(xo + (ok ? xrel[j] : xsafe));
+      okx |= (ok ? 1u : 0u) << j;
+    }
+#pragma unroll
+    for (int j = 0; j < NDI; ++j) {
+      const int d = d0 + (dpos[j] & 255), h = h0 + ((dpos[j] >> 8) & 255), w = w0 + ((dpos[j] >> 16) & 255);
+      const bool ok = !(dpos[j] >> 24) && d < g.D && h < g.H && w < g.W;
+      rd[j] = *reinterpret_cast<const bf16x8*>(yo + (ok ? drel[j] : 0));
+      okd |= (ok ? 1u : 0u) << j;
+    }
+  };
+  if ((int)blockIdx.x < nbricks) gload(blockIdx.x);
+  for (int brick = blockIdx.x; brick < nbricks; brick += gridDim.x) {
+    const int d0 = ((brick / (g.nbw * g.nbh)) % g.nbd) * WBD, h0 = ((brick / g.nbw) % g.nbh) * BH;
     __syncthreads();      // every wave is done with the previous brick's images
-    for (int idx = tid; idx < HROWS * GX; idx += WG_THREADS) {
-      const int row = idx / GX, cg = idx - row * GX;
-      const int hd = row / (HH * HW), rem = row - hd * (HH * HW);
-      const int hh = rem / HW, hw = rem - hh * HW;
-      const int d = d0 - 1 + hd, h = h0 - 1 + hh, w = w0 - 1 + hw;
-      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (d >= 0 && d < g.D && h >= 0 && h < g.H && w >= 0 && w < g.W) v = *reinterpret_cast<const bf16x8*>(x + ((((int64_t)b * g.D + d) * g.H + h) * g.W + w) * ldx + cg * 8);
-      *reinterpret_cast<bf16x8*>(lx + row * RBX + cg * 16) = v;
-    }
-    for (int idx = tid; idx < NVOX * GD; idx += WG_THREADS) {
-      const int row = idx / GD, cg = idx - row * GD;
-      const int vd = row / (BH * BW), rem = row - vd * (BH * BW);
-      const int vh = rem / BW, vw = rem - vh * BW;
-      const int d = d0 + vd, h = h0 + vh, w = w0 + vw;
-      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (d < g.D && h < g.H && w < g.W) v = *reinterpret_cast<const bf16x8*>(dy + ((((int64_t)b * g.D + d) * g.H + h) * g.W + w) * lddy + cg * 8);
-      *reinterpret_cast<bf16x8*>(ld + row * RBD + cg * 16) = v;
-    }
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < NXI; ++j)
+      if (!(xpos[j] >> 24)) *reinterpret_cast<bf16x8*>(lx + xlds[j]) = (okx >> j) & 1 ? rx[j] : zero8;
+#pragma unroll
+    for (int j = 0; j < NDI; ++j)
+      if (!(dpos[j] >> 24)) *reinterpret_cast<bf16x8*>(ld + dlds[j]) = (okd >> j) & 1 ? rd[j] : zero8;
     __syncthreads();
+    if (brick + (int)gridDim.x < nbricks) gload(brick + gridDim.x);      // in flight during the multiplication below
 #pragma unroll 1
     for (int ks = 0; ks < NVOX / 32; ++ks) {
       if (d0 + (ks >> 1) >= g.D || h0 + (ks & 1) * 4 >= g.H) continue;      // k-step entirely outside the volume: all zeros
@@ -1230,22 +1266,31 @@ __global__ void __launch_bounds__(WG_THREADS, 2) conv3_wgrad_narrow_kernel(const
 
 // dw[co][ci][tap] (torch layout) (+)= sum over the workgroups' slabs [tap][co][ci], in slab order
 __global__ void __launch_bounds__(256) conv3_wgrad_narrow_reduce_kernel(const float* __restrict__ slabs, int nslabs, float* __restrict__ dw, int Cin, int Cout, int accumulate) {
+  // 64 elements per workgroup, the slabs dealt to its four waves (wave w sums slabs w, w + 4, ...: 8 loads in flight per lane), the four
+  // partial sums meet in LDS.  (One thread per element over all 512 slabs was a 26 us chain of dependent loads on 27 - 108 workgroups.)
+  __shared__ float part[4][64];
   const int n = 27 * Cout * Cin;
-  const int e = blockIdx.x * 256 + threadIdx.x;      // e = (tap, co, ci), ci fastest: coalesced slab reads
-  if (e >= n) return;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int k = 0;
-  for (; k + 3 < nslabs; k += 4) {
-    a0 += slabs[(int64_t)k * n + e];
-    a1 += slabs[(int64_t)(k + 1) * n + e];
-    a2 += slabs[(int64_t)(k + 2) * n + e];
-    a3 += slabs[(int64_t)(k + 3) * n + e];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;      // e = (tap, co, ci), ci fastest: coalesced slab reads
+  float a[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) a[u] = 0.f;
+  if (e < n) {
+    int k = w;
+    for (; k + 28 < nslabs; k += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += slabs[(int64_t)(k + 4 * u) * n + e];
+    }
+    for (; k < nslabs; k += 4) a[0] += slabs[(int64_t)k * n + e];
   }
-  for (; k < nslabs; ++k) a0 += slabs[(int64_t)k * n + e];
-  const float v = (a0 + a1) + (a2 + a3);
-  const int ci = e % Cin, co = (e / Cin) % Cout, tap = e / (Cin * Cout);
-  float* dst = dw + ((int64_t)co * Cin + ci) * 27 + tap;
-  *dst = accumulate == 1 ? *dst + v : v;
+  part[w][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (w == 0 && e < n) {
+    const float v = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    const int ci = e % Cin, co = (e / Cin) % Cout, tap = e / (Cin * Cout);
+    float* dst = dw + ((int64_t)co * Cin + ci) * 27 + tap;
+    *dst = accumulate == 1 ? *dst + v : v;
+  }
 }
 
 static constexpr int WG_NARROW_MAX_WG = 512;      // two workgroups per CU
@@ -1255,7 +1300,8 @@ static bool wgrad_narrow(const miseg_conv3_wgrad_params* p) {
 }
 static int wgrad_narrow_workgroups(const miseg_conv3_wgrad_params* p) {
   const int nbricks = p->B * cdiv(p->D, 4) * cdiv(p->H, BH) * cdiv(p->W, BW);
-  int wg = nbricks < WG_NARROW_MAX_WG ? nbricks : WG_NARROW_MAX_WG;
+  static const int cap = [] { const char* e = getenv("MISEG_NARROW_WG"); const int v = e ? atoi(e) : WG_NARROW_MAX_WG; return v > 0 && v < WG_NARROW_MAX_WG ? v : WG_NARROW_MAX_WG; }();
+  int wg = nbricks < cap ? nbricks : cap;
   if (p->max_workgroups > 0 && p->max_workgroups < wg) wg = p->max_workgroups;      // background form
   return wg;
 }
@@ -1274,7 +1320,7 @@ static int conv3_wgrad_narrow_launch(const miseg_conv3_wgrad_params* p, hipStrea
   else NARROW_LAUNCH(2, 2);
 #undef NARROW_LAUNCH
   const int n = 27 * p->Cout * p->Cin;
-  conv3_wgrad_narrow_reduce_kernel<<<cdiv(n, 256), 256, 0, s>>>((const float*)p->workspace, wg, p->dw, p->Cin, p->Cout, p->accumulate);
+  conv3_wgrad_narrow_reduce_kernel<<<cdiv(n, 64), 256, 0, s>>>((const float*)p->workspace, wg, p->dw, p->Cin, p->Cout, p->accumulate);
   MISEG_LAUNCH_CHECK("conv3_wgrad (narrow)");
   return MISEG_OK;
 }
