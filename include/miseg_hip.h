@@ -235,7 +235,10 @@ typedef struct { const float* partial; float* C; int64_t ldc; int32_t M, N, spli
 /* C[m][n] += sum over splits of partial[s][m][n] for up to MISEG_TN_REDUCE_BATCH deferred reductions in one launch (HOST descriptors) */
 int miseg_gemm_tn_reduce_batch(const miseg_tn_reduce_desc* descs_host, int n, miseg_stream_t stream);
 #define MISEG_GEMM_GROUP 24
-typedef struct { const void* A; int64_t lda; const void* B; int64_t ldb; float* C; int64_t ldc; int32_t M, N, K, pad_; } miseg_gemm_tn_desc;
+/* zeroed (ABI 5): 1 = C is known to hold zeros (a gradient slot no kernel has written since the step's fill) and no other problem of the
+ * launch writes it: a problem whose reduction is not split then STORES its tiles instead of reading C back (the 85 M fp32 weight gradients
+ * of C-UNETR's ViT: 340 MB less traffic per step). */
+typedef struct { const void* A; int64_t lda; const void* B; int64_t ldb; float* C; int64_t ldc; int32_t M, N, K, zeroed; } miseg_gemm_tn_desc;
 int miseg_gemm_tn_group(const miseg_gemm_tn_desc* descs_host, int n, int dtype, miseg_stream_t stream);
 
 /* fp32 re-layout: dst[i0][i1][i2] (+)= src[i0*s0 + i1*s1 + i2*s2]  (weight-gradient unpacking) */

@@ -1166,7 +1166,7 @@ extern "C" int miseg_gemm_tn_group(const miseg_gemm_tn_desc* descs, int n, int d
     if (split < 1) split = 1;
     q.kps = cdiv(cdiv(d.K, split), bk) * bk;
     split = cdiv(d.K, q.kps);
-    q.mode = split > 1 ? 2 : 1;                      // always accumulate into C: atomics when the reduction is split
+    q.mode = split > 1 ? 2 : (d.zeroed ? 0 : 1);     // accumulate into C (atomics when the reduction is split) unless C is known to be zero
     q.va = ((uintptr_t)d.A % 16 == 0) && (d.lda % n16 == 0);
     q.vb = ((uintptr_t)d.B % 16 == 0) && (d.ldb % n16 == 0);
     q.block0 = blocks;

@@ -434,10 +434,10 @@ class _Linear(Function):
             wt = ops.cast_matrix(weight, dy.dtype, transpose=True)      # [K, N]
             dx = ops.gemm_nt(dy, wt)
         if ctx.needs_input_grad[1]:
-            slot = _slot(ctx.params[0])
+            slot, mode = _slot_first(ctx.params[0])
             if slot is not None:
                 with ops.wgrad_side(dy, x):
-                    ops.gemm_tn(dy, x, out=slot, accumulate=True)
+                    ops.gemm_tn(dy, x, out=slot, accumulate=mode)      # (2: the slot still holds the step's zeros - a store, not a read-modify-write)
             else:
                 dw = ops.gemm_tn(dy, x).view(weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -503,10 +503,10 @@ class _Mlp(Function):
         out = [dx, None, None, None, None, dy if ctx.needs_input_grad[5] else None, None]
         for i, (p, act, g) in enumerate(((pw1, x, dh), (pw2, a, dy))):
             if ctx.needs_input_grad[1 + 2 * i]:
-                slot = _slot(p)
+                slot, mode = _slot_first(p)
                 if slot is not None:
                     with ops.wgrad_side(g, act):
-                        ops.gemm_tn(g, act, out=slot, accumulate=True)
+                        ops.gemm_tn(g, act, out=slot, accumulate=mode)
                 else:
                     out[1 + 2 * i] = ops.gemm_tn(g, act).view(p.shape)
         for i, (p, g) in enumerate(((pb1, dh), (pb2, dy))):
@@ -847,10 +847,10 @@ class _Conv1(Function):
         dx = ops.gemm_nt(dy, ops.cast_matrix(weight, dy.dtype, transpose=True)) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
-            slot = _slot(ctx.params[0])
+            slot, mode = _slot_first(ctx.params[0])
             if slot is not None:
                 with ops.wgrad_side(dy, x):
-                    ops.gemm_tn(dy, x, out=slot, accumulate=True)
+                    ops.gemm_tn(dy, x, out=slot, accumulate=mode)
             else:
                 dw = ops.gemm_tn(dy, x).view(weight.shape)
         return dx, dw, None

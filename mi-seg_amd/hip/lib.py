@@ -59,7 +59,7 @@ Gemm = _struct("Gemm", cname="miseg_gemm_params", fields=[("A", vp), ("lda", i64
                         ("scat_cout", i32)])
 TnReduceDesc = _struct("TnReduceDesc", cname="miseg_tn_reduce_desc", fields=[("partial", vp), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32), ("splits", i32), ("block0", i32)])
 ColsumDesc = _struct("ColsumDesc", cname="miseg_colsum_desc", fields=[("x", vp), ("ldx", i64), ("rows", i64), ("out", vp), ("C", i32), ("block0", i32)])
-GemmTnDesc = _struct("GemmTnDesc", cname="miseg_gemm_tn_desc", fields=[("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32), ("K", i32), ("pad_", i32)])
+GemmTnDesc = _struct("GemmTnDesc", cname="miseg_gemm_tn_desc", fields=[("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32), ("K", i32), ("zeroed", i32)])
 Colsum = _struct("Colsum", cname="miseg_colsum_params", fields=[("x", vp), ("ldx", i64), ("rows", i64), ("C", i32), ("dtype", i32), ("out", vp), ("accumulate", i32)])
 Conv3 = _struct("Conv3", cname="miseg_conv3_params", fields=[("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("wpk", vp), ("B", i32), ("D", i32), ("H", i32),
                           ("W", i32), ("Cin", i32), ("Cout", i32), ("dtype", i32), ("workspace", vp), ("res", vp), ("ldres", i64), ("stat", vp), ("background", i32), ("defer_slabs", i32)])

@@ -518,8 +518,9 @@ def gemm_tn(a, b, out=None, accumulate=False, split_k=0):
     assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == M * N
     q = _queues(out) if accumulate else None
     if q is not None and split_k <= 0 and not (M % 48 == 0 and N % 48 == 0 and K >= 2048 and a.dtype == torch.bfloat16):
-        q.lists().gemm_tn.append((a, b, out))      # small problem: grouped launch at the end of the backward pass
+        q.lists().gemm_tn.append((a, b, out, int(accumulate) == 2))      # small problem: grouped launch at the end of the backward pass
         return out
+    accumulate = bool(accumulate)      # (the direct kernels always add: "known zero" only saves the grouped launch its read of the slot)
     split_k = max(0, split_k)          # 0: the library picks the kernel and the split over the reduction rows
     p = L.Gemm(_ptr(a), lda, _ptr(b), ldb, _ptr(out), N, M, N, K, 1, 1, _dt(a), L.F32, None, L.ACT_NONE, int(accumulate), split_k, None, None, 0, None, 0, 0, 0)
     lib = L.load()
@@ -786,15 +787,18 @@ def _flush_gemm_tn(q):
     if not q:
         return
     lib = L.load()
-    for dt in {a.dtype for a, _, _ in q}:
+    once = {}
+    for it in q:      # a slot written by two problems of the same launch (a shared weight) is never "known zero" for either
+        once[it[2].data_ptr()] = once.get(it[2].data_ptr(), 0) + 1
+    for dt in {it[0].dtype for it in q}:
         items = [it for it in q if it[0].dtype == dt]
         for i in range(0, len(items), 24):
             chunk = items[i:i + 24]
             descs = (L.GemmTnDesc * len(chunk))()
-            for j, (a, b, out) in enumerate(chunk):
+            for j, (a, b, out, zeroed) in enumerate(chunk):
                 lda, K, M = rows(a)
                 ldb, _, N = rows(b)
-                descs[j] = L.GemmTnDesc(_ptr(a), lda, _ptr(b), ldb, _ptr(out), N, M, N, K, 0)
+                descs[j] = L.GemmTnDesc(_ptr(a), lda, _ptr(b), ldb, _ptr(out), N, M, N, K, 1 if (zeroed and once[out.data_ptr()] == 1) else 0)
             L.check(lib.miseg_gemm_tn_group(descs, len(chunk), _dt(chunk[0][0]), _stream()), "gemm_tn_group")
     q.clear()
 

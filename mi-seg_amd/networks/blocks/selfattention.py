@@ -20,10 +20,13 @@ class SABlock(nn.Module):
         self.head_dim = hidden_size // num_heads
         self.scale = self.head_dim ** -0.5
 
-    def forward(self, x, grid):
-        """x [B, L, C] with L = prod(grid) <= 384."""
+    def forward(self, x, grid, res=None):
+        """x [B, L, C] with L = prod(grid) <= 384.  res: the caller's residual (`x + attn(norm(x))`), added in out_proj's epilogue."""
         b, l, c = x.shape
         qkv = HF.linear(x, self.qkv.weight, self.qkv.bias)          # "b h (qkv l d)": q | k | v blocks, head-major inside
         qkv5 = qkv.view(b, grid[0], grid[1], grid[2], 3 * c)
         o = HF.window_attention(qkv5, self.qkv.bias, None, self.num_heads, grid, (0, 0, 0), 1, self.scale, self.dropout_rate, self.training)
-        return HF.dropout(HF.linear(o.view(b, l, c), self.out_proj.weight, self.out_proj.bias), self.dropout_rate, self.training)
+        if self.dropout_rate > 0.0 and self.training:      # drop_output sits between out_proj and the residual add
+            y = HF.dropout(HF.linear(o.view(b, l, c), self.out_proj.weight, self.out_proj.bias), self.dropout_rate, self.training)
+            return HF.add(res, y) if res is not None else y
+        return HF.linear(o.view(b, l, c), self.out_proj.weight, self.out_proj.bias, res=res)

@@ -4,7 +4,7 @@ from typing import Tuple, Union
 import torch.nn as nn
 
 from ...hip import functional as HF
-from ..layers.utils import apply_norm, get_norm_layer
+from ..layers.utils import apply_norm_fork, get_norm_layer
 from ..norms.conditional_instance_norm import _ConditionalInstanceNorm
 from .mlp import MLPBlock
 from .selfattention import SABlock
@@ -29,7 +29,9 @@ class TransformerBlock(nn.Module):
     def forward(self, x, styles=None, grid=None):
         if isinstance(self.norm1, _ConditionalInstanceNorm) and styles is None:
             raise ValueError("Modalities must be passed to the forward step when encoder_norm_type is 'instance_cond'.")
-        xa, xs = HF.fork(x)
-        x = HF.add(xs, self.attn(apply_norm(self.norm1, xa, styles), grid))
-        xa, xs = HF.fork(x)
-        return HF.add(xs, self.mlp(apply_norm(self.norm2, xa, styles)))
+        # as in the Swin block: the residual adds ride in the epilogues of out_proj / linear2, the fan-out sums of the backward pass in the
+        # norm-backward kernels (round 3: 48 stand-alone add launches per C-UNETR step before)
+        xn, xs = apply_norm_fork(self.norm1, x, styles)
+        x = self.attn(xn, grid, res=xs)
+        xn, xs = apply_norm_fork(self.norm2, x, styles)
+        return self.mlp(xn, res=xs)
