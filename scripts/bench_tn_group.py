@@ -12,12 +12,13 @@ fam = {
     "K=1728": [(768, 192, 1728)] * 3 + [(576, 192, 1728)] * 2 + [(192, 384, 1728)] + [(192, 768, 1728)] * 3 + [(192, 192, 1728)] * 2,
 }
 fam["all"] = fam["K=27"] + fam["K=216"] + fam["K=1728"]
+fam["vit-b (C-UNETR, one launch of 24)"] = [(2304, 768, 216), (768, 768, 216), (3072, 768, 216), (768, 3072, 216)] * 6
 for name, probs in fam.items():
     items = [(torch.randn(K, M, device="cuda").to(dt), torch.randn(K, N, device="cuda").to(dt), torch.zeros(M, N, device="cuda")) for M, N, K in probs]
     def run():
         ops.DEFAULT_QUEUES = ops.StepQueues()
         for a, b, o in items:
-            ops.gemm_tn(a, b, out=o, accumulate=True)
+            ops.gemm_tn(a, b, out=o, accumulate=2 if "zeroed" in sys.argv else True)
         ops.DEFAULT_QUEUES.flush()
         ops.DEFAULT_QUEUES = None
     run(); torch.cuda.synchronize()
