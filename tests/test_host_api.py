@@ -69,6 +69,14 @@ def test_constructor_errors():
     assert parse_normalization("instance_cond", True, 4, 2) == ("instance_cond", {"num_styles": 2, "affine": True})
 
 
+def test_use_checkpoint_is_accepted_and_says_that_it_is_not_applied():
+    """--use_checkpoint (reference utils/parser.py:24, swin_transformer_block.py:241-252): accepted for API parity; the user is told that no
+    activation checkpointing happens on this path ("say so")"""
+    from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
+    with pytest.warns(UserWarning, match="checkpoint"):
+        SwinUNETR((32, 32, 32), 1, 2, feature_size=12, use_checkpoint=True)
+
+
 def test_no_cpu_fallback():
     """the product path fails loudly without a HIP device instead of computing on the CPU."""
     from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
