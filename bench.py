@@ -189,13 +189,18 @@ def measure(a, rank, world, dist, dev):
     # all-reduced by RCCL while the encoder / Swin half still runs
     overlap = dist is not None and arena is not None and not a.no_overlap and hasattr(model, "late_backward_parameters")
     tail = arena.tail_offset(model.late_backward_parameters()) if overlap else None
-    # the side branch defers decoder1's two 96^3 weight gradients into the second half of the backward pass: their slots are a hole in the
-    # tail that goes out after the first half, and join the ranges reduced at the end
+    # decoder1's two 96^3 weight gradients leave the main stream's chain (ops.defer_to_branch).  MISEG_SPLIT_DEFER=early (default): they run on
+    # the branch stream inside the FIRST half, beside decoder2 .. 5 / encoder10, and the whole tail is final at the hook.  =late (round 2):
+    # they wait for the branch's backward pass in the second half - their slots are then a hole in the tail that goes out after the first
+    # half, and join the ranges reduced at the end
     hole = None
     if overlap and hasattr(model, "deferred_backward_parameters") and getattr(model, "side_branch", False) and dtype == torch.bfloat16 and not os.environ.get("MISEG_NO_DEFER"):
-        hole = arena.param_range(model.deferred_backward_parameters())
-        assert tail <= hole[0] < hole[1] <= arena.flat.numel()
-        model.split_defers = True
+        if os.environ.get("MISEG_SPLIT_DEFER", "early") == "early":
+            model.split_defers = "early"          # decoder1's deferred weight gradients run on the idle branch stream inside the first half: no hole
+        else:
+            hole = arena.param_range(model.deferred_backward_parameters())
+            assert tail <= hole[0] < hole[1] <= arena.flat.numel()
+            model.split_defers = True
     early_ranges = [(tail, arena.flat.numel())] if (overlap and hole is None) else ([(hole[1], arena.flat.numel()), (tail, hole[0])] if overlap else [])
     late_ranges = [(0, tail)] + ([hole] if hole is not None else []) if overlap else []
     graphed = None

@@ -650,6 +650,20 @@ def flush_branch_deferred(q):
 
 
 
+def flush_deferred_on_branch(params):
+    """(gradient hook) issue what defer_to_branch queued so far on the BRANCH stream, behind everything the main stream has issued (see
+    SwinUNETR.forward: the first half of a split step)"""
+    q = _arena_queues(params)
+    if q is None or not q.branch_deferred or _BRANCH_STREAM is None:
+        return
+    cur = torch.cuda.current_stream()
+    if cur == _BRANCH_STREAM:
+        return
+    _BRANCH_STREAM.wait_stream(cur)
+    with torch.cuda.stream(_BRANCH_STREAM):
+        flush_branch_deferred(q)
+
+
 def early_group_flush(q):
     """at the TAIL of the side branch's backward pass (its last node calls this): the small layers' weight gradients queued so far go out on
     the branch stream as one grouped launch in background form, beside what the main stream has left of its small-grid chain - instead of

@@ -270,5 +270,10 @@ class SwinUNETR(nn.Module):
         if branch and (cut is None or self.split_defers) and os.environ.get("MISEG_NO_DEFER") is None:
             ops.open_branch_deferral(self.parameters())       # decoder1's two 96^3 weight gradients wait for the branch's backward pass (hip/ops.py::defer_to_branch)
         dec0 = mark(self.decoder2(dec1, enc1, styles), "dec0")
+        if branch and cut is not None and self.split_defers == "early" and dec0.requires_grad:
+            # split step, first half: the branch stream has no backward work of its own here (the branch's backward pass is in the second
+            # half), so decoder1's two deferred weight gradients run on it in background form as soon as decoder1's backward pass has queued
+            # them - beside decoder2 .. 5 / encoder10 - and are final when the first half ends: no hole in the early all-reduce range
+            dec0.register_hook(lambda g, ps=self.out.parameters: ops.flush_deferred_on_branch(ps()))
         out = mark(self.decoder1(dec0, enc0, styles), "out")
         return self.out(out)

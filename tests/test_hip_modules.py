@@ -687,11 +687,14 @@ def test_graphed_step_replays_match_eager(use_arena):
 
 
 @pytest.mark.gpu
-def test_split_step_as_bench_times_it_at_n_gt_1():
-    """The step `bench.py --gpus N` (N > 1) times on the headline net (fs=48, 96^3, bf16): two hipGraphs, the side branch in the second one,
-    decoder1's two deferred weight gradients a HOLE in the decoder-side tail (`split_defers`).  At the hook between the graphs - where
-    bench.py starts RCCL on the early ranges - those ranges must be final and the hole must not be; after the second graph the whole arena
-    must equal the single-graph step's (reference: tune.py:103-109, one DDP exchange per step over the same gradients)."""
+@pytest.mark.parametrize("defer", ["early", "late"])
+def test_split_step_as_bench_times_it_at_n_gt_1(defer):
+    """The step `bench.py --gpus N` (N > 1) times on the headline net (fs=48, 96^3, bf16): two hipGraphs, the side branch in the second one.
+    defer = "late": decoder1's two deferred weight gradients are a HOLE in the decoder-side tail (`split_defers = True`, MISEG_SPLIT_DEFER=late):
+    at the hook between the graphs - where bench.py starts RCCL on the early ranges - those ranges must be final and the hole must not be.
+    defer = "early" (bench.py's default since round 3): the two launches run on the idle branch stream INSIDE the first half - the whole tail
+    is final at the hook, one range.  After the second graph the whole arena must equal the single-graph step's (reference: tune.py:103-109,
+    one DDP exchange per step over the same gradients)."""
     from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
     from mi_seg_amd.runtime.arena import ParamArena
     from mi_seg_amd.runtime.graph import GraphedStep
@@ -717,8 +720,8 @@ def test_split_step_as_bench_times_it_at_n_gt_1():
         tail = arena.tail_offset(net.late_backward_parameters())
         hole = arena.param_range(net.deferred_backward_parameters())
         assert 0 < tail <= hole[0] < hole[1] <= n
-        early = [(hole[1], n), (tail, hole[0])]
-        net.split_defers = True
+        early = [(hole[1], n), (tail, hole[0])] if defer == "late" else [(tail, n)]
+        net.split_defers = True if defer == "late" else "early"
         split = GraphedStep(net, x.shape, cot.shape, arena=arena, split=True)
         seen = []
         hook = lambda: seen.append(([arena.flat[lo:hi].clone() for lo, hi in early], arena.flat[hole[0]:hole[1]].clone(), arena.flat[:tail].clone()))
@@ -730,7 +733,10 @@ def test_split_step_as_bench_times_it_at_n_gt_1():
                 assert torch.equal(t, arena.flat[lo:hi]), f"replay {it}: arena[{lo}:{hi}] changed after the hook - it is not final there"
                 assert float(t.abs().max()) > 0
             # the deferred weight gradients and the encoder / Swin side are produced by the second graph
-            assert float(hole_at_hook.abs().max()) == 0.0 and float(arena.flat[hole[0]:hole[1]].abs().max()) > 0, "the hole must be written by the second graph"
+            if defer == "late":
+                assert float(hole_at_hook.abs().max()) == 0.0 and float(arena.flat[hole[0]:hole[1]].abs().max()) > 0, "the hole must be written by the second graph"
+            else:
+                assert torch.equal(hole_at_hook, arena.flat[hole[0]:hole[1]]) and float(hole_at_hook.abs().max()) > 0, "decoder1's gradients must be final at the hook"
             assert float(head_at_hook.abs().max()) == 0.0 and float(arena.flat[:tail].abs().max()) > 0
             y_ref, g_ref, none_ref = ref[m]
             assert torch.equal(y.detach(), y_ref), f"replay {it}: logits differ from the single-graph step"
