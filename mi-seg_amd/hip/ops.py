@@ -580,6 +580,7 @@ BACKGROUND_WORKGROUPS = int(os.environ.get("MISEG_BG_WG", "32"))     # cap of th
                                # two boxes, before the deferral below: 256 (no cap) -0.4 %, 128 +1.0, 64 +1.4, 32 +2.0 / +2.4, 16 +2.0, 8 -3.8
 DEFERRED_WORKGROUPS = int(os.environ.get("MISEG_DEFER_WG", "64"))       # cap of the main stream's deferred weight gradients (defer_to_branch).  (own cap, this cap) on one box, no branch =
                                # 132.6, branch alone 134.5: (24, 48) 136.9, (24, 64) 140.8, (24, 96) 139.8, (48, 64) 140.6, (64, 64) 140.7, (32, 32) 128.9
+DEFERRED_WORKGROUPS_SPLIT = int(os.environ.get("MISEG_DEFER_SPLIT_WG", "96"))      # the same launches inside the first half of a split step (flush_deferred_on_branch)
 GROUP_EARLY_WORKGROUPS = int(os.environ.get("MISEG_EARLY_GROUP_WG", "0"))      # cap of the early (branch-stream) grouped weight-gradient launch; 0 = off
 FLUSH_SMALL_ON_BRANCH = os.environ.get("MISEG_SMALL_FLUSH_ON_MAIN", "0") != "1"
 FLUSH_SIDE_ON_BRANCH = os.environ.get("MISEG_SIDE_FLUSH_AFTER_JOIN", "0") != "1"
@@ -632,7 +633,7 @@ def defer_to_branch(x, dy, slot, mode):
     return True
 
 
-def flush_branch_deferred(q):
+def flush_branch_deferred(q, cap=None):
     """launch what `defer_to_branch` queued on the current stream (the branch's, in background form; join_branch's as a fallback)"""
     global BACKGROUND_WORKGROUPS
     if q is None or not q.branch_deferred:
@@ -640,7 +641,7 @@ def flush_branch_deferred(q):
             q.branch_deferred = None
         return
     items, q.branch_deferred = q.branch_deferred, None
-    keep, BACKGROUND_WORKGROUPS = BACKGROUND_WORKGROUPS, DEFERRED_WORKGROUPS
+    keep, BACKGROUND_WORKGROUPS = BACKGROUND_WORKGROUPS, (cap or DEFERRED_WORKGROUPS)
     try:
         for x, dy, slot, mode in items:
             conv3_wgrad(x, dy, dw=slot, accumulate=mode)
@@ -661,14 +662,17 @@ def flush_deferred_on_branch(params):
         return
     _BRANCH_STREAM.wait_stream(cur)
     with torch.cuda.stream(_BRANCH_STREAM):
-        flush_branch_deferred(q)
+        # (alone on the branch stream, with ~0.8 ms of the main stream's decoder chain to hide behind: 96 workgroups finish in time where
+        # the one-graph step's 64 left the first half waiting - single-rank RCCL step 135.4 / 138.5 / 138.1 / 137.1 patches/s at 64 / 96 / 128 / 192)
+        flush_branch_deferred(q, cap=DEFERRED_WORKGROUPS_SPLIT)
 
 
 def early_group_flush(q):
     """at the TAIL of the side branch's backward pass (its last node calls this): the small layers' weight gradients queued so far go out on
     the branch stream as one grouped launch in background form, beside what the main stream has left of its small-grid chain - instead of
     after it, at the very end of the step.  (At the HEAD of the branch the same launch made the branch the critical path: 145.4 -> 134.7
-    patches/s with 64 workgroups, 141.1 with 128.)  GROUP_EARLY_WORKGROUPS = 0 switches it off.
+    patches/s with 64 workgroups, 141.1 with 128.)  DEFERRED_WORKGROUPS_SPLIT = int(os.environ.get("MISEG_DEFER_SPLIT_WG", "96"))      # the same launches inside the first half of a split step (flush_deferred_on_branch)
+GROUP_EARLY_WORKGROUPS = 0 switches it off.
     Round 3, with the wait on the main stream this launch needs for its operands: 146.5 -> 114.0 patches/s uncapped, 111.1 with 128 - the
     device-clock stamps show the WHOLE branch starting 2.3 ms later (its head at 5.9 ms instead of 3.6): a second edge main -> branch inside
     the captured step makes the hipGraph executor run the branch's segment behind the main stream's.  The same happened to a third stream

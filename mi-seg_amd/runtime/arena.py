@@ -261,7 +261,10 @@ class ParamArena:
 
     def flush(self):
         """issue everything queued so far and keep queueing (between the two halves of a split backward pass)."""
-        ops.join_branch(flush_deferred=False, queues=self.queues)      # (weight gradients deferred to the branch's backward pass wait for the second half)
+        # (weight gradients deferred to the branch's backward pass wait for the second half unless the model already issued them:
+        # SwinUNETR.split_defers = "early").  As in end_backward: the grouped GEMM gradients / column sums go out on the branch stream beside
+        # the main stream's grouped conv weight gradients
+        ops.join_branch(flush_deferred=False, queues=self.queues, flush_main=ops.FLUSH_MAIN_BEFORE_JOIN)
         if self.queues is not None:
             self.queues.flush()
 
