@@ -52,6 +52,9 @@ class _Fork(Function):
 
     @staticmethod
     def forward(ctx, x):
+        # an output nobody differentiates (the ViT's unused hidden states) must arrive as None, not as a zero tensor autograd fills in for us:
+        # that was a fill + an add launch per unused fork (9 of each per C-UNETR step)
+        ctx.set_materialize_grads(False)
         return x.view_as(x), x.view_as(x)
 
     @staticmethod
