@@ -112,6 +112,12 @@ def main():
                     help="N > 1: read the exchanged 'used on any rank' bitmap back to the host every step (what a torch optimiser needs); default: it stays "
                          "on the device for the fused optimiser and the step has no host synchronisation")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group (and take the N > 1 code path) even with one rank")
+    ap.add_argument("--train-step", action="store_true",
+                    help="c2 / c3, N = 1: time a whole OPTIMISATION step instead - versioned weight refresh + forward + fused DiceFocal loss + backward + "
+                         "one-launch AdamW in ONE replayed hipGraph (reference lightning_monai.py:149-166, 255-278); reported under `secondary`")
+    ap.add_argument("--refresh-weights", action="store_true",
+                    help="bump the arena's device-side parameter version before every step, so that every replay re-casts and re-packs all weights as a "
+                         "training loop's step does (the headline's timed steps have no optimiser step: their refresh launches find the copies current)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short configs[2] / configs[4] / fp32 runs reported under `secondary` (N = 1 only)")
     a = ap.parse_args()
 
@@ -147,14 +153,15 @@ def main():
             # headline measurement and outside its timed region; the headline line and its timed region are unchanged
             import copy
             out["secondary"] = {}
-            for name, over in (("c2_fp32_parity_mode", dict(dtype="f32", steps=5, warmup=2)), ("c3_c_unetr_bf16", dict(workload="c3", steps=10, warmup=3)),
+            for name, over in (("c2_train_step_bf16", dict(train_step=True, steps=10, warmup=3)), ("c2_with_weight_refresh", dict(refresh_weights=True, steps=10, warmup=3)),
+                               ("c2_fp32_parity_mode", dict(dtype="f32", steps=5, warmup=2)), ("c3_c_unetr_bf16", dict(workload="c3", steps=10, warmup=3)),
                                ("c5_sliding_window_bf16", dict(workload="c5", steps=2, warmup=2))):
                 b = copy.copy(a)
                 b.no_roofline, b.no_cpu_baseline = True, True
                 for k, v in over.items():
                     setattr(b, k, v)
                 r = measure(b, rank, world, dist, dev)
-                out["secondary"][name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype") if k in r}
+                out["secondary"][name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "train_step", "weight_refresh") if k in r}
                 out["secondary"][name]["workload"] = r["config"]["workload"]
                 torch.cuda.empty_cache()
         print(json.dumps(out), flush=True)
@@ -181,10 +188,13 @@ def measure(a, rank, world, dist, dev):
     cot = torch.randn(1, 6, 96, 96, 96, generator=torch.Generator().manual_seed(4321)).to(dev)
     params = [p for p in model.parameters() if p.requires_grad]
 
+    if getattr(a, "train_step", False):
+        return bench_train_step(a, model, dtype, dev, pool, mods, order, params)
     arena = None
     if not a.no_arena:
         from mi_seg_amd.runtime.arena import ParamArena
-        arena = ParamArena(params, dtype, grad_dtype=torch.bfloat16 if a.grad_dtype == "bf16" else torch.float32)
+        arena = ParamArena(params, dtype, grad_dtype=torch.bfloat16 if a.grad_dtype == "bf16" else torch.float32,
+                           force_collective=True if a.force_dist else None)
     # N > 1: the backward pass is split behind the decoder side (autograd runs it first), whose gradients - 87 % of the bytes - are
     # all-reduced by RCCL while the encoder / Swin half still runs
     overlap = dist is not None and arena is not None and not a.no_overlap and hasattr(model, "late_backward_parameters")
@@ -210,8 +220,12 @@ def measure(a, rank, world, dist, dev):
         graphed.cot.copy_(cot)
         cot = graphed.cot          # the cotangent is constant here: it lives in the graph's static buffer (a loss kernel would write it there)
 
+    refresh = bool(getattr(a, "refresh_weights", False)) and arena is not None
+
     def step(i, eager=False, sample=None, comm=True):
         k = order[i % len(order)] if sample is None else sample
+        if refresh:
+            arena.invalidate()          # one counter_add launch: the step's refresh kernels then re-lay-out every weight (as after an optimiser step)
         if overlap and sample is None and comm:
             works, ub = [], []
             if graphed is not None and not eager:
@@ -265,6 +279,7 @@ def measure(a, rank, world, dist, dev):
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+    coll0 = arena.collectives_launched if arena is not None else 0
     t0 = time.perf_counter()
     per_step = []
     for i in range(a.steps):
@@ -279,11 +294,14 @@ def measure(a, rank, world, dist, dev):
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    coll = (arena.collectives_launched - coll0) if arena is not None else 0
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    if os.environ.get("MISEG_BENCH_EARLY_PRINT") and rank == 0:      # experiments whose replay check may abort: the timing first
+        print(f"early: {world * a.steps / dt:.2f} {WORKLOADS[a.workload][1]}", file=sys.stderr)
     if ops.STAMPS and rank == 0:          # MISEG_STEP_STAMPS=1: where the streams of the last replayed step were when (device clock, us)
         st = ops.read_stamps()
         t0_ = st.get("step_begin", min(st.values()))
@@ -364,6 +382,8 @@ def measure(a, rank, world, dist, dev):
         "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic", "launch": "eager" if graphed is None else "hipGraph", "allreduce": "overlapped with the encoder half of backward" if overlap else ("after backward" if dist is not None else "none"),
         "config": {"workload": WORKLOADS[a.workload][2], "global_batch": world, "sharding": "one 16-volume CT+MR dataset, rank r takes perm[r::world] per epoch"},
     }
+    if refresh:
+        out["weight_refresh"] = "every step (device-side parameter version bumped before each replay: all casts and conv packs re-made)"
     if graphed is not None:
         check = replay_check()
         if not check["finite"] or check["logits_rel_err"] > 1e-2 or check["grad_rel_err"] > 5e-2:
@@ -378,7 +398,8 @@ def measure(a, rank, world, dist, dev):
         out["exchange_check"] = exchange_check()
         out["collective"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "grad_dtype": a.grad_dtype,
                              "payload_bytes_per_step": int(arena.flat.numel() * (4 if a.grad_dtype == "f32" else 2)),
-                             "used_flags": "device" if (a.device_flags and overlap) else "host read per step"}
+                             "used_flags": "device" if (a.device_flags and overlap) else "host read per step",
+                             "launched_per_step": coll / a.steps, "forced_on_one_rank": bool(arena.force_collective and world == 1)}
     if rank == 0:
         if not a.no_roofline:
             from mi_seg_amd.testing.roofline import profile_step, summarize
@@ -388,6 +409,48 @@ def measure(a, rank, world, dist, dev):
             out["cpu_baseline"] = cpu_baseline(a.workload)
     if arena is not None:
         arena.detach()
+    return out
+
+
+def bench_train_step(a, model, dtype, dev, pool, mods, order, params):
+    """one step = one whole optimisation step of the reference's loop (LitMonai.training_step + optimizer.step, lightning_monai.py:149-166, 255-278)
+    as ONE replayed hipGraph: versioned weight refresh (live: the optimiser changed every weight), forward, fused DiceFocal loss + dlogits,
+    backward, one-launch AdamW over the gradient arena.  N = 1."""
+    from mi_seg_amd.runtime.arena import ParamArena
+    from mi_seg_amd.runtime.graph import GraphedTrainStep
+    from mi_seg_amd.training.losses import DiceFocalLoss
+    from mi_seg_amd.training.optim import ArenaOptimizer
+    arena = ParamArena(params, dtype)
+    opt = ArenaOptimizer(arena, "adamw", lr=1e-4, weight_decay=1e-5)                       # LitMonai's defaults (lightning_monai.py:30)
+    crit = DiceFocalLoss(include_background=False, to_onehot_y=True, softmax=True, squared_pred=True, smooth_nr=0.0, smooth_dr=1e-6)
+    labels = (pool * 6).floor().clamp_(0, 5).to(torch.int32)                               # synthetic 6-class labels from the intensity bands
+    gts = GraphedTrainStep(model, crit, opt, (1, 1, 96, 96, 96), (1, 1, 96, 96, 96), arena)
+    w0 = arena.params[0].detach().clone()
+    losses = []
+    for m_ in sorted(set(mods)):          # capture both graphs outside the timed region
+        k_ = mods.index(m_)
+        gts(pool[k_:k_ + 1], labels[k_:k_ + 1], [m_])
+    for i in range(a.warmup):
+        k = order[i % len(order)]
+        gts(pool[k:k + 1], labels[k:k + 1], [mods[k]])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        k = order[(a.warmup + i) % len(order)]
+        losses.append(gts(pool[k:k + 1], labels[k:k + 1], [mods[k]]).clone())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    losses = [float(l) for l in losses]
+    moved = float((arena.params[0].detach() - w0).abs().max())
+    if not all(l == l and abs(l) < 1e6 for l in losses) or moved == 0.0:
+        raise SystemExit(f"train step: losses {losses}, first parameter moved by {moved}")
+    out = {"metric": WORKLOADS[a.workload][0].replace("fwd+bwd", "full optimisation step (refresh + fwd + DiceFocal + bwd + AdamW)"), "value": a.steps / dt,
+           "unit": WORKLOADS[a.workload][1], "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1000 * dt / a.steps, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic", "launch": "hipGraph",
+           "config": {"workload": WORKLOADS[a.workload][2] + " + fused DiceFocal loss + one-launch AdamW + live weight refresh, one hipGraph per step"},
+           "train_step": {"losses_first_last": [losses[0], losses[-1]], "optimizer": "adamw lr 1e-4 wd 1e-5 (one launch over the arena)",
+                          "loss": "DiceFocal (fused forward + dlogits)"}}
+    arena.detach()
     return out
 
 

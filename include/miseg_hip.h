@@ -31,7 +31,7 @@ enum { MISEG_ACT_NONE = 0, MISEG_ACT_LEAKY = 1, MISEG_ACT_GELU = 2, MISEG_ACT_PR
 #define MISEG_MAX_STYLES 4
 
 /* bumped on EVERY change of a struct layout or prototype; bindings must refuse a library whose version differs from the header they mirror */
-#define MISEG_ABI_VERSION 5
+#define MISEG_ABI_VERSION 6
 int miseg_abi_version(void);
 const char* miseg_last_error(void);
 /* writes e.g. "gfx950" for the code objects embedded in the library */
@@ -627,8 +627,15 @@ int miseg_counter_add(uint64_t* counter_dev, uint64_t value, miseg_stream_t stre
 int miseg_counter_copy(uint64_t* dst_dev, const uint64_t* src_dev, miseg_stream_t stream);
 /* measurement aid: *slot_dev = the device's constant-rate wall clock (100 MHz on gfx950) when the stream reaches this point.  A one-thread
  * kernel, so it can be recorded into a hipGraph: the order in which the streams of a replayed step reach their joins is visible without a
- * tracer (whose per-dispatch cost reorders exactly that; scripts/debug/step_stamps.py). */
+ * tracer (whose per-dispatch cost reorders exactly that).  Host side: MISEG_STEP_STAMPS=1|2, hip/ops.py::stamp; bench.py prints them. */
 int miseg_debug_stamp(uint64_t* slot_dev, miseg_stream_t stream);
+
+/* measurement aid (bench.py's roofline leg): while armed with a tag >= 0, EVERY kernel this library launches records its own begin / end
+ * timestamps (hipExtLaunchKernel start / stop events: the dispatch's own clock, what rocprofv3 --kernel-trace reports) - once, in place, on
+ * its own stream, beside whatever else runs.  miseg_prof_arm(-1) disarms.  miseg_prof_read waits for the recorded launches, writes up to
+ * `max` (tag, milliseconds) pairs in launch order, forgets them and returns how many there were.  Not for use under stream capture. */
+int miseg_prof_arm(int tag);
+int miseg_prof_read(int* tags, float* ms, int max);
 
 /* The resampling step of the cached, deterministic head of the data chain (Spacingd at data/multi_modal.py:41-44: image "bilinear", label
  * "nearest"): in [C][Di][Hi][Wi] -> out [C][Do][Ho][Wo], voxel centres aligned (src = (dst + 0.5) * in / out - 0.5), coordinates clamped to

@@ -54,7 +54,8 @@ def build_all(verbose=False, jobs=4):
         objs = list(ex.map(lambda s: _compile(s, verbose), srcs))
     out = lib_path()
     if _stale(out, objs):
-        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out] + objs
+        # --wrap: every kernel launch of the library goes through common.cpp::__wrap_hipLaunchKernel (in-situ timing, miseg_prof_arm)
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-Wl,--wrap=hipLaunchKernel", "-o", out] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -598,6 +598,9 @@ class _Conv3(Function):
                 if q is not None and q.branch_deferred and ops.in_branch_backward():
                     ops.stamp("branch_bwd_head", fine=True)
                     ops.flush_branch_deferred(q)
+                    ops.group_on_branch(q, "head")
+                if q is not None and ops.GROUP_AT == "mid" and x.shape[1] >= 96:
+                    ops.group_on_branch(q, "mid")
                 with ops.wgrad_side(x, dy, kind="conv"):
                     ops.conv3_wgrad(x, dy, dw=slot, accumulate=mode)
             else:
@@ -742,6 +745,10 @@ def leaky_relu(x, slope=0.01):
     key = (x.device, float(slope))
     t = _CONST_SLOPES.get(key)
     if t is None:
+        if x.is_cuda and torch.cuda.is_current_stream_capturing():
+            # a tensor created under capture lives in the graph's private pool and is only filled when the graph is replayed: cached here, a
+            # later eager call could read it unfilled.  First use inside a capture gets a private copy; the cache is filled by an eager call
+            return _PReLU.apply(x, torch.full((1,), float(slope), dtype=torch.float32, device=x.device))
         t = _CONST_SLOPES[key] = torch.full((1,), float(slope), dtype=torch.float32, device=x.device)
     return _PReLU.apply(x, t)
 

@@ -20,7 +20,7 @@ class _S(C.Structure):
     pass
 
 
-ABI_VERSION = 5          # == MISEG_ABI_VERSION of include/miseg_hip.h; load() refuses a library that reports another
+ABI_VERSION = 6          # == MISEG_ABI_VERSION of include/miseg_hip.h; load() refuses a library that reports another
 C_NAMES = {}             # ctypes mirror -> name of the C struct it mirrors (tests/test_abi.py checks sizeof / offsetof of every field)
 
 
@@ -222,6 +222,8 @@ PROTOS = {
     "miseg_dropout": (i32, [C.POINTER(Dropout), vp]),
     "miseg_counter_add": (i32, [vp, C.c_uint64, vp]),
     "miseg_debug_stamp": (i32, [vp, vp]),
+    "miseg_prof_arm": (i32, [i32]),
+    "miseg_prof_read": (i32, [vp, vp, i32]),
     "miseg_counter_copy": (i32, [vp, vp, vp]),
     "miseg_abi_struct_size": (C.c_size_t, [C.c_char_p]),
     "miseg_device_check": (i32, [i32]),

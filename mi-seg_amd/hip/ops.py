@@ -27,9 +27,9 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-STAMPS = {} if os.environ.get("MISEG_STEP_STAMPS") in ("1", "2") else None
+STAMPS = {} if os.environ.get("MISEG_STEP_STAMPS") in ("1", "2") else None      # measurement aid (bench.py prints them): name -> slot of _STAMP_BUF
 STAMPS_FINE = os.environ.get("MISEG_STEP_STAMPS") == "1"      # "2": only the stamps at the ends of the passes (every stamp is a graph node and
-                                                              # the nodes around a fork change how the executor cuts the graph into chains)      # measurement aid (scripts/debug/step_stamps.py): name -> slot of _STAMP_BUF
+                                                              # the nodes around a fork change how the executor cuts the graph into chains)
 _STAMP_BUF = None
 
 
@@ -76,29 +76,36 @@ def _fp32(t):
     return t
 
 
-PROFILE_HOOK = None   # bench.py roofline leg: list collecting (kernel, start_event, end_event, flops)
+PROFILE_HOOK = None   # bench.py roofline leg: list collecting (kernel name, flops, algorithmic bytes) per hooked call; its index is the tag
+                      # the library's in-situ timing records with every kernel launch of that call (miseg_prof_arm, csrc/common.cpp)
 
 
-PROFILE_REPS = 5      # launches per timed interval in the roofline leg (event packets cost several us each)
+class _ProfRegion:
+    """roofline leg only: every kernel the library launches inside the region records its own begin / end timestamps under one tag - once,
+    where the step issues it, on its own stream, beside whatever else is running (side branch, grouped launches: the schedule that is timed)"""
+
+    def __init__(self, name, flops=0.0, nbytes=0.0):
+        self.on = PROFILE_HOOK is not None
+        if self.on:
+            PROFILE_HOOK.append((name, float(flops), float(nbytes)))
+            self.tag = len(PROFILE_HOOK) - 1
+
+    def __enter__(self):
+        if self.on:
+            L.load().miseg_prof_arm(self.tag)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            L.load().miseg_prof_arm(-1)
+        return False
 
 
 def _call(fn_name, params, prof=None, prof_params=None, extra=()):
     lib = L.load()
     if PROFILE_HOOK is not None and prof is not None:
-        # roofline leg only: the launch is repeated back to back between two events on the launch stream, so the interval is
-        # PROFILE_REPS kernel durations and not one duration plus the event packets.  prof_params: the same launch with its accumulating
-        # outputs (epilogue statistics) redirected to scratch for the repeats; the real launch follows once, so the step stays valid
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        fn = getattr(lib, fn_name)
-        rp = prof_params if prof_params is not None else params
-        L.check(fn(C.byref(rp), *extra, _stream()), fn_name)          # warm (weights / L2 state as in a normal step)
-        e0.record()
-        for _ in range(PROFILE_REPS):
-            L.check(fn(C.byref(rp), *extra, _stream()), fn_name)
-        e1.record()
-        PROFILE_HOOK.append((prof[0], e0, e1, prof[1], prof[2] if len(prof) > 2 else 0.0))
-        if prof_params is not None:
-            L.check(fn(C.byref(params), *extra, _stream()), fn_name)
+        with _ProfRegion(prof[0], prof[1], prof[2] if len(prof) > 2 else 0.0):
+            L.check(getattr(lib, fn_name)(C.byref(params), *extra, _stream()), fn_name)
         return
     L.check(getattr(lib, fn_name)(C.byref(params), *extra, _stream()), fn_name)
 
@@ -109,8 +116,9 @@ def _nb(*tensors):
 
 
 def _prof_scratch(t):
-    """roofline leg only: a throw-away zero buffer shaped like `t` for the accumulating outputs of the repeated launches"""
-    return torch.zeros_like(t) if (t is not None and PROFILE_HOOK is not None) else None
+    """(round 3's roofline leg repeated every launch five times and sent the accumulating outputs of the repeats here; since round 4 a launch
+    is timed once, in place: no scratch)"""
+    return None
 
 
 # ------------------------------------------------------------------------------------------ instance norm
@@ -441,7 +449,7 @@ def gemm_nt(a, w, bias=None, act=L.ACT_NONE, out=None, out_dtype=None, split_k=1
                1 if preact_out is not None else 2 if gelu_grad_of is not None else 0, 0, None)
     global LAST_GEMM_STAT
     LAST_GEMM_STAT = None
-    if want_stat and PROFILE_HOOK is None and not os.environ.get("MISEG_NO_GEMM_STAT") and L.load().miseg_gemm_fuses_stat(C.byref(p)):
+    if want_stat and not os.environ.get("MISEG_NO_GEMM_STAT") and L.load().miseg_gemm_fuses_stat(C.byref(p)):
         # all M rows are one sample (the caller checked): the kernel leaves the norm statistics of the output in `stat`
         stat = STAT_POOL.take(L.load().miseg_instnorm_stat_bytes(1, N) // 8, a.device).view(-1, 1, N, 2)
         p.stat = stat.data_ptr()
@@ -452,7 +460,7 @@ def gemm_nt(a, w, bias=None, act=L.ACT_NONE, out=None, out_dtype=None, split_k=1
 
 def mlp_fused(x, hid):
     """the fused MLP kernels take this problem (bf16, 48 -> 192 -> 48 channels, >= 4096 tokens)"""
-    if PROFILE_HOOK is not None or os.environ.get("MISEG_NO_FUSED_MLP"):
+    if os.environ.get("MISEG_NO_FUSED_MLP"):
         return False
     _, M, Cc = rows(x)
     return x.dtype == torch.bfloat16 and bool(L.load().miseg_mlp_fused(M, Cc, hid, _dt(x)))
@@ -517,6 +525,8 @@ def gemm_tn(a, b, out=None, accumulate=False, split_k=0):
         accumulate = False
     assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == M * N
     q = _queues(out) if accumulate else None
+    if q is not None:
+        q.writes[out.data_ptr()] = q.writes.get(out.data_ptr(), 0) + 1      # step-wide writer count of the slot (direct and queued, main and side)
     if q is not None and split_k <= 0 and not (M % 48 == 0 and N % 48 == 0 and K >= 2048 and a.dtype == torch.bfloat16):
         q.lists().gemm_tn.append((a, b, out, int(accumulate) == 2))      # small problem: grouped launch at the end of the backward pass
         return out
@@ -671,8 +681,7 @@ def early_group_flush(q):
     """at the TAIL of the side branch's backward pass (its last node calls this): the small layers' weight gradients queued so far go out on
     the branch stream as one grouped launch in background form, beside what the main stream has left of its small-grid chain - instead of
     after it, at the very end of the step.  (At the HEAD of the branch the same launch made the branch the critical path: 145.4 -> 134.7
-    patches/s with 64 workgroups, 141.1 with 128.)  DEFERRED_WORKGROUPS_SPLIT = int(os.environ.get("MISEG_DEFER_SPLIT_WG", "96"))      # the same launches inside the first half of a split step (flush_deferred_on_branch)
-GROUP_EARLY_WORKGROUPS = 0 switches it off.
+    patches/s with 64 workgroups, 141.1 with 128.)  GROUP_EARLY_WORKGROUPS = 0 switches it off.
     Round 3, with the wait on the main stream this launch needs for its operands: 146.5 -> 114.0 patches/s uncapped, 111.1 with 128 - the
     device-clock stamps show the WHOLE branch starting 2.3 ms later (its head at 5.9 ms instead of 3.6): a second edge main -> branch inside
     the captured step makes the hipGraph executor run the branch's segment behind the main stream's.  The same happened to a third stream
@@ -685,6 +694,19 @@ GROUP_EARLY_WORKGROUPS = 0 switches it off.
     torch.cuda.current_stream().wait_stream(_MAIN_STREAM)
     stamp("early_group_begin")
     _flush_conv_wgrads(q.conv_wgrad, background=max(GROUP_EARLY_WORKGROUPS, 0), keep=True)
+    stamp("early_group_end")
+
+
+GROUP_AT = os.environ.get("MISEG_GROUP_AT", "")               # EXPERIMENT (round 4): "head" / "mid" - where in the branch's backward pass the main stream's
+GROUP_AT_WG = int(os.environ.get("MISEG_GROUP_WG", "128"))     # queued conv weight gradients go out on the branch stream, and on how many CUs
+
+
+def group_on_branch(q, where):
+    if q is None or GROUP_AT != where or not q.conv_wgrad or not in_branch_backward() or getattr(q, "_grouped_early", False):
+        return
+    q._grouped_early = True
+    stamp("early_group_begin")
+    _flush_conv_wgrads(q.conv_wgrad, background=GROUP_AT_WG, keep=True)
     stamp("early_group_end")
 
 
@@ -712,7 +734,7 @@ def join_branch(flush_deferred=True, queues=None, flush_main=False):
                     _WGRAD_KEEP.extend(t for it in lst for t in it if isinstance(t, torch.Tensor))
                 _BRANCH_STREAM.wait_stream(cur)
                 with torch.cuda.stream(_BRANCH_STREAM):
-                    _flush_gemm_tn(queues.gemm_tn)
+                    _flush_gemm_tn(queues.gemm_tn, queues.writes)
                     _flush_tn_reduces(queues.tn_reduce)
                     _flush_colsums(queues.colsum)
         queues.flush(side=False)
@@ -753,13 +775,17 @@ class StepQueues:
     streaming ones, the conv weight gradients of the 48^3-and-smaller layers.  One instance per training arena, found through the
     storage of the gradient slot a kernel accumulates into - two models (two arenas) in one process do not share anything."""
 
-    def __init__(self, side=True):
+    def __init__(self, side=True, writes=None):
         self.colsum, self.gemm_tn, self.tn_reduce, self.conv_wgrad = [], [], [], []
+        # gradient slot (data_ptr) -> how many weight-gradient GEMMs of this step write it, direct launches and both queues together: a
+        # grouped launch may STORE into a slot ("known zero", miseg_gemm_tn_desc.zeroed) only when it is the slot's one writer of the step -
+        # a tied weight's second use, wherever it was issued, would otherwise be overwritten or overwrite
+        self.writes = {} if writes is None else writes
         self.branch_deferred = None      # while the model's side branch is open: [(x, dy, slot, mode)], see defer_to_branch
         # what the side branch's backward pass queues (it reads tensors the BRANCH stream produced) is kept apart: the main stream issues
         # its own grouped launches as soon as its chain ends - beside the branch's last full-size kernels, which run in background form on
         # a fraction of the CUs - and only the branch's few wait for the join (arena.end_backward)
-        self.side = StepQueues(side=False) if side else None
+        self.side = StepQueues(side=False, writes=self.writes) if side else None
 
     def lists(self):
         """the queue a launch issued NOW belongs to"""
@@ -767,7 +793,7 @@ class StepQueues:
 
     def flush(self, side=True):
         _flush_conv_wgrads(self.conv_wgrad)
-        _flush_gemm_tn(self.gemm_tn)
+        _flush_gemm_tn(self.gemm_tn, self.writes)
         _flush_tn_reduces(self.tn_reduce)
         _flush_colsums(self.colsum)
         if side and self.side is not None:
@@ -801,13 +827,15 @@ def _flush_tn_reduces(q):
     q.clear()
 
 
-def _flush_gemm_tn(q):
+def _flush_gemm_tn(q, writes=None):
     if not q:
         return
     lib = L.load()
-    once = {}
-    for it in q:      # a slot written by two problems of the same launch (a shared weight) is never "known zero" for either
-        once[it[2].data_ptr()] = once.get(it[2].data_ptr(), 0) + 1
+    once = writes
+    if once is None:      # (no step-wide count: at least the problems of this launch)
+        once = {}
+        for it in q:      # a slot written by two problems of the same launch (a shared weight) is never "known zero" for either
+            once[it[2].data_ptr()] = once.get(it[2].data_ptr(), 0) + 1
     for dt in {it[0].dtype for it in q}:
         items = [it for it in q if it[0].dtype == dt]
         for i in range(0, len(items), 24):
@@ -816,7 +844,7 @@ def _flush_gemm_tn(q):
             for j, (a, b, out, zeroed) in enumerate(chunk):
                 lda, K, M = rows(a)
                 ldb, _, N = rows(b)
-                descs[j] = L.GemmTnDesc(_ptr(a), lda, _ptr(b), ldb, _ptr(out), N, M, N, K, 1 if (zeroed and once[out.data_ptr()] == 1) else 0)
+                descs[j] = L.GemmTnDesc(_ptr(a), lda, _ptr(b), ldb, _ptr(out), N, M, N, K, 1 if (zeroed and once.get(out.data_ptr(), 2) == 1) else 0)
             L.check(lib.miseg_gemm_tn_group(descs, len(chunk), _dt(chunk[0][0]), _stream()), "gemm_tn_group")
     q.clear()
 
@@ -948,8 +976,7 @@ def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False, defer=False):
         stat = STAT_POOL.take(lib.miseg_instnorm_stat_bytes(B, Cout) // 8, x.device).view(-1, B, Cout, 2)
     mk = lambda st: L.Conv3(_ptr(x), ld, _ptr(out), rows(out)[0], _ptr(wpk), B, D, H, W, Cin, Cout, _dt(x), _ptr(ws),
                             _ptr(res) if fuse_res else None, rows(res)[0] if fuse_res else 0, _ptr(st), bg, 1 if defer else 0)
-    scratch = torch.zeros_like(stat) if (stat is not None and PROFILE_HOOK is not None) else None
-    _call("miseg_conv3_fwd", mk(stat), prof=(name, flops, nbytes), prof_params=mk(scratch) if scratch is not None else None)
+    _call("miseg_conv3_fwd", mk(stat), prof=(name, flops, nbytes))
     if res is not None and not fuse_res:
         out = add(out, res)
     if defer:
@@ -990,7 +1017,9 @@ def _flush_conv_wgrads(q, background=0, keep=False):
                 descs[j] = L.Conv3Wgrad(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), B, D, H, W, Cin, Cout, _dt(x), acc, None, int(background) if j == 0 else 0)
             wsb = lib.miseg_conv3_wgrad_group_workspace_bytes(descs, len(chunk))
             ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32, device=chunk[0][0].device)
-            L.check(lib.miseg_conv3_wgrad_group(descs, len(chunk), _ptr(ws), _stream()), "conv3_wgrad_group")
+            fl = sum(2.0 * 27 * it[0].shape[-1] * it[1].shape[-1] * (it[0].numel() // it[0].shape[-1]) for it in chunk)
+            with _ProfRegion("conv3_wgrad_group_kernel" + (" (background)" if background else ""), fl):
+                L.check(lib.miseg_conv3_wgrad_group(descs, len(chunk), _ptr(ws), _stream()), "conv3_wgrad_group")
             if background or keep:
                 _WGRAD_KEEP.append(ws)
                 _WGRAD_KEEP.extend(t for it in chunk for t in it[:2])
@@ -1010,7 +1039,7 @@ def conv3_wgrad(x, dy, dw=None, accumulate=False):
     q = _queues(dw) if accumulate else None
     # (narrow bf16 layers - 16 / 32 channels on both sides - have a kernel of their own that finishes a 48^3 layer in ~10 us: never queued)
     narrow = x.dtype == torch.bfloat16 and Cin in (16, 32) and Cout in (16, 32)
-    if q is not None and PROFILE_HOOK is None and B * D * H * W <= CONV_WGRAD_GROUP_VOXELS and not narrow:
+    if q is not None and B * D * H * W <= CONV_WGRAD_GROUP_VOXELS and not narrow:
         q.lists().conv_wgrad.append((x, dy, dw, int(accumulate)))      # keeps x and dy alive until the flush
         return dw
     lib = L.load()

@@ -188,12 +188,11 @@ class SwinUNETR(nn.Module):
         x_in = x_in.float().contiguous()
         dt = self.compute_dtype
         # (bf16 only: in the fp32 parity mode the branch's convolutions are long enough to become the critical path when throttled - 31.2 -> 29.5)
-        # (not under bench.py's per-launch profiling hook either: that leg times every launch alone, in its normal form)
-        branch = (self.side_branch and dt == torch.bfloat16 and torch.is_grad_enabled() and not x_in.requires_grad
-                  and ops.PROFILE_HOOK is None)
+        # (round 4: bench.py's roofline leg times every launch in place, so the branch stays on there too)
+        branch = self.side_branch and dt == torch.bfloat16 and torch.is_grad_enabled() and not x_in.requires_grad
         # inference (no tape, so no ordering constraint from the backward pass): the two blocks are forked right behind `layers1` and run
         # beside the deep Swin stages, encoder3 / 4 / 10 and decoder5..3
-        infer_branch = (self.side_branch and dt == torch.bfloat16 and not torch.is_grad_enabled() and ops.PROFILE_HOOK is None
+        infer_branch = (self.side_branch and dt == torch.bfloat16 and not torch.is_grad_enabled()
                         and os.environ.get("MISEG_NO_INFER_BRANCH") is None)
         enc0 = enc1 = None
 

@@ -100,7 +100,7 @@ class UNETR(nn.Module):
         # side branch (see SwinUNETR.side_branch): encoder1 reads the image only and feeds the last decoder only, and autograd reaches its
         # backward pass right in front of the ViT's - 12 blocks of 216-token launches that leave the chip idle.  On the branch stream it runs
         # BESIDE them, in background form.
-        branch = (self.side_branch and dt == torch.bfloat16 and torch.is_grad_enabled() and not x_in.requires_grad and ops.PROFILE_HOOK is None)
+        branch = (self.side_branch and dt == torch.bfloat16 and torch.is_grad_enabled() and not x_in.requires_grad)
         if branch:
             side, cur = ops.branch_stream(x_in.device), torch.cuda.current_stream()
             side.wait_stream(cur)

@@ -2,6 +2,16 @@
 (one fill per step instead of one per parameter, and the buffer RCCL all-reduces at N > 1), plus the compute-dtype
 re-layouts of the parameters (bf16 copies, transposes, ConvTranspose regroupings) refreshed by ONE kernel per step.
 
+WHO MAY CHANGE THE PARAMETERS, AND HOW THE COPIES FOLLOW (the versioned refresh).  The refresh launches of a step re-lay-out the weights only
+when the device-side parameter version moved since they last ran.  It moves when
+  * the fused optimiser steps (training/optim.py: `miseg_opt_step` bumps it on the device - also inside a replayed hipGraph);
+  * a parameter is modified THROUGH THE PARAMETER with torch (an in-place op, `copy_`, a torch optimiser, `load_state_dict`: they bump
+    `Tensor._version`) or re-pointed (`set_`, `.data = ...`: another `data_ptr`) - `params_changed()`, called by `begin_step()`,
+    `refresh_weights()`, `GraphedStep` / `GraphedForward` / `GraphedTrainStep` before every replay, notices both and bumps it;
+  * the caller says so: `arena.invalidate()` - REQUIRED after any other write: in-place ops on the `p.data` / `p.detach()` alias (it has a
+    version counter of its own: an EMA swap-in or a weight clamp written that way is invisible), raw-pointer writes of custom kernels.
+`MISEG_REFRESH_ALWAYS=1` in the environment makes every refresh unconditional (the round-2 behaviour, ~0.2 ms per C-Swin-UNETR step).
+
 Without an arena the autograd Functions in hip/functional.py allocate and return each gradient (torch semantics,
 ``grad is None`` for parameters that were not used); with one they add into ``p._miseg_grad`` and return None, and
 ``publish()`` sets ``p.grad`` to the arena views of the parameters used since the last ``begin_step`` (None otherwise,
@@ -17,8 +27,11 @@ from ..hip import ops
 
 
 class ParamArena:
-    def __init__(self, params, dtype=torch.bfloat16, n_buckets=4, overlap_wgrad=False, grad_dtype=torch.float32):
-        """grad_dtype: the dtype the gradient buckets travel in.  float32 (default) averages the fp32 sums themselves, like the reference's DDP
+    def __init__(self, params, dtype=torch.bfloat16, n_buckets=4, overlap_wgrad=False, grad_dtype=torch.float32, force_collective=None):
+        """force_collective (default: the environment's MISEG_FORCE_COLLECTIVE=1): a one-rank process group normally skips every collective (the
+        local sums ARE the mean); with this set the exchanges are launched anyway - the RCCL leg then runs, and is testable, on a one-GPU box
+        (tests/test_hip_rccl.py, `bench.py --force-dist`).  `collectives_launched` counts every collective this arena has issued.
+        grad_dtype: the dtype the gradient buckets travel in.  float32 (default) averages the fp32 sums themselves, like the reference's DDP
         (tune.py:103-109); bfloat16 halves the bytes on xGMI (248.9 -> 124.5 MB per step for C-Swin-UNETR fs=48): every range is rounded into a
         bf16 staging buffer, averaged there, and written back to the fp32 arena when the exchange is waited for - the local sums stay fp32,
         the exchanged mean carries one bf16 rounding per rank."""
@@ -68,6 +81,9 @@ class ParamArena:
         self._bm = None         # (stream, pinned result, event) of the bitmap exchange on a card
         self.used_on_device = False     # True after an exchange that left the global "used" flags in `used_dev` only (allreduce_end(host_flags=False))
         self._offs, self._size = offs, off
+        import os
+        self.force_collective = bool(int(os.environ.get("MISEG_FORCE_COLLECTIVE", "0") or 0)) if force_collective is None else bool(force_collective)
+        self.collectives_launched = 0
         self._qkey = self.flat.untyped_storage().data_ptr()
         self.queues = None
         self.pool = ops._ZeroPool() if self.flat.is_cuda else None      # this model's statistics scratch (ops.use_pool); CPU arenas (gloo tests) have none
@@ -152,7 +168,7 @@ class ParamArena:
         replayed hipGraph - re-lays-out the copies.  The fused optimiser writes through raw pointers and bumps the device version itself."""
         v = 0
         for p in self.params:
-            v += p._version
+            v += p._version + (p.data_ptr() & 0xFFFFFFFFFFFF) * 31          # (a re-pointed parameter - set_, .data = ... - changes the address)
         if v != self.__dict__.get("_pver"):
             first = "_pver" not in self.__dict__
             self._pver = v
@@ -171,9 +187,12 @@ class ParamArena:
         self._refresh()
 
     def invalidate(self):
-        """the parameters changed (an optimiser step): the copies of this epoch must not be used again; forwards cast per call until the
-        next `begin_step()` / `refresh_weights()`.  training/optim.py::ArenaOptimizer.step calls this; a loop that steps a torch optimiser
-        itself must call it too (or simply begin every step with `begin_step()`, as every loop in this repo does)."""
+        """PUBLIC: tell the arena that parameters were written behind its back (see the module docstring: in-place ops on `p.data`, raw-pointer
+        writes, anything that does not bump `Parameter._version`).  Bumps the device-side parameter version - the next refresh launch, eager
+        or inside a replayed hipGraph, re-casts and re-packs every weight - and retires the host-side epoch, so that eager forwards cast per
+        call until the next `begin_step()` / `refresh_weights()`.  Cheap (one one-thread launch); calling it needlessly only costs the
+        re-layout.  (The fused optimiser does NOT call this: its kernel bumps the version on the device itself; torch-level updates are
+        noticed by `params_changed()`.)"""
         self.epoch += 1
         if self.versions.is_cuda:
             L.check(L.load().miseg_counter_add(C.c_void_p(self.versions.data_ptr()), 1, ops._stream()), "counter_add")
@@ -284,7 +303,7 @@ class ParamArena:
         ub = self.used_begin(group)
         works = []
         avg = self._avg(group)
-        if dist.get_world_size(group) > 1:
+        if not self._single(group):
             for lo, hi in reversed(self.buckets):
                 works.append(self._reduce_range(lo, hi, group))
         self.used_on_device = False
@@ -298,6 +317,16 @@ class ParamArena:
             p._miseg_used = bool(u)
         self.publish()
 
+    def _single(self, group=None):
+        """a one-rank group whose collectives are skipped (nothing to exchange) - unless `force_collective` asks for them anyway"""
+        import torch.distributed as dist
+        return dist.get_world_size(group) == 1 and not self.force_collective
+
+    def _all_reduce(self, t, op, group):
+        import torch.distributed as dist
+        self.collectives_launched += 1
+        return dist.all_reduce(t, op=op, group=group, async_op=True)
+
     def _convert(self, src, dst):
         """dtype-converting copy of a 16-byte-aligned range (our strided-copy kernel on the card, torch on the CPU of the gloo tests)"""
         if src.is_cuda:
@@ -310,12 +339,12 @@ class ParamArena:
         import torch.distributed as dist
         op = dist.ReduceOp.AVG if self._avg(group) else dist.ReduceOp.SUM
         if self.grad_dtype == torch.float32:
-            return dist.all_reduce(self.flat[lo:hi], op=op, group=group, async_op=True)
+            return self._all_reduce(self.flat[lo:hi], op, group)
         if self._stage is None:
             self._stage = torch.empty(self._size, dtype=self.grad_dtype, device=self.flat.device)
         self._convert(self.flat[lo:hi], self._stage[lo:hi])
         self._staged.append((lo, hi))
-        return dist.all_reduce(self._stage[lo:hi], op=op, group=group, async_op=True)
+        return self._all_reduce(self._stage[lo:hi], op, group)
 
     def _unstage(self):
         """after the exchanges have been waited for: the averaged bf16 ranges go back into the fp32 arena"""
@@ -348,7 +377,7 @@ class ParamArena:
         """start the sum all-reduce of flat[lo:hi] (pieces of `piece` elements, last first) behind everything already queued on the
         current stream; returns the work handles.  RCCL runs them on its own stream: kernels launched afterwards overlap."""
         import torch.distributed as dist
-        if dist.get_world_size(group) == 1:
+        if self._single(group):
             return []                   # a one-rank group: the local sums ARE the mean (RCCL would run a 249 MB copy kernel per step)
         piece = piece or (hi - lo)      # the whole range is final when this is called: one collective (each costs a ring latency)
         works, e = [], hi
@@ -381,16 +410,16 @@ class ParamArena:
         import torch.distributed as dist
         if not self.used_dev.is_cuda:
             self.used_dev.copy_(torch.tensor([int(p._miseg_used) for p in self.params], dtype=torch.int32))
-            work = dist.all_reduce(self.used_dev, op=dist.ReduceOp.MAX, group=group, async_op=True)
+            work = self._all_reduce(self.used_dev, dist.ReduceOp.MAX, group)
 
             def finish():
                 work.wait()
                 return self.used_dev.tolist() if host else None
             return finish
-        single = dist.get_world_size(group) == 1          # nothing to exchange: the local flags are the global ones
+        single = self._single(group)                      # nothing to exchange: the local flags are the global ones
         if not host:
             self._flags_to_device()
-            work = None if single else dist.all_reduce(self.used_dev, op=dist.ReduceOp.MAX, group=group, async_op=True)
+            work = None if single else self._all_reduce(self.used_dev, dist.ReduceOp.MAX, group)
 
             def finish_dev():
                 if work is not None:
@@ -410,7 +439,7 @@ class ParamArena:
         self._flags_to_device()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            work = dist.all_reduce(self.used_dev, op=dist.ReduceOp.MAX, group=group, async_op=True)
+            work = self._all_reduce(self.used_dev, dist.ReduceOp.MAX, group)
             work.wait()                                  # the side stream waits for RCCL's
             dst.copy_(self.used_dev, non_blocking=True)  # (the host reads `dst` in finish(), before any later step can queue another copy)
             done.record()

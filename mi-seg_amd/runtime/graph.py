@@ -56,8 +56,11 @@ class GraphedForward:
         if host is not None and host != self._styles_host:
             self.styles.copy_(torch.tensor(host, dtype=torch.int32), non_blocking=True)
             self._styles_host = host
-        if self.arena is not None and self.graphs and self.arena.params_changed():
-            self.arena.refresh_weights()          # the graphs read the arena's copies: bring them up to date (a no-op on the device otherwise)
+        if self.arena is not None and self.graphs:
+            # the graphs read the arena's copies: bring them up to date before EVERY replay.  Unconditional: torch-level updates bump
+            # Tensor._version (seen by params_changed()), the fused optimiser writes through raw pointers and bumps only the DEVICE-side
+            # version - the versioned refresh kernels see both and are a device-side no-op (two words read) when nothing changed
+            self.arena.refresh_weights()
         key = None if host is None else tuple(sorted(set(host)))
         if key not in self.graphs:
             s = torch.cuda.Stream()
@@ -204,3 +207,81 @@ class GraphedStep:
             for p, gr in zip(self.params, grads):
                 p.grad = gr
         return y
+
+
+class GraphedTrainStep:
+    """hipGraph of one whole OPTIMISATION step: versioned weight refresh + forward + fused segmentation loss + backward + the one-launch
+    optimiser - what the reference runs per iteration (LitMonai.training_step + optimizer.step, networks/lightning_monai.py:149-166, 255-278)
+    as one replay, with no host work between its kernels.
+
+    The optimiser kernel bumps the arena's device-side parameter version, so the refresh launches at the head of the NEXT replay re-cast
+    and re-pack every weight (runtime/arena.py: versioned refresh) - the cost a real training loop pays and the forward + backward
+    benchmark does not.  The learning rate lives in a device scalar (`set_lr`), so schedulers work under replay.  One graph per set of
+    modalities present in the batch (which conditional-norm rows get a gradient, and are touched by the optimiser, is recorded work)."""
+
+    def __init__(self, model, criterion, optimizer, batch_shape, label_shape, arena, label_dtype=torch.int32, warmup=2):
+        if arena is None or optimizer.arena is not arena:
+            raise ValueError("GraphedTrainStep needs the model's ParamArena and an ArenaOptimizer built over it")
+        self.model, self.criterion, self.opt, self.arena = model, criterion, optimizer, arena
+        dev = arena.flat.device
+        self.x = torch.zeros(*batch_shape, dtype=torch.float32, device=dev)
+        self.label = torch.zeros(*label_shape, dtype=label_dtype, device=dev)
+        self.styles = torch.zeros(batch_shape[0], dtype=torch.int32, device=dev)
+        self.one = torch.ones((), dtype=torch.float32, device=dev)
+        self._styles_host = None
+        self.warmup = warmup
+        self.graphs = {}
+        if optimizer.lr_dev is None:
+            optimizer.lr_dev = torch.tensor([optimizer.lr], dtype=torch.float32, device=dev)
+
+    def set_lr(self, lr):
+        self.opt.lr = float(lr)
+        self.opt.lr_dev.fill_(float(lr))
+
+    def _run(self, host, optimise):
+        self.arena.begin_step()
+        logits = self.model(self.x, (self.styles, host))
+        loss = self.criterion(logits, self.label)
+        loss.backward(self.one)
+        self.arena.end_backward()
+        if optimise:
+            self.opt.step(update_flags=False)      # the flags of this graph are static: copied to the device before every replay
+        return loss.detach()
+
+    def _capture(self, host):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(max(self.warmup, 2)):      # step 1 registers the weight re-layouts; no optimiser step: weights and moments stay put
+                self._run(host, False)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        for p in self.arena.params:
+            p.grad = None
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss = self._run(host, True)
+        ops.STAT_POOL.pin()
+        return g, [bool(p._miseg_used) for p in self.arena.params], loss
+
+    def __call__(self, x, label, modalities):
+        """one optimisation step on (x [B,C,D,H,W] fp32, label [B,1,D,H,W] class ids); returns the loss (0-dim device tensor, static buffer)"""
+        host = _check_styles(self.model, modalities, self.x.shape[0])
+        self.x.copy_(x, non_blocking=True)
+        self.label.copy_(label, non_blocking=True)
+        if host != self._styles_host:
+            self.styles.copy_(torch.tensor(host, dtype=torch.int32), non_blocking=True)
+            self._styles_host = tuple(host)
+        self.arena.params_changed()
+        key = tuple(sorted(set(host))) + (len(host),)
+        if key not in self.graphs:
+            self.graphs[key] = self._capture(host)
+        g, used, loss = self.graphs[key]
+        for p, u in zip(self.arena.params, used):
+            p._miseg_used = u
+        self.opt.set_used_from_arena()
+        g.replay()
+        self.arena.epoch += 1          # (host-side mirror of the device's parameter version: eager forwards cast per call until the next refresh)
+        for p, v, u in zip(self.arena.params, self.arena.views, used):
+            p.grad = v if u else None
+        return loss

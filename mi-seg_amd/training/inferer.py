@@ -42,8 +42,14 @@ def resident_budget(device):
     """bytes of window logits kept in HBM at a time for the gather"""
     if RESIDENT_LIMIT_BYTES is not None:
         return int(RESIDENT_LIMIT_BYTES)
+    return int(_free_bytes(device) * RESIDENT_FRACTION)
+
+
+def _free_bytes(device):
+    """bytes this process can still allocate on `device`: what the driver reports free PLUS what torch's caching allocator holds reserved but
+    unallocated (after a training run most of the card sits there: mem_get_info alone would size the buffer at its minimum or refuse it)"""
     free, _ = torch.cuda.mem_get_info(device)
-    return int(free * RESIDENT_FRACTION)
+    return int(free) + int(torch.cuda.memory_reserved(device)) - int(torch.cuda.memory_allocated(device))
 
 
 class _SlabStitcher:
@@ -59,7 +65,7 @@ class _SlabStitcher:
         budget = resident_budget(device)
         self.cap = min(nd, max(budget // (per_window * self.layer), span + 1))       # whole layers kept resident
         need = (self.cap * self.layer + (sw_batch_size if self.cap < nd else 0)) * per_window
-        if need > torch.cuda.mem_get_info(device)[0]:
+        if need > _free_bytes(device):
             raise MemoryError(f"sliding-window stitching needs {need / 1e9:.1f} GB for {self.cap} resident depth layers of {self.layer} windows")
         self.win = torch.empty((self.cap * self.layer + (sw_batch_size if self.cap < nd else 0), channels) + tuple(roi), dtype=torch.float32, device=device)
         self.lo = self.computed = self.done = 0                            # first resident layer, windows computed, depths written
@@ -95,7 +101,11 @@ class _SlabStitcher:
         keep = next((j for j in range(self.lo, upto) if sd[j] + rd > nxt), upto)
         a, b = (keep - self.lo) * self.layer, self.computed - self.lo * self.layer
         if a and b > a:
-            self.win[:b - a].copy_(self.win[a:b].clone())
+            # move the kept layers to the front in place, front to back in non-overlapping pieces of <= a windows (destination below source: a
+            # piece never overwrites windows that are still to be moved) - a clone of the tail was a second buffer of nearly the budget's size
+            for o in range(0, b - a, a):
+                n = min(a, b - a - o)
+                self.win[o:o + n].copy_(self.win[a + o:a + o + n])
         self.lo = keep
 
 

@@ -607,3 +607,94 @@ def test_litmonai_training_and_validation_steps_on_the_hip_path():
         assert opt.kind == "adamw" and opt.lr == a.lr and opt.weight_decay == a.reg_weight
     finally:
         arena.detach()
+
+
+def test_graphed_train_step_matches_the_eager_loop():
+    """runtime/graph.py::GraphedTrainStep - refresh + forward + fused DiceFocal + backward + one-launch AdamW in ONE hipGraph - against the
+    same optimisation steps launched eagerly (reference loop: lightning_monai.py:149-166, 255-278): same losses step by step, same weights
+    after six steps across both modalities, the absent modality's rows untouched, and a learning-rate change takes effect under replay."""
+    from mi_seg_amd.runtime.arena import ParamArena
+    from mi_seg_amd.runtime.graph import GraphedTrainStep
+    from mi_seg_amd.training.losses import DiceFocalLoss
+    from mi_seg_amd.training.optim import ArenaOptimizer
+    from mi_seg_amd.utils.detfill import det_input
+    crit = DiceFocalLoss(include_background=False, to_onehot_y=True, softmax=True, squared_pred=True, smooth_nr=0.0, smooth_dr=1e-6)
+    xs = [det_input(30 + i, (1, 1, 64, 64, 64)).to(DEV) for i in range(6)]
+    ys = [(x.abs() * 3).floor().clamp(0, 5).to(torch.int32) for x in xs]
+    mods = [0, 1, 1, 0, 0, 1]
+    lrs = [2e-3, 2e-3, 2e-3, 5e-4, 5e-4, 5e-4]
+    runs = {}
+    for mode in ("eager", "graph"):
+        m = _small_model(64, torch.bfloat16)
+        params = [p for p in m.parameters() if p.requires_grad]
+        arena = ParamArena(params, torch.bfloat16)
+        try:
+            opt = ArenaOptimizer(arena, "adamw", lr=lrs[0], weight_decay=1e-5)
+            losses = []
+            if mode == "graph":
+                gts = GraphedTrainStep(m, crit, opt, xs[0].shape, ys[0].shape, arena)
+            for x, y, md, lr in zip(xs, ys, mods, lrs):
+                if mode == "graph":
+                    gts.set_lr(lr)
+                    losses.append(float(gts(x, y, [md])))
+                else:
+                    arena.begin_step()
+                    loss = crit(m(x, [md]), y)
+                    loss.backward()
+                    arena.publish()
+                    opt.step(lr=lr)
+                    losses.append(float(loss))
+            torch.cuda.synchronize()
+            runs[mode] = (losses, {k: v.detach().clone() for k, v in m.state_dict().items()})
+        finally:
+            arena.detach()
+    le, lg = runs["eager"][0], runs["graph"][0]
+    print("train step losses: eager", [round(v, 5) for v in le], "graph", [round(v, 5) for v in lg])
+    assert all(v == v for v in lg) and lg[-1] < lg[0]
+    for i, (a, b) in enumerate(zip(le, lg)):
+        assert abs(a - b) < 2e-3 * (1 + i) * abs(a), (i, a, b)          # same kernels, same inputs: only the weight-gradient sum order differs
+    moved = 0
+    # weights: AdamW moves a parameter by at most lr per step whatever its gradient's size, so a parameter whose true gradient vanishes (a
+    # bias in front of an instance norm: pure rounding noise, its sign differs between two summation orders) may differ by up to sum(lr);
+    # everything else must agree closely - judged over all parameters together
+    num = den = 0.0
+    for k, v in runs["eager"][1].items():
+        w = runs["graph"][1][k]
+        if v.is_floating_point():
+            assert float((v - w).abs().max()) <= 1.01 * sum(lrs), k
+            num += float((v.double() - w.double()).pow(2).sum())
+            den += float(v.double().pow(2).sum())
+    assert (num / den) ** 0.5 < 2e-3, (num / den) ** 0.5
+    sd0 = _small_model(64).state_dict()
+    for k, v in runs["graph"][1].items():
+        if v.is_floating_point() and not torch.equal(v, sd0[k]):
+            moved += 1
+    assert moved > 50          # the optimiser inside the graph really stepped
+
+
+def test_arena_invalidate_makes_a_replay_see_writes_through_the_data_alias():
+    """the versioned refresh contract (runtime/arena.py docstring): an in-place write through `p.data` bumps no version the arena can see - the
+    replayed step keeps using the stale bf16 copies until `arena.invalidate()` is called; a write through the Parameter itself is noticed."""
+    from mi_seg_amd.runtime.arena import ParamArena
+    from mi_seg_amd.runtime.graph import GraphedStep
+    from mi_seg_amd.utils.detfill import det_input
+    m = _small_model(64, torch.bfloat16)
+    params = [p for p in m.parameters() if p.requires_grad]
+    arena = ParamArena(params, torch.bfloat16)
+    try:
+        x, cot = det_input(3, (1, 1, 64, 64, 64)).to(DEV), det_input(4, (1, 6, 64, 64, 64)).to(DEV)
+        step = GraphedStep(m, x.shape, cot.shape, arena=arena)
+        y0 = step(x, [0], cot).detach().clone()
+        w = m.swinViT.layers1[0].blocks[0].attn.qkv.weight      # the kernels read its bf16 COPY, which only the refresh re-makes
+        w.data.mul_(1.5)                                   # behind the arena's back
+        y_stale = step(x, [0], cot).detach().clone()
+        assert torch.equal(y_stale, y0)                    # (documented: not seen)
+        arena.invalidate()
+        y1 = step(x, [0], cot).detach().clone()
+        assert float((y1 - y0).abs().max()) > 1e-3         # now the 1.5x weights are in the logits
+        with torch.no_grad():
+            w.mul_(1 / 1.5)                                # through the Parameter: Tensor._version moves, params_changed() notices
+        y2 = step(x, [0], cot).detach().clone()
+        assert float((y2 - y0).abs().max()) < 1e-2 * float(y0.abs().max())
+    finally:
+        arena.detach()
