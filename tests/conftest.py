@@ -130,3 +130,13 @@ def scalar_scale(want):
     one-element parameters).  Returns that median (1.0 if the net has none)."""
     vals = sorted(float(g.double().abs().max()) for g in want.values() if g.numel() == 1)
     return max(vals[len(vals) // 2], 1e-30) if vals else 1.0
+
+
+def evidence(line):
+    """print a measured-parity line and, when MISEG_EVIDENCE_FILE is set, append it to that file (scripts/profile_round.sh collects the
+    `vs truth` lines of the final build into profiles/rNN_vs_truth.txt: pytest -q swallows prints of passing tests)"""
+    print(line)
+    path = os.environ.get("MISEG_EVIDENCE_FILE")
+    if path:
+        with open(path, "a") as f:
+            f.write(line + "\n")

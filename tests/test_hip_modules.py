@@ -5,7 +5,7 @@ import copy
 import pytest
 import torch
 
-from conftest import compare_grads, rel_err, sample, scalar_scale, state_from_meta
+from conftest import compare_grads, evidence, rel_err, sample, scalar_scale, state_from_meta
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -218,14 +218,14 @@ def test_swin_unetr_c2_vs_truth(golden, dtype, cot):
     (tests/golden/swin_unetr_c2_truth.npz, made by oracle/tools/make_golden.py from the reference's modules).  "Within 1e-3 of the fp32
     reference" is therefore below the reference's own rounding noise at this test point; what CAN be asked of an implementation is that it
     is no further from the float64 run than the reference itself is at the same precision:
-        fp32 mode:  |hip - f64| <= 4 x |ref_fp32 - f64| + 1e-5 per parameter,  median over parameters <= 1.5 x the reference's median,
+        fp32 mode:  |hip - f64| <= 3.5 x |ref_fp32 - f64| + 1e-5 per parameter,  median over parameters <= 1.5 x the reference's median,
                     logits within 8e-7 of the float64 run (the reference's fp32 run: 7.6e-7)
         bf16 mode:  |hip - f64| <= 2 x |ref_autocast - f64| per parameter,      median over parameters <= 1.25 x the reference's median
     relative L2 over the 4096-element sample of each tensor.  Both sides of each inequality are single draws of rounding noise (any change
     of a summation order re-rolls them).  Round 3: the parity mode's 3x3x3 convolution sums in blocks (csrc/conv3d.hip) - logits 1.3e-6 ->
     4.6e-7 from the float64 run; two builds of equal kernel accuracy (scripts/debug/norm_bwd_accuracy.py: the norm backward kernels of both sit
     1e-7 from float64) drew gradient medians 0.79 x / 1.29 x the reference's (white noise) and 1.01 x (cross-entropy), worst per-parameter
-    ratios 1.2 / 3.3 - which sign flips a run catches is a draw, hence 4 x per parameter (rounds 1-2, one running fp32 sum over K = 27 Cin:
+    ratios 1.2 / 3.3 - which sign flips a run catches is a draw, hence 3.5 x per parameter (round 4; 4 x in round 3; rounds 1-2, one running fp32 sum over K = 27 Cin:
     medians 1.65 x, worst 2.7 - 3.9); bf16: worst 1.2 - 1.5, medians 0.90 - 0.93.  Parameters whose true gradient is zero (a bias in front of an
     instance norm) are listed by the float64 run itself and must be ~0."""
     from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
@@ -245,7 +245,7 @@ def test_swin_unetr_c2_vs_truth(golden, dtype, cot):
     rms = {k: float(g.double().norm()) / g.numel() ** 0.5 for k, g in truth.items()}
     med = sorted(rms.values())[len(rms) // 2]
     named = dict(m.named_parameters())
-    factor, slack, med_factor = (4.0, 1e-5, 1.5) if dtype == torch.float32 else (2.0, 0.0, 1.25)
+    factor, slack, med_factor = (3.5, 1e-5, 1.5) if dtype == torch.float32 else (2.0, 0.0, 1.25)
     worst = (0.0, "")
     all_hip, all_ref = [], []
     for k, t in truth.items():
@@ -260,7 +260,8 @@ def test_swin_unetr_c2_vs_truth(golden, dtype, cot):
         assert e_hip <= factor * e_r + slack, (k, e_hip, e_r)
     m_hip, m_ref = sorted(all_hip)[len(all_hip) // 2], sorted(all_ref)[len(all_ref) // 2]
     assert m_hip <= med_factor * m_ref, ("median over parameters", m_hip, m_ref)
-    print(f"c2 vs truth {dtype} {cot}: logits {e_logits:.2e} (reference at this precision {e_ref:.2e}); gradient medians {m_hip:.2e} vs {m_ref:.2e}; worst ratio {worst}")
+    evidence(f"c2 vs truth {dtype} {cot}: logits {e_logits:.2e} (reference at this precision {e_ref:.2e}); gradient medians {m_hip:.2e} vs {m_ref:.2e}; "
+             f"worst ratio {worst[0]:.2f} ({worst[1]}); bar: per parameter {factor} x + {slack}, median {med_factor} x")
     assert sorted(k for k, p in named.items() if p.grad is None) == sorted(R.meta["cases"]["c2_m0"]["grad_none"])
 
 
@@ -360,7 +361,7 @@ def test_unetr_c3(golden, dtype, tol):
     _whole(G, "c3_m1", m, tol, dtype)
 
 
-SMALL_NET_BAR = dict(fp32=(3.0, 1e-2, 1.5), bf16=(3.0, 1e-1, 1.5), bf16_scalar_family=True)
+SMALL_NET_BAR = dict(fp32=(3.0, 1e-2, 1.5), bf16=(4.0, 2e-2, 1.5), bf16_scalar_family=True)
 """(factor, slack, median factor) of _vs_truth for the 32^3 / 64^3 nets.  Their gradients jump with every single activation-sign flip
 (LeakyReLU / PReLU on normalised pre-activations): with ~1e6 pre-activations and a forward error of 3e-7 the expected number of flips is
 below one, so the reference's fp32 run happens to sit 8e-7 from its float64 run while ONE flip near the output puts every upstream
@@ -372,7 +373,9 @@ median 174) sit 2 .. 86 away under autocast (rms 36 = 0.21 of the median) and 3 
 convolution path padded from 0 / 64 / 128 bytes: every change of a summation order in front of them re-draws all 13, the largest error
 moves from slope to slope - scripts/debug/unet_scalar_bf16.py).  One draw against one draw is no bar for them: `bf16_scalar_family` compares
 the FAMILY (rms of error / scale no more than 1.5 x autocast's + 0.05) and holds every single slope within 3 x autocast's rms + 0.1.
-The full-size nets (C2, C3) need none of this."""
+The full-size nets (C2, C3) need none of this.  Round 4: the bf16 bar is relative to autocast's own distance like C2's - 4 x per parameter
+with an absolute slack of 2e-2 (was 3 x + 1e-1: a 10 % slack is no parity check); measured worst 3.79 x on one 1x1x1 weight of the 32^3 UNETR,
+every other parameter of the three small nets within 3 x (profiles/r04_vs_truth.txt holds the printed lines of the final build)."""
 
 
 def _vs_truth(T, R, tag, model, dtype, fp32=(4.0, 1e-5, 2.0), bf16=(2.0, 0.0, 1.25), bf16_scalar_family=False):
@@ -395,6 +398,7 @@ def _vs_truth(T, R, tag, model, dtype, fp32=(4.0, 1e-5, 2.0), bf16=(2.0, 0.0, 1.
     named = dict(m.named_parameters())
     factor, slack, med_factor = fp32 if is32 else bf16
     all_hip, all_ref, worst, bad, fam = [], [], (0.0, ""), [], []
+    need = 0.0          # the absolute slack the worst parameter needs on top of `factor` x the reference's distance (reported as evidence)
     scal = scalar_scale(truth)
     for k, t in truth.items():
         got = sample(named[k].grad)
@@ -413,6 +417,7 @@ def _vs_truth(T, R, tag, model, dtype, fp32=(4.0, 1e-5, 2.0), bf16=(2.0, 0.0, 1.
         if t.numel() == 1 and not is32 and bf16_scalar_family:      # judged as a family below (SMALL_NET_BAR)
             fam.append((e_hip, e_r, k))
             continue
+        need = max(need, e_hip - factor * e_r)
         if e_hip > factor * e_r + slack:
             bad.append((round(e_hip / (e_r + 1e-12), 2), k, f"{e_hip:.2e}", f"{e_r:.2e}"))
     if fam:
@@ -422,7 +427,8 @@ def _vs_truth(T, R, tag, model, dtype, fp32=(4.0, 1e-5, 2.0), bf16=(2.0, 0.0, 1.
     assert not bad, (f"{len(bad)} of {len(all_hip)} parameters further from the float64 run than {factor} x the reference at this precision", sorted(bad)[-12:])
     m_hip, m_ref = sorted(all_hip)[len(all_hip) // 2], sorted(all_ref)[len(all_ref) // 2]
     assert m_hip <= med_factor * m_ref + slack, ("median over parameters", m_hip, m_ref)
-    print(f"{tag} vs truth {dtype}: logits {e_logits:.2e} (reference at this precision {e_ref:.2e}); gradient medians {m_hip:.2e} vs {m_ref:.2e}; worst ratio {worst}")
+    evidence(f"{tag} vs truth {dtype}: logits {e_logits:.2e} (reference at this precision {e_ref:.2e}); gradient medians {m_hip:.2e} vs {m_ref:.2e}; "
+             f"worst ratio {worst[0]:.2f} ({worst[1]}); slack needed at {factor} x: {need:.2e}; bar: per parameter {factor} x + {slack}, median {med_factor} x + {slack}")
     assert sorted(k for k, p in named.items() if p.grad is None) == sorted(R.meta["cases"][tag]["grad_none"])
 
 

@@ -655,13 +655,13 @@ def test_graphed_train_step_matches_the_eager_loop():
         assert abs(a - b) < 2e-3 * (1 + i) * abs(a), (i, a, b)          # same kernels, same inputs: only the weight-gradient sum order differs
     moved = 0
     # weights: AdamW moves a parameter by at most lr per step whatever its gradient's size, so a parameter whose true gradient vanishes (a
-    # bias in front of an instance norm: pure rounding noise, its sign differs between two summation orders) may differ by up to sum(lr);
+    # bias in front of an instance norm: pure rounding noise, its sign differs between two summation orders) may differ by up to 2 sum(lr);
     # everything else must agree closely - judged over all parameters together
     num = den = 0.0
     for k, v in runs["eager"][1].items():
         w = runs["graph"][1][k]
         if v.is_floating_point():
-            assert float((v - w).abs().max()) <= 1.01 * sum(lrs), k
+            assert float((v - w).abs().max()) <= 2.02 * sum(lrs), k          # (+lr on one side, -lr on the other, every step)
             num += float((v.double() - w.double()).pow(2).sum())
             den += float(v.double().pow(2).sum())
     assert (num / den) ** 0.5 < 2e-3, (num / den) ** 0.5
