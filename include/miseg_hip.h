@@ -323,6 +323,9 @@ typedef struct {
 } miseg_conv3_wgrad_params;
 size_t miseg_conv3_wgrad_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout);
 int miseg_conv3_wgrad(const miseg_conv3_wgrad_params* p, miseg_stream_t stream);
+/* 1 when miseg_conv3_wgrad takes a layer of this shape with the tiny-volume kernel (ABI 6: bf16, 3^3 / 6^3 voxels, Cin % 16 == 0,
+ * Cout % 48 == 0): a write-bound launch of its own that a host should not queue for miseg_conv3_wgrad_group */
+int miseg_conv3_wgrad_tiny(int B, int D, int H, int W, int Cin, int Cout, int dtype);
 /* Up to 24 layers of one dtype in one launch (+ one for the partial sums): the small-grid weight gradients of a backward pass
  * (dynunet_block.py:100-126 at 48^3 and below) fill the chip together instead of one after the other.  `workspace` of the
  * params is ignored; one shared buffer of miseg_conv3_wgrad_group_workspace_bytes is passed instead (may be NULL when that is 0). */

@@ -1325,6 +1325,127 @@ static int conv3_wgrad_narrow_launch(const miseg_conv3_wgrad_params* p, hipStrea
   return MISEG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient of TINY volumes (round 4; bf16, S^3 voxels with S = 3 or 6: encoder10 / decoder5 of C-Swin-UNETR, 384 - 768 channels,
+// networks/blocks/dynunet_block.py:100-126).  27 / 216 voxels against a 16 - 64 MB fp32 gradient: the layer is bound by the WRITE of dw, and
+// the 48 x 48 channel-pair kernel above - one 96 KB workgroup per CU, MFMAs over a 256-voxel brick that is nine tenths padding, then a
+// 249 KB epilogue with nothing beside it - spent 25 - 45 us per unit on it (139 of the 437 us of a step's grouped launch).
+// Here the TAPS are the N side of the matrix product: D[co][tap] = sum_v dy^T[co][v] * X_ci[v][tap] with X_ci[v][tap] = x[v + tap][ci], one
+// product per input channel - the accumulator tile of a lane (co = 4 fq + r, tap = fi) is then a run of consecutive addresses of the torch
+// layout [co][ci][27] over the 16 lanes of a quarter wave: no transposition, no LDS round trip, stores as they come.  MFMA efficiency is
+// beside the point (27 of 32 columns, 27 of 32 k at 3^3): the whole 768 -> 768 layer is 74 K MFMAs.  A workgroup = 48 out-channels x 16
+// in-channels (4 per wave), ~40 KB of LDS at 6^3: four workgroups per CU, so one's stores overlap another's staging and products.
+// ---------------------------------------------------------------------------------------------------------
+template <int S>
+__global__ void __launch_bounds__(256) conv3_wgrad_tiny_kernel(const bf16* __restrict__ x, int64_t ldx, const bf16* __restrict__ dy, int64_t lddy,
+                                                               float* __restrict__ dw, int B, int Cin, int Cout, int add) {
+  constexpr int P = S + 2, NP = P * P * P, V = S * S * S, NK = (V + 31) / 32, KP = NK * 32 + 8;
+  __shared__ __attribute__((aligned(16))) bf16 xh[NP * 16];      // zero-padded halo of x, [row][16 in-channels]
+  __shared__ __attribute__((aligned(16))) bf16 dyT[48 * KP];     // dy transposed, [out-channel][voxel] (voxels >= V: zero)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, fq = lane >> 4;
+  const int ci0 = blockIdx.x * 16, co0 = blockIdx.y * 48;
+  f32x4 acc[4][3][2];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) acc[c][mt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // tap of this lane in the two 16-wide tap tiles -> row offset in the halo (taps >= 27 read row 0 and are never stored: whatever they hold)
+  int toff[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int tap = 16 * tt + fi;
+    toff[tt] = tap < 27 ? ((tap / 9) * P + (tap / 3) % 3) * P + tap % 3 : 0;
+  }
+  const bf16 zero = (bf16)0.f;
+  for (int b = 0; b < B; ++b) {
+    if (b) __syncthreads();
+    for (int idx = tid; idx < NP * 2; idx += 256) {
+      const int row = idx >> 1, half = idx & 1;
+      const int pd = row / (P * P), ph = (row / P) % P, pw = row % P;
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = zero;
+      if (pd >= 1 && pd <= S && ph >= 1 && ph <= S && pw >= 1 && pw <= S)
+        v = *reinterpret_cast<const bf16x8*>(x + ((((int64_t)b * S + pd - 1) * S + ph - 1) * S + pw - 1) * ldx + ci0 + 8 * half);
+      *reinterpret_cast<bf16x8*>(xh + row * 16 + 8 * half) = v;
+    }
+    for (int idx = tid; idx < NK * 32 * 6; idx += 256) {
+      const int v = idx / 6, part = idx - v * 6;
+      bf16x8 t;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = zero;
+      if (v < V) t = *reinterpret_cast<const bf16x8*>(dy + ((int64_t)b * V + v) * lddy + co0 + 8 * part);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dyT[(8 * part + e) * KP + v] = t[e];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int s = 0; s < NK; ++s) {
+      // the 8 voxels (k) this lane supplies: their halo rows at tap (0, 0, 0); voxels beyond the volume read row 0 against a zero dy column
+      int rb[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int v = 32 * s + 8 * fq + j;
+        rb[j] = v < V ? ((v / (S * S)) * P + (v / S) % S) * P + v % S : 0;
+      }
+      bf16x8 afr[3];
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt) afr[mt] = *reinterpret_cast<const bf16x8*>(dyT + (16 * mt + fi) * KP + 32 * s + 8 * fq);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bf16* xc = xh + 4 * wave + c;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          bf16x8 bfr;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bfr[j] = xc[(rb[j] + toff[tt]) * 16];
+#pragma unroll
+          for (int mt = 0; mt < 3; ++mt) acc[c][mt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[mt], bfr, acc[c][mt][tt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // lane holds co = 16 mt + 4 fq + r, tap = 16 tt + fi of in-channel ci0 + 4 wave + c: 16 lanes write 16 consecutive floats
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int ci = ci0 + 4 * wave + c;
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int tap = 16 * tt + fi;
+        if (tap < 27) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* dst = dw + ((int64_t)(co0 + 16 * mt + 4 * fq + r) * Cin + ci) * 27 + tap;
+            *dst = add ? *dst + acc[c][mt][tt][r] : acc[c][mt][tt][r];
+          }
+        }
+      }
+  }
+}
+
+static bool wgrad_tiny_shape(int B, int D, int H, int W, int Cin, int Cout, int dtype) {
+  static const int off = [] { const char* e = getenv("MISEG_NO_TINY_WGRAD"); return e && atoi(e) ? 1 : 0; }();
+  return !off && dtype == MISEG_BF16 && D == H && H == W && (D == 3 || D == 6) && B >= 1 && B <= 64 && Cin % 16 == 0 && Cout % 48 == 0;
+}
+static bool wgrad_tiny(const miseg_conv3_wgrad_params* p) {
+  return wgrad_tiny_shape(p->B, p->D, p->H, p->W, p->Cin, p->Cout, p->dtype) && ((uintptr_t)p->x % 16 == 0) && ((uintptr_t)p->dy % 16 == 0) && p->ldx % 8 == 0 &&
+         p->lddy % 8 == 0;
+}
+static int conv3_wgrad_tiny_launch(const miseg_conv3_wgrad_params* p, hipStream_t s) {
+  const dim3 grid(p->Cin / 16, p->Cout / 48);
+  const int add = p->accumulate == 1 ? 1 : 0;      // 0 / 2 (a slot known to hold zeros): plain stores
+  if (p->D == 3)
+    conv3_wgrad_tiny_kernel<3><<<grid, 256, 0, s>>>((const bf16*)p->x, p->ldx, (const bf16*)p->dy, p->lddy, p->dw, p->B, p->Cin, p->Cout, add);
+  else
+    conv3_wgrad_tiny_kernel<6><<<grid, 256, 0, s>>>((const bf16*)p->x, p->ldx, (const bf16*)p->dy, p->lddy, p->dw, p->B, p->Cin, p->Cout, add);
+  MISEG_LAUNCH_CHECK("conv3_wgrad (tiny)");
+  return MISEG_OK;
+}
+
 // Several layers in one launch (the small-grid weight gradients of a backward pass, queued by the host): descriptors travel
 // in the kernel arguments, a workgroup finds its layer by its index range.
 struct WgradLayer {
@@ -1669,28 +1790,54 @@ static int conv3_wgrad_launch(const miseg_conv3_wgrad_params* p, hipStream_t s) 
   return MISEG_OK;
 }
 
-// grouped launch: every layer gets about WG_GROUP_BRICKS bricks per workgroup (the group as a whole fills the chip, so a
-// layer no longer needs 256 workgroups of its own and the slab traffic shrinks with the split count)
-static constexpr int WG_GROUP_BRICKS = 7;
+// grouped launch: every layer gets about `target` bricks per workgroup (the group as a whole fills the chip, so a layer no longer needs 256
+// workgroups of its own and the slab traffic shrinks with the split count).  Round 4: the target follows from the group - the brick x
+// channel-pair units of all its multi-brick layers, dealt to the CUs in ONE round (main group of a C-Swin-UNETR step: 3336 units -> 14 bricks
+// each = 256 long workgroups, and the 12^3 layers become single-split: direct epilogue, no slabs; measured 437 -> 358 us against the fixed 7
+// of rounds 1-3, scripts/micro/wgrad_group_bench.py).  MISEG_WG_GROUP_BRICKS overrides it (tuning aid).
+static int wg_group_bricks_env() {
+  static int v = -2;
+  if (v == -2) { const char* e = getenv("MISEG_WG_GROUP_BRICKS"); v = e ? atoi(e) : -1; if (v < 1) v = -1; }
+  return v;
+}
 
-static void wgrad_group_plan(const miseg_conv3_wgrad_params* p, int wbd, int* ncob, int* ncib, int* nsplit) {
+static int wgrad_group_target(const miseg_conv3_wgrad_params* descs, int n, int wbd) {
+  if (wg_group_bricks_env() > 0) return wg_group_bricks_env();
+  long units = 0;
+  for (int i = 0; i < n; ++i) {
+    const miseg_conv3_wgrad_params* p = descs + i;
+    const int nbricks = p->B * cdiv(p->D, wbd) * cdiv(p->H, BH) * cdiv(p->W, BW);
+    if (nbricks > 2) units += (long)cdiv(p->Cout, WG_CB) * cdiv(p->Cin, WG_CB) * nbricks;
+  }
+  const int cap = descs[0].max_workgroups;
+  const int slots = (cap > 0 && cap < 256) ? cap : 256;
+  int t = cdiv(units, slots);
+  if (t < 7) t = 7;          // (small groups - the side branch's two 48^3 layers: the chip is not full either way; shorter units balance better)
+  if (t > 16) t = 16;
+  return t;
+}
+
+static void wgrad_group_plan(const miseg_conv3_wgrad_params* p, int wbd, int target, int* ncob, int* ncib, int* nsplit) {
   *ncob = cdiv(p->Cout, WG_CB);
   *ncib = cdiv(p->Cin, WG_CB);
   const int nbricks = p->B * cdiv(p->D, wbd) * cdiv(p->H, BH) * cdiv(p->W, BW);
-  int ns = cdiv(nbricks, WG_GROUP_BRICKS);
+  int ns = cdiv(nbricks, target);
   if (ns >= 12 && ns + 7 <= nbricks) ns = (ns + 7) / 8 * 8;       // a multiple of 8: the XCD-contiguous brick order applies
   *nsplit = ns;
 }
 
-static size_t wgrad_group_slab_floats(const miseg_conv3_wgrad_params* p, int wbd) {
+static size_t wgrad_group_slab_floats(const miseg_conv3_wgrad_params* p, int wbd, int target) {
   int ncob, ncib, nsplit;
-  wgrad_group_plan(p, wbd, &ncob, &ncib, &nsplit);
+  wgrad_group_plan(p, wbd, target, &ncob, &ncib, &nsplit);
   return nsplit == 1 ? 0 : (size_t)ncob * ncib * nsplit * 27 * WG_CB * WG_CB;
 }
 
 extern "C" size_t miseg_conv3_wgrad_group_workspace_bytes(const miseg_conv3_wgrad_params* descs, int n) {
+  if (!descs || n <= 0) return 0;
+  const int wbd = descs[0].dtype == MISEG_BF16 ? 4 : 2;
+  const int target = wgrad_group_target(descs, n, wbd);
   size_t total = 0;
-  for (int i = 0; i < n; ++i) total += wgrad_group_slab_floats(descs + i, descs[i].dtype == MISEG_BF16 ? 4 : 2);
+  for (int i = 0; i < n; ++i) total += wgrad_group_slab_floats(descs + i, wbd, target);
   return total * sizeof(float);
 }
 
@@ -1699,12 +1846,13 @@ static int conv3_wgrad_group_launch(const miseg_conv3_wgrad_params* descs, int n
   constexpr int KPC = Vec16<T>::N;
   const int rowb = WG_CB * (int)sizeof(T) + 16;
   const size_t lds = (size_t)((WBD + 2) * HH * HW + WBD * BH * BW) * rowb;
+  const int target = wgrad_group_target(descs, n, WBD);
   // longest workgroups first
   int order[WG_GROUP_MAX];
   int weight[WG_GROUP_MAX];
   for (int i = 0; i < n; ++i) {
     int ncob, ncib, nsplit;
-    wgrad_group_plan(descs + i, WBD, &ncob, &ncib, &nsplit);
+    wgrad_group_plan(descs + i, WBD, target, &ncob, &ncib, &nsplit);
     const int nbricks = descs[i].B * cdiv(descs[i].D, WBD) * cdiv(descs[i].H, BH) * cdiv(descs[i].W, BW);
     order[i] = i;
     weight[i] = cdiv(nbricks, nsplit) * 8 - (descs[i].D < WBD ? 4 : 0) - (descs[i].H <= 4 ? 2 : 0);
@@ -1719,7 +1867,7 @@ static int conv3_wgrad_group_launch(const miseg_conv3_wgrad_params* descs, int n
     const miseg_conv3_wgrad_params* p = descs + order[k];
     WgradLayer& L = grp.l[k];
     int ncob, ncib, nsplit;
-    wgrad_group_plan(p, WBD, &ncob, &ncib, &nsplit);
+    wgrad_group_plan(p, WBD, target, &ncob, &ncib, &nsplit);
     L.x = p->x; L.dy = p->dy; L.dw = p->dw; L.ldx = p->ldx; L.lddy = p->lddy;
     L.g = ConvGeom{p->B, p->D, p->H, p->W, cdiv(p->D, WBD), cdiv(p->H, BH), cdiv(p->W, BW)};
     L.Cin = p->Cin; L.Cout = p->Cout; L.ncib = ncib; L.nsplit = nsplit;
@@ -1759,6 +1907,8 @@ extern "C" int miseg_debug_wgrad_stamps(unsigned long long* out) {   // read and
 }
 #endif
 
+extern "C" int miseg_conv3_wgrad_tiny(int B, int D, int H, int W, int Cin, int Cout, int dtype) { return wgrad_tiny_shape(B, D, H, W, Cin, Cout, dtype) ? 1 : 0; }
+
 extern "C" int miseg_conv3_wgrad_group(const miseg_conv3_wgrad_params* descs, int n, void* workspace, miseg_stream_t s_) {
   MISEG_REQUIRE(descs && n > 0 && n <= WG_GROUP_MAX, MISEG_E_BADARG, "conv3_wgrad_group: 1..%d layers per launch", WG_GROUP_MAX);
   for (int i = 0; i < n; ++i) {
@@ -1778,6 +1928,7 @@ extern "C" int miseg_conv3_wgrad(const miseg_conv3_wgrad_params* p, miseg_stream
   MISEG_REQUIRE(p->B > 0 && p->D > 0 && p->H > 0 && p->W > 0 && p->Cin > 0 && p->Cout > 0, MISEG_E_BADARG, "conv3_wgrad: bad shape");
   if (p->dtype == MISEG_F32) return conv3_wgrad_launch<float, 2>(p, (hipStream_t)s_);
   if (p->dtype == MISEG_BF16 && wgrad_narrow(p)) return conv3_wgrad_narrow_launch(p, (hipStream_t)s_);
+  if (wgrad_tiny(p)) return conv3_wgrad_tiny_launch(p, (hipStream_t)s_);
   if (p->dtype == MISEG_BF16) return conv3_wgrad_launch<bf16, 4>(p, (hipStream_t)s_);
   return set_error(MISEG_E_BADARG, "conv3_wgrad: dtype %d", p->dtype);
 }

@@ -1323,10 +1323,22 @@ __global__ void __launch_bounds__(256) colsum_batch_kernel(ColsumBatch b) {
 #pragma unroll
     for (int e = 0; e < N; ++e) acc[e] = 0.f;
     if (c < d.C) {
-      for (int64_t r = r0 + ty; r < r1; r += TY) {
-        const VT v = *reinterpret_cast<const VT*>(x + r * d.ldx + c);
+      // eight rows in flight per lane (round 4: one dependent load per iteration streamed at 2.4 TB/s; rows beyond the chunk re-read its
+      // last row and are not added)
+      constexpr int U = 8;
+      for (int64_t r = r0 + ty; r < r1; r += U * TY) {
+        VT v[U];
 #pragma unroll
-        for (int e = 0; e < N; ++e) acc[e] += to_f32(v[e]);
+        for (int u = 0; u < U; ++u) {
+          const int64_t ru = r + (int64_t)u * TY;
+          v[u] = *reinterpret_cast<const VT*>(x + (ru < r1 ? ru : r1 - 1) * d.ldx + c);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const float keep = (r + (int64_t)u * TY) < r1 ? 1.f : 0.f;
+#pragma unroll
+          for (int e = 0; e < N; ++e) acc[e] = fmaf(keep, to_f32(v[u][e]), acc[e]);
+        }
       }
     }
     // TY <= 32: one row of `red` per ty

@@ -222,6 +222,7 @@ PROTOS = {
     "miseg_dropout": (i32, [C.POINTER(Dropout), vp]),
     "miseg_counter_add": (i32, [vp, C.c_uint64, vp]),
     "miseg_debug_stamp": (i32, [vp, vp]),
+    "miseg_conv3_wgrad_tiny": (i32, [i32, i32, i32, i32, i32, i32, i32]),
     "miseg_prof_arm": (i32, [i32]),
     "miseg_prof_read": (i32, [vp, vp, i32]),
     "miseg_counter_copy": (i32, [vp, vp, vp]),

@@ -776,7 +776,7 @@ class StepQueues:
     storage of the gradient slot a kernel accumulates into - two models (two arenas) in one process do not share anything."""
 
     def __init__(self, side=True, writes=None):
-        self.colsum, self.gemm_tn, self.tn_reduce, self.conv_wgrad = [], [], [], []
+        self.colsum, self.gemm_tn, self.tn_reduce, self.conv_wgrad, self.tiny_wgrad = [], [], [], [], []
         # gradient slot (data_ptr) -> how many weight-gradient GEMMs of this step write it, direct launches and both queues together: a
         # grouped launch may STORE into a slot ("known zero", miseg_gemm_tn_desc.zeroed) only when it is the slot's one writer of the step -
         # a tied weight's second use, wherever it was issued, would otherwise be overwritten or overwrite
@@ -792,6 +792,9 @@ class StepQueues:
         return self.side if (self.side is not None and in_branch_backward()) else self
 
     def flush(self, side=True):
+        for x, dy, dw, acc in self.tiny_wgrad:
+            _conv3_wgrad_now(x, dy, dw, acc)
+        self.tiny_wgrad.clear()
         _flush_conv_wgrads(self.conv_wgrad)
         _flush_gemm_tn(self.gemm_tn, self.writes)
         _flush_tn_reduces(self.tn_reduce)
@@ -995,6 +998,7 @@ class PendingSlabs:
         self.ws, self.n, self.stride = ws, n, stride
 
 
+TINY_WGRAD_AT = os.environ.get("MISEG_TINY_WGRAD_AT", "inline")      # "inline" | "flush": where the tiny-volume weight gradients are launched (conv3_wgrad)
 CONV_WGRAD_GROUP_VOXELS = 48 ** 3   # layers up to this many voxels are queued: alone they fill a fraction of the chip for 40-85 us each
 
 
@@ -1026,6 +1030,16 @@ def _flush_conv_wgrads(q, background=0, keep=False):
     q.clear()
 
 
+def _conv3_wgrad_now(x, dy, dw, accumulate):
+    """a queued single-layer weight gradient, launched now (no workspace: the tiny-volume kernel stores straight into dw)"""
+    B, D, H, W = _vol(x)
+    ldx, _, Cin = rows(x)
+    lddy, _, Cout = rows(dy)
+    ws = torch.empty(1, dtype=torch.float32, device=x.device)
+    _call("miseg_conv3_wgrad", L.Conv3Wgrad(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), B, D, H, W, Cin, Cout, _dt(x), int(accumulate), _ptr(ws), 0),
+          prof=("conv3_wgrad_tiny_kernel", 2.0 * B * D * H * W * 27 * Cin * Cout))
+
+
 def conv3_wgrad(x, dy, dw=None, accumulate=False):
     """accumulate: False / True, or 2 = `dw` is known to hold zeros (a fresh arena slot): single-producer layers then store instead
     of read-modify-write and the others skip their zero fill."""
@@ -1039,10 +1053,16 @@ def conv3_wgrad(x, dy, dw=None, accumulate=False):
     q = _queues(dw) if accumulate else None
     # (narrow bf16 layers - 16 / 32 channels on both sides - have a kernel of their own that finishes a 48^3 layer in ~10 us: never queued)
     narrow = x.dtype == torch.bfloat16 and Cin in (16, 32) and Cout in (16, 32)
-    if q is not None and B * D * H * W <= CONV_WGRAD_GROUP_VOXELS and not narrow:
+    lib = L.load()
+    # tiny volumes (3^3 / 6^3, hundreds of channels: encoder10 / decoder5): the write-bound kernel of their own, launched where the backward
+    # pass reaches them (TINY_WGRAD_AT = "inline") or with the queued launches at its end ("flush": in front of the grouped launch)
+    tiny = bool(lib.miseg_conv3_wgrad_tiny(B, D, H, W, Cin, Cout, _dt(x)))
+    if tiny and q is not None and TINY_WGRAD_AT != "inline":
+        q.lists().tiny_wgrad.append((x, dy, dw, int(accumulate)))
+        return dw
+    if q is not None and B * D * H * W <= CONV_WGRAD_GROUP_VOXELS and not narrow and not tiny:
         q.lists().conv_wgrad.append((x, dy, dw, int(accumulate)))      # keeps x and dy alive until the flush
         return dw
-    lib = L.load()
     ws = torch.empty(lib.miseg_conv3_wgrad_workspace_bytes(B, D, H, W, Cin, Cout) // 4, dtype=torch.float32, device=x.device)
     bg = _background()
     _call("miseg_conv3_wgrad", L.Conv3Wgrad(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), B, D, H, W, Cin, Cout, _dt(x), int(accumulate), _ptr(ws), bg),

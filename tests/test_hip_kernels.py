@@ -556,6 +556,34 @@ def test_conv3_exact_integers():
         assert torch.equal(dw, dwr)
 
 
+@pytest.mark.parametrize("B,S,Cin,Cout", [(1, 3, 768, 768), (2, 3, 48, 96), (1, 6, 768, 384), (2, 6, 32, 48), (1, 6, 384, 384), (3, 3, 16, 48)])
+def test_conv3_wgrad_tiny_volumes(B, S, Cin, Cout):
+    """the write-bound weight-gradient kernel of the 3^3 / 6^3 layers (encoder10 / decoder5: dynunet_block.py:100-126 at 1/32 resolution;
+    csrc/conv3d.hip::conv3_wgrad_tiny_kernel, taps on the N side of the matrix product) against torch's conv3d_weight on the bf16-rounded
+    operands: plain, accumulate, and "slot holds zeros" modes; batches > 1 (the k dimension continues over the samples)."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    assert ops.L.load().miseg_conv3_wgrad_tiny(B, S, S, S, Cin, Cout, ops.L.BF16) == 1
+    x = rnd(B, S, S, S, Cin, dtype=dtype, seed=301)
+    dy = rnd(B, S, S, S, Cout, dtype=dtype, seed=302)
+    ref = torch.nn.grad.conv3d_weight(x.float().permute(0, 4, 1, 2, 3), (Cout, Cin, 3, 3, 3), dy.float().permute(0, 4, 1, 2, 3), padding=1)
+    dw = ops.conv3_wgrad(x, dy)
+    assert rel_err(dw, ref) < 1e-5          # exact products of bf16 operands, fp32 sums: only the summation order differs
+    base = rnd(Cout, Cin, 3, 3, 3, seed=303)
+    acc = base.clone()
+    ops.conv3_wgrad(x, dy, dw=acc, accumulate=True)
+    assert rel_err(acc - base, ref) < 1e-4
+    z = torch.zeros_like(dw)
+    ops.conv3_wgrad(x, dy, dw=z, accumulate=2)
+    assert torch.equal(z, dw)
+    # strided operands (channel slices of wider buffers, as the concat buffers of the decoders hand them out)
+    xw = rnd(B, S, S, S, Cin + 16, dtype=dtype, seed=304)
+    dyw = rnd(B, S, S, S, Cout + 8, dtype=dtype, seed=305)
+    xs, dys = xw[..., 16:], dyw[..., 8:]
+    ref2 = torch.nn.grad.conv3d_weight(xs.float().permute(0, 4, 1, 2, 3), (Cout, Cin, 3, 3, 3), dys.float().permute(0, 4, 1, 2, 3), padding=1)
+    assert rel_err(ops.conv3_wgrad(xs, dys), ref2) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv3_wgrad_grouped(dtype):
     """the queued weight gradients of a backward pass: one grouped launch (direct epilogue for single-split layers, slabs +
@@ -576,8 +604,10 @@ def test_conv3_wgrad_grouped(dtype):
             dw = base.clone()
             assert ops.conv3_wgrad(x, dy, dw=dw, accumulate=True) is dw
             outs.append(dw)
-        assert len(ops.DEFAULT_QUEUES.conv_wgrad) == len(cases)
-        assert all(torch.equal(o, c[2]) for o, c in zip(outs, cases)), "queued launches must not have run yet"
+        # (tiny volumes with whole channel blocks - bf16 (1, 3, 3, 3, 96, 96) and (1, 6, 6, 6, 48, 96) - take the write-bound kernel of their own right away)
+        tiny = [bool(ops.L.load().miseg_conv3_wgrad_tiny(*x.shape[:4], x.shape[-1], dy.shape[-1], ops._dt(x))) for x, dy, _ in cases]
+        assert len(ops.DEFAULT_QUEUES.conv_wgrad) == len(cases) - sum(tiny) and sum(tiny) == (2 if dtype == torch.bfloat16 else 0)
+        assert all(torch.equal(o, c[2]) for o, c, t in zip(outs, cases, tiny) if not t), "queued launches must not have run yet"
         ops.DEFAULT_QUEUES.flush()
         assert not ops.DEFAULT_QUEUES.conv_wgrad
     finally:
