@@ -821,6 +821,9 @@ def _flush_tn_reduces(q):
     if not q:
         return
     lib = L.load()
+    if os.environ.get("MISEG_DEBUG_QUEUES"):
+        import sys
+        print("tn_reduce queue:", [(it[3], it[4], it[5]) for it in q], file=sys.stderr)
     for i in range(0, len(q), 32):
         chunk = q[i:i + 32]
         descs = (L.TnReduceDesc * len(chunk))()
@@ -834,6 +837,9 @@ def _flush_gemm_tn(q, writes=None):
     if not q:
         return
     lib = L.load()
+    if os.environ.get("MISEG_DEBUG_QUEUES"):      # measurement aid: what the grouped launch holds (M, N, K, zeroed)
+        import sys
+        print("gemm_tn queue:", [(rows(it[0])[2], rows(it[1])[2], rows(it[0])[1], int(it[3])) for it in q], file=sys.stderr)
     once = writes
     if once is None:      # (no step-wide count: at least the problems of this launch)
         once = {}
@@ -857,6 +863,9 @@ def _flush_colsums(q):
     if not q:
         return
     lib = L.load()
+    if os.environ.get("MISEG_DEBUG_QUEUES"):
+        import sys
+        print("colsum queue:", [(rows(t)[1], rows(t)[2]) for t, _ in q], file=sys.stderr)
     for dt in {t.dtype for t, _ in q}:
         items = [(t, o) for t, o in q if t.dtype == dt]
         for i in range(0, len(items), 32):
