@@ -111,6 +111,12 @@ def main():
     ap.add_argument("--host-flags", dest="device_flags", action="store_false",
                     help="N > 1: read the exchanged 'used on any rank' bitmap back to the host every step (what a torch optimiser needs); default: it stays "
                          "on the device for the fused optimiser and the step has no host synchronisation")
+    ap.add_argument("--captured-mode", default="hook", choices=["hook", "cut"],
+                    help="--captured-collective: 'hook' = the backward pass stays whole, the model calls back when its decoder side is done; 'cut' = the two "
+                         "halves of the split step recorded into one graph")
+    ap.add_argument("--captured-collective", action="store_true",
+                    help="N > 1 (or --force-dist): record the gradient all-reduces INTO the step's hipGraph (one graph per step, RCCL's nodes between the "
+                         "two halves of the backward pass) instead of launching them between two graphs")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group (and take the N > 1 code path) even with one rank")
     ap.add_argument("--train-step", action="store_true",
                     help="c2 / c3, N = 1: time a whole OPTIMISATION step instead - versioned weight refresh + forward + fused DiceFocal loss + backward + "
@@ -143,6 +149,8 @@ def main():
         dist.init_process_group(os.environ.get("MISEG_DIST_BACKEND", "nccl"), rank=rank, world_size=world)    # "nccl" is RCCL on ROCm
         if dist.get_world_size() != a.gpus:
             raise SystemExit(f"--gpus {a.gpus} but the process group has {dist.get_world_size()} ranks")
+        dist.all_reduce(torch.zeros(8, device=dev))      # RCCL's communicator is built by the first collective: not inside a capture, not inside the timed region
+        torch.cuda.synchronize()
 
     from mi_seg_amd.hip import lib as hiplib
     hiplib.check_device(local)
@@ -194,7 +202,7 @@ def measure(a, rank, world, dist, dev):
     if not a.no_arena:
         from mi_seg_amd.runtime.arena import ParamArena
         arena = ParamArena(params, dtype, grad_dtype=torch.bfloat16 if a.grad_dtype == "bf16" else torch.float32,
-                           force_collective=True if a.force_dist else None)
+                           force_collective=True if (a.force_dist and os.environ.get("MISEG_FORCE_COLLECTIVE") != "0") else None)
     # N > 1: the backward pass is split behind the decoder side (autograd runs it first), whose gradients - 87 % of the bytes - are
     # all-reduced by RCCL while the encoder / Swin half still runs
     overlap = dist is not None and arena is not None and not a.no_overlap and hasattr(model, "late_backward_parameters")
@@ -205,7 +213,13 @@ def measure(a, rank, world, dist, dev):
     # half, and join the ranges reduced at the end
     hole = None
     if overlap and hasattr(model, "deferred_backward_parameters") and getattr(model, "side_branch", False) and dtype == torch.bfloat16 and not os.environ.get("MISEG_NO_DEFER"):
-        if os.environ.get("MISEG_SPLIT_DEFER", "early") == "early":
+        hook_mode = a.captured_collective and a.captured_mode == "hook" and not a.no_graph
+        if hook_mode:
+            # the backward pass is not cut: decoder1's two deferred weight gradients run at the head of the branch's backward pass as in the
+            # one-rank step - after the callback - so their slots are a hole in the early range
+            hole = arena.param_range(model.deferred_backward_parameters())
+            assert tail <= hole[0] < hole[1] <= arena.flat.numel()
+        elif os.environ.get("MISEG_SPLIT_DEFER", "early") == "early":
             model.split_defers = "early"          # decoder1's deferred weight gradients run on the idle branch stream inside the first half: no hole
         else:
             hole = arena.param_range(model.deferred_backward_parameters())
@@ -216,7 +230,30 @@ def measure(a, rank, world, dist, dev):
     graphed = None
     if not a.no_graph:
         from mi_seg_amd.runtime.graph import GraphedStep
-        graphed = GraphedStep(model, (1, 1, 96, 96, 96), (1, 6, 96, 96, 96), arena=arena, split=overlap)
+        fused = None
+        if overlap and a.captured_collective:
+            class _Comm:      # issued under capture: the early ranges between the halves, the late ones + the waits (RCCL's stream joins) at the end
+                @staticmethod
+                def early():
+                    works = []
+                    for lo, hi in early_ranges:
+                        if hi > lo:
+                            works.extend(arena.allreduce_begin(lo, hi))
+                    return works
+
+                @staticmethod
+                def late(works):
+                    for lo, hi in late_ranges:
+                        if hi > lo:
+                            works.extend(arena.allreduce_begin(lo, hi))
+                    for w in works:
+                        w.wait()
+                    arena._unstage()
+                    _Comm.captured = len(works)
+            _Comm.captured = 0
+            fused = _Comm
+        graphed = GraphedStep(model, (1, 1, 96, 96, 96), (1, 6, 96, 96, 96), arena=arena, split=overlap and not (fused is not None and a.captured_mode == "hook"),
+                              fused_comm=fused)
         graphed.cot.copy_(cot)
         cot = graphed.cot          # the cotangent is constant here: it lives in the graph's static buffer (a loss kernel would write it there)
 
@@ -228,6 +265,12 @@ def measure(a, rank, world, dist, dev):
             arena.invalidate()          # one counter_add launch: the step's refresh kernels then re-lay-out every weight (as after an optimiser step)
         if overlap and sample is None and comm:
             works, ub = [], []
+            if graphed is not None and not eager and a.captured_collective:
+                # the collectives are nodes of the step's graph: exchange the bitmap (known up front), replay, settle the flags
+                used_work = arena.used_begin(host=not a.device_flags)
+                graphed(pool[k:k + 1], [mods[k]], cot, publish=False)
+                arena.allreduce_finish(used_work, world, None)
+                return
             if graphed is not None and not eager:
                 def between():          # the flags of a replayed graph are known up front: the bitmap exchange starts here as well
                     ub.append(arena.used_begin(host=not a.device_flags))
@@ -399,7 +442,8 @@ def measure(a, rank, world, dist, dev):
         out["collective"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "grad_dtype": a.grad_dtype,
                              "payload_bytes_per_step": int(arena.flat.numel() * (4 if a.grad_dtype == "f32" else 2)),
                              "used_flags": "device" if (a.device_flags and overlap) else "host read per step",
-                             "launched_per_step": coll / a.steps, "forced_on_one_rank": bool(arena.force_collective and world == 1)}
+                             "launched_per_step": coll / a.steps, "captured_in_graph": bool(a.captured_collective and overlap and graphed is not None),
+                             "captured_collectives_per_step": (fused.captured if (graphed is not None and fused is not None) else 0), "forced_on_one_rank": bool(arena.force_collective and world == 1)}
     if rank == 0:
         if not a.no_roofline:
             from mi_seg_amd.testing.roofline import profile_step, summarize

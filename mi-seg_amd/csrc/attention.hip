@@ -768,7 +768,11 @@ __global__ void __launch_bounds__(NW * 64, 2) winattn_bwd_mfma_kernel(const bf16
 #pragma unroll
         for (int e = 0; e < 4; ++e) {      // all four bias gathers first: an LDS read issued behind one of the bin atomics would wait for it
           bidx[e] = qc[e] - ck[i];
+#ifdef ATT_EXP_NOBIAS
+          tbv[e] = 0.f;
+#else
           tbv[e] = *reinterpret_cast<const float*>(tkb[i] + qc[e]);      // = table + bidx: the key's share of the address is formed once per wave
+#endif
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -808,7 +812,11 @@ __global__ void __launch_bounds__(NW * 64, 2) winattn_bwd_mfma_kernel(const bf16
         const s16x4 dsT = att_tr4(ds_r);                                                 // [k = key 4kg..][col = query fi]
         dq = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kA[i], dsT, dq, 0, 0, 0);        // dQ^T[dim][query] += K^T dS^T
         __builtin_amdgcn_wave_barrier();
+#ifdef ATT_EXP_NOATOM
+        if (false) {
+#else
         if (DT) {
+#endif
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             atomicAdd(reinterpret_cast<int*>(reinterpret_cast<char*>(dtable) + bidx[e]), __float_as_int(fmaf(dsv[e], fscale, 12582912.f)) - 0x4B400000);

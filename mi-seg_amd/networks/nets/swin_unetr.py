@@ -173,11 +173,14 @@ class SwinUNETR(nn.Module):
     def late_backward_parameters(self):
         return [p for k, p in self.named_parameters() if k.startswith(self.late_backward_prefixes)]
 
-    def forward(self, x_in, modalities=None, cut=None):
+    def forward(self, x_in, modalities=None, cut=None, on_decoder_done=None):
         """x_in [B, C, D, H, W] float; modalities None | list[int] | int64 Tensor[B].  Returns fp32 logits [B, out, D, H, W].
         cut: optional list; when given, the six tensors that cross from the Swin / encoder side to the decoder side are replaced by
         detached leaves and (original, leaf) pairs are appended, so that `logits.backward(g)` stops at the leaves and
-        `torch.autograd.backward([o for o, _ in cut], [l.grad for _, l in cut])` finishes the pass (runtime/graph.py)."""
+        `torch.autograd.backward([o for o, _ in cut], [l.grad for _, l in cut])` finishes the pass (runtime/graph.py).
+        on_decoder_done: optional callable, run by the backward pass once the gradient of the deepest Swin feature map exists - autograd walks
+        the tape backwards, so out / decoder1..5 / encoder10 (`late_backward_prefixes`) have been back-propagated by then and nothing else has:
+        where a data-parallel step issues its decoder-side grouped launches and starts their all-reduce inside ONE captured step (round 4)."""
         if not x_in.is_cuda:
             raise RuntimeError("SwinUNETR (MI355X path) needs a HIP device tensor; there is no CPU fallback")
         needs = "instance_cond" in (self.vit_norm_name, self.encoder_norm_name, self.decoder_norm_name)
@@ -215,6 +218,8 @@ class SwinUNETR(nn.Module):
         enc2 = self._skip_block(self.encoder3, hs[1], styles, hs[1].shape, hs[1].shape[-1], dt)
         enc3 = self._skip_block(self.encoder4, hs[2], styles, hs[2].shape, hs[2].shape[-1], dt)
         h4, h3 = hs[4], hs[3]
+        if on_decoder_done is not None and cut is None and h4.requires_grad:
+            h4.register_hook(lambda g, fn=on_decoder_done: fn())
         if cut is not None:
             def leaf(t):
                 l = t.detach().requires_grad_(True)

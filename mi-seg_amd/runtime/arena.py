@@ -463,7 +463,13 @@ class ParamArena:
             for lo, hi in ([rest] if isinstance(rest[0], int) else rest):      # one range or several (a hole left in the tail, see bench.py)
                 if hi > lo:
                     works += self.allreduce_begin(lo, hi, group)
-        used = ub()
+        self.allreduce_finish(ub, world_size, group, works)
+
+    def allreduce_finish(self, used_work, world_size, group=None, works=()):
+        """the tail of an exchange whose collectives have been issued (allreduce_end; or recorded into the step's hipGraph - GraphedStep
+        fused_comm - and replayed): wait for the bitmap and the given works, bf16 staging back to fp32, mean where the backend only sums,
+        "used" flags, publish"""
+        used = used_work()
         for w in works:
             w.wait()
         self._unstage()

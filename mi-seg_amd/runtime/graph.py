@@ -83,19 +83,29 @@ class GraphedForward:
 
 
 class GraphedStep:
-    def __init__(self, model: torch.nn.Module, batch_shape: Sequence[int], out_shape: Sequence[int], warmup: int = 2, arena=None, split=False):
+    def __init__(self, model: torch.nn.Module, batch_shape: Sequence[int], out_shape: Sequence[int], warmup: int = 2, arena=None, split=False, fused_comm=None):
         """arena: optional runtime.arena.ParamArena of the model (gradients accumulate in its flat buffer, parameter
         re-layouts are refreshed by one kernel per step); without it every gradient is a tensor of the graph's pool.
         Capture needs a quiescent model: drop every reference to outputs of earlier eager steps first - a live autograd graph keeps its
         AccumulateGrad nodes on the eager stream, torch then inserts a cross-stream wait into the capture and hipStreamEndCapture crashes.
         split (needs an arena and a model with `forward(..., cut=)`): the step is recorded as TWO graphs - forward + the decoder
         side of the backward pass, then the encoder side - and `__call__(..., between=fn)` runs `fn()` between the two replays:
-        the data-parallel step starts the all-reduce of the decoder-side gradients there, so RCCL overlaps the second graph."""
+        the data-parallel step starts the all-reduce of the decoder-side gradients there, so RCCL overlaps the second graph.
+        fused_comm (round 4; with split): an object with `early() -> works` and `late(works)`.  The two halves are then recorded into ONE
+        graph with `early()` called - under capture - between them and `late(works)` after the second: the collectives they issue
+        (ProcessGroupNCCL joins RCCL's stream to the capture with ordinary events; scripts/debug/rccl_capture_probe.py) become nodes of the
+        step's graph, the host launches one graph per step and `between` is not used.
+        fused_comm WITHOUT split: the backward pass is not cut at all - the model calls back once its decoder side has been back-propagated
+        (`forward(..., on_decoder_done=)`), the main stream's queued launches go out there and `early()` is called; the side branch starts
+        where it always starts.  `late(works)` follows the end of the pass."""
         self.model = model
         self.arena = arena
         self.split = bool(split)
+        self.fused_comm = fused_comm
         if self.split and arena is None:
             raise ValueError("a split step needs a ParamArena")
+        if fused_comm is not None and arena is None:
+            raise ValueError("fused_comm needs a ParamArena")
         self.params = [p for p in model.parameters() if p.requires_grad]
         dev = self.params[0].device
         self.x = torch.zeros(*batch_shape, dtype=torch.float32, device=dev)
@@ -113,13 +123,26 @@ class GraphedStep:
                 p.grad = None
             ops.begin_step()
         ops.stamp("step_begin")
-        y = self.model(self.x, (self.styles, host))
+        works = []
+        if self.fused_comm is not None:
+            def early():
+                ops.stamp("decoder_done")
+                # the main stream's queued launches so far = the decoder side's: they complete the gradients that `early()` sends.  Inline on
+                # the main stream: on a stream of their own (a third chain beside main and the side branch) the captured step replayed 23 %
+                # slower (151 -> 117 patches/s) - the hipGraph executor serialises a third chain, as in round 3
+                self.arena.queues.flush(side=False)
+                works.extend(self.fused_comm.early())
+            y = self.model(self.x, (self.styles, host), on_decoder_done=early)
+        else:
+            y = self.model(self.x, (self.styles, host))
         ops.stamp("forward_end")
         y.backward(self.cot)
         if self.arena is not None:
             self.arena.end_backward()
         else:
             ops.join_branch()          # a capture must not end with a model's side branch unjoined
+        if self.fused_comm is not None:
+            self.fused_comm.late(works)
         ops.stamp("step_end")
         return y
 
@@ -158,7 +181,14 @@ class GraphedStep:
             p.grad = None
         g = torch.cuda.CUDAGraph()
         g2 = None
-        if self.split:
+        if self.split and self.fused_comm is not None:
+            with torch.cuda.graph(g):
+                y, cut = self._run_first(host)
+                works = self.fused_comm.early()
+                self._run_second(cut)
+                self.fused_comm.late(works)
+            del cut
+        elif self.split:
             with torch.cuda.graph(g):
                 y, cut = self._run_first(host)
             g2 = torch.cuda.CUDAGraph()
