@@ -1812,7 +1812,8 @@ static int wgrad_group_target(const miseg_conv3_wgrad_params* descs, int n, int 
   const int cap = descs[0].max_workgroups;
   const int slots = (cap > 0 && cap < 256) ? cap : 256;
   int t = cdiv(units, slots);
-  if (t < 7) t = 7;          // (small groups - the side branch's two 48^3 layers: the chip is not full either way; shorter units balance better)
+  static const int tmin = [] { const char* e = getenv("MISEG_WG_GROUP_MIN"); const int v = e ? atoi(e) : 7; return v > 0 ? v : 7; }();
+  if (t < tmin) t = tmin;    // (small groups - the side branch's two 48^3 layers, 864 units: 4 / 5 bricks per unit measured no better than 7 in the step)
   if (t > 16) t = 16;
   return t;
 }

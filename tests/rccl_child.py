@@ -115,6 +115,54 @@ def main():
     check_grads(arena16, flags)
     arena16.detach()
 
+    # ---- the data-parallel step with its collectives recorded INTO the step's hipGraph (bench.py --captured-collective, hook mode) ---------
+    from mi_seg_amd.runtime.graph import GraphedStep
+    arena = ParamArena(params, torch.bfloat16)
+    single = GraphedStep(net, x.shape, cot.shape, arena=arena)
+    ref = {}
+    for m in (0, 1):
+        y = single(x, [m], cot)
+        torch.cuda.synchronize()
+        ref[m] = (y.detach().clone(), arena.flat.clone(), [p.grad is None for p in params])
+    n = arena.flat.numel()
+    hole = arena.param_range(net.deferred_backward_parameters())
+    early_ranges, late_ranges = [(hole[1], n), (tail, hole[0])], [(0, tail), hole]
+
+    class Comm:
+        captured = 0
+
+        @staticmethod
+        def early():
+            works = []
+            for lo, hi in early_ranges:
+                works.extend(arena.allreduce_begin(lo, hi))
+            return works
+
+        @staticmethod
+        def late(works):
+            for lo, hi in late_ranges:
+                works.extend(arena.allreduce_begin(lo, hi))
+            for w in works:
+                w.wait()
+            arena._unstage()
+            Comm.captured = len(works)
+
+    cap = GraphedStep(net, x.shape, cot.shape, arena=arena, fused_comm=Comm)
+    for it, m in enumerate([1, 0, 0, 1]):
+        used_work = arena.used_begin(host=False)
+        y = cap(x, [m], cot, publish=False)
+        arena.allreduce_finish(used_work, 1)
+        torch.cuda.synchronize()
+        y_ref, g_ref, none_ref = ref[m]
+        assert torch.equal(y.detach(), y_ref), f"captured step, replay {it}: logits differ from the one-rank graph"
+        assert [p.grad is None for p in params] == none_ref
+        err = float((arena.flat - g_ref).norm() / g_ref.norm())
+        assert err < 1e-4, f"captured step, replay {it}: arena differs from the one-rank graph by {err:.2e}"
+        assert arena.used_dev.tolist() == [int(not v) for v in none_ref]
+    assert Comm.captured == 4, Comm.captured
+    out["captured_collectives_per_step"] = Comm.captured
+    arena.detach()
+
     dist.barrier()
     dist.destroy_process_group()
     print("RCCL_ONE_RANK_OK " + json.dumps(out), flush=True)
