@@ -211,7 +211,7 @@ def measure(a, rank, world, dist, dev):
     # the branch stream inside the FIRST half, beside decoder2 .. 5 / encoder10, and the whole tail is final at the hook.  =late (round 2):
     # they wait for the branch's backward pass in the second half - their slots are then a hole in the tail that goes out after the first
     # half, and join the ranges reduced at the end
-    hole = None
+    hole, hook_deep = None, None
     if overlap and hasattr(model, "deferred_backward_parameters") and getattr(model, "side_branch", False) and dtype == torch.bfloat16 and not os.environ.get("MISEG_NO_DEFER"):
         hook_mode = a.captured_collective and a.captured_mode == "hook" and not a.no_graph
         if hook_mode:
@@ -219,6 +219,15 @@ def measure(a, rank, world, dist, dev):
             # one-rank step - after the callback - so their slots are a hole in the early range
             hole = arena.param_range(model.deferred_backward_parameters())
             assert tail <= hole[0] < hole[1] <= arena.flat.numel()
+            if os.environ.get("MISEG_CAPTURED_EARLY", "all") == "deep":
+                # (option) early range = encoder10 + decoder5 only: 70 % of the gradient bytes (175 of 249 MB), and exactly the layers whose
+                # conv weight gradients are written INLINE by the tiny-volume kernel - at the callback only the small queued launches are
+                # issued (GraphedStep: fused_comm.flush = "small"), the grouped conv weight gradients stay at the end of the pass.  One rank:
+                # 147.6 patches/s without collectives (all: 145.2; one-rank graph 150.6) but 112 with RCCL's one-rank kernels forced (all: 140) -
+                # with the collective forked that early the hipGraph executor serialises the three chains; not the default
+                deep = arena.param_range([p for k, p in model.named_parameters() if p.requires_grad and k.startswith(("encoder10.", "decoder5."))])
+                assert deep[0] == tail and deep[1] <= hole[0]
+                hook_deep = deep
         elif os.environ.get("MISEG_SPLIT_DEFER", "early") == "early":
             model.split_defers = "early"          # decoder1's deferred weight gradients run on the idle branch stream inside the first half: no hole
         else:
@@ -227,6 +236,8 @@ def measure(a, rank, world, dist, dev):
             model.split_defers = True
     early_ranges = [(tail, arena.flat.numel())] if (overlap and hole is None) else ([(hole[1], arena.flat.numel()), (tail, hole[0])] if overlap else [])
     late_ranges = [(0, tail)] + ([hole] if hole is not None else []) if overlap else []
+    if hook_deep is not None:
+        early_ranges, late_ranges = [hook_deep], [(0, tail), (hook_deep[1], arena.flat.numel())]
     graphed = None
     if not a.no_graph:
         from mi_seg_amd.runtime.graph import GraphedStep
@@ -251,6 +262,7 @@ def measure(a, rank, world, dist, dev):
                     arena._unstage()
                     _Comm.captured = len(works)
             _Comm.captured = 0
+            _Comm.flush = "small" if hook_deep is not None else "all"
             fused = _Comm
         graphed = GraphedStep(model, (1, 1, 96, 96, 96), (1, 6, 96, 96, 96), arena=arena, split=overlap and not (fused is not None and a.captured_mode == "hook"),
                               fused_comm=fused)

@@ -791,6 +791,13 @@ class StepQueues:
         """the queue a launch issued NOW belongs to"""
         return self.side if (self.side is not None and in_branch_backward()) else self
 
+    def flush_small(self):
+        """the queued GEMM weight gradients, partial-tile sums and column sums only (the grouped conv weight gradients keep waiting): what
+        completes the small parameters of a range whose conv weights were written inline (tiny-volume layers), cheaply, mid-chain"""
+        _flush_gemm_tn(self.gemm_tn, self.writes)
+        _flush_tn_reduces(self.tn_reduce)
+        _flush_colsums(self.colsum)
+
     def flush(self, side=True):
         for x, dy, dw, acc in self.tiny_wgrad:
             _conv3_wgrad_now(x, dy, dw, acc)

@@ -130,7 +130,12 @@ class GraphedStep:
                 # the main stream's queued launches so far = the decoder side's: they complete the gradients that `early()` sends.  Inline on
                 # the main stream: on a stream of their own (a third chain beside main and the side branch) the captured step replayed 23 %
                 # slower (151 -> 117 patches/s) - the hipGraph executor serialises a third chain, as in round 3
-                self.arena.queues.flush(side=False)
+                if getattr(self.fused_comm, "flush", "all") == "small":
+                    # the early range holds only layers whose conv weight gradients are written inline (the tiny-volume kernel): the small
+                    # queued launches complete its other parameters, the grouped conv weight gradients stay at the end of the pass
+                    self.arena.queues.flush_small()
+                else:
+                    self.arena.queues.flush(side=False)
                 works.extend(self.fused_comm.early())
             y = self.model(self.x, (self.styles, host), on_decoder_done=early)
         else:
