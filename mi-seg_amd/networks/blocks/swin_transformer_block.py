@@ -1,7 +1,9 @@
 """SwinTransformerBlock (reference networks/blocks/swin_transformer_block.py:24-252) on channels-last activations."""
 from typing import Sequence, Tuple, Union
 
+import torch
 import torch.nn as nn
+from torch.utils import checkpoint
 
 from ...hip import functional as HF
 from ..layers.utils import apply_norm, apply_norm_fork, get_norm_layer
@@ -32,7 +34,7 @@ class SwinTransformerBlock(nn.Module):
         self.window_size = tuple(window_size)
         self.shift_size = tuple(shift_size)
         self.mlp_ratio = mlp_ratio
-        self.use_checkpoint = use_checkpoint  # activations are kept (288 GB HBM); flag accepted for API parity
+        self.use_checkpoint = use_checkpoint  # reference :241-252: torch.utils.checkpoint around the two parts of the block; here around the block
         self.norm_type = norm_type[0] if isinstance(norm_type, tuple) else norm_type
         spec = norm_spec_with_shape(norm_type, dim)
         self.norm1 = get_norm_layer(name=spec, spatial_dims=len(self.window_size), channels=dim)
@@ -44,7 +46,28 @@ class SwinTransformerBlock(nn.Module):
         self.mlp = Mlp(hidden_size=dim, mlp_dim=int(dim * mlp_ratio), act=act_layer, dropout_rate=drop, dropout_mode="swin")
 
     def forward(self, x, styles=None):
-        """x [B, D, H, W, C].  part1 (:99-174) + residual, part2 (:176-205) + residual (:241-252)."""
+        """x [B, D, H, W, C].  part1 (:99-174) + residual, part2 (:176-205) + residual (:241-252).
+        use_checkpoint (reference :241-252 checkpoints part1 and part2): the block's activations are dropped after the forward pass and the
+        block is run again when the backward pass reaches it - same kernels on the same inputs, bit-identical activations.  The dropout masks
+        are counter-based (hip/ops.py::_DropState): the second run draws the keys of the first (its call counter is rewound)."""
+        if self.use_checkpoint and torch.is_grad_enabled() and x.requires_grad:
+            from ...hip import ops
+            first = []
+
+            def run(x_, styles_):
+                if not first:
+                    first.append(ops.DROP.calls)
+                    return self._forward(x_, styles_)
+                keep, ops.DROP.calls = ops.DROP.calls, first[0]      # the recomputation: the same dropout keys as the first run
+                try:
+                    return self._forward(x_, styles_)
+                finally:
+                    ops.DROP.calls = keep
+            # (preserve_rng_state=False: no torch RNG is drawn in here, and reading the generator state is illegal under hipGraph capture)
+            return checkpoint.checkpoint(run, x, styles, use_reentrant=False, preserve_rng_state=False)
+        return self._forward(x, styles)
+
+    def _forward(self, x, styles=None):
         _, d, h, w, _ = x.shape
         window, shift = get_window_size((d, h, w), self.window_size, self.shift_size)
         inst = self.norm_type.startswith("instance")    # the GEMM that feeds an instance norm also produces its statistics

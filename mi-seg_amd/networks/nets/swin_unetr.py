@@ -65,12 +65,9 @@ class SwinUNETR(nn.Module):
         self.normalize = normalize
         self.in_channels = in_channels
         self.compute_dtype = torch.float32
-        if use_checkpoint:
-            # reference: swin_transformer_block.py:241-252 (torch.utils.checkpoint around each block).  Accepted for API parity, NOT applied: every
-            # activation of the 96^3 step is kept (a 288 GB card holds them at any batch the reference trains with), results are identical
-            import warnings
-            warnings.warn("use_checkpoint=True is accepted but activation checkpointing is not applied on the MI355X path (activations are kept "
-                          "in HBM; the results do not depend on it)", stacklevel=2)
+        # use_checkpoint (reference swin_transformer_block.py:241-252): every Swin block drops its activations after the forward pass and runs
+        # again in the backward pass (networks/blocks/swin_transformer_block.py); off by default - a 288 GB card holds every activation of
+        # the 96^3 step at any batch the reference trains with
 
         self.swinViT = SwinTransformer(
             in_chans=in_channels, embed_dim=feature_size, window_size=window_size, patch_size=patch_size, depths=depths,

@@ -458,6 +458,58 @@ def test_unet_vs_truth(golden, tag, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("drop", [0.0, 0.2])
+def test_activation_checkpointing_changes_memory_not_results(drop):
+    """use_checkpoint=True (reference swin_transformer_block.py:241-252): the Swin blocks drop their activations after the forward pass and
+    run again in the backward pass.  Same logits bit for bit, same gradients (up to the order of the weight-gradient sums), less memory held
+    between the passes; with dropout on (attention probabilities, MLP / projection outputs, stochastic depth) the second run must draw the
+    masks of the first - the gradients then still match the uncheckpointed net's."""
+    from mi_seg_amd.hip import ops
+    from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
+    from mi_seg_amd.utils.detfill import det_input
+    x = det_input(5, (1, 1, 64, 64, 64)).to(DEV)
+    cot = det_input(6, (1, 6, 64, 64, 64)).to(DEV)
+    res = {}
+    for ck in (False, True):
+        torch.manual_seed(1234)
+        ops.DROP.seed, ops.DROP.step_dev = None, None      # the same dropout keys for both nets
+        m = _fill(SwinUNETR((64, 64, 64), 1, 6, feature_size=24, num_heads=(3, 6, 12, 24), vit_norm_name=_norm("instance_cond"), encoder_norm_name=_norm("instance_cond"),
+                            decoder_norm_name=_norm("instance"), use_checkpoint=ck, drop_rate=drop, attn_drop_rate=drop, dropout_path_rate=drop))
+        m.set_compute_dtype(torch.bfloat16).train()
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        ops.begin_step()
+        y = m(x, [1])
+        held = torch.cuda.memory_allocated() - base          # what the tape keeps alive between the passes
+        y.backward(cot)
+        torch.cuda.synchronize()
+        res[ck] = (y.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}, held)
+        del m, y
+    assert torch.equal(res[True][0], res[False][0]), "checkpointing must not change the forward pass"
+    assert sorted(res[True][1]) == sorted(res[False][1])
+    compare_grads(res[True][1], {k: v.float().cpu() for k, v in res[False][1].items()}, 2e-3 if drop else 1e-4, skip=ZERO_GRAD)
+    assert res[True][2] < 0.8 * res[False][2], (res[True][2], res[False][2])
+    if drop == 0.0:      # ... and the checkpointed step records into a hipGraph and replays like the eager one (arena gradients)
+        from mi_seg_amd.runtime.arena import ParamArena
+        from mi_seg_amd.runtime.graph import GraphedStep
+        m = _fill(SwinUNETR((64, 64, 64), 1, 6, feature_size=24, num_heads=(3, 6, 12, 24), vit_norm_name=_norm("instance_cond"), encoder_norm_name=_norm("instance_cond"),
+                            decoder_norm_name=_norm("instance"), use_checkpoint=True))
+        m.set_compute_dtype(torch.bfloat16)
+        arena = ParamArena([p for p in m.parameters() if p.requires_grad], torch.bfloat16)
+        try:
+            step = GraphedStep(m, x.shape, cot.shape, arena=arena)
+            for _ in range(2):
+                yg = step(x, [1], cot)
+            torch.cuda.synchronize()
+            assert torch.equal(yg.detach(), res[False][0])
+            got = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+            compare_grads(got, {k: v.float().cpu() for k, v in res[False][1].items()}, 1e-4, skip=ZERO_GRAD)
+        finally:
+            arena.detach()
+
+
+@pytest.mark.gpu
 def test_two_models_in_one_process_keep_their_own_step_state():
     """VERDICT round 2 (process-global launch state): two models with an arena each - a training net and, say, its EMA / validation twin -
     whose steps INTERLEAVE (forward A, forward B, backward A, backward B).  Each arena owns its step queues, its branch-deferral queue and

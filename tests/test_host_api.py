@@ -69,12 +69,18 @@ def test_constructor_errors():
     assert parse_normalization("instance_cond", True, 4, 2) == ("instance_cond", {"num_styles": 2, "affine": True})
 
 
-def test_use_checkpoint_is_accepted_and_says_that_it_is_not_applied():
-    """--use_checkpoint (reference utils/parser.py:24, swin_transformer_block.py:241-252): accepted for API parity; the user is told that no
-    activation checkpointing happens on this path ("say so")"""
+def test_use_checkpoint_reaches_every_swin_block():
+    """--use_checkpoint (reference utils/parser.py:24, swin_transformer_block.py:241-252): every Swin block is built with the flag (round 4:
+    applied - the block runs again in the backward pass; tests/test_hip_modules.py::test_activation_checkpointing_changes_memory_not_results)"""
+    import warnings
+    from mi_seg_amd.networks.blocks.swin_transformer_block import SwinTransformerBlock
     from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
-    with pytest.warns(UserWarning, match="checkpoint"):
-        SwinUNETR((32, 32, 32), 1, 2, feature_size=12, use_checkpoint=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        m = SwinUNETR((32, 32, 32), 1, 2, feature_size=12, use_checkpoint=True)
+    blocks = [b for b in m.modules() if isinstance(b, SwinTransformerBlock)]
+    assert len(blocks) == 8 and all(b.use_checkpoint for b in blocks)
+    assert not any(b.use_checkpoint for b in SwinUNETR((32, 32, 32), 1, 2, feature_size=12).modules() if isinstance(b, SwinTransformerBlock))
 
 
 def test_no_cpu_fallback():
