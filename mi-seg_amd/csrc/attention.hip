@@ -87,8 +87,7 @@ static size_t attn_smem_bytes(int n, int hd, int tsize, bool bwd) {
   return ((size_t)2 * n * hd + (size_t)tsize * (bwd ? 2 : 1) + (size_t)5 * n + (size_t)3 * hd) * sizeof(float);
 }
 
-// dropout on the attention probabilities (attn_drop): thresh == 0 = off.  Mask = miseg_dropout's over the [windows * heads * n][n] matrix
-struct AttnDrop { unsigned thresh; float scale; uint64_t key; const uint64_t* step_dev; };
+// dropout on the attention probabilities (attn_drop): struct AttnDrop, common.h
 
 // fp32 parity mode: the library expf / logf (torch's CPU softmax evaluates these); bf16 keeps the single-instruction forms
 template <class T> __device__ __forceinline__ float exp_t(float x) {
@@ -886,8 +885,9 @@ static size_t attn_mfma_fwd_smem(int tsize) {
 }
 
 // csrc/attention_global.hip: head_dim 64 global attention on the matrix cores; return 1 when they took the call (status in *rc)
-int global_attn_fwd(const miseg_winattn_params* p, hipStream_t s, int* rc);
-int global_attn_bwd(const miseg_winattn_bwd_params* p, hipStream_t s, int* rc);
+int global_attn_fwd(const miseg_winattn_params* p, const AttnDrop& dr, hipStream_t s, int* rc);
+int global_attn_bwd(const miseg_winattn_bwd_params* p, const AttnDrop& dr, hipStream_t s, int* rc);
+bool global_attn_takes(const miseg_winattn_params* p);
 
 }  // namespace miseg
 
@@ -939,7 +939,7 @@ static bool fwd_takes_mfma(const miseg_winattn_params* p, const WinGeom& g) {
 extern "C" int miseg_winattn_on_matrix_cores(const miseg_winattn_params* p) {
   WinGeom g;
   if (!p || make_geom(p, &g)) return 0;
-  return fwd_takes_mfma(p, g) ? 1 : 0;
+  return (fwd_takes_mfma(p, g) || global_attn_takes(p)) ? 1 : 0;
 }
 
 extern "C" int miseg_winattn_fwd(const miseg_winattn_params* p, miseg_stream_t s_) {
@@ -950,7 +950,7 @@ extern "C" int miseg_winattn_fwd(const miseg_winattn_params* p, miseg_stream_t s
   if (rc) return rc;
   MISEG_REQUIRE(p->drop_p >= 0.f && p->drop_p < 1.f, MISEG_E_BADARG, "winattn_fwd: drop_p = %f must lie in [0, 1)", (double)p->drop_p);
   const AttnDrop dr = attn_drop_args(p);
-  if (!dr.thresh && global_attn_fwd(p, s, &rc)) return rc;       // one window = the whole token grid, head_dim 64, bf16 (the ViT of C-UNETR)
+  if (global_attn_fwd(p, dr, s, &rc)) return rc;       // one window = the whole token grid, head_dim 64, bf16 (the ViT of C-UNETR; round 4: with attention dropout too)
   const int tb = 2 * g.tw - 1, tsize = p->bias_table ? tb * tb * tb : 0;
   const size_t sh = attn_smem_bytes(g.n, g.hd, tsize, false);
   MISEG_REQUIRE(sh <= 160 * 1024, MISEG_E_UNSUPPORTED, "winattn_fwd: %zu bytes of LDS needed", sh);
@@ -991,7 +991,7 @@ extern "C" int miseg_winattn_bwd(const miseg_winattn_bwd_params* p, miseg_stream
   if (rc) return rc;
   MISEG_REQUIRE(p->f.drop_p >= 0.f && p->f.drop_p < 1.f, MISEG_E_BADARG, "winattn_bwd: drop_p = %f must lie in [0, 1)", (double)p->f.drop_p);
   const AttnDrop dr = attn_drop_args(&p->f);
-  if (!dr.thresh && global_attn_bwd(p, s, &rc)) return rc;       // a call it declines (stricter alignment than the forward's) falls through: every forward kernel stores the log-sum-exp in natural-log units
+  if (global_attn_bwd(p, dr, s, &rc)) return rc;       // a call it declines (stricter alignment than the forward's) falls through: every forward kernel stores the log-sum-exp in natural-log units
   const int tb = 2 * g.tw - 1, tsize = p->f.bias_table ? tb * tb * tb : 0;
   const size_t sh = attn_smem_bytes(g.n, g.hd, tsize, true);
   MISEG_REQUIRE(sh <= 160 * 1024, MISEG_E_UNSUPPORTED, "winattn_bwd: %zu bytes of LDS needed", sh);

@@ -83,8 +83,11 @@ __device__ __forceinline__ float ga_colreduce_sum(float v) {
 
 // ------------------------------------------------------------------------------------------------------------------ forward
 // grid (ceil(n / 64), heads, B), 256 threads.  LDS: K row-major [NP][72], V^T dim-major [64][NP + 8].
-template <int NT>     // NT = NP / 16 (even): the score tiles stay in registers, so the count is a compile-time constant
-__global__ void __launch_bounds__(256) gattn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float* __restrict__ lse, GaGeom g) {
+// DROP (round 4): dropout on the attention probabilities (MONAI SABlock.drop_weights, reference transformer_block.py:59) - miseg_dropout's mask
+// over [samples * heads * n][n], re-created from its key: an accumulator lane holds the 4 consecutive keys 16 t + 4 kg .. + 3 of its query,
+// i.e. exactly one 64-bit hash per tile; the softmax denominator is taken BEFORE the mask, O^T += V^T (P o M s)^T.
+template <int NT, bool DROP>     // NT = NP / 16 (even): the score tiles stay in registers, so the count is a compile-time constant
+__global__ void __launch_bounds__(256) gattn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float* __restrict__ lse, GaGeom g, AttnDrop dr) {
   extern __shared__ __attribute__((aligned(16))) char ga_lds[];
   const int TS = g.NP + 8;
   bf16* Kimg = reinterpret_cast<bf16*>(ga_lds);
@@ -126,6 +129,17 @@ __global__ void __launch_bounds__(256) gattn_fwd_kernel(const bf16* __restrict__
       l += st[t][r];
     }
   l = ga_colreduce_sum(l);
+  if (DROP) {
+    const uint64_t k0 = dropout_step_key(dr.key, dr.step_dev);
+    const int64_t row = ((int64_t)b * g.heads + h) * g.n + q;
+    const int dcg = (g.n + 3) / 4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const uint64_t hh = dropout_group_hash(k0, row, dcg, 16 * t + 4 * kg);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st[t][r] = dropout_keeps(hh, r, dr.thresh) ? st[t][r] * dr.scale : 0.f;
+    }
+  }
   f32x4 o[4];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) o[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -154,9 +168,11 @@ __global__ void __launch_bounds__(256) gattn_fwd_kernel(const bf16* __restrict__
 //   dQ  : LDS K, V row-major + K^T dim-major.                      dQ = scale * dS K
 //   dKV : LDS Q, dO row-major + Q^T, dO^T dim-major + lse, delta.    dV = P^T dO, dK = scale * dS^T Q
 // with P = exp2(S c - lse), dS = P o (dO V^T - delta), delta_q = sum_d dO[q][d] O[q][d].
-template <int NT>
+// DROP: dS = P o (M s o dP - delta) with delta from the dropped output, dV = (P o M s)^T dO.  Role dQ holds 4 keys of one query (one hash per
+// tile), role dK,dV one key of 4 queries (four hashes per tile).
+template <int NT, bool DROP>
 __global__ void __launch_bounds__(256) gattn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out, const bf16* __restrict__ dout,
-                                                        const float* __restrict__ lse, bf16* __restrict__ dqkv, GaGeom g, int nqt) {
+                                                        const float* __restrict__ lse, bf16* __restrict__ dqkv, GaGeom g, int nqt, AttnDrop dr) {
   extern __shared__ __attribute__((aligned(16))) char ga_lds[];
   const int TS = g.NP + 8;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -168,6 +184,9 @@ __global__ void __launch_bounds__(256) gattn_bwd_kernel(const bf16* __restrict__
   const bf16* dobase = dout + (int64_t)b * g.n * g.lddo + h * GA_HD;
   bf16* dbase = dqkv + (int64_t)b * g.n * g.lddq + h * GA_HD;
   const float* lrow = lse + ((int64_t)b * g.heads + h) * g.n;
+  const uint64_t dk0 = DROP ? dropout_step_key(dr.key, dr.step_dev) : 0ull;
+  const int64_t drow0 = ((int64_t)b * g.heads + h) * g.n;      // first row of this (sample, head) in the [samples * heads * n][n] mask
+  const int dcg = (g.n + 3) / 4;
   if ((int)blockIdx.x < nqt) {
     // ------------------------------------------------------------------ role dQ
     bf16* Kimg = reinterpret_cast<bf16*>(ga_lds);
@@ -207,10 +226,16 @@ __global__ void __launch_bounds__(256) gattn_bwd_kernel(const bf16* __restrict__
           s = ga_mma(*reinterpret_cast<const bf16x8*>(Kimg + (16 * t + fi) * GA_RS + 32 * ks + 8 * kg), qb[ks], s);
           dp = ga_mma(*reinterpret_cast<const bf16x8*>(Vimg + (16 * t + fi) * GA_RS + 32 * ks + 8 * kg), dob[ks], dp);
         }
+        const uint64_t hh = DROP ? dropout_group_hash(dk0, drow0 + q, dcg, 16 * t + 4 * kg) : 0ull;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float p = (16 * t + 4 * kg + r < g.n) ? exp2f(s[r] * c - lq) : 0.f;
-          ds[half][r] = p * (dp[r] - delta);
+          if (DROP) {
+            const float pm = dropout_keeps(hh, r, dr.thresh) ? p * dr.scale : 0.f;
+            ds[half][r] = fmaf(pm, dp[r], -p * delta);
+          } else {
+            ds[half][r] = p * (dp[r] - delta);
+          }
         }
       }
       const bf16x8 dsb = ga_pack(ds[0], ds[1]);
@@ -290,8 +315,15 @@ __global__ void __launch_bounds__(256) gattn_bwd_kernel(const bf16* __restrict__
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float p = exp2f(s[r] * c - lq[r]);
-        pp[half][r] = p;
-        ds[half][r] = p * (dp[r] - dl[r]);
+        if (DROP) {
+          const uint64_t hh = dropout_group_hash(dk0, drow0 + 16 * t + 4 * kg + r, dcg, key);
+          const float pm = dropout_keeps(hh, key, dr.thresh) ? p * dr.scale : 0.f;
+          pp[half][r] = pm;
+          ds[half][r] = fmaf(pm, dp[r], -p * dl[r]);
+        } else {
+          pp[half][r] = p;
+          ds[half][r] = p * (dp[r] - dl[r]);
+        }
       }
     }
     const bf16x8 pb = ga_pack(pp[0], pp[1]), dsb = ga_pack(ds[0], ds[1]);
@@ -323,26 +355,33 @@ static bool ga_geom(const miseg_winattn_params* p, GaGeom* g) {
   return true;
 }
 
+bool global_attn_takes(const miseg_winattn_params* p) {
+  GaGeom g;
+  return ga_geom(p, &g) && g.NP / 16 >= 2 && g.NP / 16 <= 16;
+}
+
 // 1: handled (rc in *rc), 0: not this kernel's shape
-int global_attn_fwd(const miseg_winattn_params* p, hipStream_t s, int* rc) {
+int global_attn_fwd(const miseg_winattn_params* p, const AttnDrop& dr, hipStream_t s, int* rc) {
   GaGeom g;
   if (!ga_geom(p, &g)) return 0;
   const size_t sh = (size_t)(g.NP * GA_RS + GA_HD * (g.NP + 8)) * 2;
   const dim3 grid(cdiv(g.n, 64), g.heads, g.B);
-#define GA_FWD(NT) do { MISEG_SET_SMEM((gattn_fwd_kernel<NT>), sh); \
-    gattn_fwd_kernel<NT><<<grid, 256, sh, s>>>((const bf16*)p->qkv, (bf16*)p->out, p->lse, g); } while (0)
+#define GA_FWD_D(NT, D) do { MISEG_SET_SMEM((gattn_fwd_kernel<NT, D>), sh); \
+    gattn_fwd_kernel<NT, D><<<grid, 256, sh, s>>>((const bf16*)p->qkv, (bf16*)p->out, p->lse, g, dr); } while (0)
+#define GA_FWD(NT) do { if (dr.thresh) GA_FWD_D(NT, true); else GA_FWD_D(NT, false); } while (0)
   switch (g.NP / 16) {
     case 2: GA_FWD(2); break; case 4: GA_FWD(4); break; case 6: GA_FWD(6); break; case 8: GA_FWD(8); break;
     case 10: GA_FWD(10); break; case 12: GA_FWD(12); break; case 14: GA_FWD(14); break; case 16: GA_FWD(16); break;
     default: return 0;
   }
 #undef GA_FWD
+#undef GA_FWD_D
   hipError_t e = hipGetLastError();
   *rc = e == hipSuccess ? MISEG_OK : set_error(MISEG_E_LAUNCH, "gattn_fwd: %s", hipGetErrorString(e));
   return 1;
 }
 
-int global_attn_bwd(const miseg_winattn_bwd_params* p, hipStream_t s, int* rc) {
+int global_attn_bwd(const miseg_winattn_bwd_params* p, const AttnDrop& dr, hipStream_t s, int* rc) {
   GaGeom g;
   if (!ga_geom(&p->f, &g)) return 0;
   if (p->lddo % 8 || p->lddq % 4 || p->f.ldo % 8 || ((uintptr_t)p->dout & 15) || ((uintptr_t)p->f.out & 15) || ((uintptr_t)p->dqkv & 7)) return 0;
@@ -352,14 +391,16 @@ int global_attn_bwd(const miseg_winattn_bwd_params* p, hipStream_t s, int* rc) {
   const size_t sh_k = (size_t)(2 * g.NP * GA_RS + 2 * GA_HD * (g.NP + 8)) * 2 + (size_t)2 * g.NP * 4;
   const size_t sh = sh_q > sh_k ? sh_q : sh_k;
   const dim3 grid(2 * nqt, g.heads, g.B);
-#define GA_BWD(NT) do { MISEG_SET_SMEM((gattn_bwd_kernel<NT>), sh); \
-    gattn_bwd_kernel<NT><<<grid, 256, sh, s>>>((const bf16*)p->f.qkv, (const bf16*)p->f.out, (const bf16*)p->dout, p->f.lse, (bf16*)p->dqkv, g, nqt); } while (0)
+#define GA_BWD_D(NT, D) do { MISEG_SET_SMEM((gattn_bwd_kernel<NT, D>), sh); \
+    gattn_bwd_kernel<NT, D><<<grid, 256, sh, s>>>((const bf16*)p->f.qkv, (const bf16*)p->f.out, (const bf16*)p->dout, p->f.lse, (bf16*)p->dqkv, g, nqt, dr); } while (0)
+#define GA_BWD(NT) do { if (dr.thresh) GA_BWD_D(NT, true); else GA_BWD_D(NT, false); } while (0)
   switch (g.NP / 16) {
     case 2: GA_BWD(2); break; case 4: GA_BWD(4); break; case 6: GA_BWD(6); break; case 8: GA_BWD(8); break;
     case 10: GA_BWD(10); break; case 12: GA_BWD(12); break; case 14: GA_BWD(14); break; case 16: GA_BWD(16); break;
     default: return 0;
   }
 #undef GA_BWD
+#undef GA_BWD_D
   hipError_t e = hipGetLastError();
   *rc = e == hipSuccess ? MISEG_OK : set_error(MISEG_E_LAUNCH, "gattn_bwd: %s", hipGetErrorString(e));
   return 1;

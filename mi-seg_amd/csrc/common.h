@@ -143,6 +143,9 @@ __device__ __forceinline__ uint64_t dropout_step_key(uint64_t key, const uint64_
 __device__ __forceinline__ uint64_t dropout_group_hash(uint64_t k, int64_t row, int cg, int c) { return mix64(k + (uint64_t)(row * cg + (c >> 2)) * 0xD1342543DE82EF95ull); }
 __device__ __forceinline__ bool dropout_keeps(uint64_t h, int c, unsigned thresh) { return (unsigned)((h >> (16 * (c & 3))) & 0xffff) >= thresh; }
 
+// dropout on attention probabilities (attn_drop): thresh == 0 = off.  The mask is miseg_dropout's over the [windows * heads * n][n] matrix
+struct AttnDrop { unsigned thresh; float scale; uint64_t key; const uint64_t* step_dev; };
+
 // norm.hip: second launch of a split convolution - y = round(sum of nslabs fp32 slabs [B * S][C] (+ res)), and the instance-norm statistics
 // of y into `stat` (replicated fp64 layout of miseg_instnorm_stats; may be null)
 int slabs_to_out_stats(const float* slabs, int nslabs, void* y, int64_t ldy, const void* res, int64_t ldres, int B, int S, int C, int dtype, double* stat,

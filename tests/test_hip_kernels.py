@@ -853,16 +853,25 @@ def test_window_attention_dropout_on_the_probabilities(dtype, dims, ws, ss, head
         assert rel_err(dqb, qbr.grad) < 2 * tol
 
 
-def test_global_attention_dropout_takes_the_query_lane_kernels():
-    """the SABlock of the ViT with dropout_rate > 0 (MONAI SABlock.drop_weights): head_dim 64, no bias table, one window"""
+@pytest.mark.parametrize("dims,heads", [((4, 4, 4), 2), ((6, 6, 6), 12), ((5, 5, 5), 2), ((2, 3, 5), 3)])
+def test_global_attention_dropout_on_the_matrix_cores(dims, heads):
+    """the SABlock of the ViT with dropout_rate > 0 (MONAI SABlock.drop_weights, reference transformer_block.py:59): head_dim 64, no bias table,
+    one window.  Round 4: the head_dim-64 matrix-core kernels (csrc/attention_global.hip) draw miseg_dropout's mask over [samples * heads * n][n]
+    in their accumulator layouts themselves; against softmax(q k^T scale) o mask @ v with the mask miseg_dropout gives for the same key."""
+    import ctypes
+    from mi_seg_amd.hip import lib as hiplib
     ops = _ops()
-    B, heads, dims, p = 2, 2, (4, 4, 4), 0.1
-    C, n = 64 * heads, 64
+    B, p = 2, 0.1
+    C, n = 64 * heads, dims[0] * dims[1] * dims[2]
     qkv = rnd(B, *dims, 3 * C, dtype=torch.bfloat16, seed=93)
     scale = 64 ** -0.5
     ops.begin_step()
     key = ops.DROP.next_key(qkv.device)
     mask = ops.dropout_apply(torch.ones(B * heads * n, n, device=DEV), p, key).view(B, heads, n, n)
+    assert 0.05 < float((mask == 0).float().mean()) < 0.15
+    out = torch.empty(B, *dims, C, dtype=torch.bfloat16, device=DEV)
+    prm = ops.winattn_params(qkv, out, None, None, torch.empty(B, heads, n, device=DEV), heads, dims, (0, 0, 0), 1, scale, drop=(p, key))
+    assert hiplib.load().miseg_winattn_on_matrix_cores(ctypes.byref(prm)) == 1
     out, lse = ops.winattn_fwd(qkv, None, None, heads, dims, (0, 0, 0), 1, scale, drop=(p, key))
     qr = qkv.float().clone().requires_grad_(True)
     q, k, v = qr.reshape(B, n, 3, heads, 64).permute(2, 0, 3, 1, 4)
@@ -871,7 +880,13 @@ def test_global_attention_dropout_takes_the_query_lane_kernels():
     g = rnd(*out.shape, dtype=torch.bfloat16, seed=94)
     ref.backward(g.float())
     dqkv = ops.winattn_bwd(qkv, out, lse, g, None, None, heads, dims, (0, 0, 0), 1, scale, None, None, drop=(p, key))
-    assert rel_err(dqkv, qr.grad) < 2 * TOL[torch.bfloat16]
+    for i, name in enumerate("qkv"):
+        assert rel_err(dqkv[..., i * C:(i + 1) * C], qr.grad[..., i * C:(i + 1) * C]) < 2 * TOL[torch.bfloat16], f"d{name}"
+    # the same key gives the same mask again (what the backward pass relies on); another key another mask
+    out2, _ = ops.winattn_fwd(qkv, None, None, heads, dims, (0, 0, 0), 1, scale, drop=(p, key))
+    assert torch.equal(out, out2)
+    out3, _ = ops.winattn_fwd(qkv, None, None, heads, dims, (0, 0, 0), 1, scale, drop=(p, ops.DROP.next_key(qkv.device)))
+    assert not torch.equal(out, out3)
 
 
 @pytest.mark.parametrize("dims,heads", [((6, 6, 6), 12), ((5, 5, 5), 2), ((3, 3, 3), 3), ((4, 8, 8), 1), ((2, 3, 5), 2)])
