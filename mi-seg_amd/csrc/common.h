@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <atomic>
 #include "../../include/miseg_hip.h"
 
@@ -112,6 +113,15 @@ static inline hipError_t fill_words_2d_async(void* dst, size_t pitch, uint32_t v
 // current costs the dispatch of this many empty workgroups - and the epilogue every workgroup of a working launch runs: the last one to arrive
 // records the version the copies now hold (all of them read state[0] before their first tile, so nobody can see the new value in this launch).
 static constexpr int REFRESH_MAX_WG = 2048;
+// Round 4: the launch time of a WORKING refresh grows by ~34 ns per workgroup - every workgroup ends with one atomic on the same arrival counter
+// (refresh_done), which the L2 serialises - so the grids are capped where the per-tile latency chain and that queue balance (live refresh of
+// C-Swin-UNETR: casts 110 -> 81 us at 1024 workgroups, conv packs 237 -> 174 us at 512; 8192 workgroups: 324 / 438 us)
+static constexpr int REFRESH_CAST_WG = 1024, REFRESH_PACK_WG = 512;
+static inline int refresh_max_wg(const char* env, int dflt) {      // tuning aid: MISEG_CAST_WG / MISEG_PACK_WG
+  const char* e = getenv(env);
+  const int v = e ? atoi(e) : dflt;
+  return v > 0 ? v : dflt;
+}
 __device__ __forceinline__ void refresh_done(const int64_t* params_version, int64_t* state, int64_t pv) {
   if (!params_version) return;
   __syncthreads();

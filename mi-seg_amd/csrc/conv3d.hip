@@ -580,12 +580,36 @@ __device__ __forceinline__ void pack_conv3_tile(const float* __restrict__ w, T* 
   __shared__ float tile[PK_T * PK_LD];
   const int ci0 = bx * PK_T, co0 = by * PK_T;
   const int nci = min(PK_T, Cin - ci0);
-  for (int i = threadIdx.x; i < PK_T * PK_T * 27; i += 256) {
-    const int co = i / (PK_T * 27), r = i - co * (PK_T * 27);     // r = ci_local * 27 + tap
-    tile[co * PK_LD + r] = (co0 + co < Cout && r < nci * 27) ? w[((int64_t)(co0 + co) * Cin + ci0) * 27 + r] : 0.f;
+  if (nci == PK_T && (Cin & 3) == 0) {
+    // whole tile, 16-byte aligned rows (432 floats per out-channel): seven float4 loads per thread, ALL in flight before the first LDS write.
+    // Round 4: the scalar loop below issued its 27 loads a few at a time - 27 memory round trips per tile, 265 us for the 55 M weights of
+    // C-Swin-UNETR (1.7 TB/s of its 440 MB); what a live weight refresh costs every optimisation step
+    constexpr int R4 = PK_T * 27 / 4, NV = (PK_T * R4 + 255) / 256;      // 108 float4 per row, 7 per thread
+    f32x4 v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int idx = threadIdx.x + k * 256, co = idx / R4, r4 = idx - co * R4;
+      v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < PK_T * R4 && co0 + co < Cout) v[k] = *reinterpret_cast<const f32x4*>(w + ((int64_t)(co0 + co) * Cin + ci0) * 27 + 4 * r4);
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int idx = threadIdx.x + k * 256, co = idx / R4, r4 = idx - co * R4;
+      if (idx < PK_T * R4) {
+        float* t = tile + co * PK_LD + 4 * r4;
+        t[0] = v[k][0]; t[1] = v[k][1]; t[2] = v[k][2]; t[3] = v[k][3];
+      }
+    }
+  } else {
+#pragma unroll 1
+    for (int i = threadIdx.x; i < PK_T * PK_T * 27; i += 256) {
+      const int co = i / (PK_T * 27), r = i - co * (PK_T * 27);     // r = ci_local * 27 + tap
+      tile[co * PK_LD + r] = (co0 + co < Cout && r < nci * 27) ? w[((int64_t)(co0 + co) * Cin + ci0) * 27 + r] : 0.f;
+    }
   }
   __syncthreads();
   if (fwd) {   // K side = ci: vector = KPC consecutive ci of (co, tap)
+#pragma unroll 1
     for (int i = threadIdx.x; i < PK_T * 27 * NG; i += 256) {
       int co, tap, cg;
       if (fwd_planar) { co = i % PK_T; cg = (i / PK_T) % NG; tap = i / (PK_T * NG); }
@@ -602,6 +626,7 @@ __device__ __forceinline__ void pack_conv3_tile(const float* __restrict__ w, T* 
       for (int ch = (ci0 + 6 * KPC - 1) / (6 * KPC); ch * 6 * KPC < ci0 + PK_T && ch * 6 * KPC < CinP; ++ch) fwd96_pack_dummies<T>(fwd, ch, co0, Cout16);
   }
   if (bwd) {   // K side = co, taps mirrored: vector = KPC consecutive co of (ci, tap)
+#pragma unroll 1
     for (int i = threadIdx.x; i < PK_T * 27 * NG; i += 256) {
       int ci, tap, cg;
       if (bwd_planar) { ci = i % PK_T; cg = (i / PK_T) % NG; tap = i / (PK_T * NG); }
@@ -625,17 +650,26 @@ __global__ void __launch_bounds__(256) pack_conv3_kernel(const float* __restrict
   pack_conv3_tile<T>(w, fwd, bwd, Cin, Cout, CinP, CoutP, Cin16, Cout16, fwd_planar, bwd_planar, blockIdx.x, blockIdx.y);
 }
 
+// (round 4: four workgroups per CU - the kernel is a latency chain per tile (search, load, two LDS passes, stores) and 230 VGPRs left room for
+// two; the descriptor search runs on an LDS copy of the tile offsets instead of six dependent global loads per tile)
 template <class T>
 __global__ void __launch_bounds__(256) pack_conv3_batch_kernel(const miseg_pack_conv3_desc* __restrict__ descs, int n, int total_tiles,
-                                                               const int64_t* __restrict__ params_version, int64_t* __restrict__ state, int pad_min) {
+                                                                  const int64_t* __restrict__ params_version, int64_t* __restrict__ state, int pad_min) {
   constexpr int KPC = Vec16<T>::N;
+  constexpr int NS = 128;
+  __shared__ int s_tile0[NS];
   const int64_t pv = params_version ? *params_version : 0;
   if (params_version && state[0] == pv) return;      // versioned refresh (miseg_hip.h): the packs were made from the current parameters
+  const bool in_lds = n <= NS;
+  if (in_lds) {
+    for (int i = threadIdx.x; i < n; i += 256) s_tile0[i] = descs[i].tile0;
+    __syncthreads();
+  }
   for (int tl = blockIdx.x; tl < total_tiles; tl += gridDim.x) {
     int lo = 0, hi = n - 1;
     while (lo < hi) {   // last descriptor with tile0 <= tl
       const int mid = (lo + hi + 1) >> 1;
-      if (descs[mid].tile0 <= tl) lo = mid; else hi = mid - 1;
+      if ((in_lds ? s_tile0[mid] : descs[mid].tile0) <= tl) lo = mid; else hi = mid - 1;
     }
     const miseg_pack_conv3_desc d = descs[lo];
     const int kf = conv3_k96(d.Cin, (int)sizeof(T), pad_min), kb = conv3_k96(d.Cout, (int)sizeof(T), pad_min);
@@ -1716,7 +1750,8 @@ extern "C" int miseg_pack_conv3_batch(const miseg_pack_conv3_desc* descs, int n,
   MISEG_REQUIRE((params_version == nullptr) == (state == nullptr), MISEG_E_BADARG, "pack_conv3_batch: params_version and state go together");
   return dispatch_dtype(dtype, [&](auto* tag) -> int {
     typedef typename std::remove_pointer<decltype(tag)>::type T;
-    pack_conv3_batch_kernel<T><<<total_tiles < REFRESH_MAX_WG ? total_tiles : REFRESH_MAX_WG, 256, 0, (hipStream_t)s_>>>(descs, n, total_tiles, params_version, state,
+    static const int cap = refresh_max_wg("MISEG_PACK_WG", REFRESH_PACK_WG);
+    pack_conv3_batch_kernel<T><<<total_tiles < cap ? total_tiles : cap, 256, 0, (hipStream_t)s_>>>(descs, n, total_tiles, params_version, state,
                                                                                                                          conv3_pad_min_bytes());
     MISEG_LAUNCH_CHECK("pack_conv3_batch");
     return MISEG_OK;
