@@ -32,7 +32,7 @@ WORKLOADS = {
     "c3": ("96^3 patches/sec fwd+bwd, C-UNETR (ViT-B/16 encoder, instance_cond) 6-class", "patches/s",
            "configs[2]: C-UNETR hidden 768 mlp 3072 heads 12 layers 12 feature_size=16 perceptron, 96^3 patch, 6 classes, batch 1 per GPU, fwd+bwd"),
     "c5": ("96^3 windows/sec, sliding-window inference of a 512x512x363 volume (overlap 0.5, 700 windows), C-Swin-UNETR fs=48 6-class", "windows/s",
-           "configs[4]: whole 512x512x363 CT volume resident in HBM, roi 96^3, overlap 0.5 -> 700 windows in batches of 4 (modality broadcast), "
+           "configs[4]: whole 512x512x363 CT volume resident in HBM, roi 96^3, overlap 0.5 -> 700 windows in batches of 20 (modality broadcast), "
            "hipGraph forward, all window logits resident (14.9 GB), one gather-stitch pass; a step = one volume"),
 }
 
@@ -514,7 +514,7 @@ def bench_sliding_window(a, model, dtype, dev, rank, world, dist):
     """BASELINE configs[4]: one step = the sliding-window inference of one whole 512 x 512 x 363 volume resident in HBM (700 windows)."""
     from mi_seg_amd.runtime.graph import GraphedForward
     from mi_seg_amd.training.inferer import sliding_window_inference, window_grid
-    size, sw = (512, 512, 363), 4
+    size, sw = (512, 512, 363), int(os.environ.get("MISEG_SW_BATCH", "20"))      # windows per forward (modality broadcast): 4 / 7 / 10 / 14 / 20 -> 593 / 619 / 627 / 632 / 643 windows/s
     vol = torch.rand(1, 1, *size, generator=torch.Generator().manual_seed(2000 + rank)).to(dev)
     nwin = len(window_grid(size, (96, 96, 96), 0.5))
     from mi_seg_amd.runtime.arena import ParamArena
@@ -543,7 +543,7 @@ def bench_sliding_window(a, model, dtype, dev, rank, world, dist):
     grid = window_grid(size, (96, 96, 96), 0.5)
     worst = 0.0
     with torch.no_grad():
-        for i0 in (0, 348, 696, 4, 0):
+        for i0 in (0, 348, nwin - sw, sw, 0):
             xb = torch.cat([vol[:, :, d:d + 96, h:h + 96, w:w + 96] for (d, h, w) in grid[i0:i0 + sw]], 0).contiguous()
             yg = pred(xb, [0] * sw).float().clone()
             ye = model(xb, [0] * sw).float()
