@@ -279,9 +279,9 @@ def measure(a, rank, world, dist, dev):
             works, ub = [], []
             if graphed is not None and not eager and a.captured_collective:
                 # the collectives are nodes of the step's graph: exchange the bitmap (known up front), replay, settle the flags
-                used_work = arena.used_begin(host=not a.device_flags)
-                graphed(pool[k:k + 1], [mods[k]], cot, publish=False)
-                arena.allreduce_finish(used_work, world, None)
+                ub = []
+                graphed(pool[k:k + 1], [mods[k]], cot, publish=False, before=lambda: ub.append(arena.used_begin(host=not a.device_flags)))
+                arena.allreduce_finish(ub[0], world, None)
                 return
             if graphed is not None and not eager:
                 def between():          # the flags of a replayed graph are known up front: the bitmap exchange starts here as well

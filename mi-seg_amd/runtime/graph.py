@@ -210,10 +210,11 @@ class GraphedStep:
             grads = [p.grad for p in self.params]
         return (g, g2), grads, y
 
-    def __call__(self, x, modalities: Sequence[int], cot, between=None, publish=True):
+    def __call__(self, x, modalities: Sequence[int], cot, between=None, publish=True, before=None):
         """x [B,C,D,H,W] fp32, cotangent d(loss)/d(logits); returns logits (static buffer) with p.grad populated.
         between: called between the two replays of a split step; publish=False leaves `p.grad` to the caller
-        (arena.allreduce_end does it after the exchange)."""
+        (arena.allreduce_end does it after the exchange).  before: called right before the (first) replay, once this step's "used" flags
+        are set on the parameters - where a step with captured collectives starts its bitmap exchange."""
         host = _check_styles(self.model, modalities, self.x.shape[0])
         self.x.copy_(x, non_blocking=True)
         if cot.data_ptr() != self.cot.data_ptr():      # a caller that writes d(loss)/d(logits) into `self.cot` itself (the fused loss) skips the copy
@@ -230,6 +231,8 @@ class GraphedStep:
         if self.arena is not None:
             for p, used in zip(self.arena.params, grads):      # static per graph: known before the replay (the split step's hook
                 p._miseg_used = used                           # exchanges the "used" bitmap early)
+        if before is not None:
+            before()
         g.replay()
         if g2 is not None:
             if between is not None:

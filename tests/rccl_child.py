@@ -149,9 +149,9 @@ def main():
 
     cap = GraphedStep(net, x.shape, cot.shape, arena=arena, fused_comm=Comm)
     for it, m in enumerate([1, 0, 0, 1]):
-        used_work = arena.used_begin(host=False)
-        y = cap(x, [m], cot, publish=False)
-        arena.allreduce_finish(used_work, 1)
+        ub = []
+        y = cap(x, [m], cot, publish=False, before=lambda: ub.append(arena.used_begin(host=False)))      # (the flags of THIS step are set by then)
+        arena.allreduce_finish(ub[0], 1)
         torch.cuda.synchronize()
         y_ref, g_ref, none_ref = ref[m]
         assert torch.equal(y.detach(), y_ref), f"captured step, replay {it}: logits differ from the one-rank graph"
