@@ -628,6 +628,11 @@ int miseg_counter_add(uint64_t* counter_dev, uint64_t value, miseg_stream_t stre
 /* *dst = *src on the device (a plain kernel: device-to-device copies recorded as memcpy nodes crashed hipStreamEndCapture on ROCm 7.2).
  * A dropout call snapshots the step counter so that its backward pass re-creates the same mask after the counter moved on. */
 int miseg_counter_copy(uint64_t* dst_dev, const uint64_t* src_dev, miseg_stream_t stream);
+/* ABI 6: the stream waits ON THE DEVICE (a one-thread kernel that spins with s_sleep) until *flag_dev >= *want_dev - e.g. a flag another
+ * stream, or another hipGraph launch, sets with miseg_counter_copy once its producers have run: an ordering between two captured graphs that
+ * needs no edge between them.  After timeout_us (<= 2 s) the kernel gives up, increments *timed_out_dev (may be null) and returns: what
+ * follows then runs on data that may be incomplete - check the counter. */
+int miseg_flag_wait(const uint64_t* flag_dev, const uint64_t* want_dev, uint64_t timeout_us, uint32_t* timed_out_dev, miseg_stream_t stream);
 /* measurement aid: *slot_dev = the device's constant-rate wall clock (100 MHz on gfx950) when the stream reaches this point.  A one-thread
  * kernel, so it can be recorded into a hipGraph: the order in which the streams of a replayed step reach their joins is visible without a
  * tracer (whose per-dispatch cost reorders exactly that).  Host side: MISEG_STEP_STAMPS=1|2, hip/ops.py::stamp; bench.py prints them. */

@@ -746,6 +746,29 @@ extern "C" int miseg_counter_add(uint64_t* c, uint64_t v, miseg_stream_t s_) {
   return MISEG_OK;
 }
 
+// one-thread spin on a device flag (round 4): returns once *flag >= *want - set by miseg_counter_copy from another stream / another graph launch -
+// or after `timeout_ticks` of the 100 MHz wall clock, in which case *timed_out is incremented and the caller's results are not to be trusted
+// (every wave reaches an exit: a flag that never comes costs the timeout, not the card).  Agent-scope acquire loads: the flag is written by
+// a kernel that may run on another XCD.
+__global__ void flag_wait_kernel(const uint64_t* flag, const uint64_t* want, uint64_t timeout_ticks, uint32_t* timed_out) {
+  const uint64_t w = *want, t0 = wall_clock64();
+  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < w) {
+    if (wall_clock64() - t0 > timeout_ticks) {
+      if (timed_out) atomicAdd(timed_out, 1u);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(32);
+  }
+}
+
+extern "C" int miseg_flag_wait(const uint64_t* flag, const uint64_t* want, uint64_t timeout_us, uint32_t* timed_out, miseg_stream_t s_) {
+  MISEG_REQUIRE(flag && want, MISEG_E_BADARG, "flag_wait: null pointer");
+  MISEG_REQUIRE(timeout_us > 0 && timeout_us <= 2000000, MISEG_E_BADARG, "flag_wait: timeout %llu us (1 .. 2,000,000)", (unsigned long long)timeout_us);
+  flag_wait_kernel<<<1, 1, 0, (hipStream_t)s_>>>(flag, want, timeout_us * 100, timed_out);
+  MISEG_LAUNCH_CHECK("flag_wait");
+  return MISEG_OK;
+}
+
 __global__ void stamp_kernel(uint64_t* slot) { *slot = wall_clock64(); }
 
 extern "C" int miseg_debug_stamp(uint64_t* slot, miseg_stream_t s_) {

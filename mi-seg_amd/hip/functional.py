@@ -70,6 +70,32 @@ def fork(x):
     return _Fork.apply(x)
 
 
+class _Mark(Function):
+    """identity whose backward calls `fn()` (host code; no kernel) when the backward pass gets here: placed at the INPUT of a sub-network it
+    fires right behind that sub-network's backward pass - autograd runs the ready node with the highest sequence number first - where a
+    tensor hook would only fire in front of the input's own producer, which may be much later (runtime/graph.py: leaf-graph points)"""
+
+    @staticmethod
+    def forward(ctx, x, fn):
+        ctx.fn = fn
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.fn()
+        return g, None
+
+
+def backward_mark(x, fn):
+    if fn is None or not x.requires_grad:
+        return x
+    y = _Mark.apply(x, fn)
+    for a in ("_miseg_stat", "_miseg_cat"):      # tags the producer hung on the tensor travel with it
+        if hasattr(x, a):
+            setattr(y, a, getattr(x, a))
+    return y
+
+
 class _Add(Function):
     @staticmethod
     def forward(ctx, a, b):

@@ -226,6 +226,7 @@ PROTOS = {
     "miseg_prof_arm": (i32, [i32]),
     "miseg_prof_read": (i32, [vp, vp, i32]),
     "miseg_counter_copy": (i32, [vp, vp, vp]),
+    "miseg_flag_wait": (i32, [vp, vp, C.c_uint64, vp, vp]),
     "miseg_abi_struct_size": (C.c_size_t, [C.c_char_p]),
     "miseg_device_check": (i32, [i32]),
 }

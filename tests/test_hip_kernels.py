@@ -947,3 +947,40 @@ def test_instnorm_fused_small(dtype, B, S, C):
     assert rel_err(dx, xf.grad.float()) < tol and rel_err(dres, rf.grad.float()) < tol
     for s_ in set(styles.tolist()):
         assert rel_err(dg[s_], gp[s_].grad.float()) < tol and rel_err(db[s_], bp[s_].grad.float()) < tol
+
+
+def test_flag_wait_orders_two_streams_on_the_device_and_gives_up_after_its_timeout():
+    """miseg_flag_wait (round 4): a one-thread kernel that spins until *flag >= *want - an ordering between two streams (or two hipGraph
+    launches) without an event.  (a) a flag set later by another stream releases the waiter, and what follows it sees the producer's data;
+    (b) a flag that never comes costs the timeout, increments *timed_out and lets the stream go on (no wave spins for ever)."""
+    import ctypes as C
+    import time
+    from mi_seg_amd.hip import lib as hiplib
+    lib = hiplib.load()
+    P = lambda t: C.c_void_p(t.data_ptr())
+    flag = torch.zeros(1, dtype=torch.int64, device=DEV)
+    want = torch.ones(1, dtype=torch.int64, device=DEV)
+    one = torch.ones(1, dtype=torch.int64, device=DEV)
+    tout = torch.zeros(1, dtype=torch.int32, device=DEV)
+    data = torch.zeros(1 << 20, device=DEV)
+    seen = torch.zeros(1 << 20, device=DEV)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(sb):      # the consumer first: it must wait on the device
+        hiplib.check(lib.miseg_flag_wait(P(flag), P(want), 1000000, P(tout), C.c_void_p(sb.cuda_stream)), "flag_wait")
+        seen.copy_(data)
+    time.sleep(0.05)
+    assert not sb.query(), "the waiter must still be spinning: nobody has set the flag"
+    with torch.cuda.stream(sa):      # the producer: data, then the flag
+        data.fill_(7.0)
+        hiplib.check(lib.miseg_counter_copy(P(flag), P(one), C.c_void_p(sa.cuda_stream)), "counter_copy")
+    torch.cuda.synchronize()
+    assert int(tout.item()) == 0 and bool((seen == 7.0).all())
+    # (b) nobody sets flag >= 5: the wait gives up after ~2 ms
+    want.fill_(5)
+    t0 = time.perf_counter()
+    hiplib.check(lib.miseg_flag_wait(P(flag), P(want), 2000, P(tout), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "flag_wait")
+    torch.cuda.synchronize()
+    assert int(tout.item()) == 1 and time.perf_counter() - t0 < 0.5
+    with pytest.raises(ValueError):
+        hiplib.check(lib.miseg_flag_wait(P(flag), P(want), 0, P(tout), C.c_void_p(0)), "flag_wait")
