@@ -146,6 +146,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        # (ProcessGroupNCCL's event cache hands an event last recorded by a CAPTURED collective to a later eager one; the watchdog thread's
+        # poll of it aborts the process - tests/rccl_child.py: 1 run in 8 with the cache, 0 in 24 without)
+        os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
         dist.init_process_group(os.environ.get("MISEG_DIST_BACKEND", "nccl"), rank=rank, world_size=world)    # "nccl" is RCCL on ROCm
         if dist.get_world_size() != a.gpus:
             raise SystemExit(f"--gpus {a.gpus} but the process group has {dist.get_world_size()} ranks")
@@ -243,7 +246,7 @@ def measure(a, rank, world, dist, dev):
         from mi_seg_amd.runtime.graph import GraphedStep
         fused = None
         if overlap and a.captured_collective:
-            class _Comm:      # issued under capture: the early ranges between the halves, the late ones + the waits (RCCL's stream joins) at the end
+            class _Comm:      # issued under capture: the bitmap, the early ranges between the halves, the late ones + the waits (RCCL's stream joins) at the end
                 @staticmethod
                 def early():
                     works = []
@@ -257,10 +260,12 @@ def measure(a, rank, world, dist, dev):
                     for lo, hi in late_ranges:
                         if hi > lo:
                             works.extend(arena.allreduce_begin(lo, hi))
+                    ub = arena.used_begin(host=False)      # this graph's "used" flags are known now: their exchange is a node of the graph too
                     for w in works:
                         w.wait()
+                    ub()                                   # (the current stream waits for the bitmap exchange; the global flags stay in `used_dev`)
                     arena._unstage()
-                    _Comm.captured = len(works)
+                    _Comm.captured = len(works) + 1
             _Comm.captured = 0
             _Comm.flush = "small" if hook_deep is not None else "all"
             fused = _Comm
@@ -279,9 +284,8 @@ def measure(a, rank, world, dist, dev):
             works, ub = [], []
             if graphed is not None and not eager and a.captured_collective:
                 # the collectives are nodes of the step's graph: exchange the bitmap (known up front), replay, settle the flags
-                ub = []
-                graphed(pool[k:k + 1], [mods[k]], cot, publish=False, before=lambda: ub.append(arena.used_begin(host=not a.device_flags)))
-                arena.allreduce_finish(ub[0], world, None)
+                graphed(pool[k:k + 1], [mods[k]], cot, publish=False)
+                arena.allreduce_finish(lambda: None, world, None)      # every exchange was a node of the graph; the global flags are in `used_dev`
                 return
             if graphed is not None and not eager:
                 def between():          # the flags of a replayed graph are known up front: the bitmap exchange starts here as well

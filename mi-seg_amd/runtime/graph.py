@@ -13,6 +13,17 @@ import torch
 from ..hip import ops
 
 
+def _graph_capture(g, **kw):
+    """torch.cuda.graph(g, ...) for this package.  With a process group alive the capture is THREAD-LOCAL: ProcessGroupNCCL's watchdog thread
+    polls the events of earlier, eager collectives (hipEventQuery), which a capture in the default "global" error mode forbids to every thread
+    of the process - the watchdog then dies with "operation not permitted when stream is capturing" and takes the process with it (seen once in
+    six runs of tests/rccl_child.py, depending on whether the watchdog had already reaped the works)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        kw.setdefault("capture_error_mode", "thread_local")
+    return torch.cuda.graph(g, **kw)
+
+
 def _check_styles(model, modalities, batch):
     """host tuple of style ids, range-checked BEFORE it reaches the static device tensor a captured graph reads (the kernels index
     by-value argument arrays with it: an id outside [0, num_styles) would be a wild pointer)"""
@@ -73,7 +84,7 @@ class GraphedForward:
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with _graph_capture(g):
                 y = self._run(host)
             ops.STAT_POOL.pin()
             self.graphs[key] = (g, y)
@@ -94,7 +105,9 @@ class GraphedStep:
         fused_comm (round 4; with split): an object with `early() -> works` and `late(works)`.  The two halves are then recorded into ONE
         graph with `early()` called - under capture - between them and `late(works)` after the second: the collectives they issue
         (ProcessGroupNCCL joins RCCL's stream to the capture with ordinary events; scripts/debug/rccl_capture_probe.py) become nodes of the
-        step's graph, the host launches one graph per step and `between` is not used.
+        step's graph, the host launches one graph per step and `between` is not used.  The warm-up runs in front of the capture issue
+        NO collective (and `late()` should exchange the "used" bitmap under capture as well): a step with captured collectives is best left
+        without eager ones - ProcessGroupNCCL's watchdog thread polling events around a capture that records into RCCL's stream killed 1 run in 8.
         fused_comm WITHOUT split: the backward pass is not cut at all - the model calls back once its decoder side has been back-propagated
         (`forward(..., on_decoder_done=)`), the main stream's queued launches go out there and `early()` is called; the side branch starts
         where it always starts.  `late(works)` follows the end of the pass."""
@@ -174,12 +187,18 @@ class GraphedStep:
     def _capture(self, host):
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(max(self.warmup, 2 if self.arena is not None else 0)):   # arena: step 1 registers the re-layouts
-                if self.split:
-                    self._run_second(self._run_first(host)[1])
-                else:
-                    self._run(host)
+        self._warming = True          # (no collective in the warm-up runs of a step with captured collectives: see __init__)
+        try:
+            with torch.cuda.stream(s):
+                for _ in range(max(self.warmup, 2 if self.arena is not None else 0)):   # arena: step 1 registers the re-layouts
+                    if self.split:
+                        self._run_second(self._run_first(host)[1])
+                    else:
+                        self._run(host)
+                if self.fused_comm is not None and self.arena is not None and self.arena.used_dev.is_cuda:
+                    self.arena._flags_to_device()      # this graph's "used" pattern on the device now: the captured exchange finds it cached (no upload under capture)
+        finally:
+            self._warming = False
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         for p in self.params:
@@ -187,21 +206,21 @@ class GraphedStep:
         g = torch.cuda.CUDAGraph()
         g2 = None
         if self.split and self.fused_comm is not None:
-            with torch.cuda.graph(g):
+            with _graph_capture(g):
                 y, cut = self._run_first(host)
                 works = self.fused_comm.early()
                 self._run_second(cut)
                 self.fused_comm.late(works)
             del cut
         elif self.split:
-            with torch.cuda.graph(g):
+            with _graph_capture(g):
                 y, cut = self._run_first(host)
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, pool=g.pool()):        # the second graph consumes activations the first one saved: one pool
+            with _graph_capture(g2, pool=g.pool()):        # the second graph consumes activations the first one saved: one pool
                 self._run_second(cut)
             del cut
         else:
-            with torch.cuda.graph(g):
+            with _graph_capture(g):
                 y = self._run(host)
         ops.STAT_POOL.pin()        # the graph holds raw pointers into the statistics chunk it was captured on
         if self.arena is not None:
@@ -297,7 +316,7 @@ class GraphedTrainStep:
         for p in self.arena.params:
             p.grad = None
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with _graph_capture(g):
             loss = self._run(host, True)
         ops.STAT_POOL.pin()
         return g, [bool(p._miseg_used) for p in self.arena.params], loss

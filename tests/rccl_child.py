@@ -19,6 +19,10 @@ os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
 os.environ["MISEG_FORCE_COLLECTIVE"] = "1"
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# ProcessGroupNCCL recycles its works' events through a cache; an event that a CAPTURED collective recorded last comes back to an eager one,
+# and the watchdog thread's poll of it ("operation not permitted on an event last recorded in a capturing stream") aborts the process:
+# 1 run in 8 - 10 here with the cache, 0 in 24 without (round 4)
+os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -142,16 +146,17 @@ def main():
         def late(works):
             for lo, hi in late_ranges:
                 works.extend(arena.allreduce_begin(lo, hi))
+            ub = arena.used_begin(host=False)
             for w in works:
                 w.wait()
+            ub()
             arena._unstage()
-            Comm.captured = len(works)
+            Comm.captured = len(works) + 1
 
     cap = GraphedStep(net, x.shape, cot.shape, arena=arena, fused_comm=Comm)
     for it, m in enumerate([1, 0, 0, 1]):
-        ub = []
-        y = cap(x, [m], cot, publish=False, before=lambda: ub.append(arena.used_begin(host=False)))      # (the flags of THIS step are set by then)
-        arena.allreduce_finish(ub[0], 1)
+        y = cap(x, [m], cot, publish=False)                  # bitmap + 4 ranges: all nodes of the graph, no eager collective
+        arena.allreduce_finish(lambda: None, 1)
         torch.cuda.synchronize()
         y_ref, g_ref, none_ref = ref[m]
         assert torch.equal(y.detach(), y_ref), f"captured step, replay {it}: logits differ from the one-rank graph"
@@ -159,7 +164,7 @@ def main():
         err = float((arena.flat - g_ref).norm() / g_ref.norm())
         assert err < 1e-4, f"captured step, replay {it}: arena differs from the one-rank graph by {err:.2e}"
         assert arena.used_dev.tolist() == [int(not v) for v in none_ref]
-    assert Comm.captured == 4, Comm.captured
+    assert Comm.captured == 5, Comm.captured
     out["captured_collectives_per_step"] = Comm.captured
     arena.detach()
 

@@ -27,8 +27,8 @@ def test_rccl_exchange_one_rank():
     assert lines, tail
     out = json.loads(lines[-1].split(" ", 1)[1])
     # every collective of the N > 1 step was really launched: 4 buckets + bitmap, and bitmap + tail + head for the overlapped exchange
-    # ... and the step with the collectives recorded into its hipGraph replays what the one-rank graph computes (4 captured collectives)
-    assert out == {"allreduce_collectives": 5, "overlapped_collectives": 3, "bf16_collectives": 3, "captured_collectives_per_step": 4}, out
+    # ... and the step with the collectives recorded into its hipGraph replays what the one-rank graph computes (5 captured collectives: the bitmap and four ranges)
+    assert out == {"allreduce_collectives": 5, "overlapped_collectives": 3, "bf16_collectives": 3, "captured_collectives_per_step": 5}, out
 
 
 def test_force_collective_switch_is_off_by_default(monkeypatch):
