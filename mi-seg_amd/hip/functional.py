@@ -624,9 +624,6 @@ class _Conv3(Function):
                 if q is not None and q.branch_deferred and ops.in_branch_backward():
                     ops.stamp("branch_bwd_head", fine=True)
                     ops.flush_branch_deferred(q)
-                    ops.group_on_branch(q, "head")
-                if q is not None and ops.GROUP_AT == "mid" and x.shape[1] >= 96:
-                    ops.group_on_branch(q, "mid")
                 with ops.wgrad_side(x, dy, kind="conv"):
                     ops.conv3_wgrad(x, dy, dw=slot, accumulate=mode)
             else:

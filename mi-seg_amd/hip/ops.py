@@ -697,19 +697,6 @@ def early_group_flush(q):
     stamp("early_group_end")
 
 
-GROUP_AT = os.environ.get("MISEG_GROUP_AT", "")               # EXPERIMENT (round 4): "head" / "mid" - where in the branch's backward pass the main stream's
-GROUP_AT_WG = int(os.environ.get("MISEG_GROUP_WG", "128"))     # queued conv weight gradients go out on the branch stream, and on how many CUs
-
-
-def group_on_branch(q, where):
-    if q is None or GROUP_AT != where or not q.conv_wgrad or not in_branch_backward() or getattr(q, "_grouped_early", False):
-        return
-    q._grouped_early = True
-    stamp("early_group_begin")
-    _flush_conv_wgrads(q.conv_wgrad, background=GROUP_AT_WG, keep=True)
-    stamp("early_group_end")
-
-
 def join_branch(flush_deferred=True, queues=None, flush_main=False):
     """the current stream waits for the branch stream: before anything that consumes what the branch's backward produced (the side queue's
     launches of arena.end_backward, the optimiser, the end of a hipGraph capture).  queues: the arena's StepQueues whose
