@@ -231,6 +231,12 @@ def measure(a, rank, world, dist, dev):
                 deep = arena.param_range([p for k, p in model.named_parameters() if p.requires_grad and k.startswith(("encoder10.", "decoder5."))])
                 assert deep[0] == tail and deep[1] <= hole[0]
                 hook_deep = deep
+        elif os.environ.get("MISEG_SPLIT_EARLY", "all") == "deep":
+            # (option, two-graph step) only encoder10 + decoder5 go out between the graphs - 70 % of the bytes, conv gradients written inline by
+            # the tiny-volume kernel - so the first graph ends with the small queued launches only (GraphedStep first_flush="small")
+            hook_deep = arena.param_range([p for k, p in model.named_parameters() if p.requires_grad and k.startswith(("encoder10.", "decoder5."))])
+            assert hook_deep[0] == tail
+            model.split_defers = True      # decoder1's deferred weight gradients with the branch's backward pass, in the second graph
         elif os.environ.get("MISEG_SPLIT_DEFER", "early") == "early":
             model.split_defers = "early"          # decoder1's deferred weight gradients run on the idle branch stream inside the first half: no hole
         else:
@@ -270,7 +276,7 @@ def measure(a, rank, world, dist, dev):
             _Comm.flush = "small" if hook_deep is not None else "all"
             fused = _Comm
         graphed = GraphedStep(model, (1, 1, 96, 96, 96), (1, 6, 96, 96, 96), arena=arena, split=overlap and not (fused is not None and a.captured_mode == "hook"),
-                              fused_comm=fused)
+                              fused_comm=fused, first_flush="small" if (hook_deep is not None and fused is None) else "all")
         graphed.cot.copy_(cot)
         cot = graphed.cot          # the cotangent is constant here: it lives in the graph's static buffer (a loss kernel would write it there)
 

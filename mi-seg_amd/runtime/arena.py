@@ -278,6 +278,14 @@ class ParamArena:
         ops.join_wgrad()
         ops.WGRAD_STREAM = None
 
+    def flush_small(self):
+        """between the two halves of a split backward pass when the range that goes out early holds only layers whose conv weight gradients were
+        written where the pass reached them (encoder10 / decoder5: the tiny-volume kernel): the queued GEMM weight gradients, partial sums and
+        column sums complete its other parameters; the grouped conv weight gradients keep waiting for the end of the pass"""
+        ops.join_branch(flush_deferred=False, queues=None, flush_main=False)      # (a capture must not end with the branch stream unjoined)
+        if self.queues is not None:
+            self.queues.flush_small()
+
     def flush(self):
         """issue everything queued so far and keep queueing (between the two halves of a split backward pass)."""
         # (weight gradients deferred to the branch's backward pass wait for the second half unless the model already issued them:

@@ -94,7 +94,8 @@ class GraphedForward:
 
 
 class GraphedStep:
-    def __init__(self, model: torch.nn.Module, batch_shape: Sequence[int], out_shape: Sequence[int], warmup: int = 2, arena=None, split=False, fused_comm=None):
+    def __init__(self, model: torch.nn.Module, batch_shape: Sequence[int], out_shape: Sequence[int], warmup: int = 2, arena=None, split=False, fused_comm=None,
+                 first_flush="all"):
         """arena: optional runtime.arena.ParamArena of the model (gradients accumulate in its flat buffer, parameter
         re-layouts are refreshed by one kernel per step); without it every gradient is a tensor of the graph's pool.
         Capture needs a quiescent model: drop every reference to outputs of earlier eager steps first - a live autograd graph keeps its
@@ -115,6 +116,7 @@ class GraphedStep:
         self.arena = arena
         self.split = bool(split)
         self.fused_comm = fused_comm
+        self.first_flush = first_flush          # split step: "all" queued launches at the end of the first half, or "small" (arena.flush_small)
         if self.split and arena is None:
             raise ValueError("a split step needs a ParamArena")
         if fused_comm is not None and arena is None:
@@ -174,7 +176,10 @@ class GraphedStep:
         ops.stamp("forward_end")
         y.backward(self.cot)
         ops.stamp("first_half_chain_end")
-        self.arena.flush()
+        if self.first_flush == "small":
+            self.arena.flush_small()
+        else:
+            self.arena.flush()
         ops.stamp("first_half_end")
         return y, cut
 
