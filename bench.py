@@ -469,7 +469,8 @@ def measure(a, rank, world, dist, dev):
     if rank == 0:
         if not a.no_roofline:
             from mi_seg_amd.testing.roofline import profile_step, summarize
-            out["roofline"] = summarize(profile_step(lambda: step(a.warmup + a.steps, eager=True, comm=False)), dtype)      # rank 0 alone: no collectives
+            out["roofline"] = summarize(profile_step(lambda: step(a.warmup + a.steps, eager=True, comm=False)), dtype,
+                                        counters=(a.workload == "c2" and a.dtype == "bf16"))      # rank 0 alone: no collectives
         if world == 1 and not a.no_cpu_baseline:
             from mi_seg_amd.testing.cpu_baseline import cpu_baseline
             out["cpu_baseline"] = cpu_baseline(a.workload)
@@ -574,7 +575,7 @@ def bench_sliding_window(a, model, dtype, dev, rank, world, dist):
             def one_batch():
                 with torch.no_grad():
                     model(xw, [0] * sw)
-            out["roofline"] = summarize(profile_step(one_batch), dtype)
+            out["roofline"] = summarize(profile_step(one_batch), dtype, counters=False)
     arena.detach()
     return out
 

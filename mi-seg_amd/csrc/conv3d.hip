@@ -190,9 +190,14 @@ __global__ void __launch_bounds__(256) conv3_fwd_kernel(const T* __restrict__ x,
 // combo = 4 phase + q -> (kdw, cg) with per-lane divisions every phase, ~100 VALU cycles of address arithmetic per phase beside 576 of
 // MFMA - and the weight pack is stored in exactly this order, [chunk][phase][kh * 4 + q][CoutP16][16 B], so a phase's 12 groups are one
 // linear run: uniform base + lane constant (the [tap][group] pack cost three 64-bit multiply-add chains per thread and phase).
-__host__ __device__ constexpr int fwd96_phase_of(int kdw, int cg) { return cg < 4 ? kdw : 9 + (kdw >> 1); }
-__host__ __device__ constexpr int fwd96_slot_of(int kdw, int cg) { return cg < 4 ? cg : ((kdw & 1) << 1) + (cg - 4); }
-static constexpr int FWD96_PHASES = 14, FWD96_GROUPS = 12;
+// Narrow rows (round 4).  A chunk need not be 6 groups wide: the two halves of the table above stand on their own -
+//   GPT = 4 (64-byte chunks: 32 / 64 / 128 / 256 bf16 channels): phases 0..8 only, 9 phases, no dummy slot;
+//   GPT = 2 (32-byte rows: 16 bf16 channels): the "groups 4, 5" half with groups 0, 1: phase = kdw >> 1, 5 phases (kdw == 9: zero dummy).
+// Until then such rows were padded to 96 bytes (14 phases, a third to two thirds of the MFMAs multiplying zeros) or went to the generic kernel.
+__host__ __device__ constexpr int fwd96_phases(int gpt) { return gpt == 6 ? 14 : gpt == 4 ? 9 : 5; }
+__host__ __device__ constexpr int fwd96_phase_of(int gpt, int kdw, int cg) { return gpt == 2 ? (kdw >> 1) : (cg < 4 ? kdw : 9 + (kdw >> 1)); }
+__host__ __device__ constexpr int fwd96_slot_of(int gpt, int kdw, int cg) { return gpt == 2 ? ((kdw & 1) << 1) + cg : (cg < 4 ? cg : ((kdw & 1) << 1) + (cg - 4)); }
+static constexpr int FWD96_GROUPS = 12;
 
 static constexpr int FBD = 4, FBH = 4, FBW = 16;
 static constexpr int FHH = FBH + 2, FHW = FBW + 2;
@@ -202,19 +207,20 @@ static constexpr int FPS = 656;                            // plane stride in ro
 // WD = how many phases ahead the weights are requested (3: a phase's 36 MFMAs per wave last ~0.3 us, an L2 round trip under load ~1 us;
 // measured on 48->48 @ 96^3, same box: WD 1 / 2 / 3 = 135 / 128 / 123 us once the loads were branch-free - see wload below)
 // EPI: the optional epilogue pieces (residual add, norm statistics) are compiled in; the plain instantiation carries none of it
-template <class T, int NT, int WD = 1, bool EPI = false>
-__global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, const T* __restrict__ wpk,
+template <class T, int NT, int WD = 1, bool EPI = false, int GPT = 6>
+// (workgroups per CU the LDS images leave room for: 6 groups 81 KB -> 2; 4 groups 48 / 54 / 60 KB -> 3 / 2 / 2; 2 groups 27 / 33 / 39 KB -> 4 / 3 / 3 asked for)
+__global__ void __launch_bounds__(256, GPT == 6 ? 2 : GPT == 4 ? (NT == 1 ? 3 : 2) : (NT == 1 ? 4 : 3)) conv3_fwd96_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, const T* __restrict__ wpk,
                                                              ConvGeom g, int Cin, int CinP, int Cout, int CoP, bool vec_x, bool vec_y,
                                                              float* __restrict__ scratch, int chunks_per_split, const T* __restrict__ res, int64_t ldres,
                                                              double* __restrict__ stat, int ny) {
   typedef typename Vec16<T>::type VT;
   constexpr int KPC = MmaC<T>::KPC;
-  constexpr int GPT = 6, CHUNK = GPT * KPC;
+  constexpr int CHUNK = GPT * KPC, NPH = fwd96_phases(GPT);
   constexpr int NROWS = 16 * NT;
   constexpr int WITEMS = 12 * NROWS;                       // 16-byte items of one weight phase
   constexpr int WLOADS = (WITEMS + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  char* lh = lds;                                          // [6][FPS][16]
+  char* lh = lds;                                          // [GPT][FPS][16]
   char* lw = lds + GPT * FPS * 16;                         // 2 x [12][NROWS][16] (double buffer)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // workgroup -> brick.  The hardware deals consecutive workgroups to the 8 XCDs round-robin, each with its own L2: with bid = blockIdx.x
@@ -270,7 +276,7 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
   }
   const int64_t wphase_stride = (int64_t)FWD96_GROUPS * CoP * KPC;
   auto wload = [&](int phase, int chunk, int slot) {
-    const T* wph = wpk + ((int64_t)chunk * FWD96_PHASES + phase) * wphase_stride;      // uniform
+    const T* wph = wpk + ((int64_t)chunk * NPH + phase) * wphase_stride;      // uniform
 #pragma unroll
     for (int i = 0; i < WLOADS; ++i) wreg[slot][i] = *reinterpret_cast<const VT*>(wph + wl[i]);     // unconditional (surplus lanes re-read item 0)
   };
@@ -281,7 +287,7 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
   };
   // halo addresses of this lane: plane = channel group of its k-slot (see the phase table above), row of (d = wave, h = 0, w = fi)
   const int laneA = (fq * FPS + (wave * FHH) * FHW + fi) * 16;
-  const int laneB = ((4 + (fq & 1)) * FPS + (wave * FHH) * FHW + fi) * 16;
+  const int laneB = (((GPT == 6 ? 4 : 0) + (fq & 1)) * FPS + (wave * FHH) * FHW + fi) * 16;
   const bool hiB = (fq >> 1) != 0;
   const int wfrag = fi * 16;
 
@@ -302,20 +308,21 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
     // while 48 consecutive lanes read 8 voxels x 96 contiguous bytes from HBM; all 16 loads of a lane are issued before
     // the first LDS write (row -> global offset comes from the table built once per workgroup)
     {
-      constexpr int NIT = (FHROWS * GPT + 255) / 256;      // 16
+      constexpr int NIT = (FHROWS * GPT + 255) / 256;      // 16 (6 groups), 11, 6
+      constexpr int IPB = 8 * GPT;                         // items of a block of 8 rows
       VT hv[NIT];
       int ro[NIT];
 #pragma unroll
       for (int i = 0; i < NIT; ++i) {                      // the 16 table reads first (in-kernel timestamps: with the read inside the
         const int idx = tid + 256 * i;                     // load loop every load waited for its own LDS round trip, 4300 cycles)
-        const int blk = idx / 48, j = idx - blk * 48;
+        const int blk = idx / IPB, j = idx - blk * IPB;
         ro[i] = idx < FHROWS * GPT ? rowoff[blk * 8 + (j & 7)] : -1;
       }
       if (vec_x && c0 + CHUNK <= Cin) {                    // whole chunk present and 16-byte aligned: branch-free vector loads
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
           const int idx = tid + 256 * i;
-          const int j = idx % 48;
+          const int j = idx % IPB;
           VT v;
 #pragma unroll
           for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(0.f);
@@ -326,7 +333,7 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
           const int idx = tid + 256 * i;
-          const int j = idx % 48;
+          const int j = idx % IPB;
           VT v;
 #pragma unroll
           for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(0.f);
@@ -346,19 +353,20 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
 #pragma unroll
       for (int i = 0; i < NIT; ++i) {
         const int idx = tid + 256 * i;
-        const int blk = idx / 48, j = idx - blk * 48;
+        const int blk = idx / IPB, j = idx - blk * IPB;
         if (idx < FHROWS * GPT) *reinterpret_cast<VT*>(lh + ((j >> 3) * FPS + blk * 8 + (j & 7)) * 16) = hv[i];
       }
     }
     wstore(0, 0);
     __syncthreads();
     auto run_phase = [&](int phase, int slot_load, int slot_store) {      // `phase` is a compile-time constant after unrolling
-      if (phase + WD < FWD96_PHASES) wload(phase + WD, c0 / CHUNK, slot_load);
+      if (phase + WD < NPH) wload(phase + WD, c0 / CHUNK, slot_load);
       const char* abase;
-      if (phase < 9) {
+      if (GPT == 4 || (GPT == 6 && phase < 9)) {
         abase = lh + laneA + (((phase / 3) * FHH) * FHW + phase % 3) * 16;
       } else {
-        const int k0 = 2 * (phase - 9), k1 = k0 + 1 > 8 ? 8 : k0 + 1;       // (kdw == 9: the dummy slots read a valid row against zero weights)
+        const int pb = GPT == 6 ? phase - 9 : phase;
+        const int k0 = 2 * pb, k1 = k0 + 1 > 8 ? 8 : k0 + 1;       // (kdw == 9: the dummy slots read a valid row against zero weights)
         const int d0 = (((k0 / 3) * FHH) * FHW + k0 % 3) * 16, d1 = (((k1 / 3) * FHH) * FHW + k1 % 3) * 16;
         abase = lh + laneB + (hiB ? d1 : d0);
       }
@@ -413,13 +421,13 @@ __global__ void __launch_bounds__(256, 2) conv3_fwd96_kernel(const T* __restrict
             for (int nt = 0; nt < NT; ++nt) MmaC<T>::run(acc[mt][nt], bfr[kh & 1][nt], af[mt + kh]);
         }
       }
-      if (phase + 1 < FWD96_PHASES) {
+      if (phase + 1 < NPH) {
         wstore((phase + 1) & 1, slot_store);     // buffer last read in phase - 1: every wave is past that phase's barrier
         __syncthreads();
       }
     };
 #pragma unroll
-    for (int phase = 0; phase < FWD96_PHASES; ++phase) run_phase(phase, phase % WD, (phase + 1) % WD);   // phase, ring slots: compile-time
+    for (int phase = 0; phase < NPH; ++phase) run_phase(phase, phase % WD, (phase + 1) % WD);   // phase, ring slots: compile-time
     __syncthreads();                 // halo + weight buffers are free for the next chunk
   }
   // epilogue: lane holds channels n0 + 16nt + 4fq .. +3 of voxel (d0 + wave, h0 + mt, w0 + fi)
@@ -533,48 +541,65 @@ static constexpr int PK_LD = PK_T * 27 + 1;      // floats per co row of the LDS
 // the fused residual / statistics epilogue although a third to a half of their MFMA work multiplies zeros (C-UNETR patches/s with the
 // threshold at 0 / 256 / 128 / 64 / 32 bytes: 146.2 / 155.2 / 161.0 / 165.7 / 163.4 - 16 channels padded to 48 no longer pay).  ONE predicate for the pack, the launch, the
 // workspace size and the host side (miseg_conv3_k96).
-__host__ __device__ inline int conv3_k96(int C, int esz, int pad_min_bytes) {
-  const int kpc = 16 / esz, cp = (C + kpc - 1) / kpc * kpc, per = 96 / esz;
+// Round 4: rows of 4 k groups (64 bytes: 32, 64, 128, 256 bf16 channels) and of 2 groups (16 bf16 channels) are walked in chunks of their own
+// width (fwd96_phases: 9 / 5 phases per chunk, nothing padded); `pad_min_bytes` carries the switch in bit 20 (CONV3_NARROW; MISEG_CONV3_NARROW=0
+// restores the padding).  conv3_gpt: groups per chunk of the K extent conv3_k96 returns (6 when padded).
+static constexpr int CONV3_NARROW = 1 << 20;
+__host__ __device__ inline int conv3_gpt(int C, int esz, int plan) {
+  const int kpc = 16 / esz, g = (C + kpc - 1) / kpc;
+  if (g % 6 == 0 || !(plan & CONV3_NARROW)) return 6;
+  if (g % 4 == 0) return 4;
+  if (g == 2) return 2;
+  return 6;
+}
+__host__ __device__ inline int conv3_k96(int C, int esz, int plan) {
+  const int kpc = 16 / esz, cp = (C + kpc - 1) / kpc * kpc, per = 96 / esz, pad_min_bytes = plan & (CONV3_NARROW - 1);
   if ((cp * esz) % 96 == 0) return cp;
+  if (conv3_gpt(C, esz, plan) != 6) return cp;
   if (pad_min_bytes > 0 && cp * esz >= pad_min_bytes) return (C + per - 1) / per * per;
   return 0;
 }
 
-static int conv3_pad_min_bytes() {      // MISEG_CONV3_PAD_MIN (bytes of a channel row; 0 = never pad), read once
+static int conv3_pad_min_bytes() {      // MISEG_CONV3_PAD_MIN (bytes of a channel row; 0 = never pad) | CONV3_NARROW (MISEG_CONV3_NARROW), read once
   static const int v = [] {
     const char* e = getenv("MISEG_CONV3_PAD_MIN");
-    return e ? atoi(e) : 64;
+    const char* n = getenv("MISEG_CONV3_NARROW");
+    return (e ? (atoi(e) & (CONV3_NARROW - 1)) : 64) | ((n && atoi(n) == 0) ? 0 : CONV3_NARROW);
   }();
   return v;
 }
 
 // element offset of the 16-byte group (tap, K-side channel group kg, N-side row) in the phase-ordered pack of the fast path
-// [chunk = kg / 6][phase][kh * 4 + slot][N16][KPC]
-__device__ __forceinline__ int64_t fwd96_pack_offset(int tap, int kg, int row, int N16, int KPC) {
-  const int chunk = kg / 6, cg = kg - chunk * 6;
+// [chunk = kg / gpt][phase][kh * 4 + slot][N16][KPC]
+__device__ __forceinline__ int64_t fwd96_pack_offset(int gpt, int tap, int kg, int row, int N16, int KPC) {
+  const int chunk = kg / gpt, cg = kg - chunk * gpt;
   const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3, kdw = kd * 3 + kw;
-  const int phase = fwd96_phase_of(kdw, cg), slot = fwd96_slot_of(kdw, cg);
-  return ((((int64_t)chunk * FWD96_PHASES + phase) * FWD96_GROUPS + kh * 4 + slot) * N16 + row) * KPC;
+  const int phase = fwd96_phase_of(gpt, kdw, cg), slot = fwd96_slot_of(gpt, kdw, cg);
+  return ((((int64_t)chunk * fwd96_phases(gpt) + phase) * FWD96_GROUPS + kh * 4 + slot) * N16 + row) * KPC;
 }
 
-// the two k-slots of phase 13 that no (tap, group) maps to must read as zero: written by the tile that opens a chunk, for its 16 rows
+// the two k-slots of the last phase that no (tap, group) maps to (6 and 2 groups per chunk) must read as zero: written by the tile that opens
+// a chunk, for its 16 rows
 template <class T>
-__device__ __forceinline__ void fwd96_pack_dummies(T* pack, int chunk, int row0, int N16) {
+__device__ __forceinline__ void fwd96_pack_dummies(int gpt, T* pack, int chunk, int row0, int N16) {
   typedef typename Vec16<T>::type VT;
   constexpr int KPC = Vec16<T>::N;
+  if (gpt == 4) return;
+  const int nph = fwd96_phases(gpt);
   VT z;
 #pragma unroll
   for (int e = 0; e < KPC; ++e) z[e] = from_f32<T>(0.f);
   for (int i = threadIdx.x; i < 3 * 2 * PK_T; i += 256) {
     const int r = i % PK_T, sl = 2 + (i / PK_T) % 2, kh = i / (2 * PK_T);
     if (row0 + r < N16)
-      *reinterpret_cast<VT*>(pack + ((((int64_t)chunk * FWD96_PHASES + 13) * FWD96_GROUPS + kh * 4 + sl) * N16 + row0 + r) * KPC) = z;
+      *reinterpret_cast<VT*>(pack + ((((int64_t)chunk * nph + nph - 1) * FWD96_GROUPS + kh * 4 + sl) * N16 + row0 + r) * KPC) = z;
   }
 }
 
 template <class T>
 __device__ __forceinline__ void pack_conv3_tile(const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ bwd, int Cin, int Cout, int CinP, int CoutP,
-                                                int Cin16, int Cout16, bool fwd_planar, bool bwd_planar, int bx, int by) {
+                                                int Cin16, int Cout16, int fwd_gpt, int bwd_gpt, int bx, int by) {
+  const bool fwd_planar = fwd_gpt != 0, bwd_planar = bwd_gpt != 0;      // groups per chunk of the planar pack's K side, 0 = row-major pack
   typedef typename Vec16<T>::type VT;
   constexpr int KPC = Vec16<T>::N, NG = PK_T / KPC;
   __shared__ float tile[PK_T * PK_LD];
@@ -619,11 +644,12 @@ __device__ __forceinline__ void pack_conv3_tile(const float* __restrict__ w, T* 
       VT v;
 #pragma unroll
       for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(tile[co * PK_LD + (cg * KPC + e) * 27 + tap]);
-      const int64_t off = fwd_planar ? fwd96_pack_offset(tap, cib / KPC, co0 + co, Cout16, KPC) : ((int64_t)(co0 + co) * 27 + tap) * CinP + cib;
+      const int64_t off = fwd_planar ? fwd96_pack_offset(fwd_gpt, tap, cib / KPC, co0 + co, Cout16, KPC) : ((int64_t)(co0 + co) * 27 + tap) * CinP + cib;
       *reinterpret_cast<VT*>(fwd + off) = v;
     }
     if (fwd_planar)      // every chunk that starts inside this tile's K range
-      for (int ch = (ci0 + 6 * KPC - 1) / (6 * KPC); ch * 6 * KPC < ci0 + PK_T && ch * 6 * KPC < CinP; ++ch) fwd96_pack_dummies<T>(fwd, ch, co0, Cout16);
+      for (int ch = (ci0 + fwd_gpt * KPC - 1) / (fwd_gpt * KPC); ch * fwd_gpt * KPC < ci0 + PK_T && ch * fwd_gpt * KPC < CinP; ++ch)
+        fwd96_pack_dummies<T>(fwd_gpt, fwd, ch, co0, Cout16);
   }
   if (bwd) {   // K side = co, taps mirrored: vector = KPC consecutive co of (ci, tap)
 #pragma unroll 1
@@ -636,18 +662,19 @@ __device__ __forceinline__ void pack_conv3_tile(const float* __restrict__ w, T* 
       VT v;
 #pragma unroll
       for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(tile[(cg * KPC + e) * PK_LD + ci * 27 + (26 - tap)]);
-      const int64_t off = bwd_planar ? fwd96_pack_offset(tap, cob / KPC, ci0 + ci, Cin16, KPC) : ((int64_t)(ci0 + ci) * 27 + tap) * CoutP + cob;
+      const int64_t off = bwd_planar ? fwd96_pack_offset(bwd_gpt, tap, cob / KPC, ci0 + ci, Cin16, KPC) : ((int64_t)(ci0 + ci) * 27 + tap) * CoutP + cob;
       *reinterpret_cast<VT*>(bwd + off) = v;
     }
     if (bwd_planar)
-      for (int ch = (co0 + 6 * KPC - 1) / (6 * KPC); ch * 6 * KPC < co0 + PK_T && ch * 6 * KPC < CoutP; ++ch) fwd96_pack_dummies<T>(bwd, ch, ci0, Cin16);
+      for (int ch = (co0 + bwd_gpt * KPC - 1) / (bwd_gpt * KPC); ch * bwd_gpt * KPC < co0 + PK_T && ch * bwd_gpt * KPC < CoutP; ++ch)
+        fwd96_pack_dummies<T>(bwd_gpt, bwd, ch, ci0, Cin16);
   }
 }
 
 template <class T>
 __global__ void __launch_bounds__(256) pack_conv3_kernel(const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ bwd, int Cin, int Cout, int CinP, int CoutP,
-                                                         int Cin16, int Cout16, bool fwd_planar, bool bwd_planar) {
-  pack_conv3_tile<T>(w, fwd, bwd, Cin, Cout, CinP, CoutP, Cin16, Cout16, fwd_planar, bwd_planar, blockIdx.x, blockIdx.y);
+                                                         int Cin16, int Cout16, int fwd_gpt, int bwd_gpt) {
+  pack_conv3_tile<T>(w, fwd, bwd, Cin, Cout, CinP, CoutP, Cin16, Cout16, fwd_gpt, bwd_gpt, blockIdx.x, blockIdx.y);
 }
 
 // (round 4: four workgroups per CU - the kernel is a latency chain per tile (search, load, two LDS passes, stores) and 230 VGPRs left room for
@@ -677,7 +704,7 @@ __global__ void __launch_bounds__(256) pack_conv3_batch_kernel(const miseg_pack_
     const int CinP = kf ? kf : (d.Cin + KPC - 1) / KPC * KPC, CoutP = kb ? kb : (d.Cout + KPC - 1) / KPC * KPC;
     __syncthreads();      // pack_conv3_tile's LDS tile of the previous iteration has been read
     pack_conv3_tile<T>(d.w, (T*)d.fwd_pack, (T*)d.bwd_pack, d.Cin, d.Cout, CinP, CoutP, (d.Cin + 15) / 16 * 16, (d.Cout + 15) / 16 * 16,
-                       kf != 0, kb != 0, t % tci, t / tci);
+                       kf ? conv3_gpt(d.Cin, (int)sizeof(T), pad_min) : 0, kb ? conv3_gpt(d.Cout, (int)sizeof(T), pad_min) : 0, t % tci, t / tci);
   }
   refresh_done(params_version, state, pv);
 }
@@ -1612,7 +1639,7 @@ extern "C" size_t miseg_conv3_fwd_workspace_bytes(int B, int D, int H, int W, in
   const int rowbytes = conv3_k96(Cin, esz, conv3_pad_min_bytes()) * esz;
   if (!rowbytes) return 0;
   int nt, ks;
-  fwd96_plan(B * cdiv(D, FBD) * cdiv(H, FBH) * cdiv(W, FBW), Cout, rowbytes / 96, &nt, &ks);
+  fwd96_plan(B * cdiv(D, FBD) * cdiv(H, FBH) * cdiv(W, FBW), Cout, rowbytes / (16 * conv3_gpt(Cin, esz, conv3_pad_min_bytes())), &nt, &ks);
   return ks > 1 ? (size_t)ks * B * D * H * W * Cout * sizeof(float) : 0;
 }
 
@@ -1621,7 +1648,7 @@ extern "C" int miseg_conv3_fwd_splits(int B, int D, int H, int W, int Cin, int C
   const int rowbytes = conv3_k96(Cin, esz, conv3_pad_min_bytes()) * esz;
   if (!rowbytes) return 1;
   int nt, ks;
-  const int nchunks = rowbytes / 96;
+  const int nchunks = rowbytes / (16 * conv3_gpt(Cin, esz, conv3_pad_min_bytes()));
   fwd96_plan(B * cdiv(D, FBD) * cdiv(H, FBH) * cdiv(W, FBW), Cout, nchunks, &nt, &ks);
   const int cps = cdiv(nchunks, ks);
   return cdiv(nchunks, cps);
@@ -1642,33 +1669,35 @@ static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
     ConvGeom gf{p->B, p->D, p->H, p->W, cdiv(p->D, FBD), cdiv(p->H, FBH), cdiv(p->W, FBW)};
     const int nbr = gf.B * gf.nbd * gf.nbh * gf.nbw;
     int nt, ksplit;
-    const int nchunks = rowbytes / 96;
+    const int gpt = conv3_gpt(p->Cin, (int)sizeof(T), conv3_pad_min_bytes());
+    const int nchunks = rowbytes / (16 * gpt);
     fwd96_plan(nbr, p->Cout, nchunks, &nt, &ksplit);
     const int cps = cdiv(nchunks, ksplit);
     ksplit = cdiv(nchunks, cps);
     float* scratch = nullptr;
-    const int64_t nvox = (int64_t)p->B * p->D * p->H * p->W;
     if (ksplit > 1) {
       MISEG_REQUIRE(p->workspace, MISEG_E_BADARG, "conv3_fwd: workspace required (miseg_conv3_fwd_workspace_bytes)");
       scratch = (float*)p->workspace;
     }
     const bool vec_y = ((uintptr_t)p->y % 16 == 0) && (p->ldy % KPC == 0);
     const int CoP = round_up(p->Cout, 16);
-    size_t lds = (size_t)6 * FPS * 16 + (size_t)2 * 12 * 16 * nt * 16;
+    size_t lds = (size_t)gpt * FPS * 16 + (size_t)2 * 12 * 16 * nt * 16;
     if (p->background && lds < 83 * 1024) lds = 83 * 1024;      // more than half of the 160 KB: one workgroup per CU
     MISEG_REQUIRE((int64_t)p->B * p->D * p->H * p->W < (1LL << 31), MISEG_E_UNSUPPORTED, "conv3_fwd: more than 2^31 voxels");
     const int ny = cdiv(p->Cout, 16 * nt);
     dim3 grid(nbr * ny, 1, ksplit);
-#define F96_LAUNCH(n, wd, epi)                                                                                                               \
-    (void)hipFuncSetAttribute((const void*)conv3_fwd96_kernel<T, n, wd, epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-    conv3_fwd96_kernel<T, n, wd, epi><<<grid, 256, lds, s>>>((const T*)p->x, p->ldx, (T*)p->y, p->ldy, (const T*)p->wpk, gf, p->Cin, CinP,    \
-                                                             p->Cout, CoP, vec_x, vec_y, scratch, cps, scratch ? nullptr : (const T*)p->res,   \
-                                                             p->ldres, (double*)p->stat, ny)
-#define F96_CASE(n, wd)                                                                                                                      \
+#define F96_LAUNCH(n, wd, epi, gp)                                                                                                           \
+    (void)hipFuncSetAttribute((const void*)conv3_fwd96_kernel<T, n, wd, epi, gp>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+    conv3_fwd96_kernel<T, n, wd, epi, gp><<<grid, 256, lds, s>>>((const T*)p->x, p->ldx, (T*)p->y, p->ldy, (const T*)p->wpk, gf, p->Cin, CinP, \
+                                                                 p->Cout, CoP, vec_x, vec_y, scratch, cps, scratch ? nullptr : (const T*)p->res, \
+                                                                 p->ldres, (double*)p->stat, ny)
+#define F96_CASE(n, wd, gp)                                                                                                                  \
   case n:                                                                                                                                   \
-    if (!scratch && (p->res || p->stat)) { F96_LAUNCH(n, wd, true); } else { F96_LAUNCH(n, wd, false); }                                    \
+    if (!scratch && (p->res || p->stat)) { F96_LAUNCH(n, wd, true, gp); } else { F96_LAUNCH(n, wd, false, gp); }                            \
     break;
-    switch (nt) { F96_CASE(1, 3) F96_CASE(2, 2) F96_CASE(3, 3) }
+    if (gpt == 6) { switch (nt) { F96_CASE(1, 3, 6) F96_CASE(2, 2, 6) F96_CASE(3, 3, 6) } }
+    else if (gpt == 4) { switch (nt) { F96_CASE(1, 3, 4) F96_CASE(2, 2, 4) F96_CASE(3, 3, 4) } }
+    else { switch (nt) { F96_CASE(1, 3, 2) F96_CASE(2, 2, 2) F96_CASE(3, 3, 2) } }
 #undef F96_CASE
 #undef F96_LAUNCH
     MISEG_LAUNCH_CHECK("conv3_fwd96");
@@ -1733,12 +1762,12 @@ extern "C" int miseg_pack_conv3_weight(const miseg_pack_conv3_params* p, miseg_s
     constexpr int KPC = Vec16<T>::N;
     const int kf = conv3_k96(p->Cin, (int)sizeof(T), conv3_pad_min_bytes()), kb = conv3_k96(p->Cout, (int)sizeof(T), conv3_pad_min_bytes());
     const int CinP = kf ? kf : round_up(p->Cin, KPC), CoutP = kb ? kb : round_up(p->Cout, KPC);
-    const bool fplanar = kf != 0, bplanar = kb != 0;
+    const int fgpt = kf ? conv3_gpt(p->Cin, (int)sizeof(T), conv3_pad_min_bytes()) : 0, bgpt = kb ? conv3_gpt(p->Cout, (int)sizeof(T), conv3_pad_min_bytes()) : 0;
     MISEG_REQUIRE((!p->fwd_pack || (uintptr_t)p->fwd_pack % 16 == 0) && (!p->bwd_pack || (uintptr_t)p->bwd_pack % 16 == 0), MISEG_E_BADARG,
                   "pack_conv3_weight: packs must be 16-byte aligned");
     dim3 grid(cdiv(kf > p->Cin ? kf : p->Cin, PK_T), cdiv(kb > p->Cout ? kb : p->Cout, PK_T));     // the padded K groups get their (zero) tiles
     pack_conv3_kernel<T><<<grid, 256, 0, s>>>(p->w, (T*)p->fwd_pack, (T*)p->bwd_pack, p->Cin, p->Cout, CinP, CoutP, round_up(p->Cin, 16), round_up(p->Cout, 16),
-                                              fplanar, bplanar);
+                                              fgpt, bgpt);
     MISEG_LAUNCH_CHECK("pack_conv3_weight");
     return MISEG_OK;
   });

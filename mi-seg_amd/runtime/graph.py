@@ -116,6 +116,7 @@ class GraphedStep:
         self.arena = arena
         self.split = bool(split)
         self.fused_comm = fused_comm
+        self._warming = False
         self.first_flush = first_flush          # split step: "all" queued launches at the end of the first half, or "small" (arena.flush_small)
         if self.split and arena is None:
             raise ValueError("a split step needs a ParamArena")
@@ -151,7 +152,8 @@ class GraphedStep:
                     self.arena.queues.flush_small()
                 else:
                     self.arena.queues.flush(side=False)
-                works.extend(self.fused_comm.early())
+                if not self._warming:          # (the warm-up runs issue no collective: __init__)
+                    works.extend(self.fused_comm.early())
             y = self.model(self.x, (self.styles, host), on_decoder_done=early)
         else:
             y = self.model(self.x, (self.styles, host))
@@ -161,7 +163,7 @@ class GraphedStep:
             self.arena.end_backward()
         else:
             ops.join_branch()          # a capture must not end with a model's side branch unjoined
-        if self.fused_comm is not None:
+        if self.fused_comm is not None and not self._warming:
             self.fused_comm.late(works)
         ops.stamp("step_end")
         return y

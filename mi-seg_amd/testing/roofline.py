@@ -99,7 +99,9 @@ def classes(prof, dtype):
     return sorted(out, key=lambda d: -d["ms"])
 
 
-def summarize(prof, dtype):
+def summarize(prof, dtype, counters=True):
+    """counters: the committed PMC file (profiles/*_pmc_traffic.json) was collected over THIS workload (bench.py's default: configs[1], bf16,
+    training step); any other workload reports `traffic: null` rather than another workload's bytes"""
     # the dominant kernel of every workload so far: the 3x3x3 implicit GEMM.  All its launches of the step, the side branch's throttled
     # ("background") ones included - one kernel symbol, what the rocprofv3 average of the same command covers; the other classes: `classes`
     groups = {}
@@ -113,7 +115,7 @@ def summarize(prof, dtype):
     flops = sum(t[1] for t in lst)
     achieved = flops / (tot_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[dtype]
-    traffic, src = _pmc_traffic(name)
+    traffic, src = _pmc_traffic(name) if counters else (None, None)
     alg_bytes = sum(t[2] for t in lst) / len(lst)
     avg_s = tot_ms * 1e-3 / len(lst)
     # the 3x3x3 conv is reported against BOTH roofs - the matrix-core roof that bounds it (frac) and the HBM roof north_star

@@ -11,6 +11,7 @@ Prints RCCL_ONE_RANK_OK and a JSON summary on success; any failed check raises."
 import json
 import os
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -26,6 +27,10 @@ os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
+
+
+def stage(name):
+    print("STAGE " + name, flush=True)
 
 
 def main():
@@ -62,6 +67,7 @@ def main():
                 assert p.grad is None, "a parameter unused on every rank keeps grad None"
 
     # ---- fp32 buckets -----------------------------------------------------------------------------------------------------------------
+    stage("fp32 buckets")
     arena = ParamArena(params, torch.bfloat16)
     assert arena.force_collective
     local, flags = local_step(arena, 0)
@@ -100,6 +106,7 @@ def main():
     arena.detach()
 
     # ---- bf16 buckets (bench.py --grad-dtype bf16): rounded into the staging buffer, averaged there, written back ------------------------
+    stage("bf16 buckets")
     arena16 = ParamArena(params, torch.bfloat16, grad_dtype=torch.bfloat16)
     local, flags = local_step(arena16, 1)
     n0 = arena16.collectives_launched
@@ -121,6 +128,9 @@ def main():
 
     # ---- the data-parallel step with its collectives recorded INTO the step's hipGraph (bench.py --captured-collective, hook mode) ---------
     from mi_seg_amd.runtime.graph import GraphedStep
+    torch.cuda.synchronize()
+    time.sleep(0.3)          # ProcessGroupNCCL's watchdog (100 ms poll) reaps the eager works above before the first capture starts
+    stage("one-rank graph")
     arena = ParamArena(params, torch.bfloat16)
     single = GraphedStep(net, x.shape, cot.shape, arena=arena)
     ref = {}
@@ -153,8 +163,10 @@ def main():
             arena._unstage()
             Comm.captured = len(works) + 1
 
+    stage("captured step: warm-up + first capture")
     cap = GraphedStep(net, x.shape, cot.shape, arena=arena, fused_comm=Comm)
     for it, m in enumerate([1, 0, 0, 1]):
+        stage(f"captured step: replay {it}")
         y = cap(x, [m], cot, publish=False)                  # bitmap + 4 ranges: all nodes of the graph, no eager collective
         arena.allreduce_finish(lambda: None, 1)
         torch.cuda.synchronize()
@@ -168,7 +180,6 @@ def main():
     out["captured_collectives_per_step"] = Comm.captured
     arena.detach()
 
-    dist.barrier()
     dist.destroy_process_group()
     print("RCCL_ONE_RANK_OK " + json.dumps(out), flush=True)
 

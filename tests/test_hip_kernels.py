@@ -457,7 +457,9 @@ def test_conv3_fwd_dgrad_wgrad(dtype, B, D, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,D,H,W,Cin,Cout", [(2, 8, 8, 16, 48, 48), (1, 5, 9, 11, 96, 24), (1, 12, 8, 20, 48, 96)])
+@pytest.mark.parametrize("B,D,H,W,Cin,Cout", [(2, 8, 8, 16, 48, 48), (1, 5, 9, 11, 96, 24), (1, 12, 8, 20, 48, 96),
+                                             # chunks of 4 and of 2 k groups (64- / 32-byte rows, round 4): no padding to 96 bytes
+                                             (1, 8, 8, 16, 32, 32), (2, 5, 9, 11, 16, 16), (1, 8, 12, 16, 64, 32), (1, 9, 8, 17, 16, 48)])
 def test_conv3_fused_residual_and_statistics(dtype, B, D, H, W, Cin, Cout):
     """epilogue pieces of the 96-byte-chunk path: out = conv(x) + res, and the instance-norm statistics of the ROUNDED output
     (what miseg_instnorm_stats computes from the stored tensor) accumulated into the zeroed fp64 buffer."""
@@ -483,7 +485,8 @@ def test_conv3_fused_residual_and_statistics(dtype, B, D, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,D,H,W,Cin,Cout,with_res", [(1, 12, 12, 12, 192, 192, True), (2, 6, 6, 6, 96, 48, False), (1, 3, 3, 3, 768, 768, True), (2, 5, 7, 6, 96, 96, True)])
+@pytest.mark.parametrize("B,D,H,W,Cin,Cout,with_res", [(1, 12, 12, 12, 192, 192, True), (2, 6, 6, 6, 96, 48, False), (1, 3, 3, 3, 768, 768, True), (2, 5, 7, 6, 96, 96, True),
+                                                      (1, 12, 12, 12, 128, 128, True), (1, 6, 6, 6, 256, 128, False)])      # 64-byte chunks (C-UNETR's deep layers)
 def test_split_conv_leaves_its_slabs_to_the_instance_norm(dtype, B, D, H, W, Cin, Cout, with_res):
     """conv -> (conditional) instance norm -> + residual -> LeakyReLU at the small stages (dynunet_block.py:100-126): a split convolution
     asked with want_stat="defer" stops after its fp32 partial slabs and the norm's ONE launch sums them, writes the convolution's output
