@@ -31,7 +31,7 @@ enum { MISEG_ACT_NONE = 0, MISEG_ACT_LEAKY = 1, MISEG_ACT_GELU = 2, MISEG_ACT_PR
 #define MISEG_MAX_STYLES 4
 
 /* bumped on EVERY change of a struct layout or prototype; bindings must refuse a library whose version differs from the header they mirror */
-#define MISEG_ABI_VERSION 6
+#define MISEG_ABI_VERSION 7
 int miseg_abi_version(void);
 const char* miseg_last_error(void);
 /* writes e.g. "gfx950" for the code objects embedded in the library */
@@ -644,6 +644,26 @@ int miseg_debug_stamp(uint64_t* slot_dev, miseg_stream_t stream);
  * `max` (tag, milliseconds) pairs in launch order, forgets them and returns how many there were.  Not for use under stream capture. */
 int miseg_prof_arm(int tag);
 int miseg_prof_read(int* tags, float* ms, int max);
+
+/* A captured multi-stream hipGraph replayed as single-stream graphs (csrc/graphsplit.cpp, ABI 7; opt-in, MISEG_GRAPH_SPLIT=1 in
+ * runtime/graph.py).  miseg_graph_split_create takes the hipGraph_t of a finished capture (torch: CUDAGraph(keep_graph=True)
+ * .raw_cuda_graph()), decomposes it into chains, cuts them at the edges that cross between chains and instantiates every piece as a graph
+ * of its own; miseg_graph_split_launch replays the pieces - the longest chain on `stream` itself, the others on streams the plan owns (at
+ * most max_side_streams, else MISEG_E_UNSUPPORTED; picked at creation so that they demonstrably run beside `launch_stream`, see
+ * miseg_graph_split_info.streams_concurrent), one event per
+ * crossing edge - in the partial order of the captured graph, and leaves `stream` waiting for all of it.  The memory pool the captured
+ * nodes point into must outlive the plan's launches; the plan itself holds clones of the graph.  An alternative to the runtime's
+ * hipGraphLaunch of the whole graph, which leaves the launch stream waiting on its internal streams for the whole replay (what that
+ * costs, and what this buys where: csrc/graphsplit.cpp). */
+typedef void* miseg_graph_split_t;
+typedef struct {
+  int nodes, lanes, segments, crossing_edges, side_streams, main_lane_nodes;
+  int streams_concurrent;      /* 1: the plan's streams were seen to run beside the launch stream and each other (else pieces may serialise) */
+} miseg_graph_split_info;
+int miseg_graph_split_create(void* hip_graph, miseg_stream_t launch_stream, int max_side_streams, miseg_graph_split_t* out,
+                             miseg_graph_split_info* info /* may be null */);
+int miseg_graph_split_launch(miseg_graph_split_t plan, miseg_stream_t stream);
+void miseg_graph_split_destroy(miseg_graph_split_t plan);
 
 /* The resampling step of the cached, deterministic head of the data chain (Spacingd at data/multi_modal.py:41-44: image "bilinear", label
  * "nearest"): in [C][Di][Hi][Wi] -> out [C][Do][Ho][Wo], voxel centres aligned (src = (dst + 0.5) * in / out - 0.5), coordinates clamped to

@@ -12,7 +12,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-Wno-unused-value",
          "-I", os.path.join(ROOT, "include"), f'-DMISEG_COMPILED_ARCH="{ARCH}"']
-SOURCES = ["common.cpp", "norm.hip", "elementwise.hip", "gemm.hip", "mlp.hip", "conv3d.hip", "attention.hip", "attention_global.hip", "training.hip"]
+SOURCES = ["common.cpp", "graphsplit.cpp", "norm.hip", "elementwise.hip", "gemm.hip", "mlp.hip", "conv3d.hip", "attention.hip", "attention_global.hip", "training.hip"]
 
 
 def lib_path():

@@ -20,7 +20,7 @@ class _S(C.Structure):
     pass
 
 
-ABI_VERSION = 6          # == MISEG_ABI_VERSION of include/miseg_hip.h; load() refuses a library that reports another
+ABI_VERSION = 7          # == MISEG_ABI_VERSION of include/miseg_hip.h; load() refuses a library that reports another
 C_NAMES = {}             # ctypes mirror -> name of the C struct it mirrors (tests/test_abi.py checks sizeof / offsetof of every field)
 
 
@@ -75,6 +75,8 @@ Winattn = _struct("Winattn", cname="miseg_winattn_params", fields=[("qkv", vp), 
 WinattnBwd = _struct("WinattnBwd", cname="miseg_winattn_bwd_params", fields=[("f", Winattn), ("dout", vp), ("lddo", i64), ("dqkv", vp), ("lddq", i64),
                                     ("dqkv_bias", vp), ("dbias_table", vp)])
 Add = _struct("Add", cname="miseg_add_params", fields=[("a", vp), ("lda", i64), ("b", vp), ("ldb", i64), ("y", vp), ("ldy", i64), ("rows", i64), ("C", i32), ("dtype", i32)])
+GraphSplitInfo = _struct("GraphSplitInfo", cname="miseg_graph_split_info", fields=[("nodes", i32), ("lanes", i32), ("segments", i32), ("crossing_edges", i32),
+                                                                                  ("side_streams", i32), ("main_lane_nodes", i32), ("streams_concurrent", i32)])
 Affine2 = _struct("Affine2", cname="miseg_affine2_params", fields=[("struct_size", C.c_uint32), ("a", vp), ("lda", i64), ("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("coef", vp),
                                                                   ("B", i32), ("S", i32), ("C", i32), ("dtype", i32)])
 Copy2d = _struct("Copy2d", cname="miseg_copy2d_params", fields=[("src", vp), ("lds", i64), ("sdtype", i32), ("dst", vp), ("ldd", i64), ("ddtype", i32), ("rows", i64), ("C", i32)])
@@ -227,6 +229,9 @@ PROTOS = {
     "miseg_prof_read": (i32, [vp, vp, i32]),
     "miseg_counter_copy": (i32, [vp, vp, vp]),
     "miseg_flag_wait": (i32, [vp, vp, C.c_uint64, vp, vp]),
+    "miseg_graph_split_create": (i32, [vp, vp, i32, C.POINTER(vp), vp]),
+    "miseg_graph_split_launch": (i32, [vp, vp]),
+    "miseg_graph_split_destroy": (None, [vp]),
     "miseg_abi_struct_size": (C.c_size_t, [C.c_char_p]),
     "miseg_device_check": (i32, [i32]),
 }

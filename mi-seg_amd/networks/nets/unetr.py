@@ -99,7 +99,8 @@ class UNETR(nn.Module):
         x, hidden = self.vit(x_in, styles, dt)
         # side branch (see SwinUNETR.side_branch): encoder1 reads the image only and feeds the last decoder only, and autograd reaches its
         # backward pass right in front of the ViT's - 12 blocks of 216-token launches that leave the chip idle.  On the branch stream it runs
-        # BESIDE them, in background form.
+        # BESIDE them, in background form.  (Round 4: encoder2-4 on the branch as well - their backward passes beside the ViT's instead of in
+        # front of it, correct, 3 more stream edges in each direction - replayed 20 % SLOWER, 210 -> 167 patches/s: DESIGN.md R4.3.)
         branch = (self.side_branch and dt == torch.bfloat16 and torch.is_grad_enabled() and not x_in.requires_grad)
         if branch:
             side, cur = ops.branch_stream(x_in.device), torch.cuda.current_stream()
@@ -109,8 +110,11 @@ class UNETR(nn.Module):
                     t.record_stream(side)
             with torch.cuda.stream(side):
                 enc1 = self.encoder1(None, styles, image=x_in, dtype=dt)
-            ops.close_branch_deferral(self.parameters())       # decoder2's 96^3 weight gradients stay where they are: at 16 channels they are long launches (0.29 ms)
-                                             # that become the critical path when throttled and gain nothing un-throttled (133.2 -> 123 .. 132.9)
+            # decoder2's two 96^3 weight gradients wait for the branch's backward pass (hip/ops.py::defer_to_branch), as decoder1's do in
+            # SwinUNETR.  Round 3 left them inline (0.29 ms launches then: throttled they became the critical path, 133.2 -> 123 .. 132.9); with
+            # the narrow-layer weight-gradient kernel they are 45 + 60 us and deferring pays: 204.8 / 207.6 -> 209.2 / 211.5 patches/s
+            # (MISEG_UNETR_DEFER=0 keeps them inline)
+            (ops.close_branch_deferral if os.environ.get("MISEG_UNETR_DEFER") == "0" else ops.open_branch_deferral)(self.parameters())
         else:
             enc1 = self.encoder1(None, styles, image=x_in, dtype=dt)
         enc2 = self.encoder2(self.proj_feat(hidden[3]), styles)

@@ -6,6 +6,7 @@ set of modalities present in the batch, because which conditional-norm rows rece
 ``grad is None``) is part of the recorded work; the per-sample style ids themselves live in a static device tensor
 that is overwritten before each replay.
 """
+import os
 from typing import Dict, List, Sequence, Tuple
 
 import torch
@@ -21,7 +22,87 @@ def _graph_capture(g, **kw):
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         kw.setdefault("capture_error_mode", "thread_local")
-    return torch.cuda.graph(g, **kw)
+    return _Capture(g, kw)
+
+
+class _Capture:
+    """`with _graph_capture(g):` - torch.cuda.graph around a _Graph, then the split plan"""
+
+    def __init__(self, g, kw):
+        self.g = g
+        self.ctx = torch.cuda.graph(g.g, **kw)
+
+    def __enter__(self):
+        return self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        r = self.ctx.__exit__(*exc)
+        if exc[0] is None:
+            self.g.finish()
+        return r
+
+
+# replay multi-stream captures as single-stream pieces (csrc/graphsplit.cpp): OFF by default - correct, and 1.6 x faster than the runtime's
+# replay on chains of tiny kernels beside a side stream (scripts/debug/graph_split_probe.py), but 2 - 3 % slower on the training step
+# (149 against 153 patches/s, DESIGN.md R4.3)
+SPLIT_REPLAY = os.environ.get("MISEG_GRAPH_SPLIT", "0") == "1"
+SPLIT_SIDE_STREAMS = int(os.environ.get("MISEG_GRAPH_SPLIT_STREAMS", "2"))
+
+
+class _Graph:
+    """one captured graph of this package: a torch.cuda.CUDAGraph that is replayed either by torch (`replay()` = hipGraphLaunch of the whole
+    graph) or - when the capture holds more than one chain of nodes, i.e. the model's side branch or RCCL's stream took part - as the
+    single-stream pieces of csrc/graphsplit.cpp (`miseg_graph_split_*`, include/miseg_hip.h; MISEG_GRAPH_SPLIT=1).  Torch's replay is the
+    default: see SPLIT_REPLAY."""
+
+    def __init__(self):
+        self.g = torch.cuda.CUDAGraph(keep_graph=True) if SPLIT_REPLAY else torch.cuda.CUDAGraph()
+        self.plan = None
+        self.info = None
+
+    def pool(self):
+        return self.g.pool()
+
+    def finish(self):
+        """after the capture: build the split plan where it pays"""
+        if not SPLIT_REPLAY:
+            return
+        import ctypes as C
+        from ..hip import lib as L
+        lib = L.load()
+        plan, info = C.c_void_p(), L.GraphSplitInfo()
+        rc = lib.miseg_graph_split_create(C.c_void_p(self.g.raw_cuda_graph()), C.c_void_p(torch.cuda.current_stream().cuda_stream), SPLIT_SIDE_STREAMS, C.byref(plan),
+                                          C.byref(info))
+        if rc == -2:          # MISEG_E_UNSUPPORTED: more concurrent chains than side streams allowed: torch's replay
+            self.info = {"unsupported": lib.miseg_last_error().decode()}
+            self.g.instantiate()
+            return
+        L.check(rc, "miseg_graph_split_create")
+        self.info = {k: getattr(info, k) for k, _ in L.GraphSplitInfo._fields_}
+        if self.info["lanes"] > 1:
+            self.plan = plan
+            self._launch = lib.miseg_graph_split_launch
+        else:                               # one chain: the runtime's own replay is the fast path already
+            lib.miseg_graph_split_destroy(plan)
+            self.g.instantiate()
+
+    def replay(self):
+        if self.plan is None:
+            self.g.replay()
+            return
+        rc = self._launch(self.plan, torch.cuda.current_stream().cuda_stream)
+        if rc:
+            from ..hip import lib as L
+            L.check(rc, "miseg_graph_split_launch")
+
+    def __del__(self):
+        if getattr(self, "plan", None) is not None:
+            try:
+                from ..hip import lib as L
+                L.load().miseg_graph_split_destroy(self.plan)
+            except Exception:
+                pass
+            self.plan = None
 
 
 def _check_styles(model, modalities, batch):
@@ -83,7 +164,7 @@ class GraphedForward:
                     self.arena.refresh_weights()
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
+            g = _Graph()
             with _graph_capture(g):
                 y = self._run(host)
             ops.STAT_POOL.pin()
@@ -210,7 +291,7 @@ class GraphedStep:
         torch.cuda.synchronize()
         for p in self.params:
             p.grad = None
-        g = torch.cuda.CUDAGraph()
+        g = _Graph()
         g2 = None
         if self.split and self.fused_comm is not None:
             with _graph_capture(g):
@@ -222,7 +303,7 @@ class GraphedStep:
         elif self.split:
             with _graph_capture(g):
                 y, cut = self._run_first(host)
-            g2 = torch.cuda.CUDAGraph()
+            g2 = _Graph()
             with _graph_capture(g2, pool=g.pool()):        # the second graph consumes activations the first one saved: one pool
                 self._run_second(cut)
             del cut
@@ -322,7 +403,7 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         for p in self.arena.params:
             p.grad = None
-        g = torch.cuda.CUDAGraph()
+        g = _Graph()
         with _graph_capture(g):
             loss = self._run(host, True)
         ops.STAT_POOL.pin()
