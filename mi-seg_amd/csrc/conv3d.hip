@@ -409,6 +409,8 @@ __global__ void __launch_bounds__(256, GPT == 6 ? 2 : GPT == 4 ? (NT == 1 ? 3 : 
           }
         }
       } else {
+        // (s_setprio 1 / 3 around this block, so that the other workgroup's staging does not delay the MFMA issue: 96^3 48->48 122.8 / 122.5 /
+        // 125.9 us - nothing; scripts/debug/build_conv_exp.sh builds such variants beside the library)
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
           if (kh + 1 < 3) {   // next step's weight fragments in flight during the MFMAs
