@@ -923,19 +923,33 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
       if (split == 1 && !p->accumulate && p->M <= 2048 && p->K % 32 == 0 && p->N % 16 == 0 && al_a && al_b && ((uintptr_t)p->C % 8 == 0) && p->ldc % 4 == 0 && epi_vec_ok) {
         // the largest tile that still leaves >= 140 workgroups (sweep over the deep-stage / ViT shapes in the kernel's comment: with fewer
         // the launch is one workgroup's K loop long; beyond, the smaller tile only adds operand traffic)
+        // round 4: a grid of at most 256 workgroups - one round on the 256 CUs - beats a finer tile that needs a second, partly empty round
+        // (216 x 768 -> 3072: 32 x 64 tiles = 336 workgroups 11.6 us, 64 x 48 tiles = 256 workgroups 9.0 us; 216 x 768 -> 2304: 32 x 64 = 252
+        // workgroups 7.6 us, 64 x 48 = 192: 8.9): the candidate with the most workgroups <= 256 wins when it has >= 140, else the rule above
         int mtw = 1, ntw = 1;
         {
-          static const int cand[5][2] = {{2, 4}, {2, 2}, {2, 1}, {1, 2}, {1, 1}};
-          for (int c = 0; c < 5; ++c) {
+          static const int cand[6][2] = {{4, 3}, {2, 4}, {2, 2}, {2, 1}, {1, 2}, {1, 1}};
+          int best = -1;
+          int64_t best_wg = 0;
+          for (int c = 0; c < 6; ++c) {
             const int a_ = cand[c][0], b_ = cand[c][1];
-            if (p->N % (16 * b_) != 0 || (a_ == 2 && p->M <= 16)) continue;
-            mtw = a_; ntw = b_;
-            if ((int64_t)cdiv(p->M, 16 * a_) * (p->N / (16 * b_)) >= 140) break;
+            if (p->N % (16 * b_) != 0 || (a_ >= 2 && p->M <= 16 * (a_ / 2))) continue;
+            const int64_t wg = (int64_t)cdiv(p->M, 16 * a_) * (p->N / (16 * b_));
+            if (wg >= 140 && wg <= 256 && wg > best_wg) { best = c; best_wg = wg; }
+          }
+          if (best >= 0) { mtw = cand[best][0]; ntw = cand[best][1]; }
+          else {
+            for (int c = 1; c < 6; ++c) {
+              const int a_ = cand[c][0], b_ = cand[c][1];
+              if (p->N % (16 * b_) != 0 || (a_ == 2 && p->M <= 16)) continue;
+              mtw = a_; ntw = b_;
+              if ((int64_t)cdiv(p->M, 16 * a_) * (p->N / (16 * b_)) >= 140) break;
+            }
           }
         }
         if (const char* e = getenv("MISEG_GEMM_SMALL_TILE")) {      // sweeps (scripts/bench_gemm.py small): "mtw,ntw"
           int a_ = 0, b_ = 0;
-          if (sscanf(e, "%d,%d", &a_, &b_) == 2 && (a_ == 1 || a_ == 2) && (b_ == 1 || b_ == 2 || b_ == 4) && p->N % (16 * b_) == 0) { mtw = a_; ntw = b_; }
+          if (sscanf(e, "%d,%d", &a_, &b_) == 2 && p->N % (16 * b_) == 0 && (((a_ == 1 || a_ == 2) && (b_ == 1 || b_ == 2 || b_ == 4)) || (a_ == 4 && b_ == 3))) { mtw = a_; ntw = b_; }
         }
         const int gm = cdiv(p->M, 16 * mtw);
         dim3 grid(gm * (p->N / (16 * ntw)));
@@ -945,7 +959,8 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
     if (ge) gemm_nt_small_kernel<m_, n_, true><<<grid, 256, 0, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, p->K, epi, gm); \
     else gemm_nt_small_kernel<m_, n_, false><<<grid, 256, 0, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, p->K, epi, gm); \
   } while (0)
-        if (mtw == 2) { if (ntw == 4) SM_LAUNCH(2, 4); else if (ntw == 2) SM_LAUNCH(2, 2); else SM_LAUNCH(2, 1); }
+        if (mtw == 4) SM_LAUNCH(4, 3);
+        else if (mtw == 2) { if (ntw == 4) SM_LAUNCH(2, 4); else if (ntw == 2) SM_LAUNCH(2, 2); else SM_LAUNCH(2, 1); }
         else { if (ntw == 4) SM_LAUNCH(1, 4); else if (ntw == 2) SM_LAUNCH(1, 2); else SM_LAUNCH(1, 1); }
 #undef SM_LAUNCH
         MISEG_LAUNCH_CHECK("gemm_nt_small");
