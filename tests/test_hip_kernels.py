@@ -321,7 +321,8 @@ def test_gemm_nt_rank1(dtype):
 
 
 @pytest.mark.parametrize("M,N,K", [(216, 1536, 384), (216, 384, 1536), (27, 3072, 768), (1728, 768, 192), (1727, 192, 768), (215, 1152, 384), (100, 16, 32),
-                                   (2048, 48, 96), (512, 256, 128), (512, 256, 96), (512, 256, 64), (2048, 64, 128)])
+                                   (2048, 48, 96), (512, 256, 128), (512, 256, 96), (512, 256, 64), (2048, 64, 128),
+                                   (216, 3072, 768), (200, 2880, 64)])      # the 64 x 48 tile (one round of <= 256 workgroups), ragged M
 def test_gemm_nt_small_path(M, N, K):
     """deep-stage linears (M <= 2048, K % 32 == 0) take the register-direct kernel with K split over the four waves."""
     ops, L = _ops(), _L()
