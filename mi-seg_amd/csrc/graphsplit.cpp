@@ -332,8 +332,14 @@ extern "C" int miseg_graph_split_create(void* graph_, miseg_stream_t launch_stre
             plan->segs.size(), plan->side.size(), plan->concurrent ? "" : " (NOT seen to run concurrently)");
     for (size_t s = 0; s < plan->segs.size(); ++s) {
       const Segment& g = plan->segs[s];
-      fprintf(stderr, "  seg %zu: lane %d stream %d, %zu nodes (topo %d..%d)%s, waits:", s, g.lane, g.stream, g.nodes.size(), pos[g.nodes.front()], pos[g.nodes.back()],
-              g.record ? ", records" : "");
+      int nk = 0, nc = 0, nm = 0, no = 0;      // kernel / memcpy / memset / other nodes
+      for (int v : g.nodes) {
+        hipGraphNodeType ty = hipGraphNodeTypeEmpty;
+        (void)hipGraphNodeGetType(nodes[v], &ty);
+        if (ty == hipGraphNodeTypeKernel) ++nk; else if (ty == hipGraphNodeTypeMemcpy) ++nc; else if (ty == hipGraphNodeTypeMemset) ++nm; else ++no;
+      }
+      fprintf(stderr, "  seg %zu: lane %d stream %d, %zu nodes (%d kernels, %d copies, %d memsets, %d other; topo %d..%d)%s, waits:", s, g.lane, g.stream, g.nodes.size(), nk, nc, nm, no,
+              pos[g.nodes.front()], pos[g.nodes.back()], g.record ? ", records" : "");
       for (int w : g.waits) fprintf(stderr, " %d", w);
       fprintf(stderr, "\n");
     }
