@@ -174,6 +174,8 @@ def main():
                 r = measure(b, rank, world, dist, dev)
                 out["secondary"][name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "train_step", "weight_refresh") if k in r}
                 out["secondary"][name]["workload"] = r["config"]["workload"]
+                if "sw_batch_size" in r["config"]:      # (round 4 moved c5 from 4 to 20 windows per forward: 593 -> 643 windows/s of the 590 -> 641 between the rounds)
+                    out["secondary"][name]["sw_batch_size"] = r["config"]["sw_batch_size"]
                 torch.cuda.empty_cache()
         print(json.dumps(out), flush=True)
     if dist is not None:

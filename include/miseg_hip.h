@@ -31,7 +31,7 @@ enum { MISEG_ACT_NONE = 0, MISEG_ACT_LEAKY = 1, MISEG_ACT_GELU = 2, MISEG_ACT_PR
 #define MISEG_MAX_STYLES 4
 
 /* bumped on EVERY change of a struct layout or prototype; bindings must refuse a library whose version differs from the header they mirror */
-#define MISEG_ABI_VERSION 7
+#define MISEG_ABI_VERSION 8
 int miseg_abi_version(void);
 const char* miseg_last_error(void);
 /* writes e.g. "gfx950" for the code objects embedded in the library */
@@ -628,42 +628,8 @@ int miseg_counter_add(uint64_t* counter_dev, uint64_t value, miseg_stream_t stre
 /* *dst = *src on the device (a plain kernel: device-to-device copies recorded as memcpy nodes crashed hipStreamEndCapture on ROCm 7.2).
  * A dropout call snapshots the step counter so that its backward pass re-creates the same mask after the counter moved on. */
 int miseg_counter_copy(uint64_t* dst_dev, const uint64_t* src_dev, miseg_stream_t stream);
-/* ABI 6: the stream waits ON THE DEVICE (a one-thread kernel that spins with s_sleep) until *flag_dev >= *want_dev - e.g. a flag another
- * stream, or another hipGraph launch, sets with miseg_counter_copy once its producers have run: an ordering between two captured graphs that
- * needs no edge between them.  After timeout_us (<= 2 s) the kernel gives up, increments *timed_out_dev (may be null) and returns: what
- * follows then runs on data that may be incomplete - check the counter. */
-int miseg_flag_wait(const uint64_t* flag_dev, const uint64_t* want_dev, uint64_t timeout_us, uint32_t* timed_out_dev, miseg_stream_t stream);
-/* measurement aid: *slot_dev = the device's constant-rate wall clock (100 MHz on gfx950) when the stream reaches this point.  A one-thread
- * kernel, so it can be recorded into a hipGraph: the order in which the streams of a replayed step reach their joins is visible without a
- * tracer (whose per-dispatch cost reorders exactly that).  Host side: MISEG_STEP_STAMPS=1|2, hip/ops.py::stamp; bench.py prints them. */
-int miseg_debug_stamp(uint64_t* slot_dev, miseg_stream_t stream);
-
-/* measurement aid (bench.py's roofline leg): while armed with a tag >= 0, EVERY kernel this library launches records its own begin / end
- * timestamps (hipExtLaunchKernel start / stop events: the dispatch's own clock, what rocprofv3 --kernel-trace reports) - once, in place, on
- * its own stream, beside whatever else runs.  miseg_prof_arm(-1) disarms.  miseg_prof_read waits for the recorded launches, writes up to
- * `max` (tag, milliseconds) pairs in launch order, forgets them and returns how many there were.  Not for use under stream capture. */
-int miseg_prof_arm(int tag);
-int miseg_prof_read(int* tags, float* ms, int max);
-
-/* A captured multi-stream hipGraph replayed as single-stream graphs (csrc/graphsplit.cpp, ABI 7; opt-in, MISEG_GRAPH_SPLIT=1 in
- * runtime/graph.py).  miseg_graph_split_create takes the hipGraph_t of a finished capture (torch: CUDAGraph(keep_graph=True)
- * .raw_cuda_graph()), decomposes it into chains, cuts them at the edges that cross between chains and instantiates every piece as a graph
- * of its own; miseg_graph_split_launch replays the pieces - the longest chain on `stream` itself, the others on streams the plan owns (at
- * most max_side_streams, else MISEG_E_UNSUPPORTED; picked at creation so that they demonstrably run beside `launch_stream`, see
- * miseg_graph_split_info.streams_concurrent), one event per
- * crossing edge - in the partial order of the captured graph, and leaves `stream` waiting for all of it.  The memory pool the captured
- * nodes point into must outlive the plan's launches; the plan itself holds clones of the graph.  An alternative to the runtime's
- * hipGraphLaunch of the whole graph, which leaves the launch stream waiting on its internal streams for the whole replay (what that
- * costs, and what this buys where: csrc/graphsplit.cpp). */
-typedef void* miseg_graph_split_t;
-typedef struct {
-  int nodes, lanes, segments, crossing_edges, side_streams, main_lane_nodes;
-  int streams_concurrent;      /* 1: the plan's streams were seen to run beside the launch stream and each other (else pieces may serialise) */
-} miseg_graph_split_info;
-int miseg_graph_split_create(void* hip_graph, miseg_stream_t launch_stream, int max_side_streams, miseg_graph_split_t* out,
-                             miseg_graph_split_info* info /* may be null */);
-int miseg_graph_split_launch(miseg_graph_split_t plan, miseg_stream_t stream);
-void miseg_graph_split_destroy(miseg_graph_split_t plan);
+/* (measurement and experiment entry points - miseg_debug_stamp, miseg_prof_*, miseg_flag_wait, miseg_graph_split_* - are declared in
+ * include/miseg_hip_debug.h: no product path calls them) */
 
 /* The resampling step of the cached, deterministic head of the data chain (Spacingd at data/multi_modal.py:41-44: image "bilinear", label
  * "nearest"): in [C][Di][Hi][Wi] -> out [C][Do][Ho][Wo], voxel centres aligned (src = (dst + 0.5) * in / out - 0.5), coordinates clamped to
@@ -679,6 +645,9 @@ int miseg_resample3d(const miseg_resample3d_params* p, miseg_stream_t stream);
 /* sizeof() of a params struct as this library was compiled ("miseg_gemm_params", ...), 0 for an unknown name: bindings compare it with
  * their own mirror at load time (together with miseg_abi_version) so that header and binding cannot drift silently. */
 size_t miseg_abi_struct_size(const char* struct_name);
+/* sha256 (hex) over the sources this library was compiled from (csrc/build.py); a binding that finds the sources beside the library
+ * compares and refuses a stale build */
+const char* miseg_source_digest(void);
 /* MISEG_OK when HIP device `device` runs the code objects embedded in this library (gcnArchName starts with miseg_device_arch) */
 int miseg_device_check(int device);
 

@@ -1,5 +1,6 @@
 // Error reporting + library identity for libmiseg_hip.so
 #include "common.h"
+#include "../../include/miseg_hip_debug.h"
 #include <string.h>
 
 #ifndef MISEG_COMPILED_ARCH
@@ -58,12 +59,15 @@ extern "C" int miseg_device_check(int device) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// In-situ kernel timing (bench.py's roofline leg): the library is linked with --wrap=hipLaunchKernel (csrc/build.py), so every `<<<>>>` of
-// every translation unit arrives here.  Disarmed (always, outside that leg) the call goes straight to the runtime.  Armed with a tag, each
-// launch is issued through hipExtLaunchKernel with its own start / stop events: the runtime stamps them with the dispatch's begin / end
-// timestamps (what rocprofv3 --kernel-trace reports), on the stream the kernel is launched on, ONCE, where the step issues it - beside
-// whatever else is running.  Not capture-safe (events are created per launch): the roofline leg runs the step eagerly.
+// In-situ kernel timing (bench.py's roofline leg; include/miseg_hip_debug.h).  ONLY the measurement build of the library,
+// libmiseg_hip_prof.so, carries it: csrc/build.py compiles this file a second time with -DMISEG_PROF_WRAP and links that variant with
+// -Wl,--wrap=hipLaunchKernel, so that every `<<<>>>` of every translation unit arrives at __wrap_hipLaunchKernel.  Disarmed, the call goes
+// straight to the runtime.  Armed with a tag, each launch is issued through hipExtLaunchKernel with its own start / stop events: the runtime
+// stamps them with the dispatch's begin / end timestamps (what rocprofv3 --kernel-trace reports), on the stream the kernel is launched on,
+// ONCE, where the step issues it - beside whatever else is running.  Not capture-safe (events are created per launch): the roofline leg
+// runs the step eagerly.  The product library, libmiseg_hip.so, is linked without the wrap and answers MISEG_E_UNSUPPORTED.
 // ---------------------------------------------------------------------------------------------------------
+#ifdef MISEG_PROF_WRAP
 #include <mutex>
 #include <vector>
 extern "C" hipError_t __real_hipLaunchKernel(const void* f, dim3 grid, dim3 block, void** args, size_t shmem, hipStream_t s);
@@ -104,3 +108,19 @@ extern "C" int miseg_prof_read(int* tags, float* ms, int max) {
   g_prof.clear();
   return n;
 }
+extern "C" int miseg_prof_available(void) { return 1; }
+#else
+extern "C" int miseg_prof_arm(int tag) {
+  if (tag < 0) return MISEG_OK;
+  return miseg::set_error(MISEG_E_UNSUPPORTED, "prof_arm: this is the product library; in-place launch timing lives in libmiseg_hip_prof.so (csrc/build.py)");
+}
+extern "C" int miseg_prof_read(int*, float*, int) { return 0; }
+extern "C" int miseg_prof_available(void) { return 0; }
+#endif
+
+// sha256 over the sources this library was compiled from (csrc/build.py: every csrc/*.hip, *.cpp, *.h and include/*.h, in name order);
+// hip/lib.py::load() compares it with the sources it finds beside the library and refuses a stale build
+#ifndef MISEG_SOURCE_DIGEST
+#define MISEG_SOURCE_DIGEST "unknown"
+#endif
+extern "C" const char* miseg_source_digest(void) { return MISEG_SOURCE_DIGEST; }

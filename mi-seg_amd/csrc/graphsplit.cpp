@@ -27,7 +27,7 @@
 #include <vector>
 
 #include "common.h"
-#include "miseg_hip.h"
+#include "../../include/miseg_hip_debug.h"
 
 namespace {
 
@@ -46,6 +46,8 @@ struct Plan {
   std::vector<hipStream_t> side;         // streams 1 .. of the plan
   std::vector<hipEvent_t> side_end;
   hipEvent_t start = nullptr;
+  hipEvent_t tail = nullptr;             // recorded on the caller's stream behind the last piece of a launch: destroy waits for it
+  bool launched = false;
   int nodes = 0, lanes = 0, cross = 0;
   bool concurrent = true;                 // the side streams were seen to run beside the launch stream and each other
 };
@@ -101,6 +103,10 @@ std::vector<hipStream_t> concurrent_streams(hipStream_t with, int k, int tries =
 
 void destroy_plan(Plan* p) {
   if (!p) return;
+  // pieces of a launch may still be in flight: their execs, events and side streams are freed below
+  if (p->launched && p->tail) (void)hipEventSynchronize(p->tail);
+  for (auto s : p->side)
+    if (s) (void)hipStreamSynchronize(s);
   for (auto& s : p->segs) {
     if (s.exec) (void)hipGraphExecDestroy(s.exec);
     if (s.graph) (void)hipGraphDestroy(s.graph);
@@ -110,6 +116,7 @@ void destroy_plan(Plan* p) {
   for (auto s : p->side)
     if (s) (void)hipStreamDestroy(s);
   if (p->start) (void)hipEventDestroy(p->start);
+  if (p->tail) (void)hipEventDestroy(p->tail);
   delete p;
 }
 
@@ -302,6 +309,7 @@ extern "C" int miseg_graph_split_create(void* graph_, miseg_stream_t launch_stre
     }
   }
   hipError_t e = hipEventCreateWithFlags(&plan->start, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&plan->tail, hipEventDisableTiming);
   for (size_t i = 0; i < plan->side.size() && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&plan->side_end[i], hipEventDisableTiming);
   if (e != hipSuccess) { destroy_plan(plan); return miseg::set_error(MISEG_E_LAUNCH, "graph_split_create: events: %s", hipGetErrorString(e)); }
   {
@@ -369,7 +377,26 @@ extern "C" int miseg_graph_split_launch(miseg_graph_split_t plan_, miseg_stream_
     GS_CHECK(hipEventRecord(p->side_end[i], p->side[i]));
     GS_CHECK(hipStreamWaitEvent(main, p->side_end[i], 0));
   }
+  GS_CHECK(hipEventRecord(p->tail, main));
+  p->launched = true;
   return MISEG_OK;
 }
 
 extern "C" void miseg_graph_split_destroy(miseg_graph_split_t plan_) { destroy_plan((Plan*)plan_); }
+
+// 1: kernels launched on the two streams were seen to run side by side (they sit on different hardware queues); 0: one after the other.
+// What a device-side wait between two streams (miseg_flag_wait) needs to be told before it is used: a waiter that shares its producer's
+// hardware queue blocks the kernel that would release it and runs into its timeout.
+extern "C" int miseg_streams_run_concurrently(miseg_stream_t a_, miseg_stream_t b_) {
+  hipStream_t a = (hipStream_t)a_, b = (hipStream_t)b_;
+  MISEG_REQUIRE(a != b, MISEG_E_BADARG, "streams_run_concurrently: one stream given twice");
+  hipEvent_t e0 = nullptr, e1 = nullptr, eb = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreateWithFlags(&eb, hipEventDisableTiming) != hipSuccess) {
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return miseg::set_error(MISEG_E_LAUNCH, "streams_run_concurrently: hipEventCreate failed");
+  }
+  const bool ok = run_concurrently(a, b, e0, e1, eb);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(eb);
+  return ok ? 1 : 0;
+}

@@ -5,6 +5,7 @@
 //   * sliding-window stitching as one gather over resident window logits                                     (lightning_monai.py:86-93,187)
 // MONAI 1.1.0 arithmetic restated from its public API (parity unpinned by any reference test).
 #include "common.h"
+#include "../../include/miseg_hip_debug.h"
 #include <math.h>
 
 namespace miseg {

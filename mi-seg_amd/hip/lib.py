@@ -20,7 +20,7 @@ class _S(C.Structure):
     pass
 
 
-ABI_VERSION = 7          # == MISEG_ABI_VERSION of include/miseg_hip.h; load() refuses a library that reports another
+ABI_VERSION = 8          # == MISEG_ABI_VERSION of include/miseg_hip.h; load() refuses a library that reports another
 C_NAMES = {}             # ctypes mirror -> name of the C struct it mirrors (tests/test_abi.py checks sizeof / offsetof of every field)
 
 
@@ -223,18 +223,26 @@ PROTOS = {
     "miseg_resample3d": (i32, [C.POINTER(Resample3d), vp]),
     "miseg_dropout": (i32, [C.POINTER(Dropout), vp]),
     "miseg_counter_add": (i32, [vp, C.c_uint64, vp]),
-    "miseg_debug_stamp": (i32, [vp, vp]),
     "miseg_conv3_wgrad_tiny": (i32, [i32, i32, i32, i32, i32, i32, i32]),
+    "miseg_counter_copy": (i32, [vp, vp, vp]),
+    "miseg_abi_struct_size": (C.c_size_t, [C.c_char_p]),
+    "miseg_device_check": (i32, [i32]),
+    "miseg_source_digest": (C.c_char_p, []),
+}
+# measurement / experiment entry points of include/miseg_hip_debug.h (same shared object; no product path calls them)
+DEBUG_PROTOS = {
+    "miseg_debug_stamp": (i32, [vp, vp]),
     "miseg_prof_arm": (i32, [i32]),
     "miseg_prof_read": (i32, [vp, vp, i32]),
-    "miseg_counter_copy": (i32, [vp, vp, vp]),
+    "miseg_prof_available": (i32, []),
     "miseg_flag_wait": (i32, [vp, vp, C.c_uint64, vp, vp]),
+    "miseg_streams_run_concurrently": (i32, [vp, vp]),
     "miseg_graph_split_create": (i32, [vp, vp, i32, C.POINTER(vp), vp]),
     "miseg_graph_split_launch": (i32, [vp, vp]),
     "miseg_graph_split_destroy": (None, [vp]),
-    "miseg_abi_struct_size": (C.c_size_t, [C.c_char_p]),
-    "miseg_device_check": (i32, [i32]),
 }
+DEBUG_STRUCTS = {"miseg_graph_split_info"}      # mirrors of structs that include/miseg_hip_debug.h declares
+PROF_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libmiseg_hip_prof.so")
 
 _lib = None
 
@@ -243,26 +251,65 @@ class MisegHipError(RuntimeError):
     pass
 
 
-def load():
-    """Load the shared object (once).  Raises if it was not built -- there is no CPU fallback."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise MisegHipError(f"{LIB_PATH} is missing: run `python __graft_entry__.py` (build()) first; "
+def source_digest():
+    """sha256 over the library's sources as csrc/build.py hashes them (None when the sources are not beside the library)"""
+    try:
+        from ..csrc import build as _b
+        return _b.source_digest()
+    except Exception:
+        return None
+
+
+def _open(path):
+    if not os.path.exists(path):
+        raise MisegHipError(f"{path} is missing: run `python __graft_entry__.py` (build()) first; "
                             "the MI355X path has no fallback implementation")
-    lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in PROTOS.items():
-        fn = getattr(lib, name)  # AttributeError if the library does not export it
-        fn.restype, fn.argtypes = res, args
+    lib = C.CDLL(path)
+    for table in (PROTOS, DEBUG_PROTOS):
+        for name, (res, args) in table.items():
+            fn = getattr(lib, name)  # AttributeError if the library does not export it
+            fn.restype, fn.argtypes = res, args
     # header / library / binding drift is an error at load time, not a kernel reading past a struct later
     if lib.miseg_abi_version() != ABI_VERSION:
-        raise MisegHipError(f"{LIB_PATH} reports ABI version {lib.miseg_abi_version()}, this binding mirrors version {ABI_VERSION}: rebuild (build())")
+        raise MisegHipError(f"{path} reports ABI version {lib.miseg_abi_version()}, this binding mirrors version {ABI_VERSION}: rebuild (build())")
     for t, cname in C_NAMES.items():
         if cname is not None and lib.miseg_abi_struct_size(cname.encode()) != C.sizeof(t):
             raise MisegHipError(f"sizeof({cname}) is {lib.miseg_abi_struct_size(cname.encode())} in the library, {C.sizeof(t)} in hip/lib.py")
-    _lib = lib
+    # a library older than the sources beside it is refused (the in-tree .so travels with its sources; MISEG_ALLOW_STALE_LIB=1 for A/B runs
+    # against a kept build)
+    want = None if (os.environ.get("MISEG_ALLOW_STALE_LIB") or os.environ.get("MISEG_HIP_LIB")) else source_digest()
+    have = lib.miseg_source_digest().decode()
+    if want is not None and have != want:
+        raise MisegHipError(f"{path} was built from other sources (digest {have[:12]}, the tree has {want[:12]}): run build()")
     return lib
+
+
+def load():
+    """Load the shared object (once).  Raises if it was not built -- there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        _lib = _open(LIB_PATH)
+    return _lib
+
+
+class profiling_library:
+    """`with profiling_library():` - every call of the block goes to libmiseg_hip_prof.so, the measurement build of the SAME objects linked
+    with -Wl,--wrap=hipLaunchKernel (csrc/build.py, csrc/common.cpp): bench.py's roofline leg times one extra eager step through it.  The
+    library keeps no state of the caller's (buffers, packs, pools are the caller's), so the two builds are interchangeable call by call."""
+    _prof = None
+
+    def __enter__(self):
+        global _lib
+        load()
+        if profiling_library._prof is None:
+            profiling_library._prof = _open(PROF_LIB_PATH)
+        self.keep, _lib = _lib, profiling_library._prof
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.keep
+        return False
 
 
 def check_device(index=0):

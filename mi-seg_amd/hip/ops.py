@@ -780,7 +780,11 @@ class StepQueues:
 
     def flush_small(self):
         """the queued GEMM weight gradients, partial-tile sums and column sums only (the grouped conv weight gradients keep waiting): what
-        completes the small parameters of a range whose conv weights were written inline (tiny-volume layers), cheaply, mid-chain"""
+        completes the small parameters of a range whose conv weights were written inline (tiny-volume layers), cheaply, mid-chain.  With
+        MISEG_TINY_WGRAD_AT=flush those conv weights are queued too: they go out here, or the range would be reduced without them"""
+        for x, dy, dw, acc in self.tiny_wgrad:
+            _conv3_wgrad_now(x, dy, dw, acc)
+        self.tiny_wgrad.clear()
         _flush_gemm_tn(self.gemm_tn, self.writes)
         _flush_tn_reduces(self.tn_reduce)
         _flush_colsums(self.colsum)
@@ -1034,11 +1038,12 @@ def _flush_conv_wgrads(q, background=0, keep=False):
 
 
 def _conv3_wgrad_now(x, dy, dw, accumulate):
-    """a queued single-layer weight gradient, launched now (no workspace: the tiny-volume kernel stores straight into dw)"""
+    """a queued single-layer weight gradient, launched now.  The tiny-volume kernel stores straight into dw; the workspace is still sized
+    by the library, so that a layer it sends to the slab kernels after all (operands it finds misaligned) has its slabs"""
     B, D, H, W = _vol(x)
     ldx, _, Cin = rows(x)
     lddy, _, Cout = rows(dy)
-    ws = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws = torch.empty(max(L.load().miseg_conv3_wgrad_workspace_bytes(B, D, H, W, Cin, Cout) // 4, 1), dtype=torch.float32, device=x.device)
     _call("miseg_conv3_wgrad", L.Conv3Wgrad(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), B, D, H, W, Cin, Cout, _dt(x), int(accumulate), _ptr(ws), 0),
           prof=("conv3_wgrad_tiny_kernel", 2.0 * B * D * H * W * 27 * Cin * Cout))
 
@@ -1059,7 +1064,9 @@ def conv3_wgrad(x, dy, dw=None, accumulate=False):
     lib = L.load()
     # tiny volumes (3^3 / 6^3, hundreds of channels: encoder10 / decoder5): the write-bound kernel of their own, launched where the backward
     # pass reaches them (TINY_WGRAD_AT = "inline") or with the queued launches at its end ("flush": in front of the grouped launch)
-    tiny = bool(lib.miseg_conv3_wgrad_tiny(B, D, H, W, Cin, Cout, _dt(x)))
+    # (the library's own test also wants 16-byte aligned operands and row strides that are multiples of 8 elements: the same test here)
+    tiny = (bool(lib.miseg_conv3_wgrad_tiny(B, D, H, W, Cin, Cout, _dt(x))) and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0
+            and ldx % 8 == 0 and lddy % 8 == 0)
     if tiny and q is not None and TINY_WGRAD_AT != "inline":
         q.lists().tiny_wgrad.append((x, dy, dw, int(accumulate)))
         return dw

@@ -75,7 +75,9 @@ class ParamArena:
         if grad_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("grad_dtype must be torch.float32 or torch.bfloat16")
         self.grad_dtype = grad_dtype
-        self._stage = None      # bf16 staging copy of the arena (grad_dtype bfloat16)
+        # bf16 staging copy of the arena (grad_dtype bfloat16): allocated HERE, eagerly - first use inside a capture would put it into the
+        # graph's private pool, and exchange_check reads it eagerly afterwards
+        self._stage = torch.empty(off, dtype=grad_dtype, device=dev) if grad_dtype != torch.float32 else None
         self._staged = []       # ranges whose exchanged values still sit in the staging buffer
         self.used_dev = torch.zeros(len(self.params), dtype=torch.int32, device=dev)
         self._bm = None         # (stream, pinned result, event) of the bitmap exchange on a card
@@ -402,8 +404,8 @@ class ParamArena:
         cache = self.__dict__.setdefault("_flag_cache", {})
         dev = cache.get(key)
         if dev is None:
-            if len(cache) >= 64:
-                cache.clear()
+            # grow-only: a captured step records this copy with the pattern tensor's raw address as its source - evicting an entry would
+            # free memory live hipGraphs still read.  One entry per present-modality set: 2^num_styles at most in practice
             dev = cache[key] = torch.tensor(list(key), dtype=torch.int32, device=self.used_dev.device)
         self.used_dev.copy_(dev, non_blocking=True)
 

@@ -1,6 +1,6 @@
 """roofline leg of bench.py: per-launch device time of the conv3 implicit-GEMM kernels measured with HIP events on the
 launch stream during one extra forward+backward step - every launch ONCE, in place, in the schedule that is timed (round 4;
-csrc/common.cpp::__wrap_hipLaunchKernel) -, priced against the dense MFMA peak of the compute dtype (MI355X_MICROARCH.md: bf16 ~2.5 PFLOP/s dense, fp32 matrix
+csrc/common.cpp::__wrap_hipLaunchKernel of the measurement build libmiseg_hip_prof.so) -, priced against the dense MFMA peak of the compute dtype (MI355X_MICROARCH.md: bf16 ~2.5 PFLOP/s dense, fp32 matrix
 157.3 TFLOP/s).  `traffic` is the HBM bytes per launch of the same kernel from the committed rocprofv3 PMC passes
 (profiles/*_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled on gfx950), null when absent."""
 import glob
@@ -21,19 +21,20 @@ def profile_step(step_fn):
     where it runs, by its own dispatch timestamps.  Returns {kernel: [(ms of the call's first kernel, flops, bytes, ms of all its kernels)]}"""
     import ctypes as C
     from ..hip import lib as L
-    lib = L.load()
-    lib.miseg_prof_read(None, None, 0)          # forget anything recorded earlier
-    rec = []
-    ops.PROFILE_HOOK = rec
-    try:
-        step_fn()
-        torch.cuda.synchronize()
-    finally:
-        ops.PROFILE_HOOK = None
-        lib.miseg_prof_arm(-1)
-    cap = 64 * max(1, len(rec))
-    tags, ms = (C.c_int * cap)(), (C.c_float * cap)()
-    n = lib.miseg_prof_read(tags, ms, cap)
+    # the measurement build of the same objects (libmiseg_hip_prof.so: linked with --wrap=hipLaunchKernel); the product library has no hook
+    with L.profiling_library() as lib:
+        lib.miseg_prof_read(None, None, 0)          # forget anything recorded earlier
+        rec = []
+        ops.PROFILE_HOOK = rec
+        try:
+            step_fn()
+            torch.cuda.synchronize()
+        finally:
+            ops.PROFILE_HOOK = None
+            lib.miseg_prof_arm(-1)
+        cap = 64 * max(1, len(rec))
+        tags, ms = (C.c_int * cap)(), (C.c_float * cap)()
+        n = lib.miseg_prof_read(tags, ms, cap)
     if n > cap:
         raise RuntimeError(f"roofline: {n} launches recorded, room for {cap}")
     per = {}

@@ -49,9 +49,7 @@ class ArenaOptimizer:
         # with its own asynchronous upload once the host ran ahead of the device (sync-free loops), and a step then saw the next step's flags.
         key = bytes(1 if p._miseg_used else 0 for p in self.arena.params)
         dev = self._used_cache.get(key)
-        if dev is None:
-            if len(self._used_cache) >= 64:
-                self._used_cache.clear()
+        if dev is None:      # (grow-only: a captured train step reads the pattern tensor by its raw address - see ParamArena._flags_to_device)
             dev = self._used_cache[key] = torch.tensor(list(key), dtype=torch.int32, device=self.used.device)
         self.used.copy_(dev, non_blocking=True)
 

@@ -9,6 +9,7 @@ import subprocess
 from conftest import ROOT
 
 HEADER = os.path.join(ROOT, "include", "miseg_hip.h")
+DEBUG_HEADER = os.path.join(ROOT, "include", "miseg_hip_debug.h")      # measurement / experiment entry points: not the product ABI
 
 
 def _lib():
@@ -20,12 +21,51 @@ def test_every_header_struct_has_a_ctypes_mirror():
     lib = _lib()
     declared = set(re.findall(r"\}\s*(miseg_\w+);", open(HEADER).read()))
     mirrored = {v for v in lib.C_NAMES.values() if v}
-    assert declared == mirrored, (sorted(declared - mirrored), sorted(mirrored - declared))
+    assert declared == mirrored - lib.DEBUG_STRUCTS, (sorted(declared - mirrored), sorted(mirrored - declared))
+    assert set(re.findall(r"\}\s*(miseg_\w+);", open(DEBUG_HEADER).read())) == lib.DEBUG_STRUCTS
+
+
+def _prototypes(path):
+    """names of the functions a header declares (a line that starts with a return type and `miseg_name(`)"""
+    text = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+    return set(re.findall(r"^(?:int|size_t|void|const char\*)\s+(miseg_\w+)\s*\(", text, flags=re.M))
+
+
+def test_every_prototype_is_bound_and_the_debug_entry_points_stay_out_of_the_product_header():
+    """include/miseg_hip.h == hip/lib.py::PROTOS and include/miseg_hip_debug.h == DEBUG_PROTOS, name for name; the library exports all of
+    them (load() binds every name of both tables)"""
+    lib = _lib()
+    assert _prototypes(HEADER) == set(lib.PROTOS), (sorted(_prototypes(HEADER) - set(lib.PROTOS)), sorted(set(lib.PROTOS) - _prototypes(HEADER)))
+    assert _prototypes(DEBUG_HEADER) == set(lib.DEBUG_PROTOS), (sorted(_prototypes(DEBUG_HEADER) ^ set(lib.DEBUG_PROTOS)))
+    assert not (set(lib.PROTOS) & set(lib.DEBUG_PROTOS))
+    so = lib.load()
+    assert so.miseg_prof_available() == 0                      # the product library is linked without --wrap=hipLaunchKernel ...
+    assert so.miseg_prof_arm(3) == -2 and b"libmiseg_hip_prof.so" in so.miseg_last_error()
+    assert so.miseg_prof_arm(-1) == 0
+    assert os.path.exists(lib.PROF_LIB_PATH)                   # ... the measurement build beside it carries the hook
+    with lib.profiling_library() as prof:
+        assert prof.miseg_prof_available() == 1 and prof.miseg_source_digest() == so.miseg_source_digest()
+    assert lib.load() is so
+
+
+def test_a_library_older_than_its_sources_is_refused():
+    """the .so carries the sha256 of the sources it was compiled from; load() compares it with the tree (csrc/build.py::source_digest)"""
+    lib = _lib()
+    so = lib.load()
+    assert so.miseg_source_digest().decode() == lib.source_digest()
+    import pytest
+    keep = lib.source_digest
+    try:
+        lib.source_digest = lambda: "0" * 64
+        with pytest.raises(lib.MisegHipError, match="other sources"):
+            lib._open(lib.LIB_PATH)
+    finally:
+        lib.source_digest = keep
 
 
 def test_struct_layouts_match_a_c_compile_of_the_header(tmp_path):
     lib = _lib()
-    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', f'#include "{DEBUG_HEADER}"', "int main(void) {"]
     for t, cname in lib.C_NAMES.items():
         lines.append(f'  printf("S {cname} %zu\\n", sizeof({cname}));')
         for fname, _ in t._fields_:

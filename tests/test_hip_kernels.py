@@ -968,7 +968,20 @@ def test_flag_wait_orders_two_streams_on_the_device_and_gives_up_after_its_timeo
     tout = torch.zeros(1, dtype=torch.int32, device=DEV)
     data = torch.zeros(1 << 20, device=DEV)
     seen = torch.zeros(1 << 20, device=DEV)
-    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    # the waiter must not share a hardware queue with the producer (it would block the kernel that releases it: ADVICE round 4) - streams
+    # are picked by the library's own probe, as include/miseg_hip_debug.h demands of every user of miseg_flag_wait
+    sa, sb, rejected = torch.cuda.Stream(), None, []
+    for _ in range(12):
+        cand = torch.cuda.Stream()
+        rc = lib.miseg_streams_run_concurrently(C.c_void_p(sa.cuda_stream), C.c_void_p(cand.cuda_stream))
+        assert rc >= 0, lib.miseg_last_error()
+        if rc == 1:
+            sb = cand
+            break
+        rejected.append(cand)          # kept alive: a destroyed stream's queue slot would be handed out again
+    assert sb is not None, "no second stream on a hardware queue of its own in 12 tries"
+    with pytest.raises(ValueError):
+        hiplib.check(lib.miseg_streams_run_concurrently(C.c_void_p(sa.cuda_stream), C.c_void_p(sa.cuda_stream)), "streams_run_concurrently")
     torch.cuda.synchronize()
     with torch.cuda.stream(sb):      # the consumer first: it must wait on the device
         hiplib.check(lib.miseg_flag_wait(P(flag), P(want), 1000000, P(tout), C.c_void_p(sb.cuda_stream)), "flag_wait")
@@ -979,7 +992,8 @@ def test_flag_wait_orders_two_streams_on_the_device_and_gives_up_after_its_timeo
         data.fill_(7.0)
         hiplib.check(lib.miseg_counter_copy(P(flag), P(one), C.c_void_p(sa.cuda_stream)), "counter_copy")
     torch.cuda.synchronize()
-    assert int(tout.item()) == 0 and bool((seen == 7.0).all())
+    assert int(tout.item()) == 0, "the waiter ran into its timeout: its results are void (a hard error, never a statistic)"
+    assert bool((seen == 7.0).all())
     # (b) nobody sets flag >= 5: the wait gives up after ~2 ms
     want.fill_(5)
     t0 = time.perf_counter()
