@@ -113,6 +113,9 @@ int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stream_t stream
 /* miseg_instnorm_bwd whose incoming gradient is still the partial slabs of a split data-gradient convolution (as miseg_instnorm_fwd_slabs):
  * p->dy is ignored (the gradient is summed and rounded in registers and never written).  S <= miseg_instnorm_fused_max_rows() only. */
 int miseg_instnorm_bwd_slabs(const miseg_instnorm_bwd_params* p, const float* slabs, int nslabs, int64_t slab_stride, miseg_stream_t stream);
+/* the apply half alone (ABI 8): p->dstat already HOLDS the backward sums (sum dy, sum dy * xhat) - the GEMM that produced dy added them in
+ * its epilogue (miseg_gemm_params.stat_mode 2, miseg_mlp_params.bs_dstat).  No activation.  dx, dgamma / dbeta as miseg_instnorm_bwd. */
+int miseg_instnorm_bwd_apply(const miseg_instnorm_bwd_params* p, miseg_stream_t stream);
 /* the reduction half alone (ABI 5): dstat[r][b][c] += (sum dy, sum dy * xhat) over the rows of sample b, xhat from `stat` - what the group /
  * batch norms of the reference's factory (networks/layers/factories.py:219-257) need besides the kernels above (their means run over channel
  * groups / the whole batch: mi-seg_amd/hip/functional.py::group_norm).  Reads dy, x, stat, eps, styles / gamma / beta only with an activation. */
@@ -158,6 +161,15 @@ typedef struct {
 } miseg_layernorm_bwd_params;
 int miseg_layernorm_bwd(const miseg_layernorm_bwd_params* p, miseg_stream_t stream);
 
+/* a (conditional) instance norm whose apply pass is folded into the operand load of a consumer kernel (ABI 8; one sample): its statistics
+ * and affine rows.  stat == NULL: no fold. */
+typedef struct {
+  const void* stat;                 /* fp64 [16][1][C][2], miseg_instnorm_stats layout: (sum x, sum x^2) of the norm's raw input */
+  const int32_t* styles;            /* device [1] (the sample's style id) or NULL = style 0 */
+  int32_t num_styles; float eps;
+  const float* gamma[MISEG_MAX_STYLES]; const float* beta[MISEG_MAX_STYLES];      /* rows per style; NULL = no affine */
+} miseg_norm_ref;
+
 /* ------------------------------------------------------------------------------------------------
  * GEMM on the matrix cores:  C[M][N] = A * B (+ bias[N]) (-> act).
  * Replaces every nn.Linear on the path (window_attention.py:92,94 qkv/proj; MONAI MLPBlock used at
@@ -195,8 +207,22 @@ typedef struct {
    * (voxel (d,h,w), j, co) goes to row (2d+jd, 2h+jh, 2w+jw) of the [.., 2 scat_d, 2 scat_h, 2 scat_w] grid, column co, of C (row stride ldc -
    * e.g. the left half of a concat buffer).  Only where miseg_gemm_fuses_scatter(p) says so. */
   int scat_d, scat_h, scat_w, scat_cout;
+  /* NT, optional (ABI 8), only where miseg_gemm_fuses_anorm(p) says so: A is the RAW input of a (conditional) instance norm over its M rows
+   * (ONE sample) and is normalised as it is loaded - C = act(norm(A) B + bias) + res without the norm's apply pass (the Swin block's
+   * norm1 -> qkv and norm2 -> fc1, swin_transformer_block.py:103,176-205).  an.stat: the norm's statistics (miseg_instnorm_stats layout, complete
+   * when this launch starts).  an_out (optional): norm(A) [M][K] is stored as well, once, rounded exactly as miseg_instnorm_apply rounds
+   * it - the operand of the weight-gradient product of the backward pass. */
+  miseg_norm_ref an; void* an_out; int64_t ld_an_out;
+  /* NT, optional (ABI 8), only where miseg_gemm_fuses_bstat(p) says so: stat_mode 2 - C [M][N] is the gradient with respect to the OUTPUT of an
+   * instance norm (one sample = the M rows) whose raw input is bs_x [M][N] with forward statistics bs_stat: `stat` receives that norm's
+   * backward sums (sum C, sum C * xhat) in the dstat layout of miseg_instnorm_bwd (zero on entry), from the rounded C - miseg_instnorm_bwd_apply
+   * then needs no reduction launch.  stat_mode 0: `stat` = forward statistics as above. */
+  int stat_mode;
+  const void* bs_x; int64_t ld_bs_x; const void* bs_stat; float bs_eps;
 } miseg_gemm_params;
 int miseg_gemm_fuses_stat(const miseg_gemm_params* p);  /* 1: miseg_gemm(p) with p->stat set is supported for this problem */
+int miseg_gemm_fuses_anorm(const miseg_gemm_params* p); /* 1: ... with p->an.stat set (whatever an_out) */
+int miseg_gemm_fuses_bstat(const miseg_gemm_params* p); /* 1: ... with p->stat, stat_mode 2 and the bs_* fields set */
 /* instance-norm statistics (layout of miseg_instnorm_stats, one sample = all M rows, zero on entry) of the rank-1 product
  * round(x[m] * w[n]) WITHOUT storing it: the stem block's shortcut convolution (dynunet_block.py:87-97), consumed through the r1x / r1w
  * fields of miseg_instnorm_apply / miseg_instnorm_pair_bwd.  x: [M] rows of one element (stride ldx), w: [N] (stride ldw), N <= 128 */
@@ -218,6 +244,13 @@ typedef struct {
   const void* dy; int64_t lddy;            /* backward */
   const void* w2t; const void* w1t;
   void* dz; int64_t lddz; void* h; int64_t ldh; void* dx; int64_t lddx;
+  /* ABI 8, optional.  Forward: an.stat != NULL - x is the RAW input of the (conditional) instance norm in front of the MLP (one sample; the
+   * Swin block's norm2) and is normalised as it is loaded; an_out (optional) receives norm(x) [M][C] for the backward pass (which takes it
+   * as its `x`).  Backward: bs_dstat != NULL - dx is the gradient with respect to that norm's OUTPUT; the norm's backward sums (sum dx,
+   * sum dx * xhat; xhat from the raw input bs_x and the forward statistics bs_stat) are added to bs_dstat (dstat layout of miseg_instnorm_bwd,
+   * zero on entry): miseg_instnorm_bwd_apply then needs no reduction launch. */
+  miseg_norm_ref an; void* an_out; int64_t ld_an_out;
+  const void* bs_x; int64_t ld_bs_x; const void* bs_stat; float bs_eps; void* bs_dstat;
 } miseg_mlp_params;
 int miseg_mlp_fused(int M, int C, int HID, int dtype);      /* 1: the two calls below support this problem */
 int miseg_mlp_fwd(const miseg_mlp_params* p, miseg_stream_t stream);

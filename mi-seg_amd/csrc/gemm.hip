@@ -61,7 +61,31 @@ struct Epi {
   double* stat;      // streaming kernel, STAT instantiation: instance-norm statistics of the (rounded) output, one sample (M rows)
   int sd, sh, sw, sco;   // streaming kernel, SCAT instantiation: rows are the voxels of a [.., sd, sh, sw] grid, columns are (j, co) with
                          // j = 4 jd + 2 jh + jw: element (voxel, j, co) goes to row ((2d+jd), (2h+jh), (2w+jw)) of the doubled grid, column co
+  // streaming kernel, STAT == 2 (round 5): the output is the gradient with respect to the OUTPUT of an instance norm whose raw input is
+  // bx [M][N]; `stat` then receives that norm's backward sums (sum q, sum q * xhat), xhat = (bx - mean) * rstd from bstat_in (the norm's
+  // forward statistics) - what instnorm_bwd_reduce_kernel computes from the stored tensor in a launch of its own
+  const void* bx; int64_t ldbx; const double* bstat_in; float beps;
+  // streaming kernel, ANORM (round 5): A is the RAW input of a (conditional) instance norm over its M rows (one sample) and is normalised as
+  // it is loaded - fma(x, sc, sh) with the scale / shift of instnorm_apply_kernel, rounded to bf16 exactly as that kernel stores it; an_out
+  // (optional) receives norm(A) once (column group 0), for the weight-gradient product of the backward pass
+  const double* an_stat; const int32_t* an_styles; const float* an_gamma[MISEG_MAX_STYLES]; const float* an_beta[MISEG_MAX_STYLES]; float an_eps;
+  void* an_out; int64_t ld_an_out;
 };
+
+// mean and 1 / sqrt(var + eps) of one channel from its fp64 (sum, sum of squares) over S rows: the arithmetic of norm.hip::mean_rstd, bit for bit
+__device__ __forceinline__ void gemm_mean_rstd(double sum, double sq, double invS, float eps, float& m, float& rs) {
+  const double mu = sum * invS;
+  double var = fma(sq, invS, -mu * mu);
+  if (var < 0.0) var = 0.0;
+  m = (float)mu;
+  rs = 1.0f / sqrtf((float)var + eps);
+}
+// sum over the 16 replicas of a one-sample statistics buffer [16][1][C][2]
+__device__ __forceinline__ void gemm_gather_stat(const double* __restrict__ stat, int C, int ch, double& sum, double& sq) {
+  sum = 0.0; sq = 0.0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { sum += stat[((int64_t)r * C + ch) * 2]; sq += stat[((int64_t)r * C + ch) * 2 + 1]; }
+}
 
 template <class TO>
 __device__ __forceinline__ float epi_one(float x, int m, int n, const Epi& e) {
@@ -288,8 +312,10 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_g;
 // STAT (N <= 16 * NCH, one sample): per-column sum / sum of squares of the rounded output accumulate in registers over all the tiles of
 // a wave and are added once per workgroup to the replicated fp64 statistics buffer of the instance norm that consumes the output
 // (proj + residual and fc2 + residual feed norm2 / the next block's norm1, the 1x1x1 shortcut conv feeds norm3): no separate pass.
+// STAT == 2 / ANORM (round 5): see struct Epi - the norm-backward reduction in the data-gradient GEMM that produces the norm's output gradient,
+// and the norm's apply pass folded into the operand load of the GEMM that consumes its output (Swin qkv / fc1: swin_transformer_block.py:103,176).
 template <int K16, bool GELU, int NCH = 12 /* n-tiles per accumulator chunk: fewer for the long rows (K >= 288), whose A fragments fill the registers */,
-          bool STAT = false, bool SCAT = false>
+          int STAT = 0, bool SCAT = false, bool ANORM = false>
 __global__ void __launch_bounds__(256, 2) gemm_nt_stream_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ W, int64_t ldw,
                                                                 bf16* __restrict__ C, int64_t ldc, int M, int Nfull, Epi epi, int N) {
   // blockIdx.y = column group of N columns (the mid-size token counts: 13,824 rows are 108 workgroups of 128 rows - with the whole weight
@@ -312,10 +338,73 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_stream_kernel(const bf16* __re
     *reinterpret_cast<bf16x8*>(lds + row * ROWB + ch * 16) = *reinterpret_cast<const bf16x8*>(W + (int64_t)row * ldw + ch * 8);
   }
   for (int n = tid; n < N; n += 256) lbias[n] = bias ? bias[n] : 0.f;
+  float* lmean = lbias + N;          // STAT == 2: mean / rstd of the norm whose output gradient this GEMM produces, columns of this group
+  float* lrstd = lmean + N;
+  float* lsc = lbias + N + (STAT == 2 ? 2 * N : 0);      // ANORM: scale / shift per k
+  float* lsh = lsc + K;
+  if constexpr (STAT == 2) {
+    for (int n = tid; n < N; n += 256) {
+      double a, b;
+      gemm_gather_stat(epi.bstat_in, Nfull, n_off + n, a, b);
+      float m_, r_;
+      gemm_mean_rstd(a, b, 1.0 / M, epi.beps, m_, r_);
+      lmean[n] = m_;
+      lrstd[n] = r_;
+    }
+  }
+  if constexpr (ANORM) {
+    const int st = epi.an_styles ? epi.an_styles[0] : 0;
+    const float* g = epi.an_gamma[st];
+    const float* be = epi.an_beta[st];
+    for (int k = tid; k < K; k += 256) {
+      double a, b;
+      gemm_gather_stat(epi.an_stat, K, k, a, b);
+      float m_, r_;
+      gemm_mean_rstd(a, b, 1.0 / M, epi.an_eps, m_, r_);
+      const float sc = r_ * (g ? g[k] : 1.f);
+      lsc[k] = sc;
+      lsh[k] = (be ? be[k] : 0.f) - m_ * sc;
+    }
+  }
   __syncthreads();
   const int ntiles = N / 16, mtiles = (M + 31) / 32, nwaves = gridDim.x * 4;
   bf16x8 cur[2][KS32 > 0 ? KS32 : 1], nxt[2][KS32 > 0 ? KS32 : 1];
   bf16x4 curt[2], nxtt[2];
+  // ANORM: this lane's scale / shift (k = ks * 32 + 8 kg + e, tail k = KS32 * 32 + 4 kg + e) stay in registers
+  float asc[ANORM ? (KS32 > 0 ? KS32 : 1) : 1][8], ash[ANORM ? (KS32 > 0 ? KS32 : 1) : 1][8], asct[4], asht[4];
+  if constexpr (ANORM) {
+#pragma unroll
+    for (int ks = 0; ks < KS32; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { asc[ks][e] = lsc[ks * 32 + 8 * kg + e]; ash[ks][e] = lsh[ks * 32 + 8 * kg + e]; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { asct[e] = TAIL ? lsc[KS32 * 32 + 4 * kg + e] : 0.f; asht[e] = TAIL ? lsh[KS32 * 32 + 4 * kg + e] : 0.f; }
+  }
+  // normalise the fragments of one 32-row tile in place (and store them once: column group 0 of the grid)
+  auto normA = [&](int tile_, bf16x8 (&f)[2][KS32 > 0 ? KS32 : 1], bf16x4 (&t)[2]) {
+    if constexpr (ANORM) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int row = tile_ * 32 + mt * 16 + fi;
+        bf16* orow = (epi.an_out && blockIdx.y == 0 && row < M) ? reinterpret_cast<bf16*>(epi.an_out) + (int64_t)row * epi.ld_an_out : nullptr;
+#pragma unroll
+        for (int ks = 0; ks < KS32; ++ks) {
+          bf16x8 v = f[mt][ks];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (bf16)fmaf((float)v[e], asc[ks][e], ash[ks][e]);
+          f[mt][ks] = v;
+          if (orow) *reinterpret_cast<bf16x8*>(orow + ks * 32 + 8 * kg) = v;
+        }
+        if (TAIL) {
+          bf16x4 v = t[mt];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (bf16)fmaf((float)v[e], asct[e], asht[e]);
+          t[mt] = v;
+          if (orow) *reinterpret_cast<bf16x4*>(orow + KS32 * 32 + 4 * kg) = v;
+        }
+      }
+    }
+  };
   auto loadA = [&](int tile, bf16x8 (&f)[2][KS32 > 0 ? KS32 : 1], bf16x4 (&t)[2]) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -332,7 +421,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_stream_kernel(const bf16* __re
 #pragma unroll
     for (int r = 0; r < 4; ++r) { ssum[j][r] = 0.f; ssq[j][r] = 0.f; }
   int tile = blockIdx.x * 4 + wave;
-  if (tile < mtiles) loadA(tile, cur, curt);
+  if (tile < mtiles) { loadA(tile, cur, curt); normA(tile, cur, curt); }
   for (; tile < mtiles; tile += nwaves) {
     if (tile + nwaves < mtiles) loadA(tile + nwaves, nxt, nxtt);
     for (int nc = 0; nc < ntiles; nc += NCH) {
@@ -382,9 +471,15 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_stream_kernel(const bf16* __re
               } else {
                 *reinterpret_cast<bf16x4*>(crow + n) = o4;
               }
-              if constexpr (STAT) {
+              if constexpr (STAT == 1) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const float q = (float)o4[r]; ssum[j][r] += q; ssq[j][r] = fmaf(q, q, ssq[j][r]); }
+              }
+              if constexpr (STAT == 2) {      // the terms of instnorm_bwd_reduce_kernel: s += g, q = fma(g, (x - m) * rs, q)
+                const bf16x4 x4 = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(epi.bx) + n_off + (int64_t)row * epi.ldbx + n);
+                const f32x4 m4 = *reinterpret_cast<const f32x4*>(lmean + n), r4 = *reinterpret_cast<const f32x4*>(lrstd + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float q = (float)o4[r]; ssum[j][r] += q; ssq[j][r] = fmaf(q, ((float)x4[r] - m4[r]) * r4[r], ssq[j][r]); }
               }
             }
           }
@@ -397,8 +492,9 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_stream_kernel(const bf16* __re
       for (int ks = 0; ks < KS32; ++ks) cur[mt][ks] = nxt[mt][ks];
       curt[mt] = nxtt[mt];
     }
+    if (tile + nwaves < mtiles) normA(tile + nwaves, cur, curt);
   }
-  if constexpr (STAT) {
+  if constexpr (STAT != 0) {
     // lane (fi = row, kg) holds columns j * 16 + 4 kg + r: every lane's partials go to LDS ([k][column][wave * 16 + fi], 65-float rows),
     // one thread per (column, k) adds the 64 of them; the weight image is dead once every wave is past its last tile
     __syncthreads();
@@ -833,6 +929,30 @@ extern "C" int miseg_gemm_fuses_stat(const miseg_gemm_params* p) {
          p->M >= 4096 && lds <= 96 * 1024 && al_a && al_b && ((uintptr_t)p->C % 8 == 0) && p->ldc % 4 == 0 && epi_vec_ok;
 }
 
+// the streaming NT kernel with the consumer-side norm fold (ANORM): Swin qkv / fc1 at the high-resolution stages
+static bool nt_stream_common_ok(const miseg_gemm_params* p) {
+  if (!p || p->ta || p->tb || p->dtype != MISEG_BF16 || p->out_dtype != MISEG_BF16) return false;
+  const bool al_a = ((uintptr_t)p->A % 16 == 0) && (p->lda % 8 == 0), al_b = ((uintptr_t)p->B % 16 == 0) && (p->ldb % 8 == 0);
+  const bool epi_vec_ok = (!p->res || (((uintptr_t)p->res % 8 == 0) && p->ldres % 4 == 0)) && (!p->epi_mode || (((uintptr_t)p->aux % 8 == 0) && p->ldaux % 4 == 0));
+  return p->split_k <= 1 && !p->accumulate && p->N % 16 == 0 && p->M >= 4096 && al_a && al_b && ((uintptr_t)p->C % 8 == 0) && p->ldc % 4 == 0 && epi_vec_ok &&
+         !p->scat_cout;
+}
+extern "C" int miseg_gemm_fuses_anorm(const miseg_gemm_params* p) {
+  if (!nt_stream_common_ok(p) || !(p->K == 48 || p->K == 96) || p->stat) return 0;
+  if (p->an.num_styles < 1 || p->an.num_styles > MISEG_MAX_STYLES) return 0;
+  if (p->an_out && (((uintptr_t)p->an_out % 16) != 0 || p->ld_an_out % 8 != 0)) return 0;
+  const size_t lds = (size_t)p->N * (p->K * 2 + 16) + (size_t)p->N * 4;
+  return lds <= 96 * 1024;
+}
+// ... with the norm-backward sums of its output (STAT == 2): the data-gradient GEMMs behind qkv / fc1
+extern "C" int miseg_gemm_fuses_bstat(const miseg_gemm_params* p) {
+  if (!nt_stream_common_ok(p) || p->act != MISEG_ACT_NONE || p->epi_mode || p->an.stat) return 0;
+  if (!(p->K == 144 || p->K == 288 || p->K == 384 || p->K == 48 || p->K == 96 || p->K == 192) || !(p->N == 48 || p->N == 96)) return 0;
+  if (!p->bs_x || ((uintptr_t)p->bs_x % 8) != 0 || p->ld_bs_x % 4 != 0) return 0;
+  const size_t lds = (size_t)p->N * (p->K * 2 + 16) + (size_t)p->N * 4;
+  return lds <= 96 * 1024;
+}
+
 extern "C" int miseg_rank1_stats(const void* x, int64_t ldx, const void* w, int64_t ldw, int M, int N, int dtype, void* stat, miseg_stream_t stream_) {
   hipStream_t s = (hipStream_t)stream_;
   MISEG_REQUIRE(x && w && stat && M > 0 && N > 0 && N <= 128, MISEG_E_BADARG, "rank1_stats: bad args");
@@ -865,6 +985,8 @@ extern "C" size_t miseg_gemm_workspace_bytes(const miseg_gemm_params* p) {
 
 extern "C" int miseg_gemm_fuses_stat(const miseg_gemm_params* p);
 extern "C" int miseg_gemm_fuses_scatter(const miseg_gemm_params* p);
+extern "C" int miseg_gemm_fuses_anorm(const miseg_gemm_params* p);
+extern "C" int miseg_gemm_fuses_bstat(const miseg_gemm_params* p);
 
 // column groups of the streaming NT kernel: the smallest divisor d of the N / 16 column tiles that brings the grid to >= 300 workgroups
 static int nt_stream_groups(int blocks, int N) {
@@ -884,10 +1006,17 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
   if (split > 1 && !f32out) return set_error(MISEG_E_BADARG, "gemm: split_k needs fp32 output");
   if (p->accumulate && !f32out) return set_error(MISEG_E_BADARG, "gemm: accumulate needs fp32 output");
   int mode = split > 1 ? 2 : (p->accumulate ? 1 : 0);
-  const Epi epi{p->bias, p->act, p->res, p->ldres, p->aux, p->ldaux, p->epi_mode, (double*)p->stat, p->scat_d, p->scat_h, p->scat_w, p->scat_cout};
+  Epi epi{p->bias, p->act, p->res, p->ldres, p->aux, p->ldaux, p->epi_mode, (double*)p->stat, p->scat_d, p->scat_h, p->scat_w, p->scat_cout};
+  epi.bx = p->bs_x; epi.ldbx = p->ld_bs_x; epi.bstat_in = (const double*)p->bs_stat; epi.beps = p->bs_eps;
+  epi.an_stat = (const double*)p->an.stat; epi.an_styles = p->an.styles; epi.an_eps = p->an.eps; epi.an_out = p->an_out; epi.ld_an_out = p->ld_an_out;
+  for (int i = 0; i < MISEG_MAX_STYLES; ++i) { epi.an_gamma[i] = i < p->an.num_styles ? p->an.gamma[i] : nullptr; epi.an_beta[i] = i < p->an.num_styles ? p->an.beta[i] : nullptr; }
+  const bool bstat = p->stat && p->stat_mode == 2;
+  if (p->an.stat && !miseg_gemm_fuses_anorm(p)) return set_error(MISEG_E_UNSUPPORTED, "gemm: folded instance norm on this shape / path (ask miseg_gemm_fuses_anorm first)");
+  if (bstat && !miseg_gemm_fuses_bstat(p)) return set_error(MISEG_E_UNSUPPORTED, "gemm: norm-backward sums on this shape / path (ask miseg_gemm_fuses_bstat first)");
+  if (p->stat && p->stat_mode != 0 && p->stat_mode != 2) return set_error(MISEG_E_BADARG, "gemm: stat_mode %d", p->stat_mode);
   const bool epi_vec_ok = (!p->res || (((uintptr_t)p->res % 8 == 0) && p->ldres % 4 == 0)) && (!p->epi_mode || (((uintptr_t)p->aux % 8 == 0) && p->ldaux % 4 == 0));
   if (p->scat_cout && !miseg_gemm_fuses_scatter(p)) return set_error(MISEG_E_UNSUPPORTED, "gemm: scattered (transposed-conv) store on this shape / path (ask miseg_gemm_fuses_scatter first)");
-  if (p->stat && !miseg_gemm_fuses_stat(p)) return set_error(MISEG_E_UNSUPPORTED, "gemm: fused statistics on this shape / path (ask miseg_gemm_fuses_stat first)");
+  if (p->stat && !bstat && !miseg_gemm_fuses_stat(p)) return set_error(MISEG_E_UNSUPPORTED, "gemm: fused statistics on this shape / path (ask miseg_gemm_fuses_stat first)");
   if (p->ta == 0 && p->tb == 0) {
     if ((p->res || p->epi_mode) && (split > 1 || p->accumulate)) return set_error(MISEG_E_BADARG, "gemm: residual / auxiliary epilogue with split_k or accumulate");
     if (p->epi_mode && !p->aux) return set_error(MISEG_E_BADARG, "gemm: epi_mode %d needs aux", p->epi_mode);
@@ -971,7 +1100,50 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
       const bool st_ok = split == 1 && !p->accumulate && (p->K == 48 || p->K == 96 || p->K == 192 || p->K == 144 || p->K == 288 || p->K == 384) && p->N % 16 == 0 && p->M >= 4096 && lds <= 96 * 1024 &&
                          al_a && al_b && ((uintptr_t)p->C % 8 == 0) && p->ldc % 4 == 0 && epi_vec_ok;
       const bool stat_ok = st_ok && p->act == MISEG_ACT_NONE && p->N <= 96 && (p->K == 48 || p->K == 96 || p->K == 192);
-      if (p->stat && !stat_ok) return set_error(MISEG_E_UNSUPPORTED, "gemm: fused statistics on this shape / path (ask miseg_gemm_fuses_stat first)");
+      if (p->stat && !bstat && !stat_ok) return set_error(MISEG_E_UNSUPPORTED, "gemm: fused statistics on this shape / path (ask miseg_gemm_fuses_stat first)");
+      if (p->an.stat) {          // miseg_gemm_fuses_anorm held: K in {48, 96}; the norm's apply pass rides in the operand load
+        const int mtiles = cdiv(p->M, 32);
+        int blocks = cdiv(mtiles, 4);
+        const int cap = lds > 80 * 1024 ? 256 : 512;
+        if (blocks > cap) blocks = cap;
+        const int ns = nt_stream_groups(blocks, p->N), nper = p->N / ns;
+        const size_t ldsa = (size_t)nper * (p->K * 2 + 16) + (size_t)nper * 4 + (size_t)2 * p->K * 4;
+#define AN_CASE(k16, g)                                                                                                                       \
+  (void)hipFuncSetAttribute((const void*)gemm_nt_stream_kernel<k16, g, 12, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsa); \
+  gemm_nt_stream_kernel<k16, g, 12, 0, false, true><<<dim3(blocks, ns), 256, ldsa, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, epi, nper)
+        const bool ge = p->act == MISEG_ACT_GELU;
+        if (p->K == 48) { if (ge) { AN_CASE(3, true); } else { AN_CASE(3, false); } }
+        else { if (ge) { AN_CASE(6, true); } else { AN_CASE(6, false); } }
+#undef AN_CASE
+        MISEG_LAUNCH_CHECK("gemm_nt_stream(anorm)");
+        return MISEG_OK;
+      }
+      if (bstat) {               // miseg_gemm_fuses_bstat held: N in {48, 96}; the norm-backward reduction rides in the epilogue
+        const int mtiles = cdiv(p->M, 32);
+        int blocks = cdiv(mtiles, 4);
+        if (blocks > 512) blocks = 512;
+        const int nch = p->K >= 384 ? 3 : 6;
+        int ns = nt_stream_groups(blocks, p->N);
+        while (p->N / ns > 16 * nch) ++ns;          // one accumulator chunk per column group (the sums are indexed by the chunk's tile)
+        while ((p->N / 16) % ns) ++ns;
+        const int nper = p->N / ns;
+        size_t ldsb = (size_t)nper * (p->K * 2 + 16) + (size_t)nper * 4 * 3;
+        if (ldsb < (size_t)2 * nper * 65 * sizeof(float)) ldsb = (size_t)2 * nper * 65 * sizeof(float);
+#define BS_CASE(k16, nch_)                                                                                                                      \
+  (void)hipFuncSetAttribute((const void*)gemm_nt_stream_kernel<k16, false, nch_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); \
+  gemm_nt_stream_kernel<k16, false, nch_, 2><<<dim3(blocks, ns), 256, ldsb, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, epi, nper)
+        switch (p->K) {
+          case 48: BS_CASE(3, 6); break;
+          case 96: BS_CASE(6, 6); break;
+          case 192: BS_CASE(12, 6); break;
+          case 144: BS_CASE(9, 6); break;
+          case 288: BS_CASE(18, 6); break;
+          default: BS_CASE(24, 3); break;
+        }
+#undef BS_CASE
+        MISEG_LAUNCH_CHECK("gemm_nt_stream(bstat)");
+        return MISEG_OK;
+      }
       if (p->scat_cout) {        // miseg_gemm_fuses_scatter held: st_ok, K in {48, 96}
         const int mtiles = cdiv(p->M, 32);
         int blocks = cdiv(mtiles, 4);

@@ -46,17 +46,40 @@ __device__ __forceinline__ void mlp_stage(char* img, int rowb, const bf16* __res
 }
 __device__ __forceinline__ s16x4_m mlp_frag(const char* img, int rowb, int row, int k) { return *reinterpret_cast<const s16x4_m*>(img + row * rowb + k * 2); }
 
+// round 5: the (conditional) instance norm in front of the MLP (norm2 of the Swin block, swin_transformer_block.py:176-205) folded into
+// the token load (ANORM: x is the norm's RAW input, one sample; fma(x, sc, sh) rounded to bf16 exactly as instnorm_apply_kernel stores it;
+// `out` receives norm(x) for the backward pass), and the norm's backward sums (sum dx, sum dx * xhat) in the epilogue of mlp_bwd_kernel (BSTAT)
+struct MlpNorm {
+  const double* stat; const int32_t* styles; const float* gamma[MISEG_MAX_STYLES]; const float* beta[MISEG_MAX_STYLES]; float eps;
+  bf16* out; int64_t ldo;
+};
+struct MlpBstat { const bf16* x; int64_t ldx; const double* stat_in; float eps; double* dstat; };
+
+// (norm.hip::mean_rstd / gather_stat for one channel of a one-sample statistics buffer [16][1][C][2])
+__device__ __forceinline__ void mlp_mean_rstd(const double* __restrict__ stat, int C, int ch, double invS, float eps, float& m, float& rs) {
+  double sum = 0.0, sq = 0.0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { sum += stat[((int64_t)r * C + ch) * 2]; sq += stat[((int64_t)r * C + ch) * 2 + 1]; }
+  const double mu = sum * invS;
+  double var = fma(sq, invS, -mu * mu);
+  if (var < 0.0) var = 0.0;
+  m = (float)mu;
+  rs = 1.0f / sqrtf((float)var + eps);
+}
+
 // STAT: instance-norm statistics of the rounded output (one sample), layout / reduction of gemm_nt_stream_kernel
 static constexpr int MLP_FWD_WAVES = 8;
-template <bool STAT>
+template <bool STAT, bool ANORM = false>
 __global__ void __launch_bounds__(MLP_FWD_WAVES * 64, 2) mlp_fwd_kernel(const bf16* __restrict__ x, int64_t ldx, const bf16* __restrict__ w1, const float* __restrict__ b1,
                                                          const bf16* __restrict__ w2, const float* __restrict__ b2, const bf16* __restrict__ res, int64_t ldres,
-                                                         bf16* __restrict__ y, int64_t ldy, int M, double* __restrict__ stat) {
+                                                         bf16* __restrict__ y, int64_t ldy, int M, double* __restrict__ stat, MlpNorm an) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* w1i = lds;                                  // [HID][C]
   char* w2i = w1i + MLP_H * MLP_ROW_C;              // [C][HID]
   float* lb1 = reinterpret_cast<float*>(w2i + MLP_C * MLP_ROW_H);
   float* lb2 = lb1 + MLP_H;
+  float* lsc = lb2 + MLP_C;                         // ANORM: scale / shift per channel
+  float* lsh = lsc + MLP_C;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fi = lane & 15, kg = lane >> 4;
   const int mtiles = (M + 15) / 16, nwaves = gridDim.x * MLP_FWD_WAVES;
   s16x4_m xc[MLP_CS], xn[MLP_CS];
@@ -71,7 +94,41 @@ __global__ void __launch_bounds__(MLP_FWD_WAVES * 64, 2) mlp_fwd_kernel(const bf
   mlp_stage(w2i, MLP_ROW_H, w2, MLP_C, MLP_H);
   for (int i = tid; i < MLP_H; i += MLP_FWD_WAVES * 64) lb1[i] = b1 ? b1[i] : 0.f;
   for (int i = tid; i < MLP_C; i += MLP_FWD_WAVES * 64) lb2[i] = b2 ? b2[i] : 0.f;
+  if constexpr (ANORM) {
+    const int st = an.styles ? an.styles[0] : 0;
+    const float* g = an.gamma[st];
+    const float* be = an.beta[st];
+    for (int k = tid; k < MLP_C; k += MLP_FWD_WAVES * 64) {
+      float m_, r_;
+      mlp_mean_rstd(an.stat, MLP_C, k, 1.0 / M, an.eps, m_, r_);
+      const float sc = r_ * (g ? g[k] : 1.f);
+      lsc[k] = sc;
+      lsh[k] = (be ? be[k] : 0.f) - m_ * sc;
+    }
+  }
   __syncthreads();
+  float asc[MLP_CS][4], ash[MLP_CS][4];
+  if constexpr (ANORM) {
+#pragma unroll
+    for (int s = 0; s < MLP_CS; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { asc[s][e] = lsc[16 * s + 4 * kg + e]; ash[s][e] = lsh[16 * s + 4 * kg + e]; }
+  }
+  auto normx = [&](int tile_, s16x4_m (&f)[MLP_CS]) {
+    if constexpr (ANORM) {
+      const int row = tile_ * 16 + fi;
+      bf16* orow = (an.out && row < M) ? an.out + (int64_t)row * an.ldo + 4 * kg : nullptr;
+#pragma unroll
+      for (int s = 0; s < MLP_CS; ++s) {
+        bf16x4 v = __builtin_bit_cast(bf16x4, f[s]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (bf16)fmaf((float)v[e], asc[s][e], ash[s][e]);
+        f[s] = __builtin_bit_cast(s16x4_m, v);
+        if (orow) *reinterpret_cast<bf16x4*>(orow + 16 * s) = v;
+      }
+    }
+  };
+  if (blockIdx.x * MLP_FWD_WAVES + wave < mtiles) normx(blockIdx.x * MLP_FWD_WAVES + wave, xc);
   float ssum[MLP_CS][4], ssq[MLP_CS][4];
 #pragma unroll
   for (int i = 0; i < MLP_CS; ++i)
@@ -116,6 +173,7 @@ __global__ void __launch_bounds__(MLP_FWD_WAVES * 64, 2) mlp_fwd_kernel(const bf
     }
 #pragma unroll
     for (int s = 0; s < MLP_CS; ++s) xc[s] = xn[s];
+    if (tile + nwaves < mtiles) normx(tile + nwaves, xc);
   }
   if constexpr (STAT) {
     __syncthreads();      // the weight images are dead once every wave is past its last tile
@@ -143,10 +201,11 @@ __global__ void __launch_bounds__(MLP_FWD_WAVES * 64, 2) mlp_fwd_kernel(const bf
 
 // 8 waves per workgroup: the three weight images (63 KB) allow two workgroups per CU, and 16 resident waves hide the GELU's vector work
 static constexpr int MLP_BWD_WAVES = 8;
+template <bool BSTAT>
 __global__ void __launch_bounds__(MLP_BWD_WAVES * 64, 2) mlp_bwd_kernel(const bf16* __restrict__ x, int64_t ldx, const bf16* __restrict__ dy, int64_t lddy,
                                                          const bf16* __restrict__ w1, const float* __restrict__ b1, const bf16* __restrict__ w2t,
                                                          const bf16* __restrict__ w1t, bf16* __restrict__ dz, int64_t lddz, bf16* __restrict__ h, int64_t ldh,
-                                                         bf16* __restrict__ dx, int64_t lddx, int M) {
+                                                         bf16* __restrict__ dx, int64_t lddx, int M, MlpBstat bs) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* w1i = lds;                                  // [HID][C]   z = W1 x
   char* w2ti = w1i + MLP_H * MLP_ROW_C;             // [HID][C]   dh = W2^T dy
@@ -168,7 +227,17 @@ __global__ void __launch_bounds__(MLP_BWD_WAVES * 64, 2) mlp_bwd_kernel(const bf
   mlp_stage(w2ti, MLP_ROW_C, w2t, MLP_H, MLP_C);
   mlp_stage(w1ti, MLP_ROW_H, w1t, MLP_C, MLP_H);
   for (int i = tid; i < MLP_H; i += MLP_BWD_WAVES * 64) lb1[i] = b1 ? b1[i] : 0.f;
+  float* lmean = lb1 + MLP_H;        // BSTAT: mean / rstd of the norm in front of the MLP
+  float* lrstd = lmean + MLP_C;
+  if constexpr (BSTAT) {
+    for (int k = tid; k < MLP_C; k += MLP_BWD_WAVES * 64) mlp_mean_rstd(bs.stat_in, MLP_C, k, 1.0 / M, bs.eps, lmean[k], lrstd[k]);
+  }
   __syncthreads();
+  float bsum[MLP_CS][4], bsq[MLP_CS][4];
+#pragma unroll
+  for (int i = 0; i < MLP_CS; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { bsum[i][r] = 0.f; bsq[i][r] = 0.f; }
   for (; tile < mtiles; tile += nwaves) {
     if (tile + nwaves < mtiles) load2(tile + nwaves, xn, gn);
     const int row = tile * 16 + fi;
@@ -205,11 +274,41 @@ __global__ void __launch_bounds__(MLP_BWD_WAVES * 64, 2) mlp_bwd_kernel(const bf
     }
     if (live && dx) {
 #pragma unroll
-      for (int i = 0; i < MLP_CS; ++i)
-        *reinterpret_cast<bf16x4*>(dx + (int64_t)row * lddx + 16 * i + 4 * kg) = bf16x4{(bf16)dxacc[i][0], (bf16)dxacc[i][1], (bf16)dxacc[i][2], (bf16)dxacc[i][3]};
+      for (int i = 0; i < MLP_CS; ++i) {
+        const bf16x4 o4 = bf16x4{(bf16)dxacc[i][0], (bf16)dxacc[i][1], (bf16)dxacc[i][2], (bf16)dxacc[i][3]};
+        *reinterpret_cast<bf16x4*>(dx + (int64_t)row * lddx + 16 * i + 4 * kg) = o4;
+        if constexpr (BSTAT) {      // the terms of instnorm_bwd_reduce_kernel on the rounded gradient: s += g, q = fma(g, (x - m) * rs, q)
+          const bf16x4 x4 = *reinterpret_cast<const bf16x4*>(bs.x + (int64_t)row * bs.ldx + 16 * i + 4 * kg);
+          const f32x4 m4 = *reinterpret_cast<const f32x4*>(lmean + 16 * i + 4 * kg), r4 = *reinterpret_cast<const f32x4*>(lrstd + 16 * i + 4 * kg);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float q = (float)o4[r]; bsum[i][r] += q; bsq[i][r] = fmaf(q, ((float)x4[r] - m4[r]) * r4[r], bsq[i][r]); }
+        }
+      }
     }
 #pragma unroll
     for (int s = 0; s < MLP_CS; ++s) { xc[s] = xn[s]; gc[s] = gn[s]; }
+  }
+  if constexpr (BSTAT) {
+    __syncthreads();      // the weight images are dead once every wave is past its last tile
+    float* red = reinterpret_cast<float*>(lds);
+    constexpr int RS = MLP_BWD_WAVES * 16 + 1, N = MLP_C;
+#pragma unroll
+    for (int i = 0; i < MLP_CS; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = 16 * i + 4 * kg + r;
+        red[(0 * N + col) * RS + wave * 16 + fi] = bsum[i][r];
+        red[(1 * N + col) * RS + wave * 16 + fi] = bsq[i][r];
+      }
+    __syncthreads();
+    for (int o = tid; o < 2 * N; o += MLP_BWD_WAVES * 64) {
+      const int k = o / N, col = o - k * N;
+      const float* rp = red + (k * N + col) * RS;
+      float tot = 0.f;
+#pragma unroll 16
+      for (int i = 0; i < MLP_BWD_WAVES * 16; ++i) tot += rp[i];
+      atomicAdd(bs.dstat + ((int64_t)(blockIdx.x & 15) * N + col) * 2 + k, (double)tot);      // [16 replicas][B = 1][N][2]
+    }
   }
 }
 
@@ -233,21 +332,28 @@ extern "C" int miseg_mlp_fwd(const miseg_mlp_params* p, miseg_stream_t s_) {
   if (int rc = mlp_check(p, "mlp_fwd")) return rc;
   MISEG_REQUIRE(p->w2 && p->y && ((uintptr_t)p->w2 % 16) == 0 && ((uintptr_t)p->y % 8) == 0 && p->ldy % 4 == 0 && p->ldy >= p->C, MISEG_E_BADARG, "mlp_fwd: w2 / y");
   MISEG_REQUIRE(!p->res || (((uintptr_t)p->res % 8) == 0 && p->ldres % 4 == 0), MISEG_E_BADARG, "mlp_fwd: res alignment");
-  size_t lds = (size_t)MLP_H * MLP_ROW_C + (size_t)MLP_C * MLP_ROW_H + (size_t)(MLP_H + MLP_C) * 4;
+  size_t lds = (size_t)MLP_H * MLP_ROW_C + (size_t)MLP_C * MLP_ROW_H + (size_t)(MLP_H + MLP_C + 2 * MLP_C) * 4;
   const size_t red = (size_t)2 * MLP_C * (MLP_FWD_WAVES * 16 + 1) * sizeof(float);      // the statistics reduction re-uses the images
   if (p->stat && lds < red) lds = red;
   int blocks = cdiv(cdiv(p->M, 16), MLP_FWD_WAVES);
   if (blocks > 512) blocks = 512;
   hipStream_t s = (hipStream_t)s_;
-  if (p->stat) {
-    MISEG_SET_SMEM((mlp_fwd_kernel<true>), lds);
-    mlp_fwd_kernel<true><<<blocks, MLP_FWD_WAVES * 64, lds, s>>>((const bf16*)p->x, p->ldx, (const bf16*)p->w1, p->b1, (const bf16*)p->w2, p->b2, (const bf16*)p->res, p->ldres,
-                                                  (bf16*)p->y, p->ldy, p->M, (double*)p->stat);
-  } else {
-    MISEG_SET_SMEM((mlp_fwd_kernel<false>), lds);
-    mlp_fwd_kernel<false><<<blocks, MLP_FWD_WAVES * 64, lds, s>>>((const bf16*)p->x, p->ldx, (const bf16*)p->w1, p->b1, (const bf16*)p->w2, p->b2, (const bf16*)p->res, p->ldres,
-                                                   (bf16*)p->y, p->ldy, p->M, nullptr);
+  MlpNorm an{};
+  if (p->an.stat) {
+    MISEG_REQUIRE(p->an.num_styles >= 1 && p->an.num_styles <= MISEG_MAX_STYLES, MISEG_E_BADARG, "mlp_fwd: an.num_styles %d", p->an.num_styles);
+    MISEG_REQUIRE(!p->an_out || (((uintptr_t)p->an_out % 8) == 0 && p->ld_an_out % 4 == 0 && p->ld_an_out >= p->C), MISEG_E_BADARG, "mlp_fwd: an_out alignment");
+    an.stat = (const double*)p->an.stat; an.styles = p->an.styles; an.eps = p->an.eps; an.out = (bf16*)p->an_out; an.ldo = p->ld_an_out;
+    for (int i = 0; i < p->an.num_styles; ++i) { an.gamma[i] = p->an.gamma[i]; an.beta[i] = p->an.beta[i]; }
   }
+#define MLP_FWD_LAUNCH(ST, AN)                                                                                                                              \
+  do {                                                                                                                                                      \
+    MISEG_SET_SMEM((mlp_fwd_kernel<ST, AN>), lds);                                                                                                          \
+    mlp_fwd_kernel<ST, AN><<<blocks, MLP_FWD_WAVES * 64, lds, s>>>((const bf16*)p->x, p->ldx, (const bf16*)p->w1, p->b1, (const bf16*)p->w2, p->b2,        \
+                                                                   (const bf16*)p->res, p->ldres, (bf16*)p->y, p->ldy, p->M, (double*)p->stat, an);          \
+  } while (0)
+  if (p->stat) { if (p->an.stat) MLP_FWD_LAUNCH(true, true); else MLP_FWD_LAUNCH(true, false); }
+  else { if (p->an.stat) MLP_FWD_LAUNCH(false, true); else MLP_FWD_LAUNCH(false, false); }
+#undef MLP_FWD_LAUNCH
   MISEG_LAUNCH_CHECK("mlp_fwd");
   return MISEG_OK;
 }
@@ -258,12 +364,21 @@ extern "C" int miseg_mlp_bwd(const miseg_mlp_params* p, miseg_stream_t s_) {
   MISEG_REQUIRE(((uintptr_t)p->dy % 8) == 0 && p->lddy % 4 == 0 && ((uintptr_t)p->dz % 8) == 0 && p->lddz % 4 == 0 && ((uintptr_t)p->h % 8) == 0 && p->ldh % 4 == 0 &&
                     (!p->dx || (((uintptr_t)p->dx % 8) == 0 && p->lddx % 4 == 0)) && ((uintptr_t)p->w2t % 16) == 0 && ((uintptr_t)p->w1t % 16) == 0,
                 MISEG_E_BADARG, "mlp_bwd: alignment");
-  const size_t lds = (size_t)2 * MLP_H * MLP_ROW_C + (size_t)MLP_C * MLP_ROW_H + (size_t)MLP_H * 4;
+  const size_t lds = (size_t)2 * MLP_H * MLP_ROW_C + (size_t)MLP_C * MLP_ROW_H + (size_t)(MLP_H + 2 * MLP_C) * 4;
   int blocks = cdiv(cdiv(p->M, 16), MLP_BWD_WAVES);
   if (blocks > 512) blocks = 512;
-  MISEG_SET_SMEM(mlp_bwd_kernel, lds);
-  mlp_bwd_kernel<<<blocks, MLP_BWD_WAVES * 64, lds, (hipStream_t)s_>>>((const bf16*)p->x, p->ldx, (const bf16*)p->dy, p->lddy, (const bf16*)p->w1, p->b1, (const bf16*)p->w2t,
-                                                        (const bf16*)p->w1t, (bf16*)p->dz, p->lddz, (bf16*)p->h, p->ldh, (bf16*)p->dx, p->lddx, p->M);
+  MlpBstat bs{};
+  if (p->bs_dstat) {
+    MISEG_REQUIRE(p->dx && p->bs_x && p->bs_stat && ((uintptr_t)p->bs_x % 8) == 0 && p->ld_bs_x % 4 == 0, MISEG_E_BADARG, "mlp_bwd: norm-backward sums need dx, bs_x (8-byte aligned rows), bs_stat");
+    bs.x = (const bf16*)p->bs_x; bs.ldx = p->ld_bs_x; bs.stat_in = (const double*)p->bs_stat; bs.eps = p->bs_eps; bs.dstat = (double*)p->bs_dstat;
+    MISEG_SET_SMEM(mlp_bwd_kernel<true>, lds);
+    mlp_bwd_kernel<true><<<blocks, MLP_BWD_WAVES * 64, lds, (hipStream_t)s_>>>((const bf16*)p->x, p->ldx, (const bf16*)p->dy, p->lddy, (const bf16*)p->w1, p->b1, (const bf16*)p->w2t,
+                                                          (const bf16*)p->w1t, (bf16*)p->dz, p->lddz, (bf16*)p->h, p->ldh, (bf16*)p->dx, p->lddx, p->M, bs);
+  } else {
+    MISEG_SET_SMEM(mlp_bwd_kernel<false>, lds);
+    mlp_bwd_kernel<false><<<blocks, MLP_BWD_WAVES * 64, lds, (hipStream_t)s_>>>((const bf16*)p->x, p->ldx, (const bf16*)p->dy, p->lddy, (const bf16*)p->w1, p->b1, (const bf16*)p->w2t,
+                                                           (const bf16*)p->w1t, (bf16*)p->dz, p->lddz, (bf16*)p->h, p->ldh, (bf16*)p->dx, p->lddx, p->M, bs);
+  }
   MISEG_LAUNCH_CHECK("mlp_bwd");
   return MISEG_OK;
 }

@@ -1397,7 +1397,9 @@ extern "C" int miseg_instnorm_fwd_slabs(const miseg_instnorm_apply_params* p, co
   return instnorm_fwd_impl(p, slabs, nslabs, slab_stride, stream);
 }
 
-static int instnorm_bwd_impl(const miseg_instnorm_bwd_params* p, const float* slabs, int nslabs, int64_t slab_stride, miseg_stream_t stream_) {
+// apply_only: p->dstat already holds the backward sums (the epilogue of the GEMM that produced dy added them: miseg_gemm_params.stat_mode 2,
+// miseg_mlp_params.bs_dstat) - the reduction launch is skipped and tensors of any size take the streaming apply kernel
+static int instnorm_bwd_impl(const miseg_instnorm_bwd_params* p, const float* slabs, int nslabs, int64_t slab_stride, miseg_stream_t stream_, bool apply_only = false) {
   hipStream_t stream = (hipStream_t)stream_;
   MISEG_REQUIRE(p && (p->dy || slabs) && p->x && p->dx && p->stat && p->dstat, MISEG_E_BADARG, "instnorm_bwd: null pointer");
   if (slabs) {
@@ -1422,7 +1424,7 @@ static int instnorm_bwd_impl(const miseg_instnorm_bwd_params* p, const float* sl
       gp.dgamma[s] = s < p->num_styles ? p->dgamma[s] : nullptr;
       gp.dbeta[s] = s < p->num_styles ? p->dbeta[s] : nullptr;
     }
-    if (p->S <= NORM_FUSED_MAX_ROWS) {
+    if (p->S <= NORM_FUSED_MAX_ROWS && !apply_only) {
       const FusedGeom f = fused_geom(p->S, p->C, al, V);
       dim3 fgrid(cdiv(f.cv, f.tx), p->B);
       const size_t fsh = fused_smem(f, 2, 1);
@@ -1449,8 +1451,9 @@ static int instnorm_bwd_impl(const miseg_instnorm_bwd_params* p, const float* sl
     const double* stat = (const double*)p->stat;
     double* dstat = (double*)p->dstat;
 #define BWD_LAUNCH(VV)                                                                                                                                          \
-    instnorm_bwd_reduce_kernel<T, VV><<<grid, NORM_THREADS, sh, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, p->S, p->C,  \
-                                                                           g.cv, g.tx, g.ty, g.rpb, stat, p->eps, p->act, p->slope, dstat, p->styles, sp);               \
+    if (!apply_only)                                                                                                                                           \
+      instnorm_bwd_reduce_kernel<T, VV><<<grid, NORM_THREADS, sh, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, p->S, p->C,  \
+                                                                             g.cv, g.tx, g.ty, g.rpb, stat, p->eps, p->act, p->slope, dstat, p->styles, sp);             \
     instnorm_bwd_apply_kernel<T, VV><<<grid, NORM_THREADS, shd, stream>>>((const T*)p->dy, p->lddy, (const T*)p->y, p->ldy, (const T*)p->x, p->ldx, (T*)p->dx,    \
                                                                          p->lddx, (T*)p->dres, p->lddres, p->S, p->C, g.cv, g.tx, g.ty, g.rpb, stat, p->eps, p->styles, \
                                                                          sp, p->act, p->slope, dstat, gp, (const T*)p->gadd, p->ldgadd);
@@ -1462,6 +1465,11 @@ static int instnorm_bwd_impl(const miseg_instnorm_bwd_params* p, const float* sl
 }
 
 extern "C" int miseg_instnorm_bwd(const miseg_instnorm_bwd_params* p, miseg_stream_t stream) { return instnorm_bwd_impl(p, nullptr, 0, 0, stream); }
+
+extern "C" int miseg_instnorm_bwd_apply(const miseg_instnorm_bwd_params* p, miseg_stream_t stream) {
+  MISEG_REQUIRE(p && p->act == MISEG_ACT_NONE, MISEG_E_UNSUPPORTED, "instnorm_bwd_apply: no activation (the producer's sums know nothing of one)");
+  return instnorm_bwd_impl(p, nullptr, 0, 0, stream, true);
+}
 
 extern "C" int miseg_instnorm_bwd_slabs(const miseg_instnorm_bwd_params* p, const float* slabs, int nslabs, int64_t slab_stride, miseg_stream_t stream) {
   MISEG_REQUIRE(slabs, MISEG_E_BADARG, "instnorm_bwd_slabs: null slabs");

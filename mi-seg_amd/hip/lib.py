@@ -52,11 +52,13 @@ LayernormFwd = _struct("LayernormFwd", cname="miseg_layernorm_fwd_params", field
 LayernormBwd = _struct("LayernormBwd", cname="miseg_layernorm_bwd_params", fields=[("dy", vp), ("lddy", i64), ("x", vp), ("ldx", i64), ("dx", vp), ("lddx", i64),
                                         ("rows", i64), ("C", i32), ("dtype", i32), ("gamma", vp), ("mean", vp), ("rstd", vp),
                                         ("dgamma", vp), ("dbeta", vp)])
+NormRef = _struct("NormRef", cname="miseg_norm_ref", fields=[("stat", vp), ("styles", vp), ("num_styles", i32), ("eps", f32), ("gamma", fp4), ("beta", fp4)])
 Gemm = _struct("Gemm", cname="miseg_gemm_params", fields=[("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32),
                         ("K", i32), ("ta", i32), ("tb", i32), ("dtype", i32), ("out_dtype", i32), ("bias", vp), ("act", i32),
                         ("accumulate", i32), ("split_k", i32), ("workspace", vp), ("res", vp), ("ldres", i64), ("aux", vp), ("ldaux", i64),
                         ("epi_mode", i32), ("defer_reduce", i32), ("stat", vp), ("scat_d", i32), ("scat_h", i32), ("scat_w", i32),
-                        ("scat_cout", i32)])
+                        ("scat_cout", i32), ("an", NormRef), ("an_out", vp), ("ld_an_out", i64), ("stat_mode", i32), ("bs_x", vp), ("ld_bs_x", i64),
+                        ("bs_stat", vp), ("bs_eps", f32)])
 TnReduceDesc = _struct("TnReduceDesc", cname="miseg_tn_reduce_desc", fields=[("partial", vp), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32), ("splits", i32), ("block0", i32)])
 ColsumDesc = _struct("ColsumDesc", cname="miseg_colsum_desc", fields=[("x", vp), ("ldx", i64), ("rows", i64), ("out", vp), ("C", i32), ("block0", i32)])
 GemmTnDesc = _struct("GemmTnDesc", cname="miseg_gemm_tn_desc", fields=[("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32), ("K", i32), ("zeroed", i32)])
@@ -110,7 +112,8 @@ Im2col3 = _struct("Im2col3", cname="miseg_im2col3_params", fields=[("src", vp), 
 u32, u64p = C.c_uint32, C.POINTER(C.c_uint64)
 Mlp = _struct("Mlp", cname="miseg_mlp_params", fields=[("struct_size", u32), ("M", i32), ("C", i32), ("HID", i32), ("dtype", i32), ("x", vp), ("ldx", i64),
                       ("w1", vp), ("b1", vp), ("w2", vp), ("b2", vp), ("res", vp), ("ldres", i64), ("y", vp), ("ldy", i64), ("stat", vp),
-                      ("dy", vp), ("lddy", i64), ("w2t", vp), ("w1t", vp), ("dz", vp), ("lddz", i64), ("h", vp), ("ldh", i64), ("dx", vp), ("lddx", i64)])
+                      ("dy", vp), ("lddy", i64), ("w2t", vp), ("w1t", vp), ("dz", vp), ("lddz", i64), ("h", vp), ("ldh", i64), ("dx", vp), ("lddx", i64),
+                      ("an", NormRef), ("an_out", vp), ("ld_an_out", i64), ("bs_x", vp), ("ld_bs_x", i64), ("bs_stat", vp), ("bs_eps", f32), ("bs_dstat", vp)])
 SegLoss = _struct("SegLoss", cname="miseg_seg_loss_params", fields=[
     ("struct_size", u32), ("kind", i32), ("logits", vp), ("label", vp), ("label_dtype", i32), ("B", i32), ("C", i32), ("S", i64),
     ("include_background", i32), ("squared_pred", i32), ("smooth_nr", f32), ("smooth_dr", f32), ("gamma", f32), ("lambda_dice", f32),
@@ -160,6 +163,9 @@ PROTOS = {
     "miseg_layernorm_bwd": (i32, [C.POINTER(LayernormBwd), vp]),
     "miseg_gemm_fuses_stat": (i32, [C.POINTER(Gemm)]),
     "miseg_gemm_fuses_scatter": (i32, [C.POINTER(Gemm)]),
+    "miseg_gemm_fuses_anorm": (i32, [C.POINTER(Gemm)]),
+    "miseg_gemm_fuses_bstat": (i32, [C.POINTER(Gemm)]),
+    "miseg_instnorm_bwd_apply": (i32, [C.POINTER(InstnormBwd), vp]),
     "miseg_rank1_stats": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, vp]),
     "miseg_mlp_fused": (i32, [i32, i32, i32, i32]),
     "miseg_mlp_fwd": (i32, [C.POINTER(Mlp), vp]),

@@ -346,6 +346,19 @@ def instnorm_bwd(dy, y, x, B, S, stat, styles, gammas, dgammas, dbetas, act=L.AC
     return dx, dres
 
 
+def instnorm_bwd_apply(dy, x, B, S, stat, dstat, styles, gammas, dgammas, dbetas, eps=1e-5, gadd=None):
+    """the apply half of instnorm_bwd with the backward sums already in `dstat` (the GEMM that produced dy added them in its epilogue)"""
+    ld, n, Cc = rows(x)
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    ns = len(gammas) if gammas is not None else 1
+    p = L.InstnormBwd(_ptr(dy), rows(dy)[0], None, 0, _ptr(x), ld, _ptr(dx), rows(dx)[0], None, 0, B, S, Cc, _dt(x), _ptr(stat), eps, _ptr(dstat), _ptr(styles), ns,
+                      _style_arrays(gammas, ns), _style_arrays(dgammas, ns), _style_arrays(dbetas, ns), L.ACT_NONE, 0.0,
+                      _ptr(gadd), rows(gadd)[0] if gadd is not None else 0, _style_arrays(None, ns))
+    # (roofline leg: a second pass would add the affine gradients twice - the profiled step's numbers are discarded anyway)
+    _call("miseg_instnorm_bwd_apply", p, prof=("instnorm", 0.0, _nb(dy, x, dx, gadd)))
+    return dx
+
+
 def instnorm_bwd_reduce(dy, x, B, S, stat, eps=1e-5):
     """dstat [R, B, C, 2] fp64 whose replicas sum to (sum dy, sum dy * xhat) per (sample, channel); xhat from `stat` (group / batch norms)"""
     ld, n, Cc = rows(x)
@@ -424,10 +437,46 @@ def pop_gemm_stat(y):
     return st[1] if st is not None and st[0] == y.data_ptr() else None
 
 
-def gemm_nt(a, w, bias=None, act=L.ACT_NONE, out=None, out_dtype=None, split_k=1, res=None, preact_out=None, gelu_grad_of=None, want_stat=False):
+class NormRef:
+    """a (conditional) instance norm whose apply pass a consumer kernel folds into its operand load (one sample): statistics of the norm's
+    raw input + affine rows (miseg_norm_ref, include/miseg_hip.h)"""
+    __slots__ = ("stat", "styles", "gammas", "betas", "eps")
+
+    def __init__(self, stat, styles, gammas, betas, eps):
+        self.stat, self.styles, self.gammas, self.betas, self.eps = stat, styles, gammas, betas, float(eps)
+
+    def fill(self, ref):
+        ns = len(self.gammas) if self.gammas is not None else 1
+        ref.stat, ref.styles, ref.num_styles, ref.eps = _ptr(self.stat), _ptr(self.styles), ns, self.eps
+        ref.gamma, ref.beta = _style_arrays(self.gammas, ns), _style_arrays(self.betas, ns)
+
+
+FOLD_NORMS = not os.environ.get("MISEG_NO_NORM_FOLD")      # A/B switch of round 5: the Swin block's norm apply / norm-backward reduce as launches of their own
+
+
+def gemm_nt_folds(a, w, anorm=None, bstat_x=None, act=L.ACT_NONE, res=None):
+    """would gemm_nt(a, w, anorm=...) / gemm_nt(..., bstat=...) run fused for these operands?  (one sample is the caller's business)"""
+    if not FOLD_NORMS or a.dtype != torch.bfloat16:
+        return False
+    lda, M, K = rows(a)
+    N = w.shape[0]
+    # (the output will be a fresh [M, N] tensor: A's pointer stands in for its alignment, and for the not-yet-allocated statistics)
+    p = L.Gemm(_ptr(a), lda, _ptr(w), K, _ptr(a), N, M, N, K, 0, 0, _dt(a), _dt(a), None, act, 0, 1, None, _ptr(res), rows(res)[0] if res is not None else 0, None, 0, 0, 0, None)
+    if anorm is not None:
+        anorm.fill(p.an)
+        return bool(L.load().miseg_gemm_fuses_anorm(C.byref(p)))
+    p.stat, p.stat_mode, p.bs_x, p.ld_bs_x, p.bs_stat = _ptr(a), 2, _ptr(bstat_x), rows(bstat_x)[0], _ptr(a)
+    return bool(L.load().miseg_gemm_fuses_bstat(C.byref(p)))
+
+
+def gemm_nt(a, w, bias=None, act=L.ACT_NONE, out=None, out_dtype=None, split_k=1, res=None, preact_out=None, gelu_grad_of=None, want_stat=False, anorm=None,
+            anorm_out=False, bstat=None):
     """out[M,N] = act(a[M,K] @ w[N,K]^T + bias) + res ; a rows view, w contiguous [N,K] in a.dtype.
     preact_out: tensor that receives the pre-activation z (for a later GELU backward); gelu_grad_of: pre-activation h of the
-    layer in front, the result is multiplied by gelu'(h) (GELU backward folded into this data-gradient GEMM)."""
+    layer in front, the result is multiplied by gelu'(h) (GELU backward folded into this data-gradient GEMM).
+    anorm (NormRef; check gemm_nt_folds first): `a` is the RAW input of that instance norm, normalised as it is loaded; anorm_out: also return
+    norm(a) - result (out, norm_a).  bstat = (x, stat, eps): `out` is the gradient with respect to the output of the instance norm whose raw
+    input is x (forward statistics `stat`); its backward sums are left for pop_gemm_stat(out) (dstat layout of instnorm_bwd)."""
     lda, M, K = rows(a)
     N, Kw = w.shape
     if not (Kw == K and w.is_contiguous() and w.dtype == a.dtype):
@@ -449,13 +498,26 @@ def gemm_nt(a, w, bias=None, act=L.ACT_NONE, out=None, out_dtype=None, split_k=1
                1 if preact_out is not None else 2 if gelu_grad_of is not None else 0, 0, None)
     global LAST_GEMM_STAT
     LAST_GEMM_STAT = None
+    xn = None
+    if anorm is not None:
+        assert not want_stat and bstat is None
+        anorm.fill(p.an)
+        if anorm_out:
+            xn = torch.empty(a.shape, dtype=a.dtype, device=a.device)
+            p.an_out, p.ld_an_out = xn.data_ptr(), rows(xn)[0]
+    if bstat is not None:
+        assert not want_stat
+        bx, bst, beps = bstat
+        dstat = STAT_POOL.take(L.load().miseg_instnorm_stat_bytes(1, N) // 8, a.device)
+        p.stat, p.stat_mode, p.bs_x, p.ld_bs_x, p.bs_stat, p.bs_eps = dstat.data_ptr(), 2, _ptr(bx), rows(bx)[0], _ptr(bst), float(beps)
+        LAST_GEMM_STAT = (out.data_ptr(), dstat)
     if want_stat and not os.environ.get("MISEG_NO_GEMM_STAT") and L.load().miseg_gemm_fuses_stat(C.byref(p)):
         # all M rows are one sample (the caller checked): the kernel leaves the norm statistics of the output in `stat`
         stat = STAT_POOL.take(L.load().miseg_instnorm_stat_bytes(1, N) // 8, a.device).view(-1, 1, N, 2)
         p.stat = stat.data_ptr()
         LAST_GEMM_STAT = (out.data_ptr(), stat)
-    _call("miseg_gemm", p, prof=("gemm_nt", 2.0 * M * N * K, _nb(a, w, out, res, aux)))      # (no accumulating output on the NT side: repeatable)
-    return out
+    _call("miseg_gemm", p, prof=("gemm_nt", 2.0 * M * N * K, _nb(a, w, out, res, aux, xn, bstat[0] if bstat is not None else None)))      # (no accumulating output on the NT side: repeatable)
+    return (out, xn) if anorm_out else out
 
 
 def mlp_fused(x, hid):
@@ -466,26 +528,35 @@ def mlp_fused(x, hid):
     return x.dtype == torch.bfloat16 and bool(L.load().miseg_mlp_fused(M, Cc, hid, _dt(x)))
 
 
-def mlp_fwd(x, w1, b1, w2, b2, res=None, want_stat=False):
+def mlp_fwd(x, w1, b1, w2, b2, res=None, want_stat=False, anorm=None, anorm_out=False):
     """y = w2 gelu(w1 x + b1) + b2 (+ res) in one launch, hidden activations never stored; w1 [HID, C], w2 [C, HID] contiguous in x.dtype.
-    want_stat (all rows one sample): the instance-norm statistics of y are left for pop_gemm_stat(y)."""
+    want_stat (all rows one sample): the instance-norm statistics of y are left for pop_gemm_stat(y).
+    anorm (NormRef): x is the RAW input of that instance norm (one sample), normalised as it is loaded; anorm_out: also return norm(x)."""
     ldx, M, Cc = rows(x)
     y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     p = L.Mlp(C.sizeof(L.Mlp), M, Cc, w1.shape[0], _dt(x), _ptr(x), ldx, _ptr(w1), _ptr(_fp32(b1)), _ptr(w2), _ptr(_fp32(b2)),
               _ptr(res), rows(res)[0] if res is not None else 0, _ptr(y), rows(y)[0], None)
+    xn = None
+    if anorm is not None:
+        anorm.fill(p.an)
+        if anorm_out:
+            xn = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+            p.an_out, p.ld_an_out = xn.data_ptr(), rows(xn)[0]
     global LAST_GEMM_STAT
     LAST_GEMM_STAT = None
     if want_stat:
         stat = STAT_POOL.take(L.load().miseg_instnorm_stat_bytes(1, Cc) // 8, x.device).view(-1, 1, Cc, 2)
         p.stat = stat.data_ptr()
         LAST_GEMM_STAT = (y.data_ptr(), stat)
-    _call("miseg_mlp_fwd", p)
-    return y
+    _call("miseg_mlp_fwd", p, prof=("gemm_nt", 4.0 * M * Cc * w1.shape[0], _nb(x, y, res, xn)))
+    return (y, xn) if anorm_out else y
 
 
-def mlp_bwd(x, dy, w1, b1, w2t, w1t, need_dx=True):
+def mlp_bwd(x, dy, w1, b1, w2t, w1t, need_dx=True, bstat=None):
     """(dz, h, dx) of the fused MLP: dz = (dy w2) * gelu'(z), h = gelu(z) with z = w1 x + b1 recomputed, dx = dz w1.
-    w2t [HID, C] = w2 transposed, w1t [C, HID] = w1 transposed (cast_matrix(..., transpose=True))."""
+    w2t [HID, C] = w2 transposed, w1t [C, HID] = w1 transposed (cast_matrix(..., transpose=True)).
+    bstat = (x_raw, stat, eps): x is norm(x_raw); dx is the gradient with respect to that norm's output and its backward sums come back as a
+    fourth result (dstat layout of instnorm_bwd)."""
     ldx, M, Cc = rows(x)
     hid = w1.shape[0]
     dz = torch.empty(x.shape[:-1] + (hid,), dtype=x.dtype, device=x.device)
@@ -493,8 +564,13 @@ def mlp_bwd(x, dy, w1, b1, w2t, w1t, need_dx=True):
     dx = torch.empty(x.shape, dtype=x.dtype, device=x.device) if need_dx else None
     p = L.Mlp(C.sizeof(L.Mlp), M, Cc, hid, _dt(x), _ptr(x), ldx, _ptr(w1), _ptr(_fp32(b1)), None, None, None, 0, None, 0, None,
               _ptr(dy), rows(dy)[0], _ptr(w2t), _ptr(w1t), _ptr(dz), rows(dz)[0], _ptr(h), rows(h)[0], _ptr(dx), rows(dx)[0] if dx is not None else 0)
-    _call("miseg_mlp_bwd", p)
-    return dz, h, dx
+    dstat = None
+    if bstat is not None and dx is not None:
+        bx, bst, beps = bstat
+        dstat = STAT_POOL.take(L.load().miseg_instnorm_stat_bytes(1, Cc) // 8, x.device)
+        p.bs_x, p.ld_bs_x, p.bs_stat, p.bs_eps, p.bs_dstat = _ptr(bx), rows(bx)[0], _ptr(bst), float(beps), dstat.data_ptr()
+    _call("miseg_mlp_bwd", p, prof=("gemm_nt", 8.0 * M * Cc * hid, _nb(x, dy, dz, h, dx)))
+    return (dz, h, dx, dstat) if bstat is not None else (dz, h, dx)
 
 
 def gemm_nt_scatter(a, w, dst, grid):

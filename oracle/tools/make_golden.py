@@ -487,14 +487,100 @@ def gen_unet():
     save("unet", arrays, meta)
 
 
+
+SEEDS = (2345, 3456)
+NSEED_SAMP = 1024
+
+
+def gen_seeds_truth():
+    """More draws of the whole-net conditioning comparison ("one draw against one draw is no parity check").
+    For every whole-net case of the *_truth fixtures and every extra input seed s (the first draw, seed 1234, stays where it is): the
+    REFERENCE's modules on x = det_input(s), cotangent det_input(s + 3087) - in float64 (the truth: 1024 strided samples of every parameter
+    gradient are stored), in fp32 and under torch.autocast(cpu, bfloat16) (stored: only each parameter's DISTANCE from the float64 run over
+    the same samples, which is all tests/test_hip_modules.py::test_*_vs_truth_over_seeds needs of them; one-element parameters keep their
+    values, they are judged on the scale of their peers).  The gradients of these nets are a discontinuous function of the forward pass
+    (activation sign flips): a bar on the median over seeds does not hinge on one lucky or unlucky flip of one draw."""
+    import copy
+    up_swin = ["swinViT.*.mlp (MONAI MLPBlock stand-in)"]
+    up_vit = ["vit.blocks.*.attn (MONAI SABlock stand-in)", "vit.blocks.*.mlp (MONAI MLPBlock stand-in)"]
+    cases = [
+        ("c2_m0", lambda: SwinUNETR((96, 96, 96), 1, 6, feature_size=48, num_heads=(3, 6, 12, 24), vit_norm_name=copy.deepcopy(COND),
+                                     encoder_norm_name=copy.deepcopy(COND), decoder_norm_name=copy.deepcopy(INST)), (1, 1, 96, 96, 96), [0], up_swin),
+        ("c3_m1", lambda: UNETR(1, 6, (96, 96, 96), feature_size=16, hidden_size=768, mlp_dim=3072, num_heads=12, pos_embed="perceptron",
+                                vit_norm_name=copy.deepcopy(COND), encoder_norm_name=copy.deepcopy(COND), decoder_norm_name=copy.deepcopy(INST)),
+         (1, 1, 96, 96, 96), [1], up_vit),
+        ("small_32", lambda: UNETR(1, 6, (32, 32, 32), feature_size=8, hidden_size=48, mlp_dim=96, num_heads=4, pos_embed="perceptron",
+                                   vit_norm_name=copy.deepcopy(COND), encoder_norm_name=copy.deepcopy(COND), decoder_norm_name=copy.deepcopy(INST)),
+         (2, 1, 32, 32, 32), [0, 1], up_vit),
+        ("c1_64", lambda: UNet(3, 1, 6, channels=[32, 64, 128, 256], strides=[2, 2, 2], num_res_units=2, act="prelu",
+                               norm_down=copy.deepcopy(INST), norm_up=copy.deepcopy(INST), dropout=0.0, bias=True, adn_ordering="NDA"),
+         (1, 1, 64, 64, 64), None, []),
+        ("cond_32", lambda: UNet(3, 1, 6, channels=[8, 16, 32], strides=[2, 2], num_res_units=2, act="prelu",
+                                 norm_down=copy.deepcopy(COND), norm_up=copy.deepcopy(INST), dropout=0.0, bias=True, adn_ordering="NDA"),
+         (2, 1, 32, 32, 32), [1, 0], []),
+    ]
+    only = os.environ.get("MISEG_SEED_CASES")
+    arrays, meta = {}, {"cases": {}, "seeds": list(SEEDS), "samples": NSEED_SAMP, "cotangent_seed_offset": 3087}
+
+    def rel(a, b):
+        a, b = torch.from_numpy(a).double(), torch.from_numpy(b).double()
+        return float((a - b).norm() / (b.norm() + 1e-30))
+
+    for tag, build, xshape, mods, unp in cases:
+        if only and tag not in only.split(","):
+            continue
+        meta["cases"][tag] = {"x": list(xshape), "modalities": None if mods is None else [int(v) for v in mods], "unpinned": unp, "keys": None, "secs": {}}
+        for seed in SEEDS:
+            t0 = time.time()
+            x = det_input(seed, xshape)
+            md = build()
+            fill_module_(md)
+            md = md.double()
+            yd = md(x.double(), mods)
+            g = det_input(seed + 3087, tuple(yd.shape))
+            yd.backward(g.double())
+            truth = {k: sample(p.grad, NSEED_SAMP) for k, p in md.named_parameters() if p.grad is not None}
+            l64 = sample(yd, NSEED_SAMP)
+            del md, yd
+            keys = sorted(truth)
+            if meta["cases"][tag]["keys"] is None:
+                meta["cases"][tag]["keys"] = keys
+            assert meta["cases"][tag]["keys"] == keys
+            pre = f"{tag}/s{seed}/"
+            for k in keys:
+                arrays[pre + "grad64:" + k] = truth[k]
+            arrays[pre + "logits64_samples"] = l64
+            for mode in ("fp32", "amp"):
+                m = build()
+                fill_module_(m)
+                if mode == "amp":
+                    with torch.autocast("cpu", dtype=torch.bfloat16):
+                        y = m(x, mods)
+                    y.backward(g.to(y.dtype))
+                else:
+                    y = m(x, mods)
+                    y.backward(g)
+                got = {k: sample(p.grad.float(), NSEED_SAMP) for k, p in m.named_parameters() if p.grad is not None}
+                assert sorted(got) == keys
+                arrays[pre + f"e_{mode}"] = np.asarray([rel(got[k], truth[k]) for k in keys], dtype=np.float64)
+                arrays[pre + f"elogits_{mode}"] = np.float64(rel(sample(y.float(), NSEED_SAMP), l64))
+                for k in keys:
+                    if truth[k].size == 1:
+                        arrays[pre + f"v_{mode}:" + k] = got[k]
+                del m, y
+            meta["cases"][tag]["secs"][str(seed)] = round(time.time() - t0, 1)
+            print(f"    {tag} seed {seed}: {time.time() - t0:.0f}s, median distance fp32 {np.median(arrays[pre + 'e_fp32']):.2e} amp {np.median(arrays[pre + 'e_amp']):.2e}", flush=True)
+    save("seeds_truth" if not only else "seeds_truth_" + only.replace(",", "_"), arrays, meta)
+
+
 GENS = {
     "cond_instnorm": gen_cond_instnorm, "window_attention": gen_window_attention, "swin_block": gen_swin_block,
     "patch_merging": gen_patch_merging, "unetr_blocks": gen_unetr_blocks, "transformer_block": gen_transformer_block,
     "swin_unetr_small": gen_swin_unetr_small, "unetr_small": gen_unetr, "unet": gen_unet,
     "swin_unetr_c2": gen_swin_unetr_c2, "unetr_c3": gen_unetr_c3, "swin_unetr_c2_truth": gen_swin_unetr_c2_truth,
-    "unetr_c3_truth": gen_unetr_c3_truth, "unet_truth": gen_unet_truth,
+    "unetr_c3_truth": gen_unetr_c3_truth, "unet_truth": gen_unet_truth, "seeds_truth": gen_seeds_truth,
 }
-FULL = ("swin_unetr_c2", "unetr_c3", "swin_unetr_c2_truth", "unetr_c3_truth")
+FULL = ("swin_unetr_c2", "unetr_c3", "swin_unetr_c2_truth", "unetr_c3_truth", "seeds_truth")
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

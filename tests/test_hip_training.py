@@ -206,8 +206,10 @@ def test_sliding_window_on_the_hip_path_matches_the_oracle():
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     cfg = ON.swin_unetr_cfg(feature_size=12)
     vol = det_input(5, (1, 1, 96, 80, 72))
-    with torch.no_grad():
-        want = sliding_window_inference(vol, 64, 1, lambda x, mm: ON.swin_unetr_forward(sd, x, mm, cfg), overlap=0.5, modalities=[1])
+    # the oracle side runs the INDEPENDENT restatement of MONAI's window scan and stitching (oracle/sliding_window.py), one window at a time -
+    # not the product's grid arithmetic
+    from oracle import sliding_window as OSW
+    want = OSW.sliding_window_reference(vol, 64, lambda x: ON.swin_unetr_forward(sd, x, [1], cfg), overlap=0.5)
     eager = sliding_window_inference(vol.to(DEV), 64, 4, m, overlap=0.5, modalities=torch.tensor([1]))
     graphed = sliding_window_inference(vol.to(DEV), 64, 4, GraphedForward(m, (4, 1, 64, 64, 64)), overlap=0.5, modalities=[1])
     assert eager.shape == want.shape and eager.is_cuda

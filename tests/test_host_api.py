@@ -247,3 +247,37 @@ def test_bench_refuses_to_time_fewer_ranks_than_asked_for():
     assert r.returncode != 0
     assert f"--gpus {have + 2} but this node shows {have} GPU(s)" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")], "no JSON line may be printed"
+
+
+def test_window_grid_against_the_independent_restatement():
+    """VERDICT round 4 (weak 13): the product's window grid (closed form, training/inferer.py::window_grid / _starts) against an independent
+    restatement of MONAI 1.1.0's scan (oracle/sliding_window.py walks the scan positions one by one) - at BASELINE configs[4]'s
+    512 x 512 x 363, at odd sizes, at sizes equal to / below the roi and at several overlaps; and the CPU stitching loop of the product against
+    the oracle's loop on a toy predictor, padding case included."""
+    from mi_seg_amd.training.inferer import sliding_window_inference, window_grid
+    from oracle import sliding_window as OSW
+    grid = window_grid((512, 512, 363), (96, 96, 96), 0.5)
+    assert grid == OSW.window_origins((512, 512, 363), (96, 96, 96), 0.5) and len(grid) == 700
+    assert grid[0] == (0, 0, 0) and grid[-1] == (416, 416, 267) and grid[1] == (0, 0, 48) and grid[6] == (0, 0, 267)
+    n = 0
+    for size in ((96, 96, 96), (97, 96, 130), (191, 193, 95 + 96), (100, 143, 289), (160, 160, 128), (96, 80 + 96, 333), (250, 96, 97)):
+        for roi in ((96, 96, 96), (64, 64, 64), (64, 96, 32)):
+            if any(s < r for s, r in zip(size, roi)):
+                continue
+            for ov in (0.5, 0.25, 0.7, 0.0, 0.99):
+                assert window_grid(size, roi, ov) == OSW.window_origins(size, roi, ov), (size, roi, ov)
+                n += 1
+    assert n > 80
+    # the whole CPU path (pad, grid, accumulate, divide, crop) on a predictor whose output depends on the window's content and position in it
+    g = torch.Generator().manual_seed(3)
+
+    def pred(x, *a, **k):
+        ramp = torch.linspace(0.0, 1.0, x.shape[-1]).view(1, 1, 1, 1, -1)
+        return torch.cat([x * 2.0 + ramp, x.flip(-1) - 0.5 * ramp, x.mean(dim=(2, 3, 4), keepdim=True).expand_as(x)], 1)
+
+    for size, roi, ov in (((40, 37, 50), 16, 0.5), ((20, 33, 12), (16, 16, 16), 0.25), ((16, 16, 47), 16, 0.5), ((10, 16, 21), (16, 8, 8), 0.5)):
+        vol = torch.rand((2, 1) + size, generator=g)
+        want = OSW.sliding_window_reference(vol, roi, pred, overlap=ov)
+        got = sliding_window_inference(vol, roi, 3, pred, overlap=ov)
+        assert got.shape == want.shape == (2, 3) + size
+        assert torch.allclose(got, want, rtol=0, atol=1e-6), (size, roi, ov, float((got - want).abs().max()))
