@@ -441,7 +441,29 @@ def measure(a, rank, world, dist, dev):
         dist.all_reduce(want)
         want /= world
         step(a.warmup + a.steps + 1)
-        return {"grad_rel_err_vs_mean_of_ranks": float((arena.flat - want).norm() / want.norm())}
+        res = {"grad_rel_err_vs_mean_of_ranks": float((arena.flat - want).norm() / want.norm())}
+        # "unused on EVERY rank => no gradient, no update" (torch DDP with find_unused_parameters, reference tune.py:105-109): find a step in
+        # which all ranks drew the same modality, run it, and compare the exchanged flags with the conditional-norm rows of the other one
+        names = [n for n, p in model.named_parameters() if p.requires_grad]
+        for i in range(a.warmup + a.steps + 2, a.warmup + a.steps + 2 + 12):
+            mods_all = [None] * world
+            dist.all_gather_object(mods_all, int(mods[order[i % len(order)]]))
+            if len(set(mods_all)) != 1:
+                continue
+            step(i)
+            torch.cuda.synchronize()
+            flags = arena.used_dev.tolist() if arena.used_on_device else [int(bool(p._miseg_used)) for p in arena.params]
+            unused = sorted(n for n, f in zip(names, flags) if not f)
+            expected = sorted(n for n in names if f".norms.{1 - mods_all[0]}." in n)
+            res["globally_unused"] = {"modality_of_every_rank": mods_all[0], "params_flagged_unused": len(unused), "as_expected": unused == expected,
+                                      "flags": "device (used_dev)" if arena.used_on_device else "host"}
+            if not arena.used_on_device:      # host flags: p.grad follows the GLOBAL flags
+                named = dict(model.named_parameters())
+                res["globally_unused"]["grad_is_none_exactly_for_them"] = all((named[n].grad is None) == (n in set(unused)) for n in names)
+            break
+        else:
+            res["globally_unused"] = "not exercised: no step of the next 12 in which every rank draws the same modality"
+        return res
 
     out = {
         "metric": WORKLOADS[a.workload][0], "value": world * a.steps / dt, "unit": WORKLOADS[a.workload][1],

@@ -95,9 +95,9 @@ __global__ void __launch_bounds__(MLP_FWD_WAVES * 64, 2) mlp_fwd_kernel(const bf
   for (int i = tid; i < MLP_H; i += MLP_FWD_WAVES * 64) lb1[i] = b1 ? b1[i] : 0.f;
   for (int i = tid; i < MLP_C; i += MLP_FWD_WAVES * 64) lb2[i] = b2 ? b2[i] : 0.f;
   if constexpr (ANORM) {
-    const int st = an.styles ? an.styles[0] : 0;
-    const float* g = an.gamma[st];
-    const float* be = an.beta[st];
+    const int st = an.styles ? an.styles[0] : 0;      // (select chain: no run-time index into the by-value argument struct)
+    const float* g = st == 0 ? an.gamma[0] : st == 1 ? an.gamma[1] : st == 2 ? an.gamma[2] : an.gamma[3];
+    const float* be = st == 0 ? an.beta[0] : st == 1 ? an.beta[1] : st == 2 ? an.beta[2] : an.beta[3];
     for (int k = tid; k < MLP_C; k += MLP_FWD_WAVES * 64) {
       float m_, r_;
       mlp_mean_rstd(an.stat, MLP_C, k, 1.0 / M, an.eps, m_, r_);

@@ -478,6 +478,195 @@ class _Linear(Function):
         return dx, dw, db, (dy if ctx.needs_input_grad[3] else None), None
 
 
+def _norm_grad_slots(params, affine, num_styles, styles_host, Cc, device):
+    """where the affine gradients of a (conditional) instance norm go: (dgamma rows, dbeta rows, in_arena, builder of the returned gradients).
+    Rows of a style absent from the batch stay None (reference: grad is None)."""
+    present = sorted(set(styles_host)) if styles_host is not None else [0]
+    if not affine:
+        return None, None, False, lambda: []
+    in_arena = getattr(params[0], "_miseg_grad", None) is not None
+    if in_arena:
+        dgam = [_slot(params[2 * s]) if s in present else None for s in range(num_styles)]
+        dbet = [_slot(params[2 * s + 1]) if s in present else None for s in range(num_styles)]
+        return dgam, dbet, True, lambda: [None, None] * num_styles
+    buf = ops.zeros_f32((num_styles, 2, Cc), device)
+    dgam = [buf[s, 0] if s in present else None for s in range(num_styles)]
+    dbet = [buf[s, 1] if s in present else None for s in range(num_styles)]
+
+    def build():
+        pg = []
+        for s in range(num_styles):
+            pg += [dgam[s], dbet[s]]
+        return pg
+    return dgam, dbet, False, build
+
+
+def _wgrad_into(p, g, act):
+    """dW = g^T act of a linear layer: into the parameter's arena slot (returns None) or as a fresh tensor"""
+    slot, mode = _slot_first(p)
+    if slot is not None:
+        with ops.wgrad_side(g, act):
+            ops.gemm_tn(g, act, out=slot, accumulate=mode)      # (2: the slot still holds the step's zeros - a store, not a read-modify-write)
+        return None
+    return ops.gemm_tn(g, act).view(p.shape)
+
+
+def _bgrad_into(p, g):
+    slot = _slot(p)
+    if slot is not None:
+        ops.colsum(g, out=slot, accumulate=True)
+        return None
+    return ops.colsum(g)
+
+
+def _norm_bwd_from(dxn, x, S, stat, dstat, styles_dev, gammas, dgam, dbet, eps, gadd):
+    """the instance-norm backward behind a data-gradient GEMM: apply only when the GEMM's epilogue left the sums (dstat), else both halves"""
+    if dstat is not None:
+        return ops.instnorm_bwd_apply(dxn, x, 1, S, stat, dstat, styles_dev, gammas, dgam, dbet, eps=eps, gadd=gadd)
+    return ops.instnorm_bwd(dxn, None, x, 1, S, stat, styles_dev, gammas, dgam, dbet, eps=eps, gadd=gadd)[0]
+
+
+class _NormLinear(Function):
+    """y = norm(x) W^T + b with the (conditional) instance norm's apply pass folded into the GEMM's operand load (ONE sample, bf16, the
+    tall-skinny GEMM path): the Swin block's norm1 -> qkv (swin_transformer_block.py:103, window_attention.py:101).  fork: second output = x, the
+    skip branch of `x + f(norm(x))`; its gradient is added inside the norm-backward apply pass.  Backward: the data-gradient GEMM leaves the
+    norm's backward sums in its epilogue, so the norm backward is ONE launch (apply) instead of two."""
+
+    @staticmethod
+    def forward(ctx, x, styles_dev, styles_host, num_styles, affine, eps, fork, stat_in, weight, bias, *params):
+        S = ops.rows(x)[1]
+        gammas = list(params[0::2]) if affine else None
+        betas = list(params[1::2]) if affine else None
+        stat = stat_in if stat_in is not None else ops.instnorm_stats(x, 1, S)
+        keep = any(ctx.needs_input_grad)
+        ref = ops.NormRef(stat, styles_dev, gammas, betas, eps)
+        r = ops.gemm_nt(x, ops.cast_matrix(weight, x.dtype), bias, anorm=ref, anorm_out=keep)
+        y, xn = r if keep else (r, None)
+        ctx.save_for_backward(x, xn, stat, styles_dev, weight, *(gammas or []))
+        ctx.meta = (S, styles_host, num_styles, affine, eps)
+        ctx.params = (weight, bias) + tuple(params)
+        return (y, x.view_as(x)) if fork else y
+
+    @staticmethod
+    def backward(ctx, dy, gskip=None):
+        x, xn, stat, styles_dev, weight, *gammas = ctx.saved_tensors
+        S, styles_host, num_styles, affine, eps = ctx.meta
+        pw, pb = ctx.params[0], ctx.params[1]
+        dy = _rv(dy)
+        dgam, dbet, _, build = _norm_grad_slots(ctx.params[2:], affine, num_styles, styles_host, x.shape[-1], x.device)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = ops.cast_matrix(weight, dy.dtype, transpose=True)      # [K, N]
+            if ops.gemm_nt_folds(dy, wt, bstat_x=x):
+                dxn = ops.gemm_nt(dy, wt, bstat=(x, stat, eps))
+                dstat = ops.pop_gemm_stat(dxn)
+            else:
+                dxn, dstat = ops.gemm_nt(dy, wt), None
+            dx = _norm_bwd_from(dxn, x, S, stat, dstat, styles_dev, gammas if affine else None, dgam, dbet, eps, _rv(gskip))
+        dw = _wgrad_into(pw, dy, xn) if ctx.needs_input_grad[8] else None
+        db = _bgrad_into(pb, dy) if (pb is not None and ctx.needs_input_grad[9]) else None
+        return (dx, None, None, None, None, None, None, None, dw, db, *build())
+
+
+def norm_linear(x, params, styles_dev, styles_host, eps, weight, bias=None, fork=False):
+    """linear(instance_norm(x)) [, x] with the norm folded into the GEMM (see _NormLinear), or None where that form does not apply (more
+    than one sample, fp32, a shape outside the tall-skinny path): the caller then composes instance_norm + linear.
+    params: None | [(gamma, beta)] | one pair per style."""
+    if not (_one_sample(x) and x.dtype == torch.bfloat16):
+        return None
+    n = len(params) if params is not None else 1
+    st = _carried_stat(x)
+    ref = ops.NormRef(st if st is not None else x, styles_dev, [g for g, _ in params] if params is not None else None,
+                      [b for _, b in params] if params is not None else None, eps)
+    if not ops.gemm_nt_folds(x, weight, anorm=ref):
+        return None
+    flat = []
+    if params is not None:
+        for g, b in params:
+            flat += [g, b]
+    return _NormLinear.apply(x, styles_dev, styles_host, n, params is not None, eps, fork, st, weight, bias, *flat)
+
+
+class _NormMlp(Function):
+    """y = x + W2 gelu(W1 norm(x) + b1) + b2: the second half of a Swin block (swin_transformer_block.py:176-205,251) with the (conditional)
+    instance norm's apply pass folded into the token load of the fused MLP kernel / of the fc1 GEMM, the residual in the fc2 epilogue, and -
+    backward - the norm's sums in the epilogue of the kernel that produces the gradient of its output (ONE sample, bf16)."""
+
+    @staticmethod
+    def forward(ctx, x, styles_dev, styles_host, num_styles, affine, eps, want_stat, stat_in, w1, b1, w2, b2, *params):
+        S = ops.rows(x)[1]
+        gammas = list(params[0::2]) if affine else None
+        betas = list(params[1::2]) if affine else None
+        stat = stat_in if stat_in is not None else ops.instnorm_stats(x, 1, S)
+        keep = any(ctx.needs_input_grad)
+        ref = ops.NormRef(stat, styles_dev, gammas, betas, eps)
+        ctx.fused = ops.mlp_fused(x, w1.shape[0])
+        w1c, w2c = ops.cast_matrix(w1, x.dtype), ops.cast_matrix(w2, x.dtype)
+        h = a = None
+        if ctx.fused:
+            r = ops.mlp_fwd(x, w1c, b1, w2c, b2, res=x, want_stat=want_stat, anorm=ref, anorm_out=keep)
+            y, xn = r if keep else (r, None)
+        else:
+            h = torch.empty(x.shape[:-1] + (w1.shape[0],), dtype=x.dtype, device=x.device) if keep else None
+            r = ops.gemm_nt(x, w1c, b1, act=L.ACT_GELU, preact_out=h, anorm=ref, anorm_out=keep)
+            a, xn = r if keep else (r, None)
+            y = ops.gemm_nt(a, w2c, b2, res=x, want_stat=want_stat)
+        ctx.save_for_backward(x, xn, h, a, stat, styles_dev, w1, w2, *(gammas or []))
+        ctx.meta = (S, styles_host, num_styles, affine, eps)
+        ctx.params = (w1, b1, w2, b2) + tuple(params)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, xn, h, a, stat, styles_dev, w1, w2, *gammas = ctx.saved_tensors
+        S, styles_host, num_styles, affine, eps = ctx.meta
+        pw1, pb1, pw2, pb2 = ctx.params[:4]
+        dy = _rv(dy)
+        dgam, dbet, _, build = _norm_grad_slots(ctx.params[4:], affine, num_styles, styles_host, x.shape[-1], x.device)
+        w1t, w2t = ops.cast_matrix(w1, dy.dtype, transpose=True), ops.cast_matrix(w2, dy.dtype, transpose=True)
+        if ctx.fused:      # z recomputed from norm(x); dz and h are written once, for the two weight-gradient products below
+            dh, a, dxn, dstat = ops.mlp_bwd(xn, dy, ops.cast_matrix(w1, dy.dtype), pb1, w2t, w1t, need_dx=True, bstat=(x, stat, eps))
+        else:
+            dh = ops.gemm_nt(dy, w2t, gelu_grad_of=h)
+            if ops.gemm_nt_folds(dh, w1t, bstat_x=x):
+                dxn = ops.gemm_nt(dh, w1t, bstat=(x, stat, eps))
+                dstat = ops.pop_gemm_stat(dxn)
+            else:
+                dxn, dstat = ops.gemm_nt(dh, w1t), None
+        # the skip branch's gradient is dy itself: added inside the norm-backward apply pass
+        dx = _norm_bwd_from(dxn, x, S, stat, dstat, styles_dev, gammas if affine else None, dgam, dbet, eps, dy)
+        out = [dx, None, None, None, None, None, None, None, None, None, None, None]
+        if ctx.needs_input_grad[8]:
+            out[8] = _wgrad_into(pw1, dh, xn)
+        if ctx.needs_input_grad[10]:
+            out[10] = _wgrad_into(pw2, dy, a)
+        if pb1 is not None and ctx.needs_input_grad[9]:
+            out[9] = _bgrad_into(pb1, dh)
+        if pb2 is not None and ctx.needs_input_grad[11]:
+            out[11] = _bgrad_into(pb2, dy)
+        return (*out, *build())
+
+
+def norm_mlp(x, params, styles_dev, styles_host, eps, w1, b1, w2, b2, want_stat=False):
+    """x + mlp(instance_norm(x)) with the norm folded into the MLP's first product (see _NormMlp), or None where that form does not apply."""
+    if not (_one_sample(x) and x.dtype == torch.bfloat16):
+        return None
+    n = len(params) if params is not None else 1
+    st = _carried_stat(x)
+    ref = ops.NormRef(st if st is not None else x, styles_dev, [g for g, _ in params] if params is not None else None,
+                      [b for _, b in params] if params is not None else None, eps)
+    if not ops.FOLD_NORMS:
+        return None
+    if not ops.mlp_fused(x, w1.shape[0]) and not ops.gemm_nt_folds(x, w1, anorm=ref, act=L.ACT_GELU):
+        return None
+    flat = []
+    if params is not None:
+        for g, b in params:
+            flat += [g, b]
+    y = _NormMlp.apply(x, styles_dev, styles_host, n, params is not None, eps, want_stat, st, w1, b1, w2, b2, *flat)
+    return _tag_stat(y) if want_stat else y
+
+
 def _one_sample(x):
     return x.dim() >= 3 and x.shape[0] == 1
 

@@ -6,7 +6,7 @@ import torch.nn as nn
 from torch.utils import checkpoint
 
 from ...hip import functional as HF
-from ..layers.utils import apply_norm, apply_norm_fork, get_norm_layer
+from ..layers.utils import apply_norm, apply_norm_fork, get_norm_layer, norm_fold_spec
 from ..utils.swin_utils import get_window_size
 from .mlp import MLPBlock as Mlp
 from .window_attention import WindowAttention
@@ -71,6 +71,21 @@ class SwinTransformerBlock(nn.Module):
         _, d, h, w, _ = x.shape
         window, shift = get_window_size((d, h, w), self.window_size, self.shift_size)
         inst = self.norm_type.startswith("instance")    # the GEMM that feeds an instance norm also produces its statistics
+        plain = not (self.training and (self.drop_path_rate > 0.0 or self.attn.proj_drop > 0.0 or self.mlp.dropout_rate > 0.0))
+        if inst and plain:
+            # one sample, bf16, the tall-skinny GEMM path (stages 1 - 2 of the headline net): norm1's apply pass rides in the qkv GEMM's operand
+            # load and norm2's in the MLP's first product; backward, the norms' sums ride in the data-gradient epilogues (HF._NormLinear / _NormMlp)
+            spec = norm_fold_spec(self.norm1, styles)
+            r = HF.norm_linear(x, *spec, self.attn.qkv.weight, self.attn.qkv.bias, fork=True) if spec is not None else None
+            if r is not None:
+                qkv, xs = r
+                x = self.attn(None, window, shift, res=xs, want_stat=inst, qkv=qkv)
+                spec2 = norm_fold_spec(self.norm2, styles)
+                y = HF.norm_mlp(x, *spec2, self.mlp.linear1.weight, self.mlp.linear1.bias, self.mlp.linear2.weight, self.mlp.linear2.bias, want_stat=inst)
+                if y is not None:
+                    return y
+                xn, xs = apply_norm_fork(self.norm2, x, styles)
+                return self.mlp(xn, res=xs, want_stat=inst)
         xn, xs = apply_norm_fork(self.norm1, x, styles)
         if self.drop_path_rate > 0.0 and self.training:                 # stochastic depth (:247,:251): x + drop_path(branch)
             x = HF.add(xs, HF.drop_path(self.attn(xn, window, shift), self.drop_path_rate))

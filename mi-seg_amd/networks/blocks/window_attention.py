@@ -41,9 +41,11 @@ class WindowAttention(nn.Module):
         if not (ws[0] == ws[1] == ws[2]):
             raise NotImplementedError("non-cubic table windows")
 
-    def forward(self, x, window, shift, res=None, want_stat=False):
-        """x: normalised tokens on the unpadded grid [B, D, H, W, C]; window/shift already clamped."""
-        qkv = HF.linear(x, self.qkv.weight, self.qkv.bias)
+    def forward(self, x, window, shift, res=None, want_stat=False, qkv=None):
+        """x: normalised tokens on the unpadded grid [B, D, H, W, C]; window/shift already clamped.
+        qkv: the caller already formed qkv(x) (the Swin block folds its norm1 into that GEMM: HF.norm_linear); x is then ignored."""
+        if qkv is None:
+            qkv = HF.linear(x, self.qkv.weight, self.qkv.bias)
         o = HF.window_attention(qkv, self.qkv.bias, self.relative_position_bias_table, self.num_heads, window, shift,
                                 self.window_size[0], self.scale, self.attn_drop, self.training)
         if self.proj_drop > 0.0 and self.training:        # window_attention.py:120-121: proj_drop(proj(x)); the residual is then added separately

@@ -63,6 +63,18 @@ def apply_norm_fork(norm: nn.Module, x, styles=None):
     return apply_norm(norm, xa, styles), xs
 
 
+def norm_fold_spec(norm: nn.Module, styles=None):
+    """(params, styles_dev, styles_host, eps) of a (conditional) instance norm for the consumers that fold its apply pass into their operand
+    load (HF.norm_linear / HF.norm_mlp), or None for the other norm kinds"""
+    if isinstance(norm, _ConditionalInstanceNorm):
+        if styles is None:
+            raise ValueError("Modalities must be passed to the forward step when encoder_norm_type is 'instance_cond'.")
+        return norm.style_params(), styles[0], styles[1], norm.eps
+    if isinstance(norm, _INSTANCE):
+        return ([(norm.weight, norm.bias)] if norm.affine else None), None, None, norm.eps
+    return None
+
+
 def apply_res_norm_pair(norm_a: nn.Module, xa, norm_b: nn.Module, xb, styles=None, slope=0.01, stat_a=None, out=None, w1=None):
     """LeakyReLU(norm_a(xa) + norm_b(xb)) in one apply pass (HF.res_norm_pair) where both norms are instance norms of the same kind (any
     size: the joint backward is ONE register-resident launch up to 2048 rows per sample, two chunked ones above); None where that does not apply.

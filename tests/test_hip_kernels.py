@@ -388,6 +388,96 @@ def test_fused_mlp_forward_and_backward(M):
     assert rel_err(dz, ops.gemm_nt(dy, w2b.t().contiguous(), gelu_grad_of=pre)) < 1e-2
 
 
+@pytest.mark.parametrize("M,K,N,gelu,styled", [(110592, 48, 144, False, True), (13824, 96, 288, False, True), (13824, 96, 384, True, False), (4100, 48, 48, False, False)])
+def test_gemm_with_the_instance_norm_folded_into_its_operand_load(M, K, N, gelu, styled):
+    """round 5: y = act(norm(x) W^T + b) with the (conditional) instance norm's apply pass inside the streaming GEMM's operand load
+    (miseg_gemm_params.an) - the same bits as miseg_instnorm_apply followed by the plain GEMM (same fma, same rounding), for y, for the stored
+    norm(x) and for the GELU pre-activation; the Swin shapes qkv @ 48^3 / 24^3, fc1 @ 24^3 and a ragged row count."""
+    ops, L = _ops(), _L()
+    dt = torch.bfloat16
+    x = (rnd(1, M, K, dtype=torch.float32, seed=91) * 1.7 + 0.4).to(dt)
+    w, b = (rnd(N, K, seed=92) / K ** 0.5).to(dt), rnd(N, seed=93) / 4
+    gam = [rnd(K, seed=94) * 0.2 + 1.0, rnd(K, seed=95) * 0.2 + 1.0] if styled else None
+    bet = [rnd(K, seed=96) * 0.3, rnd(K, seed=97) * 0.3] if styled else None
+    styles = torch.tensor([1], dtype=torch.int32, device=DEV) if styled else None
+    ops.begin_step()
+    stat = ops.instnorm_stats(x, 1, M)
+    xn0 = ops.instnorm_apply(x, 1, M, stat, styles, gam, bet)
+    pre0 = torch.empty(1, M, N, dtype=dt, device=DEV) if gelu else None
+    y0 = ops.gemm_nt(xn0, w, b, act=L.ACT_GELU if gelu else L.ACT_NONE, preact_out=pre0)
+    ref = ops.NormRef(stat, styles, gam, bet, 1e-5)
+    assert ops.gemm_nt_folds(x, w, anorm=ref, act=L.ACT_GELU if gelu else L.ACT_NONE)
+    pre1 = torch.empty(1, M, N, dtype=dt, device=DEV) if gelu else None
+    y1, xn1 = ops.gemm_nt(x, w, b, act=L.ACT_GELU if gelu else L.ACT_NONE, preact_out=pre1, anorm=ref, anorm_out=True)
+    assert torch.equal(xn0, xn1), rel_err(xn1, xn0)
+    assert torch.equal(y0, y1), rel_err(y1, y0)
+    assert not gelu or torch.equal(pre0, pre1)
+    y2 = ops.gemm_nt(x, w, b, act=L.ACT_GELU if gelu else L.ACT_NONE, anorm=ref)            # without the stored copy
+    assert torch.equal(y0, y2)
+    # and against torch in fp32 on the same operands
+    mu, var = x.float().mean(1, keepdim=True), x.float().var(1, unbiased=False, keepdim=True)
+    xr = (x.float() - mu) / torch.sqrt(var + 1e-5) * (gam[1] if styled else 1.0) + (bet[1] if styled else 0.0)
+    assert rel_err(xn1, xr) < 5e-3
+
+
+@pytest.mark.parametrize("M,K,N", [(110592, 144, 48), (13824, 288, 96), (5000, 96, 48)])
+def test_gemm_with_the_norm_backward_sums_in_its_epilogue(M, K, N):
+    """round 5: the data-gradient GEMM behind an instance norm leaves the norm's backward sums (sum g, sum g * xhat) in its epilogue
+    (miseg_gemm_params.stat_mode 2) - against miseg_instnorm_bwd_reduce over the stored gradient, and the apply-only backward
+    (miseg_instnorm_bwd_apply) against the two-launch backward incl. affine gradients and the skip-branch add."""
+    ops = _ops()
+    dt = torch.bfloat16
+    dy = rnd(1, M, K, dtype=dt, seed=101)
+    wt = (rnd(N, K, seed=102) / K ** 0.5).to(dt)
+    x = (rnd(1, M, N, dtype=torch.float32, seed=103) * 1.3 - 0.2).to(dt)
+    gskip = rnd(1, M, N, dtype=dt, seed=104)
+    gam, styles = [rnd(N, seed=105) * 0.2 + 1.0, rnd(N, seed=106) * 0.2 + 1.0], torch.tensor([0], dtype=torch.int32, device=DEV)
+    ops.begin_step()
+    stat = ops.instnorm_stats(x, 1, M)
+    g0 = ops.gemm_nt(dy, wt)
+    assert ops.gemm_nt_folds(dy, wt, bstat_x=x)
+    g1 = ops.gemm_nt(dy, wt, bstat=(x, stat, 1e-5))
+    dstat = ops.pop_gemm_stat(g1)
+    assert torch.equal(g0, g1) and dstat is not None
+    want = ops.instnorm_bwd_reduce(g0, x, 1, M, stat).sum(0)                      # [1, N, 2] fp64
+    got = dstat.view(-1, 1, N, 2).sum(0)
+    scale = want.abs().max(dim=1, keepdim=True).values
+    assert float(((got - want).abs() / scale).max()) < 2e-5, float(((got - want).abs() / scale).max())
+    dg0, db0, dg1, db1 = (torch.zeros(2, N, device=DEV) for _ in range(4))
+    dx0, _ = ops.instnorm_bwd(g0, None, x, 1, M, stat, styles, gam, [dg0[0], None], [db0[0], None], gadd=gskip)
+    dx1 = ops.instnorm_bwd_apply(g1, x, 1, M, stat, dstat, styles, gam, [dg1[0], None], [db1[0], None], gadd=gskip)
+    assert rel_err(dx1, dx0) < 2e-3                   # bf16 outputs of sums that differ in their last fp32 bits
+    assert rel_err(dg1[0], dg0[0]) < 1e-4 and rel_err(db1[0], db0[0]) < 1e-4 and float(dg1[1].abs().max()) == 0.0
+
+
+def test_fused_mlp_with_the_norm_folded_in_and_its_backward_sums():
+    """round 5: mlp_fwd with norm2 folded into its token load = instnorm_apply + mlp_fwd bit for bit (y, the stored norm(x), the fused output
+    statistics); mlp_bwd's norm-backward sums against miseg_instnorm_bwd_reduce over its dx"""
+    ops = _ops()
+    dt, M = torch.bfloat16, 110592
+    x, dy = (rnd(1, M, 48, dtype=torch.float32, seed=111) * 1.5 + 0.3).to(dt), rnd(1, M, 48, dtype=dt, seed=112)
+    w1, b1 = (rnd(192, 48, seed=113) / 48 ** 0.5).to(dt), rnd(192, seed=114) / 4
+    w2, b2 = (rnd(48, 192, seed=115) / 192 ** 0.5).to(dt), rnd(48, seed=116) / 4
+    gam, bet, styles = [rnd(48, seed=117) * 0.2 + 1.0], [rnd(48, seed=118) * 0.3], None
+    ops.begin_step()
+    stat = ops.instnorm_stats(x, 1, M)
+    xn0 = ops.instnorm_apply(x, 1, M, stat, styles, gam, bet)
+    y0 = ops.mlp_fwd(xn0, w1, b1, w2, b2, res=x, want_stat=True)
+    s0 = ops.pop_gemm_stat(y0)
+    y1, xn1 = ops.mlp_fwd(x, w1, b1, w2, b2, res=x, want_stat=True, anorm=ops.NormRef(stat, styles, gam, bet, 1e-5), anorm_out=True)
+    s1 = ops.pop_gemm_stat(y1)
+    assert torch.equal(xn0, xn1) and torch.equal(y0, y1)
+    assert torch.allclose(s0.sum(0), s1.sum(0), rtol=1e-6, atol=1e-3)
+    w2t, w1t = w2.t().contiguous(), w1.t().contiguous()
+    dz0, h0, dx0 = ops.mlp_bwd(xn0, dy, w1, b1, w2t, w1t)
+    dz1, h1, dx1, dstat = ops.mlp_bwd(xn1, dy, w1, b1, w2t, w1t, bstat=(x, stat, 1e-5))
+    assert torch.equal(dz0, dz1) and torch.equal(h0, h1) and torch.equal(dx0, dx1)
+    want = ops.instnorm_bwd_reduce(dx0, x, 1, M, stat).sum(0)
+    got = dstat.view(-1, 1, 48, 2).sum(0)
+    scale = want.abs().max(dim=1, keepdim=True).values
+    assert float(((got - want).abs() / scale).max()) < 2e-5
+
+
 def test_gemm_nt_exact_integers():
     """asymmetric small-integer operands: catches transposed / permuted MFMA fragment maps exactly."""
     ops = _ops()

@@ -1,6 +1,7 @@
 """GPU parity tests, module level: the drop-in modules (HIP kernels through the C ABI) against the golden vectors
 captured from the reference's own modules, and against the CPU oracle.  fp32 tolerance 1e-3 (north_star)."""
 import copy
+import os
 
 import pytest
 import torch
@@ -102,6 +103,44 @@ def test_swin_block(golden, tag):
     assert rel_err(y, G.t(f"{tag}/y")) < TOL
     assert rel_err(x.grad, G.t(f"{tag}/dx")) < TOL
     _check_param_grads(m, G.grads(tag), case["grad_none"], TOL)
+
+
+@pytest.mark.parametrize("dim,heads,grid,shift,norm", [(48, 3, (16, 16, 16), (0, 0, 0), "instance_cond"), (96, 6, (16, 18, 16), (3, 3, 3), "instance_cond"),
+                                                  (48, 3, (16, 16, 17), (3, 3, 3), "instance")])
+def test_swin_block_with_its_norms_folded_into_the_gemms(dim, heads, grid, shift, norm):
+    """round 5 (stages 1 - 2 of the headline net: one sample, bf16, >= 4096 tokens): norm1's apply pass inside the qkv GEMM's operand load,
+    norm2's inside the MLP's first product, the norms' backward sums in the data-gradient epilogues (HF._NormLinear / _NormMlp) - against the
+    same block with every norm pass a launch of its own (ops.FOLD_NORMS = False): same output bit for bit (same fma, same rounding), gradients
+    to the summation order of the backward sums; and the launch count drops by the folded passes."""
+    from mi_seg_amd.hip import ops
+    from mi_seg_amd.networks.blocks.swin_transformer_block import SwinTransformerBlock
+    from mi_seg_amd.testing import roofline
+    m = _fill(SwinTransformerBlock(dim, heads, (7, 7, 7), shift, norm_type=_norm(norm)))
+    m.to(DEV)
+    st = _styles([1], 1)
+    g = torch.Generator().manual_seed(7)
+    x0 = (torch.randn((1,) + grid + (dim,), generator=g) * 1.5 + 0.3).to(DEV).to(torch.bfloat16)
+    cot = torch.randn((1,) + grid + (dim,), generator=g).to(DEV).to(torch.bfloat16)
+    res = {}
+    for fold in (True, False):
+        ops.FOLD_NORMS = fold
+        try:
+            m.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            y = m(x, st)
+            y.backward(cot)
+            res[fold] = (y.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None},
+                         sorted(k for k, p in m.named_parameters() if p.grad is None))
+        finally:
+            ops.FOLD_NORMS = True
+    (y1, dx1, g1, n1), (y0, dx0, g0, n0) = res[True], res[False]
+    assert torch.equal(y1, y0), rel_err(y1, y0)
+    assert n1 == n0 and sorted(g1) == sorted(g0)
+    assert rel_err(dx1, dx0) < 4e-3, rel_err(dx1, dx0)
+    for k in g0:
+        assert rel_err(g1[k], g0[k]) < 4e-3, (k, rel_err(g1[k], g0[k]))
+    if norm == "instance_cond":
+        assert any(k.endswith("norms.0.weight") for k in n1)          # the absent style's rows keep grad None in both forms
 
 
 @pytest.mark.parametrize("tag", ["merging", "mergingv2", "merging_odd_layer"])
@@ -361,12 +400,14 @@ def test_unetr_c3(golden, dtype, tol):
     _whole(G, "c3_m1", m, tol, dtype)
 
 
-SMALL_NET_BAR = dict(fp32=(3.0, 1e-2, 1.5), bf16=(4.0, 2e-2, 1.5), bf16_scalar_family=True)
+SMALL_NET_BAR = dict(fp32=(3.0, 1e-3, 1.5), bf16=(4.0, 2e-2, 1.5), bf16_scalar_family=True)
 """(factor, slack, median factor) of _vs_truth for the 32^3 / 64^3 nets.  Their gradients jump with every single activation-sign flip
 (LeakyReLU / PReLU on normalised pre-activations): with ~1e6 pre-activations and a forward error of 3e-7 the expected number of flips is
 below one, so the reference's fp32 run happens to sit 8e-7 from its float64 run while ONE flip near the output puts every upstream
 gradient 1e-4 .. 7e-3 away (measured: UNETR 32^3, 205 of 276 parameters at 3.6e-3 .. 6.6e-3 together; UNet 64^3, the six parameters in front of
-the first PReLU at 1.1e-4) - the slack is that jump, the 1e-2 the fp32 fixtures are compared at (`_whole`).  bf16: torch.autocast keeps norm outputs / activations in fp32 and only runs convolutions
+the first PReLU at 1.1e-4) - the fp32 slack was that jump (1e-2) through round 4.  Round 5: 1e-3 - the fp32 convolutions keep ONE summation
+plan and the fp32 GEMMs sum in blocks, neither small net catches a flip on this input any more (gradient medians 5.4e-7 / 1.1e-6); the
+robust form of this check is test_vs_truth_over_seeds (three inputs, medians over seeds, no slack at all).  bf16: torch.autocast keeps norm outputs / activations in fp32 and only runs convolutions
 and linears in bf16, this path STORES every activation in bf16 - sums with heavy cancellation (the one-element PReLU slope gradients: a
 sum over ~2 M voxels) carry that storage rounding, and so do autocast's: against the float64 run the 13 slopes of the C1 UNet (|g| 1.5 .. 1166,
 median 174) sit 2 .. 86 away under autocast (rms 36 = 0.21 of the median) and 3 .. 103 away here (rms 33 / 41 / 41 with the 96-byte-chunk
@@ -455,6 +496,112 @@ def test_unet_vs_truth(golden, tag, dtype):
     m = UNet(3, 1, 6, channels=c["channels"], strides=c["strides"], num_res_units=c["num_res_units"], act="prelu",
              norm_down=_norm(c.get("norm_down", "instance")), norm_up=_norm("instance"), dropout=0.0, bias=True, adn_ordering="NDA")
     _vs_truth(T, R, tag, m, dtype, **SMALL_NET_BAR)
+
+
+def _seed_case_model(tag):
+    from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
+    from mi_seg_amd.networks.nets.unet import UNet
+    from mi_seg_amd.networks.nets.unetr import UNETR
+    cond, inst = (lambda: _norm("instance_cond")), (lambda: _norm("instance"))
+    if tag == "c2_m0":
+        return SwinUNETR((96, 96, 96), 1, 6, feature_size=48, num_heads=(3, 6, 12, 24), vit_norm_name=cond(), encoder_norm_name=cond(), decoder_norm_name=inst())
+    if tag == "c3_m1":
+        return UNETR(1, 6, (96, 96, 96), feature_size=16, hidden_size=768, mlp_dim=3072, num_heads=12, pos_embed="perceptron", vit_norm_name=cond(),
+                     encoder_norm_name=cond(), decoder_norm_name=inst())
+    if tag == "small_32":
+        return UNETR(1, 6, (32, 32, 32), feature_size=8, hidden_size=48, mlp_dim=96, num_heads=4, pos_embed="perceptron", vit_norm_name=cond(),
+                     encoder_norm_name=cond(), decoder_norm_name=inst())
+    if tag == "c1_64":
+        return UNet(3, 1, 6, channels=[32, 64, 128, 256], strides=[2, 2, 2], num_res_units=2, act="prelu", norm_down=inst(), norm_up=inst(), dropout=0.0,
+                    bias=True, adn_ordering="NDA")
+    return UNet(3, 1, 6, channels=[8, 16, 32], strides=[2, 2], num_res_units=2, act="prelu", norm_down=cond(), norm_up=inst(), dropout=0.0, bias=True,
+                adn_ordering="NDA")
+
+
+SEED_BARS = {torch.float32: dict(per_param=2.5, family=1.5, logits=1.25), torch.bfloat16: dict(per_param=1.6, family=1.25, logits=1.25)}
+"""test_vs_truth_over_seeds, no absolute slack anywhere (the 1e-9 below only keeps 0 / 0 apart):
+  * per parameter: the MEDIAN OVER THE THREE INPUT SEEDS of (distance of the HIP gradient from the reference's float64 run) / (distance of the
+    reference's own run at the same precision from it) <= `per_param`;
+  * per net: the median over seeds of (median over parameters of the HIP distances / median of the reference's) <= `family`;
+  * the logits of EVERY seed within `logits` x the reference's distance;
+  * one-element parameters in bf16 (PReLU slopes: sums over ~2 M voxels with heavy cancellation, SMALL_NET_BAR) as a family: the median over
+    seeds of rms(HIP errors) / rms(reference errors) <= 1.5.
+One draw against one draw (the single-seed tests above) hinges on which activation-sign flips the two runs happen to catch: the reference's
+own fp32 run of the 32^3 UNETR sits 1.7e-6, 6.7e-3 and 1.2e-4 from its float64 run on the three seeds, the plain UNet's 1.2e-6, 1.2e-6,
+2.5e-4 (oracle/tools/make_golden.py::gen_seeds_truth prints them); a median over seeds does not.
+Measured on the round-5 build (profiles/r05_vs_truth_seeds.txt): fp32 worst per-parameter ratio 0.85 (C2) / 1.07 (C3) / 1.12 / 1.66 / 2.13 (the last
+two: one-element PReLU slopes of the small UNets), family ratios 0.41 ... 1.06; bf16 worst 1.05 / 1.23 / 1.46, families 0.91 ... 1.07.
+This test found a real gap on its first run: C-UNETR's fp32 logits sat 1.5 - 1.9 x further from float64 than the reference's on every seed
+(one running fp32 sum over K = 4096 in the patch-embedding GEMM); the blocked accumulation of csrc/gemm.hip put them at 0.5 x."""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("tag", ["c2_m0", "c3_m1", "small_32", "c1_64", "cond_32"])
+def test_vs_truth_over_seeds(golden, tag, dtype):
+    """every whole-net configuration of BASELINE.json on THREE inputs (tests/golden/seeds_truth.npz: the reference's
+    float64 gradients and the distances of its own fp32 / autocast-bf16 runs from them, 1024 samples per parameter)."""
+    from mi_seg_amd.utils.detfill import det_input
+    S = golden("seeds_truth")
+    case, seeds, n = S.meta["cases"][tag], S.meta["seeds"], S.meta["samples"]
+    keys = case["keys"]
+    bars = SEED_BARS[dtype]
+    is32 = dtype == torch.float32
+    mode = "fp32" if is32 else "amp"
+    m = _fill(_seed_case_model(tag))
+    m.set_compute_dtype(dtype)
+    named = dict(m.named_parameters())
+    ratios = {k: [] for k in keys}
+    lines, fam_ratio, scal_ratio = [], [], []
+    measure = bool(os.environ.get("MISEG_SEEDS_MEASURE"))      # print every line, assert nothing: how the bars were read off (profiles/r05_vs_truth_seeds.txt)
+    for seed in seeds:
+        pre = f"{tag}/s{seed}/"
+        m.zero_grad(set_to_none=True)
+        y = m(det_input(seed, tuple(case["x"])).to(DEV), case["modalities"])
+        e_log, e_log_ref = rel_err(sample(y, n), S.t(pre + "logits64_samples")), float(S.z[pre + f"elogits_{mode}"])
+        assert measure or e_log <= bars["logits"] * e_log_ref, (tag, seed, "logits", e_log, e_log_ref)
+        y.backward(det_input(seed + S.meta["cotangent_seed_offset"], tuple(y.shape)).to(DEV))
+        truth = {k: S.t(pre + "grad64:" + k) for k in keys}
+        e_ref = dict(zip(keys, [float(v) for v in S.z[pre + f"e_{mode}"]]))
+        rms = {k: float(g.double().norm()) / g.numel() ** 0.5 for k, g in truth.items()}
+        med = sorted(rms.values())[len(rms) // 2]
+        scal = scalar_scale(truth)
+        hip, ref, sh, sr = [], [], [], []
+        for k in keys:
+            got, t = sample(named[k].grad, n), truth[k]
+            if rms[k] < 1e-3 * med:                                   # analytically zero gradient: must vanish here too
+                assert float(got.double().norm()) / got.numel() ** 0.5 < (1e-4 if is32 else 0.1) * med, (k, seed, "should vanish")
+                continue
+            if t.numel() == 1:      # an ill-conditioned one-element sum (PReLU slopes): judged on the scale of its peers (conftest.scalar_scale)
+                scale = max(float(t.double().abs().max()), scal)
+                e_h = float((got.double() - t.double()).abs().max()) / scale
+                e_r = float((S.t(pre + f"v_{mode}:" + k).double() - t.double()).abs().max()) / scale
+                if not is32:        # bf16: as a family (see SEED_BARS)
+                    sh.append(e_h)
+                    sr.append(e_r)
+                    continue
+            else:
+                e_h, e_r = rel_err(got, t), e_ref[k]
+            ratios[k].append(e_h / (e_r + 1e-9))
+            hip.append(e_h)
+            ref.append(e_r)
+        mh, mr = sorted(hip)[len(hip) // 2], sorted(ref)[len(ref) // 2]
+        fam_ratio.append(mh / (mr + 1e-12))
+        if sh:
+            scal_ratio.append((sum(v * v for v in sh) / len(sh)) ** 0.5 / ((sum(v * v for v in sr) / len(sr)) ** 0.5 + 1e-12))
+        lines.append(f"seed {seed}: logits {e_log:.2e} (ref {e_log_ref:.2e}), gradient medians {mh:.2e} vs {mr:.2e}")
+    meds = {k: sorted(v)[len(v) // 2] for k, v in ratios.items() if v}
+    worst = max(meds.items(), key=lambda kv: kv[1])
+    over = sorted(((round(v, 2), k) for k, v in meds.items() if v > bars["per_param"]), reverse=True)
+    fam = sorted(fam_ratio)[len(fam_ratio) // 2]
+    sfam = sorted(scal_ratio)[len(scal_ratio) // 2] if scal_ratio else None
+    evidence(f"{tag} over seeds {seeds} {dtype}: " + "; ".join(lines) + f"; per-parameter median-over-seeds ratio: worst {worst[1]:.2f} ({worst[0]}), "
+             f"median {sorted(meds.values())[len(meds) // 2]:.2f}; family ratio per seed {[round(v, 2) for v in fam_ratio]} (median {fam:.2f})"
+             + (f"; one-element parameters as a family, rms ratio per seed {[round(v, 2) for v in scal_ratio]}" if scal_ratio else "")
+             + f"; bars: per parameter {bars['per_param']} x, family {bars['family']} x, logits {bars['logits']} x, no slack")
+    assert measure or fam <= bars["family"], (tag, "median over seeds of the family ratio", fam_ratio)
+    assert measure or sfam is None or sfam <= 1.5, (tag, "one-element parameters as a family", scal_ratio)
+    assert measure or not over, (f"{len(over)} of {len(meds)} parameters: median over seeds of the distance ratio above {bars['per_param']}", over[:12])
 
 
 @pytest.mark.gpu
