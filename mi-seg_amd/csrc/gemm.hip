@@ -549,13 +549,19 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_stream_kernel(const bf16* __re
 // K loop with unconditional, clamped loads was SLOWER: 216 x 768 x 3072 18.8 -> 20.3 us, it over-fetches two batches per wave): 32 x 32
 // outputs read 64 operand rows per k-step for 4 MFMAs where 16 x 32 read 48 for 2 (216 x 768 x 3072: 20.2 -> 14.2 us, 216 x 768 x 768:
 // 8.4 -> 6.4), 32 x 64 read 96 for 8 (216 x 2304 x 768: 12.8 -> 8.9).  scripts/bench_gemm.py small, MISEG_GEMM_SMALL_TILE.
+// Round 5 (the deep Swin stages, 1,728 / 216 tokens of ONE sample): STAT = 1 - instance-norm statistics of the rounded output in the epilogue
+// (proj + residual, fc2 + residual: the consumer norm then has no statistics pass); STAT = 2 - the backward sums (sum q, sum q * xhat) of
+// the norm whose output gradient this GEMM produces; ANORM - A is the raw input of an instance norm, normalised as it is loaded (scale /
+// shift per k from LDS), norm(A) stored once by the workgroups of the first column tile.  With these the norm between two linears of a deep
+// Swin block is no launch at all in the forward pass (it was one 5 - 8 us launch each: ~6 % of the stage's chain).
 static constexpr int SM_BS = 4;      // k-steps whose loads are in flight together
-template <int MTW, int NTW, bool GELU>
+template <int MTW, int NTW, bool GELU, int STAT = 0, bool ANORM = false>
 __global__ void __launch_bounds__(256) gemm_nt_small_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ W, int64_t ldw, bf16* __restrict__ C,
                                                             int64_t ldc, int M, int N, int K, Epi epi, int gm) {
   const float* bias = epi.bias;
   constexpr int NTILE = MTW * NTW;
   __shared__ __attribute__((aligned(16))) float part[4][NTILE][64][4];
+  __shared__ __attribute__((aligned(16))) float ncoef[(ANORM || STAT == 2) ? 2 * 384 : 4];      // ANORM: scale[K], shift[K] (K <= 384); STAT 2: mean / rstd of this tile's columns
   // wave index as a SCALAR: the k-range guards below must be real branches -- an MFMA ignores EXEC, so a guard the compiler
   // if-converts (it cannot know tid >> 6 is wave-uniform) would let the skipped k-steps accumulate garbage operands
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fi = lane & 15, kg = lane >> 4;
@@ -569,6 +575,34 @@ __global__ void __launch_bounds__(256) gemm_nt_small_kernel(const bf16* __restri
   }
   const int ksteps = K / 32, kpw = (ksteps + 3) / 4;
   const int ks0 = wave * kpw, ks1 = min(ksteps, ks0 + kpw);
+  if constexpr (ANORM) {
+    const int st = epi.an_styles ? epi.an_styles[0] : 0;
+    const float* g = st == 0 ? epi.an_gamma[0] : st == 1 ? epi.an_gamma[1] : st == 2 ? epi.an_gamma[2] : epi.an_gamma[3];
+    const float* be = st == 0 ? epi.an_beta[0] : st == 1 ? epi.an_beta[1] : st == 2 ? epi.an_beta[2] : epi.an_beta[3];
+    for (int k = tid; k < K; k += 256) {
+      double a, b;
+      gemm_gather_stat(epi.an_stat, K, k, a, b);
+      float m_, r_;
+      gemm_mean_rstd(a, b, 1.0 / M, epi.an_eps, m_, r_);
+      const float sc = r_ * (g ? g[k] : 1.f);
+      ncoef[k] = sc;
+      ncoef[384 + k] = (be ? be[k] : 0.f) - m_ * sc;
+    }
+    __syncthreads();
+  }
+  if constexpr (STAT == 2) {
+    for (int c = tid; c < 16 * NTW; c += 256) {
+      float m_ = 0.f, r_ = 0.f;
+      if (n0 + c < N) {
+        double a, b;
+        gemm_gather_stat(epi.bstat_in, N, n0 + c, a, b);
+        gemm_mean_rstd(a, b, 1.0 / M, epi.beps, m_, r_);
+      }
+      ncoef[c] = m_;
+      ncoef[384 + c] = r_;
+    }
+    // (visible to the epilogue's readers through the barrier behind the partial-tile stores)
+  }
   const bf16* arow[MTW];
   const bf16* wrow[NTW];
 #pragma unroll
@@ -594,6 +628,19 @@ __global__ void __launch_bounds__(256) gemm_nt_small_kernel(const bf16* __restri
 #pragma unroll
     for (int u = 0; u < SM_BS; ++u) {
       if (ks + u < ks1) {
+        if constexpr (ANORM) {      // fma(x, sc, sh) rounded to bf16: the bits instnorm_apply_kernel would have stored
+          const f32x4 s0 = *reinterpret_cast<const f32x4*>(ncoef + (ks + u) * 32 + 8 * kg), s1 = *reinterpret_cast<const f32x4*>(ncoef + (ks + u) * 32 + 8 * kg + 4);
+          const f32x4 h0 = *reinterpret_cast<const f32x4*>(ncoef + 384 + (ks + u) * 32 + 8 * kg), h1 = *reinterpret_cast<const f32x4*>(ncoef + 384 + (ks + u) * 32 + 8 * kg + 4);
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) {
+            bf16x8 v = af[u][mt];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = (bf16)fmaf((float)v[e], s0[e], h0[e]); v[4 + e] = (bf16)fmaf((float)v[4 + e], s1[e], h1[e]); }
+            af[u][mt] = v;
+            const int row = m0 + mt * 16 + fi;
+            if (epi.an_out && n0 == 0 && row < M) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(epi.an_out) + (int64_t)row * epi.ld_an_out + (ks + u) * 32 + 8 * kg) = v;
+          }
+        }
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -613,10 +660,34 @@ __global__ void __launch_bounds__(256) gemm_nt_small_kernel(const bf16* __restri
 #pragma unroll
     for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(&part[w][t][lane][0]);
     const int m = m0 + mt * 16 + fi, n = n0 + nt * 16 + 4 * kg;
+    float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
     if (m < M && n < N) {
       if (bias) { v[0] += bias[n]; v[1] += bias[n + 1]; v[2] += bias[n + 2]; v[3] += bias[n + 3]; }
       v = epi_vec4_bf16(v, m, n, epi, GELU);
-      *reinterpret_cast<bf16x4*>(C + (int64_t)m * ldc + n) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+      const bf16x4 o4 = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+      *reinterpret_cast<bf16x4*>(C + (int64_t)m * ldc + n) = o4;
+      if constexpr (STAT == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s4[r] = (float)o4[r]; q4[r] = s4[r] * s4[r]; }
+      }
+      if constexpr (STAT == 2) {
+        const bf16x4 x4 = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(epi.bx) + (int64_t)m * epi.ldbx + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s4[r] = (float)o4[r]; q4[r] = s4[r] * (((float)x4[r] - ncoef[nt * 16 + 4 * kg + r]) * ncoef[384 + nt * 16 + 4 * kg + r]); }
+      }
+    }
+    if constexpr (STAT != 0) {
+      // the 16 rows of the tile sit on the 16 lanes fi of each kg group: butterfly over fi, then one fp64 atomic per (column, which) from lane fi == 0
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s4[r] += __shfl_xor(s4[r], o, 64); q4[r] += __shfl_xor(q4[r], o, 64); }
+      }
+      if (fi == 0 && n < N) {
+        double* dst = epi.stat + ((int64_t)(((m0 >> 4) + mt) & 15) * N + n) * 2;      // replica = row tile mod 16: [16][B = 1][N][2]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { atomicAdd(dst + 2 * r, (double)s4[r]); atomicAdd(dst + 2 * r + 1, (double)q4[r]); }
+      }
     }
   }
 }
@@ -932,6 +1003,14 @@ static bool tn_stream_plan(const miseg_gemm_params* p, TnStreamPlan* pl) {
   return true;
 }
 
+// the small-M kernel (M <= 2048 rows of one sample) takes the same folds (gemm_nt_small_kernel)
+static bool nt_small_ok(const miseg_gemm_params* p) {
+  if (!p || p->ta || p->tb || p->dtype != MISEG_BF16 || p->out_dtype != MISEG_BF16) return false;
+  const bool al_a = ((uintptr_t)p->A % 16 == 0) && (p->lda % 8 == 0), al_b = ((uintptr_t)p->B % 16 == 0) && (p->ldb % 8 == 0);
+  const bool epi_vec_ok = (!p->res || (((uintptr_t)p->res % 8 == 0) && p->ldres % 4 == 0)) && (!p->epi_mode || (((uintptr_t)p->aux % 8 == 0) && p->ldaux % 4 == 0));
+  return p->split_k <= 1 && !p->accumulate && p->M <= 2048 && p->M >= 16 && p->K % 32 == 0 && p->N % 16 == 0 && al_a && al_b && ((uintptr_t)p->C % 8 == 0) &&
+         p->ldc % 4 == 0 && epi_vec_ok && !p->scat_cout;
+}
 extern "C" int miseg_gemm_fuses_stat(const miseg_gemm_params* p) {
   if (p && !p->ta && !p->tb && p->dtype == p->out_dtype && p->K == 1) {      // the rank-1 kernel (stem shortcut), either dtype
     const int n16 = p->dtype == MISEG_BF16 ? 8 : 4;
@@ -939,6 +1018,7 @@ extern "C" int miseg_gemm_fuses_stat(const miseg_gemm_params* p) {
            ((uintptr_t)p->C % 16 == 0) && p->ldc % n16 == 0 && !p->scat_cout;
   }
   if (!p || p->ta || p->tb || p->dtype != MISEG_BF16 || p->out_dtype != MISEG_BF16) return 0;
+  if (nt_small_ok(p) && p->act == MISEG_ACT_NONE && !p->an.stat) return 1;      // the small-M kernel: any N (round 5)
   const size_t lds = (size_t)p->N * (p->K * 2 + 16) + (size_t)p->N * 4;
   const bool al_a = ((uintptr_t)p->A % 16 == 0) && (p->lda % 8 == 0), al_b = ((uintptr_t)p->B % 16 == 0) && (p->ldb % 8 == 0);
   const bool epi_vec_ok = (!p->res || (((uintptr_t)p->res % 8 == 0) && p->ldres % 4 == 0)) && (!p->epi_mode || (((uintptr_t)p->aux % 8 == 0) && p->ldaux % 4 == 0));
@@ -955,6 +1035,9 @@ static bool nt_stream_common_ok(const miseg_gemm_params* p) {
          !p->scat_cout;
 }
 extern "C" int miseg_gemm_fuses_anorm(const miseg_gemm_params* p) {
+  if (nt_small_ok(p) && !p->stat && p->K <= 384 && p->an.num_styles >= 1 && p->an.num_styles <= MISEG_MAX_STYLES &&
+      (!p->an_out || (((uintptr_t)p->an_out % 16) == 0 && p->ld_an_out % 8 == 0)))
+    return 1;
   if (!nt_stream_common_ok(p) || !(p->K == 48 || p->K == 96) || p->stat) return 0;
   if (p->an.num_styles < 1 || p->an.num_styles > MISEG_MAX_STYLES) return 0;
   if (p->an_out && (((uintptr_t)p->an_out % 16) != 0 || p->ld_an_out % 8 != 0)) return 0;
@@ -963,6 +1046,7 @@ extern "C" int miseg_gemm_fuses_anorm(const miseg_gemm_params* p) {
 }
 // ... with the norm-backward sums of its output (STAT == 2): the data-gradient GEMMs behind qkv / fc1
 extern "C" int miseg_gemm_fuses_bstat(const miseg_gemm_params* p) {
+  if (nt_small_ok(p) && p->act == MISEG_ACT_NONE && !p->epi_mode && !p->an.stat && p->bs_x && ((uintptr_t)p->bs_x % 8) == 0 && p->ld_bs_x % 4 == 0 && p->N <= 384) return 1;
   if (!nt_stream_common_ok(p) || p->act != MISEG_ACT_NONE || p->epi_mode || p->an.stat) return 0;
   // (K = 384, the fc1 data gradient of the 96-channel stage: its operand fragments fill the register file - 156 bytes of scratch per lane with
   // the sums beside them - and it keeps the reduction launch)
@@ -1102,15 +1186,21 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
         const int gm = cdiv(p->M, 16 * mtw);
         dim3 grid(gm * (p->N / (16 * ntw)));
         const bool ge = p->act == MISEG_ACT_GELU;
+        const int smode = p->an.stat ? 3 : !p->stat ? 0 : bstat ? 2 : 1;      // 3: folded norm on the A side (no statistics with it)
+#define SM_ARGS (const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, p->K, epi, gm
 #define SM_LAUNCH(m_, n_)                                                                                                                       \
   do {                                                                                                                                          \
-    if (ge) gemm_nt_small_kernel<m_, n_, true><<<grid, 256, 0, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, p->K, epi, gm); \
-    else gemm_nt_small_kernel<m_, n_, false><<<grid, 256, 0, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (bf16*)p->C, p->ldc, p->M, p->N, p->K, epi, gm); \
+    if (smode == 3) { if (ge) gemm_nt_small_kernel<m_, n_, true, 0, true><<<grid, 256, 0, s>>>(SM_ARGS); else gemm_nt_small_kernel<m_, n_, false, 0, true><<<grid, 256, 0, s>>>(SM_ARGS); } \
+    else if (smode == 2) gemm_nt_small_kernel<m_, n_, false, 2><<<grid, 256, 0, s>>>(SM_ARGS);                                                  \
+    else if (smode == 1) gemm_nt_small_kernel<m_, n_, false, 1><<<grid, 256, 0, s>>>(SM_ARGS);                                                  \
+    else if (ge) gemm_nt_small_kernel<m_, n_, true><<<grid, 256, 0, s>>>(SM_ARGS);                                                              \
+    else gemm_nt_small_kernel<m_, n_, false><<<grid, 256, 0, s>>>(SM_ARGS);                                                                     \
   } while (0)
         if (mtw == 4) SM_LAUNCH(4, 3);
         else if (mtw == 2) { if (ntw == 4) SM_LAUNCH(2, 4); else if (ntw == 2) SM_LAUNCH(2, 2); else SM_LAUNCH(2, 1); }
         else { if (ntw == 4) SM_LAUNCH(1, 4); else if (ntw == 2) SM_LAUNCH(1, 2); else SM_LAUNCH(1, 1); }
 #undef SM_LAUNCH
+#undef SM_ARGS
         MISEG_LAUNCH_CHECK("gemm_nt_small");
         return MISEG_OK;
       }

@@ -316,7 +316,10 @@ def instance_norm(x, params=None, styles_dev=None, styles_host=None, res=None, a
     _PENDING_OUT = out
     if stat is None:
         stat = _carried_stat(x)
-    return _InstNorm.apply(x, res, styles_dev, styles_host, n, params is not None, act, slope, eps, fork, stat, *flat)
+    r = _InstNorm.apply(x, res, styles_dev, styles_host, n, params is not None, act, slope, eps, fork, stat, *flat)
+    if fork and isinstance(stat, torch.Tensor) and res is None:
+        r[1]._miseg_stat = stat      # the skip branch is x itself: statistics its producer left on it stay valid for the next norm of x
+    return r
 
 
 class _GroupStatNorm(Function):

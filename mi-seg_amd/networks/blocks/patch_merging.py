@@ -28,7 +28,8 @@ class PatchMergingV2(nn.Module):
             raise ValueError(f"expecting 5D x, got {x.shape}.")
         x = HF.space_to_channel(x, self.offsets)          # odd grids are zero-padded by the gather itself
         x = apply_norm(self.norm, x, styles)
-        return HF.linear(x, self.reduction.weight, None)
+        # the result feeds instance norms (the stage's output norm and the next block's norm1): statistics from the GEMM's epilogue where it has one
+        return HF.linear(x, self.reduction.weight, None, want_stat=self.norm_type.startswith("instance"))
 
 
 class PatchMerging(PatchMergingV2):

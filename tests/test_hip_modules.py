@@ -106,7 +106,8 @@ def test_swin_block(golden, tag):
 
 
 @pytest.mark.parametrize("dim,heads,grid,shift,norm", [(48, 3, (16, 16, 16), (0, 0, 0), "instance_cond"), (96, 6, (16, 18, 16), (3, 3, 3), "instance_cond"),
-                                                  (48, 3, (16, 16, 17), (3, 3, 3), "instance")])
+                                                  (48, 3, (16, 16, 17), (3, 3, 3), "instance"), (192, 12, (12, 12, 12), (3, 3, 3), "instance_cond"),
+                                                  (384, 24, (6, 6, 6), (0, 0, 0), "instance_cond")])
 def test_swin_block_with_its_norms_folded_into_the_gemms(dim, heads, grid, shift, norm):
     """round 5 (stages 1 - 2 of the headline net: one sample, bf16, >= 4096 tokens): norm1's apply pass inside the qkv GEMM's operand load,
     norm2's inside the MLP's first product, the norms' backward sums in the data-gradient epilogues (HF._NormLinear / _NormMlp) - against the
@@ -134,7 +135,10 @@ def test_swin_block_with_its_norms_folded_into_the_gemms(dim, heads, grid, shift
         finally:
             ops.FOLD_NORMS = True
     (y1, dx1, g1, n1), (y0, dx0, g0, n0) = res[True], res[False]
-    assert torch.equal(y1, y0), rel_err(y1, y0)
+    if x0.numel() // dim >= 4096:
+        assert torch.equal(y1, y0), rel_err(y1, y0)
+    else:      # the deep stages: the unfolded form is the register-resident one-launch norm kernel, whose statistics are summed in another order
+        assert rel_err(y1, y0) < 4e-3, rel_err(y1, y0)
     assert n1 == n0 and sorted(g1) == sorted(g0)
     assert rel_err(dx1, dx0) < 4e-3, rel_err(dx1, dx0)
     for k in g0:
