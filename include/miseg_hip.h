@@ -263,7 +263,8 @@ int miseg_gemm(const miseg_gemm_params* p, miseg_stream_t stream);
 /* up to MISEG_GEMM_GROUP independent TN problems C[M][N] += A[K][M]^T B[K][N] (fp32 C, accumulate mode) in ONE launch: the weight
  * gradients of the deep stages are a few dozen workgroups each; the host queues them during the backward pass and issues them
  * together.  `descs` is a HOST array (copied into the kernel arguments). */
-typedef struct { const float* partial; float* C; int64_t ldc; int32_t M, N, splits, block0; } miseg_tn_reduce_desc;
+/* regroup > 0 (ABI 8): column n = j * regroup + c of the summed product is stored at column c * (N / regroup) + j (see miseg_gemm_tn_desc) */
+typedef struct { const float* partial; float* C; int64_t ldc; int32_t M, N, splits, block0, regroup, pad_; } miseg_tn_reduce_desc;
 #define MISEG_TN_REDUCE_BATCH 32
 /* C[m][n] += sum over splits of partial[s][m][n] for up to MISEG_TN_REDUCE_BATCH deferred reductions in one launch (HOST descriptors) */
 int miseg_gemm_tn_reduce_batch(const miseg_tn_reduce_desc* descs_host, int n, miseg_stream_t stream);
@@ -271,7 +272,10 @@ int miseg_gemm_tn_reduce_batch(const miseg_tn_reduce_desc* descs_host, int n, mi
 /* zeroed (ABI 5): 1 = C is known to hold zeros (a gradient slot no kernel has written since the step's fill) and no other problem of the
  * launch writes it: a problem whose reduction is not split then STORES its tiles instead of reading C back (the 85 M fp32 weight gradients
  * of C-UNETR's ViT: 340 MB less traffic per step). */
-typedef struct { const void* A; int64_t lda; const void* B; int64_t ldb; float* C; int64_t ldc; int32_t M, N, K, zeroed; } miseg_gemm_tn_desc;
+/* regroup > 0 (ABI 8): column n = j * regroup + c of the product is stored at column c * (N / regroup) + j - the weight gradient of a
+ * ConvTranspose3d(k2, s2) as x^T dy8 (dy8's columns in (j, co) order, regroup = Cout) lands in the torch layout [Cin][Cout][2][2][2]
+ * (unetr_block.py:51-59) without a permute pass */
+typedef struct { const void* A; int64_t lda; const void* B; int64_t ldb; float* C; int64_t ldc; int32_t M, N, K, zeroed, regroup, pad_; } miseg_gemm_tn_desc;
 int miseg_gemm_tn_group(const miseg_gemm_tn_desc* descs_host, int n, int dtype, miseg_stream_t stream);
 
 /* fp32 re-layout: dst[i0][i1][i2] (+)= src[i0*s0 + i1*s1 + i2*s2]  (weight-gradient unpacking) */

@@ -711,9 +711,12 @@ template <> struct TnFrag<bf16> {
   }
 };
 
+// regroup > 0 (fp32 output): column n = j * regroup + c of the product is stored at column c * (N / regroup) + j - the weight gradient of a
+// ConvTranspose3d(k2, s2) computed as x^T dy8 with dy8's columns in (j, co) order lands in the torch layout [Cin][Cout][2][2][2] directly
+// (round 5: no [(j, co)][ci] intermediate, no permute launch, no fill)
 template <class T, class TO>
 __device__ __forceinline__ void gemm_tn_body(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, TO* __restrict__ C, int64_t ldc,
-                                             int M, int N, int K, int mode, bool vec_a, bool vec_b, int k_per_split, int bx, int by, int bz) {
+                                             int M, int N, int K, int mode, bool vec_a, bool vec_b, int k_per_split, int bx, int by, int bz, int regroup = 0) {
   typedef typename Vec16<T>::type VT;
   constexpr int KPC = Mma<T>::KPC;     // elements per 16-byte chunk (here along m / n)
   constexpr int BM = 64, BN = 64, BK = std::is_same<T, bf16>::value ? 128 : 64;   // k rows per stage
@@ -796,6 +799,29 @@ __device__ __forceinline__ void gemm_tn_body(const T* __restrict__ A, int64_t ld
         for (int nt = 0; nt < 2; ++nt) { tot[mt][nt] += acc[mt][nt]; acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
   }
+  if constexpr (std::is_same<TO, float>::value) {
+    if (regroup > 0) {
+      const int per = N / regroup;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const f32x4 v = std::is_same<T, float>::value ? tot[mt][nt] : acc[mt][nt];
+          const int m = m0 + wm * 32 + mt * 16 + fi;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wn * 32 + nt * 16 + fq * 4 + r;
+            if (m < M && n < N) {
+              float* p = C + (int64_t)m * ldc + (n % regroup) * per + n / regroup;
+              if (mode == 2) atomicAdd(p, v[r]);
+              else if (mode == 1) *p += v[r];
+              else *p = v[r];
+            }
+          }
+        }
+      return;
+    }
+  }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -813,7 +839,7 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const T* __restrict__ A, i
 // grouped form: a list of independent TN problems (the weight gradients of the deep stages, a few dozen workgroups each)
 // in ONE launch; descriptors travel in the kernel arguments
 struct TnGroup {
-  struct P { const void* A; int64_t lda; const void* B; int64_t ldb; float* C; int64_t ldc; int M, N, K, kps, gx, gy, block0, mode; bool va, vb; } p[MISEG_GEMM_GROUP];
+  struct P { const void* A; int64_t lda; const void* B; int64_t ldb; float* C; int64_t ldc; int M, N, K, kps, gx, gy, block0, mode, regroup; bool va, vb; } p[MISEG_GEMM_GROUP];
   int n;
 };
 
@@ -824,7 +850,7 @@ __global__ void __launch_bounds__(256) gemm_tn_group_kernel(TnGroup g) {
   const TnGroup::P& q = g.p[k];
   const int local = blockIdx.x - q.block0;
   const int bx = local % q.gx, by = (local / q.gx) % q.gy, bz = local / (q.gx * q.gy);
-  gemm_tn_body<T, float>((const T*)q.A, q.lda, (const T*)q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, q.mode, q.va, q.vb, q.kps, bx, by, bz);
+  gemm_tn_body<T, float>((const T*)q.A, q.lda, (const T*)q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, q.mode, q.va, q.vb, q.kps, bx, by, bz, q.regroup);
 }
 
 // ------------------------------------------------------------------------------------------------ TN, streaming
@@ -1408,6 +1434,15 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce_batch_kernel(TnReduceBatch
   }
   for (; s < s1; ++s) a[0] += *reinterpret_cast<const f32x4*>(p + s * stride);
   const f32x4 v = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  if (d.regroup > 0) {      // see gemm_tn_body: column n = j * regroup + c goes to column c * (N / regroup) + j
+    const int per = d.N / d.regroup;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float* c = d.C + (int64_t)m * d.ldc + ((n + r) % d.regroup) * per + (n + r) / d.regroup;
+      if (d.splits <= TNB_SG) *c += v[r]; else atomicAdd(c, v[r]);
+    }
+    return;
+  }
   float* c = d.C + (int64_t)m * d.ldc + n;
   if (d.splits <= TNB_SG) {
     if ((d.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(d.C) & 15) == 0) {
@@ -1432,6 +1467,7 @@ extern "C" int miseg_gemm_tn_reduce_batch(const miseg_tn_reduce_desc* descs, int
   for (int i = 0; i < n; ++i) {
     MISEG_REQUIRE(descs[i].partial && descs[i].C && descs[i].M > 0 && descs[i].N > 0 && descs[i].N % 4 == 0 && descs[i].splits > 0, MISEG_E_BADARG,
                   "gemm_tn_reduce_batch: descriptor %d", i);
+    MISEG_REQUIRE(descs[i].regroup >= 0 && (descs[i].regroup == 0 || descs[i].N % descs[i].regroup == 0), MISEG_E_BADARG, "gemm_tn_reduce_batch: descriptor %d: regroup", i);
     b.d[i] = descs[i];
     b.d[i].block0 = blocks;
     blocks += cdiv(descs[i].M * (descs[i].N / 4), 256) * cdiv(descs[i].splits, miseg::TNB_SG);
@@ -1453,6 +1489,8 @@ extern "C" int miseg_gemm_tn_group(const miseg_gemm_tn_desc* descs, int n, int d
     MISEG_REQUIRE(d.A && d.B && d.C && d.M > 0 && d.N > 0 && d.K > 0, MISEG_E_BADARG, "gemm_tn_group: problem %d", i);
     TnGroup::P& q = g.p[i];
     q.A = d.A; q.lda = d.lda; q.B = d.B; q.ldb = d.ldb; q.C = d.C; q.ldc = d.ldc; q.M = d.M; q.N = d.N; q.K = d.K;
+    MISEG_REQUIRE(d.regroup >= 0 && (d.regroup == 0 || d.N % d.regroup == 0), MISEG_E_BADARG, "gemm_tn_group: problem %d: regroup %d does not divide N %d", i, d.regroup, d.N);
+    q.regroup = d.regroup;
     q.gx = cdiv(d.M, 64); q.gy = cdiv(d.N, 64);
     // split the reduction only when it is long: split partials meet in fp32 atomics, and ~4 M of them (the 12^3-stage problems,
     // K = 1728, split 4 ways) cost 3x what the whole family takes unsplit (75 -> 25 us); the group as a whole fills the chip

@@ -1126,8 +1126,13 @@ class _UpCat(Function):
         if ctx.needs_input_grad[0]:
             dx = ops.gemm_nt(dy8, ops.cast_matrix(weight, x.dtype, regroup=(8, Cout)))   # [ci][(j,co)]
         if ctx.needs_input_grad[2]:
-            slot = _slot(ctx.params[0])
-            if slot is not None:
+            slot, mode = _slot_first(ctx.params[0])
+            if slot is not None and ops.gemm_tn_regroups(x, dy8, slot):
+                # dW[ci][co][j] = sum over voxels of x[v][ci] dy8[v][(j, co)]: the grouped launch / the batched partial-tile sum stores the product's
+                # column (j, co) at (co, j) - the torch layout of the arena slot, no [(j, co)][ci] intermediate, no permute pass (round 5)
+                with ops.wgrad_side(x, dy8):
+                    ops.gemm_tn(x, dy8, out=slot.view(Cin, 8 * Cout), accumulate=mode, regroup=Cout)
+            elif slot is not None:
                 with ops.wgrad_side(dy8, x):
                     dwf = ops.gemm_tn(dy8, x)                                             # [(j,co)][ci]
                     ops.permute3(dwf, slot, (Cin, Cout, 8), (1, Cin, Cout * Cin), accumulate=True)

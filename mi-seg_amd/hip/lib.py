@@ -59,9 +59,11 @@ Gemm = _struct("Gemm", cname="miseg_gemm_params", fields=[("A", vp), ("lda", i64
                         ("epi_mode", i32), ("defer_reduce", i32), ("stat", vp), ("scat_d", i32), ("scat_h", i32), ("scat_w", i32),
                         ("scat_cout", i32), ("an", NormRef), ("an_out", vp), ("ld_an_out", i64), ("stat_mode", i32), ("bs_x", vp), ("ld_bs_x", i64),
                         ("bs_stat", vp), ("bs_eps", f32)])
-TnReduceDesc = _struct("TnReduceDesc", cname="miseg_tn_reduce_desc", fields=[("partial", vp), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32), ("splits", i32), ("block0", i32)])
+TnReduceDesc = _struct("TnReduceDesc", cname="miseg_tn_reduce_desc", fields=[("partial", vp), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32), ("splits", i32), ("block0", i32),
+                                                                            ("regroup", i32), ("pad_", i32)])
 ColsumDesc = _struct("ColsumDesc", cname="miseg_colsum_desc", fields=[("x", vp), ("ldx", i64), ("rows", i64), ("out", vp), ("C", i32), ("block0", i32)])
-GemmTnDesc = _struct("GemmTnDesc", cname="miseg_gemm_tn_desc", fields=[("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32), ("K", i32), ("zeroed", i32)])
+GemmTnDesc = _struct("GemmTnDesc", cname="miseg_gemm_tn_desc", fields=[("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32), ("K", i32), ("zeroed", i32),
+                                                                      ("regroup", i32), ("pad_", i32)])
 Colsum = _struct("Colsum", cname="miseg_colsum_params", fields=[("x", vp), ("ldx", i64), ("rows", i64), ("C", i32), ("dtype", i32), ("out", vp), ("accumulate", i32)])
 Conv3 = _struct("Conv3", cname="miseg_conv3_params", fields=[("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("wpk", vp), ("B", i32), ("D", i32), ("H", i32),
                           ("W", i32), ("Cin", i32), ("Cout", i32), ("dtype", i32), ("workspace", vp), ("res", vp), ("ldres", i64), ("stat", vp), ("background", i32), ("defer_slabs", i32)])

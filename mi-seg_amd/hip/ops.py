@@ -452,6 +452,10 @@ class NormRef:
 
 
 FOLD_NORMS = not os.environ.get("MISEG_NO_NORM_FOLD")      # A/B switch of round 5: the Swin block's norm apply / norm-backward reduce as launches of their own
+# the norm-backward sums in the epilogue of the SMALL-M data-gradient GEMM (<= 2048 rows: the deep Swin stages): the kernels have it (tested),
+# the step does not use it - there the norm backward is ONE register-resident launch already, the fold would trade it for an apply launch
+# (same launch count; measured 153.0 / 153.4 with it against 152.9 / 153.2 without: nothing); the forward folds stay on at every stage
+SMALL_BSTAT = bool(os.environ.get("MISEG_SMALL_BSTAT"))
 
 
 def gemm_nt_folds(a, w, anorm=None, bstat_x=None, act=L.ACT_NONE, res=None):
@@ -460,6 +464,8 @@ def gemm_nt_folds(a, w, anorm=None, bstat_x=None, act=L.ACT_NONE, res=None):
         return False
     lda, M, K = rows(a)
     N = w.shape[0]
+    if bstat_x is not None and M <= 2048 and not SMALL_BSTAT:
+        return False
     # (the output will be a fresh [M, N] tensor: A's pointer stands in for its alignment, and for the not-yet-allocated statistics)
     p = L.Gemm(_ptr(a), lda, _ptr(w), K, _ptr(a), N, M, N, K, 0, 0, _dt(a), _dt(a), None, act, 0, 1, None, _ptr(res), rows(res)[0] if res is not None else 0, None, 0, 0, 0, None)
     if anorm is not None:
@@ -591,8 +597,22 @@ def gemm_nt_scatter(a, w, dst, grid):
     return True
 
 
-def gemm_tn(a, b, out=None, accumulate=False, split_k=0):
-    """out[M,N] (fp32) (+)= a[K,M]^T @ b[K,N]; a, b row views sharing the row count K (weight gradients)."""
+def gemm_tn_regroups(a, b, out):
+    """can gemm_tn(a, b, out, accumulate=..., regroup=...) run for these operands?  (needs a step queue: the regrouped store lives in the
+    grouped launch / the batched partial-tile sum at the end of the backward pass)"""
+    if _queues(out) is None or os.environ.get("MISEG_NO_TN_REGROUP"):      # (the A/B switch of round 5: gemm_tn + permute3)
+        return False
+    lda, K, M = rows(a)
+    N = rows(b)[2]
+    if not (M % 48 == 0 and N % 48 == 0 and K >= 2048 and a.dtype == torch.bfloat16):
+        return True                      # grouped launch
+    p = L.Gemm(_ptr(a), lda, _ptr(b), rows(b)[0], _ptr(out), N, M, N, K, 1, 1, _dt(a), L.F32, None, L.ACT_NONE, 1, 0, None, None, 0, None, 0, 0, 0)
+    return L.load().miseg_gemm_tn_splits(C.byref(p)) > 1      # streaming kernel with partial tiles: their deferred sum regroups
+
+
+def gemm_tn(a, b, out=None, accumulate=False, split_k=0, regroup=0):
+    """out[M,N] (fp32) (+)= a[K,M]^T @ b[K,N]; a, b row views sharing the row count K (weight gradients).
+    regroup = c > 0 (accumulate mode, after gemm_tn_regroups said yes): column j * c + i of the product is stored at column i * (N / c) + j."""
     lda, K, M = rows(a)
     ldb, Kb, N = rows(b)
     assert K == Kb and a.dtype == b.dtype
@@ -601,10 +621,11 @@ def gemm_tn(a, b, out=None, accumulate=False, split_k=0):
         accumulate = False
     assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == M * N
     q = _queues(out) if accumulate else None
+    assert not regroup or (q is not None and split_k <= 0 and N % regroup == 0)
     if q is not None:
         q.writes[out.data_ptr()] = q.writes.get(out.data_ptr(), 0) + 1      # step-wide writer count of the slot (direct and queued, main and side)
     if q is not None and split_k <= 0 and not (M % 48 == 0 and N % 48 == 0 and K >= 2048 and a.dtype == torch.bfloat16):
-        q.lists().gemm_tn.append((a, b, out, int(accumulate) == 2))      # small problem: grouped launch at the end of the backward pass
+        q.lists().gemm_tn.append((a, b, out, int(accumulate) == 2, int(regroup)))      # small problem: grouped launch at the end of the backward pass
         return out
     accumulate = bool(accumulate)      # (the direct kernels always add: "known zero" only saves the grouped launch its read of the slot)
     split_k = max(0, split_k)          # 0: the library picks the kernel and the split over the reduction rows
@@ -616,7 +637,8 @@ def gemm_tn(a, b, out=None, accumulate=False, split_k=0):
         p.workspace = ws.data_ptr()
         if q is not None:      # the per-split partial tiles are summed by one batched launch later
             p.defer_reduce = 1
-            q.lists().tn_reduce.append((ws, out, N, M, N, lib.miseg_gemm_tn_splits(C.byref(p))))
+            q.lists().tn_reduce.append((ws, out, N, M, N, lib.miseg_gemm_tn_splits(C.byref(p)), int(regroup)))
+    assert not regroup or p.defer_reduce, "gemm_tn: regroup on a path without a deferred sum (ask gemm_tn_regroups first)"
     _call("miseg_gemm", p)
     return out
 
@@ -901,8 +923,8 @@ def _flush_tn_reduces(q):
     for i in range(0, len(q), 32):
         chunk = q[i:i + 32]
         descs = (L.TnReduceDesc * len(chunk))()
-        for j, (ws, out, ldc, M, N, splits) in enumerate(chunk):
-            descs[j] = L.TnReduceDesc(_ptr(ws), _ptr(out), ldc, M, N, splits, 0)
+        for j, (ws, out, ldc, M, N, splits, regroup) in enumerate(chunk):
+            descs[j] = L.TnReduceDesc(_ptr(ws), _ptr(out), ldc, M, N, splits, 0, regroup, 0)
         L.check(lib.miseg_gemm_tn_reduce_batch(descs, len(chunk), _stream()), "gemm_tn_reduce_batch")
     q.clear()
 
@@ -913,7 +935,7 @@ def _flush_gemm_tn(q, writes=None):
     lib = L.load()
     if os.environ.get("MISEG_DEBUG_QUEUES"):      # measurement aid: what the grouped launch holds (M, N, K, zeroed)
         import sys
-        print("gemm_tn queue:", [(rows(it[0])[2], rows(it[1])[2], rows(it[0])[1], int(it[3])) for it in q], file=sys.stderr)
+        print("gemm_tn queue:", [(rows(it[0])[2], rows(it[1])[2], rows(it[0])[1], int(it[3]), it[4]) for it in q], file=sys.stderr)
     once = writes
     if once is None:      # (no step-wide count: at least the problems of this launch)
         once = {}
@@ -924,10 +946,10 @@ def _flush_gemm_tn(q, writes=None):
         for i in range(0, len(items), 24):
             chunk = items[i:i + 24]
             descs = (L.GemmTnDesc * len(chunk))()
-            for j, (a, b, out, zeroed) in enumerate(chunk):
+            for j, (a, b, out, zeroed, regroup) in enumerate(chunk):
                 lda, K, M = rows(a)
                 ldb, _, N = rows(b)
-                descs[j] = L.GemmTnDesc(_ptr(a), lda, _ptr(b), ldb, _ptr(out), N, M, N, K, 1 if (zeroed and once.get(out.data_ptr(), 2) == 1) else 0)
+                descs[j] = L.GemmTnDesc(_ptr(a), lda, _ptr(b), ldb, _ptr(out), N, M, N, K, 1 if (zeroed and once.get(out.data_ptr(), 2) == 1) else 0, regroup, 0)
             L.check(lib.miseg_gemm_tn_group(descs, len(chunk), _dt(chunk[0][0]), _stream()), "gemm_tn_group")
     q.clear()
 

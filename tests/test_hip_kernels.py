@@ -437,7 +437,7 @@ def test_gemm_with_the_norm_backward_sums_in_its_epilogue(M, K, N):
     ops.begin_step()
     stat = ops.instnorm_stats(x, 1, M)
     g0 = ops.gemm_nt(dy, wt)
-    assert ops.gemm_nt_folds(dy, wt, bstat_x=x)
+    assert ops.gemm_nt_folds(dy, wt, bstat_x=x) == (M > 2048 or ops.SMALL_BSTAT)      # (small M: the kernel has the epilogue, the step keeps the one-launch norm backward)
     g1 = ops.gemm_nt(dy, wt, bstat=(x, stat, 1e-5))
     dstat = ops.pop_gemm_stat(g1)
     assert torch.equal(g0, g1) and dstat is not None
@@ -727,6 +727,33 @@ def test_conv3_wgrad_grouped(dtype):
         z2 = torch.zeros_like(z)
         ops.conv3_wgrad(x, dy, dw=z2, accumulate=2)
         assert rel_err(z2, z) < 1e-5 if dtype == torch.float32 else 1e-3, tuple(x.shape)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("K,Cin,Cout", [(27, 768, 384), (216, 384, 192), (1728, 192, 96), (13824, 96, 48), (110592, 48, 48)])
+def test_gemm_tn_with_the_transposed_conv_regrouping_in_its_store(dtype, K, Cin, Cout):
+    """round 5: dW[ci][co][j] of a ConvTranspose3d(k2, s2) = x^T dy8 with the product's column (j, co) stored at (co, j) by the grouped
+    launch / the batched partial-tile sum (miseg_gemm_tn_desc.regroup, miseg_tn_reduce_desc.regroup) - against gemm_tn + permute3, the
+    two-launch form with its [(j, co)][ci] intermediate; both the accumulate-onto-existing and the known-zero slot"""
+    ops = _ops()
+    x, dy8 = rnd(K, Cin, dtype=dtype, seed=61), rnd(K, 8 * Cout, dtype=dtype, seed=62)
+    dwf = ops.gemm_tn(dy8, x)                                                          # [(j, co)][ci]
+    want = torch.zeros(Cin, Cout, 8, device=DEV)
+    ops.permute3(dwf, want, (Cin, Cout, 8), (1, Cin, Cout * Cin))
+    assert rel_err(want, (x.float().t() @ dy8.float()).view(Cin, 8, Cout).transpose(1, 2)) < TOL[dtype]
+    base = rnd(Cin, Cout, 8, seed=63)
+    for mode, start in ((2, torch.zeros_like(base)), (1, base.clone())):
+        out = start.clone()
+        ops.DEFAULT_QUEUES = ops.StepQueues()
+        try:
+            if dtype == torch.float32 and K >= 2048 and Cin % 48 == 0:
+                pass      # (fp32 takes the grouped launch at every size)
+            assert ops.gemm_tn_regroups(x, dy8, out)
+            ops.gemm_tn(x, dy8, out=out.view(Cin, 8 * Cout), accumulate=mode, regroup=Cout)
+            ops.DEFAULT_QUEUES.flush()
+        finally:
+            ops.DEFAULT_QUEUES = None
+        assert rel_err(out - (start if mode == 1 else 0), want) < (1e-5 if dtype == torch.float32 else 2e-3), (mode, rel_err(out - (start if mode == 1 else 0), want))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
