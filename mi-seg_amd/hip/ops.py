@@ -814,11 +814,16 @@ def join_branch(flush_deferred=True, queues=None, flush_main=False):
             # the main stream's grouped conv weight gradients: that launch holds one 96 KB workgroup per CU and leaves the rest of the CU idle
             with torch.cuda.stream(_BRANCH_STREAM):
                 queues.side.flush()
-            if FLUSH_SMALL_ON_BRANCH and (queues.gemm_tn or queues.tn_reduce or queues.colsum):
-                for lst in (queues.gemm_tn, queues.tn_reduce, queues.colsum):      # operands of the main stream, read on the branch: alive until join_wgrad
+            if FLUSH_SMALL_ON_BRANCH and (queues.gemm_tn or queues.tn_reduce or queues.colsum or queues.tiny_wgrad):
+                for lst in (queues.gemm_tn, queues.tn_reduce, queues.colsum, queues.tiny_wgrad):      # operands of the main stream, read on the branch: alive until join_wgrad
                     _WGRAD_KEEP.extend(t for it in lst for t in it if isinstance(t, torch.Tensor))
                 _BRANCH_STREAM.wait_stream(cur)
                 with torch.cuda.stream(_BRANCH_STREAM):
+                    # (MISEG_TINY_WGRAD_AT=flush: the tiny-volume conv weight gradients of encoder10 / decoder5 - write-bound, 176 MB in four ~20 us
+                    # launches - go out here, beside the main stream's grouped conv weight gradients; measured slower than inline, see TINY_WGRAD_AT)
+                    for x_, dy_, dw_, acc_ in queues.tiny_wgrad:
+                        _conv3_wgrad_now(x_, dy_, dw_, acc_)
+                    queues.tiny_wgrad.clear()
                     _flush_gemm_tn(queues.gemm_tn, queues.writes)
                     _flush_tn_reduces(queues.tn_reduce)
                     _flush_colsums(queues.colsum)
@@ -1103,7 +1108,12 @@ class PendingSlabs:
         self.ws, self.n, self.stride = ws, n, stride
 
 
-TINY_WGRAD_AT = os.environ.get("MISEG_TINY_WGRAD_AT", "inline")      # "inline" | "flush": where the tiny-volume weight gradients are launched (conv3_wgrad)
+# where the tiny-volume weight gradients are launched (conv3_wgrad): "inline" (default) = where the backward pass reaches the layer; "flush" =
+# queued for the end of the backward pass - with a side branch they then run on the BRANCH stream beside the main stream's grouped launch
+# (join_branch), without one (and in the two-graph data-parallel step, whose first half must finish these layers) in front of it.
+# Round 5, same box: inline 155.2 / 154.5 patches/s, on the branch at the end 154.2 / 154.2 - four write-bound launches (176 MB) beside the
+# grouped conv weight gradients lengthen the tail by more than the 80 us they take off the chain
+TINY_WGRAD_AT = os.environ.get("MISEG_TINY_WGRAD_AT", "inline")
 CONV_WGRAD_GROUP_VOXELS = 48 ** 3   # layers up to this many voxels are queued: alone they fill a fraction of the chip for 40-85 us each
 
 
