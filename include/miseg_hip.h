@@ -604,6 +604,12 @@ typedef struct {
   float lr, beta1, beta2, eps, weight_decay, momentum;
   const float* lr_dev;             /* optional device scalar overriding lr (schedulers under hipGraph replay) */
   int64_t* params_version;         /* optional DEVICE int64, incremented once per launch: the parameters changed (miseg_pack_conv3_batch) */
+  /* ABI 8, a step in TWO launches over disjoint descriptor tables (the parameters whose gradients are final early - the big tiny-volume conv
+   * weights of the headline net - are updated on a side stream beside the end of the backward pass, the rest after it):
+   * index (optional, DEVICE int32 [ndesc]): descriptor d of THIS table is parameter index[d] of used / steps (NULL: d itself);
+   * count_n: > 0 = after the update, steps[i] += used[i] for i < count_n and params_version is bumped (the LAST launch of a step, over all
+   * parameters); 0 = an early launch: neither (every launch of a step must see the step counts of before it); < 0 = ndesc (one-launch step). */
+  const int32_t* index; int32_t count_n;
 } miseg_opt_step_params;
 int miseg_opt_step(const miseg_opt_step_params* p, miseg_stream_t stream);
 

@@ -293,7 +293,7 @@ constexpr int OPT_BLOCK = 4096;     // elements per workgroup (256 threads x 4 f
 
 static __global__ void __launch_bounds__(256) opt_step_kernel(const miseg_opt_desc* __restrict__ descs, int ndesc, int kind, const float* __restrict__ grad, float* __restrict__ s1,
                                                             float* __restrict__ s2, const int32_t* __restrict__ used, int32_t* __restrict__ steps, float lr, float b1, float b2,
-                                                            float eps, float wd, float mom, const float* __restrict__ lr_dev) {
+                                                            float eps, float wd, float mom, const float* __restrict__ lr_dev, const int32_t* __restrict__ index) {
   // descriptor of this workgroup: the last one with block0 <= blockIdx.x
   int lo = 0, hi = ndesc - 1;
   while (lo < hi) {
@@ -301,10 +301,11 @@ static __global__ void __launch_bounds__(256) opt_step_kernel(const miseg_opt_de
     if (descs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const miseg_opt_desc d = descs[lo];
-  if (used && !used[lo]) return;
+  const int pi = index ? index[lo] : lo;             // the parameter's row in used / steps (a table may hold a subset of the parameters)
+  if (used && !used[pi]) return;
   if (lr_dev) lr = *lr_dev;
   const int blk = blockIdx.x - d.block0;
-  const int step = steps[lo] + 1;                    // read by every workgroup of the tensor; written back by a separate tiny launch
+  const int step = steps[pi] + 1;                    // read by every workgroup of the tensor; written back by a separate tiny launch
   float bc1 = 1.f, bc2s = 1.f;
   if (kind != MISEG_OPT_SGD_NESTEROV) {
     bc1 = 1.f - powf(b1, (float)step);
@@ -622,10 +623,14 @@ extern "C" int miseg_opt_step(const miseg_opt_step_params* p, miseg_stream_t s_)
   MISEG_REQUIRE(p->kind == MISEG_OPT_ADAMW || p->kind == MISEG_OPT_ADAM || p->kind == MISEG_OPT_SGD_NESTEROV, MISEG_E_BADARG, "opt_step: kind %d", p->kind);
   MISEG_REQUIRE(p->kind == MISEG_OPT_SGD_NESTEROV || p->state2, MISEG_E_BADARG, "opt_step: Adam needs state2");
   opt_step_kernel<<<p->total_blocks, 256, 0, s>>>(p->descs_dev, p->ndesc, p->kind, p->grad, p->state1, p->kind == MISEG_OPT_SGD_NESTEROV ? nullptr : p->state2, p->used,
-                                                 p->steps, p->lr, p->beta1, p->beta2, p->eps, p->weight_decay, p->momentum, p->lr_dev);
+                                                 p->steps, p->lr, p->beta1, p->beta2, p->eps, p->weight_decay, p->momentum, p->lr_dev, p->index);
   MISEG_LAUNCH_CHECK("opt_step");
-  opt_count_kernel<<<cdiv(p->ndesc, 256), 256, 0, s>>>(p->used, p->steps, p->ndesc, p->params_version);
-  MISEG_LAUNCH_CHECK("opt_count");
+  const int cn = p->count_n < 0 ? p->ndesc : p->count_n;
+  MISEG_REQUIRE(p->index || p->count_n < 0 || p->count_n == p->ndesc, MISEG_E_BADARG, "opt_step: count_n %d without an index table", p->count_n);
+  if (cn > 0) {
+    opt_count_kernel<<<cdiv(cn, 256), 256, 0, s>>>(p->used, p->steps, cn, p->params_version);
+    MISEG_LAUNCH_CHECK("opt_count");
+  }
   return MISEG_OK;
 }
 

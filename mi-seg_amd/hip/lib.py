@@ -125,7 +125,8 @@ DiceMetric = _struct("DiceMetric", cname="miseg_dice_metric_params", fields=[
 OptDesc = _struct("OptDesc", cname="miseg_opt_desc", fields=[("param", vp), ("off", i64), ("n", i32), ("block0", i32)])
 OptStep = _struct("OptStep", cname="miseg_opt_step_params", fields=[
     ("struct_size", u32), ("kind", i32), ("descs_dev", vp), ("ndesc", i32), ("total_blocks", i32), ("grad", vp), ("state1", vp), ("state2", vp),
-    ("used", vp), ("steps", vp), ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("momentum", f32), ("lr_dev", vp), ("params_version", vp)])
+    ("used", vp), ("steps", vp), ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("momentum", f32), ("lr_dev", vp), ("params_version", vp),
+    ("index", vp), ("count_n", i32)])
 Stitch = _struct("Stitch", cname="miseg_stitch_params", fields=[
     ("struct_size", u32), ("win", vp), ("out", vp), ("count", vp), ("C", i32), ("D", i32), ("H", i32), ("W", i32), ("rd", i32), ("rh", i32), ("rw", i32),
     ("nd", i32), ("nh", i32), ("nw", i32), ("start_d", vp), ("start_h", vp), ("start_w", vp), ("d_begin", i32), ("d_count", i32)])

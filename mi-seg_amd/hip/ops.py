@@ -827,6 +827,13 @@ def join_branch(flush_deferred=True, queues=None, flush_main=False):
                     _flush_gemm_tn(queues.gemm_tn, queues.writes)
                     _flush_tn_reduces(queues.tn_reduce)
                     _flush_colsums(queues.colsum)
+            if queues.on_branch_end is not None and cur != _BRANCH_STREAM:
+                # round 5 (runtime/graph.py::GraphedTrainStep): work that only needs what the main CHAIN has produced - the optimiser update of the
+                # parameters whose gradients were written inline (StepQueues.inline_final) - goes out on the branch stream here, beside the
+                # main stream's grouped launches below, instead of behind the whole pass
+                _BRANCH_STREAM.wait_stream(cur)
+                with torch.cuda.stream(_BRANCH_STREAM):
+                    queues.on_branch_end()
         queues.flush(side=False)
         stamp("main_flushed")
     if _BRANCH_STREAM is not None:
@@ -867,6 +874,9 @@ class StepQueues:
 
     def __init__(self, side=True, writes=None):
         self.colsum, self.gemm_tn, self.tn_reduce, self.conv_wgrad, self.tiny_wgrad = [], [], [], [], []
+        self.inline_final = []       # arena slots whose ONLY write of the step happened inline, as a plain store (the tiny-volume conv weight gradients):
+                                     # final as soon as the main chain of the backward pass is through
+        self.on_branch_end = None    # callable issued on the branch stream where join_branch sends the end-of-pass small launches (see there)
         # gradient slot (data_ptr) -> how many weight-gradient GEMMs of this step write it, direct launches and both queues together: a
         # grouped launch may STORE into a slot ("known zero", miseg_gemm_tn_desc.zeroed) only when it is the slot's one writer of the step -
         # a tied weight's second use, wherever it was issued, would otherwise be overwritten or overwrite
@@ -1181,6 +1191,8 @@ def conv3_wgrad(x, dy, dw=None, accumulate=False):
     if q is not None and B * D * H * W <= CONV_WGRAD_GROUP_VOXELS and not narrow and not tiny:
         q.lists().conv_wgrad.append((x, dy, dw, int(accumulate)))      # keeps x and dy alive until the flush
         return dw
+    if tiny and q is not None and int(accumulate) == 2:
+        q.inline_final.append(dw)      # written here, once, by plain stores: nothing queued will touch the slot again
     ws = torch.empty(lib.miseg_conv3_wgrad_workspace_bytes(B, D, H, W, Cin, Cout) // 4, dtype=torch.float32, device=x.device)
     bg = _background()
     _call("miseg_conv3_wgrad", L.Conv3Wgrad(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), B, D, H, W, Cin, Cout, _dt(x), int(accumulate), _ptr(ws), bg),

@@ -118,6 +118,7 @@ class ParamArena:
         # the launch-bound tails of this step's backward pass (bias-gradient reductions, small weight-gradient GEMMs, partial-tile sums,
         # the conv weight gradients of the 48^3-and-smaller layers) are queued per arena and issued by end_backward()
         self.queues = ops.QUEUES[self._qkey] = ops.StepQueues()
+        self.queues.on_branch_end = getattr(self, "branch_end_hook", None)
         ops.WGRAD_STREAM = self.wgrad_stream      # None unless overlap_wgrad: measured SLOWER on one MI355X (93.3 -> 90 patches/s: the
                                                   # cross-stream edges of the hipGraph cost more than the idle CUs they fill)
         self.epoch += 1
@@ -273,6 +274,9 @@ class ParamArena:
         ops.join_branch(queues=self.queues, flush_main=ops.FLUSH_MAIN_BEFORE_JOIN)
         if self.queues is not None:
             self.queues.flush()
+            # parameters whose gradient was complete when the main chain of the pass ended (see StepQueues.inline_final)
+            ptrs = {t.data_ptr() for t in self.queues.inline_final}
+            self.inline_final_params = [p for p, v in zip(self.params, self.views) if v.data_ptr() in ptrs]
             self.queues = None
             ops.QUEUES.pop(self._qkey, None)
         ops.stamp("queues_flushed")

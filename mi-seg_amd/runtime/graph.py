@@ -376,6 +376,10 @@ class GraphedTrainStep:
         self._styles_host = None
         self.warmup = warmup
         self.graphs = {}
+        # opt-in (MISEG_EARLY_OPT=1): measured SLOWER on the headline net - 138.1 / 137.3 patches/s against 140.1 / 139.1 with the one-launch
+        # step behind the pass (same box): 1.2 GB of optimiser traffic beside the end-of-pass grouped launches lengthens the tail by more than
+        # the 0.28 ms it takes off the chain (the same finding as the tiny-volume weight gradients on the branch, hip/ops.py::TINY_WGRAD_AT)
+        self.early_optimizer = bool(os.environ.get("MISEG_EARLY_OPT"))
         if optimizer.lr_dev is None:
             optimizer.lr_dev = torch.tensor([optimizer.lr], dtype=torch.float32, device=dev)
 
@@ -384,11 +388,18 @@ class GraphedTrainStep:
         self.opt.lr_dev.fill_(float(lr))
 
     def _run(self, host, optimise):
-        self.arena.begin_step()
-        logits = self.model(self.x, (self.styles, host))
-        loss = self.criterion(logits, self.label)
-        loss.backward(self.one)
-        self.arena.end_backward()
+        # round 5, opt-in (self.early_optimizer): the parameters whose gradients are final when the main chain of the backward pass ends (the
+        # tiny-volume conv weights of encoder10 / decoder5: 70 % of the headline net's bytes) are updated on the branch stream beside the
+        # end-of-pass grouped launches (ops.join_branch -> branch_end_hook), the rest behind the pass: two launches over disjoint tables
+        self.arena.branch_end_hook = (lambda: self.opt.step_early()) if (optimise and self.early_optimizer) else None
+        try:
+            self.arena.begin_step()
+            logits = self.model(self.x, (self.styles, host))
+            loss = self.criterion(logits, self.label)
+            loss.backward(self.one)
+            self.arena.end_backward()
+        finally:
+            self.arena.branch_end_hook = None
         if optimise:
             self.opt.step(update_flags=False)      # the flags of this graph are static: copied to the device before every replay
         return loss.detach()
@@ -401,6 +412,8 @@ class GraphedTrainStep:
                 self._run(host, False)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        if self.early_optimizer:      # which parameters the warm-up steps wrote inline (none: the one-launch optimiser step)
+            self.opt.split_early(getattr(self.arena, "inline_final_params", []))
         for p in self.arena.params:
             p.grad = None
         g = _Graph()

@@ -40,6 +40,55 @@ class ArenaOptimizer:
         self._table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
         self._blocks = block0
         self.lr_dev = None
+        self._early = None          # (table, index, blocks, n) of the parameters updated by step_early(), and of the rest
+        self._late = None
+        self._early_done = False
+
+    def split_early(self, early_params):
+        """Two launches per step: `early_params` (parameters whose gradients are final before the end of the backward pass: what
+        ParamArena.inline_final_params reports after a step) are updated by step_early() - which the caller may issue on a side stream beside the
+        rest of the pass - and all the others by step().  Same arithmetic, same result as the one-launch step (each parameter is touched once)."""
+        ids = {id(p) for p in early_params}
+        # (tables a captured hipGraph points at by raw address must never be freed: an unchanged set keeps its tables - a second capture, of
+        # another modality set, asks again - and replaced ones are retired, not dropped)
+        if getattr(self, "_early_ids", None) == ids:
+            return
+        dev = self.state1.device
+
+        def table(sel):
+            descs, index, block0 = (L.OptDesc * len(sel))(), [], 0
+            for j, i in enumerate(sel):
+                p = self.arena.params[i]
+                descs[j] = L.OptDesc(p.data_ptr(), self.arena._offs[i], p.numel(), block0)
+                block0 += (p.numel() + L.OPT_BLOCK - 1) // L.OPT_BLOCK
+                index.append(i)
+            return (torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev), torch.tensor(index, dtype=torch.int32, device=dev), block0, len(sel))
+        n = len(self.arena.params)
+        early = [i for i in range(n) if id(self.arena.params[i]) in ids]
+        late = [i for i in range(n) if id(self.arena.params[i]) not in ids]
+        if len(early) != len(ids) or (ids and not late):
+            raise ValueError("split_early: parameters that are not in the arena (or nothing left for the second launch)")
+        new = (table(early), table(late)) if ids else (None, None)
+        self.__dict__.setdefault("_retired", []).append((self._early, self._late))
+        self._early, self._late = new
+        self._early_ids = ids
+
+    def _launch(self, tab, lr, count_n):
+        table, index, blocks, n = tab
+        p = L.OptStep(C.sizeof(L.OptStep), KINDS[self.kind], table.data_ptr(), n, blocks, self.arena.flat.data_ptr(),
+                      self.state1.data_ptr(), self.state2.data_ptr() if self.state2 is not None else None, self.used.data_ptr(), self.steps.data_ptr(),
+                      self.lr if lr is None else float(lr), self.betas[0], self.betas[1], self.eps, self.weight_decay, self.momentum,
+                      self.lr_dev.data_ptr() if self.lr_dev is not None else None, self.arena.params_version_ptr(),
+                      index.data_ptr() if index is not None else None, count_n)
+        ops._call("miseg_opt_step", p)
+
+    def step_early(self, lr=None):
+        """the first launch of a split step (split_early): the `used` flags must be on the device already (set_used_from_arena / a captured
+        step's static flags); step() then updates the rest and closes the step"""
+        if self._early is None or self._early_done:
+            return
+        self._launch(self._early, lr, 0)
+        self._early_done = True
 
     def set_used_from_arena(self):
         """copy the host "used" flags of this step (arena.publish / allreduce have settled them) to the device; under hipGraph replay call
@@ -61,11 +110,11 @@ class ArenaOptimizer:
                 self.used.copy_(self.arena.used_dev, non_blocking=True)
             else:
                 self.set_used_from_arena()
-        p = L.OptStep(C.sizeof(L.OptStep), KINDS[self.kind], self._table.data_ptr(), len(self.arena.params), self._blocks, self.arena.flat.data_ptr(),
-                      self.state1.data_ptr(), self.state2.data_ptr() if self.state2 is not None else None, self.used.data_ptr(), self.steps.data_ptr(),
-                      self.lr if lr is None else float(lr), self.betas[0], self.betas[1], self.eps, self.weight_decay, self.momentum,
-                      self.lr_dev.data_ptr() if self.lr_dev is not None else None, self.arena.params_version_ptr())
-        ops._call("miseg_opt_step", p)
+        if self._early_done:          # the early launch of this step is out: the rest, then the step counts of ALL parameters and the version bump
+            self._launch(self._late, lr, len(self.arena.params))
+            self._early_done = False
+        else:
+            self._launch((self._table, None, self._blocks, len(self.arena.params)), lr, -1)
         # the compute-dtype copies of the parameters are stale now: the kernel bumped the arena's device-side parameter version (the refresh
         # launches of the next step re-lay-out everything); the host-side epoch moves on too, so that eager forwards cast per call until then
         self.arena.epoch += 1

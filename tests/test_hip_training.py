@@ -91,10 +91,13 @@ def test_dice_metric_kernel():
     assert abs(float(torch.nanmean(got)) - float(torch.nanmean(want))) < 1e-6
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("kind", ["adamw", "adam", "sgd"])
-def test_arena_optimizer_matches_torch(kind):
+def test_arena_optimizer_matches_torch(kind, split):
     """five steps of the one-launch optimiser against torch.optim on the same gradients, with a parameter that has NO gradient in some
-    steps (torch skips `grad is None` entirely: no decay, no moment update, no step count) and odd sizes / unaligned tails."""
+    steps (torch skips `grad is None` entirely: no decay, no moment update, no step count) and odd sizes / unaligned tails.
+    split (round 5): the same step as TWO launches over disjoint tables (ArenaOptimizer.split_early: what GraphedTrainStep issues on the
+    branch stream for the parameters whose gradients are final early) - the early launch on a side stream, the rest + the step counts after."""
     from mi_seg_amd.runtime.arena import ParamArena
     from mi_seg_amd.training.optim import ArenaOptimizer
     g = torch.Generator().manual_seed(1)
@@ -121,7 +124,21 @@ def test_arena_optimizer_matches_torch(kind):
                     p._miseg_used, r.grad = True, gr.clone()
                     arena.views[i].copy_(gr)
             topt.step()
-            opt.step()
+            if split:
+                if step == 0:
+                    opt.split_early([params[0], params[3], params[5]])
+                    with pytest.raises(ValueError):
+                        opt.split_early([torch.nn.Parameter(torch.zeros(3, device=DEV))])
+                    opt.split_early([params[0], params[3], params[5]])
+                opt.set_used_from_arena()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    opt.step_early()
+                torch.cuda.current_stream().wait_stream(side)
+                opt.step(update_flags=False)
+            else:
+                opt.step()
             for i, (p, r) in enumerate(zip(params, ref)):
                 assert rel_err(p.detach(), r.detach()) < 2e-6, (kind, step, i)
         assert opt.steps.tolist() == [5, 3, 5, 3, 5, 4]
