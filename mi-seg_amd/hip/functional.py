@@ -191,7 +191,7 @@ class _InstNorm(Function):
             dbet = [buf[s, 1] if s in present else None for s in range(num_styles)]
         dx, dres = ops.instnorm_bwd(dy, y, x, B, S, stat, styles_dev, gammas if affine else None, dgam, dbet, act=act, slope=slope, eps=eps,
                                     want_dres=has_res and ctx.needs_input_grad[1], gadd=_rv(gskip), betas=betas,
-                                    pending=ops.PENDING_DX.pop(dy.data_ptr(), None) if ops.PENDING_DX else None)
+                                    pending=ops.pending_dx_take(dy))
         pg = []
         if affine:
             for s in range(num_styles):
@@ -772,7 +772,7 @@ class _Conv3(Function):
     @staticmethod
     def forward(ctx, x, weight, want_stat=False, fork=False, dx_to_norm=False):
         """dx_to_norm: x is the output of a (conditional) instance norm that nothing else reads, so the data gradient computed here goes
-        straight to that norm's backward pass - a split launch over a small stage may then leave its partial slabs to it (ops.PENDING_DX)"""
+        straight to that norm's backward pass - a split launch over a small stage may then leave its partial slabs to it (ops.pending_dx_put)"""
         need_dx = ctx.needs_input_grad[0]
         ctx.dx_to_norm = bool(dx_to_norm)
         fwdp, bwdp = ops.pack_conv3(weight, x.dtype, True, need_dx)
@@ -803,7 +803,7 @@ class _Conv3(Function):
             if ctx.dx_to_norm and gskip is None:
                 dx, pend = ops.conv3_fwd(dy, bwdp, ctx.wshape[1], defer=True)
                 if pend is not None:
-                    ops.PENDING_DX[dx.data_ptr()] = pend
+                    ops.pending_dx_put(dx, pend)
             else:
                 dx = ops.conv3_fwd(dy, bwdp, ctx.wshape[1], res=gskip)
         dw = None

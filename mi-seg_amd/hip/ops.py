@@ -5,6 +5,7 @@ dims collapse to one uniform row stride (e.g. a contiguous [B, D, H, W, C] tenso
 """
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -427,14 +428,24 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta):
 
 
 # ------------------------------------------------------------------------------------------ GEMM family
-LAST_GEMM_STAT = None      # (data_ptr of the output, statistics tensor) of the last gemm_nt(want_stat=True) that fused them
+# Hand-offs between a producer op and the op right behind it are PER THREAD (the forward pass runs on the caller's thread, the backward pass on
+# the autograd engine's device thread; two models stepped from two threads never see each other's): the statistics a GEMM left for the norm
+# that consumes its output, and the slab sums a split data-gradient convolution left to the norm backward behind it
+_TLS = threading.local()
+_ALL_PENDING = []          # every thread's pending-slab table (check_no_pending looks at all of them from the stepping thread)
+_ALL_PENDING_LOCK = threading.Lock()
+
+
+def _set_gemm_stat(out, stat):
+    """(key of the output, statistics tensor) of the gemm_nt / mlp_fwd call that just fused them, or None"""
+    _TLS.gemm_stat = None if out is None else ((out.data_ptr(), out.numel(), out.dtype), stat)
 
 
 def pop_gemm_stat(y):
-    """the instance-norm statistics the last gemm_nt produced for `y` in its epilogue, or None"""
-    global LAST_GEMM_STAT
-    st, LAST_GEMM_STAT = LAST_GEMM_STAT, None
-    return st[1] if st is not None and st[0] == y.data_ptr() else None
+    """the statistics the last gemm_nt / mlp_fwd of THIS thread produced for `y` in its epilogue (handed over once), or None"""
+    st = getattr(_TLS, "gemm_stat", None)
+    _TLS.gemm_stat = None
+    return st[1] if st is not None and st[0] == (y.data_ptr(), y.numel(), y.dtype) else None
 
 
 class NormRef:
@@ -502,8 +513,7 @@ def gemm_nt(a, w, bias=None, act=L.ACT_NONE, out=None, out_dtype=None, split_k=1
     p = L.Gemm(_ptr(a), lda, _ptr(w), K, _ptr(out), ldc, M, N, K, 0, 0, _dt(a), _dt(out), _ptr(_fp32(bias)), act, 0, split_k, None,
                _ptr(res), rows(res)[0] if res is not None else 0, _ptr(aux), rows(aux)[0] if aux is not None else 0,
                1 if preact_out is not None else 2 if gelu_grad_of is not None else 0, 0, None)
-    global LAST_GEMM_STAT
-    LAST_GEMM_STAT = None
+    _set_gemm_stat(None, None)
     xn = None
     if anorm is not None:
         assert not want_stat and bstat is None
@@ -516,12 +526,12 @@ def gemm_nt(a, w, bias=None, act=L.ACT_NONE, out=None, out_dtype=None, split_k=1
         bx, bst, beps = bstat
         dstat = STAT_POOL.take(L.load().miseg_instnorm_stat_bytes(1, N) // 8, a.device)
         p.stat, p.stat_mode, p.bs_x, p.ld_bs_x, p.bs_stat, p.bs_eps = dstat.data_ptr(), 2, _ptr(bx), rows(bx)[0], _ptr(bst), float(beps)
-        LAST_GEMM_STAT = (out.data_ptr(), dstat)
+        _set_gemm_stat(out, dstat)
     if want_stat and not os.environ.get("MISEG_NO_GEMM_STAT") and L.load().miseg_gemm_fuses_stat(C.byref(p)):
         # all M rows are one sample (the caller checked): the kernel leaves the norm statistics of the output in `stat`
         stat = STAT_POOL.take(L.load().miseg_instnorm_stat_bytes(1, N) // 8, a.device).view(-1, 1, N, 2)
         p.stat = stat.data_ptr()
-        LAST_GEMM_STAT = (out.data_ptr(), stat)
+        _set_gemm_stat(out, stat)
     _call("miseg_gemm", p, prof=("gemm_nt", 2.0 * M * N * K, _nb(a, w, out, res, aux, xn, bstat[0] if bstat is not None else None)))      # (no accumulating output on the NT side: repeatable)
     return (out, xn) if anorm_out else out
 
@@ -548,12 +558,11 @@ def mlp_fwd(x, w1, b1, w2, b2, res=None, want_stat=False, anorm=None, anorm_out=
         if anorm_out:
             xn = torch.empty(x.shape, dtype=x.dtype, device=x.device)
             p.an_out, p.ld_an_out = xn.data_ptr(), rows(xn)[0]
-    global LAST_GEMM_STAT
-    LAST_GEMM_STAT = None
+    _set_gemm_stat(None, None)
     if want_stat:
         stat = STAT_POOL.take(L.load().miseg_instnorm_stat_bytes(1, Cc) // 8, x.device).view(-1, 1, Cc, 2)
         p.stat = stat.data_ptr()
-        LAST_GEMM_STAT = (y.data_ptr(), stat)
+        _set_gemm_stat(y, stat)
     _call("miseg_mlp_fwd", p, prof=("gemm_nt", 4.0 * M * Cc * w1.shape[0], _nb(x, y, res, xn)))
     return (y, xn) if anorm_out else y
 
@@ -1059,15 +1068,33 @@ def _vol(x):
     return x.shape[0], x.shape[1], x.shape[2], x.shape[3]
 
 
-PENDING_DX = {}      # data_ptr of a data gradient whose split convolution left its slabs to the norm backward that consumes it -> PendingSlabs
+def _pending():
+    """this thread's table: key of a data gradient whose split convolution left its slabs to the norm backward that consumes it -> PendingSlabs"""
+    d = getattr(_TLS, "pending", None)
+    if d is None:
+        d = _TLS.pending = {}
+        with _ALL_PENDING_LOCK:
+            _ALL_PENDING.append(d)
+    return d
+
+
+def pending_dx_put(dx, pend):
+    _pending()[(dx.data_ptr(), dx.numel(), dx.dtype)] = pend
+
+
+def pending_dx_take(dy):
+    d = getattr(_TLS, "pending", None)
+    return d.pop((dy.data_ptr(), dy.numel(), dy.dtype), None) if d else None
 
 
 def check_no_pending():
     """every deferred slab sum must have been taken by its consumer (the instance-norm backward right behind the data-gradient convolution):
     a gradient tensor that reached anything else would have been read unwritten"""
-    if PENDING_DX:
-        n = len(PENDING_DX)
-        PENDING_DX.clear()
+    with _ALL_PENDING_LOCK:
+        n = sum(len(d) for d in _ALL_PENDING)
+        for d in _ALL_PENDING:
+            d.clear()
+    if n:
         raise RuntimeError(f"{n} deferred data-gradient slab sum(s) were never consumed (conv3(..., dx_to_norm=True) in front of something that is no instance norm)")
 
 

@@ -97,5 +97,7 @@ def cpu_baseline(workload="c2"):
     return {"value": 1.0 / med, "unit": "patches/s", "cores": best, "kind": "port", "cpu_model": model_name, "physical_cores": phys,
             "logical_cpus": logical, "seconds_per_patch_median": med, "seconds_each": [round(t, 2) for t in times],
             "warmup_seconds_by_threads": {str(k): round(v, 2) for k, v in trial.items()},
+            # BASELINE.md section 3 words the protocol as "all physical cores": that figure beside the one above (one iteration at that width)
+            "all_physical_cores": {"cores": phys, "value": 1.0 / trial[phys], "unit": "patches/s", "sample": "one forward+backward patch (the warm-up run at this width)"},
             "sample": f"1 warm-up + 3 timed 96^3 forward+backward patches (median), oracle/nets.py fp32 restatement of the reference path, "
                       f"{best} threads on {model_name} ({phys} physical cores available)"}
