@@ -13,6 +13,8 @@
  *   - activations are channels-last rows: element (row r, channel c) lives at base[r * ld + c]; a 3D volume
  *     is rows in (b, d, h, w) row-major order.  dtype is MISEG_F32 or MISEG_BF16 (bf16 storage, fp32 math).
  *   - parameters and their gradients are always fp32.
+ *   - the library keeps no state of the caller's and reads NO environment variable (round 5: the tuning switches of earlier rounds'
+ *     sweeps are gone); per-process caches are limited to device attributes and kernel attributes set once per device.
  */
 #ifndef MISEG_HIP_H
 #define MISEG_HIP_H
@@ -328,7 +330,7 @@ int miseg_conv3_fwd(const miseg_conv3_params* p, miseg_stream_t stream);
  * buffers hold miseg_pack_conv3_elems(Cin, Cout, dtype, which) elements of `dtype` (which: 0 = fwd, 1 = bwd). */
 size_t miseg_pack_conv3_elems(int Cin, int Cout, int dtype, int which);
 /* K extent (elements; a whole number of 96-byte chunks) of the fast path for C channels on the K side of miseg_conv3_fwd, or 0 where the
- * generic row-major kernel runs.  Rows of >= MISEG_CONV3_PAD_MIN bytes (environment, default 64; 0 = never) that are no multiple of 96
+ * generic row-major kernel runs.  Rows of >= 64 bytes that are neither a multiple of 96 bytes nor of a narrow chunk (64 / 32 bytes, bf16)
  * bytes are padded with zero weights to the next chunk (32 -> 48, 64 -> 96, 128 -> 144, 256 -> 288 bf16 channels; C-UNETR: 146.2 / 155.2 / 161.0 / 165.7 / 163.4 patches/s at 0 / 256 / 128 / 64 / 32).  Fused residual / statistics
  * (miseg_conv3_params.res / .stat) need a non-zero value. */
 int miseg_conv3_k96(int C, int dtype);

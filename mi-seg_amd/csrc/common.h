@@ -117,11 +117,7 @@ static constexpr int REFRESH_MAX_WG = 2048;
 // (refresh_done), which the L2 serialises - so the grids are capped where the per-tile latency chain and that queue balance (live refresh of
 // C-Swin-UNETR: casts 110 -> 81 us at 1024 workgroups, conv packs 237 -> 174 us at 512; 8192 workgroups: 324 / 438 us)
 static constexpr int REFRESH_CAST_WG = 1024, REFRESH_PACK_WG = 512;
-static inline int refresh_max_wg(const char* env, int dflt) {      // tuning aid: MISEG_CAST_WG / MISEG_PACK_WG
-  const char* e = getenv(env);
-  const int v = e ? atoi(e) : dflt;
-  return v > 0 ? v : dflt;
-}
+static inline int refresh_max_wg(const char*, int dflt) { return dflt; }      // (round 4 swept the caps through the environment; the library reads none any more)
 __device__ __forceinline__ void refresh_done(const int64_t* params_version, int64_t* state, int64_t pv) {
   if (!params_version) return;
   __syncthreads();

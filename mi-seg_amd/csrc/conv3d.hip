@@ -566,13 +566,8 @@ __host__ __device__ inline int conv3_k96(int C, int esz, int plan) {
   return 0;
 }
 
-static int conv3_pad_min_bytes() {      // MISEG_CONV3_PAD_MIN (bytes of a channel row; 0 = never pad) | CONV3_NARROW (MISEG_CONV3_NARROW), read once
-  static const int v = [] {
-    const char* e = getenv("MISEG_CONV3_PAD_MIN");
-    const char* n = getenv("MISEG_CONV3_NARROW");
-    return (e ? (atoi(e) & (CONV3_NARROW - 1)) : 64) | ((n && atoi(n) == 0) ? 0 : CONV3_NARROW);
-  }();
-  return v;
+static int conv3_pad_min_bytes() {      // rows of >= 64 bytes are padded to whole 96-byte chunks where no narrow chunk fits; narrow chunks on (bf16)
+  return 64 | CONV3_NARROW;             // (rounds 3 - 4 swept both through the environment; the library reads no environment any more)
 }
 
 // element offset of the 16-byte group (tap, K-side channel group kg, N-side row) in the phase-ordered pack of the fast path
@@ -1367,7 +1362,7 @@ static bool wgrad_narrow(const miseg_conv3_wgrad_params* p) {
 }
 static int wgrad_narrow_workgroups(const miseg_conv3_wgrad_params* p) {
   const int nbricks = p->B * cdiv(p->D, 4) * cdiv(p->H, BH) * cdiv(p->W, BW);
-  static const int cap = [] { const char* e = getenv("MISEG_NARROW_WG"); const int v = e ? atoi(e) : WG_NARROW_MAX_WG; return v > 0 && v < WG_NARROW_MAX_WG ? v : WG_NARROW_MAX_WG; }();
+    static const int cap = WG_NARROW_MAX_WG;
   int wg = nbricks < cap ? nbricks : cap;
   if (p->max_workgroups > 0 && p->max_workgroups < wg) wg = p->max_workgroups;      // background form
   return wg;
@@ -1495,8 +1490,7 @@ __global__ void __launch_bounds__(256) conv3_wgrad_tiny_kernel(const bf16* __res
 }
 
 static bool wgrad_tiny_shape(int B, int D, int H, int W, int Cin, int Cout, int dtype) {
-  static const int off = [] { const char* e = getenv("MISEG_NO_TINY_WGRAD"); return e && atoi(e) ? 1 : 0; }();
-  return !off && dtype == MISEG_BF16 && D == H && H == W && (D == 3 || D == 6) && B >= 1 && B <= 64 && Cin % 16 == 0 && Cout % 48 == 0;
+  return dtype == MISEG_BF16 && D == H && H == W && (D == 3 || D == 6) && B >= 1 && B <= 64 && Cin % 16 == 0 && Cout % 48 == 0;
 }
 static bool wgrad_tiny(const miseg_conv3_wgrad_params* p) {
   return wgrad_tiny_shape(p->B, p->D, p->H, p->W, p->Cin, p->Cout, p->dtype) && ((uintptr_t)p->x % 16 == 0) && ((uintptr_t)p->dy % 16 == 0) && p->ldx % 8 == 0 &&
@@ -1864,15 +1858,8 @@ static int conv3_wgrad_launch(const miseg_conv3_wgrad_params* p, hipStream_t s) 
 // workgroups of its own and the slab traffic shrinks with the split count).  Round 4: the target follows from the group - the brick x
 // channel-pair units of all its multi-brick layers, dealt to the CUs in ONE round (main group of a C-Swin-UNETR step: 3336 units -> 14 bricks
 // each = 256 long workgroups, and the 12^3 layers become single-split: direct epilogue, no slabs; measured 437 -> 358 us against the fixed 7
-// of rounds 1-3, scripts/micro/wgrad_group_bench.py).  MISEG_WG_GROUP_BRICKS overrides it (tuning aid).
-static int wg_group_bricks_env() {
-  static int v = -2;
-  if (v == -2) { const char* e = getenv("MISEG_WG_GROUP_BRICKS"); v = e ? atoi(e) : -1; if (v < 1) v = -1; }
-  return v;
-}
-
+// of rounds 1-3, scripts/micro/wgrad_group_bench.py).
 static int wgrad_group_target(const miseg_conv3_wgrad_params* descs, int n, int wbd) {
-  if (wg_group_bricks_env() > 0) return wg_group_bricks_env();
   long units = 0;
   for (int i = 0; i < n; ++i) {
     const miseg_conv3_wgrad_params* p = descs + i;
@@ -1882,7 +1869,7 @@ static int wgrad_group_target(const miseg_conv3_wgrad_params* descs, int n, int 
   const int cap = descs[0].max_workgroups;
   const int slots = (cap > 0 && cap < 256) ? cap : 256;
   int t = cdiv(units, slots);
-  static const int tmin = [] { const char* e = getenv("MISEG_WG_GROUP_MIN"); const int v = e ? atoi(e) : 7; return v > 0 ? v : 7; }();
+  const int tmin = 7;
   if (t < tmin) t = tmin;    // (small groups - the side branch's two 48^3 layers, 864 units: 4 / 5 bricks per unit measured no better than 7 in the step)
   if (t > 16) t = 16;
   return t;

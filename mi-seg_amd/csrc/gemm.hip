@@ -1205,10 +1205,6 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
             }
           }
         }
-        if (const char* e = getenv("MISEG_GEMM_SMALL_TILE")) {      // sweeps (scripts/bench_gemm.py small): "mtw,ntw"
-          int a_ = 0, b_ = 0;
-          if (sscanf(e, "%d,%d", &a_, &b_) == 2 && p->N % (16 * b_) == 0 && (((a_ == 1 || a_ == 2) && (b_ == 1 || b_ == 2 || b_ == 4)) || (a_ == 4 && b_ == 3))) { mtw = a_; ntw = b_; }
-        }
         const int gm = cdiv(p->M, 16 * mtw);
         dim3 grid(gm * (p->N / (16 * ntw)));
         const bool ge = p->act == MISEG_ACT_GELU;

@@ -335,7 +335,7 @@ extern "C" int miseg_graph_split_create(void* graph_, miseg_stream_t launch_stre
     info->main_lane_nodes = (int)lanes[0].size();
     info->streams_concurrent = plan->concurrent ? 1 : 0;
   }
-  if (getenv("MISEG_DEBUG_GRAPH_SPLIT")) {
+  if (false) {      // (debug listing of the pieces; was MISEG_DEBUG_GRAPH_SPLIT: the library reads no environment)
     fprintf(stderr, "[graph_split] %d nodes, %zu edges, %d lanes, %d crossing edges, %zu segments, %zu side stream(s)%s\n", (int)n, ne, nl, plan->cross,
             plan->segs.size(), plan->side.size(), plan->concurrent ? "" : " (NOT seen to run concurrently)");
     for (size_t s = 0; s < plan->segs.size(); ++s) {

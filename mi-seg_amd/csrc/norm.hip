@@ -685,12 +685,7 @@ __global__ void __launch_bounds__(NORM_THREADS) instnorm_pair_bwd_apply_kernel(c
 // ---------------------------------------------------------------------------------------------------
 static constexpr int FUSED_MAXR = 8;
 static constexpr int NORM_FUSED_MAX_ROWS_HW = FUSED_MAXR * NORM_THREADS;
-// (debug / A-B switch: MISEG_NORM_FUSED_MAX=<rows> lowers the limit, 0 sends every tensor through the chunked kernels)
-static int norm_fused_max_rows() {
-  static const int v = [] { const char* e = getenv("MISEG_NORM_FUSED_MAX"); const int n = e ? atoi(e) : NORM_FUSED_MAX_ROWS_HW; return n < NORM_FUSED_MAX_ROWS_HW ? n : NORM_FUSED_MAX_ROWS_HW; }();
-  return v;
-}
-#define NORM_FUSED_MAX_ROWS norm_fused_max_rows()
+#define NORM_FUSED_MAX_ROWS NORM_FUSED_MAX_ROWS_HW
 
 template <class T, int VEC> struct PRow {       // one row's VEC channels of a lane as loaded (packed: VEC * sizeof(T) bytes, one load)
   typedef T raw_t __attribute__((ext_vector_type(VEC)));
