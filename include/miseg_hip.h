@@ -543,6 +543,11 @@ int miseg_im2col3(const miseg_im2col3_params* p, miseg_stream_t stream);
 int miseg_col2im3(const miseg_im2col3_params* p, miseg_stream_t stream);
 
 /* fill a buffer of n 32-bit words with a value (gradient arenas, accumulators) */
+#define MISEG_FILL_RANGES 16
+/* dst[off .. off + len) = value for up to MISEG_FILL_RANGES (offset, length) pairs, in 32-bit words, of one 16-byte aligned buffer in ONE launch
+ * (ABI 8; ranges_host: HOST array [n][2], copied into the kernel arguments; offsets multiples of 4 words): the per-step zero fill of the gradient
+ * arena minus the slots whose weight-gradient kernel overwrites them whole (mi-seg_amd/runtime/arena.py) */
+int miseg_fill32_ranges(void* dst, uint32_t value, const uint64_t* ranges_host, int n, miseg_stream_t stream);
 int miseg_fill32(void* dst, uint32_t value, size_t n, miseg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

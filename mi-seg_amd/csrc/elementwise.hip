@@ -2045,6 +2045,47 @@ extern "C" int miseg_colsum_batch(const miseg_colsum_desc* descs, int n, int dty
   });
 }
 
+// up to MISEG_FILL_RANGES word ranges of one buffer in ONE launch (the gradient arena minus the slots a kernel will overwrite whole, round 5):
+// ranges are 16-byte aligned (arena slots are) and a multiple of 4 words long except possibly the last
+namespace miseg {
+struct FillRanges { uint64_t off[MISEG_FILL_RANGES], len[MISEG_FILL_RANGES], start[MISEG_FILL_RANGES + 1]; int n; };
+static __global__ void __launch_bounds__(256) fill_ranges_kernel(uint32_t* __restrict__ dst, uint32_t v, FillRanges r) {
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+  const u32x4 vv = {v, v, v, v};
+  const uint64_t total4 = r.start[r.n];                       // in 16-byte units over all ranges (each range rounded up)
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (uint64_t)gridDim.x * 256) {
+    int k = 0;
+    while (k + 1 < r.n && r.start[k + 1] <= i) ++k;
+    const uint64_t w = (i - r.start[k]) * 4;                  // word offset inside range k
+    uint32_t* p = dst + r.off[k] + w;
+    if (w + 4 <= r.len[k]) *reinterpret_cast<u32x4*>(p) = vv;
+    else for (uint64_t e = w; e < r.len[k]; ++e) dst[r.off[k] + e] = v;
+  }
+}
+}  // namespace miseg
+
+extern "C" int miseg_fill32_ranges(void* dst, uint32_t value, const uint64_t* ranges_host, int n, miseg_stream_t s_) {
+  MISEG_REQUIRE(dst && ranges_host && n >= 1 && n <= MISEG_FILL_RANGES, MISEG_E_BADARG, "fill32_ranges: 1..%d ranges", MISEG_FILL_RANGES);
+  MISEG_REQUIRE(((uintptr_t)dst % 16) == 0, MISEG_E_BADARG, "fill32_ranges: the buffer must be 16-byte aligned");
+  miseg::FillRanges r;
+  r.n = n;
+  uint64_t acc = 0;
+  for (int i = 0; i < n; ++i) {
+    r.off[i] = ranges_host[2 * i];
+    r.len[i] = ranges_host[2 * i + 1];
+    MISEG_REQUIRE(r.off[i] % 4 == 0 && r.len[i] > 0, MISEG_E_BADARG, "fill32_ranges: range %d (offset %llu words, %llu words): offsets are multiples of 4 words", i,
+                  (unsigned long long)r.off[i], (unsigned long long)r.len[i]);
+    r.start[i] = acc;
+    acc += (r.len[i] + 3) / 4;
+  }
+  r.start[n] = acc;
+  uint64_t blocks = (acc + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  miseg::fill_ranges_kernel<<<(int)blocks, 256, 0, (hipStream_t)s_>>>((uint32_t*)dst, value, r);
+  MISEG_LAUNCH_CHECK("fill32_ranges");
+  return MISEG_OK;
+}
+
 extern "C" int miseg_fill32(void* dst, uint32_t value, size_t n, miseg_stream_t s_) {
   MISEG_REQUIRE(dst || n == 0, MISEG_E_BADARG, "fill32: null pointer");
   if (n == 0) return MISEG_OK;

@@ -146,6 +146,7 @@ LOSS_DICE_FOCAL, LOSS_DICE_CE = 0, 1
 OPT_ADAMW, OPT_ADAM, OPT_SGD_NESTEROV = 0, 1, 2
 OPT_BLOCK = 4096
 STITCH_MAX_WINDOWS = 64
+FILL_RANGES = 16
 
 # symbol -> (restype, argtypes); every prototype of include/miseg_hip.h appears here (checked by tests/test_abi.py)
 PROTOS = {
@@ -215,6 +216,7 @@ PROTOS = {
     "miseg_im2col3": (i32, [C.POINTER(Im2col3), vp]),
     "miseg_col2im3": (i32, [C.POINTER(Im2col3), vp]),
     "miseg_fill32": (i32, [vp, C.c_uint32, C.c_size_t, vp]),
+    "miseg_fill32_ranges": (i32, [vp, C.c_uint32, vp, i32, vp]),
     "miseg_param_cast_batch": (i32, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "miseg_resample2": (i32, [C.POINTER(Resample2), vp]),
     "miseg_rowbias_add": (i32, [C.POINTER(Rowbias), vp]),

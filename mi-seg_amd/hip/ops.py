@@ -883,6 +883,8 @@ class StepQueues:
 
     def __init__(self, side=True, writes=None):
         self.colsum, self.gemm_tn, self.tn_reduce, self.conv_wgrad, self.tiny_wgrad = [], [], [], [], []
+        self.unzeroed = set()        # data_ptr of arena slots the step's fill left out (their weight-gradient kernel overwrites them whole: arena.begin_step);
+                                     # conv3_wgrad zero-fills one first if the launch it is about to issue would read or only add to it
         self.inline_final = []       # arena slots whose ONLY write of the step happened inline, as a plain store (the tiny-volume conv weight gradients):
                                      # final as soon as the main chain of the backward pass is through
         self.on_branch_end = None    # callable issued on the branch stream where join_branch sends the end-of-pass small launches (see there)
@@ -1212,6 +1214,10 @@ def conv3_wgrad(x, dy, dw=None, accumulate=False):
     # (the library's own test also wants 16-byte aligned operands and row strides that are multiples of 8 elements: the same test here)
     tiny = (bool(lib.miseg_conv3_wgrad_tiny(B, D, H, W, Cin, Cout, _dt(x))) and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0
             and ldx % 8 == 0 and lddy % 8 == 0)
+    if q is not None and q.unzeroed and dw.data_ptr() in q.unzeroed:
+        q.unzeroed.discard(dw.data_ptr())
+        if not (tiny and int(accumulate) == 2):      # anything but the overwriting launch reads (or only adds to) the slot: it gets its zeros now
+            fill32(dw)
     if tiny and q is not None and TINY_WGRAD_AT != "inline":
         q.lists().tiny_wgrad.append((x, dy, dw, int(accumulate)))
         return dw
@@ -1466,6 +1472,19 @@ def fill32(t, word=0):
     lib = L.load()
     assert t.is_contiguous() and t.element_size() == 4
     L.check(lib.miseg_fill32(_ptr(t), word, t.numel(), _stream()), "fill32")
+    return t
+
+
+def fill32_ranges(t, ranges, word=0):
+    """t[off : off + n] = word for every (off, n) of `ranges` (element offsets into the contiguous 4-byte tensor t, multiples of 4) in one launch
+    per L.FILL_RANGES ranges"""
+    lib = L.load()
+    assert t.is_contiguous() and t.element_size() == 4
+    ranges = [(int(o), int(n)) for o, n in ranges if n > 0]
+    for i in range(0, len(ranges), L.FILL_RANGES):
+        chunk = ranges[i:i + L.FILL_RANGES]
+        arr = (C.c_uint64 * (2 * len(chunk)))(*[v for r in chunk for v in r])
+        L.check(lib.miseg_fill32_ranges(_ptr(t), word, arr, len(chunk), _stream()), "fill32_ranges")
     return t
 
 

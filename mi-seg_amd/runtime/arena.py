@@ -20,10 +20,15 @@ like the reference's find_unused_parameters DDP: tune.py:103-109).  Gradient acc
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from ..hip import lib as L
 from ..hip import ops
+
+
+SKIP_OVERWRITTEN_FILL = not os.environ.get("MISEG_FULL_ARENA_FILL")      # A/B switch of round 5 (read once)
 
 
 class ParamArena:
@@ -125,10 +130,41 @@ class ParamArena:
         if getattr(self, "_accumulating", False):     # the previous micro-batch ran under no_sync(): keep summing into the arena
             zero = False
         if zero:
-            ops.fill32(self.flat)
+            self._zero_fill()
             for p in self.params:
                 p._miseg_used = False
         self._refresh()
+
+    def _zero_fill(self):
+        """the step's zero fill of the gradient arena - minus the slots whose weight-gradient kernel overwrites them whole (round 5): the
+        tiny-volume conv weights of encoder10 / decoder5 are 70 % of the headline net's 249 MB, and their kernel stores every element without
+        reading it.  A slot is left out when the PREVIOUS step wrote it that way (StepQueues.inline_final -> self._overwritten); the queue of
+        this step carries the set (`unzeroed`), so that ops.conv3_wgrad fills a slot after all if the launch it is about to issue is not the
+        overwriting one, and end_backward fills the ones nothing wrote (an unused parameter's slot must read zero for the all-reduce)."""
+        skip = [i for i in getattr(self, "_overwritten", ()) if SKIP_OVERWRITTEN_FILL]
+        if skip:
+            # data-parallel steps reduce ranges of the arena BEFORE end_backward settles the left-out slots: they keep the full fill
+            import torch.distributed as dist
+            if self.force_collective or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+                skip = []
+        if not skip or not self.flat.is_cuda:
+            ops.fill32(self.flat)
+            return
+        key = tuple(skip)
+        cached = self.__dict__.get("_fill_plan")
+        if cached is None or cached[0] != key:
+            ranges, pos = [], 0
+            for i in skip:                                       # ascending parameter order = ascending offsets
+                lo = self._offs[i]
+                hi = self._offs[i + 1] if i + 1 < len(self._offs) else self._size
+                if lo > pos:
+                    ranges.append((pos, lo - pos))
+                pos = hi
+            if self._size > pos:
+                ranges.append((pos, self._size - pos))
+            cached = self._fill_plan = (key, ranges)
+        ops.fill32_ranges(self.flat, cached[1])
+        self.queues.unzeroed = {self.views[i].data_ptr() for i in skip}
 
     def _refresh(self):
         """one launch each: every registered parameter re-layout (casts / transposes / regroupings) and every 3x3x3 weight pack"""
@@ -277,6 +313,12 @@ class ParamArena:
             # parameters whose gradient was complete when the main chain of the pass ended (see StepQueues.inline_final)
             ptrs = {t.data_ptr() for t in self.queues.inline_final}
             self.inline_final_params = [p for p, v in zip(self.params, self.views) if v.data_ptr() in ptrs]
+            # slots the fill left out and nothing wrote (the parameter went unused): they must read zero from here on
+            for i, v in enumerate(self.views):
+                if v.data_ptr() in self.queues.unzeroed:
+                    ops.fill32(v)
+            # ... and the slots this step's kernels overwrote whole: the next step's fill leaves them out (_zero_fill)
+            self._overwritten = sorted(i for i, v in enumerate(self.views) if v.data_ptr() in ptrs)
             self.queues = None
             ops.QUEUES.pop(self._qkey, None)
         ops.stamp("queues_flushed")

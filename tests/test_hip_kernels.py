@@ -729,6 +729,21 @@ def test_conv3_wgrad_grouped(dtype):
         assert rel_err(z2, z) < 1e-5 if dtype == torch.float32 else 1e-3, tuple(x.shape)
 
 
+def test_fill32_ranges():
+    """round 5: up to 16 (offset, length) word ranges of one buffer in one launch (the gradient arena minus the slots a kernel overwrites whole)"""
+    ops = _ops()
+    n = 1 << 20
+    t = torch.full((n,), 7.0, device=DEV)
+    ranges = [(0, 4096), (8192, 12), (8208, 3), (100000, 65537), (n - 8, 8)] + [(200000 + 64 * i, 5 + i) for i in range(20)]
+    ops.fill32_ranges(t, ranges)
+    want = torch.full((n,), 7.0)
+    for o, l in ranges:
+        want[o:o + l] = 0.0
+    assert torch.equal(t.cpu(), want)
+    with pytest.raises(ValueError):
+        ops.fill32_ranges(t, [(2, 8)])            # offsets are multiples of 4 words
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("K,Cin,Cout", [(27, 768, 384), (216, 384, 192), (1728, 192, 96), (13824, 96, 48), (110592, 48, 48)])
 def test_gemm_tn_with_the_transposed_conv_regrouping_in_its_store(dtype, K, Cin, Cout):
