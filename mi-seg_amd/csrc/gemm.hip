@@ -714,12 +714,14 @@ template <> struct TnFrag<bf16> {
 // regroup > 0 (fp32 output): column n = j * regroup + c of the product is stored at column c * (N / regroup) + j - the weight gradient of a
 // ConvTranspose3d(k2, s2) computed as x^T dy8 with dy8's columns in (j, co) order lands in the torch layout [Cin][Cout][2][2][2] directly
 // (round 5: no [(j, co)][ci] intermediate, no permute launch, no fill)
-template <class T, class TO>
+// BKB (bf16; 0 = 128): k rows per stage.  The GROUPED launch runs beside the grouped conv weight gradients, whose one workgroup per CU holds
+// 96 KB of LDS: with 128-row stages (36 KB) ONE of these workgroups fits beside it, with 96-row stages (27 KB) two (round 5)
+template <class T, class TO, int BKB = 0>
 __device__ __forceinline__ void gemm_tn_body(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb, TO* __restrict__ C, int64_t ldc,
                                              int M, int N, int K, int mode, bool vec_a, bool vec_b, int k_per_split, int bx, int by, int bz, int regroup = 0) {
   typedef typename Vec16<T>::type VT;
   constexpr int KPC = Mma<T>::KPC;     // elements per 16-byte chunk (here along m / n)
-  constexpr int BM = 64, BN = 64, BK = std::is_same<T, bf16>::value ? 128 : 64;   // k rows per stage
+  constexpr int BM = 64, BN = 64, BK = std::is_same<T, bf16>::value ? (BKB ? BKB : 128) : 64;   // k rows per stage
   constexpr int ROWB = BM * (int)sizeof(T) + 16;   // bytes per k-row of a tile (padded)
   __shared__ __attribute__((aligned(16))) char lds[2 * BK * ROWB];
   char* lA = lds;
@@ -836,6 +838,7 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const T* __restrict__ A, i
   gemm_tn_body<T, TO>(A, lda, B, ldb, C, ldc, M, N, K, mode, vec_a, vec_b, k_per_split, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+static constexpr int TN_GROUP_BK = 96;      // bf16 stage depth of the grouped launch (see gemm_tn_body)
 // grouped form: a list of independent TN problems (the weight gradients of the deep stages, a few dozen workgroups each)
 // in ONE launch; descriptors travel in the kernel arguments
 struct TnGroup {
@@ -850,7 +853,7 @@ __global__ void __launch_bounds__(256) gemm_tn_group_kernel(TnGroup g) {
   const TnGroup::P& q = g.p[k];
   const int local = blockIdx.x - q.block0;
   const int bx = local % q.gx, by = (local / q.gx) % q.gy, bz = local / (q.gx * q.gy);
-  gemm_tn_body<T, float>((const T*)q.A, q.lda, (const T*)q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, q.mode, q.va, q.vb, q.kps, bx, by, bz, q.regroup);
+  gemm_tn_body<T, float, TN_GROUP_BK>((const T*)q.A, q.lda, (const T*)q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, q.mode, q.va, q.vb, q.kps, bx, by, bz, q.regroup);
 }
 
 // ------------------------------------------------------------------------------------------------ TN, streaming
@@ -1479,7 +1482,7 @@ extern "C" int miseg_gemm_tn_group(const miseg_gemm_tn_desc* descs, int n, int d
   TnGroup g;
   g.n = n;
   int blocks = 0;
-  const int n16 = dtype == MISEG_F32 ? 4 : 8, bk = dtype == MISEG_F32 ? 64 : 128;
+  const int n16 = dtype == MISEG_F32 ? 4 : 8, bk = dtype == MISEG_F32 ? 64 : miseg::TN_GROUP_BK;
   for (int i = 0; i < n; ++i) {
     const miseg_gemm_tn_desc& d = descs[i];
     MISEG_REQUIRE(d.A && d.B && d.C && d.M > 0 && d.N > 0 && d.K > 0, MISEG_E_BADARG, "gemm_tn_group: problem %d", i);
