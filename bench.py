@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS), help="c2 = BASELINE configs[1] (the metric); c3 / c5 = configs[2] / configs[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-launches", default=None, help="write the roofline leg's per-launch table (JSON) here")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-arena", action="store_true", help="torch-style per-parameter gradient tensors and per-call weight casts")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: all-reduce after the whole backward pass instead of overlapping the encoder half")
@@ -493,8 +494,11 @@ def measure(a, rank, world, dist, dev):
     if rank == 0:
         if not a.no_roofline:
             from mi_seg_amd.testing.roofline import profile_step, summarize
-            out["roofline"] = summarize(profile_step(lambda: step(a.warmup + a.steps, eager=True, comm=False)), dtype,
-                                        counters=(a.workload == "c2" and a.dtype == "bf16"))      # rank 0 alone: no collectives
+            prof = profile_step(lambda: step(a.warmup + a.steps, eager=True, comm=False))
+            out["roofline"] = summarize(prof, dtype, counters=(a.workload == "c2" and a.dtype == "bf16"))      # rank 0 alone: no collectives
+            if a.dump_launches:      # every hooked launch of that step: {kernel: [(ms, flops, algorithmic bytes, ms of all its kernels)]} in issue order
+                with open(a.dump_launches, "w") as f:
+                    json.dump(prof, f)
         if world == 1 and not a.no_cpu_baseline:
             from mi_seg_amd.testing.cpu_baseline import cpu_baseline
             out["cpu_baseline"] = cpu_baseline(a.workload)

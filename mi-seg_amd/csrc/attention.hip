@@ -400,6 +400,18 @@ __device__ __forceinline__ void att_load16v(const bf16* p, bool vec, float* dst)
   }
 }
 
+// workgroup -> (window, head) of the matrix-core kernels (1-D grid of windows * heads).  The hardware deals consecutive workgroups to the 8
+// XCDs round-robin, each with its own L2; a head reads its 32-byte slices of the window's q / k / v / dO / O rows, i.e. the same 128-byte
+// lines as the window's other heads.  As grid (window, head) those ran a whole grid.x apart on other XCDs and every line came from HBM once
+// per head (round 5, stage 1 backward: the operand staging alone 37 of 142 us = 174 MB at 4.7 TB/s for 59 MB of operands).  XCD k takes the
+// k-th contiguous eighth of the units, heads of a window adjacent: they are dispatched back to back on one XCD and share the lines in its L2.
+__device__ __forceinline__ void att_unit(int heads, int& win, int& head) {
+  const int nb = gridDim.x, xcd = blockIdx.x & 7, q = nb >> 3, r = nb & 7;
+  const int unit = xcd * q + (xcd < r ? xcd : r) + (blockIdx.x >> 3);
+  win = unit / heads;
+  head = unit - win * heads;
+}
+
 // NW = waves per workgroup; a wave owns whole 32-query tiles (11 of them for a 7^3 window).  8 for the large grids (measured: 4 -> 8
 // +0.7 % on the step, 11 no better), 11 - one tile per wave - when the launch has fewer workgroups than CUs (stages 3 and 4) and lasts
 // exactly as long as one workgroup.
@@ -418,7 +430,9 @@ __global__ void __launch_bounds__(NW * 64) winattn_fwd_mfma_kernel(const bf16* _
   int* klab = kofs + ATT_NP;                                // [NP] region label of the rolled grid
   int* rowq = klab + ATT_NP;                                // [NP]
   float* table = reinterpret_cast<float*>(rowq + ATT_NP);   // [tsize] * log2e
-  const int win = blockIdx.x, head = blockIdx.y, tid = threadIdx.x;
+  int win, head;
+  att_unit(g.heads, win, head);
+  const int tid = threadIdx.x;
   const int n = g.n, C = g.C, ntiles = (n + 31) / 32;
   for (int t = tid; t < ntiles * 32; t += NW * 64) {
     int row = -1, label = 0, code = 0;
@@ -631,8 +645,13 @@ __global__ void __launch_bounds__(NW * 64, 2) winattn_bwd_mfma_kernel(const bf16
   bf16* Qs = reinterpret_cast<bf16*>(ndelta + ATT_NP);      // [NP][16] q * scale * log2e
   bf16* Gs = Qs + ATT_NP * 16;                              // dO
   bf16* Ks = Gs + ATT_NP * 16;
-  const int win = blockIdx.x, head = blockIdx.y, tid = threadIdx.x;
+  int win, head;
+  att_unit(g.heads, win, head);
+  const int tid = threadIdx.x;
   const int n = g.n, C = g.C, nt16 = (n + 15) / 16;
+#if defined(ATT_EXP_STOP) && ATT_EXP_STOP == 0
+  return;
+#endif
   if (tid < 52) padb[tid] = 0.f;
   __syncthreads();
   float mg2 = 0.f, mv2 = 0.f, mda = 0.f;
@@ -688,6 +707,9 @@ __global__ void __launch_bounds__(NW * 64, 2) winattn_bwd_mfma_kernel(const bf16
   // LDS float atomics cost ~190 cycles per wave-instruction on gfx950 (integer ones 4-8): the rel-pos bias gradient is
   // binned in fixed point.  |dS_qk| <= p_qk (|dO_q||V_k| + |delta_q|) and a bin receives at most one key per query, so
   // |bin| <= n * bmax; the scale keeps two bits of headroom for the bf16 rounding of the operands.
+#if defined(ATT_EXP_STOP) && ATT_EXP_STOP == 1
+  if (tsize != -1) return;
+#endif
   const float bmax = sqrtf(__uint_as_float(bound[0]) * __uint_as_float(bound[1])) + __uint_as_float(bound[2]);
   // (a contribution stays below 2^21 so that fma(x, fscale, 1.5 * 2^23) rounds it to an integer in the low mantissa bits: one fma + one
   // integer subtract where mul + rndne + cvt were three instructions)
@@ -734,6 +756,9 @@ __global__ void __launch_bounds__(NW * 64, 2) winattn_bwd_mfma_kernel(const bf16
       if (kt == nt16 - 1 && (n & 15)) { itail = i; kval = ki < n; }
     }
   }
+#if defined(ATT_EXP_STOP) && ATT_EXP_STOP == 2
+  if (tsize != -1) return;
+#endif
   const uint64_t dk0 = DROP ? dropout_step_key(dr.key, dr.step_dev) : 0ull;
   const int dcg = (n + 3) / 4;
   const int64_t dbase = ((int64_t)win * g.heads + head) * n;
@@ -741,7 +766,12 @@ __global__ void __launch_bounds__(NW * 64, 2) winattn_bwd_mfma_kernel(const bf16
   char* const ds_w = mytile + fi * ATT_DS_LD + kg * 8;                         // dS[key fi][queries 4kg..]
   const char* const ds_r = mytile + (4 * kg + (fi >> 2)) * ATT_DS_LD + (fi & 3) * 8;   // transposed read: lane (query fi, keys 4kg..)
 
+  f32x4 padq = f32x4{0.f, 0.f, 0.f, 0.f};      // dQ of zero-padded queries (lane: dims 4 (lane & 3) ..), summed over this wave's query tiles
+#ifdef ATT_EXP_QDIV
+  for (int qt = 0; qt < nt16 / ATT_EXP_QDIV; ++qt) {
+#else
   for (int qt = 0; qt < nt16; ++qt) {
+#endif
     const int q0 = qt * 16;
     const int4 qc4 = *reinterpret_cast<const int4*>(qcode + q0 + 4 * kg);
     const int qc[4] = {qc4.x, qc4.y, qc4.z, qc4.w};
@@ -837,14 +867,31 @@ __global__ void __launch_bounds__(NW * 64, 2) winattn_bwd_mfma_kernel(const bf16
           *reinterpret_cast<bf16x4*>(dqkv + (int64_t)row * lddq + head * 16 + 4 * d4) =
               bf16x4{(bf16)(sum[0] * g.scale), (bf16)(sum[1] * g.scale), (bf16)(sum[2] * g.scale), (bf16)(sum[3] * g.scale)};
         } else if (dqkv_bias) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) atomicAdd(&padb[4 * d4 + e], sum[e] * g.scale);
+          padq += sum;
         }
       }
     }
   }
+#if defined(ATT_EXP_STOP) && ATT_EXP_STOP == 3
+  if (tsize != -1) return;
+#endif
+  // bias gradient of the zero-padded tokens (their q / k / v rows are the bias itself): per-lane sums, folded over the lanes that hold the same
+  // dims, one LDS atomic per (dim, wave).  Round 5: as one LDS float atomic per padded token and dim - 16 lanes of a wave on ONE address, ~190
+  // cycles each - they were 30 of the 86 us of the 24^3 stage (37 % of its padded 28^3 grid is padding) and 5 us per query tile of a border window.
+  if (dqkv_bias) {
+#pragma unroll
+    for (int o2 = 4; o2 < 64; o2 <<= 1)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) padq[e] += __shfl_xor(padq[e], o2, 64);
+    if (lane < 4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (padq[e] != 0.f) atomicAdd(&padb[4 * lane + e], padq[e] * g.scale);
+    }
+  }
   // ---- dK, dV of the wave's keys: lane (key fi, dims 4kg..4kg+3); dK carries 1/log2e from Q'
   constexpr float LN2 = 0.6931471805599453f;
+  f32x4 padk = f32x4{0.f, 0.f, 0.f, 0.f}, padv = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int ki = (wave + NW * i) * 16 + fi;
@@ -855,16 +902,33 @@ __global__ void __launch_bounds__(NW * 64, 2) winattn_bwd_mfma_kernel(const bf16
         *reinterpret_cast<bf16x4*>(pk) = bf16x4{(bf16)(dkt[i][0] * LN2), (bf16)(dkt[i][1] * LN2), (bf16)(dkt[i][2] * LN2), (bf16)(dkt[i][3] * LN2)};
         *reinterpret_cast<bf16x4*>(pk + C) = bf16x4{(bf16)dvt[i][0], (bf16)dvt[i][1], (bf16)dvt[i][2], (bf16)dvt[i][3]};
       } else if (dqkv_bias) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          atomicAdd(&padb[16 + 4 * kg + e], dkt[i][e] * LN2);
-          atomicAdd(&padb[32 + 4 * kg + e], dvt[i][e]);
-        }
+        padk += dkt[i];
+        padv += dvt[i];
       }
     }
   }
+  if (dqkv_bias) {      // lanes fi = 0..15 of a k group hold the same dims: fold them, then one LDS atomic per (dim, wave)
+#pragma unroll
+    for (int o2 = 1; o2 < 16; o2 <<= 1)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { padk[e] += __shfl_xor(padk[e], o2, 64); padv[e] += __shfl_xor(padv[e], o2, 64); }
+    if (fi == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (padk[e] != 0.f) atomicAdd(&padb[16 + 4 * kg + e], padk[e] * LN2);
+        if (padv[e] != 0.f) atomicAdd(&padb[32 + 4 * kg + e], padv[e]);
+      }
+    }
+  }
+#if defined(ATT_EXP_STOP) && ATT_EXP_STOP == 4
+  if (tsize != -1) return;
+#endif
   __syncthreads();
+#ifdef ATT_EXP_NOFLUSH
+  if (false)
+#else
   if (dbias_table)
+#endif
     for (int i = tid; i < tsize; i += NTHR) {
       const int v = dtable[i];
       if (v != 0) atomicAdd(dbias_table + (int64_t)i * g.heads + head, (float)v / fscale);
@@ -962,7 +1026,7 @@ extern "C" int miseg_winattn_fwd(const miseg_winattn_params* p, miseg_stream_t s
     const bool wide = (int64_t)grid.x * grid.y < 256;       // fewer workgroups than CUs: one query tile per wave
 #define FWD_MFMA_D(M, NWV, D)                                                                                                                  \
   MISEG_SET_SMEM((winattn_fwd_mfma_kernel<M, NWV, D>), shm);                    \
-  winattn_fwd_mfma_kernel<M, NWV, D><<<grid, NWV * 64, shm, s>>>((const bf16*)p->qkv, p->ldq, (bf16*)p->out, p->ldo, p->qkv_bias, p->bias_table, \
+  winattn_fwd_mfma_kernel<M, NWV, D><<<grid.x * grid.y, NWV * 64, shm, s>>>((const bf16*)p->qkv, p->ldq, (bf16*)p->out, p->ldo, p->qkv_bias, p->bias_table, \
                                                                  p->lse, g, tsize, vec, dr)
 #define FWD_MFMA(M, NWV) do { if (dr.thresh) { FWD_MFMA_D(M, NWV, true); } else { FWD_MFMA_D(M, NWV, false); } } while (0)
     if ((g.sd | g.sh | g.sw) != 0) { if (wide) { FWD_MFMA(true, 11); } else { FWD_MFMA(true, 8); } }
@@ -1006,7 +1070,7 @@ extern "C" int miseg_winattn_bwd(const miseg_winattn_bwd_params* p, miseg_stream
     const size_t shm = attn_mfma_bwd_smem(tsize, wide ? 8 : 4);
 #define BWD_MFMA_X(M, D, NWV, X)                                                                                                                            \
   MISEG_SET_SMEM((winattn_bwd_mfma_kernel<M, D, NWV, X>), shm);                              \
-  winattn_bwd_mfma_kernel<M, D, NWV, X><<<grid, NWV * 64, shm, s>>>((const bf16*)p->f.qkv, p->f.ldq, (const bf16*)p->f.out, p->f.ldo, (const bf16*)p->dout,    \
+  winattn_bwd_mfma_kernel<M, D, NWV, X><<<grid.x * grid.y, NWV * 64, shm, s>>>((const bf16*)p->f.qkv, p->f.ldq, (const bf16*)p->f.out, p->f.ldo, (const bf16*)p->dout,    \
                                                                     p->lddo, (bf16*)p->dqkv, p->lddq, p->f.qkv_bias, p->f.bias_table, p->f.lse, p->dqkv_bias, \
                                                                     p->dbias_table, g, tsize, vec, dr)
 #define BWD_MFMA(M, D, NWV) do { if (dr.thresh) { BWD_MFMA_X(M, D, NWV, true); } else { BWD_MFMA_X(M, D, NWV, false); } } while (0)

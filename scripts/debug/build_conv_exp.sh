@@ -5,5 +5,5 @@ R=$(cd "$(dirname "$0")/../.." && pwd)
 B=$R/mi-seg_amd/csrc/build
 TAG=$1; shift
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I $R/include '-DMISEG_COMPILED_ARCH="gfx950"' "$@" -c $R/mi-seg_amd/csrc/conv3d.hip -o /tmp/conv3d_$TAG.o
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -Wl,--wrap=hipLaunchKernel -o $R/scripts/micro/libmiseg_conv_$TAG.so $(ls $B/*.o | grep -v conv3d.hip.o) /tmp/conv3d_$TAG.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $R/scripts/micro/libmiseg_conv_$TAG.so $(ls $B/*.o | grep -v common_prof | grep -v conv3d.hip.o) /tmp/conv3d_$TAG.o
 echo built $R/scripts/micro/libmiseg_conv_$TAG.so
