@@ -732,8 +732,8 @@ __device__ unsigned long long miseg_wg_stamps[8];   // debug build only (scripts
 // direct = 0: the 27x48x48 partial goes to its slab (summed by the reduce kernel);
 // direct = 1 (only with nsplit == 1: every dw element has exactly one producer): transposed through LDS and added to
 //             (2: stored into) the torch-layout gradient in contiguous runs - no slab round trip, no second launch.
-// PIPED (bf16, whole 48-channel blocks, 16-byte aligned rows, D % WBD == 0 and H % BH == 0 so that every k-step of every brick
-// is inside the volume): the software-pipelined MFMA loop.  A separate instantiation, not a branch: with both loops in one
+// PIPED (bf16, whole 48-channel blocks, 16-byte aligned rows, at least one whole brick along every axis - the last one may be partial,
+// its rows beyond the volume are staged as zeros): the software-pipelined MFMA loop.  A separate instantiation, not a branch: with both loops in one
 // body the 252 accumulator registers of the two paths met in PHIs and the kernel spilled 350 VGPRs.
 template <class T, int WBD /*brick depth*/, bool PIPED>
 __device__ __forceinline__ void conv3_wgrad_body(const T* __restrict__ x, int64_t ldx, const T* __restrict__ dy, int64_t lddy, float* __restrict__ slabs,
@@ -825,15 +825,20 @@ __device__ __forceinline__ void conv3_wgrad_body(const T* __restrict__ x, int64_
   // multiplies).  Per lane and item, constant over the bricks: a 32-bit byte offset from the brick's halo (dy: brick) origin
   // and 8 "face" bits - which faces of the halo the item sits on (bit 7: lane beyond the item count); per brick, scalar: the two
   // origins and which faces lie outside the volume.  An item on such a face reads the halo's first interior voxel instead and
-  // is zeroed by vmask.  Needs D % WBD == H % BH == W % BW == 0 (every brick inside the volume).
+  // is zeroed by vmask.
+  // Round 5: volumes that are no whole number of bricks (12^3: H = W = 8 + 4).  The last brick along an axis is PARTIAL: three more item
+  // bits - the item lies beyond the remainder r = extent % brick on that axis - against three more brick bits - this brick is the partial one
+  // there (16 bits per item now).  Until then such layers walked the generic loop (17 us per brick against 8.5: the 12^3 layers were the
+  // long workgroups of the grouped launch, 238 us for a group whose other workgroups need 130).
   uint32_t ioff[PIPED ? NXI + NDI : 1];
-  uint32_t iface[PIPED ? (NXI + NDI + 3) / 4 : 1];
+  uint32_t iface[PIPED ? (NXI + NDI + 1) / 2 : 1];
   const char* xorg = nullptr;
   const char* dorg = nullptr;
-  uint32_t bfaces = 0xff, ctr = 0;
+  uint32_t bfaces = 0xffff, ctr = 0;
   if constexpr (PIPED) {
+    const int rd_ = g.D % WBD, rh_ = g.H % BH, rw_ = g.W % BW;
 #pragma unroll
-    for (int q = 0; q < (NXI + NDI + 3) / 4; ++q) iface[q] = 0;
+    for (int q = 0; q < (NXI + NDI + 1) / 2; ++q) iface[q] = 0;
 #pragma unroll
     for (int j = 0; j < NXI + NDI; ++j) {
       uint32_t f;
@@ -844,16 +849,16 @@ __device__ __forceinline__ void conv3_wgrad_body(const T* __restrict__ x, int64_
         const int hh = rem / HW, hw = rem - hh * HW;
         ioff[j] = (uint32_t)((((int64_t)hd * g.H + hh) * g.W + hw) * ldx + cg * KPC) * (uint32_t)sizeof(T);
         f = (hd == 0 ? 1u : 0u) | (hd == WBD + 1 ? 2u : 0u) | (hh == 0 ? 4u : 0u) | (hh == HH - 1 ? 8u : 0u) | (hw == 0 ? 16u : 0u) | (hw == HW - 1 ? 32u : 0u) |
-            (idx >= HROWS * GPR ? 128u : 0u);
+            (idx >= HROWS * GPR ? 128u : 0u) | (hd > rd_ ? 256u : 0u) | (hh > rh_ ? 512u : 0u) | (hw > rw_ ? 1024u : 0u);
       } else {
         const int idx = tid + (j - NXI) * WG_THREADS;
         const int row = idx / GPR, cg = idx - row * GPR;
         const int vd = row / (BH * BW), rem = row - vd * (BH * BW);
         const int vh = rem / BW, vw = rem - vh * BW;
         ioff[j] = (uint32_t)((((int64_t)vd * g.H + vh) * g.W + vw) * lddy + cg * KPC) * (uint32_t)sizeof(T);
-        f = idx >= NVOX * GPR ? 128u : 0u;
+        f = (idx >= NVOX * GPR ? 128u : 0u) | (vd >= rd_ ? 256u : 0u) | (vh >= rh_ ? 512u : 0u) | (vw >= rw_ ? 1024u : 0u);
       }
-      iface[j >> 2] |= f << ((j & 3) * 8);
+      iface[j >> 1] |= f << ((j & 1) * 16);
     }
     ctr = (uint32_t)((((int64_t)g.H + 1) * g.W + 1) * ldx) * (uint32_t)sizeof(T);
   }
@@ -865,12 +870,12 @@ __device__ __forceinline__ void conv3_wgrad_body(const T* __restrict__ x, int64_
     xorg = reinterpret_cast<const char*>(x + ((((int64_t)b * g.D + d0 - 1) * g.H + h0 - 1) * g.W + w0 - 1) * ldx + ci0);
     dorg = reinterpret_cast<const char*>(dy + ((((int64_t)b * g.D + d0) * g.H + h0) * g.W + w0) * lddy + co0);
     bfaces = ok ? (128u | (d0 == 0 ? 1u : 0u) | (d0 + WBD >= g.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) | (h0 + BH >= g.H ? 8u : 0u) | (w0 == 0 ? 16u : 0u) |
-                   (w0 + BW >= g.W ? 32u : 0u))
-                : 0xffu;
+                   (w0 + BW >= g.W ? 32u : 0u) | (d0 + WBD > g.D ? 256u : 0u) | (h0 + BH > g.H ? 512u : 0u) | (w0 + BW > g.W ? 1024u : 0u))
+                : 0xffffu;
     vmask = 0;
   };
   auto pitem = [&](int j) {
-    const bool ok = ((iface[j >> 2] >> ((j & 3) * 8)) & bfaces) == 0;
+    const bool ok = ((iface[j >> 1] >> ((j & 1) * 16)) & bfaces) == 0;
     if (j < NXI) rx[j] = *reinterpret_cast<const VT*>(xorg + (ok ? ioff[j] : ctr));
     else rd[j - NXI] = *reinterpret_cast<const VT*>(dorg + (ok ? ioff[j] : 0u));
     vmask |= (ok ? 1u : 0u) << j;
@@ -1520,23 +1525,25 @@ struct WgradLayer {
 static constexpr int WG_GROUP_MAX = 24;
 struct WgradGroup { WgradLayer l[WG_GROUP_MAX]; int n; };
 
-template <class T, int WBD>
+// Round 5: ONE loop form per kernel (PIPED is a template parameter, the host launches the pipelined layers and the others as two grids).  With
+// both bodies behind a per-unit branch the 252 accumulator registers of the two paths met and the kernel spilled 1.5 KB per lane - in the
+// grouped launch only: the single-layer kernel always had one instantiation per form.
+template <class T, int WBD, bool PIPED, bool WALK>
 __global__ void __launch_bounds__(WG_THREADS) conv3_wgrad_group_kernel(const WgradGroup grp, int rowb, int total_units) {
-  // one unit = one (layer, channel pair, split).  Normal form: one workgroup per unit.  Background form (max_workgroups of the first
-  // descriptor: the launch runs on a side stream beside another stream's kernels): a capped grid walks the units, longest layers first.
+  // one unit = one (layer, channel pair, split).  Normal form (WALK = false): one workgroup per unit.  Background form (max_workgroups of the
+  // first descriptor: the launch runs on a side stream beside another stream's kernels): a capped grid walks the units, longest layers first.
   for (int unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
-    if (unit != (int)blockIdx.x) __syncthreads();      // the LDS images of the previous unit have been read
+    if (unit != (int)blockIdx.x) {
+      if constexpr (!WALK) break;
+      __syncthreads();      // the LDS images of the previous unit have been read
+    }
     int li = 0;
     for (int i = 1; i < grp.n; ++i)
       if (unit >= grp.l[i].wg0) li = i;
     const WgradLayer& L = grp.l[li];
     const int local = unit - L.wg0;
-    if (std::is_same<T, bf16>::value && ((L.flags >> 4) & 1))
-      conv3_wgrad_body<T, WBD, true>((const T*)L.x, L.ldx, (const T*)L.dy, L.lddy, L.slabs, L.dw, L.g, L.Cin, L.Cout, L.ncib, L.nsplit, rowb, true, true,
-                                     local % L.nsplit, local / L.nsplit, (L.flags >> 2) & 3, ((L.nsplit | L.wg0) & 7) == 0);
-    else
-      conv3_wgrad_body<T, WBD, false>((const T*)L.x, L.ldx, (const T*)L.dy, L.lddy, L.slabs, L.dw, L.g, L.Cin, L.Cout, L.ncib, L.nsplit, rowb, L.flags & 1,
-                                      (L.flags >> 1) & 1, local % L.nsplit, local / L.nsplit, (L.flags >> 2) & 3, ((L.nsplit | L.wg0) & 7) == 0);
+    conv3_wgrad_body<T, WBD, PIPED>((const T*)L.x, L.ldx, (const T*)L.dy, L.lddy, L.slabs, L.dw, L.g, L.Cin, L.Cout, L.ncib, L.nsplit, rowb, PIPED || (L.flags & 1),
+                                    PIPED || ((L.flags >> 1) & 1), local % L.nsplit, local / L.nsplit, (L.flags >> 2) & 3, ((L.nsplit | L.wg0) & 7) == 0);
   }
 }
 
@@ -1815,7 +1822,9 @@ extern "C" size_t miseg_conv3_wgrad_workspace_bytes(int B, int D, int H, int W, 
 template <class T, int WBD>
 static bool wgrad_piped(const miseg_conv3_wgrad_params* p, bool vec_x, bool vec_dy) {
   const int64_t span = (int64_t)(WBD + 2) * p->H * p->W * (p->ldx > p->lddy ? p->ldx : p->lddy) * (int64_t)sizeof(T);   // 32-bit item offsets
-  return std::is_same<T, bf16>::value && vec_x && vec_dy && p->Cin % WG_CB == 0 && p->Cout % WG_CB == 0 && p->D % WBD == 0 && p->H % BH == 0 && p->W % BW == 0 &&
+  // (round 5: the last brick along an axis may be partial; every axis holds at least one whole brick, so a brick's first interior voxel -
+  // what an invalid item reads instead - is inside the volume)
+  return std::is_same<T, bf16>::value && vec_x && vec_dy && p->Cin % WG_CB == 0 && p->Cout % WG_CB == 0 && p->D >= WBD && p->H >= BH && p->W >= BW &&
          span < ((int64_t)1 << 31);
 }
 
@@ -1949,9 +1958,37 @@ static int conv3_wgrad_group_launch(const miseg_conv3_wgrad_params* descs, int n
       rb += L.tiles * L.groups;
     }
   }
-  hipFuncSetAttribute((const void*)conv3_wgrad_group_kernel<T, WBD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int cap = descs[0].max_workgroups;      // > 0: background form (see the kernel)
-  conv3_wgrad_group_kernel<T, WBD><<<(cap > 0 && cap < wg) ? cap : wg, WG_THREADS, lds, s>>>(grp, rowb, wg);
+  // the pipelined layers and the others: one grid each (same descriptors, workgroups renumbered; the reduce launch walks `grp`)
+  for (int form = 0; form < 2; ++form) {
+    WgradGroup sub;
+    sub.n = 0;
+    int nwg = 0;
+    for (int k = 0; k < n; ++k) {
+      if ((((grp.l[k].flags >> 4) & 1) != 0) != (form == 0)) continue;
+      WgradLayer& L = sub.l[sub.n++];
+      L = grp.l[k];
+      const int units = (k + 1 < n ? grp.l[k + 1].wg0 : wg) - grp.l[k].wg0;
+      L.wg0 = nwg;
+      nwg += units;
+    }
+    if (!sub.n) continue;
+    const bool walk = cap > 0 && cap < nwg;
+    const int grid = walk ? cap : nwg;
+#define MISEG_WG_GROUP_LAUNCH(PIPED_, WALK_)                                                                                                       \
+    do {                                                                                                                                           \
+      hipFuncSetAttribute((const void*)conv3_wgrad_group_kernel<T, WBD, PIPED_, WALK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+      conv3_wgrad_group_kernel<T, WBD, PIPED_, WALK_><<<grid, WG_THREADS, lds, s>>>(sub, rowb, nwg);                                                \
+    } while (0)
+    if (form == 0) {
+      if constexpr (std::is_same<T, bf16>::value) {
+        if (walk) MISEG_WG_GROUP_LAUNCH(true, true); else MISEG_WG_GROUP_LAUNCH(true, false);
+      }
+    } else {
+      if (walk) MISEG_WG_GROUP_LAUNCH(false, true); else MISEG_WG_GROUP_LAUNCH(false, false);
+    }
+#undef MISEG_WG_GROUP_LAUNCH
+  }
   if (rb > 0) conv3_wgrad_reduce_group_kernel<<<rb, 256, 0, s>>>(grp);
   MISEG_LAUNCH_CHECK("conv3_wgrad_group");
   return MISEG_OK;

@@ -96,6 +96,54 @@ def backward_mark(x, fn):
     return y
 
 
+class _InnerTape(Function):
+    """outputs computed EARLIER on a tape of their own (from detached leaves) enter the outer tape HERE.  Autograd runs the ready node with the
+    highest sequence number first, so where a node is taped decides when its backward pass is issued; a side branch whose forward should
+    run early (beside one launch-bound part of the step) and whose backward should run early too (beside another) cannot be taped where its
+    forward runs.  forward: aliases of the inner outputs; backward: the inner tape's backward pass (a nested autograd call on the stream
+    this node was taped on) and the gradients its leaves collected."""
+
+    @staticmethod
+    def forward(ctx, holder, *outer):
+        ctx.holder = holder
+        return tuple(o.detach() for o in holder["outs"])
+
+    @staticmethod
+    def backward(ctx, *g):
+        h = ctx.holder
+        pairs = [(o, gi) for o, gi in zip(h["outs"], g) if gi is not None and o.requires_grad]
+        if pairs:
+            torch.autograd.backward([o for o, _ in pairs], [gi for _, gi in pairs])
+        grads = []
+        for leaf in h["leaves"]:
+            grads.append(leaf.grad if leaf is not None else None)
+            if leaf is not None:
+                leaf.grad = None
+        h["outs"] = h["leaves"] = None          # the inner tape is spent
+        return (None,) + tuple(grads)
+
+
+def inner_tape_leaf(t):
+    """a leaf that starts an inner tape at `t` (see _InnerTape); tags travel with it"""
+    l = t.detach().requires_grad_(t.requires_grad)
+    for a in ("_miseg_stat", "_miseg_cat"):
+        if hasattr(t, a):
+            setattr(l, a, getattr(t, a))
+    return l
+
+
+def inner_tape_join(outs, outer, leaves):
+    """outs: tensors computed from `leaves` (= inner_tape_leaf(o) for o in outer; None where the outer tensor needs no gradient).  Returns
+    aliases of `outs` that are taped at the CALLER's position, on the caller's current stream."""
+    holder = {"outs": list(outs), "leaves": list(leaves)}
+    res = _InnerTape.apply(holder, *outer)
+    for r, o in zip(res, outs):
+        for a in ("_miseg_stat", "_miseg_cat"):
+            if hasattr(o, a):
+                setattr(r, a, getattr(o, a))
+    return res
+
+
 class _Add(Function):
     @staticmethod
     def forward(ctx, a, b):

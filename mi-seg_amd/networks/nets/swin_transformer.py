@@ -90,10 +90,12 @@ class SwinTransformer(nn.Module):
             return HF.instance_norm(x, None)
         return x
 
-    def forward(self, x, normalize=True, styles=None, dtype=torch.float32, after_stage1=None):
+    def forward(self, x, normalize=True, styles=None, dtype=torch.float32, after_stage1=None, on_feature=None):
         """x: NCDHW fp32 network input.  Returns 5 channels-last feature maps.
         after_stage1: optional callable(first feature map), called once the launches of `layers1` are queued (SwinUNETR's inference
-        forward forks its image-resolution encoder blocks there)."""
+        forward forks its image-resolution encoder blocks there).
+        on_feature: optional callable(i, feature map i), called as soon as the launches that produce returned feature map i are queued
+        (SwinUNETR's training forward forks its side branch at one of them)."""
         x0 = self.patch_embed(x, styles, dtype)
         x0 = HF.dropout(x0, self.drop_rate, self.training)        # pos_drop (swin_transformer.py:149)
         outs = []
@@ -106,6 +108,8 @@ class SwinTransformer(nn.Module):
             else:
                 a, cur = HF.fork(cur)
                 outs.append(self.proj_out(a, normalize))
+            if on_feature is not None:
+                on_feature(len(outs) - 1, outs[-1])
             cur = layers[0](cur, styles)
             if after_stage1 is not None and layers is self.layers1:
                 after_stage1(outs[0])

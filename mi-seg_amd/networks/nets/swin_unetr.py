@@ -149,6 +149,10 @@ class SwinUNETR(nn.Module):
     # hip/ops.py::_background), and their forward runs beside encoder10 / decoder5..3.  Measured A/B;
     # `MISEG_NO_BRANCH=1` switches it off.
     side_branch = os.environ.get("MISEG_NO_BRANCH") is None
+    # Where the training forward forks that branch: "e10" = where it is taped (in front of encoder10, beside encoder10 / decoder5..3);
+    # "s0" / "s1" / "s2" = as soon as Swin feature map 0 / 1 / 2 is queued, i.e. beside the Swin stages behind it, on a tape of its own that
+    # joins the outer tape in front of encoder10 (HF.inner_tape_join): the backward pass is issued where it always was
+    fork_at = os.environ.get("MISEG_FORK_AT", "e10")
 
     @staticmethod
     def _skip_block(block, inp, styles, shape, channels, dt, **kw):
@@ -207,7 +211,28 @@ class SwinUNETR(nn.Module):
                 enc0 = self._skip_block(self.encoder1, None, styles, x_in.shape, self.encoder1.layer.conv2.conv.weight.shape[0], dt, image=x_in, dtype=dt)
                 enc1 = self._skip_block(self.encoder2, hs0, styles, hs0.shape, hs0.shape[-1], dt)
 
-        hs = self.swinViT(x_in, self.normalize, styles, dt, after_stage1=fork_inference if infer_branch else None)
+        inner, feats = {}, []
+
+        def fork_training(i, feat):
+            feats.append(feat)
+            if i != {"s0": 0, "s1": 1, "s2": 2}[self.fork_at] or not feats[0].requires_grad:
+                return
+            side, cur = ops.branch_stream(x_in.device), torch.cuda.current_stream()
+            ops._MAIN_STREAM = cur
+            side.wait_stream(cur)
+            for t in (feats[0], x_in, styles[0] if styles is not None else None):
+                if t is not None:
+                    t.record_stream(side)
+            with torch.cuda.stream(side):
+                leaf0 = HF.inner_tape_leaf(feats[0])
+                e0 = self._skip_block(self.encoder1, None, styles, x_in.shape, self.encoder1.layer.conv2.conv.weight.shape[0], dt, image=x_in, dtype=dt)
+                e1 = self._skip_block(self.encoder2, leaf0, styles, leaf0.shape, leaf0.shape[-1], dt)
+                ops.stamp("branch_fwd_end", fine=True)
+            inner.update(outs=(e0, e1), outer=(feats[0],), leaves=(leaf0,))
+
+        early = branch and self.fork_at in ("s0", "s1", "s2")
+        hs = self.swinViT(x_in, self.normalize, styles, dt, after_stage1=fork_inference if infer_branch else None,
+                          on_feature=fork_training if early else None)
         ops.stamp("swin_end", fine=True)
         if not branch and not infer_branch:
             enc0 = self._skip_block(self.encoder1, None, styles, x_in.shape, self.encoder1.layer.conv2.conv.weight.shape[0], dt, image=x_in, dtype=dt)
@@ -237,6 +262,10 @@ class SwinUNETR(nn.Module):
             # behind the Swin transformer 143.3)
             side, cur = ops.branch_stream(x_in.device), torch.cuda.current_stream()
             ops._MAIN_STREAM = cur
+            if inner:      # forked earlier, on a tape of its own: the backward pass is taped here (nothing is launched)
+                with torch.cuda.stream(side):
+                    enc0, enc1 = HF.inner_tape_join(inner["outs"], inner["outer"], inner["leaves"])
+        if branch and not inner:
             side.wait_stream(cur)
             for t in (hs[0], x_in, styles[0] if styles is not None else None):      # allocated on this stream, read by the branch's kernels
                 if t is not None:

@@ -523,7 +523,10 @@ def _conv_case(dtype, B, D, H, W, Cin, Cout, seed=0):
                                              (1, 5, 8, 8, 32, 32),       # (the 16 / 32-channel bf16 cases take the narrow-layer weight-gradient kernel)
                                              # rows >= 256 bytes that are no multiple of 96: K side padded to the next chunk (miseg_conv3_k96),
                                              # forward on Cin, data gradient on Cout; ragged channel counts and a generic-path partner
-                                             (1, 12, 12, 12, 128, 256), (1, 6, 7, 5, 256, 128), (2, 5, 6, 7, 130, 64), (1, 4, 4, 4, 200, 40)])
+                                             (1, 12, 12, 12, 128, 256), (1, 6, 7, 5, 256, 128), (2, 5, 6, 7, 130, 64), (1, 4, 4, 4, 200, 40),
+                                             # whole 48-channel blocks on volumes that are no whole number of 4 x 8 x 8 bricks: the pipelined weight-gradient
+                                             # loop with partial last bricks (round 5; remainders 4 / 1, 5, 3 / 2, 3)
+                                             (1, 12, 12, 12, 192, 96), (1, 9, 13, 19, 48, 48), (2, 6, 11, 8, 96, 96)])
 def test_conv3_fwd_dgrad_wgrad(dtype, B, D, H, W, Cin, Cout):
     ops = _ops()
     x, w = _conv_case(dtype, B, D, H, W, Cin, Cout)
@@ -686,7 +689,7 @@ def test_conv3_wgrad_grouped(dtype):
     grouped partial sums for the others) must accumulate exactly what the per-layer launches give, on top of what dw held."""
     ops = _ops()
     shapes = [(1, 3, 3, 3, 96, 96), (1, 6, 6, 6, 48, 96), (2, 12, 12, 12, 48, 48), (1, 24, 24, 24, 96, 48), (1, 5, 9, 11, 12, 24),
-              (1, 3, 3, 3, 40, 72), (1, 16, 40, 24, 48, 48)]
+              (1, 3, 3, 3, 40, 72), (1, 16, 40, 24, 48, 48), (1, 9, 13, 19, 48, 96)]
     cases = []
     for i, (B, D, H, W, Cin, Cout) in enumerate(shapes):
         x = rnd(B, D, H, W, Cin, dtype=dtype, seed=70 + i)
