@@ -33,7 +33,7 @@ enum { MISEG_ACT_NONE = 0, MISEG_ACT_LEAKY = 1, MISEG_ACT_GELU = 2, MISEG_ACT_PR
 #define MISEG_MAX_STYLES 4
 
 /* bumped on EVERY change of a struct layout or prototype; bindings must refuse a library whose version differs from the header they mirror */
-#define MISEG_ABI_VERSION 8
+#define MISEG_ABI_VERSION 9
 int miseg_abi_version(void);
 const char* miseg_last_error(void);
 /* writes e.g. "gfx950" for the code objects embedded in the library */
@@ -619,6 +619,18 @@ typedef struct {
   const int32_t* index; int32_t count_n;
 } miseg_opt_step_params;
 int miseg_opt_step(const miseg_opt_step_params* p, miseg_stream_t stream);
+
+/* ABI 9.  The optimiser step of every 3x3x3 conv weight of a model TOGETHER WITH its re-layout (lightning_monai.py:255-278 + what the next
+ * forward pass needs of dynunet_block.py:295-326): the launch walks the 16 x 16 (co, ci) tiles of the miseg_pack_conv3_batch table, updates a
+ * tile's weights / state from their gradients (same arithmetic as miseg_opt_step, element offsets of `grad` / `state1` / `state2` = map[i].off
+ * + the element's index in the weight) and writes the tile's forward and data-gradient packs from the NEW values.  The refresh launch of the
+ * next step then has nothing to do for these weights: with `pack_state` (the `state` words of that table's versioned refresh) the launch
+ * records the new parameter version there.  map[i] belongs to descs[i]; param_index = the weight's row in used / steps.  A tensor with
+ * used[param_index] == 0 is left alone (weights, state, packs).  `p`: descs_dev / ndesc / total_blocks / index are ignored; count_n > 0 = this is
+ * the LAST launch of the step (steps[i] += used[i] for i < count_n, version bump - see miseg_opt_step); 0 = another launch follows. */
+typedef struct { int64_t off; int32_t param_index, pad_; } miseg_opt_pack_map;
+int miseg_opt_step_pack_conv3(const miseg_opt_step_params* p, const miseg_pack_conv3_desc* descs_dev, const miseg_opt_pack_map* map_dev, int n, int total_tiles,
+                              int dtype, int64_t* pack_state, miseg_stream_t stream);
 
 /* Sliding-window stitching (MONAI sliding_window_inference, mode="constant", as used at lightning_monai.py:86-93,187): every window's logits
  * stay resident (win: fp32 [nd*nh*nw][C][rd][rh][rw], window (id, ih, iw) at index (id*nh + ih)*nw + iw, origin (start_d[id], start_h[ih],

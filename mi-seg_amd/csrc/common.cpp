@@ -33,7 +33,7 @@ extern "C" size_t miseg_abi_struct_size(const char* name) {
   MISEG_SZ(miseg_cast_params) MISEG_SZ(miseg_cast_desc) MISEG_SZ(miseg_gelu_fwd_params) MISEG_SZ(miseg_gelu_bwd_params) MISEG_SZ(miseg_s2c_params)
   MISEG_SZ(miseg_patch_embed_params) MISEG_SZ(miseg_patch_embed_bwd_params) MISEG_SZ(miseg_conv3_thin_params) MISEG_SZ(miseg_conv3_thin_wgrad_params)
   MISEG_SZ(miseg_resample2_params) MISEG_SZ(miseg_rowbias_params) MISEG_SZ(miseg_prelu_fwd_params) MISEG_SZ(miseg_prelu_bwd_params) MISEG_SZ(miseg_head_params)
-  MISEG_SZ(miseg_head_bwd_params) MISEG_SZ(miseg_im2col3_params) MISEG_SZ(miseg_seg_loss_params) MISEG_SZ(miseg_dice_metric_params) MISEG_SZ(miseg_opt_desc)
+  MISEG_SZ(miseg_head_bwd_params) MISEG_SZ(miseg_im2col3_params) MISEG_SZ(miseg_seg_loss_params) MISEG_SZ(miseg_dice_metric_params) MISEG_SZ(miseg_opt_desc) MISEG_SZ(miseg_opt_pack_map)
   MISEG_SZ(miseg_opt_step_params) MISEG_SZ(miseg_stitch_params) MISEG_SZ(miseg_aug_sample) MISEG_SZ(miseg_augment_params) MISEG_SZ(miseg_resample3d_params) MISEG_SZ(miseg_dropout_params)
   MISEG_SZ(miseg_affine2_params) MISEG_SZ(miseg_graph_split_info) MISEG_SZ(miseg_norm_ref)
 #undef MISEG_SZ

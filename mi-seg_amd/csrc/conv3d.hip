@@ -13,6 +13,7 @@
 //   fp32 slab per workgroup and reduced by a second kernel (deterministic, no atomics).
 #include <type_traits>
 #include "common.h"
+#include "opt_math.h"
 
 namespace miseg {
 
@@ -597,9 +598,13 @@ __device__ __forceinline__ void fwd96_pack_dummies(int gpt, T* pack, int chunk, 
   }
 }
 
-template <class T>
-__device__ __forceinline__ void pack_conv3_tile(const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ bwd, int Cin, int Cout, int CinP, int CoutP,
-                                                int Cin16, int Cout16, int fwd_gpt, int bwd_gpt, int bx, int by) {
+// OPT (round 5, miseg_opt_step_pack_conv3): the tile is first UPDATED - one optimiser step on its weights, read with their gradient and
+// state slots at the same element offsets of the flat arena - and the packs are written from the new values: the separate refresh pass of
+// the next step (a second read of the 55 M conv weights, 440 MB moved) is gone.
+struct OptTile { const float* g; float* m; float* v; OptHyper h; };      // g / m / v: already offset to this parameter's slot
+template <class T, bool OPT = false>
+__device__ __forceinline__ void pack_conv3_tile(typename std::conditional<OPT, float, const float>::type* __restrict__ w, T* __restrict__ fwd, T* __restrict__ bwd, int Cin,
+                                                int Cout, int CinP, int CoutP, int Cin16, int Cout16, int fwd_gpt, int bwd_gpt, int bx, int by, const OptTile* ot = nullptr) {
   const bool fwd_planar = fwd_gpt != 0, bwd_planar = bwd_gpt != 0;      // groups per chunk of the planar pack's K side, 0 = row-major pack
   typedef typename Vec16<T>::type VT;
   constexpr int KPC = Vec16<T>::N, NG = PK_T / KPC;
@@ -618,6 +623,28 @@ __device__ __forceinline__ void pack_conv3_tile(const float* __restrict__ w, T* 
       v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (idx < PK_T * R4 && co0 + co < Cout) v[k] = *reinterpret_cast<const f32x4*>(w + ((int64_t)(co0 + co) * Cin + ci0) * 27 + 4 * r4);
     }
+    if constexpr (OPT) {
+      const bool adam = ot->h.kind != MISEG_OPT_SGD_NESTEROV;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int idx = threadIdx.x + k * 256, co = idx / R4, r4 = idx - co * R4;
+        if (idx < PK_T * R4 && co0 + co < Cout) {
+          const int64_t off = ((int64_t)(co0 + co) * Cin + ci0) * 27 + 4 * r4;
+          const f32x4 g4 = *reinterpret_cast<const f32x4*>(ot->g + off);
+          f32x4 m4 = *reinterpret_cast<const f32x4*>(ot->m + off);
+          f32x4 v4 = adam ? *reinterpret_cast<const f32x4*>(ot->v + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float we = v[k][e], me = m4[e], ve = v4[e];
+            opt_update(ot->h, we, g4[e], me, ve);
+            v[k][e] = we; m4[e] = me; v4[e] = ve;
+          }
+          *reinterpret_cast<f32x4*>(w + off) = v[k];
+          *reinterpret_cast<f32x4*>(ot->m + off) = m4;
+          if (adam) *reinterpret_cast<f32x4*>(ot->v + off) = v4;
+        }
+      }
+    }
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int idx = threadIdx.x + k * 256, co = idx / R4, r4 = idx - co * R4;
@@ -630,7 +657,19 @@ __device__ __forceinline__ void pack_conv3_tile(const float* __restrict__ w, T* 
 #pragma unroll 1
     for (int i = threadIdx.x; i < PK_T * PK_T * 27; i += 256) {
       const int co = i / (PK_T * 27), r = i - co * (PK_T * 27);     // r = ci_local * 27 + tap
-      tile[co * PK_LD + r] = (co0 + co < Cout && r < nci * 27) ? w[((int64_t)(co0 + co) * Cin + ci0) * 27 + r] : 0.f;
+      float wv = 0.f;
+      if (co0 + co < Cout && r < nci * 27) {
+        const int64_t off = ((int64_t)(co0 + co) * Cin + ci0) * 27 + r;
+        wv = w[off];
+        if constexpr (OPT) {
+          float me = ot->m[off], ve = ot->h.kind != MISEG_OPT_SGD_NESTEROV ? ot->v[off] : 0.f;
+          opt_update(ot->h, wv, ot->g[off], me, ve);
+          w[off] = wv;
+          ot->m[off] = me;
+          if (ot->h.kind != MISEG_OPT_SGD_NESTEROV) ot->v[off] = ve;
+        }
+      }
+      tile[co * PK_LD + r] = wv;
     }
   }
   __syncthreads();
@@ -708,6 +747,43 @@ __global__ void __launch_bounds__(256) pack_conv3_batch_kernel(const miseg_pack_
                        kf ? conv3_gpt(d.Cin, (int)sizeof(T), pad_min) : 0, kb ? conv3_gpt(d.Cout, (int)sizeof(T), pad_min) : 0, t % tci, t / tci);
   }
   refresh_done(params_version, state, pv);
+}
+
+// one optimiser step on every 3x3x3 weight of the table + its packs (miseg_opt_step_pack_conv3).  Same tile walk as the refresh kernel above;
+// a tensor without a gradient this step (used[] == 0) is left alone - weights, state and packs.
+template <class T>
+__global__ void __launch_bounds__(256) opt_pack_conv3_batch_kernel(const miseg_pack_conv3_desc* __restrict__ descs, const miseg_opt_pack_map* __restrict__ map, int n,
+                                                                      int total_tiles, int pad_min, int kind, const float* __restrict__ grad, float* __restrict__ s1,
+                                                                      float* __restrict__ s2, const int32_t* __restrict__ used, const int32_t* __restrict__ steps, float lr,
+                                                                      float b1, float b2, float eps, float wd, float mom, const float* __restrict__ lr_dev) {
+  constexpr int KPC = Vec16<T>::N;
+  constexpr int NS = 128;
+  __shared__ int s_tile0[NS];
+  __shared__ OptTile s_ot;
+  const bool in_lds = n <= NS;
+  if (in_lds) {
+    for (int i = threadIdx.x; i < n; i += 256) s_tile0[i] = descs[i].tile0;
+    __syncthreads();
+  }
+  if (lr_dev) lr = *lr_dev;
+  for (int tl = blockIdx.x; tl < total_tiles; tl += gridDim.x) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {   // last descriptor with tile0 <= tl
+      const int mid = (lo + hi + 1) >> 1;
+      if ((in_lds ? s_tile0[mid] : descs[mid].tile0) <= tl) lo = mid; else hi = mid - 1;
+    }
+    const miseg_opt_pack_map mp = map[lo];
+    if (used && !used[mp.param_index]) continue;      // (uniform per workgroup)
+    const miseg_pack_conv3_desc d = descs[lo];
+    const int kf = conv3_k96(d.Cin, (int)sizeof(T), pad_min), kb = conv3_k96(d.Cout, (int)sizeof(T), pad_min);
+    const int t = tl - d.tile0, tci = ((kf > d.Cin ? kf : d.Cin) + PK_T - 1) / PK_T;
+    const int CinP = kf ? kf : (d.Cin + KPC - 1) / KPC * KPC, CoutP = kb ? kb : (d.Cout + KPC - 1) / KPC * KPC;
+    __syncthreads();      // the LDS tile (and s_ot) of the previous iteration has been read
+    if (threadIdx.x == 0) s_ot = OptTile{grad + mp.off, s1 + mp.off, s2 ? s2 + mp.off : nullptr, opt_hyper(kind, steps[mp.param_index] + 1, lr, b1, b2, eps, wd, mom)};
+    __syncthreads();
+    pack_conv3_tile<T, true>(const_cast<float*>(d.w), (T*)d.fwd_pack, (T*)d.bwd_pack, d.Cin, d.Cout, CinP, CoutP, (d.Cin + 15) / 16 * 16, (d.Cout + 15) / 16 * 16,
+                             kf ? conv3_gpt(d.Cin, (int)sizeof(T), pad_min) : 0, kb ? conv3_gpt(d.Cout, (int)sizeof(T), pad_min) : 0, t % tci, t / tci, &s_ot);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1792,6 +1868,29 @@ extern "C" int miseg_pack_conv3_batch(const miseg_pack_conv3_desc* descs, int n,
     MISEG_LAUNCH_CHECK("pack_conv3_batch");
     return MISEG_OK;
   });
+}
+
+extern "C" int miseg_opt_step_pack_conv3(const miseg_opt_step_params* p, const miseg_pack_conv3_desc* descs, const miseg_opt_pack_map* map, int n, int total_tiles,
+                                         int dtype, int64_t* pack_state, miseg_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  MISEG_REQUIRE(p && p->struct_size == sizeof(miseg_opt_step_params), MISEG_E_BADARG, "opt_step_pack_conv3: struct_size %u != %zu", p ? p->struct_size : 0u,
+                sizeof(miseg_opt_step_params));
+  MISEG_REQUIRE(descs && map && n > 0 && total_tiles > 0 && p->grad && p->state1 && p->steps, MISEG_E_BADARG, "opt_step_pack_conv3: null pointer / empty table");
+  MISEG_REQUIRE(p->kind == MISEG_OPT_ADAMW || p->kind == MISEG_OPT_ADAM || p->kind == MISEG_OPT_SGD_NESTEROV, MISEG_E_BADARG, "opt_step_pack_conv3: kind %d", p->kind);
+  MISEG_REQUIRE(p->kind == MISEG_OPT_SGD_NESTEROV || p->state2, MISEG_E_BADARG, "opt_step_pack_conv3: Adam needs state2");
+  MISEG_REQUIRE(p->count_n >= 0, MISEG_E_BADARG, "opt_step_pack_conv3: count_n must name the number of parameters of the whole step (or 0)");
+  const int rc = dispatch_dtype(dtype, [&](auto* tag) -> int {
+    typedef typename std::remove_pointer<decltype(tag)>::type T;
+    const int cap = 2048;      // (7 loads + 3 stores of 16 bytes per thread and tile in flight: more workgroups than the refresh kernel's 512)
+    opt_pack_conv3_batch_kernel<T><<<total_tiles < cap ? total_tiles : cap, 256, 0, s>>>(descs, map, n, total_tiles, conv3_pad_min_bytes(), p->kind, p->grad, p->state1,
+                                                                                         p->kind == MISEG_OPT_SGD_NESTEROV ? nullptr : p->state2, p->used, p->steps, p->lr,
+                                                                                         p->beta1, p->beta2, p->eps, p->weight_decay, p->momentum, p->lr_dev);
+    MISEG_LAUNCH_CHECK("opt_step_pack_conv3");
+    return MISEG_OK;
+  });
+  if (rc != MISEG_OK) return rc;
+  if (p->count_n > 0) return opt_count_launch(p->used, p->steps, p->count_n, p->params_version, pack_state, s);
+  return MISEG_OK;
 }
 
 static void wgrad_plan(int B, int D, int H, int W, int Cin, int Cout, int wbd, int* ncob, int* ncib, int* nsplit, int max_wg = 0) {

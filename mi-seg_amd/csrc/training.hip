@@ -5,13 +5,15 @@
 //   * sliding-window stitching as one gather over resident window logits                                     (lightning_monai.py:86-93,187)
 // MONAI 1.1.0 arithmetic restated from its public API (parity unpinned by any reference test).
 #include "common.h"
+#include "opt_math.h"
 #include "../../include/miseg_hip_debug.h"
 #include <math.h>
 
 namespace miseg {
 
 constexpr int LOSS_MAXC = 16;          // channels kept in registers per voxel
-constexpr int LOSS_VPB = 2048;         // voxels per workgroup (256 threads x 2 float4 groups)
+constexpr int LOSS_VPB = 1024;         // voxels per workgroup (256 threads x 1 float4 group; round 5: 2048 left 1.7 workgroups per CU - a chain of
+                                       // transcendentals per voxel with nobody to hide it: 50 / 59 us forward / backward on the 96^3 x 6 logits)
 
 template <class L> __device__ __forceinline__ int label_at(const L* lab, int64_t i) { return (int)lab[i]; }
 
@@ -132,29 +134,26 @@ __global__ void __launch_bounds__(256) seg_loss_fwd_kernel(const float* __restri
   }
 }
 
-// one workgroup: sums[b][c][k] = sum over blocks (fixed order), sums[3 B C] = total of the focal / CE term, loss scalar
-static __global__ void __launch_bounds__(256) seg_loss_finalize_kernel(const double* __restrict__ part, int nblk, LossGeom g, float nr, float dr, float ld, float lo,
-                                                                    double* __restrict__ sums, float* __restrict__ loss) {
-  const int nv = 3 * g.C + 1, tid = threadIdx.x;
-  __shared__ double sh[256];
+// one workgroup: sums[b][c][k] = sum over blocks (fixed order), sums[3 B C] = total of the focal / CE term, loss scalar.
+// One WAVE per (sample, value): a lane adds every 64th block partial, the 64 lane sums meet in a shuffle tree (round 5: the 256-thread LDS
+// tree took 8 barriers per value, 19 values per sample one after the other - 23 us for what is 7 additions per lane).
+static __global__ void __launch_bounds__(1024) seg_loss_finalize_kernel(const double* __restrict__ part, int nblk, LossGeom g, float nr, float dr, float ld, float lo,
+                                                                     double* __restrict__ sums, float* __restrict__ loss) {
+  const int nv = 3 * g.C + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
   __shared__ double other[64];
-  for (int b = 0; b < g.B; ++b) {
-    for (int v = 0; v < nv; ++v) {
-      double a = 0.0;
-      for (int k = tid; k < nblk; k += 256) a += part[((int64_t)b * nblk + k) * nv + v];
-      sh[tid] = a;
-      __syncthreads();
-      for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) sh[tid] += sh[tid + o];
-        __syncthreads();
-      }
-      if (tid == 0) {
-        if (v < 3 * g.C) sums[(int64_t)b * 3 * g.C + v] = sh[0];
-        else other[b] = sh[0];
-      }
-      __syncthreads();
+  for (int job = wave; job < g.B * nv; job += nwave) {
+    const int b = job / nv, v = job - b * nv;
+    double a = 0.0;
+    for (int k = lane; k < nblk; k += 64) a += part[((int64_t)b * nblk + k) * nv + v];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (lane == 0) {
+      if (v < 3 * g.C) sums[(int64_t)b * 3 * g.C + v] = a;
+      else other[b] = a;
     }
   }
+  __threadfence_block();
+  __syncthreads();
   if (tid == 0) {
     double tot_o = 0.0, dice = 0.0;
     for (int b = 0; b < g.B; ++b) {
@@ -305,13 +304,8 @@ static __global__ void __launch_bounds__(256) opt_step_kernel(const miseg_opt_de
   if (used && !used[pi]) return;
   if (lr_dev) lr = *lr_dev;
   const int blk = blockIdx.x - d.block0;
-  const int step = steps[pi] + 1;                    // read by every workgroup of the tensor; written back by a separate tiny launch
-  float bc1 = 1.f, bc2s = 1.f;
-  if (kind != MISEG_OPT_SGD_NESTEROV) {
-    bc1 = 1.f - powf(b1, (float)step);
-    bc2s = sqrtf(1.f - powf(b2, (float)step));
-  }
-  const float step_size = lr / bc1;
+  // (steps[pi]: read by every workgroup of the tensor; written back by a separate tiny launch)
+  const OptHyper hy = opt_hyper(kind, steps[pi] + 1, lr, b1, b2, eps, wd, mom);
   float* p = d.param;
   const float* gp = grad + d.off;
   float* m = s1 + d.off;
@@ -340,25 +334,7 @@ static __global__ void __launch_bounds__(256) opt_step_kernel(const miseg_opt_de
       }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float g = gv[k], w = pv[k];
-      if (kind == MISEG_OPT_ADAMW) {
-        w *= 1.f - lr * wd;
-      } else {
-        g += wd * w;                                  // Adam / SGD: L2 term folded into the gradient
-      }
-      if (kind == MISEG_OPT_SGD_NESTEROV) {
-        const float buf = step == 1 ? g : mom * mv[k] + g;      // torch.optim.SGD: the first momentum buffer is the gradient itself
-        mv[k] = buf;
-        w -= lr * (g + mom * buf);
-      } else {
-        mv[k] = mv[k] + (1.f - b1) * (g - mv[k]);               // torch: exp_avg.lerp_(grad, 1 - beta1)
-        vv[k] = b2 * vv[k] + (1.f - b2) * g * g;
-        const float denom = sqrtf(vv[k]) / bc2s + eps;
-        w -= step_size * (mv[k] / denom);
-      }
-      pv[k] = w;
-    }
+    for (int k = 0; k < 4; ++k) opt_update(hy, pv[k], gv[k], mv[k], vv[k]);
     if (vec && cnt == 4) {
       f32x4 tp, tm, tv;
 #pragma unroll
@@ -374,10 +350,14 @@ static __global__ void __launch_bounds__(256) opt_step_kernel(const miseg_opt_de
   }
 }
 
-static __global__ void opt_count_kernel(const int32_t* __restrict__ used, int32_t* __restrict__ steps, int n, int64_t* __restrict__ params_version) {
+static __global__ void opt_count_kernel(const int32_t* __restrict__ used, int32_t* __restrict__ steps, int n, int64_t* __restrict__ params_version,
+                                        int64_t* __restrict__ pack_state) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && (!used || used[i])) steps[i] += 1;
-  if (i == 0 && params_version) *params_version += 1;      // the parameters changed: the versioned refresh kernels re-lay-out their copies
+  if (i == 0 && params_version) {
+    *params_version += 1;      // the parameters changed: the versioned refresh kernels re-lay-out their copies
+    if (pack_state) pack_state[0] = *params_version;      // ... except the packs the fused launch in front of this one has just written (opt_math.h)
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ stitching
@@ -569,7 +549,7 @@ extern "C" int miseg_seg_loss_fwd(const miseg_seg_loss_params* p, miseg_stream_t
       seg_loss_fwd_kernel<L, LOSS_MAXC, 1><<<grid, 256, 0, s>>>(p->logits, (const L*)p->label, g, (double*)p->workspace);
     }
     MISEG_LAUNCH_CHECK("seg_loss_fwd");
-    seg_loss_finalize_kernel<<<1, 256, 0, s>>>((const double*)p->workspace, nblk, g, p->smooth_nr, p->smooth_dr, p->lambda_dice, p->lambda_other, p->sums, p->loss);
+    seg_loss_finalize_kernel<<<1, 1024, 0, s>>>((const double*)p->workspace, nblk, g, p->smooth_nr, p->smooth_dr, p->lambda_dice, p->lambda_other, p->sums, p->loss);
     MISEG_LAUNCH_CHECK("seg_loss_finalize");
     return MISEG_OK;
   });
@@ -628,9 +608,15 @@ extern "C" int miseg_opt_step(const miseg_opt_step_params* p, miseg_stream_t s_)
   const int cn = p->count_n < 0 ? p->ndesc : p->count_n;
   MISEG_REQUIRE(p->index || p->count_n < 0 || p->count_n == p->ndesc, MISEG_E_BADARG, "opt_step: count_n %d without an index table", p->count_n);
   if (cn > 0) {
-    opt_count_kernel<<<cdiv(cn, 256), 256, 0, s>>>(p->used, p->steps, cn, p->params_version);
-    MISEG_LAUNCH_CHECK("opt_count");
+    const int rc = opt_count_launch(p->used, p->steps, cn, p->params_version, nullptr, s);
+    if (rc != MISEG_OK) return rc;
   }
+  return MISEG_OK;
+}
+
+int miseg::opt_count_launch(const int32_t* used, int32_t* steps, int n, int64_t* params_version, int64_t* pack_state, hipStream_t s) {
+  opt_count_kernel<<<cdiv(n, 256), 256, 0, s>>>(used, steps, n, params_version, pack_state);
+  MISEG_LAUNCH_CHECK("opt_count");
   return MISEG_OK;
 }
 

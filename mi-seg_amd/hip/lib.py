@@ -20,7 +20,7 @@ class _S(C.Structure):
     pass
 
 
-ABI_VERSION = 8          # == MISEG_ABI_VERSION of include/miseg_hip.h; load() refuses a library that reports another
+ABI_VERSION = 9          # == MISEG_ABI_VERSION of include/miseg_hip.h; load() refuses a library that reports another
 C_NAMES = {}             # ctypes mirror -> name of the C struct it mirrors (tests/test_abi.py checks sizeof / offsetof of every field)
 
 
@@ -123,6 +123,7 @@ SegLoss = _struct("SegLoss", cname="miseg_seg_loss_params", fields=[
 DiceMetric = _struct("DiceMetric", cname="miseg_dice_metric_params", fields=[
     ("struct_size", u32), ("logits", vp), ("label", vp), ("label_dtype", i32), ("B", i32), ("C", i32), ("S", i64), ("counts", vp), ("dice", vp)])
 OptDesc = _struct("OptDesc", cname="miseg_opt_desc", fields=[("param", vp), ("off", i64), ("n", i32), ("block0", i32)])
+OptPackMap = _struct("OptPackMap", cname="miseg_opt_pack_map", fields=[("off", i64), ("param_index", i32), ("pad_", i32)])
 OptStep = _struct("OptStep", cname="miseg_opt_step_params", fields=[
     ("struct_size", u32), ("kind", i32), ("descs_dev", vp), ("ndesc", i32), ("total_blocks", i32), ("grad", vp), ("state1", vp), ("state2", vp),
     ("used", vp), ("steps", vp), ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("momentum", f32), ("lr_dev", vp), ("params_version", vp),
@@ -229,6 +230,7 @@ PROTOS = {
     "miseg_seg_loss_bwd": (i32, [C.POINTER(SegLoss), vp]),
     "miseg_dice_metric": (i32, [C.POINTER(DiceMetric), vp]),
     "miseg_opt_step": (i32, [C.POINTER(OptStep), vp]),
+    "miseg_opt_step_pack_conv3": (i32, [C.POINTER(OptStep), vp, vp, i32, i32, i32, vp, vp]),
     "miseg_stitch_windows": (i32, [C.POINTER(Stitch), vp]),
     "miseg_augment_crop": (i32, [C.POINTER(Augment), vp]),
     "miseg_resample3d": (i32, [C.POINTER(Resample3d), vp]),

@@ -28,10 +28,19 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-STAMPS = {} if os.environ.get("MISEG_STEP_STAMPS") in ("1", "2") else None      # measurement aid (bench.py prints them): name -> slot of _STAMP_BUF
+STAMPS = {} if os.environ.get("MISEG_STEP_STAMPS") in ("1", "2", "3") else None      # measurement aid (bench.py prints them): name -> slot of _STAMP_BUF
 STAMPS_FINE = os.environ.get("MISEG_STEP_STAMPS") == "1"      # "2": only the stamps at the ends of the passes (every stamp is a graph node and
                                                               # the nodes around a fork change how the executor cuts the graph into chains)
+STAMPS_BRANCH = os.environ.get("MISEG_STEP_STAMPS") == "3"   # "3": also one stamp behind every launch of the side branch's backward pass and of the
+                                                              # end-of-pass flush on either stream (name@stream#n): where the tail of the step goes
 _STAMP_BUF = None
+_FLUSHING = False
+
+
+def _stamp_launch(fn_name):
+    if STAMPS_BRANCH and (_FLUSHING or in_branch_backward()) and len(STAMPS) < 1000:
+        on = "b" if (_BRANCH_STREAM is not None and torch.cuda.current_stream() == _BRANCH_STREAM) else "m"
+        stamp(f"{fn_name.replace('miseg_', '')}@{on}#{len(STAMPS)}")
 
 
 def stamp(name, stream=None, fine=False):
@@ -41,7 +50,7 @@ def stamp(name, stream=None, fine=False):
     if STAMPS is None or (fine and not STAMPS_FINE):
         return
     if _STAMP_BUF is None:
-        _STAMP_BUF = torch.zeros(64, dtype=torch.int64, device="cuda")
+        _STAMP_BUF = torch.zeros(1024, dtype=torch.int64, device="cuda")
     slot = STAMPS.setdefault(name, len(STAMPS))
     st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
     L.check(L.load().miseg_debug_stamp(C.c_void_p(_STAMP_BUF.data_ptr() + 8 * slot), st), "debug_stamp")
@@ -109,6 +118,8 @@ def _call(fn_name, params, prof=None, prof_params=None, extra=()):
             L.check(getattr(lib, fn_name)(C.byref(params), *extra, _stream()), fn_name)
         return
     L.check(getattr(lib, fn_name)(C.byref(params), *extra, _stream()), fn_name)
+    if STAMPS_BRANCH:
+        _stamp_launch(fn_name)
 
 
 def _nb(*tensors):
@@ -693,9 +704,9 @@ def wgrad_side(*keep, kind="gemm"):
 _BRANCH_STREAM = None
 _MAIN_STREAM = None            # the stream a model's forward forked its side branch from (swin_unetr.py sets it)
 BACKGROUND_LAUNCHES = 0        # running count of launches issued in background form (bench.py reports the per-step figure)
-BACKGROUND_WORKGROUPS = 32     # cap of the branch's own background weight-gradient launch (each workgroup owns a CU).  Step against no branch,
+BACKGROUND_WORKGROUPS = int(os.environ.get("MISEG_BG_WG", "32"))     # cap of the branch's own background weight-gradient launch (each workgroup owns a CU).  Step against no branch,
                                # two boxes, before the deferral below: 256 (no cap) -0.4 %, 128 +1.0, 64 +1.4, 32 +2.0 / +2.4, 16 +2.0, 8 -3.8
-DEFERRED_WORKGROUPS = 64       # cap of the main stream's deferred weight gradients (defer_to_branch).  (own cap, this cap) on one box, no branch =
+DEFERRED_WORKGROUPS = int(os.environ.get("MISEG_DEFER_WG", "64"))       # cap of the main stream's deferred weight gradients (defer_to_branch).  (own cap, this cap) on one box, no branch =
                                # 132.6, branch alone 134.5: (24, 48) 136.9, (24, 64) 140.8, (24, 96) 139.8, (48, 64) 140.6, (64, 64) 140.7, (32, 32) 128.9
 DEFERRED_WORKGROUPS_SPLIT = 96      # the same launches inside the first half of a split step (flush_deferred_on_branch)
 GROUP_EARLY_WORKGROUPS = 0      # cap of the early (branch-stream) grouped weight-gradient launch; 0 = off
@@ -809,11 +820,13 @@ def join_branch(flush_deferred=True, queues=None, flush_main=False):
     launches of arena.end_backward, the optimiser, the end of a hipGraph capture).  queues: the arena's StepQueues whose
     deferred launches are issued here when the branch's backward never ran (nothing in it needed a gradient).
     flush_main: the main stream's own queued launches go out BEFORE the wait (they read nothing of the branch's)."""
+    global _FLUSHING
     if flush_deferred:
         for q in ([queues] if queues is not None else list(QUEUES.values())):
             if q.branch_deferred:
                 flush_branch_deferred(q)
     stamp("main_chain_end")
+    _FLUSHING = True
     if flush_main and queues is not None:
         cur = torch.cuda.current_stream() if _BRANCH_STREAM is not None else None      # (no side stream: the CPU ranks of the gloo tests)
         if queues.side is not None and _BRANCH_STREAM is not None and FLUSH_SIDE_ON_BRANCH and cur != _BRANCH_STREAM:
@@ -850,6 +863,7 @@ def join_branch(flush_deferred=True, queues=None, flush_main=False):
             stamp("branch_end", _BRANCH_STREAM)
         torch.cuda.current_stream().wait_stream(_BRANCH_STREAM)
         stamp("joined")
+    _FLUSHING = False
 
 
 def in_branch_backward():
@@ -952,6 +966,7 @@ def _flush_tn_reduces(q):
         for j, (ws, out, ldc, M, N, splits, regroup) in enumerate(chunk):
             descs[j] = L.TnReduceDesc(_ptr(ws), _ptr(out), ldc, M, N, splits, 0, regroup, 0)
         L.check(lib.miseg_gemm_tn_reduce_batch(descs, len(chunk), _stream()), "gemm_tn_reduce_batch")
+        _stamp_launch("gemm_tn_reduce_batch")
     q.clear()
 
 
@@ -977,6 +992,7 @@ def _flush_gemm_tn(q, writes=None):
                 ldb, _, N = rows(b)
                 descs[j] = L.GemmTnDesc(_ptr(a), lda, _ptr(b), ldb, _ptr(out), N, M, N, K, 1 if (zeroed and once.get(out.data_ptr(), 2) == 1) else 0, regroup, 0)
             L.check(lib.miseg_gemm_tn_group(descs, len(chunk), _dt(chunk[0][0]), _stream()), "gemm_tn_group")
+            _stamp_launch("gemm_tn_group")
     q.clear()
 
 
@@ -997,6 +1013,7 @@ def _flush_colsums(q):
                 ld, n, Cc = rows(t)
                 descs[j] = L.ColsumDesc(_ptr(t), ld, n, _ptr(o), Cc, 0)
             L.check(lib.miseg_colsum_batch(descs, len(chunk), _dt(chunk[0][0]), _stream()), "colsum_batch")
+            _stamp_launch("colsum_batch")
     q.clear()
 
 
@@ -1178,6 +1195,7 @@ def _flush_conv_wgrads(q, background=0, keep=False):
             fl = sum(2.0 * 27 * it[0].shape[-1] * it[1].shape[-1] * (it[0].numel() // it[0].shape[-1]) for it in chunk)
             with _ProfRegion("conv3_wgrad_group_kernel" + (" (background)" if background else ""), fl):
                 L.check(lib.miseg_conv3_wgrad_group(descs, len(chunk), _ptr(ws), _stream()), "conv3_wgrad_group")
+            _stamp_launch("conv3_wgrad_group")
             if background or keep:
                 _WGRAD_KEEP.append(ws)
                 _WGRAD_KEEP.extend(t for it in chunk for t in it[:2])

@@ -414,6 +414,7 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         if self.early_optimizer:      # which parameters the warm-up steps wrote inline (none: the one-launch optimiser step)
             self.opt.split_early(getattr(self.arena, "inline_final_params", []))
+        self.opt.prepare()            # device tables of the fused conv-weight launch: uploaded here, not under capture
         for p in self.arena.params:
             p.grad = None
         g = _Graph()

@@ -7,6 +7,7 @@ runtime/arena.py::ParamArena (set by the weight-gradient kernels' autograd nodes
 device and the kernel leaves unused tensors alone, with a per-parameter step count for Adam's bias correction.  The moments live in two
 flat fp32 buffers laid out like the arena."""
 import ctypes as C
+import os
 
 import torch
 
@@ -14,6 +15,7 @@ from ..hip import lib as L
 from ..hip import ops
 
 KINDS = {"adamw": L.OPT_ADAMW, "adam": L.OPT_ADAM, "sgd": L.OPT_SGD_NESTEROV}
+FUSE_CONV_PACKS = os.environ.get("MISEG_NO_OPT_PACK") is None      # A/B switch of round 5 (ArenaOptimizer._fused_tables)
 
 
 class ArenaOptimizer:
@@ -43,6 +45,60 @@ class ArenaOptimizer:
         self._early = None          # (table, index, blocks, n) of the parameters updated by step_early(), and of the rest
         self._late = None
         self._early_done = False
+
+    def _subset_table(self, sel):
+        """(descriptor table, index, blocks, count) of the arena parameters `sel` (a list of indices) on the device"""
+        dev = self.state1.device
+        descs, index, block0 = (L.OptDesc * len(sel))(), [], 0
+        for j, i in enumerate(sel):
+            p = self.arena.params[i]
+            descs[j] = L.OptDesc(p.data_ptr(), self.arena._offs[i], p.numel(), block0)
+            block0 += (p.numel() + L.OPT_BLOCK - 1) // L.OPT_BLOCK
+            index.append(i)
+        return (torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev), torch.tensor(index, dtype=torch.int32, device=dev), block0, len(sel))
+
+    def _fused_tables(self):
+        """Round 5: the 3x3x3 conv weights (55 of C-Swin-UNETR's 62 M parameters) are updated by the launch that also writes their packs
+        (miseg_opt_step_pack_conv3), everything else by the element-wise launch in front of it.  Returns (rest table | None, map, pack table) once
+        the arena holds a current conv-pack table whose weights are all trainable arena parameters, else None (the plain one-launch step)."""
+        a = self.arena
+        if not FUSE_CONV_PACKS or self._early is not None or not a.flat.is_cuda or a._ptable is None or a._pdirty or a.dtype not in (torch.float32, torch.bfloat16):
+            return None
+        key = a._ptable[0].data_ptr()
+        cur = self.__dict__.get("_fused")
+        if cur is not None and cur[0] == key:
+            return cur[1]
+        if torch.cuda.is_current_stream_capturing():
+            return None                                  # (tables are uploaded eagerly: the warm-up steps in front of a capture build them)
+        idx_of = {id(p): i for i, p in enumerate(a.params)}
+        maps, conv = (L.OptPackMap * len(a._packs))(), set()
+        for j, ent in enumerate(a._packs.values()):
+            i = idx_of.get(id(ent[0]))
+            if i is None or not ent[4]:                  # a frozen weight has packs but no arena slot: the plain step handles such models
+                self._fused = (key, None)
+                return None
+            maps[j] = L.OptPackMap(a._offs[i], i, 0)
+            conv.add(i)
+        rest = [i for i in range(len(a.params)) if i not in conv]
+        tabs = (self._subset_table(rest) if rest else None, torch.frombuffer(bytearray(bytes(maps)), dtype=torch.uint8).to(self.state1.device), a._ptable)
+        self.__dict__.setdefault("_retired", []).append(cur)      # a captured hipGraph may still point at the old tables
+        self._fused = (key, tabs)
+        return tabs
+
+    def prepare(self):
+        """build (and upload) the launch tables now - call before capturing a step that contains `step()` into a hipGraph"""
+        self._fused_tables()
+
+    def _launch_pack(self, tabs, lr, count_n):
+        _, maps, (ptab, n, tiles) = tabs
+        a = self.arena
+        p = L.OptStep(C.sizeof(L.OptStep), KINDS[self.kind], None, 0, 0, a.flat.data_ptr(),
+                      self.state1.data_ptr(), self.state2.data_ptr() if self.state2 is not None else None, self.used.data_ptr(), self.steps.data_ptr(),
+                      self.lr if lr is None else float(lr), self.betas[0], self.betas[1], self.eps, self.weight_decay, self.momentum,
+                      self.lr_dev.data_ptr() if self.lr_dev is not None else None, a.params_version_ptr(), None, count_n)
+        state = a._ver(3)[1]
+        L.check(L.load().miseg_opt_step_pack_conv3(C.byref(p), C.c_void_p(ptab.data_ptr()), C.c_void_p(maps.data_ptr()), n, tiles,
+                                                   L.F32 if a.dtype == torch.float32 else L.BF16, state, ops._stream()), "opt_step_pack_conv3")
 
     def split_early(self, early_params):
         """Two launches per step: `early_params` (parameters whose gradients are final before the end of the backward pass: what
@@ -110,9 +166,14 @@ class ArenaOptimizer:
                 self.used.copy_(self.arena.used_dev, non_blocking=True)
             else:
                 self.set_used_from_arena()
+        fused = self._fused_tables()
         if self._early_done:          # the early launch of this step is out: the rest, then the step counts of ALL parameters and the version bump
             self._launch(self._late, lr, len(self.arena.params))
             self._early_done = False
+        elif fused is not None:       # everything but the 3x3x3 conv weights, then those together with their packs (which closes the step)
+            if fused[0] is not None:
+                self._launch(fused[0], lr, 0)
+            self._launch_pack(fused, lr, len(self.arena.params))
         else:
             self._launch((self._table, None, self._blocks, len(self.arena.params)), lr, -1)
         # the compute-dtype copies of the parameters are stale now: the kernel bumped the arena's device-side parameter version (the refresh

@@ -146,6 +146,62 @@ def test_arena_optimizer_matches_torch(kind, split):
         arena.detach()
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("kind", ["adamw", "sgd"])
+def test_arena_optimizer_updates_conv_weights_together_with_their_packs(kind, dtype):
+    """round 5 (miseg_opt_step_pack_conv3): the 3x3x3 conv weights are updated by the launch that also writes their forward / data-gradient
+    packs; everything else by the element-wise launch.  Against torch.optim on the same gradients; the packs the fused launch leaves behind
+    must be bit-identical to what the refresh launch makes of the updated weights, the refresh of the next step must find them current, and
+    a weight without a gradient keeps weights, state and packs."""
+    from mi_seg_amd.runtime.arena import ParamArena
+    from mi_seg_amd.training.optim import ArenaOptimizer
+    g = torch.Generator().manual_seed(5)
+    shapes = [(48, 48, 3, 3, 3), (7,), (96, 48, 3, 3, 3), (40, 24, 3, 3, 3), (96, 33), (16, 16, 3, 3, 3), (130, 64, 3, 3, 3)]
+    conv = [i for i, s_ in enumerate(shapes) if len(s_) == 5]
+    params = [torch.nn.Parameter(torch.randn(*s_, generator=g).to(DEV)) for s_ in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in params]
+    arena = ParamArena(params, dtype)
+    try:
+        for i in conv:
+            assert arena.conv_packs(params[i]) is None      # first request: registered
+        arena.begin_step()                                   # builds the table, fills the packs
+        kw = dict(lr=3e-2, weight_decay=1e-2)
+        if kind == "sgd":
+            topt, opt = torch.optim.SGD(ref, momentum=0.9, nesterov=True, **kw), ArenaOptimizer(arena, "sgd", momentum=0.9, **kw)
+        else:
+            topt, opt = torch.optim.AdamW(ref, **kw), ArenaOptimizer(arena, kind, **kw)
+        raw = lambda t: t.view(torch.int16 if t.dtype == torch.bfloat16 else torch.int32)
+        for step in range(4):
+            skip = {2, 4} if step == 1 else ({0} if step == 2 else set())
+            for i, (p, r) in enumerate(zip(params, ref)):
+                gr = torch.randn(p.shape, generator=g).to(DEV)
+                if i in skip:
+                    p._miseg_used, r.grad = False, None
+                    arena.views[i].zero_()
+                else:
+                    p._miseg_used, r.grad = True, gr.clone()
+                    arena.views[i].copy_(gr)
+            before = {i: (params[i].detach().clone(), raw(arena._packs[id(params[i])][1]).clone()) for i in conv if i in skip}
+            topt.step()
+            opt.step()
+            assert opt.__dict__.get("_fused") is not None and opt._fused[1] is not None, "the fused launch must have run"
+            for i, (p, r) in enumerate(zip(params, ref)):
+                assert rel_err(p.detach(), r.detach()) < 2e-6, (kind, step, i)
+            for i, (w0, pk0) in before.items():
+                assert torch.equal(params[i].detach(), w0) and torch.equal(raw(arena._packs[id(params[i])][1]), pk0)
+            v = arena.versions.tolist()
+            assert v[3] == v[0] and v[1] != v[0], "pack table current, cast table stale"
+            got = {i: (raw(arena._packs[id(params[i])][1]).clone(), raw(arena._packs[id(params[i])][2]).clone()) for i in conv}
+            arena.versions[3] = -1                           # force the refresh launch: the same buffers, rewritten from the same weights
+            arena.begin_step()
+            for i in conv:
+                ent = arena._packs[id(params[i])]
+                assert torch.equal(raw(ent[1]), got[i][0]) and torch.equal(raw(ent[2]), got[i][1]), (kind, step, i)
+        assert opt.steps.tolist() == [3, 4, 3, 4, 3, 4, 4]
+    finally:
+        arena.detach()
+
+
 def _loop_stitch(win, starts, roi, size):
     C = win.shape[1]
     out = torch.zeros((C,) + size, dtype=torch.float32, device=win.device)
