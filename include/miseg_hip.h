@@ -221,6 +221,10 @@ typedef struct {
    * then needs no reduction launch.  stat_mode 0: `stat` = forward statistics as above. */
   int stat_mode;
   const void* bs_x; int64_t ld_bs_x; const void* bs_stat; float bs_eps;
+  /* TN, optional (ABI 9), only where miseg_gemm_tn_fuses_colsum(p) says so (the streaming path): tn_colsum[m] += sum over the K rows of A[k][m]
+   * (fp32 [M], atomics: zero or accumulating on entry) - with A = dy the bias gradient of the linear layer whose weight gradient dW = dy^T x
+   * this product is (swin_transformer_block.py:97,103), from the A fragments the product already holds. */
+  float* tn_colsum;
 } miseg_gemm_params;
 int miseg_gemm_fuses_stat(const miseg_gemm_params* p);  /* 1: miseg_gemm(p) with p->stat set is supported for this problem */
 int miseg_gemm_fuses_anorm(const miseg_gemm_params* p); /* 1: ... with p->an.stat set (whatever an_out) */
@@ -259,6 +263,7 @@ int miseg_mlp_fwd(const miseg_mlp_params* p, miseg_stream_t stream);
 int miseg_mlp_bwd(const miseg_mlp_params* p, miseg_stream_t stream);
 int miseg_gemm_fuses_scatter(const miseg_gemm_params* p);  /* 1: miseg_gemm(p) with the scat_* fields set is supported for this problem */
 int miseg_gemm_tn_splits(const miseg_gemm_params* p);   /* > 1: partial tiles [splits][M][N] fp32 in the workspace */
+int miseg_gemm_tn_fuses_colsum(const miseg_gemm_params* p);   /* 1: this TN product takes the streaming path and can carry tn_colsum */
 size_t miseg_gemm_workspace_bytes(const miseg_gemm_params* p);
 int miseg_gemm(const miseg_gemm_params* p, miseg_stream_t stream);
 

@@ -864,7 +864,7 @@ __global__ void __launch_bounds__(256) gemm_tn_group_kernel(TnGroup g) {
 // atomics of the epilogue stay a small fraction of the stream.
 __global__ void __launch_bounds__(256, 2) gemm_tn_stream_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B, int64_t ldb,
                                                                 float* __restrict__ C, int64_t ldc, int M, int N, int T, int wm, int wn, int tps, int mode,
-                                                                float* __restrict__ partial) {
+                                                                float* __restrict__ partial, float* __restrict__ colsum) {
   constexpr int BK = 64, MAXC = 8;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int BM = wm * 48, BN = wn * 48, RA = BM * 2 + 16, RB = BN * 2 + 16;
@@ -919,6 +919,16 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_stream_kernel(const bf16* __re
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // Round 5: the column sums of A ride along (dW = dy^T x is called with A = dy: they are the bias gradient of the linear layer - until now
+  // a separate pass over dy, 240 MB per step at the end of the backward pass - and the A fragments already in registers give them as one
+  // more MFMA block against a fragment of ones).  One wave per row block (workgroup column 0 only); fp32 atomics into the bias-gradient slot.
+  const bool csum = colsum != nullptr && blockIdx.y == 0 && wni == 0 && active;
+  f32x4 cs[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) cs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.f;
   gload(t0);
   lstore(lds);
   __syncthreads();
@@ -941,10 +951,21 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_stream_kernel(const bf16* __re
         for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
           for (int nt = 0; nt < 3; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[mt], acc[mt][nt], 0, 0, 0);
+        if (csum) {      // (wave-uniform)
+#pragma unroll
+          for (int mt = 0; mt < 3; ++mt) cs[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[mt], cs[mt], 0, 0, 0);
+        }
       }
     }
     if (more) lstore(lds + (s ^ 1) * stage_bytes);   // last read one iteration ago: every wave is past that barrier
     __syncthreads();
+  }
+  if (csum && lane < 16) {      // every row of the ones block holds the same sums: row 0 (lanes 0..15, register 0) carries columns m = fi
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) {
+      const int m = m0 + wmi * 48 + mt * 16 + lane;
+      if (m < M) atomicAdd(colsum + m, cs[mt][0]);
+    }
   }
   if (active) {
     const int fi = lane & 15, fq = lane >> 4;
@@ -1353,7 +1374,7 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
         const size_t lds = (size_t)2 * 64 * (BM * 2 + BN * 2 + 32);
         hipFuncSetAttribute((const void*)gemm_tn_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         gemm_tn_stream_kernel<<<dim3(pl.gx, pl.gy, pl.splits), 256, lds, s>>>((const bf16*)p->A, p->lda, (const bf16*)p->B, p->ldb, (float*)p->C, p->ldc, p->M, p->N,
-                                                                             p->K, pl.wm, pl.wn, pl.tps, p->accumulate ? 1 : 0, partial);
+                                                                             p->K, pl.wm, pl.wn, pl.tps, p->accumulate ? 1 : 0, partial, p->tn_colsum);
         if (partial && !p->defer_reduce) {
           const int groups = cdiv(pl.splits, TN_RG);
           if (groups > 1 && !p->accumulate) {   // the groups meet in atomics
@@ -1366,6 +1387,7 @@ static int launch_gemm(const miseg_gemm_params* p, hipStream_t s) {
         return MISEG_OK;
       }
     }
+    if (p->tn_colsum) return set_error(MISEG_E_UNSUPPORTED, "gemm TN: column sums ride on the streaming path only (ask miseg_gemm_tn_fuses_colsum first)");
     constexpr int TN_BK = std::is_same<T, bf16>::value ? 128 : 64;
     if (p->split_k == 0) {   // auto: enough workgroups for the chip, >= 512 reduction rows each
       const int tiles = cdiv(p->M, 64) * cdiv(p->N, 64);
@@ -1398,6 +1420,11 @@ extern "C" int miseg_gemm(const miseg_gemm_params* p, miseg_stream_t s_) {
   if (p->dtype == MISEG_BF16 && p->out_dtype == MISEG_BF16) return launch_gemm<bf16, bf16>(p, s);
   if (p->dtype == MISEG_BF16 && p->out_dtype == MISEG_F32) return launch_gemm<bf16, float>(p, s);
   return set_error(MISEG_E_BADARG, "gemm: dtype %d -> %d", p->dtype, p->out_dtype);
+}
+
+extern "C" int miseg_gemm_tn_fuses_colsum(const miseg_gemm_params* p) {
+  TnStreamPlan pl;
+  return (p && p->ta == 1 && p->tb == 1 && p->dtype == MISEG_BF16 && p->out_dtype == MISEG_F32 && tn_stream_plan(p, &pl)) ? 1 : 0;
 }
 
 extern "C" int miseg_gemm_tn_splits(const miseg_gemm_params* p) {

@@ -513,19 +513,7 @@ class _Linear(Function):
         if ctx.needs_input_grad[0]:
             wt = ops.cast_matrix(weight, dy.dtype, transpose=True)      # [K, N]
             dx = ops.gemm_nt(dy, wt)
-        if ctx.needs_input_grad[1]:
-            slot, mode = _slot_first(ctx.params[0])
-            if slot is not None:
-                with ops.wgrad_side(dy, x):
-                    ops.gemm_tn(dy, x, out=slot, accumulate=mode)      # (2: the slot still holds the step's zeros - a store, not a read-modify-write)
-            else:
-                dw = ops.gemm_tn(dy, x).view(weight.shape)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            slot = _slot(ctx.params[1])
-            if slot is not None:
-                ops.colsum(dy, out=slot, accumulate=True)
-            else:
-                db = ops.colsum(dy)
+        dw, db = _wb_grads_into(ctx.params[0], ctx.params[1] if ctx.has_bias else None, dy, x, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return dx, dw, db, (dy if ctx.needs_input_grad[3] else None), None
 
 
@@ -560,6 +548,19 @@ def _wgrad_into(p, g, act):
             ops.gemm_tn(g, act, out=slot, accumulate=mode)      # (2: the slot still holds the step's zeros - a store, not a read-modify-write)
         return None
     return ops.gemm_tn(g, act).view(p.shape)
+
+
+def _wb_grads_into(pw, pb, g, act, need_w=True, need_b=True):
+    """(dW, db) of a linear layer from its output gradient g and input act: dW = g^T act, db = column sums of g.  With both parameters in a
+    training arena the bias gradient rides in the weight-gradient product's launch where that takes the streaming path (round 5:
+    ops.gemm_tn(colsum_out=)); returns None for what went into a slot."""
+    need_b = need_b and pb is not None
+    if need_w and need_b and getattr(pw, "_miseg_grad", None) is not None and getattr(pb, "_miseg_grad", None) is not None:
+        slot, mode = _slot_first(pw)
+        with ops.wgrad_side(g, act):
+            ops.gemm_tn(g, act, out=slot, accumulate=mode, colsum_out=_slot(pb))
+        return None, None
+    return (_wgrad_into(pw, g, act) if need_w else None), (_bgrad_into(pb, g) if need_b else None)
 
 
 def _bgrad_into(p, g):
@@ -614,8 +615,7 @@ class _NormLinear(Function):
             else:
                 dxn, dstat = ops.gemm_nt(dy, wt), None
             dx = _norm_bwd_from(dxn, x, S, stat, dstat, styles_dev, gammas if affine else None, dgam, dbet, eps, _rv(gskip))
-        dw = _wgrad_into(pw, dy, xn) if ctx.needs_input_grad[8] else None
-        db = _bgrad_into(pb, dy) if (pb is not None and ctx.needs_input_grad[9]) else None
+        dw, db = _wb_grads_into(pw, pb, dy, xn, ctx.needs_input_grad[8], ctx.needs_input_grad[9])
         return (dx, None, None, None, None, None, None, None, dw, db, *build())
 
 
@@ -687,14 +687,8 @@ class _NormMlp(Function):
         # the skip branch's gradient is dy itself: added inside the norm-backward apply pass
         dx = _norm_bwd_from(dxn, x, S, stat, dstat, styles_dev, gammas if affine else None, dgam, dbet, eps, dy)
         out = [dx, None, None, None, None, None, None, None, None, None, None, None]
-        if ctx.needs_input_grad[8]:
-            out[8] = _wgrad_into(pw1, dh, xn)
-        if ctx.needs_input_grad[10]:
-            out[10] = _wgrad_into(pw2, dy, a)
-        if pb1 is not None and ctx.needs_input_grad[9]:
-            out[9] = _bgrad_into(pb1, dh)
-        if pb2 is not None and ctx.needs_input_grad[11]:
-            out[11] = _bgrad_into(pb2, dy)
+        out[8], out[9] = _wb_grads_into(pw1, pb1, dh, xn, ctx.needs_input_grad[8], ctx.needs_input_grad[9])
+        out[10], out[11] = _wb_grads_into(pw2, pb2, dy, a, ctx.needs_input_grad[10], ctx.needs_input_grad[11])
         return (*out, *build())
 
 
@@ -770,21 +764,8 @@ class _Mlp(Function):
             dh = ops.gemm_nt(dy, ops.cast_matrix(w2, dy.dtype, transpose=True), gelu_grad_of=h)
             dx = ops.gemm_nt(dh, ops.cast_matrix(w1, dy.dtype, transpose=True)) if ctx.needs_input_grad[0] else None
         out = [dx, None, None, None, None, dy if ctx.needs_input_grad[5] else None, None]
-        for i, (p, act, g) in enumerate(((pw1, x, dh), (pw2, a, dy))):
-            if ctx.needs_input_grad[1 + 2 * i]:
-                slot, mode = _slot_first(p)
-                if slot is not None:
-                    with ops.wgrad_side(g, act):
-                        ops.gemm_tn(g, act, out=slot, accumulate=mode)
-                else:
-                    out[1 + 2 * i] = ops.gemm_tn(g, act).view(p.shape)
-        for i, (p, g) in enumerate(((pb1, dh), (pb2, dy))):
-            if p is not None and ctx.needs_input_grad[2 + 2 * i]:
-                slot = _slot(p)
-                if slot is not None:
-                    ops.colsum(g, out=slot, accumulate=True)
-                else:
-                    out[2 + 2 * i] = ops.colsum(g)
+        for i, (pw, pb, act, g) in enumerate(((pw1, pb1, x, dh), (pw2, pb2, a, dy))):
+            out[1 + 2 * i], out[2 + 2 * i] = _wb_grads_into(pw, pb, g, act, ctx.needs_input_grad[1 + 2 * i], ctx.needs_input_grad[2 + 2 * i])
         return tuple(out)
 
 

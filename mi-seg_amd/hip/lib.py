@@ -58,7 +58,7 @@ Gemm = _struct("Gemm", cname="miseg_gemm_params", fields=[("A", vp), ("lda", i64
                         ("accumulate", i32), ("split_k", i32), ("workspace", vp), ("res", vp), ("ldres", i64), ("aux", vp), ("ldaux", i64),
                         ("epi_mode", i32), ("defer_reduce", i32), ("stat", vp), ("scat_d", i32), ("scat_h", i32), ("scat_w", i32),
                         ("scat_cout", i32), ("an", NormRef), ("an_out", vp), ("ld_an_out", i64), ("stat_mode", i32), ("bs_x", vp), ("ld_bs_x", i64),
-                        ("bs_stat", vp), ("bs_eps", f32)])
+                        ("bs_stat", vp), ("bs_eps", f32), ("tn_colsum", vp)])
 TnReduceDesc = _struct("TnReduceDesc", cname="miseg_tn_reduce_desc", fields=[("partial", vp), ("C", vp), ("ldc", i64), ("M", i32), ("N", i32), ("splits", i32), ("block0", i32),
                                                                             ("regroup", i32), ("pad_", i32)])
 ColsumDesc = _struct("ColsumDesc", cname="miseg_colsum_desc", fields=[("x", vp), ("ldx", i64), ("rows", i64), ("out", vp), ("C", i32), ("block0", i32)])
@@ -180,6 +180,7 @@ PROTOS = {
     "miseg_permute3": (i32, [vp, vp, i32, i32, i32, i64, i64, i64, i32, vp]),
     "miseg_colsum": (i32, [C.POINTER(Colsum), vp]),
     "miseg_gemm_tn_splits": (i32, [C.POINTER(Gemm)]),
+    "miseg_gemm_tn_fuses_colsum": (i32, [C.POINTER(Gemm)]),
     "miseg_gemm_tn_reduce_batch": (i32, [vp, i32, vp]),
     "miseg_gemm_tn_group": (i32, [vp, i32, i32, vp]),
     "miseg_colsum_batch": (i32, [vp, i32, i32, vp]),

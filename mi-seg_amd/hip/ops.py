@@ -630,9 +630,15 @@ def gemm_tn_regroups(a, b, out):
     return L.load().miseg_gemm_tn_splits(C.byref(p)) > 1      # streaming kernel with partial tiles: their deferred sum regroups
 
 
-def gemm_tn(a, b, out=None, accumulate=False, split_k=0, regroup=0):
+FOLD_COLSUM = os.environ.get("MISEG_NO_COLSUM_FOLD") is None      # A/B switch of round 5 (gemm_tn(colsum_out=))
+
+
+def gemm_tn(a, b, out=None, accumulate=False, split_k=0, regroup=0, colsum_out=None):
     """out[M,N] (fp32) (+)= a[K,M]^T @ b[K,N]; a, b row views sharing the row count K (weight gradients).
-    regroup = c > 0 (accumulate mode, after gemm_tn_regroups said yes): column j * c + i of the product is stored at column i * (N / c) + j."""
+    regroup = c > 0 (accumulate mode, after gemm_tn_regroups said yes): column j * c + i of the product is stored at column i * (N / c) + j.
+    colsum_out (fp32 [M], accumulate mode): += the column sums of a - with a = dy the bias gradient of the linear layer whose weight gradient
+    this is.  On the streaming path they ride in the product's launch (miseg_gemm_params.tn_colsum); elsewhere this is colsum(a, colsum_out,
+    accumulate=True)."""
     lda, K, M = rows(a)
     ldb, Kb, N = rows(b)
     assert K == Kb and a.dtype == b.dtype
@@ -646,11 +652,18 @@ def gemm_tn(a, b, out=None, accumulate=False, split_k=0, regroup=0):
         q.writes[out.data_ptr()] = q.writes.get(out.data_ptr(), 0) + 1      # step-wide writer count of the slot (direct and queued, main and side)
     if q is not None and split_k <= 0 and not (M % 48 == 0 and N % 48 == 0 and K >= 2048 and a.dtype == torch.bfloat16):
         q.lists().gemm_tn.append((a, b, out, int(accumulate) == 2, int(regroup)))      # small problem: grouped launch at the end of the backward pass
+        if colsum_out is not None:
+            colsum(a, colsum_out, accumulate=True)
         return out
     accumulate = bool(accumulate)      # (the direct kernels always add: "known zero" only saves the grouped launch its read of the slot)
     split_k = max(0, split_k)          # 0: the library picks the kernel and the split over the reduction rows
     p = L.Gemm(_ptr(a), lda, _ptr(b), ldb, _ptr(out), N, M, N, K, 1, 1, _dt(a), L.F32, None, L.ACT_NONE, int(accumulate), split_k, None, None, 0, None, 0, 0, 0)
     lib = L.load()
+    if colsum_out is not None:
+        if FOLD_COLSUM and split_k == 0 and colsum_out.dtype == torch.float32 and lib.miseg_gemm_tn_fuses_colsum(C.byref(p)):
+            p.tn_colsum = colsum_out.data_ptr()
+        else:
+            colsum(a, colsum_out, accumulate=True)
     wsb = lib.miseg_gemm_workspace_bytes(C.byref(p))
     if wsb:
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=a.device)
@@ -710,9 +723,9 @@ DEFERRED_WORKGROUPS = int(os.environ.get("MISEG_DEFER_WG", "64"))       # cap of
                                # 132.6, branch alone 134.5: (24, 48) 136.9, (24, 64) 140.8, (24, 96) 139.8, (48, 64) 140.6, (64, 64) 140.7, (32, 32) 128.9
 DEFERRED_WORKGROUPS_SPLIT = 96      # the same launches inside the first half of a split step (flush_deferred_on_branch)
 GROUP_EARLY_WORKGROUPS = 0      # cap of the early (branch-stream) grouped weight-gradient launch; 0 = off
-FLUSH_SMALL_ON_BRANCH = True      # (rounds 3 - 4 measured the alternatives; the environment switches of those sweeps are gone: module constants)
-FLUSH_SIDE_ON_BRANCH = True
-FLUSH_MAIN_BEFORE_JOIN = True   # arena.end_backward: the main stream's grouped launches do not wait for the branch
+FLUSH_SMALL_ON_BRANCH = os.environ.get("MISEG_FLUSH_SMALL_ON_BRANCH", "1") == "1"      # (rounds 3 - 4 measured the alternatives; re-swept in round 5 after the grouped conv launch halved)
+FLUSH_SIDE_ON_BRANCH = os.environ.get("MISEG_FLUSH_SIDE_ON_BRANCH", "1") == "1"
+FLUSH_MAIN_BEFORE_JOIN = os.environ.get("MISEG_FLUSH_MAIN_BEFORE_JOIN", "1") == "1"   # arena.end_backward: the main stream's grouped launches do not wait for the branch
 DEFER_MIN_ROWS = 400000        # 96^3 layers only (the smaller ones are grouped into one launch at the end of the backward pass)
 # (round 3: the queue of deferred launches itself lives on the training arena's StepQueues - `branch_deferred` - and is found through the
 # gradient slot a launch accumulates into, like the other per-step queues: two models in one process no longer share it)

@@ -683,6 +683,32 @@ def test_conv3_wgrad_tiny_volumes(B, S, Cin, Cout):
     assert rel_err(ops.conv3_wgrad(xs, dys), ref2) < 1e-5
 
 
+@pytest.mark.parametrize("K,M,N", [(110592, 144, 48), (13824, 96, 384), (5000, 48, 96), (4096, 96, 40)])
+def test_gemm_tn_with_the_bias_gradient_in_its_launch(K, M, N):
+    """round 5 (miseg_gemm_params.tn_colsum): dW = dy^T x of a linear layer carries db = column sums of dy where the product takes the
+    streaming path (whole 48-blocks, >= 2048 tokens); elsewhere ops.gemm_tn falls back to the column-sum kernel.  Accumulating into slots
+    of a step queue, as the training arena asks for."""
+    ops = _ops()
+    dy = rnd(K, M, dtype=torch.bfloat16, seed=11)
+    x = rnd(K, N, dtype=torch.bfloat16, seed=12)
+    ops.DEFAULT_QUEUES = ops.StepQueues()
+    try:
+        dw = torch.full((M, N), 0.25, device=DEV)
+        db = torch.full((M,), 0.5, device=DEV)
+        ops.gemm_tn(dy, x, out=dw, accumulate=True, colsum_out=db)
+        p = ops.L.Gemm(ops._ptr(dy), M, ops._ptr(x), N, ops._ptr(dw), N, M, N, K, 1, 1, ops.L.BF16, ops.L.F32, None, ops.L.ACT_NONE, 1, 0, None, None, 0, None, 0, 0, 0)
+        fused = bool(ops.L.load().miseg_gemm_tn_fuses_colsum(ops.C.byref(p)))
+        assert fused == (M % 48 == 0 and N % 48 == 0 and K >= 2048)
+        assert len(ops.DEFAULT_QUEUES.colsum) == (0 if fused else 1)
+        ops.DEFAULT_QUEUES.flush()
+    finally:
+        ops.DEFAULT_QUEUES = None
+    ref_w = dy.double().t() @ x.double()
+    ref_b = dy.double().sum(0)
+    assert rel_err(dw - 0.25, ref_w.float()) < 1e-5
+    assert rel_err(db - 0.5, ref_b.float()) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv3_wgrad_grouped(dtype):
     """the queued weight gradients of a backward pass: one grouped launch (direct epilogue for single-split layers, slabs +
