@@ -323,11 +323,18 @@ typedef struct {
   /* ABI 5: 1 = when the launch splits its reduction (miseg_conv3_fwd_splits > 1) it stops after the partial slabs in `workspace`
    * ([splits][B*D*H*W][Cout] fp32): the caller's next launch sums them (miseg_instnorm_fwd_slabs) - y and stat are NOT written.  No `res`. */
   int32_t defer_slabs;
+  /* ABI 9, only where miseg_conv3_fuses_shortcut(...) says so (bf16, 96-byte chunks, unsplit launch): y += sc_x * sc_w^T, a 1x1x1 term -
+   * the data-gradient pass of a residual block's first convolution takes the gradient of the block's 1x1x1 shortcut convolution
+   * along (dynunet_block.py:87-97,100-126: dx = dgrad3x3(g1) + g3 W3) instead of reading a [voxels][Cout] tensor that a GEMM wrote.
+   * sc_x: [B][D][H][W][sc_C] rows (ld_sc_x), sc_C a multiple of 48; sc_w: [Cout][sc_C] in `dtype` (W3 transposed), contiguous. */
+  const void* sc_x; int64_t ld_sc_x; const void* sc_w; int32_t sc_C;
 } miseg_conv3_params;
 /* small grids split the reduction over workgroups and need an fp32 staging buffer of the output */
 size_t miseg_conv3_fwd_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int dtype);
 /* number of partial slabs the launch leaves in `workspace` (1 = no split: y is written directly) */
 int miseg_conv3_fwd_splits(int B, int D, int H, int W, int Cin, int Cout, int dtype);
+/* 1 when miseg_conv3_fwd with these shapes can take a 1x1x1 shortcut term of sc_C channels along (miseg_conv3_params.sc_x) */
+int miseg_conv3_fuses_shortcut(int B, int D, int H, int W, int Cin, int Cout, int sc_C, int dtype);
 int miseg_conv3_fwd(const miseg_conv3_params* p, miseg_stream_t stream);
 
 /* w: fp32 torch layout [Cout][Cin][3][3][3].  fwd_pack feeds miseg_conv3_fwd on x, bwd_pack (taps mirrored, channels swapped) feeds it

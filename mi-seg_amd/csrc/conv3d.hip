@@ -213,7 +213,8 @@ template <class T, int NT, int WD = 1, bool EPI = false, int GPT = 6>
 __global__ void __launch_bounds__(256, GPT == 6 ? 2 : GPT == 4 ? (NT == 1 ? 3 : 2) : (NT == 1 ? 4 : 3)) conv3_fwd96_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, const T* __restrict__ wpk,
                                                              ConvGeom g, int Cin, int CinP, int Cout, int CoP, bool vec_x, bool vec_y,
                                                              float* __restrict__ scratch, int chunks_per_split, const T* __restrict__ res, int64_t ldres,
-                                                             double* __restrict__ stat, int ny) {
+                                                             double* __restrict__ stat, int ny, const T* __restrict__ scx = nullptr, int64_t ldscx = 0,
+                                                             const T* __restrict__ scw = nullptr, int Csc = 0) {
   typedef typename Vec16<T>::type VT;
   constexpr int KPC = MmaC<T>::KPC;
   constexpr int CHUNK = GPT * KPC, NPH = fwd96_phases(GPT);
@@ -432,6 +433,91 @@ __global__ void __launch_bounds__(256, GPT == 6 ? 2 : GPT == 4 ? (NT == 1 ? 3 : 
 #pragma unroll
     for (int phase = 0; phase < NPH; ++phase) run_phase(phase, phase % WD, (phase + 1) % WD);   // phase, ring slots: compile-time
     __syncthreads();                 // halo + weight buffers are free for the next chunk
+  }
+  // Round 5 - the 1x1x1 shortcut of a residual block inside the data-gradient launch of its first convolution (dynunet_block.py:100-126:
+  // out = conv1(x) ..., residual = conv3(x); backward dx = dgrad3x3(g1) + g3 W3).  The second term is one more tap: g3's 48-channel chunks at
+  // the CENTRE of the halo, two short MFMA steps per chunk (k groups 0..3, then 4..5) against W3's transposed bf16 copy [Cout][Csc] read
+  // as it is.  Until now a streaming GEMM wrote g3 W3 (170 MB at 96^3, 75 us) and this kernel read it back through its residual
+  // epilogue (+60 us).  bf16, 96-byte chunks, unsplit launches; EPI instantiations only.
+  if constexpr (EPI && GPT == 6 && std::is_same<T, bf16>::value) {
+    if (scx) {                        // (kernel argument: uniform)
+      for (int c0 = 0; c0 < Csc; c0 += CHUNK) {
+        // halo rows of the brick's OWN voxels only (the centre tap reads nothing else): the others are written as zeros and never read
+        for (int row = tid; row < FHROWS; row += 256) {
+          const int hd = row / (FHH * FHW), rem = row - hd * (FHH * FHW);
+          const int hh = rem / FHW, hw = rem - hh * FHW;
+          const int d = d0 - 1 + hd, h = h0 - 1 + hh, w = w0 - 1 + hw;
+          const bool own = hd >= 1 && hd <= FBD && hh >= 1 && hh <= FBH && hw >= 1 && hw <= FBW && d < g.D && h < g.H && w < g.W;
+          rowoff[row] = own ? (((b * g.D + d) * g.H + h) * g.W + w) : -1;
+        }
+        __syncthreads();
+        {
+          constexpr int NIT = (FHROWS * GPT + 255) / 256;
+          constexpr int IPB = 8 * GPT;
+          VT hv[NIT];
+          int ro[NIT];
+#pragma unroll
+          for (int i = 0; i < NIT; ++i) {
+            const int idx = tid + 256 * i;
+            const int blk = idx / IPB, j = idx - blk * IPB;
+            ro[i] = idx < FHROWS * GPT ? rowoff[blk * 8 + (j & 7)] : -1;
+          }
+#pragma unroll
+          for (int i = 0; i < NIT; ++i) {
+            const int idx = tid + 256 * i;
+            const int j = idx % IPB;
+            VT v;
+#pragma unroll
+            for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(0.f);
+            if (ro[i] >= 0) v = *reinterpret_cast<const VT*>(scx + (int64_t)ro[i] * ldscx + c0 + (j >> 3) * KPC);
+            hv[i] = v;
+          }
+#pragma unroll
+          for (int i = 0; i < NIT; ++i) {
+            const int idx = tid + 256 * i;
+            const int blk = idx / IPB, j = idx - blk * IPB;
+            if (idx < FHROWS * GPT) *reinterpret_cast<VT*>(lh + ((j >> 3) * FPS + blk * 8 + (j & 7)) * 16) = hv[i];
+          }
+        }
+        __syncthreads();              // every read of the row table is done: weight image 1 (which it aliases) may be written
+        // weight images [4 k-slots][NROWS][16 B]: image 0 = k groups 0..3 of this chunk, image 1 = groups 4, 5 and two slots of zeros
+        for (int idx = tid; idx < 2 * 4 * NROWS; idx += 256) {
+          const int img = idx / (4 * NROWS), it = idx - img * (4 * NROWS);
+          const int slot = it / NROWS, row = it - slot * NROWS;
+          VT v;
+#pragma unroll
+          for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(0.f);
+          const int grp = img * 4 + slot;
+          if (grp < GPT && n0 + row < Cout) v = *reinterpret_cast<const VT*>(scw + (int64_t)(n0 + row) * Csc + c0 + grp * KPC);
+          *reinterpret_cast<VT*>(lw + (img * WITEMS + it) * 16) = v;
+        }
+        __syncthreads();
+        {
+          constexpr int CENTRE = ((1 * FHH) * FHW + 1) * 16;       // tap (kd, kw) = (1, 1); kh = 1 -> halo row mt + 1
+          const char* a0 = lh + laneA + CENTRE;
+          const char* a1 = lh + laneB + CENTRE;
+          VT af0[4], af1[4], b0[NT], b1[NT];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            af0[mt] = *reinterpret_cast<const VT*>(a0 + (mt + 1) * FHW * 16);
+            af1[mt] = *reinterpret_cast<const VT*>(a1 + (mt + 1) * FHW * 16);
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            b0[nt] = *reinterpret_cast<const VT*>(lw + (fq * NROWS) * 16 + wfrag + nt * 256);
+            b1[nt] = *reinterpret_cast<const VT*>(lw + (WITEMS + fq * NROWS) * 16 + wfrag + nt * 256);
+          }
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              MmaC<T>::run(acc[mt][nt], b0[nt], af0[mt]);
+              MmaC<T>::run(acc[mt][nt], b1[nt], af1[mt]);
+            }
+        }
+        __syncthreads();              // the images are free for the next shortcut chunk / the statistics reduction of the epilogue
+      }
+    }
   }
   // epilogue: lane holds channels n0 + 16nt + 4fq .. +3 of voxel (d0 + wave, h0 + mt, w0 + fi)
   const int d = d0 + wave, w = w0 + fi;
@@ -1726,6 +1812,15 @@ extern "C" size_t miseg_conv3_fwd_workspace_bytes(int B, int D, int H, int W, in
   return ks > 1 ? (size_t)ks * B * D * H * W * Cout * sizeof(float) : 0;
 }
 
+extern "C" int miseg_conv3_fuses_shortcut(int B, int D, int H, int W, int Cin, int Cout, int Csc, int dtype) {
+  if (dtype != MISEG_BF16) return 0;
+  const int k96 = conv3_k96(Cin, 2, conv3_pad_min_bytes());
+  if (!k96 || conv3_gpt(Cin, 2, conv3_pad_min_bytes()) != 6 || Csc <= 0 || Csc % 48 != 0) return 0;
+  int nt, ks;
+  fwd96_plan(B * cdiv(D, FBD) * cdiv(H, FBH) * cdiv(W, FBW), Cout, k96 * 2 / 96, &nt, &ks);
+  return ks == 1 ? 1 : 0;
+}
+
 extern "C" int miseg_conv3_fwd_splits(int B, int D, int H, int W, int Cin, int Cout, int dtype) {
   const int esz = dtype == MISEG_F32 ? 4 : 2;
   const int rowbytes = conv3_k96(Cin, esz, conv3_pad_min_bytes()) * esz;
@@ -1764,6 +1859,12 @@ static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
     }
     const bool vec_y = ((uintptr_t)p->y % 16 == 0) && (p->ldy % KPC == 0);
     const int CoP = round_up(p->Cout, 16);
+    if (p->sc_x) {      // the fused 1x1x1 shortcut term (miseg_conv3_fuses_shortcut)
+      constexpr bool is_bf16 = std::is_same<T, bf16>::value;
+      MISEG_REQUIRE(is_bf16 && gpt == 6 && ksplit == 1 && p->sc_w && p->sc_C > 0 && p->sc_C % (6 * KPC) == 0,
+                    MISEG_E_UNSUPPORTED, "conv3_fwd: fused shortcut on this shape / dtype (ask miseg_conv3_fuses_shortcut first)");
+      MISEG_REQUIRE((uintptr_t)p->sc_x % 16 == 0 && p->ld_sc_x % KPC == 0 && (uintptr_t)p->sc_w % 16 == 0, MISEG_E_BADARG, "conv3_fwd: shortcut operands must be 16-byte aligned");
+    }
     size_t lds = (size_t)gpt * FPS * 16 + (size_t)2 * 12 * 16 * nt * 16;
     if (p->background && lds < 83 * 1024) lds = 83 * 1024;      // more than half of the 160 KB: one workgroup per CU
     MISEG_REQUIRE((int64_t)p->B * p->D * p->H * p->W < (1LL << 31), MISEG_E_UNSUPPORTED, "conv3_fwd: more than 2^31 voxels");
@@ -1773,10 +1874,10 @@ static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)conv3_fwd96_kernel<T, n, wd, epi, gp>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
     conv3_fwd96_kernel<T, n, wd, epi, gp><<<grid, 256, lds, s>>>((const T*)p->x, p->ldx, (T*)p->y, p->ldy, (const T*)p->wpk, gf, p->Cin, CinP, \
                                                                  p->Cout, CoP, vec_x, vec_y, scratch, cps, scratch ? nullptr : (const T*)p->res, \
-                                                                 p->ldres, (double*)p->stat, ny)
+                                                                 p->ldres, (double*)p->stat, ny, (const T*)p->sc_x, p->ld_sc_x, (const T*)p->sc_w, p->sc_C)
 #define F96_CASE(n, wd, gp)                                                                                                                  \
   case n:                                                                                                                                   \
-    if (!scratch && (p->res || p->stat)) { F96_LAUNCH(n, wd, true, gp); } else { F96_LAUNCH(n, wd, false, gp); }                            \
+    if (!scratch && (p->res || p->stat || p->sc_x)) { F96_LAUNCH(n, wd, true, gp); } else { F96_LAUNCH(n, wd, false, gp); }                 \
     break;
     if (gpt == 6) { switch (nt) { F96_CASE(1, 3, 6) F96_CASE(2, 2, 6) F96_CASE(3, 3, 6) } }
     else if (gpt == 4) { switch (nt) { F96_CASE(1, 3, 4) F96_CASE(2, 2, 4) F96_CASE(3, 3, 4) } }

@@ -828,13 +828,21 @@ class _Conv3(Function):
         dy = _rv(dy)
         gskip = _rv(rest[-1]) if ctx.layout[1] and rest[-1] is not None else None
         dx = None
+        # the gradient of the forked input may be a promise (_Conv1.backward, fold_dx): (g3, W3^T) of the block's 1x1x1 shortcut convolution,
+        # whose data gradient g3 W3 this launch then forms itself (ops.conv3_fwd(sc=)) - the tensor behind `gskip` was never written
+        sc = ops.pending_dx_take(gskip) if gskip is not None else None
+        if sc is not None:
+            assert isinstance(sc, tuple) and sc[0] == "sc", "the gradient of a forked conv input arrived as partial slabs"
+            sc, gskip = sc[1:], None
+        if sc is not None and not (ctx.needs_input_grad[0] and ops.conv3_fuses_shortcut(dy, ctx.wshape[1], sc[0].shape[-1])):
+            gskip, sc = ops.gemm_nt(sc[0], sc[1]), None          # (the promise cannot be kept by this launch after all: the plain product)
         if ctx.needs_input_grad[0]:
-            if ctx.dx_to_norm and gskip is None:
+            if ctx.dx_to_norm and gskip is None and sc is None:
                 dx, pend = ops.conv3_fwd(dy, bwdp, ctx.wshape[1], defer=True)
                 if pend is not None:
                     ops.pending_dx_put(dx, pend)
             else:
-                dx = ops.conv3_fwd(dy, bwdp, ctx.wshape[1], res=gskip)
+                dx = ops.conv3_fwd(dy, bwdp, ctx.wshape[1], res=gskip, sc=sc)
         dw = None
         if ctx.needs_input_grad[1]:
             slot, mode = _slot_first(ctx.params[0])
@@ -853,7 +861,14 @@ class _Conv3(Function):
 
 
 def conv3(x, weight, want_stat=False, fork=False, dx_to_norm=False):
-    return _Conv3.apply(x, weight, want_stat, fork, dx_to_norm)
+    r = _Conv3.apply(x, weight, want_stat, fork, dx_to_norm)
+    if fork and x.dtype == torch.bfloat16 and x.requires_grad and x.dim() == 5:
+        # may a 1x1x1 convolution on the forked input leave its data gradient to this convolution's data-gradient launch? (conv1(fold_dx))
+        B, D, H, W, Cin = x.shape
+        Cout = weight.shape[0]
+        if ops.FOLD_SHORTCUT and ops.L.load().miseg_conv3_fuses_shortcut(B, D, H, W, Cout, Cin, Cout, ops.L.BF16):
+            r[-1]._miseg_sc_fold = Cout
+    return r
 
 
 class _Conv3T(Function):
@@ -1088,17 +1103,28 @@ class _Conv1(Function):
     """1x1x1 conv, no bias (ResBlock shortcut dynunet_block.py:87-97) == Linear over the channel dim."""
 
     @staticmethod
-    def forward(ctx, x, weight, want_stat=False):
+    def forward(ctx, x, weight, want_stat=False, fold_dx=False):
+        """fold_dx: x is the forked input of a 3x3x3 convolution (conv3(fork=True)) whose data-gradient launch can take this layer's data
+        gradient along: backward then returns an UNWRITTEN tensor and leaves (dy, W^T) for that launch (ops.pending_dx_put)"""
         w = ops.cast_matrix(weight, x.dtype)
         ctx.save_for_backward(x, weight)
         ctx.params = (weight,)
+        ctx.fold_dx = bool(fold_dx)
         return ops.gemm_nt(x, w, want_stat=want_stat)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = _rv(dy)
-        dx = ops.gemm_nt(dy, ops.cast_matrix(weight, dy.dtype, transpose=True)) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = ops.cast_matrix(weight, dy.dtype, transpose=True)      # [Cin][Cout]
+            if (ctx.fold_dx and dy.dtype == torch.bfloat16 and dy.data_ptr() % 16 == 0 and ops.rows(dy)[0] % 8 == 0 and wt.is_contiguous()
+                    and wt.data_ptr() % 16 == 0):
+                dx = torch.empty_like(x)
+                ops.pending_dx_put(dx, ("sc", dy, wt))
+            else:
+                dx = ops.gemm_nt(dy, wt)
         dw = None
         if ctx.needs_input_grad[1]:
             slot, mode = _slot_first(ctx.params[0])
@@ -1107,12 +1133,13 @@ class _Conv1(Function):
                     ops.gemm_tn(dy, x, out=slot, accumulate=mode)
             else:
                 dw = ops.gemm_tn(dy, x).view(weight.shape)
-        return dx, dw, None
+        return dx, dw, None, None
 
 
 def conv1(x, weight, want_stat=False):
     want = want_stat and _one_sample(x)
-    y = _Conv1.apply(x, weight, want)
+    fold = getattr(x, "_miseg_sc_fold", None) == weight.shape[0]      # (the forked input of a conv3 with as many output channels: UnetResBlock)
+    y = _Conv1.apply(x, weight, want, fold)
     return _tag_stat(y) if want else y
 
 

@@ -1130,10 +1130,23 @@ def check_no_pending():
         raise RuntimeError(f"{n} deferred data-gradient slab sum(s) were never consumed (conv3(..., dx_to_norm=True) in front of something that is no instance norm)")
 
 
-def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False, defer=False):
+FOLD_SHORTCUT = os.environ.get("MISEG_NO_SC_FOLD") is None      # A/B switch of round 5 (conv3_fwd(sc=))
+
+
+def conv3_fuses_shortcut(x, Cout, Csc):
+    """can conv3_fwd(x, ..., Cout, sc=(g [.., Csc], w [Cout, Csc])) take the 1x1x1 term along (miseg_conv3_params.sc_x)?"""
+    if not FOLD_SHORTCUT or x.dtype != torch.bfloat16:
+        return False
+    B, D, H, W = _vol(x)
+    return bool(L.load().miseg_conv3_fuses_shortcut(B, D, H, W, rows(x)[2], Cout, Csc, _dt(x)))
+
+
+def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False, defer=False, sc=None):
     """x [B,D,H,W,Cin] rows view; wpk [Cout][27][CinP].  res: rows view added to the result in the epilogue (falls back to a separate
     add where the kernel path cannot fuse it).  want_stat: returns (out, stat) with stat the instance-norm statistics of `out`
-    ([16, B, Cout, 2] fp64, from the kernel's epilogue) or None where that is not available (the caller's norm then computes them)."""
+    ([16, B, Cout, 2] fp64, from the kernel's epilogue) or None where that is not available (the caller's norm then computes them).
+    sc = (g, w) (after conv3_fuses_shortcut said yes): out += g @ w^T, g a rows view over the same voxels, w [Cout, Csc] contiguous in x's
+    dtype - the 1x1x1 shortcut term of a residual block's data gradient."""
     B, D, H, W = _vol(x)
     ld, n, Cin = rows(x)
     if out is None:
@@ -1156,8 +1169,16 @@ def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False, defer=False):
     defer = nsplit > 1 and D * H * W <= lib.miseg_instnorm_fused_max_rows() and rows(out)[0] == Cout
     if want_stat and fast and not defer:      # (a split reduction computes them in its second launch)
         stat = STAT_POOL.take(lib.miseg_instnorm_stat_bytes(B, Cout) // 8, x.device).view(-1, B, Cout, 2)
+    scx, scw, ldsc, Csc = None, None, 0, 0
+    if sc is not None:
+        scx, scw = sc
+        ldsc, nsc, Csc = rows(scx)
+        assert fast and nsc == n and scw.is_contiguous() and tuple(scw.shape) == (Cout, Csc) and scw.dtype == x.dtype == scx.dtype
+        flops += 2.0 * n * Csc * Cout
+        nbytes += float(x.element_size()) * (n * Csc + scw.numel())
     mk = lambda st: L.Conv3(_ptr(x), ld, _ptr(out), rows(out)[0], _ptr(wpk), B, D, H, W, Cin, Cout, _dt(x), _ptr(ws),
-                            _ptr(res) if fuse_res else None, rows(res)[0] if fuse_res else 0, _ptr(st), bg, 1 if defer else 0)
+                            _ptr(res) if fuse_res else None, rows(res)[0] if fuse_res else 0, _ptr(st), bg, 1 if defer else 0,
+                            _ptr(scx), ldsc, _ptr(scw), Csc)
     _call("miseg_conv3_fwd", mk(stat), prof=(name, flops, nbytes))
     if res is not None and not fuse_res:
         out = add(out, res)

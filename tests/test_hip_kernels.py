@@ -580,6 +580,42 @@ def test_conv3_fused_residual_and_statistics(dtype, B, D, H, W, Cin, Cout):
     assert torch.allclose(s, ref, rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("B,D,H,W,Cin,Cout,Csc,with_res", [(1, 16, 16, 32, 48, 96, 48, False), (1, 9, 7, 17, 48, 96, 48, True), (1, 32, 32, 32, 96, 48, 96, False),
+                                                          (1, 16, 16, 16, 48, 40, 48, False)])
+def test_conv3_takes_a_1x1x1_shortcut_term_along(B, D, H, W, Cin, Cout, Csc, with_res):
+    """round 5 (miseg_conv3_params.sc_x): y = conv3x3x3(x) + g W^T [+ res] in one launch - the data-gradient pass of a residual block's first
+    convolution with the gradient of the block's 1x1x1 shortcut (dynunet_block.py:100-126) - against the two-launch route (GEMM, then the
+    convolution with the fused residual): the same bf16 rounding points except that the shortcut term joins in fp32."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    x, w = _conv_case(dtype, B, D, H, W, Cin, Cout, seed=21)
+    fwdp, _ = ops.pack_conv3(w, dtype)
+    g = rnd(B, D, H, W, Csc, dtype=dtype, seed=22)
+    ws = (rnd(Cout, Csc, seed=23) / Csc ** 0.5).to(dtype)
+    res = rnd(B, D, H, W, Cout, dtype=dtype, seed=24) if with_res else None
+    assert ops.conv3_fuses_shortcut(x, Cout, Csc)
+    assert not ops.conv3_fuses_shortcut(x.float(), Cout, Csc) and not ops.conv3_fuses_shortcut(x, Cout, 40)
+    y = ops.conv3_fwd(x, fwdp, Cout, res=res, sc=(g, ws))
+    ref = F.conv3d(x.float().permute(0, 4, 1, 2, 3), w.to(dtype).float(), padding=1).permute(0, 2, 3, 4, 1) + g.float() @ ws.float().t()
+    if with_res:
+        ref = ref + res.float()
+    assert rel_err(y.float(), ref) < TOL[dtype]
+    # against the unfused route
+    y2 = ops.conv3_fwd(x, fwdp, Cout, res=ops.gemm_nt(g, ws) if res is None else ops.add(ops.gemm_nt(g, ws), res))
+    assert rel_err(y.float(), y2.float()) < 2 * TOL[dtype]
+    # a strided shortcut operand (a channel slice of a wider buffer)
+    gw = rnd(B, D, H, W, Csc + 16, dtype=dtype, seed=25)
+    y3 = ops.conv3_fwd(x, fwdp, Cout, sc=(gw[..., 16:], ws))
+    ref3 = F.conv3d(x.float().permute(0, 4, 1, 2, 3), w.to(dtype).float(), padding=1).permute(0, 2, 3, 4, 1) + gw[..., 16:].float() @ ws.float().t()
+    assert rel_err(y3.float(), ref3) < TOL[dtype]
+
+
+def test_conv3_shortcut_is_refused_where_the_launch_splits():
+    ops = _ops()
+    x = rnd(1, 6, 6, 6, 384, dtype=torch.bfloat16, seed=3)
+    assert not ops.conv3_fuses_shortcut(x, 768, 384)        # 6^3: the reduction is split over workgroups (fp32 slabs + a second launch)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,D,H,W,Cin,Cout,with_res", [(1, 12, 12, 12, 192, 192, True), (2, 6, 6, 6, 96, 48, False), (1, 3, 3, 3, 768, 768, True), (2, 5, 7, 6, 96, 96, True),
                                                       (1, 12, 12, 12, 128, 128, True), (1, 6, 6, 6, 256, 128, False)])      # 64-byte chunks (C-UNETR's deep layers)
