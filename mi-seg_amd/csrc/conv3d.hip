@@ -442,44 +442,34 @@ __global__ void __launch_bounds__(256, GPT == 6 ? 2 : GPT == 4 ? (NT == 1 ? 3 : 
   if constexpr (EPI && GPT == 6 && std::is_same<T, bf16>::value) {
     if (scx) {                        // (kernel argument: uniform)
       for (int c0 = 0; c0 < Csc; c0 += CHUNK) {
-        // halo rows of the brick's OWN voxels only (the centre tap reads nothing else): the others are written as zeros and never read
-        for (int row = tid; row < FHROWS; row += 256) {
-          const int hd = row / (FHH * FHW), rem = row - hd * (FHH * FHW);
-          const int hh = rem / FHW, hw = rem - hh * FHW;
-          const int d = d0 - 1 + hd, h = h0 - 1 + hh, w = w0 - 1 + hw;
-          const bool own = hd >= 1 && hd <= FBD && hh >= 1 && hh <= FBH && hw >= 1 && hw <= FBW && d < g.D && h < g.H && w < g.W;
-          rowoff[row] = own ? (((b * g.D + d) * g.H + h) * g.W + w) : -1;
-        }
-        __syncthreads();
+        // the brick's OWN 256 voxels only (the centre tap reads nothing else of the halo image): 6 items of 16 bytes per thread, addressed
+        // arithmetically - 8 consecutive lanes take 8 consecutive voxels of one w-row and one channel group (conflict-free LDS writes,
+        // 48 lanes read 768 contiguous bytes)
         {
-          constexpr int NIT = (FHROWS * GPT + 255) / 256;
+          constexpr int NIT = (FBD * FBH * FBW * GPT) / 256;      // 6
           constexpr int IPB = 8 * GPT;
           VT hv[NIT];
-          int ro[NIT];
 #pragma unroll
           for (int i = 0; i < NIT; ++i) {
             const int idx = tid + 256 * i;
             const int blk = idx / IPB, j = idx - blk * IPB;
-            ro[i] = idx < FHROWS * GPT ? rowoff[blk * 8 + (j & 7)] : -1;
-          }
+            const int v = blk * 8 + (j & 7);                       // voxel of the brick: (bd, bh, bw) = (v / 64, (v / 16) % 4, v % 16)
+            const int d = d0 + (v >> 6), h = h0 + ((v >> 4) & 3), w = w0 + (v & 15);
+            VT val;
 #pragma unroll
-          for (int i = 0; i < NIT; ++i) {
-            const int idx = tid + 256 * i;
-            const int j = idx % IPB;
-            VT v;
-#pragma unroll
-            for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(0.f);
-            if (ro[i] >= 0) v = *reinterpret_cast<const VT*>(scx + (int64_t)ro[i] * ldscx + c0 + (j >> 3) * KPC);
-            hv[i] = v;
+            for (int e = 0; e < KPC; ++e) val[e] = from_f32<T>(0.f);
+            if (d < g.D && h < g.H && w < g.W) val = *reinterpret_cast<const VT*>(scx + (int64_t)(((b * g.D + d) * g.H + h) * g.W + w) * ldscx + c0 + (j >> 3) * KPC);
+            hv[i] = val;
           }
 #pragma unroll
           for (int i = 0; i < NIT; ++i) {
             const int idx = tid + 256 * i;
             const int blk = idx / IPB, j = idx - blk * IPB;
-            if (idx < FHROWS * GPT) *reinterpret_cast<VT*>(lh + ((j >> 3) * FPS + blk * 8 + (j & 7)) * 16) = hv[i];
+            const int v = blk * 8 + (j & 7);
+            const int hrow = (((v >> 6) + 1) * FHH + ((v >> 4) & 3) + 1) * FHW + (v & 15) + 1;
+            *reinterpret_cast<VT*>(lh + ((j >> 3) * FPS + hrow) * 16) = hv[i];
           }
         }
-        __syncthreads();              // every read of the row table is done: weight image 1 (which it aliases) may be written
         // weight images [4 k-slots][NROWS][16 B]: image 0 = k groups 0..3 of this chunk, image 1 = groups 4, 5 and two slots of zeros
         for (int idx = tid; idx < 2 * 4 * NROWS; idx += 256) {
           const int img = idx / (4 * NROWS), it = idx - img * (4 * NROWS);
