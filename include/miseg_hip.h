@@ -328,6 +328,11 @@ typedef struct {
    * along (dynunet_block.py:87-97,100-126: dx = dgrad3x3(g1) + g3 W3) instead of reading a [voxels][Cout] tensor that a GEMM wrote.
    * sc_x: [B][D][H][W][sc_C] rows (ld_sc_x), sc_C a multiple of 48; sc_w: [Cout][sc_C] in `dtype` (W3 transposed), contiguous. */
   const void* sc_x; int64_t ld_sc_x; const void* sc_w; int32_t sc_C;
+  /* ABI 9, only where miseg_conv3_fuses_s2c(...) says so (96-byte chunks, unsplit launch, even D / H / W): output channels [0, s2c_C) are NOT
+   * written to y but to s2c_out [B][D/2][H/2][W/2][8][s2c_C] - voxel (d, h, w) at block j = 4 (d&1) + 2 (h&1) + (w&1) of its coarse voxel: the
+   * layout in which the ConvTranspose3d(k2, s2) in front of a decoder block reads the gradient of its output (unetr_block.py:80-85; the
+   * data-gradient pass of that block's first convolution produces it, left half of the concat buffer).  Channels >= s2c_C go to y as usual. */
+  void* s2c_out; int32_t s2c_C;
 } miseg_conv3_params;
 /* small grids split the reduction over workgroups and need an fp32 staging buffer of the output */
 size_t miseg_conv3_fwd_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int dtype);
@@ -335,6 +340,8 @@ size_t miseg_conv3_fwd_workspace_bytes(int B, int D, int H, int W, int Cin, int 
 int miseg_conv3_fwd_splits(int B, int D, int H, int W, int Cin, int Cout, int dtype);
 /* 1 when miseg_conv3_fwd with these shapes can take a 1x1x1 shortcut term of sc_C channels along (miseg_conv3_params.sc_x) */
 int miseg_conv3_fuses_shortcut(int B, int D, int H, int W, int Cin, int Cout, int sc_C, int dtype);
+/* 1 when miseg_conv3_fwd with these shapes can store its first s2c_C output channels in space-to-channel order (miseg_conv3_params.s2c_out) */
+int miseg_conv3_fuses_s2c(int B, int D, int H, int W, int Cin, int Cout, int s2c_C, int dtype);
 int miseg_conv3_fwd(const miseg_conv3_params* p, miseg_stream_t stream);
 
 /* w: fp32 torch layout [Cout][Cin][3][3][3].  fwd_pack feeds miseg_conv3_fwd on x, bwd_pack (taps mirrored, channels swapped) feeds it

@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(256, GPT == 6 ? 2 : GPT == 4 ? (NT == 1 ? 3 : 
                                                              ConvGeom g, int Cin, int CinP, int Cout, int CoP, bool vec_x, bool vec_y,
                                                              float* __restrict__ scratch, int chunks_per_split, const T* __restrict__ res, int64_t ldres,
                                                              double* __restrict__ stat, int ny, const T* __restrict__ scx = nullptr, int64_t ldscx = 0,
-                                                             const T* __restrict__ scw = nullptr, int Csc = 0) {
+                                                             const T* __restrict__ scw = nullptr, int Csc = 0, T* __restrict__ s2c_out = nullptr, int s2c_C = 0) {
   typedef typename Vec16<T>::type VT;
   constexpr int KPC = MmaC<T>::KPC;
   constexpr int CHUNK = GPT * KPC, NPH = fwd96_phases(GPT);
@@ -535,6 +535,13 @@ __global__ void __launch_bounds__(256, GPT == 6 ? 2 : GPT == 4 ? (NT == 1 ? 3 : 
         continue;
       }
       T* yr = y + vox * ldy;
+      if (EPI && s2c_out && n0 < s2c_C) {
+        // Round 5: the first s2c_C output channels leave in space-to-channel order - row (coarse voxel (d/2, h/2, w/2), j = 4 (d&1) + 2 (h&1) + (w&1))
+        // of a [.., 8][s2c_C] tensor: what the transposed convolution in front of a decoder block reads as the gradient of its output
+        // (unetr_block.py:80-85).  Until now those channels were written with the others and a gather pass re-laid them out.
+        const int64_t cv = ((((int64_t)b * (g.D >> 1) + (d >> 1)) * (g.H >> 1) + (h >> 1)) * (g.W >> 1) + (w >> 1));
+        yr = s2c_out + (cv * 8 + (((d & 1) << 2) | ((h & 1) << 1) | (w & 1))) * s2c_C;
+      }
       const T* rr = (EPI && res) ? res + vox * ldres : nullptr;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -1811,6 +1818,15 @@ extern "C" int miseg_conv3_fuses_shortcut(int B, int D, int H, int W, int Cin, i
   return ks == 1 ? 1 : 0;
 }
 
+extern "C" int miseg_conv3_fuses_s2c(int B, int D, int H, int W, int Cin, int Cout, int s2c_C, int dtype) {
+  const int esz = dtype == MISEG_F32 ? 4 : 2;
+  const int k96 = conv3_k96(Cin, esz, conv3_pad_min_bytes());
+  if (!k96 || (D | H | W) & 1 || s2c_C <= 0 || s2c_C >= Cout || s2c_C % (16 / esz) != 0) return 0;
+  int nt, ks;
+  fwd96_plan(B * cdiv(D, FBD) * cdiv(H, FBH) * cdiv(W, FBW), Cout, k96 * esz / (16 * conv3_gpt(Cin, esz, conv3_pad_min_bytes())), &nt, &ks);
+  return (ks == 1 && s2c_C % (16 * nt) == 0) ? 1 : 0;
+}
+
 extern "C" int miseg_conv3_fwd_splits(int B, int D, int H, int W, int Cin, int Cout, int dtype) {
   const int esz = dtype == MISEG_F32 ? 4 : 2;
   const int rowbytes = conv3_k96(Cin, esz, conv3_pad_min_bytes()) * esz;
@@ -1855,6 +1871,11 @@ static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
                     MISEG_E_UNSUPPORTED, "conv3_fwd: fused shortcut on this shape / dtype (ask miseg_conv3_fuses_shortcut first)");
       MISEG_REQUIRE((uintptr_t)p->sc_x % 16 == 0 && p->ld_sc_x % KPC == 0 && (uintptr_t)p->sc_w % 16 == 0, MISEG_E_BADARG, "conv3_fwd: shortcut operands must be 16-byte aligned");
     }
+    if (p->s2c_out) {   // the left channels stored in space-to-channel order (miseg_conv3_fuses_s2c)
+      MISEG_REQUIRE(ksplit == 1 && p->s2c_C > 0 && p->s2c_C < p->Cout && p->s2c_C % (16 * nt) == 0 && p->D % 2 == 0 && p->H % 2 == 0 && p->W % 2 == 0,
+                    MISEG_E_UNSUPPORTED, "conv3_fwd: space-to-channel store on this shape (ask miseg_conv3_fuses_s2c first)");
+      MISEG_REQUIRE((uintptr_t)p->s2c_out % 16 == 0 && p->s2c_C % KPC == 0, MISEG_E_BADARG, "conv3_fwd: s2c_out must be 16-byte aligned");
+    }
     size_t lds = (size_t)gpt * FPS * 16 + (size_t)2 * 12 * 16 * nt * 16;
     if (p->background && lds < 83 * 1024) lds = 83 * 1024;      // more than half of the 160 KB: one workgroup per CU
     MISEG_REQUIRE((int64_t)p->B * p->D * p->H * p->W < (1LL << 31), MISEG_E_UNSUPPORTED, "conv3_fwd: more than 2^31 voxels");
@@ -1864,10 +1885,11 @@ static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)conv3_fwd96_kernel<T, n, wd, epi, gp>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
     conv3_fwd96_kernel<T, n, wd, epi, gp><<<grid, 256, lds, s>>>((const T*)p->x, p->ldx, (T*)p->y, p->ldy, (const T*)p->wpk, gf, p->Cin, CinP, \
                                                                  p->Cout, CoP, vec_x, vec_y, scratch, cps, scratch ? nullptr : (const T*)p->res, \
-                                                                 p->ldres, (double*)p->stat, ny, (const T*)p->sc_x, p->ld_sc_x, (const T*)p->sc_w, p->sc_C)
+                                                                 p->ldres, (double*)p->stat, ny, (const T*)p->sc_x, p->ld_sc_x, (const T*)p->sc_w, p->sc_C, \
+                                                                 (T*)p->s2c_out, p->s2c_C)
 #define F96_CASE(n, wd, gp)                                                                                                                  \
   case n:                                                                                                                                   \
-    if (!scratch && (p->res || p->stat || p->sc_x)) { F96_LAUNCH(n, wd, true, gp); } else { F96_LAUNCH(n, wd, false, gp); }                 \
+    if (!scratch && (p->res || p->stat || p->sc_x || p->s2c_out)) { F96_LAUNCH(n, wd, true, gp); } else { F96_LAUNCH(n, wd, false, gp); }   \
     break;
     if (gpt == 6) { switch (nt) { F96_CASE(1, 3, 6) F96_CASE(2, 2, 6) F96_CASE(3, 3, 6) } }
     else if (gpt == 4) { switch (nt) { F96_CASE(1, 3, 4) F96_CASE(2, 2, 4) F96_CASE(3, 3, 4) } }

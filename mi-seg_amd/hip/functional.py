@@ -799,11 +799,14 @@ class _Conv3(Function):
     data-gradient kernel instead of by a separate pass."""
 
     @staticmethod
-    def forward(ctx, x, weight, want_stat=False, fork=False, dx_to_norm=False):
+    def forward(ctx, x, weight, want_stat=False, fork=False, dx_to_norm=False, s2c_left=0):
         """dx_to_norm: x is the output of a (conditional) instance norm that nothing else reads, so the data gradient computed here goes
-        straight to that norm's backward pass - a split launch over a small stage may then leave its partial slabs to it (ops.pending_dx_put)"""
+        straight to that norm's backward pass - a split launch over a small stage may then leave its partial slabs to it (ops.pending_dx_put).
+        s2c_left = C > 0: x is the concat buffer of upconv_cat whose first C channels came from a ConvTranspose3d(k2, s2); the data gradient
+        of those channels leaves the kernel in the layout that layer's backward reads (ops.conv3_fwd(s2c=); handed over by ops.pending_dx_put)"""
         need_dx = ctx.needs_input_grad[0]
         ctx.dx_to_norm = bool(dx_to_norm)
+        ctx.s2c_left = int(s2c_left)
         fwdp, bwdp = ops.pack_conv3(weight, x.dtype, True, need_dx)
         # want_stat = "defer": the statistics slot may come back as ops.PendingSlabs - y is then written by the instance norm that consumes it
         y, stat = ops.conv3_fwd(x, fwdp, weight.shape[0], want_stat=want_stat) if want_stat else (ops.conv3_fwd(x, fwdp, weight.shape[0]), None)
@@ -842,7 +845,13 @@ class _Conv3(Function):
                 if pend is not None:
                     ops.pending_dx_put(dx, pend)
             else:
-                dx = ops.conv3_fwd(dy, bwdp, ctx.wshape[1], res=gskip, sc=sc)
+                dy8 = None
+                if ctx.s2c_left and ops.conv3_fuses_s2c(dy, ctx.wshape[1], ctx.s2c_left):
+                    B_, D_, H_, W_ = x.shape[:4]
+                    dy8 = torch.empty(B_, D_ // 2, H_ // 2, W_ // 2, 8 * ctx.s2c_left, dtype=dy.dtype, device=dy.device)
+                dx = ops.conv3_fwd(dy, bwdp, ctx.wshape[1], res=gskip, sc=sc, s2c=dy8)
+                if dy8 is not None:
+                    ops.pending_dx_put(dx, ("dy8", dy8))      # the first s2c_left channels of dx were NOT written: _UpCat.backward takes dy8
         dw = None
         if ctx.needs_input_grad[1]:
             slot, mode = _slot_first(ctx.params[0])
@@ -857,11 +866,11 @@ class _Conv3(Function):
                     ops.conv3_wgrad(x, dy, dw=slot, accumulate=mode)
             else:
                 dw = ops.conv3_wgrad(x, dy)
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
 
 
 def conv3(x, weight, want_stat=False, fork=False, dx_to_norm=False):
-    r = _Conv3.apply(x, weight, want_stat, fork, dx_to_norm)
+    r = _Conv3.apply(x, weight, want_stat, fork, dx_to_norm, getattr(x, "_miseg_upcat", 0) if x.requires_grad else 0)
     if fork and x.dtype == torch.bfloat16 and x.requires_grad and x.dim() == 5:
         # may a 1x1x1 convolution on the forked input leave its data gradient to this convolution's data-gradient launch? (conv1(fold_dx))
         B, D, H, W, Cin = x.shape
@@ -1177,7 +1186,12 @@ class _UpCat(Function):
         Cin, Cout = weight.shape[0], weight.shape[1]
         dcat = _rv(dcat)
         dskip = dcat[..., Cout:] if ctx.has_skip and ctx.needs_input_grad[1] else None
-        dy8 = ops.space_to_channel(dcat[..., :Cout], STD_OFFSETS)                     # [B,d,h,w,8*Cout]
+        pend = ops.pending_dx_take(dcat)      # the producer of dcat may have stored these channels in this order itself (_Conv3.backward, s2c_left)
+        if pend is not None:
+            assert isinstance(pend, tuple) and pend[0] == "dy8" and pend[1].shape[-1] == 8 * Cout
+            dy8 = pend[1]
+        else:
+            dy8 = ops.space_to_channel(dcat[..., :Cout], STD_OFFSETS)                 # [B,d,h,w,8*Cout]
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm_nt(dy8, ops.cast_matrix(weight, x.dtype, regroup=(8, Cout)))   # [ci][(j,co)]
@@ -1201,7 +1215,10 @@ class _UpCat(Function):
 
 
 def upconv_cat(x, skip, weight):
-    return _UpCat.apply(x, skip, weight)
+    cat = _UpCat.apply(x, skip, weight)
+    if skip is not None:
+        cat._miseg_upcat = weight.shape[1]      # (read by conv3(): the data gradient of these channels may leave its kernel in space-to-channel order)
+    return cat
 
 
 def concat_buffer(shape_bdhw, channels, dtype, device):

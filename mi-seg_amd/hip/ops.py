@@ -1141,12 +1141,25 @@ def conv3_fuses_shortcut(x, Cout, Csc):
     return bool(L.load().miseg_conv3_fuses_shortcut(B, D, H, W, rows(x)[2], Cout, Csc, _dt(x)))
 
 
-def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False, defer=False, sc=None):
+FOLD_S2C = os.environ.get("MISEG_NO_S2C_FOLD") is None      # A/B switch of round 5 (conv3_fwd(s2c=))
+
+
+def conv3_fuses_s2c(x, Cout, C_left):
+    """can conv3_fwd(x, ..., Cout, s2c=...) store its first C_left output channels in space-to-channel order (miseg_conv3_params.s2c_out)?"""
+    if not FOLD_S2C:
+        return False
+    B, D, H, W = _vol(x)
+    return bool(L.load().miseg_conv3_fuses_s2c(B, D, H, W, rows(x)[2], Cout, C_left, _dt(x)))
+
+
+def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False, defer=False, sc=None, s2c=None):
     """x [B,D,H,W,Cin] rows view; wpk [Cout][27][CinP].  res: rows view added to the result in the epilogue (falls back to a separate
     add where the kernel path cannot fuse it).  want_stat: returns (out, stat) with stat the instance-norm statistics of `out`
     ([16, B, Cout, 2] fp64, from the kernel's epilogue) or None where that is not available (the caller's norm then computes them).
     sc = (g, w) (after conv3_fuses_shortcut said yes): out += g @ w^T, g a rows view over the same voxels, w [Cout, Csc] contiguous in x's
-    dtype - the 1x1x1 shortcut term of a residual block's data gradient."""
+    dtype - the 1x1x1 shortcut term of a residual block's data gradient.
+    s2c = tensor [B, D/2, H/2, W/2, 8 * C_left] (after conv3_fuses_s2c said yes): the first C_left output channels are stored THERE, in
+    space-to-channel order (block j = 4 (d&1) + 2 (h&1) + (w&1)), and not in `out`."""
     B, D, H, W = _vol(x)
     ld, n, Cin = rows(x)
     if out is None:
@@ -1178,7 +1191,7 @@ def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False, defer=False, sc
         nbytes += float(x.element_size()) * (n * Csc + scw.numel())
     mk = lambda st: L.Conv3(_ptr(x), ld, _ptr(out), rows(out)[0], _ptr(wpk), B, D, H, W, Cin, Cout, _dt(x), _ptr(ws),
                             _ptr(res) if fuse_res else None, rows(res)[0] if fuse_res else 0, _ptr(st), bg, 1 if defer else 0,
-                            _ptr(scx), ldsc, _ptr(scw), Csc)
+                            _ptr(scx), ldsc, _ptr(scw), Csc, _ptr(s2c), (s2c.shape[-1] // 8) if s2c is not None else 0)
     _call("miseg_conv3_fwd", mk(stat), prof=(name, flops, nbytes))
     if res is not None and not fuse_res:
         out = add(out, res)

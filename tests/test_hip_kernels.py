@@ -610,6 +610,31 @@ def test_conv3_takes_a_1x1x1_shortcut_term_along(B, D, H, W, Cin, Cout, Csc, wit
     assert rel_err(y3.float(), ref3) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,D,H,W,Cin,Cout,Cl", [(1, 16, 16, 32, 48, 96, 48), (2, 8, 12, 34, 48, 96, 48), (1, 16, 32, 32, 96, 64, 16)])
+def test_conv3_stores_its_left_channels_in_space_to_channel_order(dtype, B, D, H, W, Cin, Cout, Cl):
+    """round 5 (miseg_conv3_params.s2c_out): the first Cl output channels leave the kernel as [.., D/2, H/2, W/2, 8, Cl] (what the transposed
+    convolution in front of a decoder block reads as the gradient of its output), the others as usual - bit-identical to the plain launch
+    followed by the gather pass."""
+    ops = _ops()
+    from mi_seg_amd.hip.functional import STD_OFFSETS
+    if dtype == torch.float32:
+        Cin = Cin // 2
+    x, w = _conv_case(dtype, B, D, H, W, Cin, Cout, seed=31)
+    fwdp, _ = ops.pack_conv3(w, dtype)
+    if not ops.conv3_fuses_s2c(x, Cout, Cl):
+        pytest.skip("this shape takes an output-channel tile that does not divide the left part")
+    plain = ops.conv3_fwd(x, fwdp, Cout)
+    want8 = ops.space_to_channel(plain[..., :Cl], STD_OFFSETS)
+    y8 = torch.full((B, D // 2, H // 2, W // 2, 8 * Cl), 7.0, dtype=dtype, device=DEV)
+    y = torch.full((B, D, H, W, Cout), 5.0, dtype=dtype, device=DEV)
+    ops.conv3_fwd(x, fwdp, Cout, out=y, s2c=y8)
+    assert torch.equal(y8, want8)
+    assert torch.equal(y[..., Cl:], plain[..., Cl:])
+    assert bool((y[..., :Cl] == 5.0).all()), "the left channels of the ordinary output must stay untouched"
+    assert not ops.conv3_fuses_s2c(rnd(1, 15, 16, 32, Cin, dtype=dtype, seed=1), Cout, Cl)      # odd extent
+
+
 def test_conv3_shortcut_is_refused_where_the_launch_splits():
     ops = _ops()
     x = rnd(1, 6, 6, 6, 384, dtype=torch.bfloat16, seed=3)
