@@ -717,15 +717,15 @@ def wgrad_side(*keep, kind="gemm"):
 _BRANCH_STREAM = None
 _MAIN_STREAM = None            # the stream a model's forward forked its side branch from (swin_unetr.py sets it)
 BACKGROUND_LAUNCHES = 0        # running count of launches issued in background form (bench.py reports the per-step figure)
-BACKGROUND_WORKGROUPS = int(os.environ.get("MISEG_BG_WG", "32"))     # cap of the branch's own background weight-gradient launch (each workgroup owns a CU).  Step against no branch,
+BACKGROUND_WORKGROUPS = 32     # cap of the branch's own background weight-gradient launch (each workgroup owns a CU).  Step against no branch,
                                # two boxes, before the deferral below: 256 (no cap) -0.4 %, 128 +1.0, 64 +1.4, 32 +2.0 / +2.4, 16 +2.0, 8 -3.8
-DEFERRED_WORKGROUPS = int(os.environ.get("MISEG_DEFER_WG", "64"))       # cap of the main stream's deferred weight gradients (defer_to_branch).  (own cap, this cap) on one box, no branch =
+DEFERRED_WORKGROUPS = 64       # cap of the main stream's deferred weight gradients (defer_to_branch).  (own cap, this cap) on one box, no branch =
                                # 132.6, branch alone 134.5: (24, 48) 136.9, (24, 64) 140.8, (24, 96) 139.8, (48, 64) 140.6, (64, 64) 140.7, (32, 32) 128.9
 DEFERRED_WORKGROUPS_SPLIT = 96      # the same launches inside the first half of a split step (flush_deferred_on_branch)
 GROUP_EARLY_WORKGROUPS = 0      # cap of the early (branch-stream) grouped weight-gradient launch; 0 = off
-FLUSH_SMALL_ON_BRANCH = os.environ.get("MISEG_FLUSH_SMALL_ON_BRANCH", "1") == "1"      # (rounds 3 - 4 measured the alternatives; re-swept in round 5 after the grouped conv launch halved)
-FLUSH_SIDE_ON_BRANCH = os.environ.get("MISEG_FLUSH_SIDE_ON_BRANCH", "1") == "1"
-FLUSH_MAIN_BEFORE_JOIN = os.environ.get("MISEG_FLUSH_MAIN_BEFORE_JOIN", "1") == "1"   # arena.end_backward: the main stream's grouped launches do not wait for the branch
+FLUSH_SMALL_ON_BRANCH = True      # (rounds 3 - 4 measured the alternatives; re-swept in round 5 after the grouped conv launch halved: 160.7 against 159.7 / 158.7 / 158.0
+FLUSH_SIDE_ON_BRANCH = True       #  with this one / the next / the third off - module constants again)
+FLUSH_MAIN_BEFORE_JOIN = True   # arena.end_backward: the main stream's grouped launches do not wait for the branch
 DEFER_MIN_ROWS = 400000        # 96^3 layers only (the smaller ones are grouped into one launch at the end of the backward pass)
 # (round 3: the queue of deferred launches itself lives on the training arena's StepQueues - `branch_deferred` - and is found through the
 # gradient slot a launch accumulates into, like the other per-step queues: two models in one process no longer share it)

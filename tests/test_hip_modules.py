@@ -889,6 +889,46 @@ def test_side_branch_matches_the_single_stream_step(mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fork_at", ["s0", "s1", "s2"])
+def test_side_branch_forked_beside_the_swin_stages_on_an_inner_tape(fork_at):
+    """round 5 (SwinUNETR.fork_at, HF.inner_tape_join): the branch's FORWARD forked as soon as Swin feature map 0 / 1 / 2 is queued, its
+    backward taped where it always was - against the default placement in a replayed hipGraph: bit-identical logits, the same None pattern,
+    the same gradients (the kernels and their operands are the same; only where the host issues them differs)."""
+    from mi_seg_amd.networks.nets.swin_unetr import SwinUNETR
+    from mi_seg_amd.runtime.arena import ParamArena
+    from mi_seg_amd.runtime.graph import GraphedStep
+    from mi_seg_amd.utils.detfill import fill_module_, det_input
+    net = SwinUNETR((64, 64, 64), 1, 3, feature_size=24, num_heads=(3, 6, 12, 24), vit_norm_name=_norm("instance_cond"),
+                    encoder_norm_name=_norm("instance_cond"), decoder_norm_name=_norm("instance")).cuda()
+    fill_module_(net)
+    net.set_compute_dtype(torch.bfloat16)
+    x = det_input(3, (1, 1, 64, 64, 64)).cuda()
+    cot = det_input(4, (1, 3, 64, 64, 64)).cuda()
+    params = [p for p in net.parameters() if p.requires_grad]
+    names = [k for k, _ in net.named_parameters()]
+
+    def run(where):
+        net.fork_at = where
+        for p in params:
+            p.grad = None
+        arena = ParamArena(params, torch.bfloat16)
+        try:
+            step = GraphedStep(net, x.shape, cot.shape, arena=arena)
+            step(x, [1], cot)
+            y = step(x, [1], cot).detach().clone()
+            torch.cuda.synchronize()
+            return y, {k: (None if p.grad is None else p.grad.detach().float().cpu().clone()) for k, p in zip(names, params)}
+        finally:
+            arena.detach()
+
+    y0, g0 = run("e10")
+    y1, g1 = run(fork_at)
+    assert torch.equal(y0, y1)
+    assert [k for k in names if g0[k] is None] == [k for k in names if g1[k] is None]
+    compare_grads({k: v for k, v in g1.items() if v is not None}, {k: v for k, v in g0.items() if v is not None}, 2e-3, skip=ZERO_GRAD)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("use_arena", [False, True, "split"])
 def test_graphed_step_replays_match_eager(use_arena):
     """every replay of the captured step - not only the first - must reproduce the eager step, for both modalities and with
