@@ -37,11 +37,25 @@ static constexpr int MLP_ROW_C = MLP_C * 2 + 16;      // byte stride of an LDS r
 static constexpr int MLP_ROW_H = MLP_H * 2 + 16;      // ... of HID channels ([C][HID] images)
 
 // image of a [R][K] bf16 matrix with padded rows; K * 2 bytes per row are copied as 16-byte pieces
+// (round 5: eight loads in flight per thread before the first LDS write - one piece per trip waited a memory round trip per 8 KB of the
+// workgroup's image: 8 - 12 trips for the 48-channel images, 19 for the 96-channel ones, most of the launch at 1 - 2 tiles per wave)
 __device__ __forceinline__ void mlp_stage(char* img, int rowb, const bf16* __restrict__ w, int R, int K) {
-  const int per = K / 8;
-  for (int c = threadIdx.x; c < R * per; c += blockDim.x) {
-    const int r = c / per, ch = c - r * per;
-    *reinterpret_cast<bf16x8*>(img + r * rowb + ch * 16) = *reinterpret_cast<const bf16x8*>(w + (int64_t)r * K + ch * 8);
+  const int per = K / 8, total = R * per, nthr = blockDim.x;
+  constexpr int NB = 8;      // (16: the 96-channel launches 23 -> 22 us, the 48-channel ones 28.5 -> 29.5)
+  for (int base = 0; base < total; base += nthr * NB) {
+    bf16x8 v[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int c = base + u * nthr + (int)threadIdx.x, cc = c < total ? c : 0;      // (clamped: unconditional loads, exact vmcnt)
+      const int r = cc / per, ch = cc - r * per;
+      v[u] = *reinterpret_cast<const bf16x8*>(w + (int64_t)r * K + ch * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int c = base + u * nthr + (int)threadIdx.x;
+      const int r = c / per, ch = c - r * per;
+      if (c < total) *reinterpret_cast<bf16x8*>(img + r * rowb + ch * 16) = v[u];
+    }
   }
 }
 __device__ __forceinline__ s16x4_m mlp_frag(const char* img, int rowb, int row, int k) { return *reinterpret_cast<const s16x4_m*>(img + row * rowb + k * 2); }
@@ -69,10 +83,13 @@ __device__ __forceinline__ void mlp_mean_rstd(const double* __restrict__ stat, i
 
 // STAT: instance-norm statistics of the rounded output (one sample), layout / reduction of gemm_nt_stream_kernel
 static constexpr int MLP_FWD_WAVES = 8;
-template <bool STAT, bool ANORM = false>
-__global__ void __launch_bounds__(MLP_FWD_WAVES * 64, 2) mlp_fwd_kernel(const bf16* __restrict__ x, int64_t ldx, const bf16* __restrict__ w1, const float* __restrict__ b1,
+// CC (round 5): channels of the block - 48 (stage 1: 63 KB of weight images, two workgroups per CU) or 96 (stage 2: 155 KB, one workgroup per CU;
+// until then two GEMM launches that wrote the hidden pre-activation and activation, 21 MB, for the backward pass to read back)
+template <bool STAT, bool ANORM = false, int CC = 48>
+__global__ void __launch_bounds__(MLP_FWD_WAVES * 64, CC == 48 ? 2 : 1) mlp_fwd_kernel(const bf16* __restrict__ x, int64_t ldx, const bf16* __restrict__ w1, const float* __restrict__ b1,
                                                          const bf16* __restrict__ w2, const float* __restrict__ b2, const bf16* __restrict__ res, int64_t ldres,
                                                          bf16* __restrict__ y, int64_t ldy, int M, double* __restrict__ stat, MlpNorm an) {
+  constexpr int MLP_C = CC, MLP_H = 4 * CC, MLP_CS = CC / 16, MLP_HS = MLP_H / 16, MLP_ROW_C = CC * 2 + 16, MLP_ROW_H = MLP_H * 2 + 16;      // (shadow the stage-1 constants)
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* w1i = lds;                                  // [HID][C]
   char* w2i = w1i + MLP_H * MLP_ROW_C;              // [C][HID]
@@ -201,16 +218,20 @@ __global__ void __launch_bounds__(MLP_FWD_WAVES * 64, 2) mlp_fwd_kernel(const bf
 
 // 8 waves per workgroup: the three weight images (63 KB) allow two workgroups per CU, and 16 resident waves hide the GELU's vector work
 static constexpr int MLP_BWD_WAVES = 8;
-template <bool BSTAT>
-__global__ void __launch_bounds__(MLP_BWD_WAVES * 64, 2) mlp_bwd_kernel(const bf16* __restrict__ x, int64_t ldx, const bf16* __restrict__ dy, int64_t lddy,
+// CC = 96 (round 5): W1 and W2^T alone fill the LDS (2 x 80 KB); the A operand of dx^T += W1^T dz_j is read TRANSPOSED from the W1 image
+// (ds_read_b64_tr_b16) instead of from a third, transposed image
+template <bool BSTAT, int CC = 48>
+__global__ void __launch_bounds__(MLP_BWD_WAVES * 64, CC == 48 ? 2 : 1) mlp_bwd_kernel(const bf16* __restrict__ x, int64_t ldx, const bf16* __restrict__ dy, int64_t lddy,
                                                          const bf16* __restrict__ w1, const float* __restrict__ b1, const bf16* __restrict__ w2t,
                                                          const bf16* __restrict__ w1t, bf16* __restrict__ dz, int64_t lddz, bf16* __restrict__ h, int64_t ldh,
                                                          bf16* __restrict__ dx, int64_t lddx, int M, MlpBstat bs) {
+  constexpr int MLP_C = CC, MLP_H = 4 * CC, MLP_CS = CC / 16, MLP_HS = MLP_H / 16, MLP_ROW_C = CC * 2 + 16, MLP_ROW_H = MLP_H * 2 + 16;      // (shadow the stage-1 constants)
+  constexpr bool W1T_IMAGE = CC == 48;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* w1i = lds;                                  // [HID][C]   z = W1 x
   char* w2ti = w1i + MLP_H * MLP_ROW_C;             // [HID][C]   dh = W2^T dy
-  char* w1ti = w2ti + MLP_H * MLP_ROW_C;            // [C][HID]   dx = W1^T dz
-  float* lb1 = reinterpret_cast<float*>(w1ti + MLP_C * MLP_ROW_H);
+  char* w1ti = w2ti + MLP_H * MLP_ROW_C;            // [C][HID]   dx = W1^T dz   (CC == 48 only)
+  float* lb1 = reinterpret_cast<float*>(w1ti + (W1T_IMAGE ? MLP_C * MLP_ROW_H : 0));
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fi = lane & 15, kg = lane >> 4;
   const int mtiles = (M + 15) / 16, nwaves = gridDim.x * MLP_BWD_WAVES;
   s16x4_m xc[MLP_CS], gc[MLP_CS], xn[MLP_CS], gn[MLP_CS];
@@ -225,7 +246,7 @@ __global__ void __launch_bounds__(MLP_BWD_WAVES * 64, 2) mlp_bwd_kernel(const bf
   if (tile < mtiles) load2(tile, xc, gc);
   mlp_stage(w1i, MLP_ROW_C, w1, MLP_H, MLP_C);
   mlp_stage(w2ti, MLP_ROW_C, w2t, MLP_H, MLP_C);
-  mlp_stage(w1ti, MLP_ROW_H, w1t, MLP_C, MLP_H);
+  if constexpr (W1T_IMAGE) mlp_stage(w1ti, MLP_ROW_H, w1t, MLP_C, MLP_H);
   for (int i = tid; i < MLP_H; i += MLP_BWD_WAVES * 64) lb1[i] = b1 ? b1[i] : 0.f;
   float* lmean = lb1 + MLP_H;        // BSTAT: mean / rstd of the norm in front of the MLP
   float* lrstd = lmean + MLP_C;
@@ -270,7 +291,14 @@ __global__ void __launch_bounds__(MLP_BWD_WAVES * 64, 2) mlp_bwd_kernel(const bf
       }
       const s16x4_m db = __builtin_bit_cast(s16x4_m, d4);
 #pragma unroll
-      for (int i = 0; i < MLP_CS; ++i) dxacc[i] = mma16(mlp_frag(w1ti, MLP_ROW_H, 16 * i + fi, 16 * j + 4 * kg), db, dxacc[i]);
+      for (int i = 0; i < MLP_CS; ++i) {
+        s16x4_m wf;
+        if constexpr (W1T_IMAGE) wf = mlp_frag(w1ti, MLP_ROW_H, 16 * i + fi, 16 * j + 4 * kg);
+        else      // lane (row c = 16 i + fi, k = hidden 16 j + 4 kg ..): element [hid][c] of the W1 image, four rows down one column
+          wf = __builtin_bit_cast(s16x4_m, __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                   (__attribute__((address_space(3))) bf16x4*)(w1i + (16 * j + 4 * kg + (fi >> 2)) * MLP_ROW_C + (16 * i + 4 * (fi & 3)) * 2)));
+        dxacc[i] = mma16(wf, db, dxacc[i]);
+      }
     }
     if (live && dx) {
 #pragma unroll
@@ -316,7 +344,7 @@ __global__ void __launch_bounds__(MLP_BWD_WAVES * 64, 2) mlp_bwd_kernel(const bf
 
 using namespace miseg;
 
-extern "C" int miseg_mlp_fused(int M, int C, int HID, int dtype) { return dtype == MISEG_BF16 && C == MLP_C && HID == MLP_H && M >= 4096; }
+extern "C" int miseg_mlp_fused(int M, int C, int HID, int dtype) { return dtype == MISEG_BF16 && (C == 48 || C == 96) && HID == 4 * C && M >= 4096; }
 
 static int mlp_check(const miseg_mlp_params* p, const char* what) {
   MISEG_REQUIRE(p && p->struct_size == sizeof(miseg_mlp_params), MISEG_E_BADARG, "%s: struct_size %u != %zu (header / binding drift)", what, p ? p->struct_size : 0u,
@@ -332,8 +360,9 @@ extern "C" int miseg_mlp_fwd(const miseg_mlp_params* p, miseg_stream_t s_) {
   if (int rc = mlp_check(p, "mlp_fwd")) return rc;
   MISEG_REQUIRE(p->w2 && p->y && ((uintptr_t)p->w2 % 16) == 0 && ((uintptr_t)p->y % 8) == 0 && p->ldy % 4 == 0 && p->ldy >= p->C, MISEG_E_BADARG, "mlp_fwd: w2 / y");
   MISEG_REQUIRE(!p->res || (((uintptr_t)p->res % 8) == 0 && p->ldres % 4 == 0), MISEG_E_BADARG, "mlp_fwd: res alignment");
-  size_t lds = (size_t)MLP_H * MLP_ROW_C + (size_t)MLP_C * MLP_ROW_H + (size_t)(MLP_H + MLP_C + 2 * MLP_C) * 4;
-  const size_t red = (size_t)2 * MLP_C * (MLP_FWD_WAVES * 16 + 1) * sizeof(float);      // the statistics reduction re-uses the images
+  const int Cc = p->C, Hh = 4 * Cc, ROW_C = Cc * 2 + 16, ROW_H = Hh * 2 + 16;
+  size_t lds = (size_t)Hh * ROW_C + (size_t)Cc * ROW_H + (size_t)(Hh + Cc + 2 * Cc) * 4;
+  const size_t red = (size_t)2 * Cc * (MLP_FWD_WAVES * 16 + 1) * sizeof(float);      // the statistics reduction re-uses the images
   if (p->stat && lds < red) lds = red;
   int blocks = cdiv(cdiv(p->M, 16), MLP_FWD_WAVES);
   if (blocks > 512) blocks = 512;
@@ -345,15 +374,18 @@ extern "C" int miseg_mlp_fwd(const miseg_mlp_params* p, miseg_stream_t s_) {
     an.stat = (const double*)p->an.stat; an.styles = p->an.styles; an.eps = p->an.eps; an.out = (bf16*)p->an_out; an.ldo = p->ld_an_out;
     for (int i = 0; i < p->an.num_styles; ++i) { an.gamma[i] = p->an.gamma[i]; an.beta[i] = p->an.beta[i]; }
   }
-#define MLP_FWD_LAUNCH(ST, AN)                                                                                                                              \
+#define MLP_FWD_LAUNCH_C(ST, AN, CCV)                                                                                                                        \
   do {                                                                                                                                                      \
-    MISEG_SET_SMEM((mlp_fwd_kernel<ST, AN>), lds);                                                                                                          \
-    mlp_fwd_kernel<ST, AN><<<blocks, MLP_FWD_WAVES * 64, lds, s>>>((const bf16*)p->x, p->ldx, (const bf16*)p->w1, p->b1, (const bf16*)p->w2, p->b2,        \
-                                                                   (const bf16*)p->res, p->ldres, (bf16*)p->y, p->ldy, p->M, (double*)p->stat, an);          \
+    MISEG_SET_SMEM((mlp_fwd_kernel<ST, AN, CCV>), lds);                                                                                                     \
+    mlp_fwd_kernel<ST, AN, CCV><<<blocks, MLP_FWD_WAVES * 64, lds, s>>>((const bf16*)p->x, p->ldx, (const bf16*)p->w1, p->b1, (const bf16*)p->w2, p->b2,   \
+                                                                        (const bf16*)p->res, p->ldres, (bf16*)p->y, p->ldy, p->M, (double*)p->stat, an);     \
   } while (0)
+#define MLP_FWD_LAUNCH(ST, AN) do { if (Cc == 48) MLP_FWD_LAUNCH_C(ST, AN, 48); else MLP_FWD_LAUNCH_C(ST, AN, 96); } while (0)
+  if (Cc == 96 && blocks > 256) blocks = 256;      // (one 155 KB workgroup per CU)
   if (p->stat) { if (p->an.stat) MLP_FWD_LAUNCH(true, true); else MLP_FWD_LAUNCH(true, false); }
   else { if (p->an.stat) MLP_FWD_LAUNCH(false, true); else MLP_FWD_LAUNCH(false, false); }
 #undef MLP_FWD_LAUNCH
+#undef MLP_FWD_LAUNCH_C
   MISEG_LAUNCH_CHECK("mlp_fwd");
   return MISEG_OK;
 }
@@ -364,21 +396,26 @@ extern "C" int miseg_mlp_bwd(const miseg_mlp_params* p, miseg_stream_t s_) {
   MISEG_REQUIRE(((uintptr_t)p->dy % 8) == 0 && p->lddy % 4 == 0 && ((uintptr_t)p->dz % 8) == 0 && p->lddz % 4 == 0 && ((uintptr_t)p->h % 8) == 0 && p->ldh % 4 == 0 &&
                     (!p->dx || (((uintptr_t)p->dx % 8) == 0 && p->lddx % 4 == 0)) && ((uintptr_t)p->w2t % 16) == 0 && ((uintptr_t)p->w1t % 16) == 0,
                 MISEG_E_BADARG, "mlp_bwd: alignment");
-  const size_t lds = (size_t)2 * MLP_H * MLP_ROW_C + (size_t)MLP_C * MLP_ROW_H + (size_t)(MLP_H + 2 * MLP_C) * 4;
+  const int Cc = p->C, Hh = 4 * Cc, ROW_C = Cc * 2 + 16, ROW_H = Hh * 2 + 16;
+  const size_t lds = (size_t)2 * Hh * ROW_C + (Cc == 48 ? (size_t)Cc * ROW_H : 0) + (size_t)(Hh + 2 * Cc) * 4;
   int blocks = cdiv(cdiv(p->M, 16), MLP_BWD_WAVES);
-  if (blocks > 512) blocks = 512;
+  if (blocks > (Cc == 48 ? 512 : 256)) blocks = Cc == 48 ? 512 : 256;
   MlpBstat bs{};
   if (p->bs_dstat) {
     MISEG_REQUIRE(p->dx && p->bs_x && p->bs_stat && ((uintptr_t)p->bs_x % 8) == 0 && p->ld_bs_x % 4 == 0, MISEG_E_BADARG, "mlp_bwd: norm-backward sums need dx, bs_x (8-byte aligned rows), bs_stat");
     bs.x = (const bf16*)p->bs_x; bs.ldx = p->ld_bs_x; bs.stat_in = (const double*)p->bs_stat; bs.eps = p->bs_eps; bs.dstat = (double*)p->bs_dstat;
-    MISEG_SET_SMEM(mlp_bwd_kernel<true>, lds);
-    mlp_bwd_kernel<true><<<blocks, MLP_BWD_WAVES * 64, lds, (hipStream_t)s_>>>((const bf16*)p->x, p->ldx, (const bf16*)p->dy, p->lddy, (const bf16*)p->w1, p->b1, (const bf16*)p->w2t,
-                                                          (const bf16*)p->w1t, (bf16*)p->dz, p->lddz, (bf16*)p->h, p->ldh, (bf16*)p->dx, p->lddx, p->M, bs);
+#define MLP_BWD_LAUNCH(BS, CCV)                                                                                                                             \
+  do {                                                                                                                                                      \
+    MISEG_SET_SMEM((mlp_bwd_kernel<BS, CCV>), lds);                                                                                                         \
+    mlp_bwd_kernel<BS, CCV><<<blocks, MLP_BWD_WAVES * 64, lds, (hipStream_t)s_>>>((const bf16*)p->x, p->ldx, (const bf16*)p->dy, p->lddy, (const bf16*)p->w1, \
+                                                                                p->b1, (const bf16*)p->w2t, (const bf16*)p->w1t, (bf16*)p->dz, p->lddz,      \
+                                                                                (bf16*)p->h, p->ldh, (bf16*)p->dx, p->lddx, p->M, bs);                      \
+  } while (0)
+    if (Cc == 48) MLP_BWD_LAUNCH(true, 48); else MLP_BWD_LAUNCH(true, 96);
   } else {
-    MISEG_SET_SMEM(mlp_bwd_kernel<false>, lds);
-    mlp_bwd_kernel<false><<<blocks, MLP_BWD_WAVES * 64, lds, (hipStream_t)s_>>>((const bf16*)p->x, p->ldx, (const bf16*)p->dy, p->lddy, (const bf16*)p->w1, p->b1, (const bf16*)p->w2t,
-                                                           (const bf16*)p->w1t, (bf16*)p->dz, p->lddz, (bf16*)p->h, p->ldh, (bf16*)p->dx, p->lddx, p->M, bs);
+    if (Cc == 48) MLP_BWD_LAUNCH(false, 48); else MLP_BWD_LAUNCH(false, 96);
   }
+#undef MLP_BWD_LAUNCH
   MISEG_LAUNCH_CHECK("mlp_bwd");
   return MISEG_OK;
 }

@@ -355,18 +355,19 @@ def test_gemm_nt_epilogues(dtype, M, N, K):
     assert rel_err(ops.gemm_nt(a, w, None, gelu_grad_of=h), (z - bias) * hf.grad) < 2 * TOL[dtype]
 
 
-@pytest.mark.parametrize("M", [4096, 13829])
-def test_fused_mlp_forward_and_backward(M):
+@pytest.mark.parametrize("M,Cm", [(4096, 48), (13829, 48), (13824, 96), (4111, 96)])
+def test_fused_mlp_forward_and_backward(M, Cm):
     """the one-launch MLP of the 48-channel Swin stage (hidden tile fed from the first product's accumulator into the second) and its
     backward (pre-activation recomputed; dz, h written for the weight-gradient products) against fp32 torch on the bf16-rounded operands,
     the fused statistics against a statistics pass over y, and the two-GEMM path it replaces (MISEG_NO_FUSED_MLP, read per call)."""
     ops = _ops()
     dt = torch.bfloat16
-    x, res, dy = rnd(1, M, 48, dtype=dt, seed=81), rnd(1, M, 48, dtype=dt, seed=82), rnd(1, M, 48, dtype=dt, seed=83)
-    w1, b1 = rnd(192, 48, seed=84) / 48 ** 0.5, rnd(192, seed=85) / 4
-    w2, b2 = rnd(48, 192, seed=86) / 192 ** 0.5, rnd(48, seed=87) / 4
+    Hm = 4 * Cm      # (round 5: the 96-channel stage too - weights resident in 155 KB of LDS, W1^T read transposed in the backward kernel)
+    x, res, dy = rnd(1, M, Cm, dtype=dt, seed=81), rnd(1, M, Cm, dtype=dt, seed=82), rnd(1, M, Cm, dtype=dt, seed=83)
+    w1, b1 = rnd(Hm, Cm, seed=84) / Cm ** 0.5, rnd(Hm, seed=85) / 4
+    w2, b2 = rnd(Cm, Hm, seed=86) / Hm ** 0.5, rnd(Cm, seed=87) / 4
     w1b, w2b = w1.to(dt), w2.to(dt)
-    assert ops.mlp_fused(x, 192)
+    assert ops.mlp_fused(x, Hm)
     ops.begin_step()
     y = ops.mlp_fwd(x, w1b, b1, w2b, b2, res=res, want_stat=True)
     stat = ops.pop_gemm_stat(y)
@@ -382,7 +383,7 @@ def test_fused_mlp_forward_and_backward(M):
     assert rel_err(h, hr) < 5e-3 and rel_err(dz, dzr) < 5e-3
     assert rel_err(dx, dz.float() @ w1b.float()) < 5e-3
     # the path it replaces (pre-activation rounded to bf16 before gelu'): same results within bf16 rounding
-    pre = torch.empty(1, M, 192, dtype=dt, device=DEV)
+    pre = torch.empty(1, M, Hm, dtype=dt, device=DEV)
     a0 = ops.gemm_nt(x, w1b, b1, act=_L().ACT_GELU, preact_out=pre)
     y0 = ops.gemm_nt(a0, w2b, b2, res=res)
     assert rel_err(y, y0) < 5e-3 and rel_err(h, a0) < 5e-3
@@ -452,15 +453,16 @@ def test_gemm_with_the_norm_backward_sums_in_its_epilogue(M, K, N):
     assert rel_err(dg1[0], dg0[0]) < 1e-4 and rel_err(db1[0], db0[0]) < 1e-4 and float(dg1[1].abs().max()) == 0.0
 
 
-def test_fused_mlp_with_the_norm_folded_in_and_its_backward_sums():
+@pytest.mark.parametrize("M,Cm", [(110592, 48), (13824, 96)])
+def test_fused_mlp_with_the_norm_folded_in_and_its_backward_sums(M, Cm):
     """round 5: mlp_fwd with norm2 folded into its token load = instnorm_apply + mlp_fwd bit for bit (y, the stored norm(x), the fused output
     statistics); mlp_bwd's norm-backward sums against miseg_instnorm_bwd_reduce over its dx"""
     ops = _ops()
-    dt, M = torch.bfloat16, 110592
-    x, dy = (rnd(1, M, 48, dtype=torch.float32, seed=111) * 1.5 + 0.3).to(dt), rnd(1, M, 48, dtype=dt, seed=112)
-    w1, b1 = (rnd(192, 48, seed=113) / 48 ** 0.5).to(dt), rnd(192, seed=114) / 4
-    w2, b2 = (rnd(48, 192, seed=115) / 192 ** 0.5).to(dt), rnd(48, seed=116) / 4
-    gam, bet, styles = [rnd(48, seed=117) * 0.2 + 1.0], [rnd(48, seed=118) * 0.3], None
+    dt, Hm = torch.bfloat16, 4 * Cm
+    x, dy = (rnd(1, M, Cm, dtype=torch.float32, seed=111) * 1.5 + 0.3).to(dt), rnd(1, M, Cm, dtype=dt, seed=112)
+    w1, b1 = (rnd(Hm, Cm, seed=113) / Cm ** 0.5).to(dt), rnd(Hm, seed=114) / 4
+    w2, b2 = (rnd(Cm, Hm, seed=115) / Hm ** 0.5).to(dt), rnd(Cm, seed=116) / 4
+    gam, bet, styles = [rnd(Cm, seed=117) * 0.2 + 1.0], [rnd(Cm, seed=118) * 0.3], None
     ops.begin_step()
     stat = ops.instnorm_stats(x, 1, M)
     xn0 = ops.instnorm_apply(x, 1, M, stat, styles, gam, bet)
@@ -475,7 +477,7 @@ def test_fused_mlp_with_the_norm_folded_in_and_its_backward_sums():
     dz1, h1, dx1, dstat = ops.mlp_bwd(xn1, dy, w1, b1, w2t, w1t, bstat=(x, stat, 1e-5))
     assert torch.equal(dz0, dz1) and torch.equal(h0, h1) and torch.equal(dx0, dx1)
     want = ops.instnorm_bwd_reduce(dx0, x, 1, M, stat).sum(0)
-    got = dstat.view(-1, 1, 48, 2).sum(0)
+    got = dstat.view(-1, 1, Cm, 2).sum(0)
     scale = want.abs().max(dim=1, keepdim=True).values
     assert float(((got - want).abs() / scale).max()) < 2e-5
 
