@@ -333,6 +333,10 @@ typedef struct {
    * layout in which the ConvTranspose3d(k2, s2) in front of a decoder block reads the gradient of its output (unetr_block.py:80-85; the
    * data-gradient pass of that block's first convolution produces it, left half of the concat buffer).  Channels >= s2c_C go to y as usual. */
   void* s2c_out; int32_t s2c_C;
+  /* ABI 9, only where miseg_conv3_fuses_fwd_shortcut(...) says so: fs_y = x * fs_w^T as a SECOND output of the launch - the 1x1x1 shortcut
+   * convolution of a residual block beside its first 3x3x3 convolution (dynunet_block.py:87-97: both read the block's input).  fs_w: [Cout][Cin]
+   * in `dtype`, contiguous; fs_y: [B][D][H][W][Cout] rows (ld_fs_y); fs_stat (optional): instance-norm statistics of fs_y, as `stat` for y. */
+  const void* fs_w; void* fs_y; int64_t ld_fs_y; void* fs_stat;
 } miseg_conv3_params;
 /* small grids split the reduction over workgroups and need an fp32 staging buffer of the output */
 size_t miseg_conv3_fwd_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int dtype);
@@ -340,6 +344,8 @@ size_t miseg_conv3_fwd_workspace_bytes(int B, int D, int H, int W, int Cin, int 
 int miseg_conv3_fwd_splits(int B, int D, int H, int W, int Cin, int Cout, int dtype);
 /* 1 when miseg_conv3_fwd with these shapes can take a 1x1x1 shortcut term of sc_C channels along (miseg_conv3_params.sc_x) */
 int miseg_conv3_fuses_shortcut(int B, int D, int H, int W, int Cin, int Cout, int sc_C, int dtype);
+/* 1 when miseg_conv3_fwd with these shapes can produce a 1x1x1 convolution of its input as a second output (miseg_conv3_params.fs_w) */
+int miseg_conv3_fuses_fwd_shortcut(int B, int D, int H, int W, int Cin, int Cout, int dtype);
 /* 1 when miseg_conv3_fwd with these shapes can store its first s2c_C output channels in space-to-channel order (miseg_conv3_params.s2c_out) */
 int miseg_conv3_fuses_s2c(int B, int D, int H, int W, int Cin, int Cout, int s2c_C, int dtype);
 int miseg_conv3_fwd(const miseg_conv3_params* p, miseg_stream_t stream);

@@ -214,7 +214,9 @@ __global__ void __launch_bounds__(256, GPT == 6 ? 2 : GPT == 4 ? (NT == 1 ? 3 : 
                                                              ConvGeom g, int Cin, int CinP, int Cout, int CoP, bool vec_x, bool vec_y,
                                                              float* __restrict__ scratch, int chunks_per_split, const T* __restrict__ res, int64_t ldres,
                                                              double* __restrict__ stat, int ny, const T* __restrict__ scx = nullptr, int64_t ldscx = 0,
-                                                             const T* __restrict__ scw = nullptr, int Csc = 0, T* __restrict__ s2c_out = nullptr, int s2c_C = 0) {
+                                                             const T* __restrict__ scw = nullptr, int Csc = 0, T* __restrict__ s2c_out = nullptr, int s2c_C = 0,
+                                                             const T* __restrict__ fsw = nullptr, T* __restrict__ fsy = nullptr, int64_t ldfsy = 0,
+                                                             double* __restrict__ fsstat = nullptr) {
   typedef typename Vec16<T>::type VT;
   constexpr int KPC = MmaC<T>::KPC;
   constexpr int CHUNK = GPT * KPC, NPH = fwd96_phases(GPT);
@@ -439,9 +441,10 @@ __global__ void __launch_bounds__(256, GPT == 6 ? 2 : GPT == 4 ? (NT == 1 ? 3 : 
   // the CENTRE of the halo, two short MFMA steps per chunk (k groups 0..3, then 4..5) against W3's transposed bf16 copy [Cout][Csc] read
   // as it is.  Until now a streaming GEMM wrote g3 W3 (170 MB at 96^3, 75 us) and this kernel read it back through its residual
   // epilogue (+60 us).  bf16, 96-byte chunks, unsplit launches; EPI instantiations only.
-  if constexpr (EPI && GPT == 6 && std::is_same<T, bf16>::value) {
-    if (scx) {                        // (kernel argument: uniform)
-      for (int c0 = 0; c0 < Csc; c0 += CHUNK) {
+  // acc += src(centre tap) * wsrc^T: src rows over the same voxels, Csrc channels (a multiple of the chunk), wsrc [Cout][Csrc]
+  auto centre_term = [&](const T* __restrict__ src, int64_t ldsrc, const T* __restrict__ wsrc, int Csrc) {
+    if constexpr (EPI && GPT == 6 && std::is_same<T, bf16>::value) {
+      for (int c0 = 0; c0 < Csrc; c0 += CHUNK) {
         // the brick's OWN 256 voxels only (the centre tap reads nothing else of the halo image): 6 items of 16 bytes per thread, addressed
         // arithmetically - 8 consecutive lanes take 8 consecutive voxels of one w-row and one channel group (conflict-free LDS writes,
         // 48 lanes read 768 contiguous bytes)
@@ -458,7 +461,7 @@ __global__ void __launch_bounds__(256, GPT == 6 ? 2 : GPT == 4 ? (NT == 1 ? 3 : 
             VT val;
 #pragma unroll
             for (int e = 0; e < KPC; ++e) val[e] = from_f32<T>(0.f);
-            if (d < g.D && h < g.H && w < g.W) val = *reinterpret_cast<const VT*>(scx + (int64_t)(((b * g.D + d) * g.H + h) * g.W + w) * ldscx + c0 + (j >> 3) * KPC);
+            if (d < g.D && h < g.H && w < g.W) val = *reinterpret_cast<const VT*>(src + (int64_t)(((b * g.D + d) * g.H + h) * g.W + w) * ldsrc + c0 + (j >> 3) * KPC);
             hv[i] = val;
           }
 #pragma unroll
@@ -478,7 +481,7 @@ __global__ void __launch_bounds__(256, GPT == 6 ? 2 : GPT == 4 ? (NT == 1 ? 3 : 
 #pragma unroll
           for (int e = 0; e < KPC; ++e) v[e] = from_f32<T>(0.f);
           const int grp = img * 4 + slot;
-          if (grp < GPT && n0 + row < Cout) v = *reinterpret_cast<const VT*>(scw + (int64_t)(n0 + row) * Csc + c0 + grp * KPC);
+          if (grp < GPT && n0 + row < Cout) v = *reinterpret_cast<const VT*>(wsrc + (int64_t)(n0 + row) * Csrc + c0 + grp * KPC);
           *reinterpret_cast<VT*>(lw + (img * WITEMS + it) * 16) = v;
         }
         __syncthreads();
@@ -508,8 +511,12 @@ __global__ void __launch_bounds__(256, GPT == 6 ? 2 : GPT == 4 ? (NT == 1 ? 3 : 
         __syncthreads();              // the images are free for the next shortcut chunk / the statistics reduction of the epilogue
       }
     }
+  };
+  if constexpr (EPI) {
+    if (scx) centre_term(scx, ldscx, scw, Csc);      // (kernel argument: uniform)
   }
   // epilogue: lane holds channels n0 + 16nt + 4fq .. +3 of voxel (d0 + wave, h0 + mt, w0 + fi)
+  auto epilogue = [&](T* __restrict__ y, int64_t ldy, bool vec_y, const T* __restrict__ res, int64_t ldres, double* __restrict__ stat, T* __restrict__ s2c_out) {
   const int d = d0 + wave, w = w0 + fi;
   const bool vec_r = res && (reinterpret_cast<uintptr_t>(res) & 15) == 0 && ldres % KPC == 0;
   float ssum[NT][4], ssq[NT][4];
@@ -606,6 +613,23 @@ __global__ void __launch_bounds__(256, GPT == 6 ? 2 : GPT == 4 ? (NT == 1 ? 3 : 
 #pragma unroll 16
       for (int i = 0; i < 64; ++i) tot += rp[i];
       if (n0 + col < Cout) atomicAdd(stat + (((int64_t)(blockIdx.x & 15) * g.B + b) * Cout + n0 + col) * 2 + k, (double)tot);
+    }
+  }
+  };
+  epilogue(y, ldy, vec_y, res, ldres, stat, s2c_out);
+  // Round 5 - forward mirror of the shortcut term: the block's 1x1x1 shortcut convolution of the SAME input as a second output of this launch
+  // (dynunet_block.py:87-97,118-122: residual = conv3(inp) beside out = conv1(inp)): the accumulators start again from zero, the centre tap of
+  // the input's chunks against W3 [Cout][Cin], a second epilogue (own output, own statistics).  Until now a streaming GEMM read the input
+  // again (170 MB at 96^3).
+  if constexpr (EPI && GPT == 6 && std::is_same<T, bf16>::value) {
+    if (fsw) {
+      __syncthreads();                // the statistics reduction of the first epilogue is through with the LDS
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      centre_term(x, ldx, fsw, Cin);
+      epilogue(fsy, ldfsy, (reinterpret_cast<uintptr_t>(fsy) & 15) == 0 && ldfsy % KPC == 0, nullptr, 0, fsstat, nullptr);
     }
   }
 }
@@ -1818,6 +1842,10 @@ extern "C" int miseg_conv3_fuses_shortcut(int B, int D, int H, int W, int Cin, i
   return ks == 1 ? 1 : 0;
 }
 
+extern "C" int miseg_conv3_fuses_fwd_shortcut(int B, int D, int H, int W, int Cin, int Cout, int dtype) {
+  return miseg_conv3_fuses_shortcut(B, D, H, W, Cin, Cout, Cin, dtype);      // (the same launch conditions; the 1x1x1 term's K side is Cin itself)
+}
+
 extern "C" int miseg_conv3_fuses_s2c(int B, int D, int H, int W, int Cin, int Cout, int s2c_C, int dtype) {
   const int esz = dtype == MISEG_F32 ? 4 : 2;
   const int k96 = conv3_k96(Cin, esz, conv3_pad_min_bytes());
@@ -1871,6 +1899,12 @@ static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
                     MISEG_E_UNSUPPORTED, "conv3_fwd: fused shortcut on this shape / dtype (ask miseg_conv3_fuses_shortcut first)");
       MISEG_REQUIRE((uintptr_t)p->sc_x % 16 == 0 && p->ld_sc_x % KPC == 0 && (uintptr_t)p->sc_w % 16 == 0, MISEG_E_BADARG, "conv3_fwd: shortcut operands must be 16-byte aligned");
     }
+    if (p->fs_w) {      // the block's 1x1x1 shortcut convolution as a second output (miseg_conv3_fuses_fwd_shortcut)
+      constexpr bool is_bf16_ = std::is_same<T, bf16>::value;
+      MISEG_REQUIRE(is_bf16_ && gpt == 6 && ksplit == 1 && p->fs_y && p->Cin % (6 * KPC) == 0 && vec_x, MISEG_E_UNSUPPORTED,
+                    "conv3_fwd: second (1x1x1) output on this shape / dtype (ask miseg_conv3_fuses_fwd_shortcut first)");
+      MISEG_REQUIRE((uintptr_t)p->fs_w % 16 == 0, MISEG_E_BADARG, "conv3_fwd: fs_w must be 16-byte aligned");
+    }
     if (p->s2c_out) {   // the left channels stored in space-to-channel order (miseg_conv3_fuses_s2c)
       MISEG_REQUIRE(ksplit == 1 && p->s2c_C > 0 && p->s2c_C < p->Cout && p->s2c_C % (16 * nt) == 0 && p->D % 2 == 0 && p->H % 2 == 0 && p->W % 2 == 0,
                     MISEG_E_UNSUPPORTED, "conv3_fwd: space-to-channel store on this shape (ask miseg_conv3_fuses_s2c first)");
@@ -1886,10 +1920,10 @@ static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
     conv3_fwd96_kernel<T, n, wd, epi, gp><<<grid, 256, lds, s>>>((const T*)p->x, p->ldx, (T*)p->y, p->ldy, (const T*)p->wpk, gf, p->Cin, CinP, \
                                                                  p->Cout, CoP, vec_x, vec_y, scratch, cps, scratch ? nullptr : (const T*)p->res, \
                                                                  p->ldres, (double*)p->stat, ny, (const T*)p->sc_x, p->ld_sc_x, (const T*)p->sc_w, p->sc_C, \
-                                                                 (T*)p->s2c_out, p->s2c_C)
+                                                                 (T*)p->s2c_out, p->s2c_C, (const T*)p->fs_w, (T*)p->fs_y, p->ld_fs_y, (double*)p->fs_stat)
 #define F96_CASE(n, wd, gp)                                                                                                                  \
   case n:                                                                                                                                   \
-    if (!scratch && (p->res || p->stat || p->sc_x || p->s2c_out)) { F96_LAUNCH(n, wd, true, gp); } else { F96_LAUNCH(n, wd, false, gp); }   \
+    if (!scratch && (p->res || p->stat || p->sc_x || p->s2c_out || p->fs_w)) { F96_LAUNCH(n, wd, true, gp); } else { F96_LAUNCH(n, wd, false, gp); }   \
     break;
     if (gpt == 6) { switch (nt) { F96_CASE(1, 3, 6) F96_CASE(2, 2, 6) F96_CASE(3, 3, 6) } }
     else if (gpt == 4) { switch (nt) { F96_CASE(1, 3, 4) F96_CASE(2, 2, 4) F96_CASE(3, 3, 4) } }

@@ -869,6 +869,84 @@ class _Conv3(Function):
         return dx, dw, None, None, None, None
 
 
+class _Conv3Shortcut(Function):
+    """(y, stat, y3, stat3) = (conv3x3x3(x, w1), conv1x1x1(x, w3)) - the first convolution of a residual block and the block's shortcut convolution
+    (dynunet_block.py:87-97,100-126: both read the block's input) as ONE launch in both directions where the kernel can (round 5):
+    forward, the shortcut's output is a second pass of the 3x3x3 launch over the centre tap (ops.conv3_fwd(fs=)); backward, its data gradient is
+    one more centre tap of the 3x3x3 data-gradient launch (sc=) and, for a concat input, the transposed convolution's half of the result
+    leaves in space-to-channel order (s2c=).  Elsewhere the separate GEMMs run."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w3, want_stat, s2c_left):
+        need_dx = ctx.needs_input_grad[0]
+        fwdp, bwdp = ops.pack_conv3(w1, x.dtype, True, need_dx)
+        Cout = w1.shape[0]
+        w3c = ops.cast_matrix(w3, x.dtype).view(w3.shape[0], -1)
+        if ops.conv3_fuses_fwd_shortcut(x, Cout) and w3c.is_contiguous():
+            y, stat, y3, stat3 = ops.conv3_fwd(x, fwdp, Cout, want_stat=want_stat, fs=(w3c, True))
+        else:
+            y, stat = ops.conv3_fwd(x, fwdp, Cout, want_stat=want_stat) if want_stat else (ops.conv3_fwd(x, fwdp, Cout), None)
+            y3 = ops.gemm_nt(x, w3c, want_stat=True)
+            stat3 = ops.pop_gemm_stat(y3)
+        ctx.save_for_backward(x, bwdp, w3)
+        ctx.wshape = w1.shape
+        ctx.params = (w1, w3)
+        ctx.s2c_left = int(s2c_left)
+        ctx.set_materialize_grads(False)
+        for st in (stat, stat3):
+            if isinstance(st, torch.Tensor):
+                ctx.mark_non_differentiable(st)
+        return y, stat, y3, stat3
+
+    @staticmethod
+    def backward(ctx, dy, _dstat, dy3, _dstat3):
+        x, bwdp, w3 = ctx.saved_tensors
+        dy, dy3 = _rv(dy), _rv(dy3)
+        Cin = ctx.wshape[1]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            w3t = ops.cast_matrix(w3, dy.dtype, transpose=True)      # [Cin][Cout3]
+            fold = (dy3.dtype == torch.bfloat16 and dy3.data_ptr() % 16 == 0 and ops.rows(dy3)[0] % 8 == 0 and w3t.is_contiguous()
+                    and ops.conv3_fuses_shortcut(dy, Cin, dy3.shape[-1]))
+            gskip = None if fold else ops.gemm_nt(dy3, w3t)
+            dy8 = None
+            if ctx.s2c_left and ops.conv3_fuses_s2c(dy, Cin, ctx.s2c_left):
+                B_, D_, H_, W_ = x.shape[:4]
+                dy8 = torch.empty(B_, D_ // 2, H_ // 2, W_ // 2, 8 * ctx.s2c_left, dtype=dy.dtype, device=dy.device)
+            dx = ops.conv3_fwd(dy, bwdp, Cin, res=gskip, sc=(dy3, w3t) if fold else None, s2c=dy8)
+            if dy8 is not None:
+                ops.pending_dx_put(dx, ("dy8", dy8))
+        dw1 = dw3 = None
+        if ctx.needs_input_grad[1]:
+            slot, mode = _slot_first(ctx.params[0])
+            if slot is not None and ops.defer_to_branch(x, dy, slot, mode):
+                pass
+            elif slot is not None:
+                with ops.wgrad_side(x, dy, kind="conv"):
+                    ops.conv3_wgrad(x, dy, dw=slot, accumulate=mode)
+            else:
+                dw1 = ops.conv3_wgrad(x, dy)
+        if ctx.needs_input_grad[2]:
+            slot, mode = _slot_first(ctx.params[1])
+            if slot is not None:
+                with ops.wgrad_side(dy3, x):
+                    ops.gemm_tn(dy3, x, out=slot, accumulate=mode)
+            else:
+                dw3 = ops.gemm_tn(dy3, x).view(w3.shape)
+        return dx, dw1, dw3, None, None
+
+
+def conv3_shortcut(x, w1, w3, want_stat=False):
+    """(out, stat, shortcut output) of a residual block with a shortcut convolution; None where this form does not apply (the caller composes
+    conv3(fork=True) + conv1)"""
+    if not (x.dtype == torch.bfloat16 and x.dim() == 5 and x.requires_grad and _one_sample(x) and ops.conv3_fuses_fwd_shortcut(x, w1.shape[0])):
+        return None
+    y, st, y3, st3 = _Conv3Shortcut.apply(x, w1, w3, want_stat, getattr(x, "_miseg_upcat", 0))
+    if st3 is not None:
+        y3._miseg_stat = st3      # (what conv1(want_stat=True) leaves on its result: the pair norm behind it skips its statistics pass)
+    return y, st, y3
+
+
 def conv3(x, weight, want_stat=False, fork=False, dx_to_norm=False):
     r = _Conv3.apply(x, weight, want_stat, fork, dx_to_norm, getattr(x, "_miseg_upcat", 0) if x.requires_grad else 0)
     if fork and x.dtype == torch.bfloat16 and x.requires_grad and x.dim() == 5:

@@ -67,7 +67,8 @@ GemmTnDesc = _struct("GemmTnDesc", cname="miseg_gemm_tn_desc", fields=[("A", vp)
 Colsum = _struct("Colsum", cname="miseg_colsum_params", fields=[("x", vp), ("ldx", i64), ("rows", i64), ("C", i32), ("dtype", i32), ("out", vp), ("accumulate", i32)])
 Conv3 = _struct("Conv3", cname="miseg_conv3_params", fields=[("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("wpk", vp), ("B", i32), ("D", i32), ("H", i32),
                           ("W", i32), ("Cin", i32), ("Cout", i32), ("dtype", i32), ("workspace", vp), ("res", vp), ("ldres", i64), ("stat", vp), ("background", i32), ("defer_slabs", i32),
-                          ("sc_x", vp), ("ld_sc_x", i64), ("sc_w", vp), ("sc_C", i32), ("s2c_out", vp), ("s2c_C", i32)])
+                          ("sc_x", vp), ("ld_sc_x", i64), ("sc_w", vp), ("sc_C", i32), ("s2c_out", vp), ("s2c_C", i32),
+                          ("fs_w", vp), ("fs_y", vp), ("ld_fs_y", i64), ("fs_stat", vp)])
 PackConv3Desc = _struct("PackConv3Desc", cname="miseg_pack_conv3_desc", fields=[("w", vp), ("fwd_pack", vp), ("bwd_pack", vp), ("Cin", i32), ("Cout", i32), ("tile0", i32), ("pad_", i32)])
 PackConv3 = _struct("PackConv3", cname="miseg_pack_conv3_params", fields=[("w", vp), ("fwd_pack", vp), ("bwd_pack", vp), ("Cin", i32), ("Cout", i32), ("dtype", i32)])
 Conv3Wgrad = _struct("Conv3Wgrad", cname="miseg_conv3_wgrad_params", fields=[("x", vp), ("ldx", i64), ("dy", vp), ("lddy", i64), ("dw", vp), ("B", i32), ("D", i32),
@@ -164,6 +165,7 @@ PROTOS = {
     "miseg_conv3_fwd_splits": (i32, [i32, i32, i32, i32, i32, i32, i32]),
     "miseg_conv3_fuses_shortcut": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
     "miseg_conv3_fuses_s2c": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
+    "miseg_conv3_fuses_fwd_shortcut": (i32, [i32, i32, i32, i32, i32, i32, i32]),
     "miseg_instnorm_fwd": (i32, [C.POINTER(InstnormApply), vp]),
     "miseg_instnorm_bwd": (i32, [C.POINTER(InstnormBwd), vp]),
     "miseg_instnorm_pair_bwd": (i32, [C.POINTER(InstnormPairBwd), vp]),

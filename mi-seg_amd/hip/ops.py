@@ -1152,14 +1152,28 @@ def conv3_fuses_s2c(x, Cout, C_left):
     return bool(L.load().miseg_conv3_fuses_s2c(B, D, H, W, rows(x)[2], Cout, C_left, _dt(x)))
 
 
-def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False, defer=False, sc=None, s2c=None):
+FOLD_FWD_SHORTCUT = os.environ.get("MISEG_NO_FS_FOLD") is None      # A/B switch of round 5 (conv3_fwd(fs=))
+
+
+def conv3_fuses_fwd_shortcut(x, Cout):
+    """can conv3_fwd(x, ..., Cout, fs=...) produce the 1x1x1 convolution of x as a second output (miseg_conv3_params.fs_w)?"""
+    if not FOLD_FWD_SHORTCUT or x.dtype != torch.bfloat16:
+        return False
+    B, D, H, W = _vol(x)
+    ld, _, Cin = rows(x)
+    return bool(L.load().miseg_conv3_fuses_fwd_shortcut(B, D, H, W, Cin, Cout, _dt(x))) and x.data_ptr() % 16 == 0 and ld % 8 == 0
+
+
+def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False, defer=False, sc=None, s2c=None, fs=None):
     """x [B,D,H,W,Cin] rows view; wpk [Cout][27][CinP].  res: rows view added to the result in the epilogue (falls back to a separate
     add where the kernel path cannot fuse it).  want_stat: returns (out, stat) with stat the instance-norm statistics of `out`
     ([16, B, Cout, 2] fp64, from the kernel's epilogue) or None where that is not available (the caller's norm then computes them).
     sc = (g, w) (after conv3_fuses_shortcut said yes): out += g @ w^T, g a rows view over the same voxels, w [Cout, Csc] contiguous in x's
     dtype - the 1x1x1 shortcut term of a residual block's data gradient.
     s2c = tensor [B, D/2, H/2, W/2, 8 * C_left] (after conv3_fuses_s2c said yes): the first C_left output channels are stored THERE, in
-    space-to-channel order (block j = 4 (d&1) + 2 (h&1) + (w&1)), and not in `out`."""
+    space-to-channel order (block j = 4 (d&1) + 2 (h&1) + (w&1)), and not in `out`.
+    fs = (w [Cout, Cin] contiguous in x's dtype, want_stat2) (after conv3_fuses_fwd_shortcut said yes; not with defer): the launch also produces
+    y2 = x @ w^T - a residual block's 1x1x1 shortcut convolution - and the return value is (out, stat | None, y2, stat2 | None)."""
     B, D, H, W = _vol(x)
     ld, n, Cin = rows(x)
     if out is None:
@@ -1189,10 +1203,23 @@ def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False, defer=False, sc
         assert fast and nsc == n and scw.is_contiguous() and tuple(scw.shape) == (Cout, Csc) and scw.dtype == x.dtype == scx.dtype
         flops += 2.0 * n * Csc * Cout
         nbytes += float(x.element_size()) * (n * Csc + scw.numel())
+    fsw = y2 = stat2 = None
+    if fs is not None:
+        fsw, want2 = fs
+        assert fast and not defer_req and fsw.is_contiguous() and tuple(fsw.shape) == (Cout, Cin) and fsw.dtype == x.dtype
+        y2 = torch.empty(B, D, H, W, Cout, dtype=x.dtype, device=x.device)
+        if want2:
+            stat2 = STAT_POOL.take(lib.miseg_instnorm_stat_bytes(B, Cout) // 8, x.device).view(-1, B, Cout, 2)
+        flops += 2.0 * n * Cin * Cout
+        nbytes += float(x.element_size()) * (n * Cout + fsw.numel())
     mk = lambda st: L.Conv3(_ptr(x), ld, _ptr(out), rows(out)[0], _ptr(wpk), B, D, H, W, Cin, Cout, _dt(x), _ptr(ws),
                             _ptr(res) if fuse_res else None, rows(res)[0] if fuse_res else 0, _ptr(st), bg, 1 if defer else 0,
-                            _ptr(scx), ldsc, _ptr(scw), Csc, _ptr(s2c), (s2c.shape[-1] // 8) if s2c is not None else 0)
+                            _ptr(scx), ldsc, _ptr(scw), Csc, _ptr(s2c), (s2c.shape[-1] // 8) if s2c is not None else 0,
+                            _ptr(fsw), _ptr(y2), Cout if y2 is not None else 0, _ptr(stat2))
     _call("miseg_conv3_fwd", mk(stat), prof=(name, flops, nbytes))
+    if fs is not None:
+        assert res is None or fuse_res
+        return out, stat, y2, stat2
     if res is not None and not fuse_res:
         out = add(out, res)
     if defer:

@@ -94,6 +94,7 @@ class UnetResBlock(nn.Module):
         """inp: channels-last activation; for a block fed by the raw image pass ``image`` (NCDHW fp32) instead.
         out_view: rows view the result is written into (HF.concat_buffer)."""
         _needs_modalities(self.norm1, styles)
+        shortcut_done = False
         if image is not None and image.shape[1] != 1:
             # multi-channel image (--in_channels > 1, dynunet_block.py:82-98): rows of C channels through the ordinary kernels; the
             # one-channel shortcuts below (rank-1 1x1x1 convolution, image-as-rows view) are a special case of the headline configuration
@@ -105,7 +106,15 @@ class UnetResBlock(nn.Module):
         elif inp.requires_grad:
             # conv1 hands its input back as the residual branch (its data-gradient epilogue adds that branch's gradient) and the
             # statistics of its output come from its epilogue
-            out, st1, residual = HF.conv3(inp, self.conv1.conv.weight, want_stat=stat_request(self.norm1), fork=True)
+            sc3 = None
+            if self.downsample:      # (only where the launch does not split its reduction: a "defer" request would not defer there either)
+                # round 5: the shortcut convolution rides in conv1's launches - forward as a second output, backward as one more centre tap
+                sc3 = HF.conv3_shortcut(inp, self.conv1.conv.weight, self.conv3.conv.weight, want_stat=True)
+            if sc3 is not None:
+                out, st1, residual = sc3
+                shortcut_done = True
+            else:
+                out, st1, residual = HF.conv3(inp, self.conv1.conv.weight, want_stat=stat_request(self.norm1), fork=True)
         else:
             (out, st1), residual = HF.conv3(inp, self.conv1.conv.weight, want_stat=stat_request(self.norm1)), inp
         out = apply_norm(self.norm1, out, styles, act=L.ACT_LEAKY, slope=LEAKY_SLOPE, stat=st1)
@@ -118,7 +127,8 @@ class UnetResBlock(nn.Module):
                                         w1=self.conv3.conv.weight)
                 if y is not None:
                     return y
-            residual = HF.conv1(residual, self.conv3.conv.weight, want_stat=True)
+            if not shortcut_done:
+                residual = HF.conv1(residual, self.conv3.conv.weight, want_stat=True)
             y = apply_res_norm_pair(self.norm2, out, self.norm3, residual, styles, slope=LEAKY_SLOPE, stat_a=st2, out=out_view)
             if y is not None:           # the shortcut's norm rides in the final apply pass
                 return y

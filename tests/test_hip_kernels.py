@@ -637,6 +637,26 @@ def test_conv3_stores_its_left_channels_in_space_to_channel_order(dtype, B, D, H
     assert not ops.conv3_fuses_s2c(rnd(1, 15, 16, 32, Cin, dtype=dtype, seed=1), Cout, Cl)      # odd extent
 
 
+@pytest.mark.parametrize("B,D,H,W,Cin,Cout", [(1, 32, 32, 64, 96, 48), (1, 33, 31, 65, 96, 48), (1, 16, 16, 16, 48, 96)])
+def test_conv3_with_the_shortcut_convolution_as_a_second_output(B, D, H, W, Cin, Cout):
+    """round 5 (miseg_conv3_params.fs_w): y = conv3x3x3(x, w1) and y3 = conv1x1x1(x, w3) from ONE launch, each with its instance-norm statistics -
+    against the 3x3x3 launch and the GEMM it replaces (bit-identical first output; second output within bf16 rounding of the GEMM's)."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    x, w = _conv_case(dtype, B, D, H, W, Cin, Cout, seed=41)
+    fwdp, _ = ops.pack_conv3(w, dtype)
+    w3 = (rnd(Cout, Cin, seed=42) / Cin ** 0.5).to(dtype)
+    assert ops.conv3_fuses_fwd_shortcut(x, Cout)
+    ops.begin_step()
+    y0, st0 = ops.conv3_fwd(x, fwdp, Cout, want_stat=True)
+    y, st, y3, st3 = ops.conv3_fwd(x, fwdp, Cout, want_stat=True, fs=(w3, True))
+    assert torch.equal(y, y0) and torch.allclose(st.sum(0), st0.sum(0), rtol=1e-9, atol=1e-6)
+    ref3 = x.float() @ w3.float().t()
+    assert rel_err(y3.float(), ref3) < TOL[dtype]
+    assert rel_err(y3.float(), ops.gemm_nt(x, w3).float()) < TOL[dtype]
+    assert torch.allclose(st3.sum(0), ops.instnorm_stats(y3, B, D * H * W).sum(0), rtol=1e-5, atol=1e-3)
+
+
 def test_conv3_shortcut_is_refused_where_the_launch_splits():
     ops = _ops()
     x = rnd(1, 6, 6, 6, 384, dtype=torch.bfloat16, seed=3)
