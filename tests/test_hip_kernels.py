@@ -766,6 +766,31 @@ def test_conv3_wgrad_tiny_volumes(B, S, Cin, Cout):
     assert rel_err(ops.conv3_wgrad(xs, dys), ref2) < 1e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_tn_grouped_launch_with_both_tile_forms(dtype):
+    """the queued small weight-gradient GEMMs of a step in one grouped call: products with large outputs and a short reduction (the ViT shapes:
+    216 tokens, 768 .. 3072 channels a side) take 128 x 128 tiles (round 5, bf16), the others 64 x 64; accumulate modes 1 (add to what the slot
+    holds) and 2 (the slot is known to hold zeros)."""
+    ops = _ops()
+    shapes = [(216, 768, 3072), (216, 2304, 768), (1728, 192, 768), (216, 384, 1536), (27, 768, 3072), (216, 768, 768), (300, 640, 512), (216, 100, 72)]
+    for mode in (1, 2):
+        ops.DEFAULT_QUEUES = ops.StepQueues()
+        try:
+            cases = []
+            for i, (K, M, N) in enumerate(shapes):
+                a, b = rnd(K, M, dtype=dtype, seed=200 + i), rnd(K, N, dtype=dtype, seed=300 + i)
+                out = torch.full((M, N), 0.25, device=DEV) if mode == 1 else torch.zeros(M, N, device=DEV)
+                ops.gemm_tn(a, b, out=out, accumulate=mode)
+                cases.append((a, b, out))
+            assert len(ops.DEFAULT_QUEUES.gemm_tn) == len(shapes)
+            ops.DEFAULT_QUEUES.flush()
+        finally:
+            ops.DEFAULT_QUEUES = None
+        for a, b, out in cases:
+            ref = a.double().t() @ b.double()
+            assert rel_err(out - (0.25 if mode == 1 else 0.0), ref.float()) < (1e-5 if dtype == torch.float32 else 2e-5), (mode, tuple(a.shape), tuple(b.shape))
+
+
 @pytest.mark.parametrize("K,M,N", [(110592, 144, 48), (13824, 96, 384), (5000, 48, 96), (4096, 96, 40)])
 def test_gemm_tn_with_the_bias_gradient_in_its_launch(K, M, N):
     """round 5 (miseg_gemm_params.tn_colsum): dW = dy^T x of a linear layer carries db = column sums of dy where the product takes the
