@@ -342,6 +342,9 @@ typedef struct {
 size_t miseg_conv3_fwd_workspace_bytes(int B, int D, int H, int W, int Cin, int Cout, int dtype);
 /* number of partial slabs the launch leaves in `workspace` (1 = no split: y is written directly) */
 int miseg_conv3_fwd_splits(int B, int D, int H, int W, int Cin, int Cout, int dtype);
+/* 1 when miseg_conv3_fwd serves these shapes with its tiny-volume weight-streaming kernel (ABI 9: 3^3 / 6^3 voxels, hundreds of channels, bf16, aligned
+ * operands) - information for a host that names / times launches; the call and its results are the same either way */
+int miseg_conv3_fwd_tiny(int B, int D, int H, int W, int Cin, int Cout, int dtype);
 /* 1 when miseg_conv3_fwd with these shapes can take a 1x1x1 shortcut term of sc_C channels along (miseg_conv3_params.sc_x) */
 int miseg_conv3_fuses_shortcut(int B, int D, int H, int W, int Cin, int Cout, int sc_C, int dtype);
 /* 1 when miseg_conv3_fwd with these shapes can produce a 1x1x1 convolution of its input as a second output (miseg_conv3_params.fs_w) */

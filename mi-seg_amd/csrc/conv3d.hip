@@ -635,6 +635,91 @@ __global__ void __launch_bounds__(256, GPT == 6 ? 2 : GPT == 4 ? (NT == 1 ? 3 : 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Round 5 - forward / data gradient on TINY volumes (3^3, 6^3: encoder10 / decoder5 of the headline net, 384 - 768 channels): weight streaming.
+// The brick kernel above spends a 256-voxel brick on 27 or 216 voxels (one or two bricks per layer), walks 14 barrier-separated phases per
+// chunk and keeps 27 KB of weights in flight per workgroup: 13 - 35 us per launch for 8 - 32 MB of weights.  Here a WAVE owns 16 output
+// channels of one 48-channel chunk: its B operands are 16-byte loads straight from the phase-ordered pack (every byte read once, a whole
+// phase - three k-steps - requested while the previous one feeds the matrix pipe, no LDS, no barrier in the loop), the A operands come from
+// a zero-bordered copy of the chunk's volume in LDS (row stride 112 bytes: conflict-free for the 16 rows of a fragment), the result is one
+// fp32 slab per chunk - the split-K slabs the brick kernel writes for these layers, summed by the same second launch / the consumer norm.
+// ---------------------------------------------------------------------------------------------------------
+static constexpr int TINY_ROWB = 112;
+template <int MT /* 16-voxel M tiles per wave */, int MG /* waves that share an output tile and split the voxels: 1 (<= 32 voxels, MT = 2) or 4 (<= 256, MT = 4) */>
+__global__ void __launch_bounds__(256) conv3_fwd_tiny_kernel(const bf16* __restrict__ x, int64_t ldx, const bf16* __restrict__ wpk, int D, int H, int W, int Cin,
+                                                             int Cout, int CoP, float* __restrict__ scratch, int nvox_total) {
+  constexpr int NPH = 14, KPC = 8;
+  extern __shared__ __attribute__((aligned(16))) char lds[];      // [(D + 2)(H + 2)(W + 2) rows][112 B], zero border
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fi = lane & 15, fq = lane >> 4;
+  const int chunk = blockIdx.y, b = blockIdx.z, nvox = D * H * W;
+  const int HP = H + 2, WP = W + 2, nrows = (D + 2) * HP * WP;
+  for (int i = tid; i < nrows * (TINY_ROWB / 16); i += 256) *reinterpret_cast<f32x4*>(lds + i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  for (int i = tid; i < nvox * 6; i += 256) {
+    const int v = i / 6, cg = i - v * 6;
+    const int d = v / (H * W), r = v - d * (H * W), h = r / W, w = r - h * W;
+    const int c = chunk * 48 + cg * KPC;
+    bf16x8 val;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) val[e] = (bf16)0.f;
+    if (c + KPC <= Cin) val = *reinterpret_cast<const bf16x8*>(x + ((int64_t)b * nvox + v) * ldx + c);
+    *reinterpret_cast<bf16x8*>(lds + (((d + 1) * HP + h + 1) * WP + w + 1) * TINY_ROWB + cg * 16) = val;
+  }
+  __syncthreads();
+  const int ct = blockIdx.x * (4 / MG) + wave / MG, mg = wave % MG;      // 16-channel output tile of this wave, its share of the voxels
+  if (ct * 16 >= CoP) return;                // (no barrier behind this point)
+  // halo row (tap (0, 0, 0)) of this lane's voxel in every M tile; voxels beyond the volume read the zero corner row 0
+  int rbase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int v = (mg * MT + mt) * 16 + fi;
+    const int d = v / (H * W), r = v - d * (H * W), h = r / W, w = r - h * W;
+    rbase[mt] = v < nvox ? ((d * HP + h) * WP + w) * TINY_ROWB : -1;
+  }
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16* wph = wpk + ((int64_t)chunk * NPH * FWD96_GROUPS * CoP + (int64_t)ct * 16 + fi) * KPC;      // + (phase * 12 + kh * 4 + fq) * CoP * KPC
+  bf16x8 wf[2][3];
+  auto wload = [&](int phase, int buf) {
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) wf[buf][kh] = *reinterpret_cast<const bf16x8*>(wph + (int64_t)((phase * FWD96_GROUPS + kh * 4 + fq) * CoP) * KPC);
+  };
+  wload(0, 0);
+#pragma unroll
+  for (int phase = 0; phase < NPH; ++phase) {
+    if (phase + 1 < NPH) wload(phase + 1, (phase + 1) & 1);
+    // this lane's (kd, kw, channel group) of the phase (the table at fwd96_phases): slot fq
+    int kdw, cg;
+    if (phase < 9) { kdw = phase; cg = fq; }
+    else { kdw = 2 * (phase - 9) + (fq >> 1); cg = 4 + (fq & 1); if (kdw > 8) kdw = 8; }      // (kdw == 9: the dummy slots - zero weights, any row)
+    const int koff = ((kdw / 3) * HP * WP + (kdw % 3)) * TINY_ROWB + cg * 16;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int off = koff + kh * WP * TINY_ROWB;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(lds + (rbase[mt] >= 0 ? rbase[mt] + off : 0));
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[phase & 1][kh], af, acc[mt], 0, 0, 0);
+      }
+    }
+  }
+  // lane: channels ct * 16 + 4 fq .. + 3 of voxel mt * 16 + fi -> the chunk's slab [split = chunk][voxel][Cout]
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int v = (mg * MT + mt) * 16 + fi, co = ct * 16 + fq * 4;
+    if (v < nvox) {
+      float* sl = scratch + ((int64_t)chunk * nvox_total + (int64_t)b * nvox + v) * Cout + co;
+      if (co + 3 < Cout) *reinterpret_cast<f32x4*>(sl) = acc[mt];
+      else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (co + r < Cout) sl[r] = acc[mt][r];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // weight packing.  Row-major packs (generic kernel):   fwd[co][tap][ciP] = w[co][ci][tap] ; bwd[ci][tap][coP] = w[co][ci][26-tap]
 // Planar packs (fast path, chosen when the K-side channel row is a multiple of 96 bytes):
 //   fwd[tap][ci / KPC][coP16][ci % KPC] = w[co][ci][tap]        bwd[tap][co / KPC][ciP16][co % KPC] = w[co][ci][26 - tap]
@@ -1842,6 +1927,17 @@ extern "C" int miseg_conv3_fuses_shortcut(int B, int D, int H, int W, int Cin, i
   return ks == 1 ? 1 : 0;
 }
 
+// 1 when miseg_conv3_fwd serves this problem with the tiny-volume weight-streaming kernel (conv3_fwd_tiny_kernel): the same predicate as its launch
+extern "C" int miseg_conv3_fwd_tiny(int B, int D, int H, int W, int Cin, int Cout, int dtype) {
+  if (dtype != MISEG_BF16 || Cin % 8 != 0) return 0;
+  const int k96 = conv3_k96(Cin, 2, conv3_pad_min_bytes());
+  if (!k96 || conv3_gpt(Cin, 2, conv3_pad_min_bytes()) != 6) return 0;
+  const int nchunks = k96 * 2 / 96, nvox = D * H * W;
+  int nt, ks;
+  fwd96_plan(B * cdiv(D, FBD) * cdiv(H, FBH) * cdiv(W, FBW), Cout, nchunks, &nt, &ks);
+  return (ks > 1 && ks == nchunks && nvox <= 256 && (size_t)(D + 2) * (H + 2) * (W + 2) * TINY_ROWB <= 64 * 1024) ? 1 : 0;
+}
+
 extern "C" int miseg_conv3_fuses_fwd_shortcut(int B, int D, int H, int W, int Cin, int Cout, int dtype) {
   return miseg_conv3_fuses_shortcut(B, D, H, W, Cin, Cout, Cin, dtype);      // (the same launch conditions; the 1x1x1 term's K side is Cin itself)
 }
@@ -1914,6 +2010,29 @@ static int conv3_fwd_launch(const miseg_conv3_params* p, hipStream_t s) {
     if (p->background && lds < 83 * 1024) lds = 83 * 1024;      // more than half of the 160 KB: one workgroup per CU
     MISEG_REQUIRE((int64_t)p->B * p->D * p->H * p->W < (1LL << 31), MISEG_E_UNSUPPORTED, "conv3_fwd: more than 2^31 voxels");
     const int ny = cdiv(p->Cout, 16 * nt);
+    if constexpr (std::is_same<T, bf16>::value) {
+      // tiny volumes whose every chunk is a split of its own: the weight-streaming kernel (same pack, same slabs)
+      const int nvox = p->D * p->H * p->W;
+      if (scratch && gpt == 6 && ksplit == nchunks && nvox <= 256 && vec_x && !p->background && p->Cin % 8 == 0 &&
+          (size_t)(p->D + 2) * (p->H + 2) * (p->W + 2) * TINY_ROWB <= 64 * 1024) {
+        const size_t lds_t = (size_t)(p->D + 2) * (p->H + 2) * (p->W + 2) * TINY_ROWB;
+        if (nvox <= 32) {
+          dim3 gt(cdiv(CoP / 16, 4), nchunks, p->B);
+          (void)hipFuncSetAttribute((const void*)conv3_fwd_tiny_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
+          conv3_fwd_tiny_kernel<2, 1><<<gt, 256, lds_t, s>>>((const bf16*)p->x, p->ldx, (const bf16*)p->wpk, p->D, p->H, p->W, p->Cin, p->Cout, CoP, scratch, p->B * nvox);
+        } else {
+          dim3 gt(CoP / 16, nchunks, p->B);
+          (void)hipFuncSetAttribute((const void*)conv3_fwd_tiny_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
+          conv3_fwd_tiny_kernel<4, 4><<<gt, 256, lds_t, s>>>((const bf16*)p->x, p->ldx, (const bf16*)p->wpk, p->D, p->H, p->W, p->Cin, p->Cout, CoP, scratch, p->B * nvox);
+        }
+        MISEG_LAUNCH_CHECK("conv3_fwd_tiny");
+        if (p->defer_slabs) {
+          MISEG_REQUIRE(!p->res, MISEG_E_UNSUPPORTED, "conv3_fwd: defer_slabs with a fused residual");
+          return MISEG_OK;
+        }
+        return slabs_to_out_stats(scratch, ksplit, p->y, p->ldy, p->res, p->ldres, p->B, nvox, p->Cout, p->dtype, (double*)p->stat, s);
+      }
+    }
     dim3 grid(nbr * ny, 1, ksplit);
 #define F96_LAUNCH(n, wd, epi, gp)                                                                                                           \
     (void)hipFuncSetAttribute((const void*)conv3_fwd96_kernel<T, n, wd, epi, gp>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \

@@ -164,6 +164,7 @@ PROTOS = {
     "miseg_instnorm_fused_max_rows": (i32, []),
     "miseg_conv3_fwd_splits": (i32, [i32, i32, i32, i32, i32, i32, i32]),
     "miseg_conv3_fuses_shortcut": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
+    "miseg_conv3_fwd_tiny": (i32, [i32, i32, i32, i32, i32, i32, i32]),
     "miseg_conv3_fuses_s2c": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
     "miseg_conv3_fuses_fwd_shortcut": (i32, [i32, i32, i32, i32, i32, i32, i32]),
     "miseg_instnorm_fwd": (i32, [C.POINTER(InstnormApply), vp]),

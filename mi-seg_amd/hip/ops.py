@@ -1184,7 +1184,9 @@ def conv3_fwd(x, wpk, Cout, out=None, res=None, want_stat=False, defer=False, sc
     flops = 2.0 * B * D * H * W * 27 * Cin * Cout
     fast = lib.miseg_conv3_k96(Cin, _dt(x)) != 0      # 96-byte chunks (padded where the rows are wide enough to pay for it)
     bg = 1 if (fast and _background()) else 0
-    name = f"conv3_fwd{'96' if fast else ''}_kernel<{'bf16' if x.dtype == torch.bfloat16 else 'f32'}>" + (" (background)" if bg else "")
+    tiny_k = fast and not bg and x.data_ptr() % 16 == 0 and ld % 8 == 0 and bool(lib.miseg_conv3_fwd_tiny(B, D, H, W, Cin, Cout, _dt(x)))
+    name = (f"conv3_fwd{'_tiny' if tiny_k else '96' if fast else ''}_kernel<{'bf16' if x.dtype == torch.bfloat16 else 'f32'}>"
+            + (" (background)" if bg else ""))
     fuse_res = res is not None and fast and res.dtype == x.dtype       # (the roofline leg times the launches exactly as the step issues them)
     # algorithmic bytes: x read once, y written once, the weight pack, the fused residual read once
     nbytes = float(x.element_size()) * (B * D * H * W * (Cin + Cout + (Cout if fuse_res else 0)) + wpk.numel())

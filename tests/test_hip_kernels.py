@@ -657,6 +657,33 @@ def test_conv3_with_the_shortcut_convolution_as_a_second_output(B, D, H, W, Cin,
     assert torch.allclose(st3.sum(0), ops.instnorm_stats(y3, B, D * H * W).sum(0), rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("B,S,Cin,Cout", [(1, 3, 768, 768), (2, 3, 96, 96), (1, 6, 384, 768), (2, 6, 96, 48), (1, 6, 144, 40)])
+def test_conv3_tiny_volume_weight_streaming_kernel(B, S, Cin, Cout):
+    """round 5 (conv3_fwd_tiny_kernel): 3^3 / 6^3 volumes whose every 48-channel chunk is a split of its own - a wave streams the pack's
+    fragments for its 16 output channels straight into the matrix pipe, the chunk's volume sits zero-bordered in LDS; same slabs, same second
+    launch as the brick kernel.  Against F.conv3d on the bf16-rounded operands, forward and data gradient."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    x, w = _conv_case(dtype, B, S, S, S, Cin, Cout, seed=61)
+    assert ops.L.load().miseg_conv3_fwd_tiny(B, S, S, S, Cin, Cout, ops.L.BF16) == 1
+    fwdp, bwdp = ops.pack_conv3(w, dtype)
+    y = ops.conv3_fwd(x, fwdp, Cout)
+    wq = w.to(dtype).float()
+    ref = F.conv3d(x.float().permute(0, 4, 1, 2, 3), wq, padding=1)
+    assert rel_err(y.permute(0, 4, 1, 2, 3), ref) < TOL[dtype]
+    dy = rnd(B, S, S, S, Cout, dtype=dtype, seed=62)
+    dx = ops.conv3_fwd(dy, bwdp, Cin)
+    refx = torch.nn.grad.conv3d_input((B, Cin, S, S, S), wq, dy.float().permute(0, 4, 1, 2, 3), padding=1)
+    assert rel_err(dx.permute(0, 4, 1, 2, 3), refx) < TOL[dtype]
+    # with the statistics and a residual behind the slab sum
+    res = rnd(B, S, S, S, Cout, dtype=dtype, seed=63)
+    ops.begin_step()
+    y2, st = ops.conv3_fwd(x, fwdp, Cout, res=res, want_stat=True)
+    assert rel_err(y2.float(), (ref.permute(0, 2, 3, 4, 1) + res.float())) < TOL[dtype]
+    if st is not None:
+        assert torch.allclose(st.sum(0), ops.instnorm_stats(y2, B, S ** 3).sum(0), rtol=1e-5, atol=1e-3)
+
+
 def test_conv3_shortcut_is_refused_where_the_launch_splits():
     ops = _ops()
     x = rnd(1, 6, 6, 6, 384, dtype=torch.bfloat16, seed=3)
