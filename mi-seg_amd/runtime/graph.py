@@ -6,6 +6,7 @@ set of modalities present in the batch, because which conditional-norm rows rece
 ``grad is None``) is part of the recorded work; the per-sample style ids themselves live in a static device tensor
 that is overwritten before each replay.
 """
+import gc
 import os
 from typing import Dict, List, Sequence, Tuple
 
@@ -26,17 +27,30 @@ def _graph_capture(g, **kw):
 
 
 class _Capture:
-    """`with _graph_capture(g):` - torch.cuda.graph around a _Graph, then the split plan"""
+    """`with _graph_capture(g):` - torch.cuda.graph around a _Graph, then the split plan.
+
+    Python's cyclic collector is held off for the length of the capture: torch.cuda.graph collects once on entry, but a step is ~10^4 Python
+    allocations and an automatic collection in the middle of it runs the destructors of whatever cycles the step itself has closed by then
+    (autograd contexts holding events / streams) while the stream is capturing - the process was seen to abort() inside such a collection
+    (gpurun_out/final/gpu_tests.log of round 5: "Garbage-collecting" under GraphedTrainStep._capture, once in two full suites)."""
 
     def __init__(self, g, kw):
         self.g = g
         self.ctx = torch.cuda.graph(g.g, **kw)
+        self.gc_was_on = False
 
     def __enter__(self):
-        return self.ctx.__enter__()
+        r = self.ctx.__enter__()
+        self.gc_was_on = gc.isenabled()
+        gc.disable()
+        return r
 
     def __exit__(self, *exc):
-        r = self.ctx.__exit__(*exc)
+        try:
+            r = self.ctx.__exit__(*exc)
+        finally:
+            if self.gc_was_on:
+                gc.enable()
         if exc[0] is None:
             self.g.finish()
         return r
