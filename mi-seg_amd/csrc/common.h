@@ -122,7 +122,10 @@ __device__ __forceinline__ void refresh_done(const int64_t* params_version, int6
   if (!params_version) return;
   __syncthreads();
   if (threadIdx.x == 0) {
-    __threadfence();
+    // No __threadfence() in front of the arrival: the copies and the recorded version are read by LATER launches only, and the end of this
+    // kernel publishes every workgroup's stores to them; the counter merely finds the workgroup that retires last.  (Round 5: the fence - a
+    // write-back of the XCD's L2 per workgroup - was 21 of the 73 us of a live cast refresh of C-Swin-UNETR, scripts/debug/cast_table_probe.py;
+    // what round 4 read as "34 ns per workgroup of serialised atomics" was this.)
     const unsigned long long prev = atomicAdd(reinterpret_cast<unsigned long long*>(state + 1), 1ull);
     if (prev == (unsigned long long)gridDim.x - 1) {
       state[0] = pv;

@@ -12,15 +12,14 @@
 namespace miseg {
 
 constexpr int LOSS_MAXC = 16;          // channels kept in registers per voxel
-constexpr int LOSS_VPB = 1024;         // voxels per workgroup (256 threads x 1 float4 group; round 5: 2048 left 1.7 workgroups per CU - a chain of
+#ifndef MISEG_LOSS_VEC
+#define MISEG_LOSS_VEC 4               // voxels per thread of the vector instantiations (4: one 16-byte load per channel)
+#endif
+constexpr int LOSS_VEC = MISEG_LOSS_VEC;
+constexpr int LOSS_VPB = 256 * LOSS_VEC;         // voxels per workgroup (256 threads x 1 float4 group; round 5: 2048 left 1.7 workgroups per CU - a chain of
                                        // transcendentals per voxel with nobody to hide it: 50 / 59 us forward / backward on the 96^3 x 6 logits)
 
 template <class L> __device__ __forceinline__ int label_at(const L* lab, int64_t i) { return (int)lab[i]; }
-
-__device__ __forceinline__ float softplus_neg(float x) {      // log(1 + exp(-x)), stable
-  return fmaxf(-x, 0.f) + log1pf(expf(-fabsf(x)));
-}
-__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 
 struct LossGeom {
   int B, C, kind, c0, sq;
@@ -30,13 +29,26 @@ struct LossGeom {
 
 // value of the per-element focal term and its derivative w.r.t. x (MONAI 1.1.0 FocalLoss, sigmoid form on raw logits):
 //   ce = x - x t + softplus(-x);   w = exp(gamma * logsigmoid(-x z)), z = 2 t - 1;   f = w ce
+// The target is one-hot (t is 0 or 1), so with u = x z, e = exp(-|x|) = exp(-|u|) and L = log1p(e) everything comes from ONE exponential and
+// ONE logarithm:  softplus(+-u) = max(+-u, 0) + L;   ce = softplus(-u);   logsigmoid(-u) = -softplus(u);   sigmoid(u) = u >= 0 ? r : e r and
+// sigmoid(-u) = u >= 0 ? e r : r with r = 1 / (1 + e);   sigmoid(x) - t = -z sigmoid(-u).  (Round 5: the literal form evaluated two
+// softplus and two sigmoids per channel - 5 exp, 2 log1p, 2 divisions - a dependent chain of ~250 instructions per element and the reason
+// the two loss kernels took 48 / 56 us on 21 MB of logits; it also lost ce to cancellation for t = 0, x << 0, where this form is exact.)
+template <bool GRAD>
 __device__ __forceinline__ void focal_term(float x, float t, float gamma, float& f, float& df) {
-  const float z = 2.f * t - 1.f;
-  const float ce = x - x * t + softplus_neg(x);
-  const float ls = -softplus_neg(-x * z);            // logsigmoid(-x z) = -softplus(x z) = -log(1 + exp(x z))
-  const float w = expf(gamma * ls);
+  const bool pos = t != 0.f;
+  const float u = pos ? x : -x;
+  const float e = expf(-fabsf(x));
+  const float L = log1pf(e);
+  const float ce = fmaxf(-u, 0.f) + L;                  // softplus(-u)
+  const float w = expf(-gamma * (fmaxf(u, 0.f) + L));   // exp(gamma logsigmoid(-u))
   f = w * ce;
-  df = w * (-gamma * z * sigmoidf(x * z) * ce + sigmoidf(x) - t);
+  if (GRAD) {
+    const float r = __builtin_amdgcn_rcpf(1.f + e);
+    const float su = u >= 0.f ? r : e * r, snu = u >= 0.f ? e * r : r;      // sigmoid(u), sigmoid(-u)
+    const float d = w * (gamma * su * ce + snu);        // df/du
+    df = pos ? -d : d;                                   // du/dx = z, and the bracket carries -z
+  }
 }
 
 // softmax over channels [c0s, C) of x -> p (p[c < c0s] = 0); returns log-sum-exp
@@ -78,6 +90,9 @@ __global__ void __launch_bounds__(256) seg_loss_fwd_kernel(const float* __restri
           const f32x4 t = *reinterpret_cast<const f32x4*>(xb + (int64_t)c * g.S + s0);
 #pragma unroll
           for (int v = 0; v < 4; ++v) xv[c][v] = t[v];
+        } else if constexpr (VEC == 2) {
+          const float2 t = *reinterpret_cast<const float2*>(xb + (int64_t)c * g.S + s0);
+          xv[c][0] = t.x; xv[c][1] = t.y;
         } else xv[c][0] = xb[(int64_t)c * g.S + s0];
       } else {
 #pragma unroll
@@ -101,7 +116,7 @@ __global__ void __launch_bounds__(256) seg_loss_fwd_kernel(const float* __restri
           aT[c] += t;
           if (g.kind == MISEG_LOSS_DICE_FOCAL) {
             float f, df;
-            focal_term(x[c], t, g.gamma, f, df);
+            focal_term<false>(x[c], t, g.gamma, f, df);
             aO += f;
           }
         }
@@ -205,6 +220,9 @@ __global__ void __launch_bounds__(256) seg_loss_bwd_kernel(const float* __restri
           const f32x4 t = *reinterpret_cast<const f32x4*>(xb + (int64_t)c * g.S + s0);
 #pragma unroll
           for (int v = 0; v < 4; ++v) xv[c][v] = t[v];
+        } else if constexpr (VEC == 2) {
+          const float2 t = *reinterpret_cast<const float2*>(xb + (int64_t)c * g.S + s0);
+          xv[c][0] = t.x; xv[c][1] = t.y;
         } else xv[c][0] = xb[(int64_t)c * g.S + s0];
       } else {
 #pragma unroll
@@ -232,7 +250,7 @@ __global__ void __launch_bounds__(256) seg_loss_bwd_kernel(const float* __restri
         if (g.kind == MISEG_LOSS_DICE_FOCAL) {
           if (c >= c0d && c < g.C) {
             float f, df;
-            focal_term(x[c], t, g.gamma, f, df);
+            focal_term<true>(x[c], t, g.gamma, f, df);
             d += ko * df;
           }
         } else if (c < g.C) d += ko * (p[c] - t);                 // CE: softmax over all channels is p itself (c0s = 0)
@@ -247,6 +265,8 @@ __global__ void __launch_bounds__(256) seg_loss_bwd_kernel(const float* __restri
 #pragma unroll
           for (int v = 0; v < 4; ++v) t[v] = dv[c][v];
           *reinterpret_cast<f32x4*>(db + (int64_t)c * g.S + s0) = t;
+        } else if constexpr (VEC == 2) {
+          *reinterpret_cast<float2*>(db + (int64_t)c * g.S + s0) = float2{dv[c][0], dv[c][1]};
         } else db[(int64_t)c * g.S + s0] = dv[c][0];
       }
     }
@@ -543,7 +563,7 @@ extern "C" int miseg_seg_loss_fwd(const miseg_seg_loss_params* p, miseg_stream_t
     typedef typename std::remove_const<typename std::remove_pointer<decltype(tag)>::type>::type L;
     dim3 grid(nblk, p->B);
     if (p->C <= 8) {
-      if (vec) seg_loss_fwd_kernel<L, 8, 4><<<grid, 256, 0, s>>>(p->logits, (const L*)p->label, g, (double*)p->workspace);
+      if (vec) seg_loss_fwd_kernel<L, 8, LOSS_VEC><<<grid, 256, 0, s>>>(p->logits, (const L*)p->label, g, (double*)p->workspace);
       else seg_loss_fwd_kernel<L, 8, 1><<<grid, 256, 0, s>>>(p->logits, (const L*)p->label, g, (double*)p->workspace);
     } else {
       seg_loss_fwd_kernel<L, LOSS_MAXC, 1><<<grid, 256, 0, s>>>(p->logits, (const L*)p->label, g, (double*)p->workspace);
@@ -568,7 +588,7 @@ extern "C" int miseg_seg_loss_bwd(const miseg_seg_loss_params* p, miseg_stream_t
 #define MISEG_LB(MAXC, VEC) seg_loss_bwd_kernel<L, MAXC, VEC><<<grid, 256, 0, s>>>(p->logits, (const L*)p->label, g, p->smooth_nr, p->smooth_dr, p->lambda_dice, \
                                                                                     p->lambda_other, p->sums, p->gscale, p->dlogits)
     if (p->C <= 8) {
-      if (vec) MISEG_LB(8, 4); else MISEG_LB(8, 1);
+      if (vec) MISEG_LB(8, LOSS_VEC); else MISEG_LB(8, 1);
     } else MISEG_LB(LOSS_MAXC, 1);
 #undef MISEG_LB
     MISEG_LAUNCH_CHECK("seg_loss_bwd");

@@ -1043,6 +1043,51 @@ def test_space_channel_im2col_misc(dtype):
     assert torch.equal(ops.cast_matrix(w, dtype, transpose=True), w.t().contiguous().to(dtype))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_param_cast_batch_every_layout_in_one_launch(dtype):
+    """miseg_param_cast_batch (include/miseg_hip.h): the per-step re-layout of every non-conv weight - plain casts (whole-tile matrices take
+    the flat path), transposes, the (co, tap) -> (tap, co) regrouping of ConvTranspose3d weights (unetr_block.py:80), ragged edges and
+    one-column matrices - in ONE launch against torch index arithmetic, bit for bit; and the versioned form skips a current table."""
+    import ctypes as C
+    L, ops = _L(), _ops()
+    lib = L.load()
+    shapes = [(64, 96, 0, 1, 1), (64, 96, 1, 1, 1), (96, 256, 0, 8, 32), (96, 256, 1, 8, 32), (37, 53, 0, 1, 1), (37, 53, 1, 1, 1), (48, 1, 0, 1, 1),
+              (50, 24, 0, 8, 3), (50, 24, 1, 8, 3), (1152, 384, 0, 1, 1), (384, 1152, 1, 1, 1), (32, 36, 0, 1, 1), (40, 64, 1, 1, 1), (33, 64, 0, 1, 1)]
+    srcs, dsts, refs = [], [], []
+    descs = (L.CastDesc * len(shapes))()
+    tile0 = 0
+    for i, (R, Cc, tr, inner, outer) in enumerate(shapes):
+        w = rnd(R, Cc, seed=300 + i)
+        m = torch.arange(Cc, device=DEV)
+        m = (m % inner) * outer + m // inner                       # destination column of source column c
+        ref = torch.empty(R, Cc, device=DEV)
+        ref[:, m] = w
+        ref = (ref.t().contiguous() if tr else ref).to(dtype)
+        dst = torch.full(ref.shape, float("nan"), dtype=dtype, device=DEV)
+        descs[i] = L.CastDesc(w.data_ptr(), dst.data_ptr(), R, Cc, tr, inner, outer, tile0)
+        tile0 += ((R + 31) // 32) * ((Cc + 31) // 32)
+        srcs.append(w); dsts.append(dst); refs.append(ref)
+    raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(DEV)
+    dt = L.F32 if dtype == torch.float32 else L.BF16
+    L.check(lib.miseg_param_cast_batch(raw.data_ptr(), len(shapes), tile0, dt, None, None, ops._stream()), "param_cast_batch")
+    torch.cuda.synchronize()
+    for sh, d, r in zip(shapes, dsts, refs):
+        assert torch.equal(d, r), sh
+    # versioned: state == version -> nothing is written; a bumped version -> everything again
+    ver = torch.tensor([5, 5, 0], dtype=torch.int64, device=DEV)      # params_version | state[0] = version of the copies, state[1] = arrival counter
+    for d in dsts:
+        d.fill_(7.0)
+    L.check(lib.miseg_param_cast_batch(raw.data_ptr(), len(shapes), tile0, dt, C.c_void_p(ver.data_ptr()), C.c_void_p(ver.data_ptr() + 8), ops._stream()), "param_cast_batch")
+    torch.cuda.synchronize()
+    assert all(bool((d == 7.0).all()) for d in dsts)
+    ver[0] = 6
+    L.check(lib.miseg_param_cast_batch(raw.data_ptr(), len(shapes), tile0, dt, C.c_void_p(ver.data_ptr()), C.c_void_p(ver.data_ptr() + 8), ops._stream()), "param_cast_batch")
+    torch.cuda.synchronize()
+    for sh, d, r in zip(shapes, dsts, refs):
+        assert torch.equal(d, r), sh
+    assert int(ver[1]) == 6 and int(ver[2]) == 0
+
+
 def _ref_window_attention(qkv, qkv_bias, table, heads, ws, ss, tw, scale, drop_mask=None):
     """plain PyTorch fp32 reference of the fused attention core (pad with the bias row, roll, partition, softmax(QK^T+bias+mask)V,
     reverse, roll back, crop) built from the oracle's helpers."""
