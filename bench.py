@@ -402,7 +402,9 @@ def measure(a, rank, world, dist, dev):
         missing = [n for n, g_ in got if g_ is None]
         other = 1 - int(mods[k])
         unexpected = [n for n in missing if f".norms.{other}." not in n]
-        zero = [n for n, g_ in got if g_ is not None and float(g_.float().abs().max()) == 0.0]
+        have = [(n, g_) for n, g_ in got if g_ is not None]       # (one multi-tensor launch and one read-back, not a launch pair and a sync per parameter)
+        peaks = torch.stack(torch._foreach_norm([g_.float() for _, g_ in have], float("inf"))).tolist() if have else []
+        zero = [n for (n, _), m_ in zip(have, peaks) if m_ == 0.0]
         res.update({"params": len(got), "params_without_grad": len(missing), "params_without_grad_unexpected": unexpected[:5], "params_with_zero_grad": zero[:5]})
         # launches per step that the model's side branch issues throttled (hip/ops.py::_background): conv3_fwd96 at one workgroup per CU,
         # conv3_wgrad on few CUs.  They run beside the main stream's launches in the step; the roofline leg times the kernels alone
@@ -412,8 +414,7 @@ def measure(a, rank, world, dist, dev):
         # (in place), replay, and compare with the eager step on the changed weights - and with the replay before the change
         if arena is not None:
             with torch.no_grad():
-                for p in params:
-                    p.mul_(1.0 + 2.0 ** -7)
+                torch._foreach_mul_(list(params), 1.0 + 2.0 ** -7)      # (in place on the Parameters themselves: bumps Tensor._version, which the arena watches)
             y2 = graphed(pool[k:k + 1], [mods[k]], cot).detach().float().clone()
             g2 = flat()
             arena.begin_step()
@@ -422,8 +423,7 @@ def measure(a, rank, world, dist, dev):
             arena.publish()
             ge2 = flat()
             with torch.no_grad():
-                for p in params:
-                    p.div_(1.0 + 2.0 ** -7)
+                torch._foreach_div_(list(params), 1.0 + 2.0 ** -7)
             res["after_weight_change"] = {"logits_rel_err_vs_eager": rel(y2, ye2.detach().float()), "grad_rel_err_vs_eager": rel(g2, ge2),
                                           "logits_moved_by": rel(y2, y), "grads_moved_by": rel(g2, g)}
             graphed(pool[k:k + 1], [mods[k]], cot)      # (and back: the restored weights are re-laid-out by this replay)
