@@ -4,6 +4,8 @@ from csrc/ (see hip/ops.py); torch supplies tensors, the caching allocator, stre
 Layout contract: activations are channels-last ([B, D, H, W, C] or [B, L, C]) in the compute dtype (float32 for the
 parity mode, bfloat16 for throughput); parameters and their gradients are float32.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -186,6 +188,8 @@ def drop_path(x, p, training=True):
 
 # ----------------------------------------------------------------------------------------------------------------
 _PENDING_OUT = None      # see _InstNorm.forward
+_LAST_STAT = None          # statistics buffer of the _InstNorm.forward that has just run (instance_norm(fork=True))
+FORK_KEEPS_STAT = os.environ.get("MISEG_NO_FORK_STAT") is None      # A/B switch of round 5
 
 
 class _InstNorm(Function):
@@ -211,6 +215,8 @@ class _InstNorm(Function):
             y = ops.instnorm_apply(x, B, S, stat, styles_dev, gammas, betas, res=res, act=act, slope=slope, eps=eps, out=out)
         else:
             y, stat = ops.instnorm_fwd(x, B, S, styles_dev, gammas, betas, res=res, act=act, slope=slope, eps=eps, out=out)
+        global _LAST_STAT
+        _LAST_STAT = stat if isinstance(stat, torch.Tensor) else None      # (instance_norm(fork=True) hangs it on the skip branch)
         ctx.meta = (B, S, styles_host, num_styles, affine, act, slope, res is not None, eps)
         ctx.params = params
         # y is kept only where a residual entered the activation: otherwise the backward kernels recompute the LeakyReLU's sign from x
@@ -364,9 +370,17 @@ def instance_norm(x, params=None, styles_dev=None, styles_host=None, res=None, a
     _PENDING_OUT = out
     if stat is None:
         stat = _carried_stat(x)
+    global _LAST_STAT
+    _LAST_STAT = None
     r = _InstNorm.apply(x, res, styles_dev, styles_host, n, params is not None, act, slope, eps, fork, stat, *flat)
-    if fork and isinstance(stat, torch.Tensor) and res is None:
-        r[1]._miseg_stat = stat      # the skip branch is x itself: statistics its producer left on it stay valid for the next norm of x
+    if fork and res is None:
+        # the skip branch is x itself: its statistics - left on it by its producer, or summed by this norm's own statistics pass (round 5: the
+        # affine-less norm of a Swin stage's returned feature map and norm1 of the stage's first block read the SAME tensor; the second
+        # statistics launch, 4.7 us of the un-overlapped forward chain per stage, is gone) - stay valid for the next norm of x
+        st = stat if isinstance(stat, torch.Tensor) else (_LAST_STAT if FORK_KEEPS_STAT else None)
+        if st is not None:
+            r[1]._miseg_stat = st
+    _LAST_STAT = None
     return r
 
 

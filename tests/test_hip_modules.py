@@ -888,6 +888,42 @@ def test_side_branch_matches_the_single_stream_step(mode):
     compare_grads({k: v for k, v in g1.items() if v is not None}, {k: v for k, v in g0.items() if v is not None}, 2e-3, skip=ZERO_GRAD)
 
 
+def test_forked_norm_leaves_its_statistics_on_the_skip_branch():
+    """round 5: the affine-less norm of a Swin stage's returned feature map (swin_transformer.py:135-136,150-158) and norm1 of the stage's first
+    block (swin_transformer_block.py:241) read the SAME tensor - `instance_norm(x, fork=True)` hangs the sums of its own statistics pass on the
+    skip branch and `norm_linear` folds norm1 into the qkv GEMM with them, no second statistics launch: same sums as a fresh pass, the same
+    bits out of the GEMM, the same gradients (to the order of their atomic sums)."""
+    from mi_seg_amd.hip import functional as HF
+    from mi_seg_amd.hip import ops
+    g = torch.Generator().manual_seed(11)
+    x0 = (torch.randn(1, 16, 16, 24, 48, generator=g) * 1.5 + 0.3).to(DEV).to(torch.bfloat16)
+    w = (torch.randn(144, 48, generator=g) / 7).to(DEV).requires_grad_(True)
+    b = (torch.randn(144, generator=g) / 4).to(DEV).requires_grad_(True)
+    gam = [(torch.randn(48, generator=g) * 0.2 + 1).to(DEV).requires_grad_(True) for _ in range(2)]
+    bet = [(torch.randn(48, generator=g) * 0.3).to(DEV).requires_grad_(True) for _ in range(2)]
+    styles = torch.tensor([1], dtype=torch.int32, device=DEV)
+    cot_a, cot_q = torch.randn(1, 16, 16, 24, 48, generator=g).to(DEV).to(torch.bfloat16), torch.randn(1, 16, 16, 24, 144, generator=g).to(DEV).to(torch.bfloat16)
+    outs = []
+    for carry in (True, False):
+        ops.begin_step()
+        x = x0.clone().requires_grad_(True)
+        for t in (w, b, *gam, *bet):
+            t.grad = None
+        a, xs = HF.instance_norm(x, None, fork=True)
+        st = getattr(xs, "_miseg_stat", None)
+        assert st is not None and torch.equal(st.sum(0), ops.instnorm_stats(x.detach(), 1, 16 * 16 * 24).sum(0))
+        if not carry:
+            del xs._miseg_stat
+        r = HF.norm_linear(xs, list(zip(gam, bet)), styles, (1,), 1e-5, w, b, fork=True)
+        assert r is not None
+        q, xs2 = r
+        torch.autograd.backward([a, q, xs2], [cot_a, cot_q, cot_a])
+        outs.append([a.detach(), q.detach(), x.grad.clone(), w.grad.clone(), b.grad.clone(), gam[1].grad.clone(), bet[1].grad.clone()])
+        assert gam[0].grad is None
+    for i, (u, v) in enumerate(zip(*outs)):      # the forward bits are the same; the gradients' sums run through float atomics (order varies run to run)
+        assert torch.equal(u, v) if i < 2 else rel_err(u, v) < (1e-4 if i == 2 else 1e-6), i
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("fork_at", ["s0", "s1", "s2"])
 def test_side_branch_forked_beside_the_swin_stages_on_an_inner_tape(fork_at):
