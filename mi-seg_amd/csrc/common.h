@@ -50,6 +50,13 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 __host__ __device__ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+// grid of a persistent tile loop: at most `cap` workgroups, and as few as walk the tiles in the same number of rounds (3456 tiles under a cap
+// of 2048 are two rounds either way: 1728 workgroups take two tiles each, 2048 leave 640 of them idle through the second round)
+static inline int balanced_grid(long ntiles, int cap) {
+  if (ntiles <= cap) return (int)(ntiles > 0 ? ntiles : 1);
+  const long rounds = (ntiles + cap - 1) / cap;
+  return (int)((ntiles + rounds - 1) / rounds);
+}
 
 // Word fills are plain kernels, never hipMemset*Async: under stream capture a memset becomes a memset node, and the ROCm 7.2
 // graph runtime was observed to replay such nodes with a stale argument block (the statistics pool came back "zeroed" with

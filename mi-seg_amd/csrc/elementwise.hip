@@ -1606,6 +1606,11 @@ extern "C" int miseg_conv3_thin_wgrad(const miseg_conv3_thin_wgrad_params* p, mi
   });
 }
 
+// workgroups of the head's persistent tile loops (256-voxel tiles; 3456 of them at 96^3).  Round 5, scripts/micro/head_bench.py on one box, forward /
+// backward (dx + dw): 2048 / 512 workgroups (until then; 640 of the 2048 idle through their second round) 35.0 / 66.4 us, balanced 1728 / 494:
+// 36.5 / 65.8, **1152 / 494: 32.6 / 62.8**, 864: 37.0 / 63.1, 576: 47.6 / 63.4, 3456: 33.8 / 82; weight gradient at 256 / 864: + 10 / + 2.5 us
+static constexpr int HEAD_GRID_CAP = 1152, HEAD_DW_GRID_CAP = 512;
+
 extern "C" int miseg_head_fwd(const miseg_head_params* p, miseg_stream_t s_) {
   hipStream_t s = (hipStream_t)s_;
   MISEG_REQUIRE(p && p->x && p->y && p->w, MISEG_E_BADARG, "head_fwd: null pointer");
@@ -1616,8 +1621,7 @@ extern "C" int miseg_head_fwd(const miseg_head_params* p, miseg_stream_t s_) {
     if (p->Cin % N == 0 && p->ldx % N == 0 && al16(p->x)) {
       const int64_t nv = (int64_t)p->B * p->S;
       const size_t sh2 = (size_t)((p->Cout * p->Cin + p->Cout + 3) & ~3) * 4 + (size_t)256 * (p->Cin * sizeof(T) + 16);
-      int grid = (int)((nv + 255) / 256);
-      if (grid > 2048) grid = 2048;
+      const int grid = balanced_grid((nv + 255) / 256, HEAD_GRID_CAP);
       hipFuncSetAttribute((const void*)head_fwd_tile_kernel<T, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2);
       head_fwd_tile_kernel<T, N><<<grid, 256, sh2, s>>>((const T*)p->x, p->ldx, p->y, p->w, p->bias, p->B, p->S, p->Cin, p->Cout);
     } else
@@ -1637,7 +1641,7 @@ extern "C" int miseg_head_bwd(const miseg_head_bwd_params* p, miseg_stream_t s_)
       size_t sh = (size_t)p->Cin * p->Cout * sizeof(float);
       if (p->Cin % N == 0 && p->lddx % N == 0 && al16(p->dx) && p->Cout <= 8 && p->S % 256 == 0 && p->Cin / N <= 32 && N == 8) {
         const int64_t ntiles = nv / 256;
-        head_bwd_dx_tile_kernel<T, N><<<(int)(ntiles < 2048 ? ntiles : 2048), 256, 0, s>>>(p->dy, (T*)p->dx, p->lddx, p->w, p->S, p->Cin, p->Cout, ntiles);
+        head_bwd_dx_tile_kernel<T, N><<<balanced_grid(ntiles, HEAD_GRID_CAP), 256, 0, s>>>(p->dy, (T*)p->dx, p->lddx, p->w, p->S, p->Cin, p->Cout, ntiles);
       } else if (p->Cin % N == 0 && p->lddx % N == 0 && al16(p->dx))
         if (nv * (p->Cin / N) < (1LL << 29))      // 32-bit item arithmetic (see s2c_kernel)
           head_bwd_dx_team_kernel<T, N, unsigned><<<ew_grid(nv * (p->Cin / N)), 256, sh, s>>>(p->dy, (T*)p->dx, p->lddx, p->w, p->B, p->S, p->Cin, p->Cout);
@@ -1650,7 +1654,7 @@ extern "C" int miseg_head_bwd(const miseg_head_bwd_params* p, miseg_stream_t s_)
     if constexpr (std::is_same<T, bf16>::value) {
       if (p->dw && p->Cin == 48 && p->Cout <= 16 && p->S % 256 == 0 && p->ldx % 8 == 0 && al16(p->x) && al16(p->dy)) {
         const int64_t ntiles = nv / 256;
-        head_bwd_dw_mfma_kernel<<<(int)(ntiles < 512 ? ntiles : 512), 256, 0, s>>>((const bf16*)p->x, p->ldx, p->dy, p->dw, p->dbias, p->S, p->Cout, ntiles);
+        head_bwd_dw_mfma_kernel<<<balanced_grid(ntiles, HEAD_DW_GRID_CAP), 256, 0, s>>>((const bf16*)p->x, p->ldx, p->dy, p->dw, p->dbias, p->S, p->Cout, ntiles);
         dw_done = true;
       }
     }
