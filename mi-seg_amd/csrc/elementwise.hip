@@ -181,7 +181,9 @@ __global__ void __launch_bounds__(256) c2s_kernel(const T* src, int64_t lds, T* 
 
 // ----------------------------------------------------------------------------- PatchEmbed k2 s2 (+bias)
 // thread = (coarse voxel, group of 8 output channels)
-template <class T>
+// IDX: the type of the item arithmetic - `unsigned` where the item count and the input's element count fit 31 bits (the 64-bit divisions of the
+// item decode and the eight 64-bit address chains were most of this kernel's instructions: round 5)
+template <class T, class IDX = int64_t>
 __global__ void __launch_bounds__(256) patch_embed_fwd_kernel(const float* __restrict__ x, T* __restrict__ y, int64_t ldy, const float* __restrict__ w,
                                                               const float* __restrict__ bias, int B, int Cin, int D, int H, int W, int Cout) {
   extern __shared__ float ws[];  // [Cin*8][Cout] transposed weights + bias[Cout]
@@ -193,14 +195,14 @@ __global__ void __launch_bounds__(256) patch_embed_fwd_kernel(const float* __res
   for (int i = threadIdx.x; i < Cout; i += blockDim.x) ws[K * Cout + i] = bias ? bias[i] : 0.f;
   __syncthreads();
   const int D2 = D / 2, H2 = H / 2, W2 = W / 2, cg = (Cout + 7) / 8;
-  const int64_t total = (int64_t)B * D2 * H2 * W2 * cg;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int g = (int)(i % cg);
-    int64_t t = i / cg;
-    const int w2 = (int)(t % W2); t /= W2;
-    const int h2 = (int)(t % H2); t /= H2;
-    const int d2 = (int)(t % D2);
-    const int b = (int)(t / D2);
+  const IDX total = (IDX)((int64_t)B * D2 * H2 * W2 * cg);
+  for (IDX i = (IDX)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (IDX)gridDim.x * blockDim.x) {
+    const int g = (int)(i % (IDX)cg);
+    IDX t = i / (IDX)cg;
+    const int w2 = (int)(t % (IDX)W2); t /= (IDX)W2;
+    const int h2 = (int)(t % (IDX)H2); t /= (IDX)H2;
+    const int d2 = (int)(t % (IDX)D2);
+    const int b = (int)(t / (IDX)D2);
     float acc[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = (g * 8 + k < Cout) ? ws[K * Cout + g * 8 + k] : 0.f;
@@ -208,16 +210,29 @@ __global__ void __launch_bounds__(256) patch_embed_fwd_kernel(const float* __res
       for (int a = 0; a < 2; ++a)
         for (int bb = 0; bb < 2; ++bb)
           for (int c = 0; c < 2; ++c) {
-            const float xv = x[((((int64_t)b * Cin + ci) * D + 2 * d2 + a) * H + 2 * h2 + bb) * W + 2 * w2 + c];
+            const float xv = x[((((IDX)b * Cin + ci) * D + 2 * d2 + a) * H + 2 * h2 + bb) * W + 2 * w2 + c];
             const float* wr = ws + ((ci * 2 + a) * 2 + bb) * 2 * Cout + c * Cout + g * 8;
 #pragma unroll
             for (int k = 0; k < 8; ++k)
               if (g * 8 + k < Cout) acc[k] = fmaf(xv, wr[k], acc[k]);
           }
-    T* yr = y + ((((int64_t)b * D2 + d2) * H2 + h2) * W2 + w2) * ldy + g * 8;
+    T* yr = y + (int64_t)((((IDX)b * D2 + d2) * H2 + h2) * W2 + w2) * ldy + g * 8;
+    // whole group, 16-byte aligned: one or two vector stores (round 5: the eight 2-byte stores per thread - eight partial-line writes per
+    // wave and group - cost 3.3 of the kernel's 18.2 us in front of the Swin stages, where nothing runs beside it)
+    if (g * 8 + 8 <= Cout && (reinterpret_cast<uintptr_t>(yr) & 15) == 0) {
+      constexpr int N = Vec16<T>::N;
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (g * 8 + k < Cout) yr[k] = from_f32<T>(acc[k]);
+      for (int h = 0; h < 8 / N; ++h) {
+        V<T, N> o;
+#pragma unroll
+        for (int k = 0; k < N; ++k) o.v[k] = acc[h * N + k];
+        o.store(yr + h * N);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (g * 8 + k < Cout) yr[k] = from_f32<T>(acc[k]);
+    }
   }
 }
 
@@ -1504,7 +1519,11 @@ extern "C" int miseg_patch_embed_fwd(const miseg_patch_embed_params* p, miseg_st
   DT(p, {
     const int64_t tot = (int64_t)p->B * (p->D / 2) * (p->H / 2) * (p->W / 2) * ((p->Cout + 7) / 8);
     size_t sh = ((size_t)p->Cin * 8 * p->Cout + p->Cout) * sizeof(float);
-    patch_embed_fwd_kernel<T><<<ew_grid(tot), 256, sh, s>>>(p->x, (T*)p->y, p->ldy, p->w, p->bias, p->B, p->Cin, p->D, p->H, p->W, p->Cout);
+    // (grid sweep, round 5: 2592 = 1296 workgroups 15.2 us, 864: 17.7, 648: 20.7 - the kernel is its instruction count, not its launch shape)
+    if (tot + 256 * 8192 < (1LL << 31) && (int64_t)p->B * p->Cin * p->D * p->H * p->W < (1LL << 31))
+      patch_embed_fwd_kernel<T, unsigned><<<ew_grid(tot), 256, sh, s>>>(p->x, (T*)p->y, p->ldy, p->w, p->bias, p->B, p->Cin, p->D, p->H, p->W, p->Cout);
+    else
+      patch_embed_fwd_kernel<T><<<ew_grid(tot), 256, sh, s>>>(p->x, (T*)p->y, p->ldy, p->w, p->bias, p->B, p->Cin, p->D, p->H, p->W, p->Cout);
     MISEG_LAUNCH_CHECK("patch_embed_fwd");
   });
 }
